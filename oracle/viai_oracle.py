@@ -1,0 +1,469 @@
+"""CPU oracle for the VIAI inpainting-GAN hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, fp32, functional) restatement of the
+reference's arithmetic for the path SURVEY.md §8 names.  It is the checker the
+HIP path is compared against; only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.  The product package never
+does (and fails loudly if its HIP library is missing).
+
+Parity status: PINNED for the networks and losses — ``tools/make_goldens.py``
+imports the reference's own ``MelEncoder`` / ``MelDecoder`` /
+``MelDiscriminator`` / ``GANLoss`` from /root/reference in the build
+container, checks this restatement against them and commits their outputs as
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` re-checks the oracle
+against those vectors everywhere.  The train *step* itself
+(``Models/Whole_Sync_inpainting_modify.AudioModel``) is absent from the
+reference, so the step ordering below is the build's own
+declared spec (pix2pix ordering, README.md:39), executed in the golden script
+with the reference's modules.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------
+# closed-form deterministic tensors (bit-identical on every machine: integer
+# hash -> 24-bit mantissa -> float32), SURVEY.md §8c "closed-form generator"
+# --------------------------------------------------------------------------
+
+_TAGS = {}
+
+
+def _tag_id(tag: str) -> int:
+    """Stable 32-bit id of a tensor name (FNV-1a)."""
+    h = 2166136261
+    for ch in tag.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+def cf_uniform(tag: str, shape, lo=0.0, hi=1.0) -> torch.Tensor:
+    """u[i] in [lo, hi): integer-hash of (tag, flat index)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    i = np.arange(n, dtype=np.uint64)
+    h = (i * np.uint64(2654435761) + np.uint64(_tag_id(tag))) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x45D9F3B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x45D9F3B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    u = (h >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    out = (np.float32(lo) + u * np.float32(hi - lo)).astype(np.float32)
+    return torch.from_numpy(out.reshape(shape))
+
+
+def cf_std(tag: str, shape, std: float) -> torch.Tensor:
+    """zero-mean uniform with the given standard deviation."""
+    a = float(std) * math.sqrt(3.0)
+    return cf_uniform(tag, shape, -a, a)
+
+
+# --------------------------------------------------------------------------
+# parameter tables (names / shapes == the reference modules' state_dict())
+# --------------------------------------------------------------------------
+
+def _bn_entries(sd, prefix, c, tag):
+    sd[prefix + ".weight"] = cf_uniform(tag + prefix + ".w", (c,), 0.8, 1.2)
+    sd[prefix + ".bias"] = cf_uniform(tag + prefix + ".b", (c,), -0.1, 0.1)
+    sd[prefix + ".running_mean"] = torch.zeros(c)
+    sd[prefix + ".running_var"] = torch.ones(c)
+    sd[prefix + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+
+
+ENC_CONVS = [  # name, cin, cout, stride  (networks/Inpainting_Networks.py:55-63)
+    ("conv1", 1, 32, (2, 2)), ("conv2", 32, 64, (2, 1)), ("conv3", 64, 128, (2, 2)),
+    ("conv4", 128, 256, (2, 2)), ("conv5", 256, 256, (2, 2)),
+]
+
+DEC_BLOCKS = [  # name, cin, cout, nums  (networks/New_Inpainting_Networks.py:57-61)
+    ("1", 256, 256, 2), ("2", 256, 128, 3), ("3", 128, 64, 3), ("4", 128, 32, 3), ("5", 32, 32, 4),
+]
+
+
+def encoder_state(tag="E.") -> "OrderedDict[str, torch.Tensor]":
+    """state_dict layout of MelEncoder (networks/Inpainting_Networks.py:49-66)."""
+    sd = OrderedDict()
+    for i, (name, cin, cout, _s) in enumerate(ENC_CONVS):
+        # kaiming fan_out scale (Inpainting_Networks.py:83): std = sqrt(2/(cout*9))
+        sd[name + ".weight"] = cf_std(tag + name, (cout, cin, 3, 3), math.sqrt(2.0 / (cout * 9)))
+        _bn_entries(sd, "bn%d" % (i + 1), cout, tag)
+    return sd
+
+
+def decoder_state(tag="G.") -> "OrderedDict[str, torch.Tensor]":
+    """state_dict layout of MelDecoder (networks/New_Inpainting_Networks.py:48-68).
+
+    ConvTranspose2d weights are (Cin, Cout, kH, kW).  convblock1 is constructed
+    but never used by forward (New_Inpainting_Networks.py:57,76-82)."""
+    sd = OrderedDict()
+
+    def convT(name, cin, cout, bias):
+        sd[name + ".weight"] = cf_std(tag + name, (cin, cout, 3, 3), math.sqrt(2.0 / (cin * 9)))
+        if bias:
+            sd[name + ".bias"] = cf_uniform(tag + name + ".bias", (cout,), -0.05, 0.05)
+
+    convT("deconv1_1", 256, 256, True)
+    _bn_entries(sd, "deconv1_1_bn", 256, tag)
+    convT("deconv1_2", 256, 256, True)
+    _bn_entries(sd, "deconv1_2_bn", 256, tag)
+    for bname, cin, cout, nums in DEC_BLOCKS:
+        c = cin
+        for i in range(nums):
+            n = "convblock%s.conv%s_%d" % (bname, bname, i)
+            convT(n, c, cout, False)
+            _bn_entries(sd, n + "_bn", cout, tag)
+            c = cout
+    convT("conv6_1", 32, 32, True)
+    convT("conv6_2", 32, 1, True)
+    _bn_entries(sd, "conv6_1_bn", 32, tag)
+    return sd
+
+
+def disc_state(tag="D.", input_nc=1, ndf=64) -> "OrderedDict[str, torch.Tensor]":
+    """state_dict layout of MelDiscriminator(n_layers=3)
+    (networks/Discriminator_Networks.py:9-35)."""
+    sd = OrderedDict()
+
+    def conv(name, cin, cout, kh, kw):
+        sd[name + ".weight"] = cf_std(tag + name, (cout, cin, kh, kw), math.sqrt(1.0 / (cin * kh * kw)))
+
+    conv("conv1", input_nc, ndf, 1, 4)
+    _bn_entries(sd, "bn1", ndf, tag)
+    conv("conv2_1", ndf, ndf * 2, 3, 3)
+    _bn_entries(sd, "norm_1", ndf * 2, tag)
+    conv("conv2_2", ndf * 2, ndf * 4, 3, 3)
+    _bn_entries(sd, "norm_2", ndf * 4, tag)
+    conv("conv3", ndf * 4, ndf * 8, 3, 3)
+    _bn_entries(sd, "norm3", ndf * 8, tag)
+    conv("conv4", ndf * 8, 1, 3, 3)
+    return sd
+
+
+def is_buffer(key: str) -> bool:
+    return key.endswith("running_mean") or key.endswith("running_var") or key.endswith("num_batches_tracked")
+
+
+def param_keys(sd):
+    return [k for k in sd if not is_buffer(k)]
+
+
+# --------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def batch_norm(sd, prefix, x, training=True):
+    """nn.BatchNorm2d semantics (torch defaults used by the reference at
+    Inpainting_Networks.py:56, New_Inpainting_Networks.py:25,54, Discriminator_Networks.py:18):
+    training: normalise with biased batch variance; running_var gets the
+    unbiased one; momentum 0.1; eps 1e-5; num_batches_tracked += 1."""
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    if training:
+        n = x.numel() // x.shape[1]
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        with torch.no_grad():
+            sd[prefix + ".running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean.detach())
+            sd[prefix + ".running_var"].mul_(1 - BN_MOMENTUM).add_(
+                BN_MOMENTUM * var.detach() * (n / max(n - 1, 1)))
+            sd[prefix + ".num_batches_tracked"].add_(1)
+    else:
+        mean, var = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    inv = torch.rsqrt(var + BN_EPS)
+    return (x - mean[None, :, None, None]) * (inv * w)[None, :, None, None] + b[None, :, None, None]
+
+
+def bilinear_ac(x, size):
+    """F.interpolate(mode='bilinear', align_corners=True)
+    (New_Inpainting_Networks.py:78,83), written out: src = dst*(in-1)/(out-1)."""
+    n, c, ih, iw = x.shape
+    oh, ow = int(size[0]), int(size[1])
+
+    def axis(i_n, o_n):
+        scale = np.float32(i_n - 1) / np.float32(o_n - 1) if o_n > 1 else np.float32(0)
+        src = (np.arange(o_n, dtype=np.float32) * scale).astype(np.float32)
+        i0 = np.minimum(src.astype(np.int64), i_n - 1)
+        i1 = i0 + (i0 < i_n - 1)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        return torch.from_numpy(i0), torch.from_numpy(i1), torch.from_numpy(l1)
+
+    y0, y1, ly = axis(ih, oh)
+    x0, x1, lx = axis(iw, ow)
+    ly = ly[None, None, :, None]
+    lx = lx[None, None, None, :]
+    top = x[:, :, y0][:, :, :, x0] * (1 - lx) + x[:, :, y0][:, :, :, x1] * lx
+    bot = x[:, :, y1][:, :, :, x0] * (1 - lx) + x[:, :, y1][:, :, :, x1] * lx
+    return top * (1 - ly) + bot * ly
+
+
+def encoder_forward(sd, c, training=True):
+    """MelEncoder.forward (networks/Inpainting_Networks.py:69-78).
+    c: (B, F, T) or (B,1,F,T).  Returns the list of 5 feature maps."""
+    b = c.shape[0]
+    f = c.shape[-2]
+    x = c.reshape(b, 1, f, -1)                                    # :70
+    net = []
+    for i, (name, _cin, _cout, stride) in enumerate(ENC_CONVS):
+        x = F.conv2d(x, sd[name + ".weight"], None, stride=stride, padding=(1, 1))  # :71,74
+        x = F.leaky_relu(batch_norm(sd, "bn%d" % (i + 1), x, training), 0.2)          # :72,75
+        net.append(x)
+    net[-1] = F.avg_pool2d(net[-1], (3, 1))                       # :77
+    return net
+
+
+def _convT(sd, name, x, padding):
+    return F.conv_transpose2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride=1, padding=padding)
+
+
+def decoder_forward(sd, net, x_size, training=True):
+    """MelDecoder.forward (networks/New_Inpainting_Networks.py:70-89)."""
+    out = _convT(sd, "deconv1_1", net[-1], (0, 1))                # :71
+    out = F.relu(batch_norm(sd, "deconv1_1_bn", out, training))  # :72-73
+    out = _convT(sd, "deconv1_2", out, (1, 1))                    # :74
+    out = F.relu(batch_norm(sd, "deconv1_2_bn", out, training))  # :75
+    for i in range(1, len(net)):                                  # :76
+        out = bilinear_ac(out, net[-1 - i].shape[2:])             # :78
+        if i == 3:
+            out = torch.cat((out, net[-(i + 1)]), 1)              # :80-81
+        bname = str(i + 1)
+        nums = dict((b[0], b[3]) for b in DEC_BLOCKS)[bname]
+        for j in range(nums):                                     # TransConvBlock.forward :31-37
+            n = "convblock%s.conv%s_%d" % (bname, bname, j)
+            out = _convT(sd, n, out, (1, 1))
+            out = F.relu(batch_norm(sd, n + "_bn", out, training))
+    out = bilinear_ac(out, x_size[2:])                            # :83
+    out = _convT(sd, "conv6_1", out, (1, 1))                      # :85
+    out = F.relu(batch_norm(sd, "conv6_1_bn", out, training))    # :86
+    out = _convT(sd, "conv6_2", out, (1, 1))                      # :87
+    return torch.sigmoid(out)                                     # :88
+
+
+def disc_forward(sd, x, training=True):
+    """MelDiscriminator.forward (networks/Discriminator_Networks.py:37-50)."""
+    net = F.conv2d(x, sd["conv1.weight"], None, stride=(1, 2), padding=(0, 1))       # :38
+    net = F.leaky_relu(batch_norm(sd, "bn1", net, training), 0.2)                     # :39
+    for n in (1, 2):                                                                  # :40-43
+        net = F.conv2d(net, sd["conv2_%d.weight" % n], None, stride=2, padding=1)
+        net = F.leaky_relu(batch_norm(sd, "norm_%d" % n, net, training), 0.2)
+    net = F.conv2d(net, sd["conv3.weight"], None, stride=1, padding=1)               # :44
+    net = F.leaky_relu(batch_norm(sd, "norm3", net, training), 0.2)                   # :45-46
+    net = F.conv2d(net, sd["conv4.weight"], None, stride=1, padding=1)               # :47
+    return torch.sigmoid(net)                                                         # :48-49
+
+
+# --------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------
+
+def gan_loss(pred, target_is_real, use_lsgan=False, real_label=1.0, fake_label=0.0):
+    """GANLoss.__call__ without soft labels (loss_functions.py:79-104):
+    scalar label expanded to pred's shape; BCELoss (log clamped at -100, torch
+    semantics) or MSELoss, mean reduction."""
+    t = real_label if target_is_real else fake_label
+    if use_lsgan:
+        return ((pred - t) ** 2).mean()
+    logp = torch.clamp(torch.log(pred), min=-100.0)
+    log1mp = torch.clamp(torch.log(1.0 - pred), min=-100.0)
+    return -(t * logp + (1.0 - t) * log1mp).mean()
+
+
+def l1_loss(a, b):
+    """mean |a-b| (the `loss_mel_L1_item` metric, train_whole_sync.py:111)."""
+    return (a - b).abs().mean()
+
+
+def l2_contrastive(f1, f2, margin=0.0, max_violation=False):
+    """L2ContrastiveLoss.forward (loss_functions.py:107-148)."""
+    n = f1.shape[0]
+    scores = torch.norm(f1[None, :, :].expand(n, n, -1).transpose(0, 1) - f2, p=2, dim=2)  # :107-109
+    diag = scores.diag()
+    cost = (margin - scores).clamp(min=0)
+    cost = cost.masked_fill(torch.eye(n) > 0.5, 0)
+    if max_violation:
+        cost = cost.max(1)[0]
+    return (torch.sum(cost ** 2) + torch.sum(diag ** 2)) / (2 * n)
+
+
+# --------------------------------------------------------------------------
+# the declared train step (pix2pix ordering)
+# --------------------------------------------------------------------------
+
+class StepConfig:
+    lr = 2e-4
+    beta1 = 0.5
+    beta2 = 0.999
+    eps = 1e-8
+    lambda_l1 = 100.0
+    use_lsgan = False
+
+
+def make_mask(b, t, tag="mask"):
+    """One full-height time gap per clip (misc/pipeline2.png; policy is the
+    build's: L = T/4, t0 ~ U{T/8 .. 5T/8}) -> (B,1,1,T) float {0,1}."""
+    u = cf_uniform(tag, (b,), 0.0, 1.0).numpy()
+    m = np.ones((b, 1, 1, t), dtype=np.float32)
+    L = max(t // 4, 1)
+    lo, hi = t // 8, (5 * t) // 8
+    for i in range(b):
+        t0 = lo + int(u[i] * (hi - lo + 1))
+        t0 = min(t0, t - L)
+        m[i, :, :, t0:t0 + L] = 0.0
+    return torch.from_numpy(m)
+
+
+class Adam:
+    """torch.optim.Adam (no amsgrad, no weight decay) on a dict of tensors."""
+
+    def __init__(self, sd, cfg=StepConfig):
+        self.keys = param_keys(sd)
+        self.m = {k: torch.zeros_like(sd[k]) for k in self.keys}
+        self.v = {k: torch.zeros_like(sd[k]) for k in self.keys}
+        self.t = 0
+        self.cfg = cfg
+
+    def step(self, sd, grads):
+        c = self.cfg
+        self.t += 1
+        bc1 = 1.0 - c.beta1 ** self.t
+        bc2 = 1.0 - c.beta2 ** self.t
+        with torch.no_grad():
+            for k in self.keys:
+                g = grads.get(k)
+                if g is None:          # e.g. convblock1.* never reached
+                    continue
+                self.m[k].mul_(c.beta1).add_(g, alpha=1 - c.beta1)
+                self.v[k].mul_(c.beta2).addcmul_(g, g, value=1 - c.beta2)
+                denom = (self.v[k].sqrt() / math.sqrt(bc2)).add_(c.eps)
+                sd[k].addcdiv_(self.m[k], denom, value=-c.lr / bc1)
+
+
+def _leafify(sd):
+    out = OrderedDict()
+    for k, v in sd.items():
+        if is_buffer(k):
+            out[k] = v
+        else:
+            out[k] = v.detach().requires_grad_(True)
+    return out
+
+
+def train_step(E, G, D, optG, optD, s, mask, cfg=StepConfig):
+    """One G+D step on spectrogram batch s (B,1,F,T) with mask (B,1,1,T).
+
+    E, G, D: state dicts (updated in place); optG covers E and G parameters
+    (keys prefixed 'E.' / 'G.'), optD covers D.  Returns a dict of tensors
+    captured along the way (the quantities SURVEY.md §8 a14 lists)."""
+    Er, Gr, Dr = _leafify(E), _leafify(G), _leafify(D)
+    s_in = s * mask
+    feats = encoder_forward(Er, s_in.reshape(s.shape[0], s.shape[2], s.shape[3]))
+    fake = decoder_forward(Gr, feats, s.shape)
+    # ---- D step
+    pred_fake_d = disc_forward(Dr, fake.detach())
+    pred_real = disc_forward(Dr, s)
+    loss_d_fake = gan_loss(pred_fake_d, False, cfg.use_lsgan)
+    loss_d_real = gan_loss(pred_real, True, cfg.use_lsgan)
+    loss_d = 0.5 * (loss_d_fake + loss_d_real)
+    dkeys = param_keys(Dr)
+    dgrads = torch.autograd.grad(loss_d, [Dr[k] for k in dkeys])
+    dgrads = dict(zip(dkeys, dgrads))
+    with torch.no_grad():
+        for k in D:
+            D[k].copy_(Dr[k].detach())
+    optD.step(D, dgrads)
+    # ---- G step (D frozen, post-update weights)
+    Df = OrderedDict((k, v.detach()) for k, v in D.items())
+    pred_fake_g = disc_forward(Df, fake)
+    loss_g_gan = gan_loss(pred_fake_g, True, cfg.use_lsgan)
+    loss_l1 = l1_loss(fake, s)
+    loss_g = loss_g_gan + cfg.lambda_l1 * loss_l1
+    ek, gk = param_keys(Er), param_keys(Gr)
+    leaves = [Er[k] for k in ek] + [Gr[k] for k in gk]
+    gg = torch.autograd.grad(loss_g, leaves, allow_unused=True)
+    egrads = dict(zip(ek, gg[:len(ek)]))
+    ggrads = dict(zip(gk, gg[len(ek):]))
+    with torch.no_grad():
+        for k in D:
+            D[k].copy_(Df[k])
+        for k in E:
+            E[k].copy_(Er[k].detach())
+        for k in G:
+            G[k].copy_(Gr[k].detach())
+    EG = OrderedDict([("E." + k, v) for k, v in E.items()] + [("G." + k, v) for k, v in G.items()])
+    eg_grads = dict([("E." + k, v) for k, v in egrads.items()] + [("G." + k, v) for k, v in ggrads.items()])
+    optG.step(EG, eg_grads)
+    return {
+        "fake": fake.detach(), "feats": [f.detach() for f in feats],
+        "pred_fake_d": pred_fake_d.detach(), "pred_real": pred_real.detach(),
+        "pred_fake_g": pred_fake_g.detach(),
+        "loss_d": loss_d.detach(), "loss_g": loss_g.detach(), "loss_g_gan": loss_g_gan.detach(),
+        "loss_l1": loss_l1.detach(),
+        "grads_D": dgrads, "grads_E": egrads, "grads_G": ggrads,
+    }
+
+
+def step_no_update(E, G, D, s, mask, cfg=StepConfig):
+    """The same step WITHOUT the two Adam updates: every quantity is a smooth
+    function of the inputs, so it is the well-conditioned parity target.
+    (With the updates, Adam's first step moves every weight by +-lr *
+    sign(g); weights whose gradient is rounding noise flip sign between any
+    two implementations, and the G step -- which sees the post-update D --
+    inherits ~1e-4 relative differences.  See DESIGN.md "parity protocol".)
+
+    BN buffers still update: E, G once; D three times (fake.detach(), real,
+    fake), all with the initial weights."""
+    Er, Gr, Dr = _leafify(E), _leafify(G), _leafify(D)
+    s_in = s * mask
+    feats = encoder_forward(Er, s_in.reshape(s.shape[0], s.shape[2], s.shape[3]))
+    fake = decoder_forward(Gr, feats, s.shape)
+    pred_fake_d = disc_forward(Dr, fake.detach())
+    pred_real = disc_forward(Dr, s)
+    loss_d = 0.5 * (gan_loss(pred_fake_d, False, cfg.use_lsgan) + gan_loss(pred_real, True, cfg.use_lsgan))
+    dkeys = param_keys(Dr)
+    dgrads = dict(zip(dkeys, torch.autograd.grad(loss_d, [Dr[k] for k in dkeys])))
+    Df = OrderedDict((k, v.detach()) for k, v in Dr.items())
+    fake_leaf = fake
+    pred_fake_g = disc_forward(Df, fake_leaf)
+    loss_g_gan = gan_loss(pred_fake_g, True, cfg.use_lsgan)
+    loss_l1 = l1_loss(fake, s)
+    loss_g = loss_g_gan + cfg.lambda_l1 * loss_l1
+    ek, gk = param_keys(Er), param_keys(Gr)
+    leaves = [Er[k] for k in ek] + [Gr[k] for k in gk]
+    d_fake = torch.autograd.grad(loss_g, fake, retain_graph=True)[0]
+    gg = torch.autograd.grad(loss_g, leaves, allow_unused=True)
+    with torch.no_grad():
+        for sd, r in ((E, Er), (G, Gr), (D, Df)):
+            for k in sd:
+                sd[k].copy_(r[k].detach())
+    return {
+        "fake": fake.detach(), "feats": [f.detach() for f in feats],
+        "pred_fake_d": pred_fake_d.detach(), "pred_real": pred_real.detach(),
+        "pred_fake_g": pred_fake_g.detach(), "d_fake": d_fake.detach(),
+        "loss_d": loss_d.detach(), "loss_g": loss_g.detach(), "loss_g_gan": loss_g_gan.detach(),
+        "loss_l1": loss_l1.detach(),
+        "grads_D": dgrads, "grads_E": dict(zip(ek, gg[:len(ek)])), "grads_G": dict(zip(gk, gg[len(ek):])),
+    }
+
+
+def new_optimizers(E, G, D, cfg=StepConfig):
+    EG = OrderedDict([("E." + k, v) for k, v in E.items()] + [("G." + k, v) for k, v in G.items()])
+    return Adam(EG, cfg), Adam(D, cfg)
+
+
+def digest(t: torch.Tensor, n_samples=64):
+    """Small fingerprint of a tensor: [sum, abs-sum, l2, n strided samples]."""
+    x = t.detach().to(torch.float64).reshape(-1)
+    n = x.numel()
+    idx = (np.arange(n_samples, dtype=np.int64) * max(n // n_samples, 1)) % max(n, 1)
+    return np.concatenate([[x.sum().item(), x.abs().sum().item(), x.pow(2).sum().sqrt().item()],
+                           x[torch.from_numpy(idx)].numpy()])

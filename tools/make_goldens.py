@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz from the REFERENCE's own modules (build container only).
+
+Imports `MelEncoder`, `MelDecoder`, `MelDiscriminator` and `GANLoss` from
+/root/reference (read-only; nothing is copied) behind the stub config modules
+in tools/oracle_stubs/ (SURVEY.md §8c recipe), loads the closed-form weights of
+oracle/viai_oracle.py into them, runs the declared pix2pix-ordered G+D step
+ with torch autograd + torch.optim.Adam, and
+
+  1. asserts the oracle restatement reproduces every captured quantity, and
+  2. writes the reference's outputs as small fixtures under tests/golden/.
+
+The fixtures are data (inputs are regenerated from the closed-form generator;
+expected outputs are stored), never reference source text.
+
+Run:  python tools/make_goldens.py            (needs /root/reference)
+"""
+import os
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(ROOT, "tools", "oracle_stubs"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+for name in ("cv2", "Data_loaders.mel_loader", "Data_loaders.AV_loader"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+import Data_loaders  # noqa: E402  (reference package; empty __init__)
+Data_loaders.mel_loader = sys.modules["Data_loaders.mel_loader"]
+Data_loaders.AV_loader = sys.modules["Data_loaders.AV_loader"]
+
+from networks import Inpainting_Networks as RefEnc          # noqa: E402
+from networks import New_Inpainting_Networks as RefDec      # noqa: E402
+from networks import Discriminator_Networks as RefDis       # noqa: E402
+import loss_functions as RefLoss                            # noqa: E402
+
+from oracle import viai_oracle as O                         # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+LAMBDA_L1 = O.StepConfig.lambda_l1
+
+
+def load_into(module, sd):
+    missing, unexpected = module.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return module
+
+
+def ref_models(F_bins):
+    RefEnc.hparams.cin_channels = F_bins
+    E = load_into(RefEnc.MelEncoder(), O.encoder_state())
+    G = load_into(RefDec.MelDecoder(), O.decoder_state())
+    D = load_into(RefDis.MelDiscriminator(), O.disc_state())
+    E.hparams.cin_channels = F_bins
+    return E, G, D
+
+
+BN_SHADOWED_BIAS = ("deconv1_1.bias", "deconv1_2.bias", "conv6_1.bias")   # bias in front of BN: true grad is 0
+
+
+def ref_step(E, G, D, optG, optD, gan, s, mask, update=True):
+    """The declared step with the reference's modules.
+    update=False skips the two optimizer steps (the well-conditioned parity
+    target, see oracle.step_no_update)."""
+    cap = {}
+    s_in = s * mask
+    feats = E(s_in.view(s.size(0), s.size(2), s.size(3)))
+    fake = G(feats, s.size())
+    fake.retain_grad()
+    # D step
+    for p in D.parameters():
+        p.requires_grad_(True)
+    optD.zero_grad()
+    pred_fake_d = D(fake.detach())
+    pred_real = D(s)
+    loss_d = 0.5 * (gan(pred_fake_d, False) + gan(pred_real, True))
+    loss_d.backward()
+    cap["grads_D"] = {k: p.grad.clone() for k, p in D.named_parameters()}
+    if update:
+        optD.step()
+    # G step
+    for p in D.parameters():
+        p.requires_grad_(False)
+    optG.zero_grad()
+    pred_fake_g = D(fake)
+    loss_g_gan = gan(pred_fake_g, True)
+    loss_l1 = torch.nn.functional.l1_loss(fake, s)
+    loss_g = loss_g_gan + LAMBDA_L1 * loss_l1
+    loss_g.backward()
+    cap["grads_E"] = {k: (p.grad.clone() if p.grad is not None else None) for k, p in E.named_parameters()}
+    cap["grads_G"] = {k: (p.grad.clone() if p.grad is not None else None) for k, p in G.named_parameters()}
+    if update:
+        optG.step()
+    cap.update(fake=fake.detach(), feats=[f.detach() for f in feats], pred_fake_d=pred_fake_d.detach(),
+               pred_real=pred_real.detach(), pred_fake_g=pred_fake_g.detach(), loss_d=loss_d.detach(),
+               loss_g=loss_g.detach(), loss_g_gan=loss_g_gan.detach(), loss_l1=loss_l1.detach(),
+               d_fake=fake.grad.detach().clone())
+    return cap
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def fresh(F_bins):
+    E, G, D = ref_models(F_bins)
+    E.train(); G.train(); D.train()
+    gan = RefLoss.GANLoss(use_lsgan=False, device=torch.device("cpu"))
+    c = O.StepConfig
+    optG = torch.optim.Adam(list(E.parameters()) + list(G.parameters()), lr=c.lr, betas=(c.beta1, c.beta2), eps=c.eps)
+    optD = torch.optim.Adam(D.parameters(), lr=c.lr, betas=(c.beta1, c.beta2), eps=c.eps)
+    return E, G, D, optG, optD, gan
+
+
+def run_case(name, B, F_bins, T, steps, full):
+    torch.manual_seed(0)
+    s = O.cf_uniform("s.%s" % name, (B, 1, F_bins, T))
+    mask = O.make_mask(B, T, "mask.%s" % name)
+    out = OrderedDict()
+    out["meta"] = np.array([B, F_bins, T, steps], dtype=np.int64)
+    worst = 0.0
+
+    # ---------------- (1) no-update step: the well-conditioned parity target
+    E, G, D, optG, optD, gan = fresh(F_bins)
+    cap = ref_step(E, G, D, optG, optD, gan, s, mask, update=False)
+    oE, oG, oD = O.encoder_state(), O.decoder_state(), O.disc_state()
+    ocap = O.step_no_update(oE, oG, oD, s, mask)
+    for k in ("fake", "pred_fake_d", "pred_real", "pred_fake_g", "d_fake", "loss_d", "loss_g", "loss_l1"):
+        e = relerr(ocap[k], cap[k]); worst = max(worst, e)
+        assert e < (1e-3 if k == "d_fake" else 5e-5), (name, k, e)
+    for i, (fo, fr) in enumerate(zip(ocap["feats"], cap["feats"])):
+        e = relerr(fo, fr); worst = max(worst, e)
+        assert e < 5e-5, (name, "feat", i, e)
+    for grp in ("grads_D", "grads_E", "grads_G"):
+        for k, g in cap[grp].items():
+            og = ocap[grp][k]
+            if g is None:
+                assert og is None, (grp, k)
+                continue
+            if grp == "grads_G" and k in BN_SHADOWED_BIAS:
+                assert g.abs().max() < 1e-4 and og.abs().max() < 1e-4
+                continue
+            e = relerr(og, g); worst = max(worst, e)
+            assert e < 5e-3, (name, grp, k, e)
+    for mod, osd, nm in ((E, oE, "E"), (G, oG, "G"), (D, oD, "D")):
+        for k, v in mod.state_dict().items():
+            if O.is_buffer(k):
+                if "num_batches" in k:
+                    assert int(v) == int(osd[k]), (nm, k)
+                else:
+                    e = relerr(osd[k], v); worst = max(worst, e)
+                    assert e < 1e-4, (name, nm, k, e)
+                out["nu.state." + nm + "." + k] = v.numpy().copy()
+    if full:
+        for k in ("fake", "pred_fake_d", "pred_real", "pred_fake_g", "d_fake"):
+            out["nu." + k] = cap[k].numpy()
+        for i, f in enumerate(cap["feats"]):
+            out["nu.feat%d" % i] = f.numpy()
+    else:
+        for k in ("fake", "pred_fake_d", "pred_real", "pred_fake_g", "d_fake"):
+            out["nu." + k + ".dg"] = O.digest(cap[k])
+        for i, f in enumerate(cap["feats"]):
+            out["nu.feat%d.dg" % i] = O.digest(f)
+    for k in ("loss_d", "loss_g", "loss_g_gan", "loss_l1"):
+        out["nu." + k] = np.float64(cap[k].item())
+    for grp in ("grads_D", "grads_E", "grads_G"):
+        for k, g in cap[grp].items():
+            if g is not None:
+                out["nu." + grp + "." + k + ".dg"] = O.digest(g)
+
+    # ---------------- (2) chained steps with Adam: losses only, loose (sign-flip chaos)
+    E, G, D, optG, optD, gan = fresh(F_bins)
+    oE, oG, oD = O.encoder_state(), O.decoder_state(), O.disc_state()
+    ooG, ooD = O.new_optimizers(oE, oG, oD)
+    for it in range(steps):
+        cap = ref_step(E, G, D, optG, optD, gan, s, mask, update=True)
+        ocap = O.train_step(oE, oG, oD, ooG, ooD, s, mask)
+        for k in ("loss_d", "loss_g", "loss_l1"):
+            e = relerr(ocap[k], cap[k])
+            assert e < 3e-2, (name, it, k, e)
+            out["ch.step%d.%s" % (it, k)] = np.float64(cap[k].item())
+    path = os.path.join(OUT, "step_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("%-10s B=%d F=%d T=%d steps=%d  worst oracle-vs-reference rel err (no-update) %.2e  -> %s (%.1f KB)"
+          % (name, B, F_bins, T, steps, worst, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
+def adam_goldens():
+    """torch.optim.Adam known-answer vectors (what the missing AudioModel's
+    optimizer_G/optimizer_D are, utils/util.py:149-150)."""
+    out = OrderedDict()
+    c = O.StepConfig
+    p = torch.nn.Parameter(O.cf_uniform("adam.p", (4096,), -1, 1))
+    opt = torch.optim.Adam([p], lr=c.lr, betas=(c.beta1, c.beta2), eps=c.eps)
+    sd = OrderedDict(p=p.detach().clone())
+    oopt = O.Adam(sd, c)
+    for t in range(3):
+        g = O.cf_uniform("adam.g%d" % t, (4096,), -1, 1) * (10.0 ** O.cf_uniform("adam.e%d" % t, (4096,), -9, 0))
+        p.grad = g.clone()
+        opt.step()
+        oopt.step(sd, {"p": g})
+        out["p_after_%d" % (t + 1)] = p.detach().numpy().copy()
+        assert relerr(sd["p"], p.detach()) < 1e-6
+    path = os.path.join(OUT, "adam.npz")
+    np.savez_compressed(path, **out)
+    print("adam -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
+def layer_goldens():
+    """Per-layer known-answer vectors from torch.nn layers the reference uses."""
+    out = OrderedDict()
+    # ConvTranspose2d stride 1 pad (0,1) (New_Inpainting_Networks.py:53)
+    x = O.cf_uniform("lg.x", (2, 32, 3, 8), -1, 1)
+    w = O.cf_std("lg.w", (32, 32, 3, 3), 0.1)
+    b = O.cf_uniform("lg.b", (32,), -0.1, 0.1)
+    m = torch.nn.ConvTranspose2d(32, 32, 3, 1, (0, 1))
+    m.weight.data.copy_(w); m.bias.data.copy_(b)
+    out["convT_p01"] = m(x).detach().numpy()
+    m = torch.nn.Conv2d(32, 64, (3, 3), stride=(2, 1), padding=(1, 1), bias=False)
+    w2 = O.cf_std("lg.w2", (64, 32, 3, 3), 0.1)
+    m.weight.data.copy_(w2)
+    out["conv_s21"] = m(x).detach().numpy()
+    out["bilinear_3x8_to_7x20"] = torch.nn.functional.interpolate(
+        x, size=[7, 20], mode="bilinear", align_corners=True).numpy()
+    assert relerr(O.bilinear_ac(x, (7, 20)), torch.from_numpy(out["bilinear_3x8_to_7x20"])) < 1e-6
+    # GANLoss (loss_functions.py:79-104), BCE and MSE, incl. the log clamp
+    p = torch.tensor([[0.0, 1.0, 0.25, 0.999999, 1e-30, 0.5]])
+    for lsgan in (False, True):
+        gan = RefLoss.GANLoss(use_lsgan=lsgan, device=torch.device("cpu"))
+        for real in (False, True):
+            v = gan(p, real).item()
+            out["gan_%s_%s" % ("mse" if lsgan else "bce", "real" if real else "fake")] = np.float64(v)
+            assert abs(O.gan_loss(p, real, lsgan).item() - v) <= 1e-6 * max(1, abs(v))
+    f1 = O.cf_uniform("lg.f1", (6, 256), -1, 1)
+    f2 = O.cf_uniform("lg.f2", (6, 256), -1, 1)
+    _cuda = torch.cuda.is_available
+    torch.cuda.is_available = lambda: False          # loss_functions.py:139 calls .cuda() if available
+    for mv in (False, True):
+        v = RefLoss.L2ContrastiveLoss(margin=12.0, max_violation=mv)(f1, f2).item()
+        out["l2c_mv%d" % mv] = np.float64(v)
+        assert abs(O.l2_contrastive(f1, f2, 12.0, mv).item() - v) <= 1e-5 * abs(v)
+    torch.cuda.is_available = _cuda
+    path = os.path.join(OUT, "layers.npz")
+    np.savez_compressed(path, **out)
+    print("layers -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    layer_goldens()
+    adam_goldens()
+    run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
+    run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]
+    if "--cfg2" in sys.argv:
+        run_case("cfg2", 16, 256, 256, 1, full=False)  # configs[1]; ~1 min on 8 cores
