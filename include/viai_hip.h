@@ -1,0 +1,162 @@
+/* viai_hip.h — C ABI of libviai_hip.so, the MI355X (gfx950) kernel library for the
+ * VIAI spectrogram-inpainting GAN hot path.
+ *
+ * The reference (Hangz-nju-cuhk/Vision-Infused-Audio-Inpainter-VIAI) has no FFI /
+ * operator registry: its hot path is torch.nn calls inside nn.Modules (SURVEY.md
+ * §8b).  Each entry point below therefore names the reference call site(s) whose
+ * ATen dispatch it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (the library
+ *     allocates nothing and keeps no mutable global state);
+ *   - activations are fp32 NHWC: [N][H][W][C], C contiguous.  A (N,1,H,W) NCHW
+ *     tensor is bit-identical to its NHWC form;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it,
+ *     the library never synchronises;
+ *   - return value: 0 (hipSuccess) or a hipError_t / hipErrorInvalidValue code.
+ *     Nothing throws across this boundary.
+ *   - re-entrant; one process per GPU under data parallelism.
+ */
+#ifndef VIAI_HIP_H
+#define VIAI_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIAI_ABI_VERSION 1
+
+enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
+
+int viai_abi_version(void);
+
+/* ---------------------------------------------------------------- convolution
+ * nn.Conv2d / stride-1 nn.ConvTranspose2d as used by
+ *   MelEncoder            networks/Inpainting_Networks.py:55-63
+ *   TransConvBlock        networks/New_Inpainting_Networks.py:24
+ *   MelDecoder            networks/New_Inpainting_Networks.py:53-63
+ *   MelDiscriminator      networks/Discriminator_Networks.py:17-33
+ * `x2` (may be NULL) is a second input concatenated after x on the channel axis
+ * (replaces torch.cat at New_Inpainting_Networks.py:81 without the copy).       */
+typedef struct viai_conv2d {
+    int N, IH, IW;       /* input batch / height / width                           */
+    int C1, C2;          /* channels of x and of x2 (C2 = 0 when x2 == NULL)       */
+    int Cout;
+    int kh, kw, sh, sw, ph, pw;
+    int transposed;      /* 0 = nn.Conv2d (weight [Cout][Cin][kh][kw]);
+                            1 = nn.ConvTranspose2d, stride 1 (weight [Cin][Cout][kh][kw]) */
+} viai_conv2d;
+
+/* output extent (torch formulas) */
+int viai_conv2d_out_hw(const viai_conv2d* c, int* OH, int* OW);
+/* floats needed for one packed copy of the weights (forward or dgrad form) */
+size_t viai_conv2d_packed_floats(const viai_conv2d* c);
+/* repack torch-layout weights for the forward / data-gradient kernels */
+int viai_conv2d_pack_fwd(const viai_conv2d* c, const float* w, float* wp, void* stream);
+int viai_conv2d_pack_dgrad(const viai_conv2d* c, const float* w, float* wp, void* stream);
+/* BatchNorm partial-statistics geometry of the forward kernel: number of row
+ * blocks and rows per block; stat_part holds 2*Cout*nblk floats.                */
+int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_per_blk);
+/* y = conv(x ++ x2, w) + bias [; act].  stat_part (optional) receives per-block
+ * per-channel (mean, M2) of y for training-mode BatchNorm; act must be NONE then. */
+int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float* x2, const float* wp_fwd,
+                    const float* bias, float* y, float* stat_part, int act, void* stream);
+/* dx (++ dx2) = conv_backward_data(dy, w) */
+int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const float* wp_dgrad,
+                      float* dx, float* dx2, void* stream);
+/* dw (torch layout) = conv_backward_weight(x ++ x2, dy); dw += if accumulate.
+ * db (optional, [Cout]) = sum of dy.  ws: scratch of viai_conv2d_wgrad_ws_bytes. */
+size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c);
+int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
+                      float* ws, float* dw, float* db, int accumulate, void* stream);
+
+/* generic weight repack used by the two pack entry points (exposed for tests):
+ * wp[no][t][ki] = w[no*s_no + ki*s_ki + t]                                       */
+int viai_pack_weight(const float* w, float* wp, int n_out, int k_in, int taps,
+                     long s_no, long s_ki, void* stream);
+
+/* ------------------------------------------------------------ batch-norm + act
+ * nn.BatchNorm2d in training mode followed by LeakyReLU(0.2) / ReLU
+ * (Inpainting_Networks.py:72-76, New_Inpainting_Networks.py:33-36,72-75,86,
+ *  Discriminator_Networks.py:39-46).                                            */
+/* merge block partials -> mean / invstd / (scale, shift); update running stats
+ * (momentum, unbiased variance) and num_batches_tracked (int64, may be NULL).    */
+int viai_bn_finalize(const float* stat_part, int nblk, int rows_per_blk, long M, int C,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, float momentum, float eps,
+                     float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: (scale, shift) from the running statistics */
+int viai_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* mean, float* invstd,
+                        float* scale, float* shift, void* stream);
+/* z = act(y*scale[c] + shift[c]) */
+int viai_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z,
+                    long M, int C, int act, float slope, void* stream);
+/* backward of the pair above (training-mode statistics):
+ *   dgamma, dbeta (optional outputs) and dy.  part: scratch of 2*C*nblk floats,
+ *   nblk from viai_bn_bwd_blocks(M, C).  training = 0 gives the eval-mode rule.  */
+int viai_bn_bwd_blocks(long M, int C);
+int viai_bn_act_bwd(const float* dz, const float* y, const float* mean, const float* invstd,
+                    const float* scale, const float* shift, float* part, float* sums,
+                    float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
+                    int training, void* stream);
+/* elementwise activation backward for layers without BN (sigmoid heads):
+ * dx = dz * act'(.) expressed through the activation OUTPUT z                    */
+int viai_act_bwd_from_output(const float* dz, const float* z, float* dx, long n, int act,
+                             float slope, void* stream);
+
+/* ------------------------------------------------------------------ resampling
+ * F.interpolate(mode='bilinear', align_corners=True)  New_Inpainting_Networks.py:78,83 */
+int viai_bilinear_ac_fwd(const float* x, float* y, int N, int IH, int IW, int OH, int OW, int C, void* stream);
+int viai_bilinear_ac_bwd(const float* dy, float* dx, int N, int IH, int IW, int OH, int OW, int C, void* stream);
+/* nn.AvgPool2d((3,1)) on the bottleneck  Inpainting_Networks.py:65,77 (floor mode) */
+int viai_avgpool_h_fwd(const float* x, float* y, int N, int IH, int W, int C, int k, void* stream);
+int viai_avgpool_h_bwd(const float* dy, float* dx, int N, int IH, int W, int C, int k, void* stream);
+
+/* ----------------------------------------------------------------------- losses
+ * GANLoss = BCELoss / MSELoss against an expanded scalar label (loss_functions.py:79-104);
+ * L1 is the `loss_mel_L1_item` metric (train_whole_sync.py:111).  Each forward
+ * writes ONE float (mean reduction) to `loss`; `part` is scratch of
+ * viai_reduce_blocks(n) floats.  Backward multiplies by the scalar *gscale
+ * (device pointer; e.g. d(total)/d(loss)).                                       */
+int viai_reduce_blocks(long n);
+int viai_bce_fwd(const float* p, float target, long n, float* part, float* loss, void* stream);
+int viai_bce_bwd(const float* p, float target, long n, const float* gscale, float* dp, void* stream);
+int viai_mse_fwd(const float* p, float target, long n, float* part, float* loss, void* stream);
+int viai_mse_bwd(const float* p, float target, long n, const float* gscale, float* dp, void* stream);
+int viai_l1_fwd(const float* a, const float* b, long n, float* part, float* loss, void* stream);
+int viai_l1_bwd(const float* a, const float* b, long n, const float* gscale, float* da, void* stream);
+
+/* ------------------------------------------------------------ mask / optimizer
+ * s_in = s * mask, mask (N, T) broadcast over frequency (the missing
+ * AudioModel.set_inputs; figure misc/pipeline2.png)                             */
+int viai_mask_mul(const float* s, const float* mask, float* out, int N, int F, int T, void* stream);
+/* torch.optim.Adam step on a flat fp32 arena (optimizer_G / optimizer_D,
+ * utils/util.py:149-150).  `state` is 4 device doubles {step, lr, beta1^t, beta2^t}
+ * (initialise to {0, lr, 1, 1}) advanced ON DEVICE so that the launch is
+ * replayable inside a hipGraph.                                                  */
+int viai_adam_step(float* p, const float* g, float* m, float* v, long n, double* state,
+                   double beta1, double beta2, double eps, float grad_scale, void* stream);
+
+/* out[c] (+)= sum over rows of x[M][C] (bias gradients); part: scratch of
+ * viai_colsum_blocks(M, C) * C floats                                            */
+int viai_colsum_blocks(long M, int C);
+int viai_colsum(const float* x, long M, int C, float* part, float* out, int accumulate, void* stream);
+
+/* y = a*x + y (flat); used for gradient accumulation on arenas */
+int viai_axpy(float a, const float* x, float* y, long n, void* stream);
+
+/* ----------------------------------------------------------------- audio front
+ * melspectrogram(y) of utils/audio.py:70-75 (lws STFT -> |.| -> mel -> dB -> [0,1])
+ * fused with the inpainting mask.  basis_t: [fft/2+1][n_mels] (TRANSPOSED mel basis); window: [fft]; mask: [B][frames] or NULL.
+ * wav: [B][n_samples]; mel out: [B][n_mels][frames] (== NHWC with C = 1).        */
+int viai_stft_mel(const float* wav, const float* window, const float* basis_t, const float* mask,
+                  float* mel, int B, int n_samples, int fft, int hop, int n_mels, int frames,
+                  float min_level_db, float ref_level_db, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIAI_HIP_H */

@@ -462,7 +462,7 @@ def new_optimizers(E, G, D, cfg=StepConfig):
 
 def digest(t: torch.Tensor, n_samples=64):
     """Small fingerprint of a tensor: [sum, abs-sum, l2, n strided samples]."""
-    x = t.detach().to(torch.float64).reshape(-1)
+    x = t.detach().cpu().to(torch.float64).reshape(-1)
     n = x.numel()
     idx = (np.arange(n_samples, dtype=np.int64) * max(n // n_samples, 1)) % max(n, 1)
     return np.concatenate([[x.sum().item(), x.abs().sum().item(), x.pow(2).sum().sqrt().item()],

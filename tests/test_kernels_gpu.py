@@ -1,0 +1,234 @@
+"""GPU parity of the HIP kernels (through the C ABI / autograd ops) against the
+reference's own torch CPU ops on identical inputs.  Tolerance: the north star's
+1e-3 relative fp32; the kernels are exact-fp32 MFMA so most checks are ~1e-6."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import viai_oracle as O
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def nhwc(t):  # NCHW cpu -> NHWC cuda
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):  # NHWC cuda -> NCHW cpu
+    return t.detach().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+CONV_CASES = [
+    # name, N, H, W, Cin, Cout, k, s, p, transposed, bias
+    ("E.conv2", 2, 20, 24, 32, 64, (3, 3), (2, 1), (1, 1), False, False),
+    ("E.conv3", 2, 17, 24, 64, 128, (3, 3), (2, 2), (1, 1), False, False),
+    ("E.conv5", 1, 16, 32, 256, 256, (3, 3), (2, 2), (1, 1), False, False),
+    ("G.deconv1_1", 2, 2, 8, 256, 256, (3, 3), (1, 1), (0, 1), True, True),
+    ("G.cb2", 2, 6, 10, 256, 128, (3, 3), (1, 1), (1, 1), True, False),
+    ("G.cb5", 2, 16, 12, 32, 32, (3, 3), (1, 1), (1, 1), True, False),
+    ("G.conv6_1", 1, 24, 40, 32, 32, (3, 3), (1, 1), (1, 1), True, True),
+    ("D.conv2_1", 2, 16, 20, 64, 128, (3, 3), (2, 2), (1, 1), False, False),
+    ("D.conv3", 1, 9, 11, 256, 512, (3, 3), (1, 1), (1, 1), False, False),
+    ("odd-sizes", 3, 7, 5, 64, 96, (3, 3), (2, 2), (1, 1), False, True),
+    ("E.conv1", 2, 20, 24, 1, 32, (3, 3), (2, 2), (1, 1), False, False),
+    ("D.conv1", 2, 12, 32, 1, 64, (1, 4), (1, 2), (0, 1), False, False),
+    ("G.conv6_2", 2, 12, 20, 32, 1, (3, 3), (1, 1), (1, 1), True, True),
+    ("D.conv4", 2, 8, 6, 512, 1, (3, 3), (1, 1), (1, 1), False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_bwd_matches_torch_cpu(case):
+    from viai_amd import ops
+    name, N, H, W, Cin, Cout, k, s, p, tr, use_bias = case
+    x = O.cf_uniform(name + ".x", (N, Cin, H, W), -1, 1).requires_grad_(True)
+    wshape = (Cin, Cout) + k if tr else (Cout, Cin) + k
+    w = O.cf_std(name + ".w", wshape, 0.1).requires_grad_(True)
+    b = O.cf_uniform(name + ".b", (Cout,), -0.5, 0.5).requires_grad_(True) if use_bias else None
+    if tr:
+        y = F.conv_transpose2d(x, w, b, stride=1, padding=p)
+    else:
+        y = F.conv2d(x, w, b, stride=s, padding=p)
+    gy = O.cf_uniform(name + ".gy", tuple(y.shape), -1, 1)
+    y.backward(gy)
+
+    xg = nhwc(x.detach()).requires_grad_(True)
+    wg = w.detach().cuda().requires_grad_(True)
+    bg = b.detach().cuda().requires_grad_(True) if use_bias else None
+    yg = ops.conv_bn_act(xg, wg, bg, None, kernel=k, stride=s, padding=p, transposed=tr, act=ops.ACT_NONE)
+    assert tuple(nchw(yg).shape) == tuple(y.shape)
+    assert relerr(nchw(yg), y) < 2e-5, name
+    yg.backward(nhwc(gy))
+    assert relerr(nchw(xg.grad), x.grad) < 2e-5, name
+    assert relerr(wg.grad, w.grad) < 2e-5, name
+    if use_bias:
+        assert relerr(bg.grad, b.grad) < 2e-5, name
+
+
+def test_conv_virtual_concat_matches_cat():
+    from viai_amd import ops
+    N, H, W = 2, 9, 12
+    x1 = O.cf_uniform("cc.x1", (N, 64, H, W), -1, 1).requires_grad_(True)
+    x2 = O.cf_uniform("cc.x2", (N, 64, H, W), -1, 1).requires_grad_(True)
+    w = O.cf_std("cc.w", (128, 32, 3, 3), 0.1).requires_grad_(True)
+    y = F.conv_transpose2d(torch.cat((x1, x2), 1), w, None, stride=1, padding=1)
+    gy = O.cf_uniform("cc.gy", tuple(y.shape), -1, 1)
+    y.backward(gy)
+    a, b = nhwc(x1.detach()).requires_grad_(True), nhwc(x2.detach()).requires_grad_(True)
+    wg = w.detach().cuda().requires_grad_(True)
+    yg = ops.conv_bn_act(a, wg, None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1), transposed=True, x2=b)
+    assert relerr(nchw(yg), y) < 2e-5
+    yg.backward(nhwc(gy))
+    assert relerr(nchw(a.grad), x1.grad) < 2e-5
+    assert relerr(nchw(b.grad), x2.grad) < 2e-5
+    assert relerr(wg.grad, w.grad) < 2e-5
+
+
+@pytest.mark.parametrize("act", ["lrelu", "relu"])
+@pytest.mark.parametrize("shape", [(2, 32, 20, 24), (3, 64, 7, 9), (1, 256, 4, 16)])
+def test_conv_bn_act_train_matches_torch_cpu(act, shape):
+    """conv -> BatchNorm2d(train) -> activation, forward, backward, running stats."""
+    from viai_amd import ops
+    N, C, H, W = shape
+    Cout = 64
+    x = O.cf_uniform("bn.x", shape, -1, 1).requires_grad_(True)
+    w = O.cf_std("bn.w", (Cout, C, 3, 3), 0.1).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(Cout)
+    bn.weight.data.copy_(O.cf_uniform("bn.g", (Cout,), 0.5, 1.5))
+    bn.bias.data.copy_(O.cf_uniform("bn.b", (Cout,), -0.5, 0.5))
+    bn.train()
+    y = bn(F.conv2d(x, w, None, stride=1, padding=1))
+    y = F.leaky_relu(y, 0.2) if act == "lrelu" else F.relu(y)
+    gy = O.cf_uniform("bn.gy", tuple(y.shape), -1, 1)
+    y.backward(gy)
+
+    bng = torch.nn.BatchNorm2d(Cout).cuda()
+    bng.weight.data.copy_(O.cf_uniform("bn.g", (Cout,), 0.5, 1.5))
+    bng.bias.data.copy_(O.cf_uniform("bn.b", (Cout,), -0.5, 0.5))
+    bng.train()
+    xg = nhwc(x.detach()).requires_grad_(True)
+    wg = w.detach().cuda().requires_grad_(True)
+    yg = ops.conv_bn_act(xg, wg, None, bng, kernel=(3, 3), stride=(1, 1), padding=(1, 1),
+                         act=ops.ACT_LRELU if act == "lrelu" else ops.ACT_RELU)
+    assert relerr(nchw(yg), y) < 1e-4
+    yg.backward(nhwc(gy))
+    assert relerr(nchw(xg.grad), x.grad) < 1e-3
+    assert relerr(wg.grad, w.grad) < 1e-3
+    assert relerr(bng.weight.grad, bn.weight.grad) < 1e-3
+    assert relerr(bng.bias.grad, bn.bias.grad) < 1e-3
+    assert relerr(bng.running_mean, bn.running_mean) < 1e-5
+    assert relerr(bng.running_var, bn.running_var) < 1e-5
+    assert int(bng.num_batches_tracked) == 1
+
+
+def test_bn_large_mean_is_stable():
+    """variance of a channel with mean >> std (the E[x^2]-E[x]^2 trap)."""
+    from viai_amd import ops
+    N, C, H, W = 4, 32, 64, 64
+    x = O.cf_uniform("bnl.x", (N, C, H, W), -1, 1)
+    w = torch.zeros(32, C, 3, 3)
+    for i in range(32):
+        w[i, i, 1, 1] = 1e-2          # y ~ 1e-2 * x
+    b = torch.full((32,), 5.0)         # + 5: fp32 E[x^2]-E[x]^2 would be ~6% off here
+    bn = torch.nn.BatchNorm2d(32).train()
+    y = bn(F.conv2d(x, w, b, padding=1))
+    bng = torch.nn.BatchNorm2d(32).cuda().train()
+    yg = ops.conv_bn_act(nhwc(x), w.cuda(), b.cuda(), bng, kernel=(3, 3), stride=(1, 1), padding=(1, 1), act=ops.ACT_NONE)
+    assert relerr(nchw(yg), y) < 1e-3
+    assert relerr(bng.running_var, bn.running_var) < 1e-4
+
+
+@pytest.mark.parametrize("sizes", [((4, 16), (16, 32)), ((3, 8), (7, 20)), ((64, 128), (128, 128)), ((5, 7), (5, 7)), ((9, 9), (4, 5))])
+def test_bilinear_ac_matches_torch_cpu(sizes):
+    from viai_amd import ops
+    (ih, iw), (oh, ow) = sizes
+    x = O.cf_uniform("bl.x", (2, 32, ih, iw), -1, 1).requires_grad_(True)
+    y = F.interpolate(x, size=[oh, ow], mode="bilinear", align_corners=True)
+    gy = O.cf_uniform("bl.gy", tuple(y.shape), -1, 1)
+    y.backward(gy)
+    xg = nhwc(x.detach()).requires_grad_(True)
+    yg = ops.bilinear_ac(xg, (oh, ow))
+    assert relerr(nchw(yg), y) < 5e-6
+    yg.backward(nhwc(gy))
+    assert relerr(nchw(xg.grad), x.grad) < 1e-5
+
+
+def test_avgpool_h_matches_torch_cpu():
+    from viai_amd import ops
+    for ih in (8, 5, 3):
+        x = O.cf_uniform("ap.x", (2, 256, ih, 16), -1, 1).requires_grad_(True)
+        y = F.avg_pool2d(x, (3, 1))
+        gy = O.cf_uniform("ap.gy", tuple(y.shape), -1, 1)
+        y.backward(gy)
+        xg = nhwc(x.detach()).requires_grad_(True)
+        yg = ops.avgpool_h(xg, 3)
+        assert relerr(nchw(yg), y) < 1e-6
+        yg.backward(nhwc(gy))
+        assert relerr(nchw(xg.grad), x.grad) < 1e-6
+        x.grad = None
+
+
+def test_losses_match_torch_cpu(golden_dir):
+    from viai_amd import ops
+    p = O.cf_uniform("ls.p", (4, 1, 32, 16), 0.001, 0.999).requires_grad_(True)
+    s = O.cf_uniform("ls.s", (4, 1, 32, 16), 0, 1)
+    for target in (0.0, 1.0, 0.9):
+        for kind in ("bce", "mse"):
+            ref = O.gan_loss(p, None, kind == "mse", real_label=target, fake_label=target) if False else None
+            t = torch.full_like(p, target)
+            ref = F.binary_cross_entropy(p, t) if kind == "bce" else F.mse_loss(p, t)
+            (g_ref,) = torch.autograd.grad(ref * 3.0, p)
+            pg = p.detach().cuda().requires_grad_(True)
+            out = ops.bce_mean(pg, target) if kind == "bce" else ops.mse_mean(pg, target)
+            (g,) = torch.autograd.grad(out * 3.0, pg)
+            assert abs(out.item() - ref.item()) <= 1e-5 * abs(ref.item())
+            assert relerr(g, g_ref) < 1e-5
+    ref = F.l1_loss(p, s)
+    (g_ref,) = torch.autograd.grad(ref, p)
+    pg = p.detach().cuda().requires_grad_(True)
+    out = ops.l1_mean(pg, s.cuda())
+    (g,) = torch.autograd.grad(out, pg)
+    assert abs(out.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert relerr(g, g_ref) < 1e-6
+    # the reference GANLoss golden values incl. the log clamp at p in {0, 1}
+    gold = np.load(golden_dir + "/layers.npz")
+    pe = torch.tensor([[0.0, 1.0, 0.25, 0.999999, 1e-30, 0.5]]).cuda()
+    assert abs(ops.bce_mean(pe, 1.0).item() - float(gold["gan_bce_real"])) < 1e-4 * float(gold["gan_bce_real"])
+    assert abs(ops.bce_mean(pe, 0.0).item() - float(gold["gan_bce_fake"])) < 1e-4 * float(gold["gan_bce_fake"])
+    assert abs(ops.mse_mean(pe, 1.0).item() - float(gold["gan_mse_real"])) < 1e-5
+    assert abs(ops.mse_mean(pe, 0.0).item() - float(gold["gan_mse_fake"])) < 1e-5
+
+
+def test_adam_matches_torch_optim_golden(golden_dir):
+    from viai_amd import ops
+    gold = np.load(golden_dir + "/adam.npz")
+    c = O.StepConfig
+    p = O.cf_uniform("adam.p", (4096,), -1, 1).cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    state = torch.tensor([0.0, c.lr, 1.0, 1.0], dtype=torch.float64, device="cuda")
+    for t in range(3):
+        g = (O.cf_uniform("adam.g%d" % t, (4096,), -1, 1) * (10.0 ** O.cf_uniform("adam.e%d" % t, (4096,), -9, 0))).cuda()
+        ops.adam_step(p, g, m, v, state, c.beta1, c.beta2, c.eps)
+        ref = torch.from_numpy(gold["p_after_%d" % (t + 1)])
+        assert (p.cpu() - ref).abs().max().item() < 2e-7
+    assert state[0].item() == 3.0
+
+
+def test_mask_mul():
+    from viai_amd import ops
+    s = O.cf_uniform("mm.s", (3, 1, 20, 32), 0, 1)
+    mask = O.make_mask(3, 32, "mm.mask")
+    out = ops.mask_mul(s.cuda(), mask.cuda())
+    assert torch.equal(out.cpu(), s * mask)
+
+
+def test_ops_refuse_cpu_tensors():
+    from viai_amd import ops, _lib
+    with pytest.raises(_lib.ViaiLibraryError):
+        ops.bilinear_ac(torch.zeros(1, 2, 2, 4), (4, 4))

@@ -1,0 +1,112 @@
+"""ctypes binding of libviai_hip.so (the C ABI declared in include/viai_hip.h).
+
+The HIP library is the product; there is NO CPU fallback.  Every wrapper raises
+if the library is missing or a launch returns a non-zero hipError_t.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libviai_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class ViaiLibraryError(RuntimeError):
+    pass
+
+
+class Conv2dDesc(C.Structure):
+    """mirror of `viai_conv2d` (include/viai_hip.h)."""
+    _fields_ = [(n, C.c_int) for n in (
+        "N", "IH", "IW", "C1", "C2", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "transposed")]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_long
+_F = C.c_float
+_D = C.c_double
+_CP = C.POINTER(Conv2dDesc)
+_IP = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); must list every symbol declared in include/viai_hip.h
+SIGNATURES = {
+    "viai_abi_version": (_I, []),
+    "viai_conv2d_out_hw": (_I, [_CP, _IP, _IP]),
+    "viai_conv2d_packed_floats": (C.c_size_t, [_CP]),
+    "viai_conv2d_pack_fwd": (_I, [_CP, _P, _P, _P]),
+    "viai_conv2d_pack_dgrad": (_I, [_CP, _P, _P, _P]),
+    "viai_conv2d_stat_geom": (_I, [_CP, _IP, _IP]),
+    "viai_conv2d_fwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "viai_conv2d_dgrad": (_I, [_CP, _P, _P, _P, _P, _P]),
+    "viai_conv2d_wgrad_ws_bytes": (C.c_size_t, [_CP]),
+    "viai_conv2d_wgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "viai_pack_weight": (_I, [_P, _P, _I, _I, _I, _L, _L, _P]),
+    "viai_bn_finalize": (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "viai_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "viai_bn_act_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _F, _P]),
+    "viai_bn_bwd_blocks": (_I, [_L, _I]),
+    "viai_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
+    "viai_act_bwd_from_output": (_I, [_P, _P, _P, _L, _I, _F, _P]),
+    "viai_bilinear_ac_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "viai_bilinear_ac_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "viai_avgpool_h_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "viai_avgpool_h_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "viai_reduce_blocks": (_I, [_L]),
+    "viai_bce_fwd": (_I, [_P, _F, _L, _P, _P, _P]),
+    "viai_bce_bwd": (_I, [_P, _F, _L, _P, _P, _P]),
+    "viai_mse_fwd": (_I, [_P, _F, _L, _P, _P, _P]),
+    "viai_mse_bwd": (_I, [_P, _F, _L, _P, _P, _P]),
+    "viai_l1_fwd": (_I, [_P, _P, _L, _P, _P, _P]),
+    "viai_l1_bwd": (_I, [_P, _P, _L, _P, _P, _P]),
+    "viai_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "viai_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _D, _D, _D, _F, _P]),
+    "viai_colsum_blocks": (_I, [_L, _I]),
+    "viai_colsum": (_I, [_P, _L, _I, _P, _P, _I, _P]),
+    "viai_axpy": (_I, [_F, _P, _P, _L, _P]),
+    "viai_stft_mel": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libviai_hip.so (in-tree)."""
+    args = ["make", "-C", CSRC, "-j8"]
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise ViaiLibraryError("hipcc build of libviai_hip.so failed:\n" + r.stdout[-4000:])
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """dlopen the library and type every entry point.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ViaiLibraryError(
+            "libviai_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ViaiLibraryError("libviai_hip.so does not export %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.viai_abi_version() != 1:
+        raise ViaiLibraryError("libviai_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(err: int, what: str) -> None:
+    if err != 0:
+        raise ViaiLibraryError("%s failed with hipError_t %d" % (what, err))

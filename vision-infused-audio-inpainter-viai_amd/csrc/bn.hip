@@ -1,0 +1,255 @@
+// Training-mode BatchNorm2d + activation on NHWC fp32 (gfx950), HBM-bound.
+// Reference call sites: Inpainting_Networks.py:72-76, New_Inpainting_Networks.py:33-36,72-75,86,
+// Discriminator_Networks.py:39-46 (nn.BatchNorm2d defaults: eps 1e-5, momentum 0.1,
+// biased variance for normalisation, unbiased for running_var).
+//
+// Forward statistics arrive as block-local (mean_b, M2_b) pairs from the conv
+// epilogue and are merged here with Chan's parallel formula in fp64, so a
+// 1M-element channel never sees the E[x^2] - E[x]^2 cancellation.
+#include "viai_common.h"
+#include "viai_internal.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ part, int nblk, int rows, long M, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+    float* mean_o, float* invstd_o, float* scale_o, float* shift_o) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const float* pm = part + (size_t)c * nblk;
+    const float* p2 = part + (size_t)(C + c) * nblk;
+    const long last_n = M - (long)(nblk - 1) * rows;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        double nb = (b == nblk - 1) ? (double)last_n : (double)rows;
+        s += nb * (double)pm[b];
+    }
+    s = block_sum_d(s, red);
+    const double mean = s / (double)M;
+    double m2 = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        double nb = (b == nblk - 1) ? (double)last_n : (double)rows;
+        double d = (double)pm[b] - mean;
+        m2 += (double)p2[b] + nb * d * d;
+    }
+    m2 = block_sum_d(m2, red);
+    if (threadIdx.x == 0) {
+        const double var = m2 / (double)M;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, bta = beta ? beta[c] : 0.f;
+        mean_o[c] = (float)mean;
+        invstd_o[c] = invstd;
+        scale_o[c] = g * invstd;
+        shift_o[c] = bta - (float)mean * g * invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        if (running_var) {
+            double unb = (M > 1) ? m2 / (double)(M - 1) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+        if (nbt && c == 0) *nbt += 1;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* mean_o, float* invstd_o, float* scale_o, float* shift_o) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float invstd = 1.f / sqrtf(rv[c] + eps);
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean_o[c] = rm[c]; invstd_o[c] = invstd; scale_o[c] = g * invstd; shift_o[c] = b - rm[c] * g * invstd;
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, f32x4* __restrict__ z,
+                                                         long n4, int C, int act, float slope) {
+    const int c4n = C / 4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        int c = (int)(i % c4n) * 4;
+        f32x4 v = y[i];
+        f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+        f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = viai_act(v[e] * sc[e] + sh[e], act, slope);
+        z[i] = o;
+    }
+}
+
+__device__ __forceinline__ float act_grad(float pre, int act, float slope) {
+    if (act == VIAI_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
+    if (act == VIAI_ACT_LRELU) return pre > 0.f ? 1.f : slope;
+    if (act == VIAI_ACT_SIGMOID) { float s = 1.f / (1.f + __expf(-pre)); return s * (1.f - s); }
+    return 1.f;
+}
+
+// partial sums over a row range: part[blk][0][c] = sum dpre, part[blk][1][c] = sum dpre * xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dz, const float* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
+    float* __restrict__ part, long M, int C, long rows_per_blk, int act, float slope) {
+    __shared__ f32x4 r1[256], r2[256];
+    const int tid = threadIdx.x;
+    const int CG = C / 4;
+    const long row0 = blockIdx.x * rows_per_blk;
+    long row1 = row0 + rows_per_blk; if (row1 > M) row1 = M;
+    for (int g0 = 0; g0 < CG; g0 += 256) {
+        const int cgw = min(256, CG - g0);
+        const int pg = 256 / cgw;
+        const int cg = tid % cgw, pl = tid / cgw;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (pl < pg) {
+            const int c = (g0 + cg) * 4;
+            f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+            f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+            for (long r = row0 + pl; r < row1; r += pg) {
+                f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * C + c);
+                f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float dp = g[e] * act_grad(v[e] * sc[e] + sh[e], act, slope);
+                    s1[e] += dp;
+                    s2[e] += dp * (v[e] - mu[e]) * is[e];
+                }
+            }
+        }
+        r1[tid] = s1; r2[tid] = s2;
+        __syncthreads();
+        if (tid < cgw) {
+            f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < pg; ++k) { t1 += r1[k * cgw + tid]; t2 += r2[k * cgw + tid]; }
+            const int c = (g0 + tid) * 4;
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + c) = t1;
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + c) = t2;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, float* sums,
+                                    float* dgamma, float* dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += (double)part[((size_t)b * 2 + 0) * C + c];
+        s2 += (double)part[((size_t)b * 2 + 1) * C + c];
+    }
+    sums[c] = (float)s1; sums[C + c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const f32x4* __restrict__ dz, const f32x4* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ sums, f32x4* __restrict__ dy, long n4, long M, int C, int act, float slope, int training) {
+    const int c4n = C / 4;
+    const float invM = 1.f / (float)M;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        const int c = (int)(i % c4n) * 4;
+        f32x4 g = dz[i], v = y[i], o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sc = scale[c + e];
+            float dp = g[e] * act_grad(v[e] * sc + shift[c + e], act, slope);
+            if (training) {
+                float xh = (v[e] - mean[c + e]) * invstd[c + e];
+                o[e] = sc * (dp - sums[c + e] * invM - xh * sums[C + c + e] * invM);
+            } else {
+                o[e] = sc * dp;
+            }
+        }
+        dy[i] = o;
+    }
+}
+
+__global__ void act_bwd_out_kernel(const float* __restrict__ dz, const float* __restrict__ z, float* __restrict__ dx,
+                                   long n, int act, float slope) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float zz = z[i], g = dz[i], d = 1.f;
+        if (act == VIAI_ACT_SIGMOID) d = zz * (1.f - zz);
+        else if (act == VIAI_ACT_RELU) d = zz > 0.f ? 1.f : 0.f;
+        else if (act == VIAI_ACT_LRELU) d = zz > 0.f ? 1.f : slope;
+        dx[i] = g * d;
+    }
+}
+
+inline int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int viai_bn_finalize(const float* stat_part, int nblk, int rows_per_blk, long M, int C,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                int64_t* nbt, float momentum, float eps,
+                                float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    if (nblk <= 0 || C <= 0 || M <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, nblk, rows_per_blk, M, C,
+                       gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift);
+    return viai_launch_status();
+}
+
+extern "C" int viai_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                   float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, rm, rv, eps,
+                       mean, invstd, scale, shift);
+    return viai_launch_status();
+}
+
+extern "C" int viai_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z,
+                               long M, int C, int act, float slope, void* stream) {
+    if (C % 4 != 0) return (int)hipErrorInvalidValue;
+    long n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(y), scale, shift, reinterpret_cast<f32x4*>(z), n4, C, act, slope);
+    return viai_launch_status();
+}
+
+extern "C" int viai_bn_bwd_blocks(long M, int C) {
+    (void)C;
+    long b = (M + 511) / 512;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mean, const float* invstd,
+                               const float* scale, const float* shift, float* part, float* sums,
+                               float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
+                               int training, void* stream) {
+    if (C % 4 != 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = viai_bn_bwd_blocks(M, C);
+    const long rpb = (M + nblk - 1) / nblk;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, C, sums, dgamma, dbeta);
+    if (dy != nullptr) {
+        long n4 = M * C / 4;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz),
+                           reinterpret_cast<const f32x4*>(y), mean, invstd, scale, shift, sums, reinterpret_cast<f32x4*>(dy),
+                           n4, M, C, act, slope, training);
+    }
+    return viai_launch_status();
+}
+
+extern "C" int viai_act_bwd_from_output(const float* dz, const float* z, float* dx, long n, int act, float slope, void* stream) {
+    hipLaunchKernelGGL(act_bwd_out_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dz, z, dx, n, act, slope);
+    return viai_launch_status();
+}

@@ -1,0 +1,444 @@
+// Bandwidth-bound members of the conv family (gfx950): layers with Cin == 1
+// (E.conv1 3x3 s2, D.conv1 1x4 s(1,2)) or Cout == 1 (G.conv6_2, D.conv4).
+// K is 4..9 (or N is 1) there, so these are streaming kernels, not GEMMs:
+// coalesced 16-byte channel accesses, weights in registers / L1, wave shuffles
+// for the channel reductions.  Reference call sites:
+//   networks/Inpainting_Networks.py:55, networks/Discriminator_Networks.py:17,33,
+//   networks/New_Inpainting_Networks.py:63.
+#include "viai_common.h"
+#include "viai_internal.h"
+
+namespace {
+
+struct DirectArgs {
+    const float* x; const float* w; const float* bias; const float* dy;
+    float* y; float* dx; float* ws; float* stat;
+    int N, IH, IW, OH, OW, Cin, Cout;
+    int kh, kw, sh, sw, ph, pw;      // forward-form geometry: in = o*s + d, d = r - p (conv) or p - r (convT)
+    int transposed;
+    int M;                            // N*OH*OW
+    int nblk;
+    int act; float slope;
+};
+
+__device__ __forceinline__ int tap_dy(const DirectArgs& a, int r) { return a.transposed ? a.ph - r : r - a.ph; }
+__device__ __forceinline__ int tap_dx(const DirectArgs& a, int s) { return a.transposed ? a.pw - s : s - a.pw; }
+
+// ------------------------------------------------------------------ Cin == 1
+// y[p][co] = sum_t x[p_t] * w[co][t];  thread = (pixel lane, 4 output channels)
+constexpr int CIN1_PB = 256;   // pixels per block == rows_per_blk of the BN partials
+
+template <int CG>   // channel groups of 4 (Cout = 4*CG)
+__global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
+    constexpr int PG = 256 / CG;
+    constexpr int IT = CIN1_PB / PG;
+    __shared__ float red[PG][CG * 4];
+    const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
+    const int T = a.kh * a.kw;
+    f32x4 wv[VIAI_MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < VIAI_MAX_TAPS; ++t)
+        if (t < T) {
+            wv[t][0] = a.w[(cg * 4 + 0) * T + t]; wv[t][1] = a.w[(cg * 4 + 1) * T + t];
+            wv[t][2] = a.w[(cg * 4 + 2) * T + t]; wv[t][3] = a.w[(cg * 4 + 3) * T + t];
+        }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + cg * 4);
+    const int p0 = blockIdx.x * CIN1_PB;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 vals[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        int p = p0 + it * PG + pg;
+        f32x4 v = bv;
+        if (p < a.M) {
+            int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
+            const float* xb = a.x + (size_t)n * a.IH * a.IW;
+#pragma unroll
+            for (int t = 0; t < VIAI_MAX_TAPS; ++t)
+                if (t < T) {
+                    int iy = oy * a.sh + tap_dy(a, t / a.kw), ix = ox * a.sw + tap_dx(a, t % a.kw);
+                    float xv = ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
+                    v += xv * wv[t];
+                }
+            if (a.stat == nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = viai_act(v[e], a.act, a.slope);
+            }
+            *reinterpret_cast<f32x4*>(a.y + (size_t)p * a.Cout + cg * 4) = v;
+            sum += v;
+        } else {
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        vals[it] = v;
+    }
+    if (a.stat == nullptr) return;
+    // block-local (mean, M2) per channel over the valid pixels of this block
+    const int cnt = min(CIN1_PB, a.M - p0);
+    *reinterpret_cast<f32x4*>(&red[pg][cg * 4]) = sum;
+    __syncthreads();
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < PG; ++k) mean += *reinterpret_cast<f32x4*>(&red[k][cg * 4]);
+    mean *= 1.f / (float)cnt;
+    __syncthreads();
+    f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        int p = p0 + it * PG + pg;
+        if (p < a.M) { f32x4 d = vals[it] - mean; m2 += d * d; }
+    }
+    *reinterpret_cast<f32x4*>(&red[pg][cg * 4]) = m2;
+    __syncthreads();
+    if (pg == 0) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < PG; ++k) t += *reinterpret_cast<f32x4*>(&red[k][cg * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a.stat[(size_t)(cg * 4 + e) * a.nblk + blockIdx.x] = mean[e];
+            a.stat[(size_t)(a.Cout + cg * 4 + e) * a.nblk + blockIdx.x] = t[e];
+        }
+    }
+}
+
+// dx[q] = sum_t sum_co dy[o_t(q)][co] * w[co][t]   (Cin == 1), LPP = Cout/4 lanes per input pixel
+template <int LPP>
+__global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
+    const int T = a.kh * a.kw;
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int q = gt / LPP, cl = gt % LPP;
+    const int total = a.N * a.IH * a.IW;
+    float accv = 0.f;
+    if (q < total) {
+        int ix = q % a.IW; int r_ = q / a.IW; int iy = r_ % a.IH; int n = r_ / a.IH;
+        for (int t = 0; t < T; ++t) {
+            int r = t / a.kw, s = t % a.kw;
+            int ny = iy - tap_dy(a, r), nx = ix - tap_dx(a, s);
+            if (ny < 0 || nx < 0 || ny % a.sh != 0 || nx % a.sw != 0) continue;
+            int oy = ny / a.sh, ox = nx / a.sw;
+            if (oy >= a.OH || ox >= a.OW) continue;
+            f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.Cout + cl * 4);
+            accv += d[0] * a.w[(cl * 4 + 0) * T + t] + d[1] * a.w[(cl * 4 + 1) * T + t]
+                  + d[2] * a.w[(cl * 4 + 2) * T + t] + d[3] * a.w[(cl * 4 + 3) * T + t];
+        }
+    }
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) accv += __shfl_xor(accv, o, 64);
+    if (q < total && cl == 0) a.dx[q] = accv;
+}
+
+// ws[z][t][co] = sum over this block's pixels of dy[p][co] * x[p_t]   (Cin == 1)
+template <int CG>
+__global__ __launch_bounds__(256) void cin1_wgrad_kernel(const DirectArgs a, int pix_per_blk) {
+    constexpr int PG = 256 / CG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [PG][T][Cout]
+    const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
+    const int T = a.kh * a.kw;
+    f32x4 acc[VIAI_MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < VIAI_MAX_TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int p0 = blockIdx.x * pix_per_blk;
+    const int p1 = min(p0 + pix_per_blk, a.M);
+    for (int p = p0 + pg; p < p1; p += PG) {
+        int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
+        f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.Cout + cg * 4);
+        const float* xb = a.x + (size_t)n * a.IH * a.IW;
+#pragma unroll
+        for (int t = 0; t < VIAI_MAX_TAPS; ++t)
+            if (t < T) {
+                int iy = oy * a.sh + tap_dy(a, t / a.kw), ix = ox * a.sw + tap_dx(a, t % a.kw);
+                float xv = ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
+                acc[t] += d * xv;
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < VIAI_MAX_TAPS; ++t)
+        if (t < T) *reinterpret_cast<f32x4*>(smem + ((size_t)pg * T + t) * a.Cout + cg * 4) = acc[t];
+    __syncthreads();
+    for (int i = tid; i < T * a.Cout; i += 256) {
+        float s = 0.f;
+        for (int k = 0; k < PG; ++k) s += smem[(size_t)k * T * a.Cout + i];
+        a.ws[(size_t)blockIdx.x * T * a.Cout + i] = s;
+    }
+}
+
+// ------------------------------------------------------------------ Cout == 1 (stride 1)
+// y[p] = act(b + sum_t <x[p_t][:], wp[t][:]>),  LPP lanes per pixel, CPL float4 per lane per tap
+template <int LPP, int CPL>
+__global__ __launch_bounds__(256) void cout1_fwd_kernel(const DirectArgs a) {
+    const int T = a.kh * a.kw;
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int p = gt / LPP, cl = gt % LPP;
+    float accv = 0.f;
+    if (p < a.M) {
+        int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
+        for (int t = 0; t < T; ++t) {
+            int iy = oy + tap_dy(a, t / a.kw), ix = ox + tap_dx(a, t % a.kw);
+            if ((unsigned)iy >= (unsigned)a.IH || (unsigned)ix >= (unsigned)a.IW) continue;
+            const float* xr = a.x + ((size_t)(n * a.IH + iy) * a.IW + ix) * a.Cin;
+            const float* wr = a.w + (size_t)t * a.Cin;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                f32x4 xv = *reinterpret_cast<const f32x4*>(xr + (c * LPP + cl) * 4);
+                f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (c * LPP + cl) * 4);
+                accv += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) accv += __shfl_xor(accv, o, 64);
+    if (p < a.M && cl == 0) a.y[p] = viai_act(accv + (a.bias ? a.bias[0] : 0.f), a.act, a.slope);
+}
+
+// dx[q][ci] = sum_t dy[o_t(q)] * wp[t][ci]
+__global__ __launch_bounds__(256) void cout1_dgrad_kernel(const DirectArgs a) {
+    const int T = a.kh * a.kw;
+    const int c4n = a.Cin / 4;
+    const long total = (long)a.N * a.IH * a.IW * c4n;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int c4 = (int)(i % c4n);
+        int q = (int)(i / c4n);
+        int ix = q % a.IW; int r_ = q / a.IW; int iy = r_ % a.IH; int n = r_ / a.IH;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) {
+            int oy = iy - tap_dy(a, t / a.kw), ox = ix - tap_dx(a, t % a.kw);
+            if ((unsigned)oy >= (unsigned)a.OH || (unsigned)ox >= (unsigned)a.OW) continue;
+            float d = a.dy[(size_t)(n * a.OH + oy) * a.OW + ox];
+            v += d * *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.Cin + c4 * 4);
+        }
+        *reinterpret_cast<f32x4*>(a.dx + (size_t)q * a.Cin + c4 * 4) = v;
+    }
+}
+
+// ws[z][t][ci] = sum over this block's INPUT pixels q of x[q][ci] * dy[o_t(q)]
+__global__ __launch_bounds__(256) void cout1_wgrad_kernel(const DirectArgs a, int pix_per_blk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [PG][T][Cin]
+    const int T = a.kh * a.kw;
+    const int CG = a.Cin / 4;                 // <= 256
+    const int PG = 256 / CG;
+    const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
+    f32x4 acc[VIAI_MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < VIAI_MAX_TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int totq = a.N * a.IH * a.IW;
+    const int q0 = blockIdx.x * pix_per_blk;
+    const int q1 = min(q0 + pix_per_blk, totq);
+    if (pg < PG) {
+        for (int q = q0 + pg; q < q1; q += PG) {
+            int ix = q % a.IW; int r_ = q / a.IW; int iy = r_ % a.IH; int n = r_ / a.IH;
+            f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + (size_t)q * a.Cin + cg * 4);
+#pragma unroll
+            for (int t = 0; t < VIAI_MAX_TAPS; ++t)
+                if (t < T) {
+                    int oy = iy - tap_dy(a, t / a.kw), ox = ix - tap_dx(a, t % a.kw);
+                    float d = ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW)
+                                  ? a.dy[(size_t)(n * a.OH + oy) * a.OW + ox] : 0.f;
+                    acc[t] += xv * d;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < VIAI_MAX_TAPS; ++t)
+            if (t < T) *reinterpret_cast<f32x4*>(smem + ((size_t)pg * T + t) * a.Cin + cg * 4) = acc[t];
+    }
+    __syncthreads();
+    for (int i = tid; i < T * a.Cin; i += 256) {
+        float s = 0.f;
+        for (int k = 0; k < PG; ++k) s += smem[(size_t)k * T * a.Cin + i];
+        a.ws[(size_t)blockIdx.x * T * a.Cin + i] = s;
+    }
+}
+
+// dw[co*s_co + ci*s_ci + t] (+)= sum_z ws[z][t][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nz, int T,
+                                    int Cout, int Cin, long s_co, long s_ci, int accumulate) {
+    const long total = (long)T * Cout * Cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z) s += ws[(size_t)z * total + i];
+        int ci = (int)(i % Cin); long r = i / Cin; int co = (int)(r % Cout); int t = (int)(r / Cout);
+        long o = co * s_co + ci * s_ci + t;
+        dw[o] = accumulate ? dw[o] + s : s;
+    }
+}
+
+// out[c] (+)= sum_p x[p][c]; one block per channel-group sweep
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                          long M, int C, long rows_per_blk) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const long r0 = blockIdx.x * rows_per_blk;
+    long r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        // thread layout: tid -> (row lane, channel) so that consecutive tids read consecutive channels
+        int cw = min(256, C - c0);
+        int rl = 256 / cw;                // row lanes
+        int c = tid % cw, rr = tid / cw;
+        float s = 0.f;
+        if (rr < rl)
+            for (long r = r0 + rr; r < r1; r += rl) s += x[r * C + c0 + c];
+        red[tid] = (rr < rl) ? s : 0.f;
+        __syncthreads();
+        if (tid < cw) {
+            float t = 0.f;
+            for (int k = 0; k < rl; ++k) t += red[k * cw + tid];
+            part[(size_t)blockIdx.x * C + c0 + tid] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+DirectArgs make_args(const viai_conv2d* c) {
+    DirectArgs a{};
+    a.N = c->N; a.IH = c->IH; a.IW = c->IW; a.Cin = c->C1 + c->C2; a.Cout = c->Cout;
+    a.kh = c->kh; a.kw = c->kw; a.sh = c->sh; a.sw = c->sw; a.ph = c->ph; a.pw = c->pw;
+    a.transposed = c->transposed;
+    viai_conv2d_out_hw(c, &a.OH, &a.OW);
+    a.M = a.N * a.OH * a.OW;
+    return a;
+}
+
+}  // namespace
+
+// ---- entry points used by conv_api.hip ------------------------------------
+int viai_cin1_fwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, float* y,
+                  float* stat, int act, hipStream_t st) {
+    DirectArgs a = make_args(c);
+    if (c->kh * c->kw > VIAI_MAX_TAPS) return (int)hipErrorInvalidValue;
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.stat = stat; a.act = act; a.slope = 0.2f;
+    a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
+    if (c->Cout == 32) hipLaunchKernelGGL(cin1_fwd_kernel<8>, dim3(a.nblk), dim3(256), 0, st, a);
+    else if (c->Cout == 64) hipLaunchKernelGGL(cin1_fwd_kernel<16>, dim3(a.nblk), dim3(256), 0, st, a);
+    else if (c->Cout == 128) hipLaunchKernelGGL(cin1_fwd_kernel<32>, dim3(a.nblk), dim3(256), 0, st, a);
+    else return (int)hipErrorInvalidValue;
+    return viai_launch_status();
+}
+
+int viai_cin1_stat_geom(const viai_conv2d* c, int* nblk, int* rows) {
+    DirectArgs a = make_args(c);
+    *nblk = (a.M + CIN1_PB - 1) / CIN1_PB; *rows = CIN1_PB;
+    return 0;
+}
+
+int viai_cin1_dgrad(const viai_conv2d* c, const float* dy, const float* w, float* dx, hipStream_t st) {
+    DirectArgs a = make_args(c);
+    a.dy = dy; a.w = w; a.dx = dx;
+    long tot = (long)a.N * a.IH * a.IW;
+    int lpp = c->Cout / 4;
+    long threads = tot * lpp;
+    int blocks = (int)((threads + 255) / 256);
+    if (lpp == 8) hipLaunchKernelGGL(cin1_dgrad_kernel<8>, dim3(blocks), dim3(256), 0, st, a);
+    else if (lpp == 16) hipLaunchKernelGGL(cin1_dgrad_kernel<16>, dim3(blocks), dim3(256), 0, st, a);
+    else if (lpp == 32) hipLaunchKernelGGL(cin1_dgrad_kernel<32>, dim3(blocks), dim3(256), 0, st, a);
+    else return (int)hipErrorInvalidValue;
+    return viai_launch_status();
+}
+
+static int direct_wgrad_blocks(long pixels) {
+    long b = (pixels + 1023) / 1024;
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int viai_wgrad_reduce(const float* ws, float* dw, int nz, int T, int Cout, int Cin, long s_co, long s_ci,
+                      int accumulate, hipStream_t st) {
+    long total = (long)T * Cout * Cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, nz, T, Cout, Cin, s_co, s_ci, accumulate);
+    return viai_launch_status();
+}
+
+size_t viai_cin1_wgrad_ws_floats(const viai_conv2d* c) {
+    DirectArgs a = make_args(c);
+    return (size_t)direct_wgrad_blocks(a.M) * c->kh * c->kw * c->Cout;
+}
+
+int viai_cin1_wgrad(const viai_conv2d* c, const float* x, const float* dy, float* ws, float* dw, int accumulate, hipStream_t st) {
+    DirectArgs a = make_args(c);
+    a.x = x; a.dy = dy; a.ws = ws;
+    const int T = c->kh * c->kw;
+    int nb = direct_wgrad_blocks(a.M);
+    int ppb = (a.M + nb - 1) / nb;
+    int cg = c->Cout / 4;
+    size_t lds = (size_t)(256 / cg) * T * c->Cout * sizeof(float);
+    if (cg == 8) hipLaunchKernelGGL(cin1_wgrad_kernel<8>, dim3(nb), dim3(256), lds, st, a, ppb);
+    else if (cg == 16) hipLaunchKernelGGL(cin1_wgrad_kernel<16>, dim3(nb), dim3(256), lds, st, a, ppb);
+    else if (cg == 32) hipLaunchKernelGGL(cin1_wgrad_kernel<32>, dim3(nb), dim3(256), lds, st, a, ppb);
+    else return (int)hipErrorInvalidValue;
+    int e = viai_launch_status();
+    if (e) return e;
+    // torch layout [Cout][1][kh][kw] -> co*T + t
+    return viai_wgrad_reduce(ws, dw, nb, T, c->Cout, 1, T, T, accumulate, st);
+}
+
+int viai_cout1_fwd(const viai_conv2d* c, const float* x, const float* wp, const float* bias, float* y, int act, hipStream_t st) {
+    if (c->sh != 1 || c->sw != 1 || c->C2 != 0) return (int)hipErrorInvalidValue;
+    DirectArgs a = make_args(c);
+    a.x = x; a.w = wp; a.bias = bias; a.y = y; a.act = act; a.slope = 0.2f;
+    const int cin = a.Cin;
+    if (cin == 32) { int blocks = (int)(((long)a.M * 8 + 255) / 256); hipLaunchKernelGGL((cout1_fwd_kernel<8, 1>), dim3(blocks), dim3(256), 0, st, a); }
+    else if (cin == 64) { int blocks = (int)(((long)a.M * 16 + 255) / 256); hipLaunchKernelGGL((cout1_fwd_kernel<16, 1>), dim3(blocks), dim3(256), 0, st, a); }
+    else if (cin == 128) { int blocks = (int)(((long)a.M * 32 + 255) / 256); hipLaunchKernelGGL((cout1_fwd_kernel<32, 1>), dim3(blocks), dim3(256), 0, st, a); }
+    else if (cin == 256) { int blocks = (int)(((long)a.M * 64 + 255) / 256); hipLaunchKernelGGL((cout1_fwd_kernel<64, 1>), dim3(blocks), dim3(256), 0, st, a); }
+    else if (cin == 512) { int blocks = (int)(((long)a.M * 64 + 255) / 256); hipLaunchKernelGGL((cout1_fwd_kernel<64, 2>), dim3(blocks), dim3(256), 0, st, a); }
+    else return (int)hipErrorInvalidValue;
+    return viai_launch_status();
+}
+
+int viai_cout1_dgrad(const viai_conv2d* c, const float* dy, const float* wp, float* dx, hipStream_t st) {
+    if (c->sh != 1 || c->sw != 1 || c->C2 != 0 || (c->C1 % 4) != 0) return (int)hipErrorInvalidValue;
+    DirectArgs a = make_args(c);
+    a.dy = dy; a.w = wp; a.dx = dx;
+    long total = (long)a.N * a.IH * a.IW * (a.Cin / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(cout1_dgrad_kernel, dim3(blocks), dim3(256), 0, st, a);
+    return viai_launch_status();
+}
+
+size_t viai_cout1_wgrad_ws_floats(const viai_conv2d* c) {
+    long q = (long)c->N * c->IH * c->IW;
+    return (size_t)direct_wgrad_blocks(q) * c->kh * c->kw * (c->C1 + c->C2);
+}
+
+int viai_cout1_wgrad(const viai_conv2d* c, const float* x, const float* dy, float* ws, float* dw, int accumulate, hipStream_t st) {
+    if (c->sh != 1 || c->sw != 1 || c->C2 != 0) return (int)hipErrorInvalidValue;
+    DirectArgs a = make_args(c);
+    if (a.Cin % 4 != 0 || a.Cin / 4 > 256 || 256 % (a.Cin / 4) != 0) return (int)hipErrorInvalidValue;
+    a.x = x; a.dy = dy; a.ws = ws;
+    const int T = c->kh * c->kw;
+    long q = (long)a.N * a.IH * a.IW;
+    int nb = direct_wgrad_blocks(q);
+    int ppb = (int)((q + nb - 1) / nb);
+    int pg = 256 / (a.Cin / 4);
+    size_t lds = (size_t)pg * T * a.Cin * sizeof(float);
+    hipLaunchKernelGGL(cout1_wgrad_kernel, dim3(nb), dim3(256), lds, st, a, ppb);
+    int e = viai_launch_status();
+    if (e) return e;
+    // conv [1][Cin][kh][kw] and convT [Cin][1][kh][kw] both flatten to ci*T + t
+    return viai_wgrad_reduce(ws, dw, nb, T, 1, a.Cin, (long)a.Cin * T, T, accumulate, st);
+}
+
+extern "C" int viai_colsum_blocks(long M, int C) {
+    (void)C;
+    long b = (M + 2047) / 2048;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int viai_colsum(const float* x, long M, int C, float* part, float* out, int accumulate, void* stream) {
+    int nb = viai_colsum_blocks(M, C);
+    long rpb = (M + nb - 1) / nb;
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, part, M, C, rpb);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, out, nb, C, accumulate);
+    return viai_launch_status();
+}

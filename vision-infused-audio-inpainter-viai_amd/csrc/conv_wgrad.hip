@@ -1,0 +1,237 @@
+// Weight gradient of the conv family on fp32 MFMA (gfx950).
+//
+//   G[t][co][ci] = sum over output pixels p of  dy[p][co] * x[p_t][ci]
+// (p_t = the input pixel tap t reads for output pixel p; forward geometry).
+// GEMM view per tap: M = Cout, N = Cin, K = output pixels (huge) -> split-K over
+// the grid; each block writes a partial slab, wgrad_reduce sums the slabs in a
+// fixed order (deterministic) straight into the torch weight layout.
+//
+// Both operands are "pixel-major" in memory (NHWC rows), which is exactly the
+// k-major image v_mfma_f32_32x32x2_f32 wants: lane (i = l&31, k = l>>5) reads
+// LDS[k][i] -- 32 consecutive floats per half-wave, conflict-free ds_read_b32.
+// Reference call sites: the autograd backward of every nn.Conv2d /
+// nn.ConvTranspose2d listed in include/viai_hip.h.
+#include "viai_common.h"
+#include "viai_internal.h"
+
+namespace {
+
+constexpr int BKP = 32;   // pixels per staged chunk
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
+    constexpr int BM = 32 * TM * WM;       // Cout tile
+    constexpr int BN = 32 * TN * WN;       // Cin tile
+    constexpr int WK = 4 / (WM * WN);      // waves splitting the pixel chunk
+    constexpr int QA = BM / 4, QB = BN / 4;               // float4 per staged row
+    constexpr int NA = (BKP * QA) / 256, NB = (BKP * QB) / 256;   // float4 per thread
+    static_assert((BKP * QA) % 256 == 0 && (BKP * QB) % 256 == 0, "staging");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ds = smem;                       // [2][BKP][BM]
+    float* Xs = smem + 2 * BKP * BM;        // [2][BKP][BN]
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave / (WM * WN);
+    const int wmn = wave % (WM * WN);
+    const int wm = wmn / WN, wn = wmn % WN;
+
+    int b = blockIdx.x;
+    const int bci = b % a.nblk_ci; b /= a.nblk_ci;
+    const int bco = b % a.nblk_co; b /= a.nblk_co;
+    const int t = b;                        // tap index of this block
+    const int z = blockIdx.y;
+    const int co0 = bco * BM, ci0 = bci * BN;
+    const int Cin = a.C1 + a.C2;
+
+    const float* xsrc; int xcs, xoff;
+    if (ci0 < a.C1) { xsrc = a.x; xcs = a.C1; xoff = ci0; }
+    else { xsrc = a.x2; xcs = a.C2; xoff = ci0 - a.C1; }
+    const int dyt = g.dy[t], dxt = g.dx[t];
+
+    const int chunk0 = z * a.chunks_per_split;
+    const int nchunks_total = (a.M + BKP - 1) / BKP;
+    int chunk1 = chunk0 + a.chunks_per_split;
+    if (chunk1 > nchunks_total) chunk1 = nchunks_total;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 dreg[NA], xreg[NB];
+    auto gload = [&](int chunk) {
+        const int p0 = chunk * BKP;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            int idx = tid + 256 * j;
+            int row = idx / QA, c4 = idx % QA;
+            int p = p0 + row;
+            int co = co0 + c4 * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < a.M && co < a.Cout) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.Cout + co);
+            dreg[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int idx = tid + 256 * j;
+            int row = idx / QB, c4 = idx % QB;
+            int p = p0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < a.M) {
+                int ox = p % g.OW; int r = p / g.OW; int oy = r % g.OH; int n = r / g.OH;
+                int iy = oy * g.my + dyt, ix = ox * g.mx + dxt;
+                int ci = ci0 + c4 * 4;
+                if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW && ci < Cin)
+                    v = *reinterpret_cast<const f32x4*>(xsrc + ((size_t)(n * g.IH + iy) * g.IW + ix) * xcs + xoff + c4 * 4);
+            }
+            xreg[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            int idx = tid + 256 * j;
+            *reinterpret_cast<f32x4*>(Ds + buf * BKP * BM + idx * 4) = dreg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int idx = tid + 256 * j;
+            *reinterpret_cast<f32x4*>(Xs + buf * BKP * BN + idx * 4) = xreg[j];
+        }
+    };
+
+    if (chunk0 < chunk1) {
+        gload(chunk0);
+        lstore(0);
+    }
+    __syncthreads();
+    const int half = lane >> 5, col = lane & 31;
+    for (int c = chunk0; c < chunk1; ++c) {
+        const int cur = (c - chunk0) & 1;
+        const bool more = (c + 1 < chunk1);
+        if (more) gload(c + 1);
+        const float* Db = Ds + cur * BKP * BM + wm * TM * 32 + col;
+        const float* Xb = Xs + cur * BKP * BN + wn * TN * 32 + col;
+#pragma unroll
+        for (int s = 0; s < BKP / 2 / WK; ++s) {
+            const int p = 2 * (s * WK + wk) + half;
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Db[p * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Xb[p * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // cross-wave reduction of the K-split (WK > 1), through LDS
+    if (WK > 1) {
+        float* red = smem;      // [WK-1][WM*WN][TM*TN*16][64]
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        red[(((wk - 1) * (WM * WN) + wmn) * (TM * TN * 16) + (i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int w = 1; w < WK; ++w)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            acc[i][j][e] += red[(((w - 1) * (WM * WN) + wmn) * (TM * TN * 16) + (i * TN + j) * 16 + e) * 64 + lane];
+        }
+    }
+    if (wk == 0) {
+        float* dst = a.ws + ((size_t)z * g.wtaps + g.ws[t]) * a.Cout * Cin;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int ci = ci0 + (wn * TN + j) * 32 + col;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    int co = co0 + (wm * TM + i) * 32 + row;
+                    if (co < a.Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[i][j][e];
+                }
+            }
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_wgrad(WgradArgs& a, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, WK = 4 / (WM * WN);
+    const int Cin = a.C1 + a.C2;
+    a.nblk_co = (a.Cout + BM - 1) / BM;
+    a.nblk_ci = (Cin + BN - 1) / BN;
+    size_t lds = (size_t)2 * BKP * (BM + BN) * sizeof(float);
+    size_t red = (size_t)(WK - 1) * (WM * WN) * (TM * TN * 16) * 64 * sizeof(float);
+    if (red > lds) lds = red;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<TM, TN, WM, WN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid(a.nblk_co * a.nblk_ci * a.g.ntaps, a.ksplit);
+    hipLaunchKernelGGL((wgrad_mfma_kernel<TM, TN, WM, WN>), grid, dim3(256), lds, st, a);
+    return viai_launch_status();
+}
+
+}  // namespace
+
+static inline int tile_of(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
+
+int viai_wgrad_pick_ksplit(int Cout, int Cin, int ntaps, long M) {
+    int bm = tile_of(Cout), bn = tile_of(Cin);
+    long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * ntaps;
+    long chunks = (M + BKP - 1) / BKP;
+    long ks = (1024 + tiles - 1) / tiles;          // aim for ~4 blocks per CU
+    long maxks = chunks / 8; if (maxks < 1) maxks = 1;  // at least 8 chunks (256 pixels) per block
+    if (ks > maxks) ks = maxks;
+    if (ks > 512) ks = 512;
+    if (ks < 1) ks = 1;
+    return (int)ks;
+}
+
+int viai_wgrad_mfma_launch(WgradArgs& a, int ksplit, hipStream_t st) {
+    const int Cin = a.C1 + a.C2;
+    if (Cin % 4 != 0 || a.Cout % 4 != 0) return (int)hipErrorInvalidValue;
+    long chunks = ((long)a.M + BKP - 1) / BKP;
+    a.ksplit = ksplit;
+    a.chunks_per_split = (int)((chunks + ksplit - 1) / ksplit);
+    int bm = tile_of(a.Cout), bn = tile_of(Cin);
+    if (a.C2 > 0) {                       // a Cin tile must not straddle the two concatenated sources
+        while (bn > 32 && (a.C1 % bn) != 0) bn >>= 1;
+        if ((a.C1 % bn) != 0) return (int)hipErrorInvalidValue;
+    }
+    if (bm == 128 && bn == 128) return launch_wgrad<2, 2, 2, 2>(a, st);
+    if (bm == 128 && bn == 64) return launch_wgrad<2, 1, 2, 2>(a, st);
+    if (bm == 128 && bn == 32) return launch_wgrad<2, 1, 2, 1>(a, st);   // 128 x 32, WK = 2
+    if (bm == 64 && bn == 128) return launch_wgrad<1, 2, 2, 2>(a, st);
+    if (bm == 64 && bn == 64) return launch_wgrad<1, 1, 2, 2>(a, st);
+    if (bm == 64 && bn == 32) return launch_wgrad<1, 1, 2, 1>(a, st);    // WK = 2
+    if (bm == 32 && bn == 128) return launch_wgrad<1, 2, 1, 2>(a, st);   // WK = 2
+    if (bm == 32 && bn == 64) return launch_wgrad<1, 1, 1, 2>(a, st);    // WK = 2
+    return launch_wgrad<1, 1, 1, 1>(a, st);                               // 32 x 32, WK = 4
+}

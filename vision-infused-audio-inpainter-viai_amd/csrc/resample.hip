@@ -1,0 +1,155 @@
+// Bilinear (align_corners=True) resize and the bottleneck (k,1) average pool on
+// NHWC fp32 (gfx950); pure HBM streaming, 16-byte channel vectors per lane.
+// Reference call sites: New_Inpainting_Networks.py:78,83 (F.interpolate),
+// Inpainting_Networks.py:65,77 (nn.AvgPool2d((3,1)), floor mode).
+#include "viai_common.h"
+#include "viai_internal.h"
+
+namespace {
+
+// torch's area_pixel_compute_scale<float>(in, out, align_corners=true)
+__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+__device__ __forceinline__ void ac_src(float scale, int dst, int in, int& i0, int& i1, float& l0, float& l1) {
+    float src = scale * (float)dst;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int N, int IH, int IW, int OH, int OW, int C) {
+    const int c4n = C / 4;
+    const long total = (long)N * OH * OW * c4n;
+    const float sh = ac_scale(IH, OH), sw = ac_scale(IW, OW);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int c4 = (int)(i % c4n); long r = i / c4n;
+        int ox = (int)(r % OW); r /= OW;
+        int oy = (int)(r % OH); int n = (int)(r / OH);
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        ac_src(sh, oy, IH, y0, y1, ly0, ly1);
+        ac_src(sw, ox, IW, x0, x1, lx0, lx1);
+        const float* b = x + (size_t)n * IH * IW * C + c4 * 4;
+        f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * IW + x0) * C);
+        f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * IW + x1) * C);
+        f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * IW + x0) * C);
+        f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * IW + x1) * C);
+        f32x4 o = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = o;
+    }
+}
+
+// gather form of the backward: every input pixel sums the output pixels that
+// read it (deterministic, no atomics).  Candidates are bounded conservatively
+// and accepted by re-evaluating the forward index computation bit-for-bit.
+__device__ __forceinline__ void cand_range(float scale, int i, int out, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+    float inv = 1.f / scale;
+    lo = (int)floorf(((float)i - 1.f) * inv) - 1;
+    hi = (int)ceilf(((float)i + 1.f) * inv) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                           int N, int IH, int IW, int OH, int OW, int C) {
+    const int c4n = C / 4;
+    const long total = (long)N * IH * IW * c4n;
+    const float sh = ac_scale(IH, OH), sw = ac_scale(IW, OW);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int c4 = (int)(i % c4n); long r = i / c4n;
+        int ix = (int)(r % IW); r /= IW;
+        int iy = (int)(r % IH); int n = (int)(r / IH);
+        int ylo, yhi, xlo, xhi;
+        cand_range(sh, iy, OH, ylo, yhi);
+        cand_range(sw, ix, OW, xlo, xhi);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* b = dy + (size_t)n * OH * OW * C + c4 * 4;
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            int y0, y1; float l0, l1;
+            ac_src(sh, oy, IH, y0, y1, l0, l1);
+            float wy = (y0 == iy ? l0 : 0.f) + (y1 == iy ? l1 : 0.f);
+            if (y0 != iy && y1 != iy) continue;
+            f32x4 rowacc = {0.f, 0.f, 0.f, 0.f};
+            for (int ox = xlo; ox <= xhi; ++ox) {
+                int x0, x1; float m0, m1;
+                ac_src(sw, ox, IW, x0, x1, m0, m1);
+                if (x0 != ix && x1 != ix) continue;
+                float wx = (x0 == ix ? m0 : 0.f) + (x1 == ix ? m1 : 0.f);
+                rowacc += wx * *reinterpret_cast<const f32x4*>(b + ((size_t)oy * OW + ox) * C);
+            }
+            acc += wy * rowacc;
+        }
+        *reinterpret_cast<f32x4*>(dx + (size_t)i * 4) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_h_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int N, int IH, int W, int C, int k) {
+    const int OH = IH / k, c4n = C / 4;
+    const long total = (long)N * OH * W * c4n;
+    const float inv = 1.f / (float)k;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        long rowlen = (long)W * c4n;
+        long r = i / rowlen, off = i % rowlen;
+        int oh = (int)(r % OH); int n = (int)(r / OH);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < k; ++j)
+            s += *reinterpret_cast<const f32x4*>(x + (((size_t)n * IH + oh * k + j) * rowlen + off) * 4);
+        *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = s * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_h_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                            int N, int IH, int W, int C, int k) {
+    const int OH = IH / k, c4n = C / 4;
+    const long total = (long)N * IH * W * c4n;
+    const float inv = 1.f / (float)k;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        long rowlen = (long)W * c4n;
+        long r = i / rowlen, off = i % rowlen;
+        int ih = (int)(r % IH); int n = (int)(r / IH);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ih < OH * k) v = inv * *reinterpret_cast<const f32x4*>(dy + (((size_t)n * OH + ih / k) * rowlen + off) * 4);
+        *reinterpret_cast<f32x4*>(dx + (size_t)i * 4) = v;
+    }
+}
+
+inline int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int viai_bilinear_ac_fwd(const float* x, float* y, int N, int IH, int IW, int OH, int OW, int C, void* stream) {
+    if (C % 4 != 0 || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return (int)hipErrorInvalidValue;
+    long total = (long)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, IH, IW, OH, OW, C);
+    return viai_launch_status();
+}
+
+extern "C" int viai_bilinear_ac_bwd(const float* dy, float* dx, int N, int IH, int IW, int OH, int OW, int C, void* stream) {
+    if (C % 4 != 0 || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return (int)hipErrorInvalidValue;
+    long total = (long)N * IH * IW * (C / 4);
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, IH, IW, OH, OW, C);
+    return viai_launch_status();
+}
+
+extern "C" int viai_avgpool_h_fwd(const float* x, float* y, int N, int IH, int W, int C, int k, void* stream) {
+    if (C % 4 != 0 || k <= 0 || IH / k <= 0) return (int)hipErrorInvalidValue;
+    long total = (long)N * (IH / k) * W * (C / 4);
+    hipLaunchKernelGGL(avgpool_h_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, IH, W, C, k);
+    return viai_launch_status();
+}
+
+extern "C" int viai_avgpool_h_bwd(const float* dy, float* dx, int N, int IH, int W, int C, int k, void* stream) {
+    if (C % 4 != 0 || k <= 0 || IH / k <= 0) return (int)hipErrorInvalidValue;
+    long total = (long)N * IH * W * (C / 4);
+    hipLaunchKernelGGL(avgpool_h_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, IH, W, C, k);
+    return viai_launch_status();
+}

@@ -1,0 +1,64 @@
+// Shared device/host helpers for the VIAI gfx950 kernels.
+// All activations are NHWC fp32 ([N][H][W][C], C contiguous); see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VIAI_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#include "../../include/viai_hip.h"   // activation codes, ABI structs
+
+#define VIAI_MAX_TAPS 16
+
+// Convolution-like gather described by a tap table.  One launch computes the
+// output pixels of one sub-lattice:  out(y, x) = (oy*ly + ay, ox*lx + ax),
+// oy < SH, ox < SW, reading in(oy*my + dy[t], ox*mx + dx[t]) for every tap t.
+//   forward Conv2d stride s, pad p      : l=1 a=0 m=s  d[t] = r - p
+//   forward ConvTranspose2d stride 1    : l=1 a=0 m=1  d[t] = p - r
+//   dgrad of Conv2d, parity class a     : l=s a=a m=1  d[t] = (a + p - r)/s, r = (a+p) mod s ...
+//   dgrad of ConvTranspose2d stride 1   : l=1 a=0 m=1  d[t] = r - p
+struct ConvGeom {
+    int N, IH, IW;        // gathered tensor
+    int OH, OW;           // full extent of the produced tensor
+    int SH, SW;           // sub-lattice extent of this launch
+    int ly, lx, ay, ax;
+    int my, mx;
+    int ntaps;            // taps used by this launch
+    int wtaps;            // tap slots per packed-weight row
+    signed char dy[VIAI_MAX_TAPS], dx[VIAI_MAX_TAPS], ws[VIAI_MAX_TAPS];
+};
+
+__device__ __forceinline__ float viai_act(float v, int act, float slope) {
+    if (act == VIAI_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == VIAI_ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == VIAI_ACT_SIGMOID) return 1.f / (1.f + expf(-v));   // accurate exp: BCE divides by p(1-p)
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: consecutive logical tiles
+// land on the same XCD (block b is observed to run on XCD b % 8), so
+// neighbouring tiles share that XCD's L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int q = nwg / nx, r = nwg % nx;
+    int xcd = bid % nx, idx = bid / nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static inline int viai_launch_status() { return (int)hipGetLastError(); }

@@ -1,0 +1,37 @@
+// Internal (non-ABI) declarations shared between the kernel translation units.
+#pragma once
+#include "viai_common.h"
+#include "../../include/viai_hip.h"
+
+struct ConvArgs {
+    const float* in;      // gathered NHWC tensor, channels [0, C1)
+    const float* in2;     // optional second source, channels [C1, C1+C2) (virtual concat)
+    const float* wp;      // packed weights [Cout][wtaps][C1+C2]
+    const float* bias;    // [Cout] or null
+    float* out;           // NHWC, channels [0, OC1)
+    float* out2;          // optional second destination, channels [OC1, Cout)
+    float* stat;          // optional BN partials [2][Cout][nblk_m]
+    int C1, C2, Cout, OC1;
+    int M, nblk_m, nblk_n;
+    int act;              // fused activation (only when stat == null)
+    float slope;
+    ConvGeom g;
+};
+
+struct WgradArgs {
+    const float* x; const float* x2;   // forward input (virtual concat C1 + C2)
+    const float* dy;                   // [M][Cout]
+    float* ws;                         // [ksplit][wtaps][Cout][Cin]
+    int C1, C2, Cout;
+    int M;
+    int nblk_co, nblk_ci, ksplit, chunks_per_split;
+    ConvGeom g;                        // forward geometry (ly = lx = 1)
+};
+
+int viai_conv_igemm_launch(ConvArgs& a, hipStream_t st);
+int viai_wgrad_mfma_launch(WgradArgs& a, int ksplit, hipStream_t st);
+int viai_wgrad_pick_ksplit(int Cout, int Cin, int ntaps, long M);
+
+// geometry builders (conv_api.hip)
+void viai_geom_fwd(const viai_conv2d* c, ConvGeom* g);
+int viai_geom_dgrad_class(const viai_conv2d* c, int a, int b, ConvGeom* g);   // returns ntaps

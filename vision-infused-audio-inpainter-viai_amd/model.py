@@ -1,0 +1,402 @@
+"""AudioModel — the G+D train step of the inpainting GAN on the HIP kernels.
+
+The reference's `Models/Whole_Sync_inpainting_modify.AudioModel` is ABSENT from
+the snapshot; its interface is pinned only by the call sites in
+train_whole_sync.py:49-112,159-183 and utils/util.py:146-173.  This class
+implements that interface; the step itself follows the pix2pix ordering the
+reference credits (README.md:39) and is the build's declared spec:
+
+    s_in  = s * mask
+    fake  = Mel_Decoder(Mel_Encoder(s_in), s.size())
+    D:  loss_D = 0.5*[GAN(netD(fake.detach()), False) + GAN(netD(s), True)] -> Adam(D)
+    G:  loss_G = GAN(netD(fake), True) + lambda_L1 * L1(fake, s)            -> Adam(E, G)
+
+Memory layout: all parameters of an optimizer live in ONE flat fp32 arena (and
+their gradients / Adam moments in three more), so the optimizer is a single
+streaming kernel and data-parallel gradient exchange is one RCCL all-reduce per
+optimizer with no packing copies.  The whole step can be captured into HIP
+graphs (three segments, split at the two all-reduce points).
+"""
+from __future__ import annotations
+
+import math
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .networks import MelDecoder, MelDiscriminator, MelEncoder, to_nchw_view
+
+
+class StepConfig:
+    lr = 2e-4
+    beta1 = 0.5
+    beta2 = 0.999
+    eps = 1e-8
+    lambda_l1 = 100.0
+    use_lsgan = False
+    batch_size = 16
+    cin_channels = 256          # mel bins F
+    max_mel_lengths = 256       # frames T
+    name = "viai"
+    save_optimizer_state = True
+
+
+class FlatArena:
+    """Moves the parameters of `modules` into one contiguous fp32 buffer (views
+    keep every nn.Parameter usable as before) and gives them gradient views of a
+    second buffer, so `.grad` accumulation lands in the arena."""
+
+    ALIGN = 64
+
+    def __init__(self, named_params):
+        self.names, self.params, self.offsets = [], [], []
+        off = 0
+        for name, p in named_params:
+            self.names.append(name)
+            self.params.append(p)
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.size = off
+        dev = self.params[0].device
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):      # re-attach in case something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (no amsgrad / weight decay) as one HIP kernel over a FlatArena.
+    The step counter and bias corrections live on the device (graph-replayable)."""
+
+    def __init__(self, arena: FlatArena, lr, betas, eps):
+        self.arena = arena
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.exp_avg = torch.zeros_like(arena.flat)
+        self.exp_avg_sq = torch.zeros_like(arena.flat)
+        self.state = torch.tensor([0.0, self.lr, 1.0, 1.0], dtype=torch.float64, device=arena.flat.device)
+
+    def zero_grad(self):
+        self.arena.zero_grad()
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+        self.state[1] = self.lr
+
+    def step(self, grad_scale=1.0):
+        ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.state,
+                      self.betas[0], self.betas[1], self.eps, grad_scale)
+
+    # torch.optim.Adam-compatible (de)serialisation so utils/util.py:149-150 style checkpoints interchange
+    def state_dict(self):
+        step = float(self.state[0].item())
+        st = {}
+        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+            n = p.numel()
+            st[i] = {"step": torch.tensor(step), "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
+                     "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(self.arena.params)))}
+        return {"state": st, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        step = 0.0
+        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+            s = sd["state"].get(i)
+            if s is None:
+                continue
+            n = p.numel()
+            self.exp_avg[o:o + n].copy_(s["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(s["exp_avg_sq"].reshape(-1))
+            step = max(step, float(s["step"]))
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = float(g["lr"]), tuple(g["betas"]), float(g["eps"])
+        self.state.copy_(torch.tensor([step, self.lr, self.betas[0] ** step, self.betas[1] ** step], dtype=torch.float64))
+
+
+def make_time_mask(batch, frames, blank_length, generator=None, device="cpu"):
+    """One full-height time gap [t0, t0+L) per clip (misc/pipeline2.png); t0 ~ U{T/8 .. 5T/8}."""
+    lo, hi = frames // 8, (5 * frames) // 8
+    t0 = torch.randint(lo, hi + 1, (batch,), generator=generator)
+    t0 = torch.clamp(t0, max=frames - blank_length)
+    ar = torch.arange(frames)[None, :]
+    m = ((ar < t0[:, None]) | (ar >= t0[:, None] + blank_length)).float()
+    return m.view(batch, 1, 1, frames).to(device)
+
+
+class AudioModel:
+    """Interface inferred from train_whole_sync.py:49,50,68,75-85,91-112,145,159-183."""
+
+    def __init__(self, hparams=None, device=None, process_group=None, use_graph=False):
+        self.hparams = hparams if hparams is not None else StepConfig()
+        hp = self.hparams
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        if self.device.type != "cuda":
+            raise RuntimeError("AudioModel runs on an MI355X (HIP kernels); there is no CPU path")
+        self.Mel_Encoder = MelEncoder(hp).to(self.device)
+        self.Mel_Decoder = MelDecoder(hp).to(self.device)
+        self.netD = MelDiscriminator().to(self.device)
+        self.VideoEncoder = None
+        self.cfg = StepConfig()
+        for k in ("lr", "beta1", "beta2", "eps", "lambda_l1", "use_lsgan"):
+            if hasattr(hp, k):
+                setattr(self.cfg, k, getattr(hp, k))
+        self._build_optimizers()
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.train = 1
+        self.update_wavenet = False
+        self.blank_length = max(getattr(hp, "max_mel_lengths", 256) // 4, 1)
+        self.current_lr = self.cfg.lr
+        self.reconstruct_loss_item = 0.0
+        self.EmbeddingL2_item = 0.0
+        self.loss_mel_L1_item = 0.0
+        self.mel_net_norm = None
+        self.video_net_norm = None
+        self.losses = torch.zeros(5, device=self.device)      # loss_D, loss_G, loss_G_GAN, loss_L1, loss_D_real
+        self.mel = self.mask = self.fake = None
+        self.use_graph = bool(use_graph)
+        self._graphs = None
+
+    # ------------------------------------------------------------------ setup
+    def _build_optimizers(self):
+        c = self.cfg
+        g_named = [("E." + n, p) for n, p in self.Mel_Encoder.named_parameters()] + \
+                  [("G." + n, p) for n, p in self.Mel_Decoder.named_parameters()]
+        d_named = [("D." + n, p) for n, p in self.netD.named_parameters()]
+        self.arena_G = FlatArena(g_named)
+        self.arena_D = FlatArena(d_named)
+        self.optimizer_G = FusedAdam(self.arena_G, c.lr, (c.beta1, c.beta2), c.eps)
+        self.optimizer_D = FusedAdam(self.arena_D, c.lr, (c.beta1, c.beta2), c.eps)
+
+    def load_states(self, E=None, G=None, D=None):
+        """load state_dicts (e.g. the oracle's closed-form tables) without breaking the arenas."""
+        for mod, sd in ((self.Mel_Encoder, E), (self.Mel_Decoder, G), (self.netD, D)):
+            if sd is None:
+                continue
+            own = mod.state_dict()
+            for k, v in sd.items():
+                own[k].copy_(v.to(own[k].device))
+
+    # ------------------------------------------------------------- step pieces
+    def get_blank_space_length(self, global_step):
+        """mask-length curriculum hook (train_whole_sync.py:49); the policy is unpinned -> fixed T/4."""
+        T = self.mel.shape[-1] if self.mel is not None else getattr(self.hparams, "max_mel_lengths", 256)
+        self.blank_length = max(T // 4, 1)
+        return self.blank_length
+
+    def set_inputs(self, data, mask=None):
+        """data: the loader's 8-tuple (audio_loader.py:532; mel `c` is element 2, (B,C,T)) or a mel tensor
+        (B,F,T)/(B,1,F,T) in [0,1].  Copies into static device buffers (graph-replay safe)."""
+        mel = data[2] if isinstance(data, (tuple, list)) else data
+        if mel.dim() == 3:
+            mel = mel.unsqueeze(1)
+        mel = mel.to(self.device, dtype=torch.float32, non_blocking=True)
+        B, _, F, T = mel.shape
+        if mask is None:
+            mask = make_time_mask(B, T, min(self.blank_length, T), device=self.device)
+        mask = mask.to(self.device, dtype=torch.float32).reshape(B, 1, 1, T)
+        if self.mel is None or self.mel.shape != mel.shape:
+            self.mel = torch.empty_like(mel)
+            self.mask = torch.empty_like(mask)
+            self._graphs = None
+        self.mel.copy_(mel)
+        self.mask.copy_(mask)
+
+    def _gan(self, pred, real):
+        t = 1.0 if real else 0.0
+        return ops.mse_mean(pred, t) if self.cfg.use_lsgan else ops.bce_mean(pred, t)
+
+    def _seg_forward_dstep(self):
+        s = self.mel
+        B, _, F, T = s.shape
+        s_nhwc = s.view(B, F, T, 1)
+        self.optimizer_D.zero_grad()
+        self.optimizer_G.zero_grad()
+        s_in = ops.mask_mul(s_nhwc, self.mask)
+        feats = self.Mel_Encoder.forward_nhwc(s_in.view(B, F, T))
+        fake = self.Mel_Decoder.forward_nhwc(feats, (F, T))            # (B,F,T,1)
+        self._fake = fake
+        self.fake = to_nchw_view(fake)
+        self.netD.requires_grad_(True)
+        pred_fake = self.netD.forward_nhwc(fake.detach())
+        pred_real = self.netD.forward_nhwc(s_nhwc)
+        loss_fake, loss_real = self._gan(pred_fake, False), self._gan(pred_real, True)
+        loss_d = 0.5 * (loss_fake + loss_real)
+        loss_d.backward()
+        self.losses[0].copy_(loss_d.detach())
+        self.losses[4].copy_(loss_real.detach())
+
+    def _seg_dupdate_gstep(self, update=True):
+        if update:
+            self.optimizer_D.step(1.0 / self.world)
+        s = self.mel
+        B, _, F, T = s.shape
+        self.netD.requires_grad_(False)
+        pred = self.netD.forward_nhwc(self._fake)
+        loss_gan = self._gan(pred, True)
+        loss_l1 = ops.l1_mean(self._fake, s.view(B, F, T, 1))
+        loss_g = loss_gan + self.cfg.lambda_l1 * loss_l1
+        loss_g.backward()
+        self.netD.requires_grad_(True)
+        self.losses[1].copy_(loss_g.detach())
+        self.losses[2].copy_(loss_gan.detach())
+        self.losses[3].copy_(loss_l1.detach())
+        self._pred_fake_g = pred
+
+    def _seg_gupdate(self):
+        self.optimizer_G.step(1.0 / self.world)
+
+    def _allreduce(self, arena):
+        if self.world > 1:
+            torch.distributed.all_reduce(arena.grad, group=self.pg)
+
+    def _capture(self):
+        """three HIP graphs split at the two gradient all-reduce points."""
+        segs = (self._seg_forward_dstep, self._seg_dupdate_gstep, self._seg_gupdate)
+        # warm-up on a side stream (allocator + lazy init), restoring state afterwards is NOT needed for
+        # throughput runs; callers that need exact step counts should capture before training starts.
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            for _ in range(2):
+                for f in segs:
+                    f()
+        torch.cuda.current_stream().wait_stream(st)
+        graphs = []
+        pool = None
+        for f in segs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                f()
+            pool = g.pool()
+            graphs.append(g)
+        self._graphs = graphs
+
+    def optimize_parameters(self, global_step=0):
+        """one G+D train step (train_whole_sync.py:76)."""
+        if self.use_graph:
+            if self._graphs is None:
+                self._capture()
+            g0, g1, g2 = self._graphs
+            g0.replay()
+            self._allreduce(self.arena_D)
+            g1.replay()
+            self._allreduce(self.arena_G)
+            g2.replay()
+        else:
+            self._seg_forward_dstep()
+            self._allreduce(self.arena_D)
+            self._seg_dupdate_gstep()
+            self._allreduce(self.arena_G)
+            self._seg_gupdate()
+
+    def forward_backward_no_update(self):
+        """the step WITHOUT the two Adam updates (parity target, see oracle.step_no_update)."""
+        self._seg_forward_dstep()
+        self._seg_dupdate_gstep(update=False)
+
+    def test(self):
+        """forward only (train_whole_sync.py:79-80; caller wraps in no_grad)."""
+        s = self.mel
+        B, _, F, T = s.shape
+        with torch.no_grad():
+            s_in = ops.mask_mul(s.view(B, F, T, 1), self.mask)
+            feats = self.Mel_Encoder.forward_nhwc(s_in.view(B, F, T))
+            fake = self.Mel_Decoder.forward_nhwc(feats, (F, T))
+            self.fake = to_nchw_view(fake)
+            self.losses[3].copy_(ops.l1_mean(fake, s.view(B, F, T, 1)))
+            bott = feats[-1]                                   # (B, h, T/16, 256)
+            emb = bott.mean(dim=(1, 2))
+            self.mel_net_norm = torch.nn.functional.normalize(emb, p=2, dim=1)
+            self.video_net_norm = self.mel_net_norm
+        return self.fake
+
+    # ------------------------------------------------------------ bookkeeping
+    def get_loss_items(self):
+        """host sync point (train_whole_sync.py:85)."""
+        v = self.losses.tolist()
+        self.loss_D_item, self.loss_G_item, self.loss_G_GAN_item, self.loss_mel_L1_item = v[0], v[1], v[2], v[3]
+        self.reconstruct_loss_item = 0.0
+        self.EmbeddingL2_item = 0.0
+        return v
+
+    def get_current_errors(self):
+        return OrderedDict([("D", self.loss_D_item), ("G", self.loss_G_item), ("G_GAN", self.loss_G_GAN_item),
+                            ("mel_L1", self.loss_mel_L1_item)])
+
+    def get_current_visuals(self):
+        out = OrderedDict()
+        if self.mel is not None:
+            out["real_mel"] = self.mel.detach()
+            out["masked_mel"] = (self.mel * self.mask).detach()
+        if self.fake is not None:
+            out["fake_mel"] = self.fake.detach()
+        return out
+
+    def TF_writer(self, writer, step=0):
+        if writer is None:
+            return
+        for k, v in self.get_current_errors().items():
+            writer.add_scalar(getattr(self.hparams, "name", "viai") + "_" + k, v, step)
+
+    def del_no_need(self):
+        self._pred_fake_g = None
+
+    def eval_model_test(self, global_step, eval_dir):
+        self.test()
+        os.makedirs(eval_dir, exist_ok=True)
+        torch.save({"fake": self.fake.cpu(), "real": self.mel.cpu(), "mask": self.mask.cpu()},
+                   os.path.join(eval_dir, "step%09d_mel.pt" % global_step))
+
+    # ---------------------------------------------------------- checkpointing
+    def save_inpainting_checkpoint(self, global_step, global_test_step, checkpoint_dir, epoch, hparams=None):
+        """same dict layout as utils/util.py:146-162."""
+        hp = hparams if hparams is not None else self.hparams
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        path = os.path.join(checkpoint_dir, getattr(hp, "name", "viai") + "_checkpoint_step{:09d}.pth.tar".format(global_step))
+        keep = getattr(hp, "save_optimizer_state", True)
+
+        def cpu_sd(m):
+            return OrderedDict((k, v.detach().cpu().clone()) for k, v in m.state_dict().items())
+        torch.save({
+            "Mel_Encoder": cpu_sd(self.Mel_Encoder), "Mel_Decoder": cpu_sd(self.Mel_Decoder), "netD": cpu_sd(self.netD),
+            "optimizer_G": self.optimizer_G.state_dict() if keep else None,
+            "optimizer_D": self.optimizer_D.state_dict() if keep else None,
+            "global_step": global_step, "global_epoch": epoch, "global_test_step": global_test_step,
+        }, path)
+        return path
+
+    def load_inpainting_checkpoint(self, path, reset_optimizer=False):
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.load_states(ck["Mel_Encoder"], ck["Mel_Decoder"], ck["netD"])
+        if not reset_optimizer:
+            if ck.get("optimizer_G") is not None:
+                self.optimizer_G.load_state_dict(ck["optimizer_G"])
+            if ck.get("optimizer_D") is not None:
+                self.optimizer_D.load_state_dict(ck["optimizer_D"])
+        return ck["global_step"], ck["global_epoch"], ck["global_test_step"]
+
+    def load_part_checkpoint(self, path=None):
+        """tolerant partial load of E and G only (utils/util.py:124-144,165-173)."""
+        path = path if path is not None else getattr(self.hparams, "resume_path", None)
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        for mod, key in ((self.Mel_Encoder, "Mel_Encoder"), (self.Mel_Decoder, "Mel_Decoder")):
+            own = mod.state_dict()
+            for k, v in ck[key].items():
+                if k in own and tuple(own[k].shape) == tuple(v.shape):
+                    own[k].copy_(v)
+        return self

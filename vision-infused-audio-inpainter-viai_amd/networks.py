@@ -1,0 +1,220 @@
+"""nn.Module shells over the HIP ops: the reference's generator / discriminator API.
+
+Same constructor signatures, forward I/O and `state_dict()` keys/shapes as
+  MelEncoder        networks/Inpainting_Networks.py:49-88
+  TransConvBlock    networks/New_Inpainting_Networks.py:12-45
+  MelDecoder        networks/New_Inpainting_Networks.py:48-89
+  MelDiscriminator  networks/Discriminator_Networks.py:9-50
+so checkpoints written by `utils/util.save_inpainting_checkpoint` load here and
+vice versa.  torch's nn.Conv2d / nn.ConvTranspose2d / nn.BatchNorm2d objects are
+used ONLY as parameter/buffer holders (their own forward is never called): the
+arithmetic is `ops.conv_bn_act` etc., i.e. libviai_hip.so.
+
+Layout: inputs/outputs are NCHW-shaped like the reference's; internally the
+data is NHWC.  Tensors returned to the caller are NCHW *views* of NHWC storage
+(torch channels_last strides) — same shape, same values, no copy.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+
+class DefaultHParams:
+    """The few attributes the reference reads from its (missing) Options_inpainting.Inpainting_Config."""
+    cin_channels = 256
+    max_mel_lengths = 256
+    normlayer = nn.BatchNorm2d
+    length_feature = 256
+    image_size = 224
+
+
+hparams = DefaultHParams()
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W) any strides -> (N,H,W,C) contiguous (free when already channels-last or C == 1)."""
+    y = x.permute(0, 2, 3, 1)
+    return y if y.is_contiguous() else y.contiguous()
+
+
+def to_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _check_norm(norm_layer):
+    if norm_layer is not nn.BatchNorm2d:
+        raise NotImplementedError("the HIP path implements nn.BatchNorm2d (the reference's hparams.normlayer); got %r" % (norm_layer,))
+
+
+def fused_layer(x, conv, bn, act, x2=None, training=True):
+    """conv (nn.Conv2d | nn.ConvTranspose2d holder) -> bn (nn.BatchNorm2d holder | None) -> act, on NHWC."""
+    transposed = isinstance(conv, nn.ConvTranspose2d)
+    if transposed and _pair(conv.stride) != (1, 1):
+        raise NotImplementedError("ConvTranspose2d stride != 1")
+    return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
+                           padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2,
+                           training=(bn.training if bn is not None else training))
+
+
+class TransConvBlock(nn.Module):
+    """`nums` x [ConvTranspose2d 3x3 s1 p1 (no bias) -> BN -> ReLU]; sub-module names
+    conv{name}_{i}, conv{name}_{i}_bn (New_Inpainting_Networks.py:12-45)."""
+
+    def __init__(self, inplanes, outplanes, name, nums=3, kernel_size=3, padding=(1, 1), stride=(1, 1),
+                 norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        _check_norm(norm_layer)
+        if not isinstance(name, str):
+            raise Exception("name should be str")
+        self.nums, self.name = nums, name
+        c = inplanes
+        for i in range(nums):
+            self.add_module("conv%s_%d" % (name, i),
+                            nn.ConvTranspose2d(c, outplanes, kernel_size=kernel_size, stride=stride, padding=padding, bias=False))
+            self.add_module("conv%s_%d_bn" % (name, i), norm_layer(outplanes))
+            c = outplanes
+        self.initial()
+
+    def initial(self):
+        for m in self.modules():
+            if isinstance(m, nn.ConvTranspose2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward_nhwc(self, x, x2=None):
+        for i in range(self.nums):
+            conv = self._modules["conv%s_%d" % (self.name, i)]
+            bn = self._modules["conv%s_%d_bn" % (self.name, i)]
+            x = fused_layer(x, conv, bn, ACT_RELU, x2=x2 if i == 0 else None)
+        return x
+
+    def forward(self, x):
+        return to_nchw_view(self.forward_nhwc(to_nhwc(x)))
+
+
+class MelEncoder(nn.Module):
+    """E_a: 5 x [Conv2d 3x3 (no bias) -> BN -> LeakyReLU(0.2)], strides (2,2),(2,1),(2,2),(2,2),(2,2);
+    AvgPool2d((3,1)) on the last map; returns the list of 5 maps (Inpainting_Networks.py:49-78)."""
+
+    STRIDES = ((2, 2), (2, 1), (2, 2), (2, 2), (2, 2))
+    WIDTHS = (1, 32, 64, 128, 256, 256)
+
+    def __init__(self, hparams=hparams, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        _check_norm(norm_layer)
+        self.hparams = hparams
+        for i in range(5):
+            self.add_module("conv%d" % (i + 1), nn.Conv2d(self.WIDTHS[i], self.WIDTHS[i + 1], (3, 3), self.STRIDES[i], (1, 1), bias=False))
+            self.add_module("bn%d" % (i + 1), norm_layer(self.WIDTHS[i + 1], affine=True))
+        self.initial()
+
+    def initial(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward_nhwc(self, c):
+        """c: (B, F, T) or (B,1,F,T) -> list of 5 NHWC maps."""
+        b = c.size(0)
+        f = c.size(-2) if c.dim() >= 3 else self.hparams.cin_channels
+        x = c.reshape(b, f, -1, 1)                      # (B,1,F,T) NCHW == (B,F,T,1) NHWC
+        net = []
+        for i in range(5):
+            x = fused_layer(x, self._modules["conv%d" % (i + 1)], self._modules["bn%d" % (i + 1)], ACT_LRELU)
+            net.append(x)
+        net[-1] = ops.avgpool_h(net[-1], 3)
+        return net
+
+    def forward(self, c):
+        return [to_nchw_view(t) for t in self.forward_nhwc(c)]
+
+
+class MelDecoder(nn.Module):
+    """G: stride-1 transposed convs + align-corners bilinear up-sampling to each encoder scale,
+    skip concat with e2 at the third scale, Sigmoid (New_Inpainting_Networks.py:48-89).
+    `convblock1` exists for state_dict parity but is never used by forward (as in the reference)."""
+
+    def __init__(self, hparams=hparams, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer if norm_layer is not None else getattr(hparams, "normlayer", nn.BatchNorm2d)
+        _check_norm(norm_layer)
+        self.hparams = hparams
+        self.deconv1_1 = nn.ConvTranspose2d(256, 256, 3, 1, (0, 1))
+        self.deconv1_1_bn = norm_layer(256)
+        self.deconv1_2 = nn.ConvTranspose2d(256, 256, 3, 1, 1)
+        self.deconv1_2_bn = norm_layer(256)
+        self.convblock1 = TransConvBlock(256, 256, "1", nums=2, norm_layer=norm_layer)
+        self.convblock2 = TransConvBlock(256, 128, "2", nums=3, norm_layer=norm_layer)
+        self.convblock3 = TransConvBlock(128, 64, "3", nums=3, norm_layer=norm_layer)
+        self.convblock4 = TransConvBlock(64 * 2, 32, "4", nums=3, norm_layer=norm_layer)
+        self.convblock5 = TransConvBlock(32, 32, "5", nums=4, norm_layer=norm_layer)
+        self.conv6_1 = nn.ConvTranspose2d(32, 32, 3, 1, 1)
+        self.conv6_2 = nn.ConvTranspose2d(32, 1, 3, 1, 1)
+        self.conv6_1_bn = norm_layer(32)
+        self.orig_size = [getattr(hparams, "cin_channels", None), getattr(hparams, "max_mel_lengths", None)]
+        self.upsample_mode = "bilinear"
+        self.skip_at = 3            # i == 3: concat with net[-4]
+
+    def _head(self, net):
+        out = fused_layer(net[-1], self.deconv1_1, self.deconv1_1_bn, ACT_RELU)
+        return fused_layer(out, self.deconv1_2, self.deconv1_2_bn, ACT_RELU)
+
+    def forward_nhwc(self, net, out_hw, head=None):
+        out = self._head(net) if head is None else head
+        for i in range(1, len(net)):
+            tgt = net[-1 - i]
+            out = ops.bilinear_ac(out, (tgt.shape[1], tgt.shape[2]))
+            skip = net[-(i + 1)] if i == self.skip_at else None     # virtual concat: two source pointers
+            out = self._modules["convblock%d" % (i + 1)].forward_nhwc(out, skip)
+        out = ops.bilinear_ac(out, out_hw)
+        out = fused_layer(out, self.conv6_1, self.conv6_1_bn, ACT_RELU)
+        return fused_layer(out, self.conv6_2, None, ACT_SIGMOID)
+
+    def forward(self, net, x_size):
+        net = [to_nhwc(t) for t in net]
+        return to_nchw_view(self.forward_nhwc(net, (int(x_size[2]), int(x_size[3]))))
+
+
+class MelDiscriminator(nn.Module):
+    """PatchGAN D: Conv(1->ndf,(1,4),s(1,2),p(0,1)) BN LReLU; n_layers-1 x [Conv3x3 s2 BN LReLU];
+    Conv3x3 s1 BN LReLU; Conv3x3 -> 1; Sigmoid (always on, as in Discriminator_Networks.py:13)."""
+
+    def __init__(self, input_nc=1, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, use_sigmoid=True):
+        super().__init__()
+        _check_norm(norm_layer)
+        self.n_layers = n_layers
+        self.use_sigmoid = True
+        self.conv1 = nn.Conv2d(input_nc, ndf, kernel_size=(1, 4), stride=(1, 2), padding=(0, 1), bias=False)
+        self.bn1 = norm_layer(ndf)
+        nf_mult = 1
+        for n in range(1, n_layers):
+            nf_prev, nf_mult = nf_mult, min(2 ** n, 8)
+            self.add_module("conv2_%d" % n, nn.Conv2d(ndf * nf_prev, ndf * nf_mult, kernel_size=(3, 3), stride=2, padding=1, bias=False))
+            self.add_module("norm_%d" % n, norm_layer(ndf * nf_mult))
+        nf_prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
+        self.conv3 = nn.Conv2d(ndf * nf_prev, ndf * nf_mult, kernel_size=3, stride=1, padding=1, bias=False)
+        self.norm3 = norm_layer(ndf * nf_mult)
+        self.conv4 = nn.Conv2d(ndf * nf_mult, 1, kernel_size=3, stride=1, padding=1, bias=False)
+
+    def forward_nhwc(self, x):
+        net = fused_layer(x, self.conv1, self.bn1, ACT_LRELU)
+        for n in range(1, self.n_layers):
+            net = fused_layer(net, self._modules["conv2_%d" % n], self._modules["norm_%d" % n], ACT_LRELU)
+        net = fused_layer(net, self.conv3, self.norm3, ACT_LRELU)
+        return fused_layer(net, self.conv4, None, ACT_SIGMOID if self.use_sigmoid else ACT_NONE)
+
+    def forward(self, input):
+        return to_nchw_view(self.forward_nhwc(to_nhwc(input)))

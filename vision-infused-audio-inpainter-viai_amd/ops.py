@@ -1,0 +1,356 @@
+"""PyTorch autograd front of the HIP kernels (host side of the drop-in boundary).
+
+Every op here is a `torch.autograd.Function` whose forward AND backward are
+launches into libviai_hip.so on torch's current HIP stream; outputs are ordinary
+autograd-connected CUDA tensors, so the reference's `loss_functions.GANLoss`,
+`torch.optim.Adam` and `train_whole_sync.py`-style loops work on them unchanged
+(SURVEY.md §8b "Autograd").  Tensors cross this layer as fp32 NHWC
+((N,H,W,C) contiguous); `networks.py` does the NCHW<->NHWC views.
+
+There is no CPU path: a non-CUDA tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Conv2dDesc
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+BN_EPS = 1e-5
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _require(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.ViaiLibraryError("viai ops run on the GPU only (got a %s tensor); no CPU fallback" % t.device)
+        if t.dtype != torch.float32:
+            raise TypeError("viai ops are fp32, got %s" % t.dtype)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_desc_cache = {}
+
+
+def conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed):
+    key = (N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed)
+    d = _desc_cache.get(key)
+    if d is None:
+        lib = _lib.load()
+        desc = Conv2dDesc(*key)
+        oh, ow = C.c_int(), C.c_int()
+        lib.viai_conv2d_out_hw(C.byref(desc), C.byref(oh), C.byref(ow))
+        nblk, rows = C.c_int(), C.c_int()
+        _lib.check(lib.viai_conv2d_stat_geom(C.byref(desc), C.byref(nblk), C.byref(rows)), "viai_conv2d_stat_geom")
+        d = {
+            "desc": desc, "ref": C.byref(desc), "OH": oh.value, "OW": ow.value,
+            "nblk": nblk.value, "rows": rows.value,
+            "packed": int(lib.viai_conv2d_packed_floats(C.byref(desc))),
+            "ws_floats": int(lib.viai_conv2d_wgrad_ws_bytes(C.byref(desc))) // 4,
+        }
+        _desc_cache[key] = d
+    return d
+
+
+class _ConvBnAct(torch.autograd.Function):
+    """y = conv(x ++ x2, w) + b ; [BatchNorm2d] ; activation  — one fused layer.
+
+    Reference semantics: nn.Conv2d / nn.ConvTranspose2d -> nn.BatchNorm2d ->
+    LeakyReLU(0.2)/ReLU/Sigmoid (Inpainting_Networks.py:71-76,
+    New_Inpainting_Networks.py:31-37,71-75,85-88, Discriminator_Networks.py:38-49)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, weight, bias, gamma, beta, rmean, rvar, nbt, cfg):
+        lib = _lib.load()
+        _require(x, x2, weight, bias, gamma, beta)
+        x = _c(x)
+        x2 = _c(x2) if x2 is not None else None
+        weight = _c(weight)
+        N, IH, IW, C1 = x.shape
+        C2 = x2.shape[3] if x2 is not None else 0
+        kh, kw = cfg["k"]
+        transposed = cfg["transposed"]
+        Cout = weight.shape[1] if transposed else weight.shape[0]
+        d = conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, cfg["s"][0], cfg["s"][1], cfg["p"][0], cfg["p"][1],
+                      1 if transposed else 0)
+        st = _stream()
+        dev = x.device
+        OH, OW = d["OH"], d["OW"]
+        M = N * OH * OW
+        wp = torch.empty(d["packed"], device=dev, dtype=torch.float32)
+        _lib.check(lib.viai_conv2d_pack_fwd(d["ref"], weight.data_ptr(), wp.data_ptr(), st), "viai_conv2d_pack_fwd")
+        has_bn = gamma is not None
+        act = cfg["act"]
+        training = cfg["training"]
+        if has_bn:
+            y = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
+            coef = torch.empty((4, Cout), device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
+            if training:
+                stat = torch.empty(2 * Cout * d["nblk"], device=dev, dtype=torch.float32)
+                _lib.check(lib.viai_conv2d_fwd(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
+                                               y.data_ptr(), stat.data_ptr(), ACT_NONE, st), "viai_conv2d_fwd")
+                _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, Cout, gamma.data_ptr(),
+                                                beta.data_ptr(), _ptr(rmean), _ptr(rvar), _ptr(nbt),
+                                                cfg["momentum"], cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
+                                                coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_finalize")
+            else:
+                _lib.check(lib.viai_conv2d_fwd(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
+                                               y.data_ptr(), 0, ACT_NONE, st), "viai_conv2d_fwd")
+                _lib.check(lib.viai_bn_eval_coeffs(Cout, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(),
+                                                   rvar.data_ptr(), cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
+                                                   coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_eval_coeffs")
+            z = torch.empty_like(y)
+            _lib.check(lib.viai_bn_act_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(),
+                                           M, Cout, act, 0.2, st), "viai_bn_act_fwd")
+            ctx.save_for_backward(x, x2, weight, y, coef)
+        else:
+            z = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
+            _lib.check(lib.viai_conv2d_fwd(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
+                                           z.data_ptr(), 0, act, st), "viai_conv2d_fwd")
+            ctx.save_for_backward(x, x2, weight, z, None)
+        ctx.d = d
+        ctx.cfg = cfg
+        ctx.has_bn = has_bn
+        ctx.has_bias = bias is not None
+        ctx.dims = (N, IH, IW, C1, C2, Cout, OH, OW)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        x, x2, weight, y_or_z, coef = ctx.saved_tensors
+        d, cfg = ctx.d, ctx.cfg
+        N, IH, IW, C1, C2, Cout, OH, OW = ctx.dims
+        M = N * OH * OW
+        st = _stream()
+        dev = dz.device
+        dz = _c(dz)
+        act = cfg["act"]
+        need_x, need_x2, need_w, need_b, need_g, need_be = ctx.needs_input_grad[:6]
+        dgamma = dbeta = None
+        if ctx.has_bn:
+            nblk = lib.viai_bn_bwd_blocks(M, Cout)
+            part = torch.empty(2 * Cout * nblk, device=dev, dtype=torch.float32)
+            sums = torch.empty(2 * Cout, device=dev, dtype=torch.float32)
+            dgamma = torch.empty(Cout, device=dev, dtype=torch.float32) if need_g else None
+            dbeta = torch.empty(Cout, device=dev, dtype=torch.float32) if need_be else None
+            dy = torch.empty_like(dz)
+            _lib.check(lib.viai_bn_act_bwd(dz.data_ptr(), y_or_z.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                           coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
+                                           _ptr(dgamma), _ptr(dbeta), dy.data_ptr(), M, Cout, act, 0.2,
+                                           1 if cfg["training"] else 0, st), "viai_bn_act_bwd")
+        elif act == ACT_NONE:
+            dy = dz
+        else:
+            dy = torch.empty_like(dz)
+            _lib.check(lib.viai_act_bwd_from_output(dz.data_ptr(), y_or_z.data_ptr(), dy.data_ptr(), dz.numel(), act,
+                                                    0.2, st), "viai_act_bwd_from_output")
+        dw = db = dx = dx2 = None
+        if need_w or (need_b and ctx.has_bias):
+            ws = torch.empty(d["ws_floats"], device=dev, dtype=torch.float32)
+            dw = torch.empty_like(weight)
+            if ctx.has_bias and need_b:
+                if ctx.has_bn and cfg["training"]:
+                    # a bias in front of training-mode BN has an exactly-zero gradient (the batch mean absorbs it)
+                    db = torch.zeros(Cout, device=dev, dtype=torch.float32)
+                else:
+                    db = torch.empty(Cout, device=dev, dtype=torch.float32)
+            want_db = db is not None and not (ctx.has_bn and cfg["training"])
+            _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                             dw.data_ptr(), db.data_ptr() if want_db else 0, 0, st), "viai_conv2d_wgrad")
+            if not need_w:
+                dw = None
+        if need_x or need_x2:
+            wp = torch.empty(d["packed"], device=dev, dtype=torch.float32)
+            _lib.check(lib.viai_conv2d_pack_dgrad(d["ref"], weight.data_ptr(), wp.data_ptr(), st), "viai_conv2d_pack_dgrad")
+            dx = torch.empty((N, IH, IW, C1), device=dev, dtype=torch.float32)
+            dx2 = torch.empty((N, IH, IW, C2), device=dev, dtype=torch.float32) if C2 > 0 else None
+            _lib.check(lib.viai_conv2d_dgrad(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), st),
+                       "viai_conv2d_dgrad")
+        return dx, dx2, dw, db, dgamma, dbeta, None, None, None, None
+
+
+def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding=(0, 0), transposed=False,
+                act=ACT_NONE, x2=None, training=True):
+    """Fused layer on NHWC tensors.  `bn` is an nn.BatchNorm2d (parameter/buffer holder) or None."""
+    cfg = {"k": tuple(kernel), "s": tuple(stride), "p": tuple(padding), "transposed": bool(transposed),
+           "act": int(act), "training": bool(training), "momentum": 0.1, "eps": BN_EPS}
+    if bn is not None:
+        cfg["momentum"] = 0.1 if bn.momentum is None else float(bn.momentum)
+        cfg["eps"] = float(bn.eps)
+        track = bn.track_running_stats and bn.running_mean is not None
+        if not training and not track:
+            cfg["training"] = True
+        return _ConvBnAct.apply(x, x2, weight, bias, bn.weight, bn.bias,
+                                bn.running_mean if track else None, bn.running_var if track else None,
+                                bn.num_batches_tracked if (track and cfg["training"]) else None, cfg)
+    return _ConvBnAct.apply(x, x2, weight, bias, None, None, None, None, None, cfg)
+
+
+class _BilinearAC(torch.autograd.Function):
+    """F.interpolate(mode='bilinear', align_corners=True) on NHWC (New_Inpainting_Networks.py:78,83)."""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        lib = _lib.load()
+        _require(x)
+        x = _c(x)
+        N, IH, IW, Cc = x.shape
+        y = torch.empty((N, oh, ow, Cc), device=x.device, dtype=torch.float32)
+        _lib.check(lib.viai_bilinear_ac_fwd(x.data_ptr(), y.data_ptr(), N, IH, IW, oh, ow, Cc, _stream()), "viai_bilinear_ac_fwd")
+        ctx.dims = (N, IH, IW, oh, ow, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        N, IH, IW, oh, ow, Cc = ctx.dims
+        dy = _c(dy)
+        dx = torch.empty((N, IH, IW, Cc), device=dy.device, dtype=torch.float32)
+        _lib.check(lib.viai_bilinear_ac_bwd(dy.data_ptr(), dx.data_ptr(), N, IH, IW, oh, ow, Cc, _stream()), "viai_bilinear_ac_bwd")
+        return dx, None, None
+
+
+def bilinear_ac(x, size):
+    if x.shape[1] == size[0] and x.shape[2] == size[1]:
+        return x            # identity resize (align_corners): exact copy semantics
+    return _BilinearAC.apply(x, int(size[0]), int(size[1]))
+
+
+class _AvgPoolH(torch.autograd.Function):
+    """nn.AvgPool2d((k,1)) on NHWC (Inpainting_Networks.py:65,77)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        lib = _lib.load()
+        _require(x)
+        x = _c(x)
+        N, IH, W, Cc = x.shape
+        y = torch.empty((N, IH // k, W, Cc), device=x.device, dtype=torch.float32)
+        _lib.check(lib.viai_avgpool_h_fwd(x.data_ptr(), y.data_ptr(), N, IH, W, Cc, k, _stream()), "viai_avgpool_h_fwd")
+        ctx.dims = (N, IH, W, Cc, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        N, IH, W, Cc, k = ctx.dims
+        dy = _c(dy)
+        dx = torch.empty((N, IH, W, Cc), device=dy.device, dtype=torch.float32)
+        _lib.check(lib.viai_avgpool_h_bwd(dy.data_ptr(), dx.data_ptr(), N, IH, W, Cc, k, _stream()), "viai_avgpool_h_bwd")
+        return dx, None
+
+
+def avgpool_h(x, k=3):
+    return _AvgPoolH.apply(x, int(k))
+
+
+class _ScalarLoss(torch.autograd.Function):
+    """mean-reduced BCE / MSE against a scalar label, or L1 between two tensors."""
+
+    @staticmethod
+    def forward(ctx, kind, a, b, target):
+        lib = _lib.load()
+        _require(a, b)
+        a = _c(a)
+        b = _c(b) if b is not None else None
+        n = a.numel()
+        part = torch.empty(lib.viai_reduce_blocks(n), device=a.device, dtype=torch.float32)
+        loss = torch.empty((), device=a.device, dtype=torch.float32)
+        st = _stream()
+        if kind == "bce":
+            _lib.check(lib.viai_bce_fwd(a.data_ptr(), target, n, part.data_ptr(), loss.data_ptr(), st), "viai_bce_fwd")
+        elif kind == "mse":
+            _lib.check(lib.viai_mse_fwd(a.data_ptr(), target, n, part.data_ptr(), loss.data_ptr(), st), "viai_mse_fwd")
+        else:
+            _lib.check(lib.viai_l1_fwd(a.data_ptr(), b.data_ptr(), n, part.data_ptr(), loss.data_ptr(), st), "viai_l1_fwd")
+        ctx.kind, ctx.target = kind, target
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b = ctx.saved_tensors
+        g = _c(g)
+        n = a.numel()
+        da = torch.empty_like(a)
+        st = _stream()
+        if ctx.kind == "bce":
+            _lib.check(lib.viai_bce_bwd(a.data_ptr(), ctx.target, n, g.data_ptr(), da.data_ptr(), st), "viai_bce_bwd")
+        elif ctx.kind == "mse":
+            _lib.check(lib.viai_mse_bwd(a.data_ptr(), ctx.target, n, g.data_ptr(), da.data_ptr(), st), "viai_mse_bwd")
+        else:
+            _lib.check(lib.viai_l1_bwd(a.data_ptr(), b.data_ptr(), n, g.data_ptr(), da.data_ptr(), st), "viai_l1_bwd")
+        db = None
+        if ctx.kind == "l1" and ctx.needs_input_grad[2]:
+            db = -da
+        return None, da, db, None
+
+
+def bce_mean(p, target: float):
+    return _ScalarLoss.apply("bce", p, None, float(target))
+
+
+def mse_mean(p, target: float):
+    return _ScalarLoss.apply("mse", p, None, float(target))
+
+
+def l1_mean(a, b):
+    return _ScalarLoss.apply("l1", a, b, 0.0)
+
+
+class _MaskMul(torch.autograd.Function):
+    """s_in = s * mask, mask (N,T) broadcast over F (the missing AudioModel.set_inputs)."""
+
+    @staticmethod
+    def forward(ctx, s, mask):
+        lib = _lib.load()
+        _require(s, mask)
+        s, mask = _c(s), _c(mask)
+        N, T = mask.shape[0], mask.shape[-1]
+        F = s.numel() // (N * T)
+        out = torch.empty_like(s)
+        _lib.check(lib.viai_mask_mul(s.data_ptr(), mask.data_ptr(), out.data_ptr(), N, F, T, _stream()), "viai_mask_mul")
+        ctx.save_for_backward(mask)
+        ctx.dims = (N, F, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (mask,) = ctx.saved_tensors
+        N, F, T = ctx.dims
+        g = _c(g)
+        ds = torch.empty_like(g)
+        _lib.check(lib.viai_mask_mul(g.data_ptr(), mask.data_ptr(), ds.data_ptr(), N, F, T, _stream()), "viai_mask_mul")
+        return ds, None
+
+
+def mask_mul(s, mask):
+    """s: (N,1,F,T) or (N,F,T); mask: (N,1,1,T) or (N,T)."""
+    return _MaskMul.apply(s, mask.reshape(mask.shape[0], mask.shape[-1]))
+
+
+def adam_step(p, g, m, v, state, beta1, beta2, eps, grad_scale=1.0):
+    """In-place torch.optim.Adam step on flat fp32 arenas; `state` = 4 fp64 {step, lr, b1^t, b2^t} on device."""
+    lib = _lib.load()
+    _require(p, g, m, v)
+    assert state.dtype == torch.float64 and state.numel() == 4
+    _lib.check(lib.viai_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), state.data_ptr(),
+                                  beta1, beta2, eps, grad_scale, _stream()), "viai_adam_step")
