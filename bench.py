@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""bench.py — VIAI inpainting-GAN train-step throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full G+D train step on one batch of
+synthetic MUSICES-shaped masked mel-spectrograms resident in HBM:
+E+G forward, 3x D forward, D backward x2, D-frozen dgrad, G+E backward, 2x Adam.
+Workload = BASELINE.json configs[1]: audio-only G + PatchGAN D, 256x256 mel,
+batch 16 per GPU, fp32 (exact-fp32 MFMA).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+METRIC = "masked mel-spectrogram clips/sec (G+D train step, 256x256 b16) at 1/2/4/8 GPUs"
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+DOMINANT = "conv_igemm_kernel<32,2,2,2,2> (128x128x32 fp32-MFMA implicit-GEMM conv, fwd + dgrad)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--bins", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print the per-layer conv timing table to stderr")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="clips per CPU-baseline step (bounded sample)")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of the conv launches on torch's current stream (the stream the kernels run on).
+    Wraps the ctypes entry points of libviai_hip.so; flops are the ALGORITHMIC 2*MACs of each call."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.records = []          # (family, flops, n_launches, ev0, ev1)
+        self.orig = {}
+
+    @staticmethod
+    def _geom(d):
+        oh = (d.IH - 1 - 2 * d.ph + d.kh) if d.transposed else (d.IH + 2 * d.ph - d.kh) // d.sh + 1
+        ow = (d.IW - 1 - 2 * d.pw + d.kw) if d.transposed else (d.IW + 2 * d.pw - d.kw) // d.sw + 1
+        cin = d.C1 + d.C2
+        flops = 2.0 * d.N * oh * ow * d.Cout * cin * d.kh * d.kw
+        return cin, flops
+
+    def install(self):
+        lib = self.lib
+
+        def wrap(name, family_of):
+            fn = getattr(lib, name)
+            self.orig[name] = fn
+
+            def timed(desc_ref, *args):
+                d = desc_ref._obj
+                fam, nl = family_of(d)
+                cin, flops = self._geom(d)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = fn(desc_ref, *args)
+                e1.record()
+                self.records.append((fam, flops, nl, e0, e1, name, (d.N, d.IH, d.IW, d.C1 + d.C2, d.Cout, d.kh, d.kw, d.sh, d.sw, d.transposed)))
+                return r
+            setattr(lib, name, timed)
+
+        def fam_fwd(d):
+            cin = d.C1 + d.C2
+            if cin == 1 or d.Cout == 1:
+                return "direct", 1
+            return ("igemm128x128" if d.Cout > 64 else "igemm128x64" if d.Cout > 32 else "igemm128x32"), 1
+
+        def fam_dgrad(d):
+            cin = d.C1 + d.C2
+            if cin == 1 or d.Cout == 1:
+                return "direct", 1
+            return ("igemm128x128" if cin > 64 else "igemm128x64" if cin > 32 else "igemm128x32"), d.sh * d.sw
+
+        def fam_wgrad(d):
+            cin = d.C1 + d.C2
+            if cin == 1 or d.Cout == 1:
+                return "direct", 1
+            return "wgrad_mfma", 1
+
+        wrap("viai_conv2d_fwd", fam_fwd)
+        wrap("viai_conv2d_dgrad", fam_dgrad)
+        wrap("viai_conv2d_wgrad", fam_wgrad)
+
+    def per_layer(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for f, flops, nl, e0, e1, name, key in self.records:
+            t = agg.setdefault((name, f, key), [0.0, 0.0, 0])
+            t[0] += flops; t[1] += e0.elapsed_time(e1) * 1e-3; t[2] += 1
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        return ["%-18s %-13s %-44s n=%3d avg %8.1f us  %6.1f TF/s" % (k[0][5:], k[1], str(k[2]), v[2], v[1] / v[2] * 1e6, v[0] / v[1] * 1e-12)
+                for k, v in rows]
+
+    def uninstall(self):
+        for k, fn in self.orig.items():
+            setattr(self.lib, k, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        fam = {}
+        for f, flops, nl, e0, e1, _n, _k in self.records:
+            t = fam.setdefault(f, [0.0, 0.0, 0])
+            t[0] += flops
+            t[1] += e0.elapsed_time(e1) * 1e-3
+            t[2] += nl
+        return fam
+
+
+def cpu_baseline(args):
+    """The oracle's train step on the host cores: a bounded sample of the same workload
+    (same 256x256 shape, `cpu_batch` clips per step), 1 warm-up + 2 timed steps."""
+    from oracle import viai_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    B = args.cpu_batch
+    s = O.cf_uniform("bench.cpu.s", (B, 1, args.bins, args.frames))
+    mask = O.make_mask(B, args.frames, "bench.cpu.mask")
+    E, G, D = O.encoder_state(), O.decoder_state(), O.disc_state()
+    oG, oD = O.new_optimizers(E, G, D)
+    O.train_step(E, G, D, oG, oD, s, mask)
+    n = 2
+    t0 = time.perf_counter()
+    for _ in range(n):
+        O.train_step(E, G, D, oG, oD, s, mask)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/viai_oracle.train_step (torch CPU fp32), %d clips of %dx%d per step, 1 warm-up + %d timed steps, %.2f s/step"
+                      % (B, args.bins, args.frames, n, dt)}
+
+
+def main():
+    args = parse()
+    from viai_amd import _lib, ddp, synth
+    from viai_amd.model import AudioModel, StepConfig
+
+    rank, local, world = ddp.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = _lib.load()
+
+    hp = StepConfig()
+    hp.cin_channels, hp.max_mel_lengths, hp.batch_size = args.bins, args.frames, args.batch
+    torch.manual_seed(1234)                               # identical init on every rank (DDP semantics)
+    model = AudioModel(hp, device=dev, use_graph=not args.no_graph)
+    ddp.broadcast_arena(model.arena_G.flat)
+    ddp.broadcast_arena(model.arena_D.flat)
+
+    s = synth.mel_batch(args.batch, args.bins, args.frames, "bench.s", rank).to(dev)
+    mask = synth.time_mask(args.batch, args.frames, "bench.mask", rank).to(dev)
+    model.set_inputs(s, mask)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.optimize_parameters(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.optimize_parameters(args.warmup + i)
+    barrier()
+    elapsed_ms = (time.perf_counter() - t0) * 1e3
+    elapsed_ms = ddp.barrier_max_ms(elapsed_ms, dev)
+    ms_per_step = elapsed_ms / args.steps
+    value = world * args.batch * args.steps / (elapsed_ms * 1e-3)
+    losses = model.get_loss_items()
+
+    out = {
+        "metric": METRIC, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: audio-only MelEncoder+MelDecoder G + MelDiscriminator (PatchGAN) D train step, "
+                               "%dx%d mel, batch %d per GPU, BCE-GAN + 100*L1, Adam(2e-4, 0.5, 0.999)" % (args.bins, args.frames, args.batch),
+                   "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                   "launch": "eager" if args.no_graph else "hipGraph replay (3 segments)",
+                   "algorithmic_gflop_per_step": 1208.0, "step_tflops": round(1208.0 * 1e-3 / (ms_per_step * 1e-3), 2),
+                   "loss_d": round(losses[0], 5), "loss_g": round(losses[1], 5)},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented eager pass over the same workload: HIP events around every conv launch
+        m2 = AudioModel(hp, device=dev, use_graph=False)
+        m2.set_inputs(s, mask)
+        for i in range(2):
+            m2.optimize_parameters(i)
+        torch.cuda.synchronize()
+        kt = KernelTimer(lib)
+        kt.install()
+        nprof = min(args.steps, 10)
+        for i in range(nprof):
+            m2.optimize_parameters(i)
+        fam = kt.summary()
+        if args.layers:
+            print("\n".join(kt.per_layer()), file=sys.stderr)
+        kt.uninstall()
+        tot_t = sum(v[1] for v in fam.values())
+        f, t, n = fam["igemm128x128"]
+        ach = f / t * 1e-12
+        out["roofline"] = {
+            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": DOMINANT, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
+            "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
+            "how": "HIP events on the launch stream around each call, %d instrumented eager steps after the timed region" % nprof,
+            "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},
+            "conv_tflops_by_kernel": {k: round(v[0] / v[1] * 1e-12, 2) for k, v in sorted(fam.items()) if v[1] > 0},
+            "conv_ms_per_step": round(tot_t / nprof * 1e3, 3),
+        }
+        del m2
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

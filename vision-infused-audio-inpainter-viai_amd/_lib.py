@@ -6,6 +6,8 @@ if the library is missing or a launch returns a non-zero hipError_t.
 from __future__ import annotations
 
 import ctypes as C
+
+import torch  # noqa: F401  -- FIRST: torch bundles its own libamdhip64; our .so must bind to that already-loaded runtime
 import os
 import subprocess
 

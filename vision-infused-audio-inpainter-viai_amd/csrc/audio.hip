@@ -76,9 +76,9 @@ extern "C" int viai_stft_mel(const float* wav, const float* window, const float*
     if (B <= 0 || frames <= 0 || hop <= 0 || hop > fft || n_mels <= 0) return (int)hipErrorInvalidValue;
     dim3 grid(frames, B);
     hipStream_t st = (hipStream_t)stream;
-    if (fft == 1024) hipLaunchKernelGGL(stft_mel_kernel<1024>, grid, dim3(256), 0, st, wav, window, basis_t, mask, mel, n_samples, hop, n_mels, frames, min_level_db, ref_level_db);
-    else if (fft == 512) hipLaunchKernelGGL(stft_mel_kernel<512>, grid, dim3(256), 0, st, wav, window, basis_t, mask, mel, n_samples, hop, n_mels, frames, min_level_db, ref_level_db);
-    else if (fft == 2048) hipLaunchKernelGGL(stft_mel_kernel<2048>, grid, dim3(256), 0, st, wav, window, basis_t, mask, mel, n_samples, hop, n_mels, frames, min_level_db, ref_level_db);
+    if (fft == 1024) VIAI_LAUNCH(stft_mel_kernel<1024>, grid, dim3(256), 0, st, wav, window, basis_t, mask, mel, n_samples, hop, n_mels, frames, min_level_db, ref_level_db);
+    else if (fft == 512) VIAI_LAUNCH(stft_mel_kernel<512>, grid, dim3(256), 0, st, wav, window, basis_t, mask, mel, n_samples, hop, n_mels, frames, min_level_db, ref_level_db);
+    else if (fft == 2048) VIAI_LAUNCH(stft_mel_kernel<2048>, grid, dim3(256), 0, st, wav, window, basis_t, mask, mel, n_samples, hop, n_mels, frames, min_level_db, ref_level_db);
     else return (int)hipErrorInvalidValue;
     return viai_launch_status();
 }

@@ -201,14 +201,14 @@ extern "C" int viai_bn_finalize(const float* stat_part, int nblk, int rows_per_b
                                 int64_t* nbt, float momentum, float eps,
                                 float* mean, float* invstd, float* scale, float* shift, void* stream) {
     if (nblk <= 0 || C <= 0 || M <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, nblk, rows_per_blk, M, C,
+    VIAI_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, nblk, rows_per_blk, M, C,
                        gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift);
     return viai_launch_status();
 }
 
 extern "C" int viai_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
                                    float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
-    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, rm, rv, eps,
+    VIAI_LAUNCH(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, rm, rv, eps,
                        mean, invstd, scale, shift);
     return viai_launch_status();
 }
@@ -217,7 +217,7 @@ extern "C" int viai_bn_act_fwd(const float* y, const float* scale, const float* 
                                long M, int C, int act, float slope, void* stream) {
     if (C % 4 != 0) return (int)hipErrorInvalidValue;
     long n4 = M * C / 4;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
+    VIAI_LAUNCH(bn_act_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const f32x4*>(y), scale, shift, reinterpret_cast<f32x4*>(z), n4, C, act, slope);
     return viai_launch_status();
 }
@@ -238,11 +238,11 @@ extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mea
     hipStream_t st = (hipStream_t)stream;
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, C, sums, dgamma, dbeta);
+    VIAI_LAUNCH(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope);
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, C, sums, dgamma, dbeta);
     if (dy != nullptr) {
         long n4 = M * C / 4;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz),
+        VIAI_LAUNCH(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz),
                            reinterpret_cast<const f32x4*>(y), mean, invstd, scale, shift, sums, reinterpret_cast<f32x4*>(dy),
                            n4, M, C, act, slope, training);
     }
@@ -250,6 +250,6 @@ extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mea
 }
 
 extern "C" int viai_act_bwd_from_output(const float* dz, const float* z, float* dx, long n, int act, float slope, void* stream) {
-    hipLaunchKernelGGL(act_bwd_out_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dz, z, dx, n, act, slope);
+    VIAI_LAUNCH(act_bwd_out_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dz, z, dx, n, act, slope);
     return viai_launch_status();
 }

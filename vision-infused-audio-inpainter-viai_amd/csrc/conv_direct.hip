@@ -313,9 +313,9 @@ int viai_cin1_fwd(const viai_conv2d* c, const float* x, const float* w, const fl
     if (c->kh * c->kw > VIAI_MAX_TAPS) return (int)hipErrorInvalidValue;
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.stat = stat; a.act = act; a.slope = 0.2f;
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
-    if (c->Cout == 32) hipLaunchKernelGGL(cin1_fwd_kernel<8>, dim3(a.nblk), dim3(256), 0, st, a);
-    else if (c->Cout == 64) hipLaunchKernelGGL(cin1_fwd_kernel<16>, dim3(a.nblk), dim3(256), 0, st, a);
-    else if (c->Cout == 128) hipLaunchKernelGGL(cin1_fwd_kernel<32>, dim3(a.nblk), dim3(256), 0, st, a);
+    if (c->Cout == 32) VIAI_LAUNCH(cin1_fwd_kernel<8>, dim3(a.nblk), dim3(256), 0, st, a);
+    else if (c->Cout == 64) VIAI_LAUNCH(cin1_fwd_kernel<16>, dim3(a.nblk), dim3(256), 0, st, a);
+    else if (c->Cout == 128) VIAI_LAUNCH(cin1_fwd_kernel<32>, dim3(a.nblk), dim3(256), 0, st, a);
     else return (int)hipErrorInvalidValue;
     return viai_launch_status();
 }
@@ -333,9 +333,9 @@ int viai_cin1_dgrad(const viai_conv2d* c, const float* dy, const float* w, float
     int lpp = c->Cout / 4;
     long threads = tot * lpp;
     int blocks = (int)((threads + 255) / 256);
-    if (lpp == 8) hipLaunchKernelGGL(cin1_dgrad_kernel<8>, dim3(blocks), dim3(256), 0, st, a);
-    else if (lpp == 16) hipLaunchKernelGGL(cin1_dgrad_kernel<16>, dim3(blocks), dim3(256), 0, st, a);
-    else if (lpp == 32) hipLaunchKernelGGL(cin1_dgrad_kernel<32>, dim3(blocks), dim3(256), 0, st, a);
+    if (lpp == 8) VIAI_LAUNCH(cin1_dgrad_kernel<8>, dim3(blocks), dim3(256), 0, st, a);
+    else if (lpp == 16) VIAI_LAUNCH(cin1_dgrad_kernel<16>, dim3(blocks), dim3(256), 0, st, a);
+    else if (lpp == 32) VIAI_LAUNCH(cin1_dgrad_kernel<32>, dim3(blocks), dim3(256), 0, st, a);
     else return (int)hipErrorInvalidValue;
     return viai_launch_status();
 }
@@ -352,7 +352,7 @@ int viai_wgrad_reduce(const float* ws, float* dw, int nz, int T, int Cout, int C
     long total = (long)T * Cout * Cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, nz, T, Cout, Cin, s_co, s_ci, accumulate);
+    VIAI_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, nz, T, Cout, Cin, s_co, s_ci, accumulate);
     return viai_launch_status();
 }
 
@@ -369,9 +369,9 @@ int viai_cin1_wgrad(const viai_conv2d* c, const float* x, const float* dy, float
     int ppb = (a.M + nb - 1) / nb;
     int cg = c->Cout / 4;
     size_t lds = (size_t)(256 / cg) * T * c->Cout * sizeof(float);
-    if (cg == 8) hipLaunchKernelGGL(cin1_wgrad_kernel<8>, dim3(nb), dim3(256), lds, st, a, ppb);
-    else if (cg == 16) hipLaunchKernelGGL(cin1_wgrad_kernel<16>, dim3(nb), dim3(256), lds, st, a, ppb);
-    else if (cg == 32) hipLaunchKernelGGL(cin1_wgrad_kernel<32>, dim3(nb), dim3(256), lds, st, a, ppb);
+    if (cg == 8) VIAI_LAUNCH(cin1_wgrad_kernel<8>, dim3(nb), dim3(256), lds, st, a, ppb);
+    else if (cg == 16) VIAI_LAUNCH(cin1_wgrad_kernel<16>, dim3(nb), dim3(256), lds, st, a, ppb);
+    else if (cg == 32) VIAI_LAUNCH(cin1_wgrad_kernel<32>, dim3(nb), dim3(256), lds, st, a, ppb);
     else return (int)hipErrorInvalidValue;
     int e = viai_launch_status();
     if (e) return e;
@@ -384,11 +384,11 @@ int viai_cout1_fwd(const viai_conv2d* c, const float* x, const float* wp, const 
     DirectArgs a = make_args(c);
     a.x = x; a.w = wp; a.bias = bias; a.y = y; a.act = act; a.slope = 0.2f;
     const int cin = a.Cin;
-    if (cin == 32) { int blocks = (int)(((long)a.M * 8 + 255) / 256); hipLaunchKernelGGL((cout1_fwd_kernel<8, 1>), dim3(blocks), dim3(256), 0, st, a); }
-    else if (cin == 64) { int blocks = (int)(((long)a.M * 16 + 255) / 256); hipLaunchKernelGGL((cout1_fwd_kernel<16, 1>), dim3(blocks), dim3(256), 0, st, a); }
-    else if (cin == 128) { int blocks = (int)(((long)a.M * 32 + 255) / 256); hipLaunchKernelGGL((cout1_fwd_kernel<32, 1>), dim3(blocks), dim3(256), 0, st, a); }
-    else if (cin == 256) { int blocks = (int)(((long)a.M * 64 + 255) / 256); hipLaunchKernelGGL((cout1_fwd_kernel<64, 1>), dim3(blocks), dim3(256), 0, st, a); }
-    else if (cin == 512) { int blocks = (int)(((long)a.M * 64 + 255) / 256); hipLaunchKernelGGL((cout1_fwd_kernel<64, 2>), dim3(blocks), dim3(256), 0, st, a); }
+    if (cin == 32) { int blocks = (int)(((long)a.M * 8 + 255) / 256); VIAI_LAUNCH((cout1_fwd_kernel<8, 1>), dim3(blocks), dim3(256), 0, st, a); }
+    else if (cin == 64) { int blocks = (int)(((long)a.M * 16 + 255) / 256); VIAI_LAUNCH((cout1_fwd_kernel<16, 1>), dim3(blocks), dim3(256), 0, st, a); }
+    else if (cin == 128) { int blocks = (int)(((long)a.M * 32 + 255) / 256); VIAI_LAUNCH((cout1_fwd_kernel<32, 1>), dim3(blocks), dim3(256), 0, st, a); }
+    else if (cin == 256) { int blocks = (int)(((long)a.M * 64 + 255) / 256); VIAI_LAUNCH((cout1_fwd_kernel<64, 1>), dim3(blocks), dim3(256), 0, st, a); }
+    else if (cin == 512) { int blocks = (int)(((long)a.M * 64 + 255) / 256); VIAI_LAUNCH((cout1_fwd_kernel<64, 2>), dim3(blocks), dim3(256), 0, st, a); }
     else return (int)hipErrorInvalidValue;
     return viai_launch_status();
 }
@@ -400,7 +400,7 @@ int viai_cout1_dgrad(const viai_conv2d* c, const float* dy, const float* wp, flo
     long total = (long)a.N * a.IH * a.IW * (a.Cin / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(cout1_dgrad_kernel, dim3(blocks), dim3(256), 0, st, a);
+    VIAI_LAUNCH(cout1_dgrad_kernel, dim3(blocks), dim3(256), 0, st, a);
     return viai_launch_status();
 }
 
@@ -420,7 +420,7 @@ int viai_cout1_wgrad(const viai_conv2d* c, const float* x, const float* dy, floa
     int ppb = (int)((q + nb - 1) / nb);
     int pg = 256 / (a.Cin / 4);
     size_t lds = (size_t)pg * T * a.Cin * sizeof(float);
-    hipLaunchKernelGGL(cout1_wgrad_kernel, dim3(nb), dim3(256), lds, st, a, ppb);
+    VIAI_LAUNCH(cout1_wgrad_kernel, dim3(nb), dim3(256), lds, st, a, ppb);
     int e = viai_launch_status();
     if (e) return e;
     // conv [1][Cin][kh][kw] and convT [Cin][1][kh][kw] both flatten to ci*T + t
@@ -438,7 +438,7 @@ extern "C" int viai_colsum_blocks(long M, int C) {
 extern "C" int viai_colsum(const float* x, long M, int C, float* part, float* out, int accumulate, void* stream) {
     int nb = viai_colsum_blocks(M, C);
     long rpb = (M + nb - 1) / nb;
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, part, M, C, rpb);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, out, nb, C, accumulate);
+    VIAI_LAUNCH(colsum_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, part, M, C, rpb);
+    VIAI_LAUNCH(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, out, nb, C, accumulate);
     return viai_launch_status();
 }

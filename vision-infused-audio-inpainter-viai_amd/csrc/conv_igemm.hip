@@ -286,7 +286,7 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BK, TM, TN, WM, WN>), dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
+    VIAI_LAUNCH((conv_igemm_kernel<BK, TM, TN, WM, WN>), dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
     return viai_launch_status();
 }
 
@@ -324,6 +324,6 @@ extern "C" int viai_pack_weight(const float* w, float* wp, int n_out, int k_in, 
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, n_out, k_in, taps, s_no, s_ki);
+    VIAI_LAUNCH(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, n_out, k_in, taps, s_no, s_ki);
     return viai_launch_status();
 }

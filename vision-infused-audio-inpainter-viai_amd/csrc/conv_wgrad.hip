@@ -194,7 +194,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(a.nblk_co * a.nblk_ci * a.g.ntaps, a.ksplit);
-    hipLaunchKernelGGL((wgrad_mfma_kernel<TM, TN, WM, WN>), grid, dim3(256), lds, st, a);
+    VIAI_LAUNCH((wgrad_mfma_kernel<TM, TN, WM, WN>), grid, dim3(256), lds, st, a);
     return viai_launch_status();
 }
 

@@ -102,15 +102,15 @@ template <int KIND>
 int loss_fwd(const float* a, const float* b, float target, long n, float* part, float* loss, void* stream) {
     if (n <= 0) return (int)hipErrorInvalidValue;
     int nb = viai_reduce_blocks(n);
-    hipLaunchKernelGGL(loss_part_kernel<KIND>, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, target, n, part);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nb, n, loss);
+    VIAI_LAUNCH(loss_part_kernel<KIND>, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, target, n, part);
+    VIAI_LAUNCH(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nb, n, loss);
     return viai_launch_status();
 }
 
 template <int KIND>
 int loss_bwd(const float* a, const float* b, float target, long n, const float* gscale, float* da, void* stream) {
     if (n <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(loss_bwd_kernel<KIND>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, n, gscale, da);
+    VIAI_LAUNCH(loss_bwd_kernel<KIND>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, n, gscale, da);
     return viai_launch_status();
 }
 
@@ -132,19 +132,19 @@ extern "C" int viai_l1_bwd(const float* a, const float* b, long n, const float* 
 
 extern "C" int viai_mask_mul(const float* s, const float* mask, float* out, int N, int F, int T, void* stream) {
     long total = (long)N * F * T;
-    hipLaunchKernelGGL(mask_mul_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, mask, out, N, F, T);
+    VIAI_LAUNCH(mask_mul_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, mask, out, N, F, T);
     return viai_launch_status();
 }
 
 extern "C" int viai_adam_step(float* p, const float* g, float* m, float* v, long n, double* state,
                               double beta1, double beta2, double eps, float grad_scale, void* stream) {
     if (n <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state, (float)beta1, (float)beta2, (float)eps, grad_scale);
+    VIAI_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
+    VIAI_LAUNCH(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state, (float)beta1, (float)beta2, (float)eps, grad_scale);
     return viai_launch_status();
 }
 
 extern "C" int viai_axpy(float a, const float* x, float* y, long n, void* stream) {
-    hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, x, y, n);
+    VIAI_LAUNCH(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, x, y, n);
     return viai_launch_status();
 }

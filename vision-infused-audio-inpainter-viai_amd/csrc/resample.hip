@@ -129,27 +129,27 @@ inline int ew_blocks(long n) {
 extern "C" int viai_bilinear_ac_fwd(const float* x, float* y, int N, int IH, int IW, int OH, int OW, int C, void* stream) {
     if (C % 4 != 0 || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return (int)hipErrorInvalidValue;
     long total = (long)N * OH * OW * (C / 4);
-    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, IH, IW, OH, OW, C);
+    VIAI_LAUNCH(bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, IH, IW, OH, OW, C);
     return viai_launch_status();
 }
 
 extern "C" int viai_bilinear_ac_bwd(const float* dy, float* dx, int N, int IH, int IW, int OH, int OW, int C, void* stream) {
     if (C % 4 != 0 || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return (int)hipErrorInvalidValue;
     long total = (long)N * IH * IW * (C / 4);
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, IH, IW, OH, OW, C);
+    VIAI_LAUNCH(bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, IH, IW, OH, OW, C);
     return viai_launch_status();
 }
 
 extern "C" int viai_avgpool_h_fwd(const float* x, float* y, int N, int IH, int W, int C, int k, void* stream) {
     if (C % 4 != 0 || k <= 0 || IH / k <= 0) return (int)hipErrorInvalidValue;
     long total = (long)N * (IH / k) * W * (C / 4);
-    hipLaunchKernelGGL(avgpool_h_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, IH, W, C, k);
+    VIAI_LAUNCH(avgpool_h_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, IH, W, C, k);
     return viai_launch_status();
 }
 
 extern "C" int viai_avgpool_h_bwd(const float* dy, float* dx, int N, int IH, int W, int C, int k, void* stream) {
     if (C % 4 != 0 || k <= 0 || IH / k <= 0) return (int)hipErrorInvalidValue;
     long total = (long)N * IH * W * (C / 4);
-    hipLaunchKernelGGL(avgpool_h_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, IH, W, C, k);
+    VIAI_LAUNCH(avgpool_h_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, IH, W, C, k);
     return viai_launch_status();
 }

@@ -61,4 +61,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-static inline int viai_launch_status() { return (int)hipGetLastError(); }
+// Launch + error capture.  hipGetLastError() is a sticky per-thread slot that other HIP users in the
+// process (torch's own probing calls) may have left set, so it is cleared before every launch and only
+// errors raised by OUR launches are accumulated (first error wins) and reported by the entry point.
+static thread_local int viai_err_acc = 0;
+#define VIAI_LAUNCH(...)                                         \
+    do {                                                         \
+        (void)hipGetLastError();                                 \
+        hipLaunchKernelGGL(__VA_ARGS__);                         \
+        int viai_e_ = (int)hipGetLastError();                    \
+        if (viai_e_ != 0 && viai_err_acc == 0) viai_err_acc = viai_e_; \
+    } while (0)
+static inline int viai_launch_status() { int e = viai_err_acc; viai_err_acc = 0; return e; }
