@@ -40,6 +40,11 @@ CONV_CASES = [
     ("D.conv1", 2, 12, 32, 1, 64, (1, 4), (1, 2), (0, 1), False, False),
     ("G.conv6_2", 2, 12, 20, 32, 1, (3, 3), (1, 1), (1, 1), True, True),
     ("D.conv4", 2, 8, 6, 512, 1, (3, 3), (1, 1), (1, 1), False, False),
+    ("D.conv1-tiny", 2, 80, 32, 1, 64, (1, 4), (1, 2), (0, 1), False, False),
+    ("G.conv6_2-tiny", 2, 80, 32, 32, 1, (3, 3), (1, 1), (1, 1), True, True),
+    ("E.conv1-tiny", 2, 80, 32, 1, 32, (3, 3), (2, 2), (1, 1), False, False),
+    ("G.cb3-tiny", 2, 10, 8, 128, 64, (3, 3), (1, 1), (1, 1), True, False),
+    ("D.conv1-wide", 1, 8, 300, 1, 64, (1, 4), (1, 2), (0, 1), False, False),
 ]
 
 
@@ -91,7 +96,7 @@ def test_conv_virtual_concat_matches_cat():
 
 
 @pytest.mark.parametrize("act", ["lrelu", "relu"])
-@pytest.mark.parametrize("shape", [(2, 32, 20, 24), (3, 64, 7, 9), (1, 256, 4, 16)])
+@pytest.mark.parametrize("shape", [(2, 32, 20, 24), (3, 64, 7, 9), (1, 256, 4, 16), (2, 32, 80, 32), (4, 32, 64, 96)])
 def test_conv_bn_act_train_matches_torch_cpu(act, shape):
     """conv -> BatchNorm2d(train) -> activation, forward, backward, running stats."""
     from viai_amd import ops
@@ -125,6 +130,34 @@ def test_conv_bn_act_train_matches_torch_cpu(act, shape):
     assert relerr(bng.running_mean, bn.running_mean) < 1e-5
     assert relerr(bng.running_var, bn.running_var) < 1e-5
     assert int(bng.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 10, 8, 64), (2, 256, 5, 4, 128), (2, 64, 20, 16, 128), (4, 32, 40, 32, 32)])
+def test_fused_layer_accuracy_against_fp64(shape):
+    """one ConvTranspose2d -> BN(train) -> ReLU layer, forward and all gradients, measured against an fp64
+    evaluation: the HIP kernels must be within 5x of torch-CPU-fp32's own rounding error (+1e-6)."""
+    from viai_amd import ops
+    N, C, H, W, Co = shape
+    x = O.cf_uniform("fa.x", (N, C, H, W), 0, 1)
+    w = O.cf_std("fa.w", (C, Co, 3, 3), 0.05)
+    gy = O.cf_uniform("fa.gy", (N, Co, H, W), -1, 1)
+    g = O.cf_uniform("fa.g", (Co,), 0.8, 1.2)
+    b = O.cf_uniform("fa.b", (Co,), -0.1, 0.1)
+
+    def run(dt):
+        xs, ws, gs, bs = [t.clone().to(dt).requires_grad_(True) for t in (x, w, g, b)]
+        z = F.relu(F.batch_norm(F.conv_transpose2d(xs, ws, None, stride=1, padding=1), None, None, gs, bs, True, 0.1, 1e-5))
+        return (z,) + torch.autograd.grad(z, [xs, ws, gs, bs], grad_outputs=gy.to(dt))
+    truth, cpu32 = run(torch.float64), run(torch.float32)
+    bn = torch.nn.BatchNorm2d(Co).cuda().train()
+    bn.weight.data.copy_(g); bn.bias.data.copy_(b)
+    xg = nhwc(x).requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    zg = ops.conv_bn_act(xg, wg, None, bn, kernel=(3, 3), stride=(1, 1), padding=(1, 1), transposed=True, act=ops.ACT_RELU)
+    zg.backward(nhwc(gy))
+    hip = (nchw(zg), nchw(xg.grad), wg.grad, bn.weight.grad, bn.bias.grad)
+    for nm, h, c32, t in zip(("z", "dx", "dw", "dgamma", "dbeta"), hip, cpu32, truth):
+        assert relerr(h, t) < 5 * relerr(c32, t) + 1e-6, (nm, relerr(h, t), relerr(c32, t))
 
 
 def test_bn_large_mean_is_stable():

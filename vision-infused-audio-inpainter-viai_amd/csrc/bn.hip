@@ -114,15 +114,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             const int c = (g0 + cg) * 4;
             f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
             f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
-            for (long r = row0 + pl; r < row1; r += pg) {
-                f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * C + c);
-                f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + c);
+            for (long r = row0 + pl; r < row1; r += 4L * pg) {
+                f32x4 g[4], v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float dp = g[e] * act_grad(v[e] * sc[e] + sh[e], act, slope);
-                    s1[e] += dp;
-                    s2[e] += dp * (v[e] - mu[e]) * is[e];
+                for (int u = 0; u < 4; ++u) {           // 8 independent 16-byte loads in flight per lane
+                    long rr = r + (long)u * pg;
+                    bool ok = rr < row1;
+                    g[u] = ok ? *reinterpret_cast<const f32x4*>(dz + rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    v[u] = ok ? *reinterpret_cast<const f32x4*>(y + rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float dp = g[u][e] * act_grad(v[u][e] * sc[e] + sh[e], act, slope);
+                        s1[e] += dp;
+                        s2[e] += dp * (v[u][e] - mu[e]) * is[e];
+                    }
             }
         }
         r1[tid] = s1; r2[tid] = s2;
@@ -138,39 +146,54 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 }
 
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, float* sums,
-                                    float* dgamma, float* dbeta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// sums over the row-block partials (fp64), 32 channels x 8 partial lanes per block.  Emits
+//   sums[0][c] = k0, sums[1][c] = k1  with  dy = scale*dpre + k1*(y-mean) + k0   (training-mode BN backward:
+//   dy = scale*(dpre - s1/M - xhat*s2/M), xhat = (y-mean)*invstd), plus dgamma = s2, dbeta = s1.
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, long M,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ scale, int training,
+                                                           float* sums, float* dgamma, float* dbeta) {
+    __shared__ double r1[8][32], r2[8][32];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += (double)part[((size_t)b * 2 + 0) * C + c];
-        s2 += (double)part[((size_t)b * 2 + 1) * C + c];
+    if (c < C)
+        for (int b = pl; b < nblk; b += 8) {
+            s1 += (double)part[((size_t)b * 2 + 0) * C + c];
+            s2 += (double)part[((size_t)b * 2 + 1) * C + c];
+        }
+    r1[pl][cl] = s1; r2[pl][cl] = s2;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { s1 += r1[k][cl]; s2 += r2[k][cl]; }
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
+        if (training) {
+            double sc = (double)scale[c];
+            sums[C + c] = (float)(-sc * s2 * (double)invstd[c] / (double)M);     // k1
+            sums[c] = (float)(-sc * s1 / (double)M);                              // k0
+        } else {
+            sums[c] = 0.f; sums[C + c] = 0.f;
+        }
     }
-    sums[c] = (float)s1; sums[C + c] = (float)s2;
-    if (dbeta) dbeta[c] = (float)s1;
-    if (dgamma) dgamma[c] = (float)s2;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const f32x4* __restrict__ dz, const f32x4* __restrict__ y, const float* __restrict__ mean,
-    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ sums, f32x4* __restrict__ dy, long n4, long M, int C, int act, float slope, int training) {
-    const int c4n = C / 4;
-    const float invM = 1.f / (float)M;
+    const f32x4* __restrict__ dz, const f32x4* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ sums, f32x4* __restrict__ dy,
+    long n4, int C, int act, float slope) {
+    const unsigned c4n = (unsigned)(C / 4);
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
-        const int c = (int)(i % c4n) * 4;
+        const int c = (int)((unsigned long)i % c4n) * 4;
         f32x4 g = dz[i], v = y[i], o;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(sums + c), k1 = *reinterpret_cast<const f32x4*>(sums + C + c);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float sc = scale[c + e];
-            float dp = g[e] * act_grad(v[e] * sc + shift[c + e], act, slope);
-            if (training) {
-                float xh = (v[e] - mean[c + e]) * invstd[c + e];
-                o[e] = sc * (dp - sums[c + e] * invM - xh * sums[C + c + e] * invM);
-            } else {
-                o[e] = sc * dp;
-            }
+            float dp = g[e] * act_grad(v[e] * sc[e] + sh[e], act, slope);
+            // (y - mean) first: keeps the fp32 rounding error relative to the centred value
+            o[e] = sc[e] * dp + (k1[e] * (v[e] - mu[e]) + k0[e]);
         }
         dy[i] = o;
     }
@@ -239,12 +262,12 @@ extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mea
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
     VIAI_LAUNCH(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope);
-    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, C, sums, dgamma, dbeta);
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training, sums, dgamma, dbeta);
     if (dy != nullptr) {
         long n4 = M * C / 4;
         VIAI_LAUNCH(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz),
-                           reinterpret_cast<const f32x4*>(y), mean, invstd, scale, shift, sums, reinterpret_cast<f32x4*>(dy),
-                           n4, M, C, act, slope, training);
+                           reinterpret_cast<const f32x4*>(y), mean, scale, shift, sums, reinterpret_cast<f32x4*>(dy),
+                           n4, C, act, slope);
     }
     return viai_launch_status();
 }

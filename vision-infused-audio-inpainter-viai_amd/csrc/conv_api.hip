@@ -131,8 +131,9 @@ extern "C" int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_
     int oh, ow;
     viai_conv2d_out_hw(c, &oh, &ow);
     long M = (long)c->N * oh * ow;
-    *rows_per_blk = 128;
-    *nblk = (int)((M + 127) / 128);
+    const int bm = (kind_of(c) == K_COUT1) ? 128 : viai_igemm_tile_m(M, c->Cout);
+    *rows_per_blk = bm;
+    *nblk = (int)((M + bm - 1) / bm);
     return 0;
 }
 

@@ -24,29 +24,33 @@ struct DirectArgs {
 __device__ __forceinline__ int tap_dy(const DirectArgs& a, int r) { return a.transposed ? a.ph - r : r - a.ph; }
 __device__ __forceinline__ int tap_dx(const DirectArgs& a, int s) { return a.transposed ? a.pw - s : s - a.pw; }
 
+// All kernels are templated on the (compile-time) kernel window KH x KW so that tap offsets, validity
+// tests and the weight registers are resolved at compile time (a runtime tap loop costs ~30 VALU
+// instructions of integer division per tap per pixel and made these kernels VALU-bound).
+
 // ------------------------------------------------------------------ Cin == 1
 // y[p][co] = sum_t x[p_t] * w[co][t];  thread = (pixel lane, 4 output channels)
 constexpr int CIN1_PB = 256;   // pixels per block == rows_per_blk of the BN partials
 
-template <int CG>   // channel groups of 4 (Cout = 4*CG)
+template <int CG, int KH, int KW>   // channel groups of 4 (Cout = 4*CG)
 __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
     constexpr int PG = 256 / CG;
     constexpr int IT = CIN1_PB / PG;
+    constexpr int T = KH * KW;
     __shared__ float red[PG][CG * 4];
     const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
-    const int T = a.kh * a.kw;
-    f32x4 wv[VIAI_MAX_TAPS];
+    f32x4 wv[T];
 #pragma unroll
-    for (int t = 0; t < VIAI_MAX_TAPS; ++t)
-        if (t < T) {
-            wv[t][0] = a.w[(cg * 4 + 0) * T + t]; wv[t][1] = a.w[(cg * 4 + 1) * T + t];
-            wv[t][2] = a.w[(cg * 4 + 2) * T + t]; wv[t][3] = a.w[(cg * 4 + 3) * T + t];
-        }
+    for (int t = 0; t < T; ++t) {
+        wv[t][0] = a.w[(cg * 4 + 0) * T + t]; wv[t][1] = a.w[(cg * 4 + 1) * T + t];
+        wv[t][2] = a.w[(cg * 4 + 2) * T + t]; wv[t][3] = a.w[(cg * 4 + 3) * T + t];
+    }
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + cg * 4);
     const int p0 = blockIdx.x * CIN1_PB;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     f32x4 vals[IT];
+    // decode the first pixel once, then walk (PG divides OW in all VIAI shapes; general carry handled)
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         int p = p0 + it * PG + pg;
@@ -54,13 +58,18 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
         if (p < a.M) {
             int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
             const float* xb = a.x + (size_t)n * a.IH * a.IW;
+            const int iy0 = oy * a.sh, ix0 = ox * a.sw;
 #pragma unroll
-            for (int t = 0; t < VIAI_MAX_TAPS; ++t)
-                if (t < T) {
-                    int iy = oy * a.sh + tap_dy(a, t / a.kw), ix = ox * a.sw + tap_dx(a, t % a.kw);
-                    float xv = ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
-                    v += xv * wv[t];
+            for (int r = 0; r < KH; ++r) {
+                const int iy = iy0 + tap_dy(a, r);
+                const bool yok = (unsigned)iy < (unsigned)a.IH;
+#pragma unroll
+                for (int q = 0; q < KW; ++q) {
+                    const int ix = ix0 + tap_dx(a, q);
+                    float xv = (yok && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
+                    v += xv * wv[r * KW + q];
                 }
+            }
             if (a.stat == nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = viai_act(v[e], a.act, a.slope);
@@ -101,58 +110,79 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
 }
 
 // dx[q] = sum_t sum_co dy[o_t(q)][co] * w[co][t]   (Cin == 1), LPP = Cout/4 lanes per input pixel
-template <int LPP>
+template <int LPP, int KH, int KW>
 __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
-    const int T = a.kh * a.kw;
-    const int gt = blockIdx.x * 256 + threadIdx.x;
-    const int q = gt / LPP, cl = gt % LPP;
-    const int total = a.N * a.IH * a.IW;
-    float accv = 0.f;
-    if (q < total) {
-        int ix = q % a.IW; int r_ = q / a.IW; int iy = r_ % a.IH; int n = r_ / a.IH;
-        for (int t = 0; t < T; ++t) {
-            int r = t / a.kw, s = t % a.kw;
-            int ny = iy - tap_dy(a, r), nx = ix - tap_dx(a, s);
-            if (ny < 0 || nx < 0 || ny % a.sh != 0 || nx % a.sw != 0) continue;
-            int oy = ny / a.sh, ox = nx / a.sw;
-            if (oy >= a.OH || ox >= a.OW) continue;
-            f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.Cout + cl * 4);
-            accv += d[0] * a.w[(cl * 4 + 0) * T + t] + d[1] * a.w[(cl * 4 + 1) * T + t]
-                  + d[2] * a.w[(cl * 4 + 2) * T + t] + d[3] * a.w[(cl * 4 + 3) * T + t];
-        }
-    }
+    constexpr int T = KH * KW;
+    const int cl = threadIdx.x % LPP;
+    f32x4 wv[T];
 #pragma unroll
-    for (int o = LPP / 2; o > 0; o >>= 1) accv += __shfl_xor(accv, o, 64);
-    if (q < total && cl == 0) a.dx[q] = accv;
+    for (int t = 0; t < T; ++t) {
+        wv[t][0] = a.w[(cl * 4 + 0) * T + t]; wv[t][1] = a.w[(cl * 4 + 1) * T + t];
+        wv[t][2] = a.w[(cl * 4 + 2) * T + t]; wv[t][3] = a.w[(cl * 4 + 3) * T + t];
+    }
+    const int total = a.N * a.IH * a.IW;
+    const int qstep = gridDim.x * (256 / LPP);
+    for (int q = blockIdx.x * (256 / LPP) + threadIdx.x / LPP; q < total + (256 / LPP); q += qstep) {
+        float accv = 0.f;
+        const bool live = q < total;
+        if (live) {
+            int ix = q % a.IW; int r_ = q / a.IW; int iy = r_ % a.IH; int n = r_ / a.IH;
+#pragma unroll
+            for (int r = 0; r < KH; ++r) {
+                const int ny = iy - tap_dy(a, r);
+                if (ny < 0 || ny % a.sh != 0) continue;
+                const int oy = ny / a.sh;
+                if (oy >= a.OH) continue;
+#pragma unroll
+                for (int s_ = 0; s_ < KW; ++s_) {
+                    const int nx = ix - tap_dx(a, s_);
+                    if (nx < 0 || nx % a.sw != 0) continue;
+                    const int ox = nx / a.sw;
+                    if (ox >= a.OW) continue;
+                    f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.Cout + cl * 4);
+                    const f32x4 w = wv[r * KW + s_];
+                    accv += d[0] * w[0] + d[1] * w[1] + d[2] * w[2] + d[3] * w[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) accv += __shfl_xor(accv, o, 64);
+        if (live && cl == 0) a.dx[q] = accv;
+        if (q >= total) break;
+    }
 }
 
 // ws[z][t][co] = sum over this block's pixels of dy[p][co] * x[p_t]   (Cin == 1)
-template <int CG>
+template <int CG, int KH, int KW>
 __global__ __launch_bounds__(256) void cin1_wgrad_kernel(const DirectArgs a, int pix_per_blk) {
     constexpr int PG = 256 / CG;
+    constexpr int T = KH * KW;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [PG][T][Cout]
     const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
-    const int T = a.kh * a.kw;
-    f32x4 acc[VIAI_MAX_TAPS];
+    f32x4 acc[T];
 #pragma unroll
-    for (int t = 0; t < VIAI_MAX_TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int p0 = blockIdx.x * pix_per_blk;
     const int p1 = min(p0 + pix_per_blk, a.M);
     for (int p = p0 + pg; p < p1; p += PG) {
         int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
         f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.Cout + cg * 4);
         const float* xb = a.x + (size_t)n * a.IH * a.IW;
+        const int iy0 = oy * a.sh, ix0 = ox * a.sw;
 #pragma unroll
-        for (int t = 0; t < VIAI_MAX_TAPS; ++t)
-            if (t < T) {
-                int iy = oy * a.sh + tap_dy(a, t / a.kw), ix = ox * a.sw + tap_dx(a, t % a.kw);
-                float xv = ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
-                acc[t] += d * xv;
+        for (int r = 0; r < KH; ++r) {
+            const int iy = iy0 + tap_dy(a, r);
+            const bool yok = (unsigned)iy < (unsigned)a.IH;
+#pragma unroll
+            for (int q = 0; q < KW; ++q) {
+                const int ix = ix0 + tap_dx(a, q);
+                float xv = (yok && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
+                acc[r * KW + q] += d * xv;
             }
+        }
     }
 #pragma unroll
-    for (int t = 0; t < VIAI_MAX_TAPS; ++t)
-        if (t < T) *reinterpret_cast<f32x4*>(smem + ((size_t)pg * T + t) * a.Cout + cg * 4) = acc[t];
+    for (int t = 0; t < T; ++t) *reinterpret_cast<f32x4*>(smem + ((size_t)pg * T + t) * a.Cout + cg * 4) = acc[t];
     __syncthreads();
     for (int i = tid; i < T * a.Cout; i += 256) {
         float s = 0.f;
@@ -163,82 +193,108 @@ __global__ __launch_bounds__(256) void cin1_wgrad_kernel(const DirectArgs a, int
 
 // ------------------------------------------------------------------ Cout == 1 (stride 1)
 // y[p] = act(b + sum_t <x[p_t][:], wp[t][:]>),  LPP lanes per pixel, CPL float4 per lane per tap
-template <int LPP, int CPL>
+template <int LPP, int CPL, int KH, int KW>
 __global__ __launch_bounds__(256) void cout1_fwd_kernel(const DirectArgs a) {
-    const int T = a.kh * a.kw;
-    const int gt = blockIdx.x * 256 + threadIdx.x;
-    const int p = gt / LPP, cl = gt % LPP;
-    float accv = 0.f;
-    if (p < a.M) {
-        int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
-        for (int t = 0; t < T; ++t) {
-            int iy = oy + tap_dy(a, t / a.kw), ix = ox + tap_dx(a, t % a.kw);
-            if ((unsigned)iy >= (unsigned)a.IH || (unsigned)ix >= (unsigned)a.IW) continue;
-            const float* xr = a.x + ((size_t)(n * a.IH + iy) * a.IW + ix) * a.Cin;
-            const float* wr = a.w + (size_t)t * a.Cin;
+    constexpr int T = KH * KW;
+    const int cl = threadIdx.x % LPP;
+    f32x4 wv[T][CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                f32x4 xv = *reinterpret_cast<const f32x4*>(xr + (c * LPP + cl) * 4);
-                f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (c * LPP + cl) * 4);
-                accv += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) wv[t][c] = *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.Cin + (c * LPP + cl) * 4);
+    const float bias = a.bias ? a.bias[0] : 0.f;
+    constexpr int PPB = 256 / LPP;
+    const int pstep = gridDim.x * PPB;
+    for (int p = blockIdx.x * PPB + threadIdx.x / LPP; p < a.M + PPB; p += pstep) {
+        float accv = 0.f;
+        const bool live = p < a.M;
+        if (live) {
+            int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
+#pragma unroll
+            for (int r = 0; r < KH; ++r) {
+                const int iy = oy + tap_dy(a, r);
+                if ((unsigned)iy >= (unsigned)a.IH) continue;
+#pragma unroll
+                for (int q = 0; q < KW; ++q) {
+                    const int ix = ox + tap_dx(a, q);
+                    if ((unsigned)ix >= (unsigned)a.IW) continue;
+                    const float* xr = a.x + ((size_t)(n * a.IH + iy) * a.IW + ix) * a.Cin;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        f32x4 xv = *reinterpret_cast<const f32x4*>(xr + (c * LPP + cl) * 4);
+                        const f32x4 w = wv[r * KW + q][c];
+                        accv += xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3];
+                    }
+                }
             }
         }
-    }
 #pragma unroll
-    for (int o = LPP / 2; o > 0; o >>= 1) accv += __shfl_xor(accv, o, 64);
-    if (p < a.M && cl == 0) a.y[p] = viai_act(accv + (a.bias ? a.bias[0] : 0.f), a.act, a.slope);
+        for (int o = LPP / 2; o > 0; o >>= 1) accv += __shfl_xor(accv, o, 64);
+        if (live && cl == 0) a.y[p] = viai_act(accv + bias, a.act, a.slope);
+        if (p >= a.M) break;
+    }
 }
 
-// dx[q][ci] = sum_t dy[o_t(q)] * wp[t][ci]
+// dx[q][ci] = sum_t dy[o_t(q)] * wp[t][ci]; thread = (pixel lane, fixed channel quad)
+template <int KH, int KW>
 __global__ __launch_bounds__(256) void cout1_dgrad_kernel(const DirectArgs a) {
-    const int T = a.kh * a.kw;
-    const int c4n = a.Cin / 4;
-    const long total = (long)a.N * a.IH * a.IW * c4n;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-        int c4 = (int)(i % c4n);
-        int q = (int)(i / c4n);
+    constexpr int T = KH * KW;
+    const int c4n = a.Cin / 4;              // divides 256
+    const int c4 = threadIdx.x % c4n;
+    f32x4 wv[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) wv[t] = *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.Cin + c4 * 4);
+    const int ppb = 256 / c4n;
+    const int totq = a.N * a.IH * a.IW;
+    for (int q = blockIdx.x * ppb + threadIdx.x / c4n; q < totq; q += gridDim.x * ppb) {
         int ix = q % a.IW; int r_ = q / a.IW; int iy = r_ % a.IH; int n = r_ / a.IH;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < T; ++t) {
-            int oy = iy - tap_dy(a, t / a.kw), ox = ix - tap_dx(a, t % a.kw);
-            if ((unsigned)oy >= (unsigned)a.OH || (unsigned)ox >= (unsigned)a.OW) continue;
-            float d = a.dy[(size_t)(n * a.OH + oy) * a.OW + ox];
-            v += d * *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.Cin + c4 * 4);
+#pragma unroll
+        for (int r = 0; r < KH; ++r) {
+            const int oy = iy - tap_dy(a, r);
+            if ((unsigned)oy >= (unsigned)a.OH) continue;
+#pragma unroll
+            for (int s_ = 0; s_ < KW; ++s_) {
+                const int ox = ix - tap_dx(a, s_);
+                if ((unsigned)ox >= (unsigned)a.OW) continue;
+                v += a.dy[(size_t)(n * a.OH + oy) * a.OW + ox] * wv[r * KW + s_];
+            }
         }
         *reinterpret_cast<f32x4*>(a.dx + (size_t)q * a.Cin + c4 * 4) = v;
     }
 }
 
 // ws[z][t][ci] = sum over this block's INPUT pixels q of x[q][ci] * dy[o_t(q)]
+template <int KH, int KW>
 __global__ __launch_bounds__(256) void cout1_wgrad_kernel(const DirectArgs a, int pix_per_blk) {
+    constexpr int T = KH * KW;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [PG][T][Cin]
-    const int T = a.kh * a.kw;
-    const int CG = a.Cin / 4;                 // <= 256
+    const int CG = a.Cin / 4;                 // <= 256, divides 256
     const int PG = 256 / CG;
     const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
-    f32x4 acc[VIAI_MAX_TAPS];
+    f32x4 acc[T];
 #pragma unroll
-    for (int t = 0; t < VIAI_MAX_TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int totq = a.N * a.IH * a.IW;
     const int q0 = blockIdx.x * pix_per_blk;
     const int q1 = min(q0 + pix_per_blk, totq);
-    if (pg < PG) {
-        for (int q = q0 + pg; q < q1; q += PG) {
-            int ix = q % a.IW; int r_ = q / a.IW; int iy = r_ % a.IH; int n = r_ / a.IH;
-            f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + (size_t)q * a.Cin + cg * 4);
+    for (int q = q0 + pg; q < q1; q += PG) {
+        int ix = q % a.IW; int r_ = q / a.IW; int iy = r_ % a.IH; int n = r_ / a.IH;
+        f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + (size_t)q * a.Cin + cg * 4);
 #pragma unroll
-            for (int t = 0; t < VIAI_MAX_TAPS; ++t)
-                if (t < T) {
-                    int oy = iy - tap_dy(a, t / a.kw), ox = ix - tap_dx(a, t % a.kw);
-                    float d = ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW)
-                                  ? a.dy[(size_t)(n * a.OH + oy) * a.OW + ox] : 0.f;
-                    acc[t] += xv * d;
-                }
+        for (int r = 0; r < KH; ++r) {
+            const int oy = iy - tap_dy(a, r);
+            const bool yok = (unsigned)oy < (unsigned)a.OH;
+#pragma unroll
+            for (int s_ = 0; s_ < KW; ++s_) {
+                const int ox = ix - tap_dx(a, s_);
+                float d = (yok && (unsigned)ox < (unsigned)a.OW) ? a.dy[(size_t)(n * a.OH + oy) * a.OW + ox] : 0.f;
+                acc[r * KW + s_] += xv * d;
+            }
         }
-#pragma unroll
-        for (int t = 0; t < VIAI_MAX_TAPS; ++t)
-            if (t < T) *reinterpret_cast<f32x4*>(smem + ((size_t)pg * T + t) * a.Cin + cg * 4) = acc[t];
     }
+#pragma unroll
+    for (int t = 0; t < T; ++t) *reinterpret_cast<f32x4*>(smem + ((size_t)pg * T + t) * a.Cin + cg * 4) = acc[t];
     __syncthreads();
     for (int i = tid; i < T * a.Cin; i += 256) {
         float s = 0.f;
@@ -247,13 +303,30 @@ __global__ __launch_bounds__(256) void cout1_wgrad_kernel(const DirectArgs a, in
     }
 }
 
-// dw[co*s_co + ci*s_ci + t] (+)= sum_z ws[z][t][co][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nz, int T,
-                                    int Cout, int Cin, long s_co, long s_ci, int accumulate) {
+// dw[co*s_co + ci*s_ci + t] (+)= sum_z ws[z][t][co][ci];  64 outputs x 4 z-lanes per block, fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nz, int T,
+                                                           int Cout, int Cin, long s_co, long s_ci, int accumulate) {
+    __shared__ float red[4][64];
     const long total = (long)T * Cout * Cin;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int z = 0; z < nz; ++z) s += ws[(size_t)z * total + i];
+    const int il = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const long i = blockIdx.x * 64L + il;
+    float s = 0.f;
+    if (i < total) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = zl;
+        for (; z + 12 < nz; z += 16) {
+            s0 += ws[(size_t)z * total + i];
+            s1 += ws[(size_t)(z + 4) * total + i];
+            s2 += ws[(size_t)(z + 8) * total + i];
+            s3 += ws[(size_t)(z + 12) * total + i];
+        }
+        for (; z < nz; z += 4) s0 += ws[(size_t)z * total + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[zl][il] = s;
+    __syncthreads();
+    if (zl == 0 && i < total) {
+        s = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
         int ci = (int)(i % Cin); long r = i / Cin; int co = (int)(r % Cout); int t = (int)(r / Cout);
         long o = co * s_co + ci * s_ci + t;
         dw[o] = accumulate ? dw[o] + s : s;
@@ -307,16 +380,28 @@ DirectArgs make_args(const viai_conv2d* c) {
 }  // namespace
 
 // ---- entry points used by conv_api.hip ------------------------------------
+// window dispatch: the VIAI layers use 3x3 and 1x4; others are rejected (hipErrorInvalidValue)
+#define VIAI_WINDOW_DISPATCH(c, CALL)                                  \
+    do {                                                               \
+        if ((c)->kh == 3 && (c)->kw == 3) { CALL(3, 3); }              \
+        else if ((c)->kh == 1 && (c)->kw == 4) { CALL(1, 4); }         \
+        else if ((c)->kh == 1 && (c)->kw == 1) { CALL(1, 1); }         \
+        else if ((c)->kh == 1 && (c)->kw == 3) { CALL(1, 3); }         \
+        else return (int)hipErrorInvalidValue;                         \
+    } while (0)
+
 int viai_cin1_fwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, float* y,
                   float* stat, int act, hipStream_t st) {
     DirectArgs a = make_args(c);
-    if (c->kh * c->kw > VIAI_MAX_TAPS) return (int)hipErrorInvalidValue;
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.stat = stat; a.act = act; a.slope = 0.2f;
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
-    if (c->Cout == 32) VIAI_LAUNCH(cin1_fwd_kernel<8>, dim3(a.nblk), dim3(256), 0, st, a);
-    else if (c->Cout == 64) VIAI_LAUNCH(cin1_fwd_kernel<16>, dim3(a.nblk), dim3(256), 0, st, a);
-    else if (c->Cout == 128) VIAI_LAUNCH(cin1_fwd_kernel<32>, dim3(a.nblk), dim3(256), 0, st, a);
-    else return (int)hipErrorInvalidValue;
+#define CALL(KH, KW)                                                                                             \
+    if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW>), dim3(a.nblk), dim3(256), 0, st, a);            \
+    else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW>), dim3(a.nblk), dim3(256), 0, st, a);      \
+    else if (c->Cout == 128) VIAI_LAUNCH((cin1_fwd_kernel<32, KH, KW>), dim3(a.nblk), dim3(256), 0, st, a);     \
+    else return (int)hipErrorInvalidValue
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
     return viai_launch_status();
 }
 
@@ -331,18 +416,22 @@ int viai_cin1_dgrad(const viai_conv2d* c, const float* dy, const float* w, float
     a.dy = dy; a.w = w; a.dx = dx;
     long tot = (long)a.N * a.IH * a.IW;
     int lpp = c->Cout / 4;
-    long threads = tot * lpp;
-    int blocks = (int)((threads + 255) / 256);
-    if (lpp == 8) VIAI_LAUNCH(cin1_dgrad_kernel<8>, dim3(blocks), dim3(256), 0, st, a);
-    else if (lpp == 16) VIAI_LAUNCH(cin1_dgrad_kernel<16>, dim3(blocks), dim3(256), 0, st, a);
-    else if (lpp == 32) VIAI_LAUNCH(cin1_dgrad_kernel<32>, dim3(blocks), dim3(256), 0, st, a);
-    else return (int)hipErrorInvalidValue;
+    long nb = (tot * lpp + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    int blocks = (int)nb;
+#define CALL(KH, KW)                                                                                            \
+    if (lpp == 8) VIAI_LAUNCH((cin1_dgrad_kernel<8, KH, KW>), dim3(blocks), dim3(256), 0, st, a);               \
+    else if (lpp == 16) VIAI_LAUNCH((cin1_dgrad_kernel<16, KH, KW>), dim3(blocks), dim3(256), 0, st, a);        \
+    else if (lpp == 32) VIAI_LAUNCH((cin1_dgrad_kernel<32, KH, KW>), dim3(blocks), dim3(256), 0, st, a);        \
+    else return (int)hipErrorInvalidValue
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
     return viai_launch_status();
 }
 
 static int direct_wgrad_blocks(long pixels) {
-    long b = (pixels + 1023) / 1024;
-    if (b > 512) b = 512;
+    long b = (pixels + 127) / 128;       // >= 128 pixels per block, up to 2048 partial slabs
+    if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -350,8 +439,7 @@ static int direct_wgrad_blocks(long pixels) {
 int viai_wgrad_reduce(const float* ws, float* dw, int nz, int T, int Cout, int Cin, long s_co, long s_ci,
                       int accumulate, hipStream_t st) {
     long total = (long)T * Cout * Cin;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (int)((total + 63) / 64);
     VIAI_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, nz, T, Cout, Cin, s_co, s_ci, accumulate);
     return viai_launch_status();
 }
@@ -369,10 +457,13 @@ int viai_cin1_wgrad(const viai_conv2d* c, const float* x, const float* dy, float
     int ppb = (a.M + nb - 1) / nb;
     int cg = c->Cout / 4;
     size_t lds = (size_t)(256 / cg) * T * c->Cout * sizeof(float);
-    if (cg == 8) VIAI_LAUNCH(cin1_wgrad_kernel<8>, dim3(nb), dim3(256), lds, st, a, ppb);
-    else if (cg == 16) VIAI_LAUNCH(cin1_wgrad_kernel<16>, dim3(nb), dim3(256), lds, st, a, ppb);
-    else if (cg == 32) VIAI_LAUNCH(cin1_wgrad_kernel<32>, dim3(nb), dim3(256), lds, st, a, ppb);
-    else return (int)hipErrorInvalidValue;
+#define CALL(KH, KW)                                                                                                  \
+    if (cg == 8) VIAI_LAUNCH((cin1_wgrad_kernel<8, KH, KW>), dim3(nb), dim3(256), lds, st, a, ppb);                   \
+    else if (cg == 16) VIAI_LAUNCH((cin1_wgrad_kernel<16, KH, KW>), dim3(nb), dim3(256), lds, st, a, ppb);            \
+    else if (cg == 32) VIAI_LAUNCH((cin1_wgrad_kernel<32, KH, KW>), dim3(nb), dim3(256), lds, st, a, ppb);            \
+    else return (int)hipErrorInvalidValue
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
     int e = viai_launch_status();
     if (e) return e;
     // torch layout [Cout][1][kh][kw] -> co*T + t
@@ -384,23 +475,34 @@ int viai_cout1_fwd(const viai_conv2d* c, const float* x, const float* wp, const 
     DirectArgs a = make_args(c);
     a.x = x; a.w = wp; a.bias = bias; a.y = y; a.act = act; a.slope = 0.2f;
     const int cin = a.Cin;
-    if (cin == 32) { int blocks = (int)(((long)a.M * 8 + 255) / 256); VIAI_LAUNCH((cout1_fwd_kernel<8, 1>), dim3(blocks), dim3(256), 0, st, a); }
-    else if (cin == 64) { int blocks = (int)(((long)a.M * 16 + 255) / 256); VIAI_LAUNCH((cout1_fwd_kernel<16, 1>), dim3(blocks), dim3(256), 0, st, a); }
-    else if (cin == 128) { int blocks = (int)(((long)a.M * 32 + 255) / 256); VIAI_LAUNCH((cout1_fwd_kernel<32, 1>), dim3(blocks), dim3(256), 0, st, a); }
-    else if (cin == 256) { int blocks = (int)(((long)a.M * 64 + 255) / 256); VIAI_LAUNCH((cout1_fwd_kernel<64, 1>), dim3(blocks), dim3(256), 0, st, a); }
-    else if (cin == 512) { int blocks = (int)(((long)a.M * 64 + 255) / 256); VIAI_LAUNCH((cout1_fwd_kernel<64, 2>), dim3(blocks), dim3(256), 0, st, a); }
-    else return (int)hipErrorInvalidValue;
+    const int lpp = cin >= 256 ? 64 : cin / 4;
+    long nb = ((long)a.M * lpp + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    const int blocks = (int)nb;
+#define CALL(KH, KW)                                                                                              \
+    if (cin == 32) VIAI_LAUNCH((cout1_fwd_kernel<8, 1, KH, KW>), dim3(blocks), dim3(256), 0, st, a);              \
+    else if (cin == 64) VIAI_LAUNCH((cout1_fwd_kernel<16, 1, KH, KW>), dim3(blocks), dim3(256), 0, st, a);        \
+    else if (cin == 128) VIAI_LAUNCH((cout1_fwd_kernel<32, 1, KH, KW>), dim3(blocks), dim3(256), 0, st, a);       \
+    else if (cin == 256) VIAI_LAUNCH((cout1_fwd_kernel<64, 1, KH, KW>), dim3(blocks), dim3(256), 0, st, a);       \
+    else if (cin == 512) VIAI_LAUNCH((cout1_fwd_kernel<64, 2, KH, KW>), dim3(blocks), dim3(256), 0, st, a);       \
+    else return (int)hipErrorInvalidValue
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
     return viai_launch_status();
 }
 
 int viai_cout1_dgrad(const viai_conv2d* c, const float* dy, const float* wp, float* dx, hipStream_t st) {
     if (c->sh != 1 || c->sw != 1 || c->C2 != 0 || (c->C1 % 4) != 0) return (int)hipErrorInvalidValue;
     DirectArgs a = make_args(c);
+    if (a.Cin / 4 > 256 || 256 % (a.Cin / 4) != 0) return (int)hipErrorInvalidValue;
     a.dy = dy; a.w = wp; a.dx = dx;
     long total = (long)a.N * a.IH * a.IW * (a.Cin / 4);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 65536) blocks = 65536;
-    VIAI_LAUNCH(cout1_dgrad_kernel, dim3(blocks), dim3(256), 0, st, a);
+    long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    const int blocks = (int)nb;
+#define CALL(KH, KW) VIAI_LAUNCH((cout1_dgrad_kernel<KH, KW>), dim3(blocks), dim3(256), 0, st, a)
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
     return viai_launch_status();
 }
 
@@ -420,7 +522,9 @@ int viai_cout1_wgrad(const viai_conv2d* c, const float* x, const float* dy, floa
     int ppb = (int)((q + nb - 1) / nb);
     int pg = 256 / (a.Cin / 4);
     size_t lds = (size_t)pg * T * a.Cin * sizeof(float);
-    VIAI_LAUNCH(cout1_wgrad_kernel, dim3(nb), dim3(256), lds, st, a, ppb);
+#define CALL(KH, KW) VIAI_LAUNCH((cout1_wgrad_kernel<KH, KW>), dim3(nb), dim3(256), lds, st, a, ppb)
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
     int e = viai_launch_status();
     if (e) return e;
     // conv [1][Cin][kh][kw] and convT [Cin][1][kh][kw] both flatten to ci*T + t

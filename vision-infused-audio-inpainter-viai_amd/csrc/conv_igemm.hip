@@ -26,6 +26,7 @@
 // (mean, M2) pairs that bn_finalize merges with Chan's formula in fp64.
 #include "viai_common.h"
 #include "viai_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -305,14 +306,26 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 }  // namespace
 
-int viai_igemm_tile_m(int cout) { (void)cout; return 128; }
-
-int viai_igemm_nblk_m(long M, int cout) { (void)cout; return (int)((M + 127) / 128); }
+// Tile choice.  128-row tiles give the best MFMA:load ratio but a launch needs >= ~2 blocks per CU
+// (256 CUs) to fill the chip; the small-M layers (E.conv4/5, G.deconv1_*, convblock2/3 at batch 16)
+// have only 16..256 such tiles, so they take 64x64 tiles (4x the blocks, 1/4 the per-block latency).
+int viai_igemm_tile_m(long M, int n_out) {
+    if (n_out <= 32) return 128;
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("VIAI_FORCE_TILE_M"); force = e ? atoi(e) : 0; }
+    if (force == 64 || force == 128) return force;
+    long b128 = ((M + 127) / 128) * ((n_out + 127) / 128);
+    if (n_out > 64) return b128 >= 512 ? 128 : 64;
+    long b64 = ((M + 127) / 128) * ((n_out + 63) / 64);
+    return b64 >= 512 ? 128 : 64;
+}
 
 int viai_conv_igemm_launch(ConvArgs& a, hipStream_t st) {
     const int Cin = a.C1 + a.C2;
     if (Cin % 32 != 0 || a.C1 % 32 != 0) return (int)hipErrorInvalidValue;
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
+    const int bm = viai_igemm_tile_m(a.M, a.Cout);
+    if (bm == 64) return launch_igemm<32, 1, 1, 2, 2>(a, st);
     if (a.Cout > 64) return launch_igemm<32, 2, 2, 2, 2>(a, st);
     if (a.Cout > 32) return launch_igemm<32, 2, 1, 2, 2>(a, st);
     return launch_igemm<32, 1, 1, 4, 1>(a, st);

@@ -29,6 +29,7 @@ struct WgradArgs {
 };
 
 int viai_conv_igemm_launch(ConvArgs& a, hipStream_t st);
+int viai_igemm_tile_m(long M, int n_out);
 int viai_wgrad_mfma_launch(WgradArgs& a, int ksplit, hipStream_t st);
 int viai_wgrad_pick_ksplit(int Cout, int Cin, int ntaps, long M);
 
