@@ -62,9 +62,9 @@ void viai_geom_fwd(const viai_conv2d* c, ConvGeom* g) {
     for (int r = 0; r < c->kh; ++r)
         for (int s = 0; s < c->kw; ++s) {
             int t = r * c->kw + s;
-            g->dy[t] = (signed char)(c->transposed ? c->ph - r : r - c->ph);
-            g->dx[t] = (signed char)(c->transposed ? c->pw - s : s - c->pw);
-            g->ws[t] = (signed char)t;
+            g->dy[t] = (c->transposed ? c->ph - r : r - c->ph);
+            g->dx[t] = (c->transposed ? c->pw - s : s - c->pw);
+            g->ws[t] = t;
         }
 }
 
@@ -91,7 +91,7 @@ int viai_geom_dgrad_class(const viai_conv2d* c, int a, int b, ConvGeom* g) {
                 if (((ny % c->sh) + c->sh) % c->sh != 0 || ((nx % c->sw) + c->sw) % c->sw != 0) continue;
                 dy = ny / c->sh; dx = nx / c->sw;   // exact (divisible), may be negative
             }
-            g->dy[nt] = (signed char)dy; g->dx[nt] = (signed char)dx; g->ws[nt] = (signed char)(r * c->kw + s);
+            g->dy[nt] = dy; g->dx[nt] = dx; g->ws[nt] = r * c->kw + s;
             ++nt;
         }
     g->ntaps = nt;

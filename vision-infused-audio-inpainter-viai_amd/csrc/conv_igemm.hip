@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int m0 = bm * BM, n0 = bn * BN;
     const int Cin = a.C1 + a.C2;
 
-    // ---- per-thread staging rows
+    // ---- per-thread staging rows.  Loads go through buffer descriptors: a lane whose row is out of the
+    // image (halo / M tail / Cout tail) gets an out-of-range offset and the hardware returns zeros, so
+    // the K loop has no divergent branches and 32-bit address math.
     const int q = tid % Q;
     const int r0 = tid / Q;
     int pixbase[NA];
@@ -76,15 +78,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             iy0[j] = -100000; ix0[j] = -100000; pixbase[j] = 0;
         }
     }
-    const float* brow[NB];
-    bool bok[NB];
+    constexpr int OOB = 0x7fffffff;
+    int brow[NB];                       // byte offset of this thread's weight rows (OOB when masked)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         int rr = r0 + RP * j;
         int co = n0 + rr;
-        bok[j] = (rr < BN) && (co < a.Cout);
-        brow[j] = a.wp + (size_t)(bok[j] ? co : 0) * g.wtaps * Cin + q * 4;
+        bool ok = (rr < BN) && (co < a.Cout);
+        brow[j] = ok ? (co * g.wtaps * Cin + q * 4) * 4 : OOB;
     }
+    const long in_pixels = (long)g.N * g.IH * g.IW;
+    const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * a.C1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in), 0,
+                                                                             (int)(in_pixels * (a.in2 ? a.C2 : a.C1) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, a.Cout * g.wtaps * Cin * 4, 0x00020000);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -97,39 +104,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int cchunks = Cin / BK;
     const int nchunks = g.ntaps * cchunks;
 
-    f32x4 areg[NA], breg[NB];
-    auto gload = [&](int t, int c0) {
+    u32x4 areg[NA], breg[NB];
+    auto gload = [&](int t_, int c0_) {
+        const int t = __builtin_amdgcn_readfirstlane(t_);      // wave-uniform -> scalar table loads
+        const int c0 = __builtin_amdgcn_readfirstlane(c0_);
         const int dyt = g.dy[t], dxt = g.dx[t];
         const int toff = dyt * g.IW + dxt;
-        const float* src; int cs, coff;
-        if (c0 < a.C1) { src = a.in; cs = a.C1; coff = c0; }
-        else { src = a.in2; cs = a.C2; coff = c0 - a.C1; }
+        const bool first = c0 < a.C1;
+        const int cs = first ? a.C1 : a.C2;
+        const int coff = (first ? c0 : c0 - a.C1) + q * 4;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int iy = iy0[j] + dyt, ix = ix0[j] + dxt;
             bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(src + (size_t)(pixbase[j] + toff) * cs + coff + q * 4);
-            areg[j] = v;
+            int off = ok ? ((pixbase[j] + toff) * cs + coff) * 4 : OOB;
+            areg[j] = first ? __builtin_amdgcn_raw_buffer_load_b128(rs_in1, off, 0, 0)
+                            : __builtin_amdgcn_raw_buffer_load_b128(rs_in2, off, 0, 0);
         }
-        const int woff = g.ws[t] * Cin + c0;
+        const int woff = (g.ws[t] * Cin + c0) * 4;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (bok[j]) v = *reinterpret_cast<const f32x4*>(brow[j] + woff);
-            breg[j] = v;
-        }
+        for (int j = 0; j < NB; ++j)
+            breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, brow[j] == OOB ? OOB : brow[j] + woff, 0, 0);
     };
     auto lstore = [&](int buf) {
         float* Ad = As + buf * BM * LS;
         float* Bd = Bs + buf * BN * LS;
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-            *reinterpret_cast<f32x4*>(Ad + (r0 + RP * j) * LS + q * 4) = areg[j];
+            *reinterpret_cast<u32x4*>(Ad + (r0 + RP * j) * LS + q * 4) = areg[j];
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            if (r0 + RP * j < BN)
-                *reinterpret_cast<f32x4*>(Bd + (r0 + RP * j) * LS + q * 4) = breg[j];
+            if (RP * (j + 1) <= BN || r0 + RP * j < BN)
+                *reinterpret_cast<u32x4*>(Bd + (r0 + RP * j) * LS + q * 4) = breg[j];
     };
 
     int t_next = 0, c_next = 0;

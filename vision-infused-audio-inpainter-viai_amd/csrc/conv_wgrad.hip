@@ -46,10 +46,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
     const int co0 = bco * BM, ci0 = bci * BN;
     const int Cin = a.C1 + a.C2;
 
-    const float* xsrc; int xcs, xoff;
-    if (ci0 < a.C1) { xsrc = a.x; xcs = a.C1; xoff = ci0; }
-    else { xsrc = a.x2; xcs = a.C2; xoff = ci0 - a.C1; }
+    const bool first = ci0 < a.C1;
+    const int xcs = first ? a.C1 : a.C2;
+    const int xoff = first ? ci0 : ci0 - a.C1;
     const int dyt = g.dy[t], dxt = g.dx[t];
+    constexpr int OOB = 0x7fffffff;
+    const long in_pixels = (long)g.N * g.IH * g.IW;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(first ? a.x : a.x2), 0, (int)(in_pixels * xcs * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((long)a.M * a.Cout * 4), 0x00020000);
 
     const int chunk0 = z * a.chunks_per_split;
     const int nchunks_total = (a.M + BKP - 1) / BKP;
@@ -64,45 +69,60 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    f32x4 dreg[NA], xreg[NB];
+    // per-thread staged rows: pixel coordinates are decoded once and advanced by BKP pixels per chunk
+    int dcol[NA];                          // byte offset of the dy column quad (OOB if past Cout)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int idx = tid + 256 * j;
+        int co = co0 + (idx % QA) * 4;
+        dcol[j] = co < a.Cout ? co * 4 : OOB;
+    }
+    int xo[NB], xy[NB], xn[NB], xcol[NB];  // ox, oy, n of the staged x rows; channel byte offset
+    const int step_x = BKP % g.OW, step_y = BKP / g.OW;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int idx = tid + 256 * j;
+        int row = idx / QB, c4 = idx % QB;
+        int p = chunk0 * BKP + row;
+        xo[j] = p % g.OW; int r = p / g.OW; xy[j] = r % g.OH; xn[j] = r / g.OH;
+        xcol[j] = (ci0 + c4 * 4 < Cin) ? (xoff + c4 * 4) * 4 : OOB;
+    }
+
+    u32x4 dreg[NA], xreg[NB];
     auto gload = [&](int chunk) {
         const int p0 = chunk * BKP;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int idx = tid + 256 * j;
-            int row = idx / QA, c4 = idx % QA;
-            int p = p0 + row;
-            int co = co0 + c4 * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < a.M && co < a.Cout) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.Cout + co);
-            dreg[j] = v;
+            int p = p0 + idx / QA;
+            int off = (p < a.M && dcol[j] != OOB) ? p * a.Cout * 4 + dcol[j] : OOB;
+            dreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            int idx = tid + 256 * j;
-            int row = idx / QB, c4 = idx % QB;
-            int p = p0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < a.M) {
-                int ox = p % g.OW; int r = p / g.OW; int oy = r % g.OH; int n = r / g.OH;
-                int iy = oy * g.my + dyt, ix = ox * g.mx + dxt;
-                int ci = ci0 + c4 * 4;
-                if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW && ci < Cin)
-                    v = *reinterpret_cast<const f32x4*>(xsrc + ((size_t)(n * g.IH + iy) * g.IW + ix) * xcs + xoff + c4 * 4);
-            }
-            xreg[j] = v;
+            int iy = xy[j] * g.my + dyt, ix = xo[j] * g.mx + dxt;
+            bool ok = xn[j] < g.N && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW && xcol[j] != OOB;
+            int off = ok ? ((xn[j] * g.IH + iy) * g.IW + ix) * xcs * 4 + xcol[j] : OOB;
+            xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+            // advance this row by BKP output pixels
+            int nx = xo[j] + step_x;
+            int carry = nx >= g.OW ? 1 : 0;
+            xo[j] = nx - carry * g.OW;
+            int ny = xy[j] + step_y + carry;
+            while (ny >= g.OH) { ny -= g.OH; ++xn[j]; }
+            xy[j] = ny;
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int idx = tid + 256 * j;
-            *reinterpret_cast<f32x4*>(Ds + buf * BKP * BM + idx * 4) = dreg[j];
+            *reinterpret_cast<u32x4*>(Ds + buf * BKP * BM + idx * 4) = dreg[j];
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int idx = tid + 256 * j;
-            *reinterpret_cast<f32x4*>(Xs + buf * BKP * BN + idx * 4) = xreg[j];
+            *reinterpret_cast<u32x4*>(Xs + buf * BKP * BN + idx * 4) = xreg[j];
         }
     };
 
@@ -206,7 +226,7 @@ int viai_wgrad_pick_ksplit(int Cout, int Cin, int ntaps, long M) {
     int bm = tile_of(Cout), bn = tile_of(Cin);
     long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * ntaps;
     long chunks = (M + BKP - 1) / BKP;
-    long ks = (1024 + tiles - 1) / tiles;          // aim for ~4 blocks per CU
+    long ks = 1024 / tiles;                        // just under two full rounds of 2 blocks/CU x 256 CUs
     long maxks = chunks / 8; if (maxks < 1) maxks = 1;  // at least 8 chunks (256 pixels) per block
     if (ks > maxks) ks = maxks;
     if (ks > 512) ks = 512;

@@ -8,6 +8,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #include "../../include/viai_hip.h"   // activation codes, ABI structs
 
@@ -28,7 +29,9 @@ struct ConvGeom {
     int my, mx;
     int ntaps;            // taps used by this launch
     int wtaps;            // tap slots per packed-weight row
-    signed char dy[VIAI_MAX_TAPS], dx[VIAI_MAX_TAPS], ws[VIAI_MAX_TAPS];
+    // 32-bit entries: the kernels index these with a wave-uniform tap id, which must lower to a scalar
+    // s_load (byte-sized entries became per-lane global loads + vmcnt(0) stalls in the K loop)
+    int dy[VIAI_MAX_TAPS], dx[VIAI_MAX_TAPS], ws[VIAI_MAX_TAPS];
 };
 
 __device__ __forceinline__ float viai_act(float v, int act, float slope) {
