@@ -96,7 +96,8 @@ int viai_bn_act_fwd(const float* y, const float* scale, const float* shift, floa
                     long M, int C, int act, float slope, void* stream);
 /* backward of the pair above (training-mode statistics):
  *   dgamma, dbeta (optional outputs) and dy.  part: scratch of 2*C*nblk floats,
- *   nblk from viai_bn_bwd_blocks(M, C).  training = 0 gives the eval-mode rule.  */
+ *   nblk from viai_bn_bwd_blocks(M, C).  `training` bit 0: 1 = batch statistics, 0 = eval-mode rule;
+ *   bit 1: accumulate into dgamma/dbeta instead of overwriting them.               */
 int viai_bn_bwd_blocks(long M, int C);
 int viai_bn_act_bwd(const float* dz, const float* y, const float* mean, const float* invstd,
                     const float* scale, const float* shift, float* part, float* sums,

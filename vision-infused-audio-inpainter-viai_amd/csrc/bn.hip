@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, long M,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ scale, int training,
-                                                           float* sums, float* dgamma, float* dbeta) {
+                                                           float* sums, float* dgamma, float* dbeta, int accumulate) {
     __shared__ double r1[8][32], r2[8][32];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
     __syncthreads();
     if (pl == 0 && c < C) {
         for (int k = 1; k < 8; ++k) { s1 += r1[k][cl]; s2 += r2[k][cl]; }
-        if (dbeta) dbeta[c] = (float)s1;
-        if (dgamma) dgamma[c] = (float)s2;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
         if (training) {
             double sc = (double)scale[c];
             sums[C + c] = (float)(-sc * s2 * (double)invstd[c] / (double)M);     // k1
@@ -262,7 +262,7 @@ extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mea
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
     VIAI_LAUNCH(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope);
-    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training, sums, dgamma, dbeta);
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1);
     if (dy != nullptr) {
         long n4 = M * C / 4;
         VIAI_LAUNCH(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz),

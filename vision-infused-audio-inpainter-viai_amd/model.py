@@ -288,6 +288,13 @@ class AudioModel:
 
     def optimize_parameters(self, global_step=0):
         """one G+D train step (train_whole_sync.py:76)."""
+        prev, ops.DIRECT_GRAD = ops.DIRECT_GRAD, True      # gradients land in the arenas in place
+        try:
+            self._optimize_parameters()
+        finally:
+            ops.DIRECT_GRAD = prev
+
+    def _optimize_parameters(self):
         if self.use_graph:
             if self._graphs is None:
                 self._capture()
@@ -306,8 +313,12 @@ class AudioModel:
 
     def forward_backward_no_update(self):
         """the step WITHOUT the two Adam updates (parity target, see oracle.step_no_update)."""
-        self._seg_forward_dstep()
-        self._seg_dupdate_gstep(update=False)
+        prev, ops.DIRECT_GRAD = ops.DIRECT_GRAD, True
+        try:
+            self._seg_forward_dstep()
+            self._seg_dupdate_gstep(update=False)
+        finally:
+            ops.DIRECT_GRAD = prev
 
     def test(self):
         """forward only (train_whole_sync.py:79-80; caller wraps in no_grad)."""

@@ -21,6 +21,11 @@ from ._lib import Conv2dDesc
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 BN_EPS = 1e-5
 
+# When True (set by model.AudioModel around its step), a parameter whose .grad already exists (a view of
+# the flat gradient arena) receives its gradient IN PLACE from the wgrad / BN-backward kernels
+# (accumulate mode) and autograd gets None for it: no per-parameter torch add launches.
+DIRECT_GRAD = False
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -142,18 +147,24 @@ class _ConvBnAct(torch.autograd.Function):
         dz = _c(dz)
         act = cfg["act"]
         need_x, need_x2, need_w, need_b, need_g, need_be = ctx.needs_input_grad[:6]
+        gt = cfg.get("gt") or (None, None, None, None)       # in-place gradient targets (arena views)
         dgamma = dbeta = None
         if ctx.has_bn:
             nblk = lib.viai_bn_bwd_blocks(M, Cout)
             part = torch.empty(2 * Cout * nblk, device=dev, dtype=torch.float32)
             sums = torch.empty(2 * Cout, device=dev, dtype=torch.float32)
-            dgamma = torch.empty(Cout, device=dev, dtype=torch.float32) if need_g else None
-            dbeta = torch.empty(Cout, device=dev, dtype=torch.float32) if need_be else None
+            acc_bn = gt[2] is not None and gt[3] is not None and need_g and need_be
+            if acc_bn:
+                pg, pb = gt[2], gt[3]
+            else:
+                dgamma = torch.empty(Cout, device=dev, dtype=torch.float32) if need_g else None
+                dbeta = torch.empty(Cout, device=dev, dtype=torch.float32) if need_be else None
+                pg, pb = dgamma, dbeta
             dy = torch.empty_like(dz)
             _lib.check(lib.viai_bn_act_bwd(dz.data_ptr(), y_or_z.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
                                            coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
-                                           _ptr(dgamma), _ptr(dbeta), dy.data_ptr(), M, Cout, act, 0.2,
-                                           1 if cfg["training"] else 0, st), "viai_bn_act_bwd")
+                                           _ptr(pg), _ptr(pb), dy.data_ptr(), M, Cout, act, 0.2,
+                                           (1 if cfg["training"] else 0) | (2 if acc_bn else 0), st), "viai_bn_act_bwd")
         elif act == ACT_NONE:
             dy = dz
         else:
@@ -163,18 +174,32 @@ class _ConvBnAct(torch.autograd.Function):
         dw = db = dx = dx2 = None
         if need_w or (need_b and ctx.has_bias):
             ws = torch.empty(d["ws_floats"], device=dev, dtype=torch.float32)
-            dw = torch.empty_like(weight)
+            shadowed = ctx.has_bn and cfg["training"]     # bias in front of train-mode BN: gradient is exactly 0
+            acc_w = gt[0] is not None and need_w
+            dw = gt[0] if acc_w else torch.empty_like(weight)
+            acc_b = False
             if ctx.has_bias and need_b:
-                if ctx.has_bn and cfg["training"]:
-                    # a bias in front of training-mode BN has an exactly-zero gradient (the batch mean absorbs it)
+                if gt[1] is not None:
+                    acc_b, db = True, gt[1]              # (+= 0 when shadowed: nothing to do)
+                elif shadowed:
                     db = torch.zeros(Cout, device=dev, dtype=torch.float32)
                 else:
                     db = torch.empty(Cout, device=dev, dtype=torch.float32)
-            want_db = db is not None and not (ctx.has_bn and cfg["training"])
-            _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                             dw.data_ptr(), db.data_ptr() if want_db else 0, 0, st), "viai_conv2d_wgrad")
-            if not need_w:
+            want_db = db is not None and not shadowed
+            if acc_w == acc_b or not want_db:
+                _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                 dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0, st),
+                           "viai_conv2d_wgrad")
+            else:   # mixed modes (only outside AudioModel): two calls keep the accumulate flag consistent
+                _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                 dw.data_ptr(), 0, 1 if acc_w else 0, st), "viai_conv2d_wgrad")
+                part_b = torch.empty(lib.viai_colsum_blocks(M, Cout) * Cout, device=dev, dtype=torch.float32)
+                _lib.check(lib.viai_colsum(dy.data_ptr(), M, Cout, part_b.data_ptr(), db.data_ptr(), 1 if acc_b else 0, st),
+                           "viai_colsum")
+            if acc_w or not need_w:
                 dw = None
+            if acc_b:
+                db = None
         if need_x or need_x2:
             wp = torch.empty(d["packed"], device=dev, dtype=torch.float32)
             _lib.check(lib.viai_conv2d_pack_dgrad(d["ref"], weight.data_ptr(), wp.data_ptr(), st), "viai_conv2d_pack_dgrad")
@@ -196,9 +221,15 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
         track = bn.track_running_stats and bn.running_mean is not None
         if not training and not track:
             cfg["training"] = True
+        if DIRECT_GRAD:
+            cfg["gt"] = tuple(p.grad if (p is not None and p.requires_grad and p.grad is not None) else None
+                              for p in (weight, bias, bn.weight, bn.bias))
         return _ConvBnAct.apply(x, x2, weight, bias, bn.weight, bn.bias,
                                 bn.running_mean if track else None, bn.running_var if track else None,
                                 bn.num_batches_tracked if (track and cfg["training"]) else None, cfg)
+    if DIRECT_GRAD:
+        cfg["gt"] = tuple(p.grad if (p is not None and p.requires_grad and p.grad is not None) else None
+                          for p in (weight, bias, None, None))
     return _ConvBnAct.apply(x, x2, weight, bias, None, None, None, None, None, cfg)
 
 
