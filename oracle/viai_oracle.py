@@ -147,6 +147,123 @@ def disc_state(tag="D.", input_nc=1, ndf=64) -> "OrderedDict[str, torch.Tensor]"
     return sd
 
 
+def decoder_variant_state(variant, tag="G."):
+    """state_dict layouts of MelDecoderImage / MelDecoderImage2 / MelDecoder_old
+    (networks/New_Inpainting_Networks.py:92-115, :146-169, :201-221)."""
+    sd = OrderedDict()
+
+    def convT(name, cin, cout, bias):
+        sd[name + ".weight"] = cf_std(tag + name, (cin, cout, 3, 3), math.sqrt(2.0 / (cin * 9)))
+        if bias:
+            sd[name + ".bias"] = cf_uniform(tag + name + ".bias", (cout,), -0.05, 0.05)
+
+    def block(bname, cin, cout, nums):
+        c = cin
+        for i in range(nums):
+            n = "convblock%s.conv%s_%d" % (bname, bname, i)
+            convT(n, c, cout, False)
+            _bn_entries(sd, n + "_bn", cout, tag)
+            c = cout
+    convT("deconv1_1", 256, 256, True)
+    _bn_entries(sd, "deconv1_1_bn", 256, tag)
+    if variant in ("image", "image2"):
+        convT("deconv1_1_1", 512, 256, True)
+        _bn_entries(sd, "deconv1_1_1_bn", 256, tag)
+    convT("deconv1_2", 256, 256, True)
+    _bn_entries(sd, "deconv1_2_bn", 256, tag)
+    if variant == "old":
+        block("1", 256, 256, 2)
+    block("2", 256, 128, 3)
+    block("3", 128, 64, 3)
+    if variant == "image":
+        block("4", 128, 32, 3)
+        block("5", 32, 32, 4)
+    else:
+        block("4", 64, 32, 3)
+        block("5", 64, 32, 2)
+    convT("conv6_1", 32, 32, True)
+    convT("conv6_2", 32, 1, True)
+    _bn_entries(sd, "conv6_1_bn", 32, tag)
+    return sd
+
+
+def decoder_variant_forward(sd, variant, net, x_size, video_net=None, training=True):
+    """MelDecoderImage.forward (:116-138), MelDecoderImage2.forward (:170-192), MelDecoder_old.forward (:223-242)."""
+    if variant in ("image", "image2"):
+        v = video_net.reshape(net[-1].shape[0], -1, net[-1].shape[2], net[-1].shape[3])    # :119
+        out = _convT(sd, "deconv1_1_1", torch.cat([net[-1], v], 1), (0, 1))                 # :120-121
+        out = F.relu(batch_norm(sd, "deconv1_1_1_bn", out, training))
+    else:
+        out = F.relu(batch_norm(sd, "deconv1_1_bn", _convT(sd, "deconv1_1", net[-1], (0, 1)), training))
+    out = F.relu(batch_norm(sd, "deconv1_2_bn", _convT(sd, "deconv1_2", out, (1, 1)), training))
+    skip_at = 3 if variant == "image" else 4
+    nums = {"2": 3, "3": 3, "4": 3, "5": 4 if variant == "image" else 2}
+    for i in range(1, len(net)):
+        out = bilinear_ac(out, net[-1 - i].shape[2:])
+        if i == skip_at:
+            out = torch.cat((out, net[-(i + 1)]), 1)
+        bname = str(i + 1)
+        for j in range(nums[bname]):
+            n = "convblock%s.conv%s_%d" % (bname, bname, j)
+            out = F.relu(batch_norm(sd, n + "_bn", _convT(sd, n, out, (1, 1)), training))
+    out = bilinear_ac(out, x_size[2:])
+    out = F.relu(batch_norm(sd, "conv6_1_bn", _convT(sd, "conv6_1", out, (1, 1)), training))
+    return torch.sigmoid(_convT(sd, "conv6_2", out, (1, 1)))
+
+
+def inpainting_dis_state(tag="ID."):
+    """Inpainting_Dis (networks/Discriminator_Networks.py:53-69)."""
+    sd = OrderedDict()
+
+    def conv(name, shape):
+        fan = int(np.prod(shape[1:]))
+        sd[name + ".weight"] = cf_std(tag + name, shape, math.sqrt(1.0 / fan))
+    conv("mel_conv1", (64, 1, 3, 3)); _bn_entries(sd, "mel_bn1", 64, tag)
+    conv("mel_conv2", (128, 64, 3, 3)); _bn_entries(sd, "mel_bn2", 128, tag)
+    conv("mel_conv3", (256, 128, 3, 3)); _bn_entries(sd, "mel_bn3", 256, tag)
+    conv("mel_conv4", (256, 256, 10, 1))
+    conv("vid_conv1", (256, 512, 3)); _bn_entries(sd, "vid_bn1", 256, tag)
+    conv("conv", (1, 512, 6))
+    return sd
+
+
+def batch_norm1d(sd, prefix, x, training=True):
+    """nn.BatchNorm1d on (B, C, L) == BatchNorm2d on (B, C, 1, L)."""
+    return batch_norm(sd, prefix, x.unsqueeze(2), training).squeeze(2)
+
+
+def inpainting_dis_forward(sd, mel, fea, training=True):
+    """Inpainting_Dis.forward (networks/Discriminator_Networks.py:71-87)."""
+    m = F.leaky_relu(batch_norm(sd, "mel_bn1", F.conv2d(mel, sd["mel_conv1.weight"], None, 2, 1), training), 0.2)
+    m = F.leaky_relu(batch_norm(sd, "mel_bn2", F.conv2d(m, sd["mel_conv2.weight"], None, 2, 1), training), 0.2)
+    m = F.leaky_relu(batch_norm(sd, "mel_bn3", F.conv2d(m, sd["mel_conv3.weight"], None, 2, 1), training), 0.2)
+    m = F.conv2d(m, sd["mel_conv4.weight"], None, 1)                                         # :79
+    v = F.leaky_relu(batch_norm1d(sd, "vid_bn1", F.conv1d(fea, sd["vid_conv1.weight"], None, 2, 1), training), 0.2)
+    net = torch.cat((m.squeeze(2), v), dim=1)                                                # :82-83
+    return torch.sigmoid(F.conv1d(net, sd["conv.weight"]).squeeze(1))                        # :84-86
+
+
+def domain_dis_state(tag="DD.", length_feature=256):
+    """DomainDis (networks/Discriminator_Networks.py:90-98)."""
+    sd = OrderedDict()
+    sd["conv1.weight"] = cf_std(tag + "conv1", (256, length_feature, 13), math.sqrt(1.0 / (length_feature * 13)))
+    sd["fc1.weight"] = cf_std(tag + "fc1", (256, 256), math.sqrt(1.0 / 256))
+    sd["fc1.bias"] = cf_uniform(tag + "fc1.b", (256,), -0.05, 0.05)
+    sd["fc2.weight"] = cf_std(tag + "fc2", (1, 256), math.sqrt(1.0 / 256))
+    sd["fc2.bias"] = cf_uniform(tag + "fc2.b", (1,), -0.05, 0.05)
+    return sd
+
+
+def domain_dis_forward(sd, x, length_feature=256):
+    """DomainDis.forward (networks/Discriminator_Networks.py:100-107)."""
+    x = x.reshape(-1, length_feature, 13)
+    out = F.relu(F.conv1d(x, sd["conv1.weight"]))
+    out = out.reshape(-1, 256)
+    out = F.linear(out, sd["fc1.weight"], sd["fc1.bias"])
+    out = F.linear(out, sd["fc2.weight"], sd["fc2.bias"])
+    return torch.sigmoid(out)
+
+
 def is_buffer(key: str) -> bool:
     return key.endswith("running_mean") or key.endswith("running_var") or key.endswith("num_batches_tracked")
 

@@ -192,6 +192,64 @@ def run_case(name, B, F_bins, T, steps, full):
           % (name, B, F_bins, T, steps, worst, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def av_goldens():
+    """AV decoders + sync / domain discriminators at the native MUSICES shape (80 x 208; SURVEY.md §8a:
+    MelDecoderImage needs bottleneck h == 1, Inpainting_Dis needs F/8 == 10, DomainDis needs T/16 == 13)."""
+    out = OrderedDict()
+    B, F_bins, T = 2, 80, 208
+    s = O.cf_uniform("av.s", (B, 1, F_bins, T))
+    video = O.cf_uniform("av.video", (B, 256, 1, 13), -1, 1)
+    fea = O.cf_uniform("av.fea", (B, 512, 52), -1, 1)
+    RefEnc.hparams.cin_channels = F_bins
+    E = load_into(RefEnc.MelEncoder(), O.encoder_state()); E.hparams.cin_channels = F_bins; E.train()
+    feats = [f.detach() for f in E(s.view(B, F_bins, T))]
+    ofeats = [f.detach() for f in O.encoder_forward(O.encoder_state(), s.view(B, F_bins, T))]
+    for variant, cls in (("image", RefDec.MelDecoderImage), ("image2", RefDec.MelDecoderImage2), ("old", RefDec.MelDecoder_old)):
+        G = load_into(cls(), O.decoder_variant_state(variant)); G.train()
+        args = (feats, s.size(), video) if variant != "old" else (feats, s.size())
+        fake = G(*args)
+        fake.mean().backward()
+        osd = O._leafify(O.decoder_variant_state(variant))
+        ofake = O.decoder_variant_forward(osd, variant, ofeats, s.shape, video if variant != "old" else None)
+        assert relerr(ofake, fake) < 5e-5, (variant, relerr(ofake, fake))
+        key = "deconv1_1_1.weight" if variant != "old" else "deconv1_1.weight"
+        (og,) = torch.autograd.grad(ofake.mean(), osd[key])
+        assert relerr(og, dict(G.named_parameters())[key].grad) < 2e-2, (variant, relerr(og, dict(G.named_parameters())[key].grad))
+        out["dec_%s.fake" % variant] = fake.detach().numpy()
+        out["dec_%s.g.%s.dg" % (variant, key)] = O.digest(dict(G.named_parameters())[key].grad)
+        out["dec_%s.g.conv6_2.weight.dg" % variant] = O.digest(G.conv6_2.weight.grad)
+    # init_deconv_1_1_1
+    G = RefDec.MelDecoderImage(); G.init_deconv_1_1_1()
+    assert torch.equal(G.deconv1_1_1.weight[:256], G.deconv1_1.weight) and torch.equal(G.deconv1_1_1.weight[256:], G.deconv1_1.weight)
+    # Inpainting_Dis
+    ID = load_into(RefDis.Inpainting_Dis(), O.inpainting_dis_state()); ID.train()
+    y = ID(s, fea)
+    y.mean().backward()
+    osd = O._leafify(O.inpainting_dis_state())
+    oy = O.inpainting_dis_forward(osd, s, fea)
+    assert tuple(y.shape) == (B, 21) and relerr(oy, y) < 5e-5, relerr(oy, y)
+    (og,) = torch.autograd.grad(oy.mean(), osd["mel_conv2.weight"])
+    assert relerr(og, ID.mel_conv2.weight.grad) < 5e-3
+    out["inp_dis.out"] = y.detach().numpy()
+    for k in ("mel_conv1.weight", "mel_conv4.weight", "vid_conv1.weight", "conv.weight", "vid_bn1.weight"):
+        out["inp_dis.g.%s.dg" % k] = O.digest(dict(ID.named_parameters())[k].grad)
+    # DomainDis
+    RefDis.hparams.length_feature = 256
+    DD = load_into(RefDis.DomainDis(), O.domain_dis_state())
+    emb = O.cf_uniform("av.emb", (4, 256, 1, 13), -1, 1)
+    y = DD(emb)
+    y.mean().backward()
+    osd = O._leafify(O.domain_dis_state())
+    oy = O.domain_dis_forward(osd, emb)
+    assert tuple(y.shape) == (4, 1) and relerr(oy, y) < 5e-6
+    out["dom_dis.out"] = y.detach().numpy()
+    for k in ("conv1.weight", "fc1.weight", "fc1.bias", "fc2.weight"):
+        out["dom_dis.g.%s.dg" % k] = O.digest(dict(DD.named_parameters())[k].grad)
+    path = os.path.join(OUT, "av.npz")
+    np.savez_compressed(path, **out)
+    print("av -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def adam_goldens():
     """torch.optim.Adam known-answer vectors (what the missing AudioModel's
     optimizer_G/optimizer_D are, utils/util.py:149-150)."""
@@ -257,6 +315,7 @@ if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count())
     layer_goldens()
     adam_goldens()
+    av_goldens()
     run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
     run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]
     if "--cfg2" in sys.argv:

@@ -387,6 +387,7 @@ DirectArgs make_args(const viai_conv2d* c) {
         else if ((c)->kh == 1 && (c)->kw == 4) { CALL(1, 4); }         \
         else if ((c)->kh == 1 && (c)->kw == 1) { CALL(1, 1); }         \
         else if ((c)->kh == 1 && (c)->kw == 3) { CALL(1, 3); }         \
+        else if ((c)->kh == 1 && (c)->kw == 6) { CALL(1, 6); }         \
         else return (int)hipErrorInvalidValue;                         \
     } while (0)
 

@@ -45,6 +45,11 @@ def to_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
     return x_nhwc.permute(0, 3, 1, 2)
 
 
+def _move_to_end(d, keys):
+    for k in keys:
+        d[k] = d.pop(k)
+
+
 def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
@@ -188,6 +193,69 @@ class MelDecoder(nn.Module):
         return to_nchw_view(self.forward_nhwc(net, (int(x_size[2]), int(x_size[3]))))
 
 
+class MelDecoderImage(MelDecoder):
+    """AV decoder: the video feature (B,256,1,T/16) is concatenated to the bottleneck on C and
+    `deconv1_1_1` (512->256) replaces `deconv1_1` (New_Inpainting_Networks.py:92-143).  `deconv1_1(+_bn)`
+    stay in the state_dict (unused by forward, exactly as in the reference); `convblock1` does not exist."""
+
+    def __init__(self, hparams=hparams, norm_layer=None):
+        super().__init__(hparams, norm_layer)
+        nl = type(self.deconv1_1_bn)
+        del self.convblock1
+        self.deconv1_1_1 = nn.ConvTranspose2d(256 * 2, 256, 3, 1, (0, 1))
+        self.deconv1_1_1_bn = nl(256)
+        self._reorder()
+
+    _ORDER = ("deconv1_1", "deconv1_1_bn", "deconv1_1_1", "deconv1_1_1_bn", "deconv1_2", "deconv1_2_bn", "convblock2",
+              "convblock3", "convblock4", "convblock5", "conv6_1", "conv6_2", "conv6_1_bn")
+
+    def _reorder(self):
+        # keep the reference's registration order so state_dict() key order matches too
+        _move_to_end(self._modules, self._ORDER)
+
+    def _head_av(self, net, video_net):
+        b, h, w = net[-1].shape[0], net[-1].shape[1], net[-1].shape[2]
+        v = video_net.reshape(b, -1, h, w)                      # reference: video_net.view(B, -1, h, w)   (:119)
+        v = to_nhwc(v)
+        out = fused_layer(net[-1], self.deconv1_1_1, self.deconv1_1_1_bn, ACT_RELU, x2=v)   # virtual concat (:120-122)
+        return fused_layer(out, self.deconv1_2, self.deconv1_2_bn, ACT_RELU)
+
+    def forward(self, net, x_size, video_net=None):
+        net = [to_nhwc(t) for t in net]
+        head = self._head_av(net, video_net)
+        return to_nchw_view(self.forward_nhwc(net, (int(x_size[2]), int(x_size[3])), head=head))
+
+    def init_deconv_1_1_1(self):
+        """duplicate the audio weight into both halves of the 512-ch layer (New_Inpainting_Networks.py:140-143)."""
+        w = self.deconv1_1.weight.detach().unsqueeze(0).expand(2, 256, 256, 3, 3).contiguous()
+        self.deconv1_1_1.weight.data.copy_(w.view(512, 256, 3, 3))
+
+
+class MelDecoderImage2(MelDecoderImage):
+    """as MelDecoderImage but the skip concat is with e1 at the LAST scale: convblock4 64->32,
+    convblock5 (32*2)->32 x2 (New_Inpainting_Networks.py:146-197)."""
+
+    def __init__(self, hparams=hparams, norm_layer=None):
+        super().__init__(hparams, norm_layer)
+        nl = type(self.deconv1_1_bn)
+        self.convblock4 = TransConvBlock(64, 32, "4", nums=3, norm_layer=nl)
+        self.convblock5 = TransConvBlock(32 * 2, 32, "5", nums=2, norm_layer=nl)
+        self.skip_at = 4
+        self._reorder()
+
+
+class MelDecoder_old(MelDecoder):
+    """audio-only decoder with the skip at the last scale (New_Inpainting_Networks.py:201-242)."""
+
+    def __init__(self, hparams=hparams, norm_layer=None):
+        super().__init__(hparams, norm_layer)
+        nl = type(self.deconv1_1_bn)
+        self.convblock4 = TransConvBlock(64, 32, "4", nums=3, norm_layer=nl)
+        self.convblock5 = TransConvBlock(32 * 2, 32, "5", nums=2, norm_layer=nl)
+        self.skip_at = 4
+        _move_to_end(self._modules, ("convblock4", "convblock5", "conv6_1", "conv6_2", "conv6_1_bn"))
+
+
 class MelDiscriminator(nn.Module):
     """PatchGAN D: Conv(1->ndf,(1,4),s(1,2),p(0,1)) BN LReLU; n_layers-1 x [Conv3x3 s2 BN LReLU];
     Conv3x3 s1 BN LReLU; Conv3x3 -> 1; Sigmoid (always on, as in Discriminator_Networks.py:13)."""
@@ -218,3 +286,67 @@ class MelDiscriminator(nn.Module):
 
     def forward(self, input):
         return to_nchw_view(self.forward_nhwc(to_nhwc(input)))
+
+
+class Inpainting_Dis(nn.Module):
+    """joint mel x video sync discriminator (Discriminator_Networks.py:53-87): mel path 3x[Conv3x3 s2 BN LReLU]
+    -> Conv(256,256,(10,1)); video path Conv1d(512,256,3,s2,p1) BN1d LReLU on fea_cat; cat on C ->
+    Conv1d(512,1,k6) -> Sigmoid.  Valid only when the mel height is 80 (F/8 == 10), as in the reference."""
+
+    def __init__(self):
+        super().__init__()
+        self.mel_conv1 = nn.Conv2d(1, 64, kernel_size=3, stride=2, padding=1, bias=False)
+        self.mel_bn1 = nn.BatchNorm2d(64)
+        self.mel_conv2 = nn.Conv2d(64, 128, 3, 2, 1, bias=False)
+        self.mel_bn2 = nn.BatchNorm2d(128)
+        self.mel_conv3 = nn.Conv2d(128, 256, 3, 2, 1, bias=False)
+        self.mel_bn3 = nn.BatchNorm2d(256)
+        self.mel_conv4 = nn.Conv2d(256, 256, (10, 1), 1, bias=False)
+        self.vid_conv1 = nn.Conv1d(512, 256, 3, 2, 1, bias=False)
+        self.vid_bn1 = nn.BatchNorm1d(256)
+        self.conv = nn.Conv1d(512, 1, 6, bias=False)
+
+    def forward(self, mel_inpainting, fea_inpainting):
+        m = fused_layer(to_nhwc(mel_inpainting), self.mel_conv1, self.mel_bn1, ACT_LRELU)
+        m = fused_layer(m, self.mel_conv2, self.mel_bn2, ACT_LRELU)
+        m = fused_layer(m, self.mel_conv3, self.mel_bn3, ACT_LRELU)
+        m = fused_layer(m, self.mel_conv4, None, ACT_NONE)              # (B, 1, W', 256)
+        v = fea_inpainting.transpose(1, 2).unsqueeze(1)                 # (B,512,N) -> NHWC (B,1,N,512)
+        v = conv1d_layer(v, self.vid_conv1, self.vid_bn1, ACT_LRELU)    # (B,1,N/2,256)
+        net = torch.cat((m, v), dim=3)                                  # cat on C (tiny tensors)
+        net = conv1d_layer(net, self.conv, None, ACT_SIGMOID)           # (B,1,W'-5,1)
+        return net.reshape(net.shape[0], net.shape[2])
+
+
+class DomainDis(nn.Module):
+    """Conv1d(256,256,k13) -> ReLU -> Linear(256,256) -> Linear(256,1) -> Sigmoid on 13-step embeddings
+    (Discriminator_Networks.py:90-107)."""
+
+    def __init__(self, hparams=hparams):
+        super().__init__()
+        self.length_feature = getattr(hparams, "length_feature", 256)
+        self.conv1 = nn.Conv1d(self.length_feature, 256, 13, 1, 0, bias=False)
+        self.fc1 = nn.Linear(256, 256)
+        self.fc2 = nn.Linear(256, 1)
+
+    def forward(self, input):
+        x = input.reshape(-1, self.length_feature, 13)                  # (B, C, 13)
+        x = x.transpose(1, 2).unsqueeze(1)                              # NHWC (B,1,13,C)
+        out = conv1d_layer(x, self.conv1, None, ACT_RELU)               # (B,1,1,256)
+        out = linear_layer(out, self.fc1, ACT_NONE)
+        out = linear_layer(out, self.fc2, ACT_SIGMOID)                  # (B,1,1,1)
+        return out.reshape(-1, 1)
+
+
+def conv1d_layer(x, conv, bn, act):
+    """nn.Conv1d (+BatchNorm1d) (+act) on NHWC (B,1,L,C): a (1,k) convolution."""
+    w = conv.weight.unsqueeze(2)                                         # (Cout,Cin,k) -> (Cout,Cin,1,k), a view
+    return ops.conv_bn_act(x, w, conv.bias, bn, kernel=(1, conv.kernel_size[0]), stride=(1, conv.stride[0]),
+                           padding=(0, conv.padding[0]), transposed=False, act=act,
+                           training=(bn.training if bn is not None else True))
+
+
+def linear_layer(x, fc, act):
+    """nn.Linear on NHWC (B,1,1,C): a 1x1 convolution with the (out,in) weight viewed as (out,in,1,1)."""
+    w = fc.weight.unsqueeze(2).unsqueeze(3)
+    return ops.conv_bn_act(x, w, fc.bias, None, kernel=(1, 1), stride=(1, 1), padding=(0, 0), transposed=False, act=act)
