@@ -130,6 +130,14 @@ int viai_mse_bwd(const float* p, float target, long n, const float* gscale, floa
 int viai_l1_fwd(const float* a, const float* b, long n, float* part, float* loss, void* stream);
 int viai_l1_bwd(const float* a, const float* b, long n, const float* gscale, float* da, void* stream);
 
+/* L2ContrastiveLoss (loss_functions.py:107-148): scores[a][b] = ||f1[a]-f2[b]||_2 (n x n, kept for the backward),
+ * loss = (sum_{a!=b} clamp(margin - s_ab, 0)^2 [or max over b per row if max_violation] + sum_a s_aa^2) / (2n).
+ * argmax_ws: n ints of scratch (max_violation only).                                                          */
+int viai_l2c_fwd(const float* f1, const float* f2, int n, int d, float margin, int max_violation,
+                 float* scores, float* loss, void* stream);
+int viai_l2c_bwd(const float* f1, const float* f2, const float* scores, int n, int d, float margin,
+                 int max_violation, const float* gscale, int* argmax_ws, float* df1, float* df2, void* stream);
+
 /* ------------------------------------------------------------ mask / optimizer
  * s_in = s * mask, mask (N, T) broadcast over frequency (the missing
  * AudioModel.set_inputs; figure misc/pipeline2.png)                             */

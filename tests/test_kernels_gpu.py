@@ -265,3 +265,41 @@ def test_ops_refuse_cpu_tensors():
     from viai_amd import ops, _lib
     with pytest.raises(_lib.ViaiLibraryError):
         ops.bilinear_ac(torch.zeros(1, 2, 2, 4), (4, 4))
+
+
+@pytest.mark.parametrize("mv", [False, True])
+def test_l2_contrastive_matches_reference_golden_and_autograd(mv, golden_dir):
+    from viai_amd import losses
+    gold = np.load(golden_dir + "/layers.npz")
+    f1 = O.cf_uniform("lg.f1", (6, 256), -1, 1)
+    f2 = O.cf_uniform("lg.f2", (6, 256), -1, 1)
+    crit = losses.L2ContrastiveLoss(margin=12.0, max_violation=mv)
+    a, b = f1.cuda().requires_grad_(True), f2.cuda().requires_grad_(True)
+    out = crit(a, b)
+    ref = float(gold["l2c_mv%d" % mv])                       # the reference's own L2ContrastiveLoss value
+    assert abs(out.item() - ref) < 1e-5 * abs(ref)
+    (out * 2.0).backward()
+    x, y = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    (O.l2_contrastive(x, y, 12.0, mv) * 2.0).backward()
+    assert relerr(a.grad, x.grad) < 1e-5
+    assert relerr(b.grad, y.grad) < 1e-5
+    # bigger, non-trivial margin hits
+    f1 = O.cf_uniform("l2c.f1", (52, 256), -1, 1)
+    f2 = O.cf_uniform("l2c.f2", (52, 256), -1, 1)
+    a, b = f1.cuda().requires_grad_(True), f2.cuda().requires_grad_(True)
+    out = losses.L2ContrastiveLoss(margin=13.0, max_violation=mv)(a, b)
+    x, y = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    ref = O.l2_contrastive(x, y, 13.0, mv)
+    assert abs(out.item() - ref.item()) < 1e-5 * abs(ref.item())
+    out.backward(); ref.backward()
+    assert relerr(a.grad, x.grad) < 1e-5 and relerr(b.grad, y.grad) < 1e-5
+
+
+def test_ganloss_module_matches_reference_semantics():
+    from viai_amd import losses
+    p = O.cf_uniform("gl.p", (4, 1, 8, 4), 0.01, 0.99)
+    for lsgan in (False, True):
+        crit = losses.GANLoss(use_lsgan=lsgan)
+        for real in (False, True):
+            out = crit(p.cuda(), real)
+            assert abs(out.item() - O.gan_loss(p, real, lsgan).item()) < 1e-5

@@ -64,6 +64,8 @@ SIGNATURES = {
     "viai_mse_bwd": (_I, [_P, _F, _L, _P, _P, _P]),
     "viai_l1_fwd": (_I, [_P, _P, _L, _P, _P, _P]),
     "viai_l1_bwd": (_I, [_P, _P, _L, _P, _P, _P]),
+    "viai_l2c_fwd": (_I, [_P, _P, _I, _I, _F, _I, _P, _P, _P]),
+    "viai_l2c_bwd": (_I, [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
     "viai_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "viai_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _D, _D, _D, _F, _P]),
     "viai_colsum_blocks": (_I, [_L, _I]),

@@ -346,6 +346,41 @@ def l1_mean(a, b):
     return _ScalarLoss.apply("l1", a, b, 0.0)
 
 
+class _L2Contrastive(torch.autograd.Function):
+    """L2ContrastiveLoss.forward (loss_functions.py:125-148)."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, margin, max_violation):
+        lib = _lib.load()
+        _require(f1, f2)
+        f1, f2 = _c(f1), _c(f2)
+        n, d = f1.shape
+        scores = torch.empty((n, n), device=f1.device, dtype=torch.float32)
+        loss = torch.empty((), device=f1.device, dtype=torch.float32)
+        _lib.check(lib.viai_l2c_fwd(f1.data_ptr(), f2.data_ptr(), n, d, margin, 1 if max_violation else 0,
+                                    scores.data_ptr(), loss.data_ptr(), _stream()), "viai_l2c_fwd")
+        ctx.save_for_backward(f1, f2, scores)
+        ctx.margin, ctx.mv = margin, bool(max_violation)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        f1, f2, scores = ctx.saved_tensors
+        n, d = f1.shape
+        g = _c(g)
+        arg = torch.empty(n, device=f1.device, dtype=torch.int32)
+        df1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
+        df2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.viai_l2c_bwd(f1.data_ptr(), f2.data_ptr(), scores.data_ptr(), n, d, ctx.margin, 1 if ctx.mv else 0,
+                                    g.data_ptr(), arg.data_ptr(), _ptr(df1), _ptr(df2), _stream()), "viai_l2c_bwd")
+        return df1, df2, None, None
+
+
+def l2_contrastive(f1, f2, margin=0.0, max_violation=False):
+    return _L2Contrastive.apply(f1, f2, float(margin), bool(max_violation))
+
+
 class _MaskMul(torch.autograd.Function):
     """s_in = s * mask, mask (N,T) broadcast over F (the missing AudioModel.set_inputs)."""
 
