@@ -116,6 +116,20 @@ int viai_bilinear_ac_bwd(const float* dy, float* dx, int N, int IH, int IW, int 
 int viai_avgpool_h_fwd(const float* x, float* y, int N, int IH, int W, int C, int k, void* stream);
 int viai_avgpool_h_bwd(const float* dy, float* dx, int N, int IH, int W, int C, int k, void* stream);
 
+/* ResNet-18 visual branch (networks/Image_Embedding.py:13-71, networks/ResNet.py:26-55).
+ * For 1 < C1 <= 4 (conv1 on RGB / flow frames) the conv entry points expect x stored with channel stride 4
+ * (zero padded): viai_nchw_to_nhwc4 produces that layout from the loader's NCHW frames.                */
+int viai_nchw_to_nhwc4(const float* x, float* y, long N, int C, long HW, void* stream);
+/* nn.MaxPool2d(k, s, p); idx: one byte per output element (window argmax) kept for the backward */
+int viai_maxpool_fwd(const float* x, float* y, unsigned char* idx, int N, int IH, int IW, int C, int k, int s, int p, void* stream);
+int viai_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int IH, int IW, int C, int k, int s, int p, void* stream);
+/* nn.AvgPool2d(7) on a 7x7 map: mean over the P = H*W positions */
+int viai_avgpool_hw_fwd(const float* x, float* y, int N, int P, int C, void* stream);
+int viai_avgpool_hw_bwd(const float* dy, float* dx, int N, int P, int C, void* stream);
+/* BasicBlock join: out = relu(a + b); backward d = g * (out > 0) (same for both addends) */
+int viai_add_relu_fwd(const float* a, const float* b, float* out, long n, void* stream);
+int viai_relu_bwd(const float* g, const float* out, float* d, long n, void* stream);
+
 /* ----------------------------------------------------------------------- losses
  * GANLoss = BCELoss / MSELoss against an expanded scalar label (loss_functions.py:79-104);
  * L1 is the `loss_mel_L1_item` metric (train_whole_sync.py:111).  Each forward

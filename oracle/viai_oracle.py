@@ -264,6 +264,86 @@ def domain_dis_forward(sd, x, length_feature=256):
     return torch.sigmoid(out)
 
 
+RESNET_PLANES = ((64, 1), (128, 2), (256, 2), (512, 2))     # (planes, stride of the first block); 2 BasicBlocks each
+
+
+def resnet_state(channel_size=3, length_feature=256, tag="R."):
+    """state_dict layout of the reference's local ResNet-18 (networks/Image_Embedding.py:13-53,
+    BasicBlock networks/ResNet.py:26-39)."""
+    sd = OrderedDict()
+
+    def conv(name, cout, cin, k):
+        sd[name + ".weight"] = cf_std(tag + name, (cout, cin, k, k), math.sqrt(2.0 / (k * k * cout)))
+    conv("conv1", 64, channel_size, 7)
+    _bn_entries(sd, "bn1", 64, tag)
+    inpl = 64
+    for li, (planes, stride) in enumerate(RESNET_PLANES):
+        for bi in range(2):
+            pre = "layer%d.%d" % (li + 1, bi)
+            conv(pre + ".conv1", planes, inpl if bi == 0 else planes, 3)
+            _bn_entries(sd, pre + ".bn1", planes, tag)
+            conv(pre + ".conv2", planes, planes, 3)
+            _bn_entries(sd, pre + ".bn2", planes, tag)
+            if bi == 0 and (stride != 1 or inpl != planes):
+                conv(pre + ".downsample.0", planes, inpl, 1)
+                _bn_entries(sd, pre + ".downsample.1", planes, tag)
+        inpl = planes
+    sd["fc.weight"] = cf_std(tag + "fc", (length_feature, 512), math.sqrt(1.0 / 512))
+    sd["fc.bias"] = cf_uniform(tag + "fc.b", (length_feature,), -0.05, 0.05)
+    return sd
+
+
+def resnet_forward(sd, x, training=True, prefix=""):
+    """ResNet.forward (networks/Image_Embedding.py:55-71) with BasicBlock.forward (networks/ResNet.py:36-55)."""
+    P = prefix
+    x = F.conv2d(x, sd[P + "conv1.weight"], None, 2, 3)
+    x = F.relu(batch_norm(sd, P + "bn1", x, training))
+    x = F.max_pool2d(x, 3, 2, 1)
+    inpl = 64
+    for li, (planes, stride) in enumerate(RESNET_PLANES):
+        for bi in range(2):
+            pre = P + "layer%d.%d" % (li + 1, bi)
+            st = stride if bi == 0 else 1
+            out = F.relu(batch_norm(sd, pre + ".bn1", F.conv2d(x, sd[pre + ".conv1.weight"], None, st, 1), training))
+            out = batch_norm(sd, pre + ".bn2", F.conv2d(out, sd[pre + ".conv2.weight"], None, 1, 1), training)
+            res = x
+            if pre + ".downsample.0.weight" in sd:
+                res = batch_norm(sd, pre + ".downsample.1", F.conv2d(x, sd[pre + ".downsample.0.weight"], None, st, 0), training)
+            x = F.relu(out + res)
+        inpl = planes
+    x = F.avg_pool2d(x, 7, 1).reshape(x.shape[0], -1)
+    return F.linear(x, sd[P + "fc.weight"], sd[P + "fc.bias"])
+
+
+def image_embedding2_state(length_feature=256, tag="IE."):
+    """ImageEmbedding2 / ImageEmbedding (networks/Image_Embedding.py:100-111,174-185)."""
+    sd = OrderedDict()
+    for k, v in resnet_state(3, length_feature, tag + "img.").items():
+        sd["image_single_model." + k] = v
+    for k, v in resnet_state(2, length_feature, tag + "flow.").items():
+        sd["flow_single_model." + k] = v
+    lf = length_feature
+    sd["conv_1.weight"] = cf_std(tag + "conv_1", (2 * lf, 2 * lf, 3), math.sqrt(1.0 / (2 * lf * 3)))
+    _bn_entries(sd, "bn_1", 2 * lf, tag)
+    sd["conv_2.weight"] = cf_std(tag + "conv_2", (lf, 2 * lf, 3), math.sqrt(1.0 / (2 * lf * 3)))
+    _bn_entries(sd, "bn_2", lf, tag)
+    return sd
+
+
+def image_embedding2_forward(sd, video_block, flow_block, image_size=224, length_feature=256, training=True, dead_bn=False):
+    """ImageEmbedding2.forward (networks/Image_Embedding.py:187-200); dead_bn=True gives ImageEmbedding.forward
+    (:113-126), whose `self.relu(self.bn_1(out))` only updates bn_1's running statistics."""
+    b = video_block.shape[0]
+    img = resnet_forward(sd, video_block.reshape(-1, 3, image_size, image_size), training, "image_single_model.")
+    flw = resnet_forward(sd, flow_block.reshape(-1, 2, image_size, image_size), training, "flow_single_model.")
+    fea_cat = torch.cat((img.reshape(b, -1, length_feature), flw.reshape(b, -1, length_feature)), 2).transpose(2, 1)
+    out = F.conv1d(fea_cat, sd["conv_1.weight"], None, 2, 1)
+    if dead_bn:
+        batch_norm1d(sd, "bn_1", out.detach(), training)
+    out = F.conv1d(out, sd["conv_2.weight"], None, 2, 1).unsqueeze(2)
+    return out, fea_cat
+
+
 def is_buffer(key: str) -> bool:
     return key.endswith("running_mean") or key.endswith("running_var") or key.endswith("num_batches_tracked")
 

@@ -1,0 +1,141 @@
+"""GPU parity of the visual branch: ResNet conv1 (7x7 s2, Cin 3/2, row-run MFMA mode), max-pool, residual join,
+1x1 stride-2 downsample, global average pool, fc, and ImageEmbedding2 / ImageEmbedding end to end against the
+oracle and the goldens produced by the reference's modules."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import viai_oracle as O
+
+
+def relerr(a, b):
+    a = torch.as_tensor(a).detach().double().cpu().reshape(-1)
+    b = torch.as_tensor(b).detach().double().cpu().reshape(-1)
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.detach().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+@pytest.mark.parametrize("cin,hw", [(3, (32, 40)), (2, (30, 30)), (3, (224, 224))])
+def test_conv7x7_s2_small_cin(cin, hw):
+    from viai_amd import ops
+    N = 2
+    x = O.cf_uniform("c7.x", (N, cin) + hw, -1, 1)
+    w = O.cf_std("c7.w", (64, cin, 7, 7), 0.05).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=2, padding=3)
+    gy = O.cf_uniform("c7.gy", tuple(y.shape), -1, 1)
+    y.backward(gy)
+    xg = ops.frames_to_nhwc4(x.cuda())
+    assert tuple(xg.shape) == (N,) + hw + (4,)
+    wg = w.detach().cuda().requires_grad_(True)
+    yg = ops.conv_bn_act(xg, wg, None, None, kernel=(7, 7), stride=(2, 2), padding=(3, 3))
+    assert relerr(nchw(yg), y) < 2e-5
+    yg.backward(nhwc(gy))
+    assert relerr(wg.grad, w.grad) < 2e-5
+
+
+def test_maxpool_addrelu_avgpool_match_torch():
+    from viai_amd import ops
+    x = O.cf_uniform("mp.x", (2, 64, 17, 22), -1, 1).requires_grad_(True)
+    x.data[0, 0, 2:4, 2:4] = 0.75            # a tie inside one window: first maximum wins, as in torch
+    y = F.max_pool2d(x, 3, 2, 1)
+    gy = O.cf_uniform("mp.gy", tuple(y.shape), -1, 1)
+    y.backward(gy)
+    xg = nhwc(x.detach()).requires_grad_(True)
+    yg = ops.maxpool(xg, 3, 2, 1)
+    assert torch.equal(nchw(yg), y.detach())
+    yg.backward(nhwc(gy))
+    assert relerr(nchw(xg.grad), x.grad) < 1e-6
+    a = O.cf_uniform("ar.a", (2, 32, 5, 6), -1, 1).requires_grad_(True)
+    b = O.cf_uniform("ar.b", (2, 32, 5, 6), -1, 1).requires_grad_(True)
+    z = F.relu(a + b)
+    gz = O.cf_uniform("ar.g", tuple(z.shape), -1, 1)
+    z.backward(gz)
+    ag, bg = nhwc(a.detach()).requires_grad_(True), nhwc(b.detach()).requires_grad_(True)
+    zg = ops.add_relu(ag, bg)
+    assert torch.equal(nchw(zg), z.detach())
+    zg.backward(nhwc(gz))
+    assert torch.equal(nchw(ag.grad), a.grad) and torch.equal(nchw(bg.grad), b.grad)
+    p = O.cf_uniform("ap.x", (3, 512, 7, 7), -1, 1).requires_grad_(True)
+    q = F.avg_pool2d(p, 7, 1)
+    gq = O.cf_uniform("ap.g", tuple(q.shape), -1, 1)
+    q.backward(gq)
+    pg = nhwc(p.detach()).requires_grad_(True)
+    qg = ops.avgpool_hw(pg)
+    assert relerr(nchw(qg), q) < 1e-6
+    qg.backward(nhwc(gq))
+    assert relerr(nchw(pg.grad), p.grad) < 1e-6
+
+
+def test_conv1x1_stride2_downsample_fwd_bwd():
+    from viai_amd import ops
+    x = O.cf_uniform("ds.x", (2, 64, 14, 14), -1, 1).requires_grad_(True)
+    w = O.cf_std("ds.w", (128, 64, 1, 1), 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=2)
+    gy = O.cf_uniform("ds.gy", tuple(y.shape), -1, 1)
+    y.backward(gy)
+    xg = nhwc(x.detach()).requires_grad_(True)
+    wg = w.detach().cuda().requires_grad_(True)
+    yg = ops.conv_bn_act(xg, wg, None, None, kernel=(1, 1), stride=(2, 2), padding=(0, 0))
+    assert relerr(nchw(yg), y) < 2e-5
+    yg.backward(nhwc(gy))
+    assert relerr(nchw(xg.grad), x.grad) < 2e-5      # 3 of 4 parity classes get exact zeros
+    assert relerr(wg.grad, w.grad) < 2e-5
+
+
+def test_image_embedding2_matches_oracle_and_golden(golden_dir):
+    from viai_amd import networks as N
+    gold = np.load(golden_dir + "/resnet.npz")
+    video = O.cf_uniform("ie.video", (1, 4, 3, 224, 224), -1, 1)
+    flow = O.cf_uniform("ie.flow", (1, 4, 2, 224, 224), -1, 1)
+    M = N.ImageEmbedding2().cuda(); M.load_state_dict(O.image_embedding2_state()); M.train()
+    out, fea = M(video.cuda(), flow.cuda())
+    assert tuple(out.shape) == (1, 256, 1, 1) and tuple(fea.shape) == (1, 512, 4)
+    assert relerr(fea, gold["fea_cat"]) < 2e-4
+    assert relerr(out, gold["out"]) < 2e-4
+    (out.pow(2).mean() + fea.pow(2).mean()).backward()
+    params = dict(M.named_parameters())
+    for k in ("image_single_model.conv1.weight", "flow_single_model.conv1.weight", "image_single_model.layer2.0.downsample.0.weight",
+              "image_single_model.layer4.1.conv2.weight", "image_single_model.fc.weight", "flow_single_model.layer1.0.bn1.weight",
+              "conv_1.weight", "conv_2.weight"):
+        dg, ref = O.digest(params[k].grad), gold["g.%s.dg" % k]
+        assert abs(dg[2] - ref[2]) < 3e-2 * ref[2], k
+        assert np.linalg.norm(dg[3:] - ref[3:]) < 6e-2 * (np.linalg.norm(ref[3:]) + 1e-12), k
+    assert M.bn_1.weight.grad is None
+    assert relerr(M.image_single_model.bn1.running_mean, gold["rm.image.bn1"]) < 1e-4
+    assert relerr(M.flow_single_model.layer3[0].downsample[1].running_var, gold["rv.flow.layer3.0.downsample.1"]) < 1e-4
+    # ImageEmbedding: dead bn_1 still moves its running statistics
+    M1 = N.ImageEmbedding().cuda(); M1.load_state_dict(O.image_embedding2_state()); M1.train()
+    o1 = M1(video.cuda(), flow.cuda())
+    assert relerr(o1, gold["ie1.out"]) < 2e-4
+    assert relerr(M1.bn_1.running_var, gold["ie1.bn_1.running_var"]) < 1e-3
+
+
+def test_av_generator_step_end_to_end():
+    """E_v -> MelDecoderImage -> losses incl. the contrastive sync term: gradients reach both ResNets."""
+    from viai_amd import losses, networks as N
+    B, F_bins, T, NF = 1, 80, 208, 52
+    s = O.cf_uniform("avs.s", (B, 1, F_bins, T)).cuda()
+    video = O.cf_uniform("avs.video", (B, 8, 3, 224, 224), -1, 1).cuda()
+    flow = O.cf_uniform("avs.flow", (B, 8, 2, 224, 224), -1, 1).cuda()
+    E, G, V = N.MelEncoder().cuda(), N.MelDecoderImage().cuda(), N.ImageEmbedding2().cuda()
+    feats = E(s.view(B, F_bins, T))
+    f_v, fea = V(video, flow)                                  # (B,256,1,2)
+    f_v13 = torch.nn.functional.interpolate(f_v, size=(1, 13), mode="nearest")      # tile the 2 steps onto the 13 bottleneck steps
+    fake = G(feats, s.size(), f_v13)
+    f_a = feats[-1].reshape(B, 256, 13).transpose(1, 2).reshape(-1, 256)
+    f_vv = f_v13.reshape(B, 256, 13).transpose(1, 2).reshape(-1, 256)
+    loss = torch.nn.functional.l1_loss(fake, s) + 0.1 * losses.L2ContrastiveLoss(margin=1.0)(f_a.contiguous(), f_vv.contiguous())
+    loss.backward()
+    assert torch.isfinite(loss).item()
+    for p in (V.image_single_model.conv1.weight, V.flow_single_model.layer4[1].conv2.weight, G.deconv1_1_1.weight, E.conv5.weight):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0

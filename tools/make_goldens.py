@@ -250,6 +250,42 @@ def av_goldens():
     print("av -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def resnet_goldens():
+    """ImageEmbedding2 (two ResNet-18s + temporal convs) on 4 frames of 224x224 (B=1, N=4)."""
+    from networks import Image_Embedding as RefIE
+    out = OrderedDict()
+    video = O.cf_uniform("ie.video", (1, 4, 3, 224, 224), -1, 1)
+    flow = O.cf_uniform("ie.flow", (1, 4, 2, 224, 224), -1, 1)
+    M = load_into(RefIE.ImageEmbedding2(), O.image_embedding2_state()); M.train()
+    o, fea = M(video, flow)
+    (o.pow(2).mean() + fea.pow(2).mean()).backward()
+    osd = O._leafify(O.image_embedding2_state())
+    oo, ofea = O.image_embedding2_forward(osd, video, flow)
+    assert tuple(o.shape) == (1, 256, 1, 1) and tuple(fea.shape) == (1, 512, 4)
+    assert relerr(ofea, fea) < 5e-5 and relerr(oo, o) < 5e-5, (relerr(ofea, fea), relerr(oo, o))
+    keys = ("image_single_model.conv1.weight", "flow_single_model.conv1.weight", "image_single_model.layer2.0.downsample.0.weight",
+            "image_single_model.layer4.1.conv2.weight", "image_single_model.fc.weight", "flow_single_model.layer1.0.bn1.weight", "conv_1.weight", "conv_2.weight")
+    og = torch.autograd.grad(oo.pow(2).mean() + ofea.pow(2).mean(), [osd[k] for k in keys])
+    for k, g in zip(keys, og):
+        e = relerr(g, dict(M.named_parameters())[k].grad)
+        assert e < 2e-2, (k, e)
+        out["g.%s.dg" % k] = O.digest(dict(M.named_parameters())[k].grad)
+    assert M.bn_1.weight.grad is None
+    out["out"] = o.detach().numpy(); out["fea_cat"] = fea.detach().numpy()
+    out["rm.image.bn1"] = M.image_single_model.bn1.running_mean.numpy().copy()
+    out["rv.flow.layer3.0.downsample.1"] = M.flow_single_model.layer3[0].downsample[1].running_var.numpy().copy()
+    # ImageEmbedding: bn_1 is dead except for its running statistics
+    M1 = load_into(RefIE.ImageEmbedding(), O.image_embedding2_state()); M1.train()
+    o1 = M1(video, flow)
+    sd1 = O.image_embedding2_state()
+    oo1, _ = O.image_embedding2_forward(sd1, video, flow, dead_bn=True)
+    assert relerr(oo1, o1) < 5e-5 and relerr(sd1["bn_1.running_var"], M1.bn_1.running_var) < 1e-4
+    out["ie1.out"] = o1.detach().numpy(); out["ie1.bn_1.running_var"] = M1.bn_1.running_var.numpy().copy()
+    path = os.path.join(OUT, "resnet.npz")
+    np.savez_compressed(path, **out)
+    print("resnet -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def adam_goldens():
     """torch.optim.Adam known-answer vectors (what the missing AudioModel's
     optimizer_G/optimizer_D are, utils/util.py:149-150)."""
@@ -316,6 +352,7 @@ if __name__ == "__main__":
     layer_goldens()
     adam_goldens()
     av_goldens()
+    resnet_goldens()
     run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
     run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]
     if "--cfg2" in sys.argv:

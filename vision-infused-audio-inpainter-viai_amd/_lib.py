@@ -57,6 +57,13 @@ SIGNATURES = {
     "viai_bilinear_ac_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "viai_avgpool_h_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "viai_avgpool_h_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "viai_nchw_to_nhwc4": (_I, [_P, _P, _L, _I, _L, _P]),
+    "viai_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "viai_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "viai_avgpool_hw_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "viai_avgpool_hw_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "viai_add_relu_fwd": (_I, [_P, _P, _P, _L, _P]),
+    "viai_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
     "viai_reduce_blocks": (_I, [_L]),
     "viai_bce_fwd": (_I, [_P, _F, _L, _P, _P, _P]),
     "viai_bce_bwd": (_I, [_P, _F, _L, _P, _P, _P]),

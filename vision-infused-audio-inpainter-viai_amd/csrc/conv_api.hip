@@ -21,17 +21,21 @@ extern "C" int viai_colsum(const float* x, long M, int C, float* part, float* ou
 static inline int cin_of(const viai_conv2d* c) { return c->C1 + c->C2; }
 static inline bool valid(const viai_conv2d* c) {
     if (!c || c->N <= 0 || c->IH <= 0 || c->IW <= 0 || c->C1 <= 0 || c->C2 < 0 || c->Cout <= 0) return false;
-    if (c->kh <= 0 || c->kw <= 0 || c->kh * c->kw > VIAI_MAX_TAPS) return false;
+    const bool runk = (cin_of(c) > 1 && cin_of(c) <= 4 && c->Cout > 1);     // row-run kind: taps are kernel rows
+    if (c->kh <= 0 || c->kw <= 0) return false;
+    if (runk ? (c->kh > VIAI_MAX_TAPS || c->kw > 8) : (c->kh * c->kw > VIAI_MAX_TAPS)) return false;
     if (c->sh <= 0 || c->sw <= 0 || c->ph < 0 || c->pw < 0) return false;
     if (c->transposed && (c->sh != 1 || c->sw != 1)) return false;
+    if (cin_of(c) > 1 && cin_of(c) <= 4 && c->Cout > 1 && (c->kw > 8 || c->transposed || c->C2 != 0)) return false;
     int oh, ow;
     viai_conv2d_out_hw(c, &oh, &ow);
     return oh > 0 && ow > 0;
 }
-enum { K_IGEMM = 0, K_CIN1 = 1, K_COUT1 = 2 };
+enum { K_IGEMM = 0, K_CIN1 = 1, K_COUT1 = 2, K_RUN = 3 };
 static inline int kind_of(const viai_conv2d* c) {
     if (cin_of(c) == 1) return K_CIN1;
     if (c->Cout == 1) return K_COUT1;
+    if (cin_of(c) <= 4) return K_RUN;       // ResNet conv1 (Cin 3 / 2): input stored with channel stride 4
     return K_IGEMM;
 }
 
@@ -49,15 +53,21 @@ extern "C" int viai_conv2d_out_hw(const viai_conv2d* c, int* OH, int* OW) {
 }
 
 extern "C" size_t viai_conv2d_packed_floats(const viai_conv2d* c) {
+    if (kind_of(c) == K_RUN) return (size_t)c->Cout * c->kh * 32;
     return (size_t)c->Cout * cin_of(c) * c->kh * c->kw;
 }
 
-void viai_geom_fwd(const viai_conv2d* c, ConvGeom* g) {
+static void geom_base(const viai_conv2d* c, ConvGeom* g) {
     int oh, ow;
     viai_conv2d_out_hw(c, &oh, &ow);
+    g->run = 0;
     g->N = c->N; g->IH = c->IH; g->IW = c->IW; g->OH = oh; g->OW = ow; g->SH = oh; g->SW = ow;
     g->ly = g->lx = 1; g->ay = g->ax = 0;
     g->my = c->sh; g->mx = c->sw;
+}
+
+void viai_geom_fwd(const viai_conv2d* c, ConvGeom* g) {
+    geom_base(c, g);
     g->ntaps = g->wtaps = c->kh * c->kw;
     for (int r = 0; r < c->kh; ++r)
         for (int s = 0; s < c->kw; ++s) {
@@ -66,6 +76,38 @@ void viai_geom_fwd(const viai_conv2d* c, ConvGeom* g) {
             g->dx[t] = (c->transposed ? c->pw - s : s - c->pw);
             g->ws[t] = t;
         }
+}
+
+// row-run geometry (1 < Cin <= 4): one "tap" per kernel row, K = 8 pixels x 4 channels per tap
+static void geom_run(const viai_conv2d* c, ConvGeom* g) {
+    geom_base(c, g);
+    g->run = 1;
+    g->ntaps = g->wtaps = c->kh;
+    for (int r = 0; r < c->kh; ++r) { g->dy[r] = r - c->ph; g->dx[r] = -c->pw; g->ws[r] = r; }
+}
+
+// wp[co][r][s*4+ch] = w[co][ch][r][s], zero for s >= kw or ch >= Cin
+__global__ void pack_run_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int kh, int kw) {
+    const int total = Cout * kh * 32;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int k = i % 32, r = (i / 32) % kh, co = i / (32 * kh);
+        int s_ = k / 4, ch = k % 4;
+        wp[i] = (s_ < kw && ch < Cin) ? w[((size_t)(co * Cin + ch) * kh + r) * kw + s_] : 0.f;
+    }
+}
+
+// dw[co][ch][r][s] (+)= sum_z ws[z][r][co][s*4+ch]
+__global__ void wgrad_reduce_run_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nz, int Cout, int Cin,
+                                        int kh, int kw, int accumulate) {
+    const int total = Cout * Cin * kh * kw;
+    const size_t slab = (size_t)kh * Cout * 32;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int s_ = i % kw, r = (i / kw) % kh, ch = (i / (kw * kh)) % Cin, co = i / (kw * kh * Cin);
+        size_t src = ((size_t)r * Cout + co) * 32 + s_ * 4 + ch;
+        float acc = 0.f;
+        for (int z = 0; z < nz; ++z) acc += ws[z * slab + src];
+        dw[i] = accumulate ? dw[i] + acc : acc;
+    }
 }
 
 // data gradient: produced tensor = dx (N, IH, IW, Cin), gathered tensor = dy (N, OH, OW, Cout).
@@ -106,6 +148,11 @@ extern "C" int viai_conv2d_pack_fwd(const viai_conv2d* c, const float* w, float*
         return viai_pack_weight(w, wp, c->Cout, 1, T, c->transposed ? T : (long)T, c->transposed ? (long)c->Cout * T : T, stream);
     case K_COUT1:   // wp[t][ci] == pack with n_out = 1 ... expressed as [1][T][Cin]
         return viai_pack_weight(w, wp, 1, Cin, T, 0, T, stream);
+    case K_RUN: {
+        int total = c->Cout * c->kh * 32;
+        VIAI_LAUNCH(pack_run_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, wp, c->Cout, Cin, c->kh, c->kw);
+        return viai_launch_status();
+    }
     default:
         if (c->transposed) return viai_pack_weight(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, stream);
         return viai_pack_weight(w, wp, c->Cout, Cin, T, (long)Cin * T, T, stream);
@@ -116,6 +163,7 @@ extern "C" int viai_conv2d_pack_dgrad(const viai_conv2d* c, const float* w, floa
     if (!valid(c)) return (int)hipErrorInvalidValue;
     const int T = c->kh * c->kw, Cin = cin_of(c);
     switch (kind_of(c)) {
+    case K_RUN: return (int)hipErrorInvalidValue;          // image inputs need no data gradient
     case K_CIN1:
     case K_COUT1:
         return viai_conv2d_pack_fwd(c, w, wp, stream);     // the streaming kernels share one image
@@ -153,7 +201,8 @@ extern "C" int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float
     a.in = x; a.in2 = x2; a.wp = wp; a.bias = bias; a.out = y; a.out2 = nullptr; a.stat = stat_part;
     a.C1 = c->C1; a.C2 = c->C2; a.Cout = c->Cout; a.OC1 = c->Cout;
     a.act = act; a.slope = 0.2f;
-    viai_geom_fwd(c, &a.g);
+    if (kind_of(c) == K_RUN) { geom_run(c, &a.g); a.C1 = 32; a.C2 = 0; }
+    else viai_geom_fwd(c, &a.g);
     a.M = a.g.N * a.g.OH * a.g.OW;
     return viai_conv_igemm_launch(a, st);
 }
@@ -164,7 +213,18 @@ extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const fl
     switch (kind_of(c)) {
     case K_CIN1: return viai_cin1_dgrad(c, dy, wp, dx, st);
     case K_COUT1: return viai_cout1_dgrad(c, dy, wp, dx, st);
+    case K_RUN: return (int)hipErrorInvalidValue;
     default: break;
+    }
+    {   // a parity class with no valid tap (e.g. 1x1 stride 2) receives no gradient: zero-fill first
+        bool empty = false;
+        for (int a_ = 0; a_ < c->sh && !empty; ++a_)
+            for (int b_ = 0; b_ < c->sw; ++b_) { ConvGeom g; if (viai_geom_dgrad_class(c, a_, b_, &g) == 0 && g.SH > 0 && g.SW > 0) { empty = true; break; } }
+        if (empty) {
+            size_t px = (size_t)c->N * c->IH * c->IW;
+            if (hipMemsetAsync(dx, 0, px * c->C1 * sizeof(float), st) != hipSuccess) return (int)hipErrorInvalidValue;
+            if (dx2 && hipMemsetAsync(dx2, 0, px * c->C2 * sizeof(float), st) != hipSuccess) return (int)hipErrorInvalidValue;
+        }
     }
     for (int a_ = 0; a_ < c->sh; ++a_)
         for (int b_ = 0; b_ < c->sw; ++b_) {
@@ -174,7 +234,7 @@ extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const fl
             a.act = VIAI_ACT_NONE; a.slope = 0.f;
             int nt = viai_geom_dgrad_class(c, a_, b_, &a.g);
             if (a.g.SH <= 0 || a.g.SW <= 0) continue;
-            if (nt == 0) return (int)hipErrorInvalidValue;   // a class with no taps would need a zero fill
+            if (nt == 0) continue;                            // zero-filled above
             a.M = a.g.N * a.g.SH * a.g.SW;
             int e = viai_conv_igemm_launch(a, st);
             if (e) return e;
@@ -188,6 +248,11 @@ extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
     switch (kind_of(c)) {
     case K_CIN1: fl = viai_cin1_wgrad_ws_floats(c); break;
     case K_COUT1: fl = viai_cout1_wgrad_ws_floats(c); break;
+    case K_RUN: {
+        int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
+        int ks = viai_wgrad_pick_ksplit(c->Cout, 32, c->kh, (long)c->N * oh * ow);
+        fl = (size_t)ks * viai_conv2d_packed_floats(c); break;
+    }
     default: {
         int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
         long M = (long)c->N * oh * ow;
@@ -212,6 +277,19 @@ extern "C" int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const flo
     switch (kind_of(c)) {
     case K_CIN1: e = viai_cin1_wgrad(c, x, dy, ws, dw, accumulate, st); used = viai_cin1_wgrad_ws_floats(c); break;
     case K_COUT1: e = viai_cout1_wgrad(c, x, dy, ws, dw, accumulate, st); used = viai_cout1_wgrad_ws_floats(c); break;
+    case K_RUN: {
+        WgradArgs a{};
+        a.x = x; a.x2 = nullptr; a.dy = dy; a.ws = ws; a.C1 = 32; a.C2 = 0; a.Cout = c->Cout; a.M = (int)M;
+        geom_run(c, &a.g);
+        int ks = viai_wgrad_pick_ksplit(c->Cout, 32, c->kh, M);
+        used = (size_t)ks * viai_conv2d_packed_floats(c);
+        e = viai_wgrad_mfma_launch(a, ks, st);
+        if (e) return e;
+        int total = c->Cout * Cin * T;
+        VIAI_LAUNCH(wgrad_reduce_run_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws, dw, ks, c->Cout, Cin, c->kh, c->kw, accumulate);
+        e = viai_launch_status();
+        break;
+    }
     default: {
         WgradArgs a{};
         a.x = x; a.x2 = x2; a.dy = dy; a.ws = ws; a.C1 = c->C1; a.C2 = c->C2; a.Cout = c->Cout; a.M = (int)M;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         brow[j] = ok ? (co * g.wtaps * Cin + q * 4) * 4 : OOB;
     }
     const long in_pixels = (long)g.N * g.IH * g.IW;
-    const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * a.C1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * (g.run ? 4 : a.C1) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in), 0,
                                                                              (int)(in_pixels * (a.in2 ? a.C2 : a.C1) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, a.Cout * g.wtaps * Cin * 4, 0x00020000);
@@ -111,13 +111,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const int dyt = g.dy[t], dxt = g.dx[t];
         const int toff = dyt * g.IW + dxt;
         const bool first = c0 < a.C1;
-        const int cs = first ? a.C1 : a.C2;
-        const int coff = (first ? c0 : c0 - a.C1) + q * 4;
+        const int cs = g.run ? 4 : (first ? a.C1 : a.C2);
+        const int coff = g.run ? 0 : ((first ? c0 : c0 - a.C1) + q * 4);
+        const int qpix = g.run ? q : 0;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            int iy = iy0[j] + dyt, ix = ix0[j] + dxt;
+            int iy = iy0[j] + dyt, ix = ix0[j] + dxt + qpix;
             bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
-            int off = ok ? ((pixbase[j] + toff) * cs + coff) * 4 : OOB;
+            int off = ok ? ((pixbase[j] + toff + qpix) * cs + coff) * 4 : OOB;
             areg[j] = first ? __builtin_amdgcn_raw_buffer_load_b128(rs_in1, off, 0, 0)
                             : __builtin_amdgcn_raw_buffer_load_b128(rs_in2, off, 0, 0);
         }

@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
     const int Cin = a.C1 + a.C2;
 
     const bool first = ci0 < a.C1;
-    const int xcs = first ? a.C1 : a.C2;
-    const int xoff = first ? ci0 : ci0 - a.C1;
+    const int xcs = g.run ? 4 : (first ? a.C1 : a.C2);
+    const int xoff = g.run ? 0 : (first ? ci0 : ci0 - a.C1);
     const int dyt = g.dy[t], dxt = g.dx[t];
     constexpr int OOB = 0x7fffffff;
     const long in_pixels = (long)g.N * g.IH * g.IW;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
         int row = idx / QB, c4 = idx % QB;
         int p = chunk0 * BKP + row;
         xo[j] = p % g.OW; int r = p / g.OW; xy[j] = r % g.OH; xn[j] = r / g.OH;
-        xcol[j] = (ci0 + c4 * 4 < Cin) ? (xoff + c4 * 4) * 4 : OOB;
+        xcol[j] = g.run ? c4 : ((ci0 + c4 * 4 < Cin) ? (xoff + c4 * 4) * 4 : OOB);   // run mode: pixel offset of the quad
     }
 
     u32x4 dreg[NA], xreg[NB];
@@ -100,9 +100,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            int iy = xy[j] * g.my + dyt, ix = xo[j] * g.mx + dxt;
+            int iy = xy[j] * g.my + dyt, ix = xo[j] * g.mx + dxt + (g.run ? xcol[j] : 0);
             bool ok = xn[j] < g.N && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW && xcol[j] != OOB;
-            int off = ok ? ((xn[j] * g.IH + iy) * g.IW + ix) * xcs * 4 + xcol[j] : OOB;
+            int off = ok ? ((xn[j] * g.IH + iy) * g.IW + ix) * xcs * 4 + (g.run ? 0 : xcol[j]) : OOB;
             xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
             // advance this row by BKP output pixels
             int nx = xo[j] + step_x;

@@ -117,6 +117,112 @@ __global__ __launch_bounds__(256) void avgpool_h_bwd_kernel(const float* __restr
     }
 }
 
+// nn.MaxPool2d(k, s, p) on NHWC with the window argmax kept as one byte per output element (first maximum in
+// row-major window order, like torch) so that the backward is an exact gather.  (networks/Image_Embedding.py:21)
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                                          int N, int IH, int IW, int OH, int OW, int C, int k, int st, int pd) {
+    const int c4n = C / 4;
+    const long total = (long)N * OH * OW * c4n;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int c4 = (int)(i % c4n); long r = i / c4n;
+        int ox = (int)(r % OW); r /= OW;
+        int oy = (int)(r % OH); int n = (int)(r / OH);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned bi[4] = {0, 0, 0, 0};
+        for (int a = 0; a < k; ++a) {
+            int iy = oy * st - pd + a;
+            if ((unsigned)iy >= (unsigned)IH) continue;
+            for (int b = 0; b < k; ++b) {
+                int ix = ox * st - pd + b;
+                if ((unsigned)ix >= (unsigned)IW) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * IH + iy) * IW + ix) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (v[e] > best[e]) { best[e] = v[e]; bi[e] = a * k + b; }
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = best;
+        *reinterpret_cast<unsigned*>(idx + (size_t)i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx,
+                                                          int N, int IH, int IW, int OH, int OW, int C, int k, int st, int pd) {
+    const int c4n = C / 4;
+    const long total = (long)N * IH * IW * c4n;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int c4 = (int)(i % c4n); long r = i / c4n;
+        int ix = (int)(r % IW); r /= IW;
+        int iy = (int)(r % IH); int n = (int)(r / IH);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // windows (oy, ox) that contain (iy, ix): oy*st - pd <= iy <= oy*st - pd + k - 1
+        int oy_lo = (iy + pd - k + 1 + st - 1) / st; if (iy + pd - k + 1 < 0) oy_lo = 0;
+        int ox_lo = (ix + pd - k + 1 + st - 1) / st; if (ix + pd - k + 1 < 0) ox_lo = 0;
+        int oy_hi = min((iy + pd) / st, OH - 1), ox_hi = min((ix + pd) / st, OW - 1);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                unsigned want = (unsigned)((iy - (oy * st - pd)) * k + (ix - (ox * st - pd)));
+                size_t o = (((size_t)n * OH + oy) * OW + ox) * c4n + c4;
+                unsigned pk = *reinterpret_cast<const unsigned*>(idx + o * 4);
+                f32x4 g = *reinterpret_cast<const f32x4*>(dy + o * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (((pk >> (8 * e)) & 0xffu) == want) acc[e] += g[e];
+            }
+        *reinterpret_cast<f32x4*>(dx + (size_t)i * 4) = acc;
+    }
+}
+
+// nn.AvgPool2d(7) on a 7x7 map == mean over HW (networks/Image_Embedding.py:27,66): y[n][c] = mean_p x[n][p][c]
+__global__ __launch_bounds__(256) void avgpool_hw_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int P, int C) {
+    const long total = (long)N * C;
+    const float inv = 1.f / (float)P;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int c = (int)(i % C); int n = (int)(i / C);
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += x[((size_t)n * P + p) * C + c];
+        y[i] = s * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_hw_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int P, int C) {
+    const long total = (long)N * P * C;
+    const float inv = 1.f / (float)P;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int c = (int)(i % C); int n = (int)(i / ((long)P * C));
+        dx[i] = dy[(size_t)n * C + c] * inv;
+    }
+}
+
+// residual join of BasicBlock: out = relu(a + b)  (networks/ResNet.py:51-52); backward: da = db = dout * (out > 0)
+__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ o, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        f32x4 v = a[i] + b[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        o[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ o, f32x4* __restrict__ d, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        f32x4 gv = g[i], ov = o[i], r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ov[e] > 0.f ? gv[e] : 0.f;
+        d[i] = r;
+    }
+}
+
+// frames (N, C, H, W) NCHW -> (N, H, W, 4) NHWC with zero-padded channels (C <= 4): the layout conv1 of the
+// ResNets consumes (Image_Embedding.py:188-189 view(-1, 3|2, 224, 224))
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long N, int C, long HW) {
+    const long total = N * HW;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        long n = i / HW, p = i % HW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) v[c] = x[(n * C + c) * HW + p];
+        y[i] = v;
+    }
+}
+
 inline int ew_blocks(long n) {
     long b = (n + 255) / 256;
     if (b > 8192) b = 8192;
@@ -151,5 +257,51 @@ extern "C" int viai_avgpool_h_bwd(const float* dy, float* dx, int N, int IH, int
     if (C % 4 != 0 || k <= 0 || IH / k <= 0) return (int)hipErrorInvalidValue;
     long total = (long)N * IH * W * (C / 4);
     VIAI_LAUNCH(avgpool_h_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, IH, W, C, k);
+    return viai_launch_status();
+}
+
+extern "C" int viai_maxpool_fwd(const float* x, float* y, unsigned char* idx, int N, int IH, int IW, int C, int k, int s, int p, void* stream) {
+    if (C % 4 != 0 || k * k > 255) return (int)hipErrorInvalidValue;
+    int OH = (IH + 2 * p - k) / s + 1, OW = (IW + 2 * p - k) / s + 1;
+    long total = (long)N * OH * OW * (C / 4);
+    VIAI_LAUNCH(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, IH, IW, OH, OW, C, k, s, p);
+    return viai_launch_status();
+}
+
+extern "C" int viai_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int IH, int IW, int C, int k, int s, int p, void* stream) {
+    if (C % 4 != 0) return (int)hipErrorInvalidValue;
+    int OH = (IH + 2 * p - k) / s + 1, OW = (IW + 2 * p - k) / s + 1;
+    long total = (long)N * IH * IW * (C / 4);
+    VIAI_LAUNCH(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, IH, IW, OH, OW, C, k, s, p);
+    return viai_launch_status();
+}
+
+extern "C" int viai_avgpool_hw_fwd(const float* x, float* y, int N, int P, int C, void* stream) {
+    VIAI_LAUNCH(avgpool_hw_fwd_kernel, dim3(ew_blocks((long)N * C)), dim3(256), 0, (hipStream_t)stream, x, y, N, P, C);
+    return viai_launch_status();
+}
+
+extern "C" int viai_avgpool_hw_bwd(const float* dy, float* dx, int N, int P, int C, void* stream) {
+    VIAI_LAUNCH(avgpool_hw_bwd_kernel, dim3(ew_blocks((long)N * P * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, P, C);
+    return viai_launch_status();
+}
+
+extern "C" int viai_add_relu_fwd(const float* a, const float* b, float* out, long n, void* stream) {
+    if (n % 4 != 0) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(add_relu_fwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(a),
+                reinterpret_cast<const f32x4*>(b), reinterpret_cast<f32x4*>(out), n / 4);
+    return viai_launch_status();
+}
+
+extern "C" int viai_relu_bwd(const float* g, const float* out, float* d, long n, void* stream) {
+    if (n % 4 != 0) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(relu_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(g),
+                reinterpret_cast<const f32x4*>(out), reinterpret_cast<f32x4*>(d), n / 4);
+    return viai_launch_status();
+}
+
+extern "C" int viai_nchw_to_nhwc4(const float* x, float* y, long N, int C, long HW, void* stream) {
+    if (C < 1 || C > 4) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(nchw_to_nhwc4_kernel, dim3(ew_blocks(N * HW)), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<f32x4*>(y), N, C, HW);
     return viai_launch_status();
 }

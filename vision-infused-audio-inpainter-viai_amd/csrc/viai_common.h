@@ -28,6 +28,8 @@ struct ConvGeom {
     int ly, lx, ay, ax;
     int my, mx;
     int ntaps;            // taps used by this launch
+    int run;              // 1: "row-run" mode for 1 < Cin <= 4 (ResNet conv1 7x7): a tap is a whole kernel ROW and
+                          //    its 32 K-values are 8 consecutive pixels x 4 (zero-padded) channels; lane quad q <-> pixel +q
     int wtaps;            // tap slots per packed-weight row
     // 32-bit entries: the kernels index these with a wave-uniform tap id, which must lower to a scalar
     // s_load (byte-sized entries became per-lane global loads + vmcnt(0) stalls in the K loop)

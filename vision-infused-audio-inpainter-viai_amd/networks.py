@@ -350,3 +350,172 @@ def linear_layer(x, fc, act):
     """nn.Linear on NHWC (B,1,1,C): a 1x1 convolution with the (out,in) weight viewed as (out,in,1,1)."""
     w = fc.weight.unsqueeze(2).unsqueeze(3)
     return ops.conv_bn_act(x, w, fc.bias, None, kernel=(1, 1), stride=(1, 1), padding=(0, 0), transposed=False, act=act)
+
+
+# --------------------------------------------------------------------------- visual branch (ResNet-18)
+class BasicBlock(nn.Module):
+    """networks/ResNet.py:26-55: conv3x3(s) BN ReLU conv3x3 BN (+ downsample(x)) -> add -> ReLU."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward_nhwc(self, x):
+        out = fused_layer(x, self.conv1, self.bn1, ACT_RELU)
+        out = fused_layer(out, self.conv2, self.bn2, ACT_NONE)
+        res = x if self.downsample is None else fused_layer(x, self.downsample[0], self.downsample[1], ACT_NONE)
+        return ops.add_relu(out, res)
+
+    def forward(self, x):
+        return to_nchw_view(self.forward_nhwc(to_nhwc(x)))
+
+
+class ResNet(nn.Module):
+    """the reference's local ResNet (networks/Image_Embedding.py:13-71): conv7x7 s2 -> BN -> ReLU -> maxpool 3x3 s2
+    -> layer1..4 -> AvgPool2d(7) -> fc(512 -> length_feature).  224x224 inputs only (as the reference)."""
+
+    def __init__(self, block=BasicBlock, layers=(2, 2, 2, 2), channel_size=3, length_feature=256):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(channel_size, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.fc = nn.Linear(512 * block.expansion, length_feature)
+        import math
+        for m in self.modules():                      # Image_Embedding.py:30-36
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        """x: (N, C, 224, 224) NCHW frames -> (N, length_feature)."""
+        h = ops.frames_to_nhwc4(x)
+        h = fused_layer(h, self.conv1, self.bn1, ACT_RELU)
+        h = ops.maxpool(h, 3, 2, 1)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                h = blk.forward_nhwc(h)
+        if h.shape[1] != 7 or h.shape[2] != 7:
+            raise RuntimeError("the reference ResNet (AvgPool2d(7) + fc) needs 224x224 frames")
+        h = ops.avgpool_hw(h)
+        return linear_layer(h, self.fc, ACT_NONE).reshape(h.shape[0], -1)
+
+
+def ImageResnet18(hparams=hparams):
+    return ResNet(BasicBlock, [2, 2, 2, 2], channel_size=3, length_feature=getattr(hparams, "length_feature", 256))
+
+
+def FlowResnet18(hparams=hparams):
+    return ResNet(BasicBlock, [2, 2, 2, 2], channel_size=2, length_feature=getattr(hparams, "length_feature", 256))
+
+
+class _ImageEmbeddingBase(nn.Module):
+    def _temporal(self, fea_bcn, use_dead_bn):
+        """fea (B, C, N) -> conv_1 (s2) -> [dead bn_1/relu: running stats only] -> conv_2 (s2) -> (B, C', N/4)."""
+        x = fea_bcn.transpose(1, 2).unsqueeze(1)                       # NHWC (B,1,N,C)
+        out = conv1d_layer(x, self.conv_1, None, ACT_NONE)
+        if use_dead_bn and self.bn_1.training:
+            with torch.no_grad():                                       # `self.relu(self.bn_1(out))` result is discarded in the
+                conv1d_layer(x, self.conv_1, self.bn_1, ACT_RELU)       # reference (Image_Embedding.py:123): only the buffers move
+        out = conv1d_layer(out, self.conv_2, None, ACT_NONE)
+        return out.squeeze(1).transpose(1, 2)                           # (B, C', N/4)
+
+
+class ImageEmbedding2(_ImageEmbeddingBase):
+    """E_v (networks/Image_Embedding.py:174-200): RGB ResNet-18 + flow ResNet-18 per frame -> cat -> Conv1d(512,512,3,2,1)
+    -> Conv1d(512,256,3,2,1); returns (out (B,256,1,N/4), fea_cat (B,512,N)).  bn_1 / bn_2 exist but are unused."""
+
+    def __init__(self, hparams=hparams):
+        super().__init__()
+        self.hparams = hparams
+        lf = getattr(hparams, "length_feature", 256)
+        self.image_single_model = ImageResnet18(hparams)
+        self.flow_single_model = FlowResnet18(hparams)
+        self.conv_1 = nn.Conv1d(2 * lf, 2 * lf, 3, 2, 1, bias=False)
+        self.bn_1 = nn.BatchNorm1d(2 * lf)
+        self.conv_2 = nn.Conv1d(2 * lf, lf, 3, 2, 1, bias=False)
+        self.bn_2 = nn.BatchNorm1d(lf)
+        self.dead_bn = False
+
+    def _features(self, video_block, flow_block):
+        sz = getattr(self.hparams, "image_size", 224)
+        lf = getattr(self.hparams, "length_feature", 256)
+        b = video_block.size(0)
+        img = self.image_single_model(video_block.reshape(-1, 3, sz, sz)).reshape(b, -1, lf)
+        flw = self.flow_single_model(flow_block.reshape(-1, 2, sz, sz)).reshape(b, -1, lf)
+        return torch.cat((img, flw), 2).transpose(2, 1)                # (B, 512, N)
+
+    def forward(self, video_block, flow_block):
+        fea_cat = self._features(video_block, flow_block)
+        out = self._temporal(fea_cat, self.dead_bn).unsqueeze(2)
+        return out, fea_cat
+
+
+class ImageEmbedding(ImageEmbedding2):
+    """networks/Image_Embedding.py:100-126: as ImageEmbedding2 but bn_1 runs (result discarded) and only `out` is returned."""
+
+    def __init__(self, hparams=hparams):
+        super().__init__(hparams)
+        self.dead_bn = True
+
+    def forward(self, video_block, flow_block):
+        return self._temporal(self._features(video_block, flow_block), True).unsqueeze(2)
+
+
+class ImageEmbedding_single(_ImageEmbeddingBase):
+    """networks/Image_Embedding.py:129-150."""
+
+    def __init__(self, hparams=hparams, image=1):
+        super().__init__()
+        self.image, self.hparams = image, hparams
+        lf = getattr(hparams, "length_feature", 256)
+        self.image_single_model = ImageResnet18(hparams) if image else FlowResnet18(hparams)
+        self.conv_1 = nn.Conv1d(lf, lf, 3, 2, 1, bias=False)
+        self.bn_1 = nn.BatchNorm1d(lf)
+        self.conv_2 = nn.Conv1d(lf, lf, 3, 2, 1, bias=False)
+        self.bn_2 = nn.BatchNorm1d(lf)
+
+    def forward(self, video_block):
+        sz = getattr(self.hparams, "image_size", 224)
+        lf = getattr(self.hparams, "length_feature", 256)
+        f = self.image_single_model(video_block.reshape(-1, 3 if self.image else 2, sz, sz)).reshape(video_block.size(0), -1, lf)
+        return self._temporal(f.transpose(1, 2), True)
+
+
+class ImageEmbedding_finetune(_ImageEmbeddingBase):
+    """networks/Image_Embedding.py:152-171: temporal convs on precomputed per-frame features (B, N, C)."""
+
+    def __init__(self, hparams=hparams, image=1):
+        super().__init__()
+        self.image, self.hparams = image, hparams
+        lf = getattr(hparams, "length_feature", 256)
+        self.conv_1 = nn.Conv1d(lf, lf, 3, 2, 1, bias=False)
+        self.bn_1 = nn.BatchNorm1d(lf)
+        self.conv_2 = nn.Conv1d(lf, lf, 3, 2, 1, bias=False)
+        self.bn_2 = nn.BatchNorm1d(lf)
+
+    def forward(self, image_out):
+        return self._temporal(image_out.transpose(1, 2), True).unsqueeze(2)

@@ -91,6 +91,9 @@ class _ConvBnAct(torch.autograd.Function):
         kh, kw = cfg["k"]
         transposed = cfg["transposed"]
         Cout = weight.shape[1] if transposed else weight.shape[0]
+        cin_w = weight.shape[0] if transposed else weight.shape[1]
+        if C2 == 0 and C1 == 4 and 1 < cin_w < 4:
+            C1 = cin_w                      # frames stored with channel stride 4 (zero padded): ResNet conv1
         d = conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, cfg["s"][0], cfg["s"][1], cfg["p"][0], cfg["p"][1],
                       1 if transposed else 0)
         st = _stream()
@@ -344,6 +347,104 @@ def mse_mean(p, target: float):
 
 def l1_mean(a, b):
     return _ScalarLoss.apply("l1", a, b, 0.0)
+
+
+class _MaxPool(torch.autograd.Function):
+    """nn.MaxPool2d(k, s, p) on NHWC (networks/Image_Embedding.py:21)."""
+
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        lib = _lib.load()
+        _require(x)
+        x = _c(x)
+        N, IH, IW, Cc = x.shape
+        OH, OW = (IH + 2 * p - k) // s + 1, (IW + 2 * p - k) // s + 1
+        y = torch.empty((N, OH, OW, Cc), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, OH, OW, Cc), device=x.device, dtype=torch.uint8)
+        _lib.check(lib.viai_maxpool_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, IH, IW, Cc, k, s, p, _stream()), "viai_maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.dims = (N, IH, IW, Cc, k, s, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        N, IH, IW, Cc, k, s, p = ctx.dims
+        dy = _c(dy)
+        dx = torch.empty((N, IH, IW, Cc), device=dy.device, dtype=torch.float32)
+        _lib.check(lib.viai_maxpool_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), N, IH, IW, Cc, k, s, p, _stream()), "viai_maxpool_bwd")
+        return dx, None, None, None
+
+
+def maxpool(x, k=3, s=2, p=1):
+    return _MaxPool.apply(x, int(k), int(s), int(p))
+
+
+class _AvgPoolHW(torch.autograd.Function):
+    """mean over the spatial positions: nn.AvgPool2d(7) on a 7x7 map (networks/Image_Embedding.py:27)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        _require(x)
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, 1, 1, Cc), device=x.device, dtype=torch.float32)
+        _lib.check(lib.viai_avgpool_hw_fwd(x.data_ptr(), y.data_ptr(), N, H * W, Cc, _stream()), "viai_avgpool_hw_fwd")
+        ctx.dims = (N, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        N, H, W, Cc = ctx.dims
+        dy = _c(dy)
+        dx = torch.empty((N, H, W, Cc), device=dy.device, dtype=torch.float32)
+        _lib.check(lib.viai_avgpool_hw_bwd(dy.data_ptr(), dx.data_ptr(), N, H * W, Cc, _stream()), "viai_avgpool_hw_bwd")
+        return dx
+
+
+def avgpool_hw(x):
+    return _AvgPoolHW.apply(x)
+
+
+class _AddRelu(torch.autograd.Function):
+    """out = relu(a + b): the BasicBlock join (networks/ResNet.py:51-52)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        _require(a, b)
+        a, b = _c(a), _c(b)
+        out = torch.empty_like(a)
+        _lib.check(lib.viai_add_relu_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "viai_add_relu_fwd")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (out,) = ctx.saved_tensors
+        g = _c(g)
+        d = torch.empty_like(g)
+        _lib.check(lib.viai_relu_bwd(g.data_ptr(), out.data_ptr(), d.data_ptr(), g.numel(), _stream()), "viai_relu_bwd")
+        return d, d
+
+
+def add_relu(a, b):
+    return _AddRelu.apply(a, b)
+
+
+def frames_to_nhwc4(x):
+    """(N, C<=4, H, W) NCHW frames -> (N, H, W, 4) NHWC, zero-padded channels (no gradient: loader output)."""
+    lib = _lib.load()
+    _require(x)
+    x = _c(x.detach())
+    N, Cc, H, W = x.shape
+    y = torch.empty((N, H, W, 4), device=x.device, dtype=torch.float32)
+    _lib.check(lib.viai_nchw_to_nhwc4(x.data_ptr(), y.data_ptr(), N, Cc, H * W, _stream()), "viai_nchw_to_nhwc4")
+    return y
 
 
 class _L2Contrastive(torch.autograd.Function):
