@@ -55,7 +55,7 @@ class KernelTimer:
 
     @staticmethod
     def _geom(d):
-        oh = (d.IH - 1 - 2 * d.ph + d.kh) if d.transposed else (d.IH + 2 * d.ph - d.kh) // d.sh + 1
+        oh = (d.IH - 1 - 2 * d.ph + d.kh) if d.transposed else (d.IH + 2 * d.ph - d.kh) // d.sh + 1    # VIAI layers: no dilation
         ow = (d.IW - 1 - 2 * d.pw + d.kw) if d.transposed else (d.IW + 2 * d.pw - d.kw) // d.sw + 1
         cin = d.C1 + d.C2
         flops = 2.0 * d.N * oh * ow * d.Cout * cin * d.kh * d.kw

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 1
+#define VIAI_ABI_VERSION 2
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -47,6 +47,11 @@ typedef struct viai_conv2d {
     int kh, kw, sh, sw, ph, pw;
     int transposed;      /* 0 = nn.Conv2d (weight [Cout][Cin][kh][kw]);
                             1 = nn.ConvTranspose2d, stride 1 (weight [Cin][Cout][kh][kw]) */
+    int dh, dw;          /* dilation (0 or 1 = none); nn.Conv2d only.  WaveNet's dilated causal Conv1d
+                            (wavenet_vocoder/modules.py:124-126) is kh = 1, kw = 3, dw = 2^i            */
+    int ph2, pw2;        /* bottom / right padding; -1 = same as ph / pw (torch's symmetric padding).
+                            pw = (k-1)*d, pw2 = 0 computes exactly the T causal outputs the reference keeps
+                            after `x[:, :, :residual.size(-1)]` (modules.py:181)                          */
 } viai_conv2d;
 
 /* output extent (torch formulas) */
@@ -151,6 +156,40 @@ int viai_l2c_fwd(const float* f1, const float* f2, int n, int d, float margin, i
                  float* scores, float* loss, void* stream);
 int viai_l2c_bwd(const float* f1, const float* f2, const float* scores, int n, int d, float margin,
                  int max_violation, const float* gscale, int* argmax_ws, float* df1, float* df2, void* stream);
+
+/* ------------------------------------------------------------------- WaveNet
+ * (wavenet_vocoder/{wavenet,modules,mixture}.py).  The dilated causal and 1x1 Conv1d layers are
+ * viai_conv2d_* with kh = 1 on (B, 1, T, C) tensors; the entry points below are the remaining pieces.  */
+/* torch weight_norm(dim=0): w[r][:] = g[r] * v[r][:] / ||v[r]||  (modules.py:39,59); norm: [rows] kept for bwd */
+int viai_weight_norm_fwd(const float* v, const float* g, float* w, float* norm, int rows, int L, void* stream);
+int viai_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, float* dv, float* dg,
+                         int rows, int L, int accumulate, void* stream);
+/* gated activation tanh(a + ca) * sigmoid(b + cb), y/yc rows = [a | b] of 2*H channels (modules.py:183-201);
+ * the backward writes ONE tensor that is the gradient of both y and yc                                 */
+int viai_glu_fwd(const float* y, const float* yc, float* z, long rows, int H, void* stream);
+int viai_glu_bwd(const float* dz, const float* y, const float* yc, float* dy, long rows, int H, void* stream);
+/* out = (a + b) * s (b may be NULL): residual / skip scaling by sqrt(0.5) (modules.py:209, wavenet.py:222-226) */
+int viai_add_scale(const float* a, const float* b, float* out, float s, long n, void* stream);
+int viai_relu_fwd(const float* a, float* out, long n, void* stream);
+/* first_conv for scalar input, Conv1d1x1(1, C): y[p][c] = x[p]*w[c] + b[c] (wavenet.py:118) and its weight grads */
+int viai_outer_fwd(const float* x, const float* w, const float* b, float* y, long rows, int C, void* stream);
+int viai_outer_bwd_blocks(long rows);
+int viai_outer_bwd(const float* dy, const float* x, float* part, float* dw, float* db, long rows, int C, int accumulate, void* stream);
+/* conditioning up-sampler: ConvTranspose2d(1,1,(KH,S),stride (1,S),padding ((KH-1)/2,0)) + ReLU on (B,F,T)
+ * (wavenet.py:153-164); part: (KH*16+1)*viai_upsample_bwd_blocks() floats                               */
+int viai_upsample_fwd(const float* x, const float* w, const float* bias, float* y, int B, int F, int T, int KH, int S, void* stream);
+int viai_upsample_bwd_blocks(void);
+int viai_upsample_bwd(const float* dy, const float* y, const float* x, const float* w, float* part, float* dx, float* dw, float* db,
+                      int B, int F, int T, int KH, int S, int accumulate, void* stream);
+/* DiscretizedMixturelogisticLoss (mixture.py:25-105 + loss_functions.py:43-62): yhat rows of `pitch` floats
+ * ([logit|mean|log_scale] x nr_mix first), target y[row], optional mask[row];  loss = sum(l*mask)/sum(mask);
+ * dyhat (optional) = d loss / d yhat.  loss_rows, wrow: [rows] scratch.                                   */
+int viai_mol_loss(const float* yhat, const float* y, const float* mask, float* loss_rows, float* wrow, float* loss,
+                  float* dyhat, long rows, int pitch, int nr_mix, float num_classes, float log_scale_min, void* stream);
+int viai_scale_by_scalar(float* d, const float* gscale, long n, void* stream);
+/* sample_from_discretized_mix_logistic (mixture.py:117-153) with injected uniforms u1[rows][nr_mix], u2[rows] */
+int viai_mol_sample(const float* yhat, const float* u1, const float* u2, float* out, long rows, int pitch, int nr_mix,
+                    float log_scale_min, void* stream);
 
 /* ------------------------------------------------------------ mask / optimizer
  * s_in = s * mask, mask (N, T) broadcast over frequency (the missing

@@ -1,0 +1,161 @@
+"""CPU oracle for the WaveNet vocoder path.  TEST INFRASTRUCTURE ONLY (see oracle/viai_oracle.py header).
+
+Plain-torch functional restatement of wavenet_vocoder/{wavenet,modules,conv,mixture}.py.  PINNED:
+tools/make_goldens.py imports the reference's own `WaveNet`, `discretized_mix_logistic_loss` and
+`sample_from_discretized_mix_logistic` (stub Config module) and checks this file against them;
+the reference's outputs are committed as tests/golden/wavenet.npz.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .viai_oracle import cf_std, cf_uniform
+
+
+class WNConfig:
+    """small test configuration (the reference's defaults: 24 layers / 4 stacks / 512 / 512 / 256, scales [4,4,4,4])."""
+    out_channels = 30
+    layers = 4
+    stacks = 2
+    residual_channels = 64
+    gate_channels = 64
+    skip_out_channels = 32
+    kernel_size = 3
+    cin_channels = 80
+    upsample_scales = (4, 4)
+    freq_axis_kernel_size = 3
+
+
+def wavenet_state(cfg=WNConfig, tag="WN."):
+    """state_dict of WaveNet with weight normalisation (keys: *.weight_g, *.weight_v, *.bias)."""
+    sd = OrderedDict()
+
+    def conv(name, cout, cin, k):
+        v = cf_std(tag + name + ".v", (cout, cin, k), math.sqrt(1.0 / (cin * k)))
+        sd[name + ".bias"] = cf_uniform(tag + name + ".b", (cout,), -0.05, 0.05)
+        sd[name + ".weight_g"] = (v.reshape(cout, -1).norm(dim=1) * cf_uniform(tag + name + ".g", (cout,), 0.8, 1.2)).reshape(cout, 1, 1)
+        sd[name + ".weight_v"] = v
+    conv("first_conv", cfg.residual_channels, 1, 1)
+    for i in range(cfg.layers):
+        p = "conv_layers.%d." % i
+        conv(p + "conv", cfg.gate_channels, cfg.residual_channels, cfg.kernel_size)
+        conv(p + "conv1x1c", cfg.gate_channels, cfg.cin_channels, 1)
+        conv(p + "conv1x1_out", cfg.residual_channels, cfg.gate_channels // 2, 1)
+        conv(p + "conv1x1_skip", cfg.skip_out_channels, cfg.gate_channels // 2, 1)
+    conv("last_conv_layers.1", cfg.skip_out_channels, cfg.skip_out_channels, 1)
+    conv("last_conv_layers.3", cfg.out_channels, cfg.skip_out_channels, 1)
+    for j, s in enumerate(cfg.upsample_scales):
+        n = "upsample_conv.%d" % (2 * j)
+        v = cf_uniform(tag + n + ".v", (1, 1, cfg.freq_axis_kernel_size, s), 0.1, 0.5)
+        sd[n + ".bias"] = cf_uniform(tag + n + ".b", (1,), -0.01, 0.01)
+        sd[n + ".weight_g"] = (v.norm() * 1.1).reshape(1, 1, 1, 1)
+        sd[n + ".weight_v"] = v
+    return sd
+
+
+def wn_weight(sd, name):
+    """torch.nn.utils.weight_norm (dim=0): w = g * v / ||v|| per output row (modules.py:39)."""
+    v, g = sd[name + ".weight_v"], sd[name + ".weight_g"]
+    n = v.reshape(v.shape[0], -1).norm(dim=1).reshape((-1,) + (1,) * (v.dim() - 1))
+    return v * (g / n)
+
+
+def wavenet_forward(sd, x, c, cfg=WNConfig):
+    """WaveNet.forward, scalar input, local conditioning with up-sampling, eval-mode dropout
+    (wavenet.py:177-235; ResidualConv1dGLU._forward modules.py:162-210)."""
+    B, _, T = x.shape
+    c = c.unsqueeze(1)                                                       # :210
+    for j, s in enumerate(cfg.upsample_scales):                              # :211-212
+        n = "upsample_conv.%d" % (2 * j)
+        c = F.relu(F.conv_transpose2d(c, wn_weight(sd, n), sd[n + ".bias"], stride=(1, s), padding=((cfg.freq_axis_kernel_size - 1) // 2, 0)))
+    c = c.squeeze(1)                                                         # :214
+    assert c.shape[-1] == T
+    h = F.conv1d(x, wn_weight(sd, "first_conv"), sd["first_conv.bias"])      # :218
+    skips = None
+    per = cfg.layers // cfg.stacks
+    for i in range(cfg.layers):
+        p = "conv_layers.%d." % i
+        d = 2 ** (i % per)
+        residual = h
+        y = F.conv1d(h, wn_weight(sd, p + "conv"), sd[p + "conv.bias"], padding=(cfg.kernel_size - 1) * d, dilation=d)[:, :, :T]   # modules.py:179-181
+        a, b = y.split(y.shape[1] // 2, dim=1)
+        yc = F.conv1d(c, wn_weight(sd, p + "conv1x1c"), sd[p + "conv1x1c.bias"])
+        ca, cb = yc.split(yc.shape[1] // 2, dim=1)
+        z = torch.tanh(a + ca) * torch.sigmoid(b + cb)                       # :201
+        s = F.conv1d(z, wn_weight(sd, p + "conv1x1_skip"), sd[p + "conv1x1_skip.bias"])
+        o = F.conv1d(z, wn_weight(sd, p + "conv1x1_out"), sd[p + "conv1x1_out.bias"])
+        h = (o + residual) * math.sqrt(0.5)                                  # :209
+        skips = s if skips is None else (skips + s) * math.sqrt(0.5)         # wavenet.py:222-226
+    h = F.relu(skips)
+    h = F.relu(F.conv1d(h, wn_weight(sd, "last_conv_layers.1"), sd["last_conv_layers.1.bias"]))
+    return F.conv1d(h, wn_weight(sd, "last_conv_layers.3"), sd["last_conv_layers.3.bias"])
+
+
+def mol_loss_rows(y_hat, y, num_classes=65536, log_scale_min=math.log(1e-14)):
+    """discretized_mix_logistic_loss(reduce=False) (mixture.py:25-105): y_hat (B,C,T), y (B,T,1) -> (B,T,1)."""
+    nr_mix = y_hat.shape[1] // 3
+    y_hat = y_hat.transpose(1, 2)
+    logit_probs = y_hat[:, :, :nr_mix]
+    means = y_hat[:, :, nr_mix:2 * nr_mix]
+    log_scales = torch.clamp(y_hat[:, :, 2 * nr_mix:3 * nr_mix], min=log_scale_min)
+    y = y.expand_as(means)
+    centered = y - means
+    inv = torch.exp(-log_scales)
+    plus_in = inv * (centered + 1. / (num_classes - 1))
+    min_in = inv * (centered - 1. / (num_classes - 1))
+    cdf_delta = torch.sigmoid(plus_in) - torch.sigmoid(min_in)
+    log_cdf_plus = plus_in - F.softplus(plus_in)
+    log_one_minus_cdf_min = -F.softplus(min_in)
+    mid_in = inv * centered
+    log_pdf_mid = mid_in - log_scales - 2. * F.softplus(mid_in)
+    c3 = (cdf_delta > 1e-5).float()
+    inner = c3 * torch.log(torch.clamp(cdf_delta, min=1e-12)) + (1. - c3) * (log_pdf_mid - np.log((num_classes - 1) / 2))
+    c2 = (y > 0.999).float()
+    inner = c2 * log_one_minus_cdf_min + (1. - c2) * inner
+    c1 = (y < -0.999).float()
+    log_probs = c1 * log_cdf_plus + (1. - c1) * inner + F.log_softmax(logit_probs, -1)
+    return -torch.logsumexp(log_probs, dim=-1, keepdim=True)
+
+
+def mol_loss(y_hat, y, mask, num_classes=65536, log_scale_min=math.log(1e-14)):
+    """DiscretizedMixturelogisticLoss.forward (loss_functions.py:43-62)."""
+    losses = mol_loss_rows(y_hat, y, num_classes, log_scale_min)
+    m = mask.expand_as(y)
+    return (losses * m).sum() / m.sum()
+
+
+def mol_sample(y, u1, u2, log_scale_min=-7.0):
+    """sample_from_discretized_mix_logistic (mixture.py:117-153) with the two uniform draws injected:
+    u1 (B,T,nr_mix), u2 (B,T)."""
+    nr_mix = y.shape[1] // 3
+    y = y.transpose(1, 2)
+    logit = y[:, :, :nr_mix]
+    arg = (logit - torch.log(-torch.log(u1))).max(dim=-1)[1]
+    onehot = F.one_hot(arg, nr_mix).float()
+    means = (y[:, :, nr_mix:2 * nr_mix] * onehot).sum(-1)
+    log_scales = torch.clamp((y[:, :, 2 * nr_mix:3 * nr_mix] * onehot).sum(-1), min=log_scale_min)
+    x = means + torch.exp(log_scales) * (torch.log(u2) - torch.log(1. - u2))
+    return torch.clamp(x, -1., 1.)
+
+
+def incremental_forward(sd, c, T, u1, u2, cfg=WNConfig, test_inputs=None, log_scale_min=-7.0):
+    """WaveNet.incremental_forward (wavenet.py:237-364) by definition of causality: sample t depends only on
+    samples < t, so it equals running the batch forward on the growing prefix (O(T^2); tiny T only)."""
+    B = c.shape[0]
+    x = torch.zeros(B, 1, T)
+    out = torch.zeros(B, 1, T)
+    cur = torch.zeros(B)                                          # initial input: zeros (wavenet.py:305-306)
+    for t in range(T):
+        if test_inputs is not None and t < test_inputs.shape[-1]:
+            cur = test_inputs[:, 0, t]
+        elif t > 0:
+            cur = out[:, 0, t - 1]
+        x[:, 0, t] = cur
+        y = wavenet_forward(sd, x, c, cfg)[:, :, t:t + 1]
+        out[:, 0, t] = mol_sample(y, u1[:, t:t + 1], u2[:, t:t + 1], log_scale_min)[:, 0]
+    return out

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_typed(lib):
         assert n in _lib.SIGNATURES, "no ctypes signature for %s" % n
     for n in _lib.SIGNATURES:
         assert n in names, "%s is bound but not declared in include/viai_hip.h" % n
-    assert lib.viai_abi_version() == 1
+    assert lib.viai_abi_version() == 2
 
 
 def test_conv_geometry_queries_match_torch(lib):
@@ -44,7 +44,7 @@ def test_conv_geometry_queries_match_torch(lib):
         (2, 5, 7, 64, 64, 32, 3, 3, 1, 1, 1, 1, 1),
     ]
     for c in cases:
-        d = Conv2dDesc(*c)
+        d = Conv2dDesc(*(c + (1, 1, -1, -1)))
         oh, ow = C.c_int(), C.c_int()
         lib.viai_conv2d_out_hw(C.byref(d), C.byref(oh), C.byref(ow))
         x = torch.zeros(1, c[3] + c[4], c[1], c[2])
@@ -63,7 +63,7 @@ def test_conv_geometry_queries_match_torch(lib):
 
 def test_invalid_descriptors_are_rejected(lib):
     from viai_amd._lib import Conv2dDesc
-    bad = Conv2dDesc(1, 8, 8, 32, 0, 32, 3, 3, 2, 2, 1, 1, 1)        # transposed with stride 2: unsupported
+    bad = Conv2dDesc(1, 8, 8, 32, 0, 32, 3, 3, 2, 2, 1, 1, 1, 1, 1, -1, -1)        # transposed with stride 2: unsupported
     nblk, rows = C.c_int(), C.c_int()
     assert lib.viai_conv2d_stat_geom(C.byref(bad), C.byref(nblk), C.byref(rows)) != 0
     assert lib.viai_conv2d_wgrad_ws_bytes(C.byref(bad)) == 0

@@ -286,6 +286,83 @@ def resnet_goldens():
     print("resnet -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def wavenet_goldens():
+    """WaveNet (small config) teacher-forced forward + MoL loss + gradients, MoL sampler, and a short
+    incremental_forward run, all from the reference's wavenet_vocoder package."""
+    import Config
+    from oracle import wavenet_oracle as W
+    cfg = W.WNConfig
+    from wavenet_vocoder import wavenet as RW, mixture as RM
+    net = RW.WaveNet(out_channels=cfg.out_channels, layers=cfg.layers, stacks=cfg.stacks, residual_channels=cfg.residual_channels,
+                     gate_channels=cfg.gate_channels, skip_out_channels=cfg.skip_out_channels, kernel_size=cfg.kernel_size, dropout=0.0,
+                     cin_channels=cfg.cin_channels, gin_channels=-1, n_speakers=None, weight_normalization=True,
+                     upsample_conditional_features=True, upsample_scales=list(cfg.upsample_scales),
+                     freq_axis_kernel_size=cfg.freq_axis_kernel_size, scalar_input=True)
+    sd = W.wavenet_state(cfg)
+    assert list(net.state_dict().keys()) == list(sd.keys()), set(net.state_dict()) ^ set(sd)
+    load_into(net, sd)
+    out = OrderedDict()
+    B, T = 2, 64
+    x = O.cf_uniform("wn.x", (B, 1, T), -1, 1)
+    c = O.cf_uniform("wn.c", (B, cfg.cin_channels, T // 16), 0, 1)
+    y = O.cf_uniform("wn.y", (B, T, 1), -1, 1)
+    y[0, 3, 0], y[1, 5, 0] = -1.0, 1.0                         # the two edge branches of the MoL likelihood
+    mask = torch.ones(B, T, 1); mask[1, T - 10:] = 0
+    net.train()
+    yh = net(x, c)
+    losses = RM.discretized_mix_logistic_loss(yh, y, num_classes=65536, log_scale_min=float(np.log(1e-14)), reduce=False)
+    loss = (losses * mask).sum() / mask.sum()
+    loss.backward()
+    osd = O._leafify(sd)
+    oyh = W.wavenet_forward(osd, x, c, cfg)
+    assert relerr(oyh, yh) < 1e-5, relerr(oyh, yh)
+    oloss = W.mol_loss(oyh, y, mask)
+    assert abs(oloss.item() - loss.item()) < 1e-5 * abs(loss.item())
+    keys = ("first_conv.weight_g", "first_conv.bias", "conv_layers.0.conv.weight_g", "conv_layers.3.conv.weight_v", "conv_layers.1.conv1x1c.weight_v",
+            "conv_layers.2.conv1x1_skip.bias", "last_conv_layers.3.weight_v", "upsample_conv.0.weight_v", "upsample_conv.2.bias")
+    og = torch.autograd.grad(oloss, [osd[k] for k in keys])
+    for k, g in zip(keys, og):
+        ref = dict(net.named_parameters())[k].grad
+        assert relerr(g, ref) < 1e-3, (k, relerr(g, ref))
+        out["g.%s" % k] = ref.numpy().copy()
+    out["yhat"] = yh.detach().numpy(); out["loss"] = np.float64(loss.item()); out["loss_rows"] = losses.detach().numpy()
+    # sampler with injected uniforms: patch Tensor.uniform_ so the reference draws OUR numbers
+    u1 = O.cf_uniform("wn.u1", (B, T, 10), 1e-5, 1 - 1e-5)
+    u2 = O.cf_uniform("wn.u2", (B, T), 1e-5, 1 - 1e-5)
+    draws = [u1, u2]
+    orig = torch.Tensor.uniform_
+    torch.Tensor.uniform_ = lambda self, a=0, b=1: self.copy_(draws.pop(0))
+    try:
+        smp = RM.sample_from_discretized_mix_logistic(yh.detach(), log_scale_min=-7.0)
+    finally:
+        torch.Tensor.uniform_ = orig
+    assert relerr(W.mol_sample(yh.detach(), u1, u2), smp) < 1e-6
+    out["sample"] = smp.numpy()
+    # incremental_forward, free-running for 24 steps (teacher-forced on the first 4), injected uniforms per step
+    net.eval()
+    Tg = 32
+    cg = O.cf_uniform("wn.cg", (B, cfg.cin_channels, Tg // 16), 0, 1)
+    v1 = O.cf_uniform("wn.v1", (B, Tg, 10), 1e-5, 1 - 1e-5)
+    v2 = O.cf_uniform("wn.v2", (B, Tg), 1e-5, 1 - 1e-5)
+    tin = O.cf_uniform("wn.tin", (B, 1, 4), -1, 1)
+    seq = []
+    for t in range(Tg):
+        seq += [v1[:, t:t + 1, :].reshape(B, 1, 10), v2[:, t:t + 1].reshape(B, 1)]
+    torch.Tensor.uniform_ = lambda self, a=0, b=1: self.copy_(seq.pop(0).reshape(self.shape))
+    try:
+        with torch.no_grad():
+            gen = net.incremental_forward(initial_input=None, c=cg, g=None, T=Tg, test_inputs=tin, tqdm=lambda z: z, softmax=False,
+                                          quantize=False, log_scale_min=-7.0)
+    finally:
+        torch.Tensor.uniform_ = orig
+    ogen = W.incremental_forward(sd, cg, Tg, v1, v2, cfg, test_inputs=tin)
+    assert tuple(gen.shape) == (B, 1, Tg) and relerr(ogen, gen) < 1e-4, relerr(ogen, gen)
+    out["gen"] = gen.numpy()
+    path = os.path.join(OUT, "wavenet.npz")
+    np.savez_compressed(path, **out)
+    print("wavenet -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def adam_goldens():
     """torch.optim.Adam known-answer vectors (what the missing AudioModel's
     optimizer_G/optimizer_D are, utils/util.py:149-150)."""
@@ -353,6 +430,7 @@ if __name__ == "__main__":
     adam_goldens()
     av_goldens()
     resnet_goldens()
+    wavenet_goldens()
     run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
     run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]
     if "--cfg2" in sys.argv:

@@ -23,7 +23,7 @@ class ViaiLibraryError(RuntimeError):
 class Conv2dDesc(C.Structure):
     """mirror of `viai_conv2d` (include/viai_hip.h)."""
     _fields_ = [(n, C.c_int) for n in (
-        "N", "IH", "IW", "C1", "C2", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "transposed")]
+        "N", "IH", "IW", "C1", "C2", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "transposed", "dh", "dw", "ph2", "pw2")]
 
 
 _P = C.c_void_p
@@ -73,6 +73,21 @@ SIGNATURES = {
     "viai_l1_bwd": (_I, [_P, _P, _L, _P, _P, _P]),
     "viai_l2c_fwd": (_I, [_P, _P, _I, _I, _F, _I, _P, _P, _P]),
     "viai_l2c_bwd": (_I, [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
+    "viai_weight_norm_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "viai_weight_norm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "viai_glu_fwd": (_I, [_P, _P, _P, _L, _I, _P]),
+    "viai_glu_bwd": (_I, [_P, _P, _P, _P, _L, _I, _P]),
+    "viai_add_scale": (_I, [_P, _P, _P, _F, _L, _P]),
+    "viai_relu_fwd": (_I, [_P, _P, _L, _P]),
+    "viai_outer_fwd": (_I, [_P, _P, _P, _P, _L, _I, _P]),
+    "viai_outer_bwd_blocks": (_I, [_L]),
+    "viai_outer_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "viai_upsample_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "viai_upsample_bwd_blocks": (_I, []),
+    "viai_upsample_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "viai_mol_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _P]),
+    "viai_scale_by_scalar": (_I, [_P, _P, _L, _P]),
+    "viai_mol_sample": (_I, [_P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "viai_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "viai_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _D, _D, _D, _F, _P]),
     "viai_colsum_blocks": (_I, [_L, _I]),
@@ -112,7 +127,7 @@ def load() -> C.CDLL:
             raise ViaiLibraryError("libviai_hip.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.viai_abi_version() != 1:
+    if lib.viai_abi_version() != 2:
         raise ViaiLibraryError("libviai_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -19,18 +19,10 @@ extern "C" int viai_colsum_blocks(long M, int C);
 extern "C" int viai_colsum(const float* x, long M, int C, float* part, float* out, int accumulate, void* stream);
 
 static inline int cin_of(const viai_conv2d* c) { return c->C1 + c->C2; }
-static inline bool valid(const viai_conv2d* c) {
-    if (!c || c->N <= 0 || c->IH <= 0 || c->IW <= 0 || c->C1 <= 0 || c->C2 < 0 || c->Cout <= 0) return false;
-    const bool runk = (cin_of(c) > 1 && cin_of(c) <= 4 && c->Cout > 1);     // row-run kind: taps are kernel rows
-    if (c->kh <= 0 || c->kw <= 0) return false;
-    if (runk ? (c->kh > VIAI_MAX_TAPS || c->kw > 8) : (c->kh * c->kw > VIAI_MAX_TAPS)) return false;
-    if (c->sh <= 0 || c->sw <= 0 || c->ph < 0 || c->pw < 0) return false;
-    if (c->transposed && (c->sh != 1 || c->sw != 1)) return false;
-    if (cin_of(c) > 1 && cin_of(c) <= 4 && c->Cout > 1 && (c->kw > 8 || c->transposed || c->C2 != 0)) return false;
-    int oh, ow;
-    viai_conv2d_out_hw(c, &oh, &ow);
-    return oh > 0 && ow > 0;
-}
+static inline int dil_h(const viai_conv2d* c) { return c->dh > 1 ? c->dh : 1; }
+static inline int dil_w(const viai_conv2d* c) { return c->dw > 1 ? c->dw : 1; }
+static inline int pad_b(const viai_conv2d* c) { return c->ph2 >= 0 ? c->ph2 : c->ph; }
+static inline int pad_r(const viai_conv2d* c) { return c->pw2 >= 0 ? c->pw2 : c->pw; }
 enum { K_IGEMM = 0, K_CIN1 = 1, K_COUT1 = 2, K_RUN = 3 };
 static inline int kind_of(const viai_conv2d* c) {
     if (cin_of(c) == 1) return K_CIN1;
@@ -39,6 +31,19 @@ static inline int kind_of(const viai_conv2d* c) {
     return K_IGEMM;
 }
 
+static inline bool valid(const viai_conv2d* c) {
+    if (!c || c->N <= 0 || c->IH <= 0 || c->IW <= 0 || c->C1 <= 0 || c->C2 < 0 || c->Cout <= 0) return false;
+    const bool runk = (cin_of(c) > 1 && cin_of(c) <= 4 && c->Cout > 1);     // row-run kind: taps are kernel rows
+    if (c->kh <= 0 || c->kw <= 0) return false;
+    if (runk ? (c->kh > VIAI_MAX_TAPS || c->kw > 8) : (c->kh * c->kw > VIAI_MAX_TAPS)) return false;
+    if (c->sh <= 0 || c->sw <= 0 || c->ph < 0 || c->pw < 0) return false;
+    if (c->transposed && (c->sh != 1 || c->sw != 1)) return false;
+    if ((dil_h(c) > 1 || dil_w(c) > 1 || c->ph2 >= 0 || c->pw2 >= 0) && (c->transposed || kind_of(c) != K_IGEMM)) return false;
+    if (cin_of(c) > 1 && cin_of(c) <= 4 && c->Cout > 1 && (c->kw > 8 || c->transposed || c->C2 != 0)) return false;
+    int oh, ow;
+    viai_conv2d_out_hw(c, &oh, &ow);
+    return oh > 0 && ow > 0;
+}
 extern "C" int viai_abi_version(void) { return VIAI_ABI_VERSION; }
 
 extern "C" int viai_conv2d_out_hw(const viai_conv2d* c, int* OH, int* OW) {
@@ -46,8 +51,8 @@ extern "C" int viai_conv2d_out_hw(const viai_conv2d* c, int* OH, int* OW) {
         *OH = c->IH - 1 - 2 * c->ph + c->kh;
         *OW = c->IW - 1 - 2 * c->pw + c->kw;
     } else {
-        *OH = (c->IH + 2 * c->ph - c->kh) / c->sh + 1;
-        *OW = (c->IW + 2 * c->pw - c->kw) / c->sw + 1;
+        *OH = (c->IH + c->ph + pad_b(c) - dil_h(c) * (c->kh - 1) - 1) / c->sh + 1;
+        *OW = (c->IW + c->pw + pad_r(c) - dil_w(c) * (c->kw - 1) - 1) / c->sw + 1;
     }
     return 0;
 }
@@ -72,8 +77,8 @@ void viai_geom_fwd(const viai_conv2d* c, ConvGeom* g) {
     for (int r = 0; r < c->kh; ++r)
         for (int s = 0; s < c->kw; ++s) {
             int t = r * c->kw + s;
-            g->dy[t] = (c->transposed ? c->ph - r : r - c->ph);
-            g->dx[t] = (c->transposed ? c->pw - s : s - c->pw);
+            g->dy[t] = (c->transposed ? c->ph - r : r * dil_h(c) - c->ph);
+            g->dx[t] = (c->transposed ? c->pw - s : s * dil_w(c) - c->pw);
             g->ws[t] = t;
         }
 }
@@ -129,7 +134,7 @@ int viai_geom_dgrad_class(const viai_conv2d* c, int a, int b, ConvGeom* g) {
             if (c->transposed) {                   // fwd: o = i - p + r  ->  gathered y = iy + (r - p)
                 dy = r - c->ph; dx = s - c->pw;
             } else {                               // fwd: i = o*s - p + r ->  o = (iy + p - r)/s
-                int ny = a + c->ph - r, nx = b + c->pw - s;
+                int ny = a + c->ph - r * dil_h(c), nx = b + c->pw - s * dil_w(c);
                 if (((ny % c->sh) + c->sh) % c->sh != 0 || ((nx % c->sw) + c->sw) % c->sw != 0) continue;
                 dy = ny / c->sh; dx = nx / c->sw;   // exact (divisible), may be negative
             }

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int cchunks = Cin / BK;
+    const int cchunks = (Cin + BK - 1) / BK;     // the last chunk of a tap may be partial (Cin % 4 == 0): masked lanes read zeros
     const int nchunks = g.ntaps * cchunks;
 
     u32x4 areg[NA], breg[NB];
@@ -114,10 +114,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const int cs = g.run ? 4 : (first ? a.C1 : a.C2);
         const int coff = g.run ? 0 : ((first ? c0 : c0 - a.C1) + q * 4);
         const int qpix = g.run ? q : 0;
+        const bool kin = g.run || (c0 + q * 4 < Cin);            // K tail of the last chunk
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int iy = iy0[j] + dyt, ix = ix0[j] + dxt + qpix;
-            bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+            bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW && kin;
             int off = ok ? ((pixbase[j] + toff + qpix) * cs + coff) * 4 : OOB;
             areg[j] = first ? __builtin_amdgcn_raw_buffer_load_b128(rs_in1, off, 0, 0)
                             : __builtin_amdgcn_raw_buffer_load_b128(rs_in2, off, 0, 0);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const int woff = (g.ws[t] * Cin + c0) * 4;
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, brow[j] == OOB ? OOB : brow[j] + woff, 0, 0);
+            breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (brow[j] == OOB || !kin) ? OOB : brow[j] + woff, 0, 0);
     };
     auto lstore = [&](int buf) {
         float* Ad = As + buf * BM * LS;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     gload(0, 0);
     lstore(0);
     c_next = BK;
-    if (c_next >= Cin) { c_next = 0; t_next = 1; }
+    if (c_next >= Cin) { c_next = 0; t_next = 1; }   // (c_next advances in BK steps; a partial last chunk still counts as one)
     __syncthreads();
 
     const int arow = (wm * TM * 32 + (lane & 31)) * LS + 4 * (lane >> 5);
@@ -329,8 +330,9 @@ int viai_igemm_tile_m(long M, int n_out) {
 
 int viai_conv_igemm_launch(ConvArgs& a, hipStream_t st) {
     const int Cin = a.C1 + a.C2;
-    if (Cin % 32 != 0 || a.C1 % 32 != 0) return (int)hipErrorInvalidValue;
+    if (Cin % 4 != 0 || (a.C2 > 0 && a.C1 % 32 != 0)) return (int)hipErrorInvalidValue;
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
+    if (a.Cout % 4 != 0 && a.Cout < 4) return (int)hipErrorInvalidValue;
     const int bm = viai_igemm_tile_m(a.M, a.Cout);
     if (bm == 64) return launch_igemm<32, 1, 1, 2, 2>(a, st);
     if (a.Cout > 64) return launch_igemm<32, 2, 2, 2, 2>(a, st);

@@ -1,0 +1,459 @@
+// WaveNet vocoder pieces that are not convolutions (gfx950): weight normalisation, the gated activation,
+// residual / skip scaling, the scalar-input first layer, the conditioning up-sampler, the discretised
+// mixture-of-logistics loss and sampler.  The dilated / 1x1 Conv1d layers themselves run on the implicit-GEMM
+// MFMA kernels (conv_igemm.hip, H = 1).  Reference: wavenet_vocoder/{wavenet,modules,mixture}.py.
+// Activations are (B, 1, T, C) NHWC, i.e. (B*T) rows of C channels.
+#include "viai_common.h"
+#include "viai_internal.h"
+
+namespace {
+
+inline int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {      // 256 threads
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------- weight norm (modules.py:39, torch weight_norm dim=0)
+// w[r][:] = g[r] * v[r][:] / ||v[r]||      one block per row r
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                              float* __restrict__ w, float* __restrict__ norm, int L) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) { float t = v[(size_t)r * L + i]; s += t * t; }
+    const float n = sqrtf(block_sum(s, red));
+    const float sc = g[r] / n;
+    for (int i = threadIdx.x; i < L; i += 256) w[(size_t)r * L + i] = v[(size_t)r * L + i] * sc;
+    if (threadIdx.x == 0) norm[r] = n;
+}
+
+// dg[r] = <dw, v>/n ;  dv = g/n * (dw - v * <dw, v>/n^2)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                                                              const float* __restrict__ g, const float* __restrict__ norm,
+                                                              float* __restrict__ dv, float* __restrict__ dg, int L, int accumulate) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) s += dw[(size_t)r * L + i] * v[(size_t)r * L + i];
+    const float dot = block_sum(s, red);
+    const float n = norm[r], gs = g[r] / n, k = dot / (n * n);
+    for (int i = threadIdx.x; i < L; i += 256) {
+        float t = gs * (dw[(size_t)r * L + i] - v[(size_t)r * L + i] * k);
+        dv[(size_t)r * L + i] = accumulate ? dv[(size_t)r * L + i] + t : t;
+    }
+    if (threadIdx.x == 0) dg[r] = accumulate ? dg[r] + dot / n : dot / n;
+}
+
+// ---------------------------------------------------------------- gated activation (modules.py:183-201)
+// y, yc: rows of 2*H channels [a | b];  z[row][h] = tanh(a + ca) * sigmoid(b + cb)
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ yc,
+                                                      float* __restrict__ z, long rows, int H) {
+    const int h4n = H / 4;
+    const long total = rows * h4n;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        long r = i / h4n; int h = (int)(i % h4n) * 4;
+        f32x4 a = *reinterpret_cast<const f32x4*>(y + r * 2 * H + h), b = *reinterpret_cast<const f32x4*>(y + r * 2 * H + H + h);
+        if (yc) { a += *reinterpret_cast<const f32x4*>(yc + r * 2 * H + h); b += *reinterpret_cast<const f32x4*>(yc + r * 2 * H + H + h); }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = tanhf(a[e]) * (1.f / (1.f + expf(-b[e])));
+        *reinterpret_cast<f32x4*>(z + r * H + h) = o;
+    }
+}
+
+// dy[row] = [dz*(1-tanh^2)*sig | dz*tanh*sig*(1-sig)]   (the same tensor is the gradient of y AND of yc)
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y, const float* __restrict__ yc,
+                                                      float* __restrict__ dy, long rows, int H) {
+    const int h4n = H / 4;
+    const long total = rows * h4n;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        long r = i / h4n; int h = (int)(i % h4n) * 4;
+        f32x4 a = *reinterpret_cast<const f32x4*>(y + r * 2 * H + h), b = *reinterpret_cast<const f32x4*>(y + r * 2 * H + H + h);
+        if (yc) { a += *reinterpret_cast<const f32x4*>(yc + r * 2 * H + h); b += *reinterpret_cast<const f32x4*>(yc + r * 2 * H + H + h); }
+        f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * H + h), da, db;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = tanhf(a[e]), s = 1.f / (1.f + expf(-b[e]));
+            da[e] = g[e] * (1.f - t * t) * s;
+            db[e] = g[e] * t * s * (1.f - s);
+        }
+        *reinterpret_cast<f32x4*>(dy + r * 2 * H + h) = da;
+        *reinterpret_cast<f32x4*>(dy + r * 2 * H + H + h) = db;
+    }
+}
+
+// out = (a + b) * s   (b may be null: out = a * s)
+__global__ __launch_bounds__(256) void add_scale_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ o, float s, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) o[i] = b ? (a[i] + b[i]) * s : a[i] * s;
+}
+
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const f32x4* __restrict__ a, f32x4* __restrict__ o, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        f32x4 v = a[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        o[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- scalar-input first conv (wavenet.py:118: Conv1d1x1(1, C))
+// y[p][c] = x[p] * w[c] + b[c]
+__global__ __launch_bounds__(256) void outer_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                        float* __restrict__ y, long rows, int C) {
+    const int c4n = C / 4;
+    const long total = rows * c4n;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        long r = i / c4n; int c = (int)(i % c4n) * 4;
+        f32x4 wv = *reinterpret_cast<const f32x4*>(w + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+        *reinterpret_cast<f32x4*>(y + r * C + c) = x[r] * wv + bv;
+    }
+}
+
+// part[blk][0][c] = sum_p dy[p][c] * x[p];  part[blk][1][c] = sum_p dy[p][c]
+__global__ __launch_bounds__(256) void outer_bwd_part_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                             long rows, int C, long rows_per_blk) {
+    __shared__ f32x4 r1[256], r2[256];
+    const int tid = threadIdx.x, CG = C / 4;
+    const long row0 = blockIdx.x * rows_per_blk;
+    long row1 = row0 + rows_per_blk; if (row1 > rows) row1 = rows;
+    for (int g0 = 0; g0 < CG; g0 += 256) {
+        const int cgw = min(256, CG - g0), pg = 256 / cgw, cg = tid % cgw, pl = tid / cgw;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (pl < pg)
+            for (long r = row0 + pl; r < row1; r += pg) {
+                f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + (g0 + cg) * 4);
+                s1 += g * x[r]; s2 += g;
+            }
+        r1[tid] = s1; r2[tid] = s2;
+        __syncthreads();
+        if (tid < cgw) {
+            f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < pg; ++k) { t1 += r1[k * cgw + tid]; t2 += r2[k * cgw + tid]; }
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + (g0 + tid) * 4) = t1;
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + (g0 + tid) * 4) = t2;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void outer_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, float* dw, float* db, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) { s1 += (double)part[((size_t)b * 2) * C + c]; s2 += (double)part[((size_t)b * 2 + 1) * C + c]; }
+    dw[c] = accumulate ? dw[c] + (float)s1 : (float)s1;
+    db[c] = accumulate ? db[c] + (float)s2 : (float)s2;
+}
+
+// ---------------------------------------------------------------- conditioning up-sampler (wavenet.py:153-164)
+// ConvTranspose2d(1, 1, (KH, S), stride (1, S), padding ((KH-1)/2, 0)) + ReLU on (B, F, T):
+//   out[b][f][t*S + j] = relu(bias + sum_r in[b][f + P - r][t] * w[r][j])
+template <int KH>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ y, long BF, int F, int T, int S) {
+    constexpr int P = (KH - 1) / 2;
+    const long total = BF * T * S;
+    const float b0 = bias[0];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        long bf = i / ((long)T * S); int to = (int)(i % ((long)T * S));
+        int t = to / S, j = to % S, f = (int)(bf % F);
+        float acc = b0;
+#pragma unroll
+        for (int r = 0; r < KH; ++r) {
+            int fi = f + P - r;
+            if ((unsigned)fi < (unsigned)F) acc += x[(bf - f + fi) * T + t] * w[r * S + j];
+        }
+        y[i] = acc > 0.f ? acc : 0.f;
+    }
+}
+
+// dx[b][f][t] = sum_{r,j} dpre[b][f - P + r][t*S + j] * w[r][j],  dpre = dy * (y > 0)
+template <int KH>
+__global__ __launch_bounds__(256) void upsample_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ w,
+                                                             float* __restrict__ dx, long BF, int F, int T, int S) {
+    constexpr int P = (KH - 1) / 2;
+    const long total = BF * T;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        long bf = i / T; int t = (int)(i % T), f = (int)(bf % F);
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < KH; ++r) {
+            int fo = f - P + r;
+            if ((unsigned)fo >= (unsigned)F) continue;
+            const long base = ((bf - f + fo) * T + t) * S;
+            for (int j = 0; j < S; ++j) { float g = y[base + j] > 0.f ? dy[base + j] : 0.f; acc += g * w[r * S + j]; }
+        }
+        dx[i] = acc;
+    }
+}
+
+// part[blk][r*S + j] = sum dpre[b][f][t*S+j] * x[b][f + P - r][t];  part[blk][KH*S] = sum dpre     (S <= 16)
+template <int KH>
+__global__ __launch_bounds__(256) void upsample_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+                                                             float* __restrict__ part, long BF, int F, int T, int S) {
+    constexpr int P = (KH - 1) / 2;
+    __shared__ float red[4];
+    float acc[KH * 16 + 1];
+#pragma unroll
+    for (int k = 0; k < KH * 16 + 1; ++k) acc[k] = 0.f;
+    const long total = BF * T;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        long bf = i / T; int t = (int)(i % T), f = (int)(bf % F);
+        float xin[KH];
+#pragma unroll
+        for (int r = 0; r < KH; ++r) { int fi = f + P - r; xin[r] = ((unsigned)fi < (unsigned)F) ? x[(bf - f + fi) * T + t] : 0.f; }
+        const long base = (bf * T + t) * S;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < S) {
+                float g = y[base + j] > 0.f ? dy[base + j] : 0.f;
+                acc[KH * 16] += g;
+#pragma unroll
+                for (int r = 0; r < KH; ++r) acc[r * 16 + j] += g * xin[r];
+            }
+    }
+    for (int k = 0; k < KH * 16 + 1; ++k) {
+        float s = block_sum(acc[k], red);
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * (KH * 16 + 1) + k] = s;
+    }
+}
+
+__global__ void upsample_bwd_final_kernel(const float* __restrict__ part, int nblk, int KH, int S, float* dw, float* db, int accumulate) {
+    int k = threadIdx.x;
+    const int W = KH * 16 + 1;
+    if (k >= W) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * W + k];
+    if (k == KH * 16) { db[0] = accumulate ? db[0] + (float)s : (float)s; return; }
+    int r = k / 16, j = k % 16;
+    if (j < S) dw[r * S + j] = accumulate ? dw[r * S + j] + (float)s : (float)s;
+}
+
+// ---------------------------------------------------------------- discretised mixture of logistics (mixture.py:25-105)
+__device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch softplus (threshold 20)
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// yhat: rows of `pitch` floats, first 3*K are [logit | mean | log_scale]; target y[row]; out loss[row] = -logsumexp_k(...)
+// dyh (optional, same pitch): d(sum_rows wrow[row] * loss[row]) / d yhat
+template <int K>
+__global__ __launch_bounds__(256) void mol_loss_kernel(const float* __restrict__ yhat, const float* __restrict__ y, const float* __restrict__ wrow,
+                                                       float* __restrict__ loss, float* __restrict__ dyh, long rows, int pitch,
+                                                       float num_classes, float log_scale_min) {
+    const float h = 1.f / (num_classes - 1.f), logh2 = logf((num_classes - 1.f) * 0.5f);
+    for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (long)gridDim.x * 256L) {
+        const float* p = yhat + r * pitch;
+        const float yy = y[r];
+        float logit[K], lp[K], dm[K], dls[K];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { logit[k] = p[k]; mx = fmaxf(mx, logit[k]); }
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) se += expf(logit[k] - mx);
+        const float lse_logit = mx + logf(se);
+        float best = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float m = p[K + k], lsr = p[2 * K + k];
+            const bool clamped = lsr < log_scale_min;
+            const float ls = clamped ? log_scale_min : lsr;
+            const float inv = expf(-ls), c = yy - m;
+            const float pin = inv * (c + h), min_ = inv * (c - h), mid = inv * c;
+            float v, gm, gs;                              // value, d/dmean, d/dlog_scale
+            if (yy < -0.999f) {
+                v = pin - softplusf(pin);
+                float d = sigmoidf(-pin);
+                gm = d * (-inv); gs = d * (-pin);
+            } else if (yy > 0.999f) {
+                v = -softplusf(min_);
+                float d = -sigmoidf(min_);
+                gm = d * (-inv); gs = d * (-min_);
+            } else {
+                const float sp = sigmoidf(pin), sm = sigmoidf(min_), cd = sp - sm;
+                if (cd > 1e-5f) {
+                    v = logf(fmaxf(cd, 1e-12f));
+                    const float dp = sp * (1.f - sp) / cd, dn = -sm * (1.f - sm) / cd;
+                    gm = (dp + dn) * (-inv); gs = dp * (-pin) + dn * (-min_);
+                } else {
+                    v = mid - ls - 2.f * softplusf(mid) - logh2;
+                    const float d = 1.f - 2.f * sigmoidf(mid);
+                    gm = d * (-inv); gs = d * (-mid) - 1.f;
+                }
+            }
+            if (clamped) gs = 0.f;
+            lp[k] = v + (logit[k] - lse_logit);
+            dm[k] = gm; dls[k] = gs;
+            best = fmaxf(best, lp[k]);
+        }
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) s2 += expf(lp[k] - best);
+        const float lse = best + logf(s2);
+        loss[r] = -lse;
+        if (dyh) {
+            const float wr = wrow ? wrow[r] : 1.f;
+            float* q = dyh + r * pitch;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float pk = expf(lp[k] - lse);                 // posterior responsibility
+                const float sk = expf(logit[k] - lse_logit);        // prior softmax
+                q[k] = wr * (sk - pk);
+                q[K + k] = wr * (-pk * dm[k]);
+                q[2 * K + k] = wr * (-pk * dls[k]);
+            }
+            for (int k = 3 * K; k < pitch; ++k) q[k] = 0.f;
+        }
+    }
+}
+
+// sample (mixture.py:117-153) with INJECTED uniforms u1[row][K], u2[row] in (1e-5, 1-1e-5)
+template <int K>
+__global__ __launch_bounds__(256) void mol_sample_kernel(const float* __restrict__ yhat, const float* __restrict__ u1, const float* __restrict__ u2,
+                                                         float* __restrict__ out, long rows, int pitch, float log_scale_min) {
+    for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (long)gridDim.x * 256L) {
+        const float* p = yhat + r * pitch;
+        float best = -INFINITY; int arg = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float t = p[k] - logf(-logf(u1[r * K + k]));
+            if (t > best) { best = t; arg = k; }
+        }
+        const float m = p[K + arg], ls = fmaxf(p[2 * K + arg], log_scale_min), u = u2[r];
+        float x = m + expf(ls) * (logf(u) - logf(1.f - u));
+        out[r] = fminf(fmaxf(x, -1.f), 1.f);
+    }
+}
+
+// masked mean: out = sum(loss * mask) / sum(mask)     (loss_functions.py:43-62)
+__global__ __launch_bounds__(256) void masked_mean_kernel(const float* __restrict__ loss, const float* __restrict__ mask, long n, float* out, float* wrow) {
+    __shared__ double r1[4], r2[4];
+    double a = 0.0, b = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) { float m = mask ? mask[i] : 1.f; a += (double)loss[i] * m; b += m; }
+    a = wave_sum_d(a); b = wave_sum_d(b);
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = a; r2[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    const double sa = r1[0] + r1[1] + r1[2] + r1[3], sb = r2[0] + r2[1] + r2[2] + r2[3];
+    if (threadIdx.x == 0) *out = (float)(sa / sb);
+    if (wrow) for (long i = threadIdx.x; i < n; i += 256) wrow[i] = (mask ? mask[i] : 1.f) / (float)sb;
+}
+
+__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ d, const float* __restrict__ gscale, long n) {
+    const float g = *gscale;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) d[i] *= g;
+}
+
+}  // namespace
+
+extern "C" int viai_weight_norm_fwd(const float* v, const float* g, float* w, float* norm, int rows, int L, void* stream) {
+    VIAI_LAUNCH(weight_norm_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, v, g, w, norm, L);
+    return viai_launch_status();
+}
+
+extern "C" int viai_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, float* dv, float* dg,
+                                    int rows, int L, int accumulate, void* stream) {
+    VIAI_LAUNCH(weight_norm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dw, v, g, norm, dv, dg, L, accumulate);
+    return viai_launch_status();
+}
+
+extern "C" int viai_glu_fwd(const float* y, const float* yc, float* z, long rows, int H, void* stream) {
+    if (H % 4 != 0) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(glu_fwd_kernel, dim3(ew_blocks(rows * (H / 4))), dim3(256), 0, (hipStream_t)stream, y, yc, z, rows, H);
+    return viai_launch_status();
+}
+
+extern "C" int viai_glu_bwd(const float* dz, const float* y, const float* yc, float* dy, long rows, int H, void* stream) {
+    if (H % 4 != 0) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(glu_bwd_kernel, dim3(ew_blocks(rows * (H / 4))), dim3(256), 0, (hipStream_t)stream, dz, y, yc, dy, rows, H);
+    return viai_launch_status();
+}
+
+extern "C" int viai_add_scale(const float* a, const float* b, float* out, float s, long n, void* stream) {
+    if (n % 4 != 0) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(add_scale_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(a),
+                reinterpret_cast<const f32x4*>(b), reinterpret_cast<f32x4*>(out), s, n / 4);
+    return viai_launch_status();
+}
+
+extern "C" int viai_relu_fwd(const float* a, float* out, long n, void* stream) {
+    if (n % 4 != 0) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(relu_fwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(a), reinterpret_cast<f32x4*>(out), n / 4);
+    return viai_launch_status();
+}
+
+extern "C" int viai_outer_fwd(const float* x, const float* w, const float* b, float* y, long rows, int C, void* stream) {
+    if (C % 4 != 0) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(outer_fwd_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, w, b, y, rows, C);
+    return viai_launch_status();
+}
+
+extern "C" int viai_outer_bwd_blocks(long rows) { long b = (rows + 1023) / 1024; if (b > 1024) b = 1024; if (b < 1) b = 1; return (int)b; }
+
+extern "C" int viai_outer_bwd(const float* dy, const float* x, float* part, float* dw, float* db, long rows, int C, int accumulate, void* stream) {
+    if (C % 4 != 0) return (int)hipErrorInvalidValue;
+    int nb = viai_outer_bwd_blocks(rows);
+    long rpb = (rows + nb - 1) / nb;
+    VIAI_LAUNCH(outer_bwd_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, part, rows, C, rpb);
+    VIAI_LAUNCH(outer_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nb, C, dw, db, accumulate);
+    return viai_launch_status();
+}
+
+extern "C" int viai_upsample_fwd(const float* x, const float* w, const float* bias, float* y, int B, int F, int T, int KH, int S, void* stream) {
+    if (KH != 3 && KH != 1) return (int)hipErrorInvalidValue;
+    long BF = (long)B * F;
+    int blocks = ew_blocks(BF * T * S);
+    if (KH == 3) VIAI_LAUNCH(upsample_fwd_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, BF, F, T, S);
+    else VIAI_LAUNCH(upsample_fwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, BF, F, T, S);
+    return viai_launch_status();
+}
+
+extern "C" int viai_upsample_bwd_blocks(void) { return 512; }
+
+extern "C" int viai_upsample_bwd(const float* dy, const float* y, const float* x, const float* w, float* part, float* dx, float* dw, float* db,
+                                 int B, int F, int T, int KH, int S, int accumulate, void* stream) {
+    if ((KH != 3 && KH != 1) || S > 16) return (int)hipErrorInvalidValue;
+    long BF = (long)B * F;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = 512;
+    if (KH == 3) {
+        if (dx) VIAI_LAUNCH(upsample_bwd_x_kernel<3>, dim3(ew_blocks(BF * T)), dim3(256), 0, st, dy, y, w, dx, BF, F, T, S);
+        VIAI_LAUNCH(upsample_bwd_w_kernel<3>, dim3(nb), dim3(256), 0, st, dy, y, x, part, BF, F, T, S);
+    } else {
+        if (dx) VIAI_LAUNCH(upsample_bwd_x_kernel<1>, dim3(ew_blocks(BF * T)), dim3(256), 0, st, dy, y, w, dx, BF, F, T, S);
+        VIAI_LAUNCH(upsample_bwd_w_kernel<1>, dim3(nb), dim3(256), 0, st, dy, y, x, part, BF, F, T, S);
+    }
+    VIAI_LAUNCH(upsample_bwd_final_kernel, dim3(1), dim3(64), 0, st, part, nb, KH, S, dw, db, accumulate);
+    return viai_launch_status();
+}
+
+extern "C" int viai_mol_loss(const float* yhat, const float* y, const float* mask, float* loss_rows, float* wrow, float* loss,
+                             float* dyhat, long rows, int pitch, int nr_mix, float num_classes, float log_scale_min, void* stream) {
+    if (nr_mix != 10 || pitch < 30) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    // pass 1: per-row losses; masked mean + normalised row weights; pass 2 (if dyhat): gradients with those weights
+    VIAI_LAUNCH(mol_loss_kernel<10>, dim3(ew_blocks(rows)), dim3(256), 0, st, yhat, y, (const float*)nullptr, loss_rows, (float*)nullptr, rows, pitch, num_classes, log_scale_min);
+    VIAI_LAUNCH(masked_mean_kernel, dim3(1), dim3(256), 0, st, loss_rows, mask, rows, loss, wrow);
+    if (dyhat) VIAI_LAUNCH(mol_loss_kernel<10>, dim3(ew_blocks(rows)), dim3(256), 0, st, yhat, y, wrow, loss_rows, dyhat, rows, pitch, num_classes, log_scale_min);
+    return viai_launch_status();
+}
+
+extern "C" int viai_scale_by_scalar(float* d, const float* gscale, long n, void* stream) {
+    VIAI_LAUNCH(scale_rows_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, d, gscale, n);
+    return viai_launch_status();
+}
+
+extern "C" int viai_mol_sample(const float* yhat, const float* u1, const float* u2, float* out, long rows, int pitch, int nr_mix,
+                               float log_scale_min, void* stream) {
+    if (nr_mix != 10) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(mol_sample_kernel<10>, dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, yhat, u1, u2, out, rows, pitch, log_scale_min);
+    return viai_launch_status();
+}

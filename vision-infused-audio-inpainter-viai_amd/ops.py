@@ -52,8 +52,8 @@ def _c(t):
 _desc_cache = {}
 
 
-def conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed):
-    key = (N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed)
+def conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed, dh=1, dw=1, ph2=-1, pw2=-1):
+    key = (N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed, dh, dw, ph2, pw2)
     d = _desc_cache.get(key)
     if d is None:
         lib = _lib.load()
@@ -94,8 +94,9 @@ class _ConvBnAct(torch.autograd.Function):
         cin_w = weight.shape[0] if transposed else weight.shape[1]
         if C2 == 0 and C1 == 4 and 1 < cin_w < 4:
             C1 = cin_w                      # frames stored with channel stride 4 (zero padded): ResNet conv1
+        dil, p2 = cfg.get("d", (1, 1)), cfg.get("p2", (-1, -1))
         d = conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, cfg["s"][0], cfg["s"][1], cfg["p"][0], cfg["p"][1],
-                      1 if transposed else 0)
+                      1 if transposed else 0, dil[0], dil[1], p2[0], p2[1])
         st = _stream()
         dev = x.device
         OH, OW = d["OH"], d["OW"]
@@ -214,10 +215,12 @@ class _ConvBnAct(torch.autograd.Function):
 
 
 def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding=(0, 0), transposed=False,
-                act=ACT_NONE, x2=None, training=True):
-    """Fused layer on NHWC tensors.  `bn` is an nn.BatchNorm2d (parameter/buffer holder) or None."""
+                act=ACT_NONE, x2=None, training=True, dilation=(1, 1), padding2=(-1, -1)):
+    """Fused layer on NHWC tensors.  `bn` is an nn.BatchNorm2d (parameter/buffer holder) or None.
+    `padding2` = (bottom, right) padding when it differs from `padding` (-1 = symmetric)."""
     cfg = {"k": tuple(kernel), "s": tuple(stride), "p": tuple(padding), "transposed": bool(transposed),
-           "act": int(act), "training": bool(training), "momentum": 0.1, "eps": BN_EPS}
+           "act": int(act), "training": bool(training), "momentum": 0.1, "eps": BN_EPS,
+           "d": tuple(dilation), "p2": tuple(padding2)}
     if bn is not None:
         cfg["momentum"] = 0.1 if bn.momentum is None else float(bn.momentum)
         cfg["eps"] = float(bn.eps)

@@ -1,0 +1,415 @@
+"""WaveNet vocoder on the HIP kernels: the reference's `wavenet_vocoder.WaveNet` API and state_dict.
+
+Reference: wavenet_vocoder/wavenet.py:62-393 (WaveNet), modules.py:30-216 (weight-normed Conv1d / Conv1d1x1 /
+ConvTranspose2d factories, ResidualConv1dGLU), conv.py:7-65 (incremental Conv1d), mixture.py:25-153 (MoL).
+Tensors are (B, 1, T, C) NHWC internally; the module API takes / returns the reference's (B, C, T).
+Known latent bugs of the reference that are NOT reproduced as features: `self.softmax(x, dim=1)` TypeError
+(wavenet.py:233) and the 5x `self.conv.clear_buffer()` (modules.py:213-216).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .ops import ACT_NONE, ACT_RELU, _c, _ptr, _require, _stream
+
+
+# ----------------------------------------------------------------------------- autograd ops
+class _WeightNorm(torch.autograd.Function):
+    """w = g * v / ||v||  per output row (torch.nn.utils.weight_norm, dim=0)."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        lib = _lib.load()
+        _require(v, g)
+        v, g = _c(v), _c(g)
+        rows = v.shape[0]
+        L = v.numel() // rows
+        w = torch.empty_like(v)
+        norm = torch.empty(rows, device=v.device, dtype=torch.float32)
+        _lib.check(lib.viai_weight_norm_fwd(v.data_ptr(), g.data_ptr(), w.data_ptr(), norm.data_ptr(), rows, L, _stream()), "viai_weight_norm_fwd")
+        ctx.save_for_backward(v, g, norm)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        lib = _lib.load()
+        v, g, norm = ctx.saved_tensors
+        dw = _c(dw)
+        rows = v.shape[0]
+        dv, dg = torch.empty_like(v), torch.empty_like(g)
+        _lib.check(lib.viai_weight_norm_bwd(dw.data_ptr(), v.data_ptr(), g.data_ptr(), norm.data_ptr(), dv.data_ptr(), dg.data_ptr(),
+                                            rows, v.numel() // rows, 0, _stream()), "viai_weight_norm_bwd")
+        return dv, dg
+
+
+def normed_weight(m):
+    """effective weight of a (possibly weight-normed) holder module."""
+    if hasattr(m, "weight_g"):
+        return _WeightNorm.apply(m.weight_v, m.weight_g)
+    return m.weight
+
+
+class _GLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, yc):
+        lib = _lib.load()
+        _require(y, yc)
+        y = _c(y)
+        yc = _c(yc) if yc is not None else None
+        H = y.shape[-1] // 2
+        rows = y.numel() // (2 * H)
+        z = torch.empty(y.shape[:-1] + (H,), device=y.device, dtype=torch.float32)
+        _lib.check(lib.viai_glu_fwd(y.data_ptr(), _ptr(yc), z.data_ptr(), rows, H, _stream()), "viai_glu_fwd")
+        ctx.save_for_backward(y, yc)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        y, yc = ctx.saved_tensors
+        dz = _c(dz)
+        H = y.shape[-1] // 2
+        dy = torch.empty_like(y)
+        _lib.check(lib.viai_glu_bwd(dz.data_ptr(), y.data_ptr(), _ptr(yc), dy.data_ptr(), y.numel() // (2 * H), H, _stream()), "viai_glu_bwd")
+        return dy, (dy if yc is not None else None)
+
+
+class _AddScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, s):
+        lib = _lib.load()
+        _require(a, b)
+        a = _c(a)
+        b = _c(b) if b is not None else None
+        out = torch.empty_like(a)
+        _lib.check(lib.viai_add_scale(a.data_ptr(), _ptr(b), out.data_ptr(), s, a.numel(), _stream()), "viai_add_scale")
+        ctx.s, ctx.hb = s, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        g = _c(g)
+        d = torch.empty_like(g)
+        _lib.check(lib.viai_add_scale(g.data_ptr(), 0, d.data_ptr(), ctx.s, g.numel(), _stream()), "viai_add_scale")
+        return d, (d if ctx.hb else None), None
+
+
+def add_scale(a, b, s):
+    return _AddScale.apply(a, b, float(s))
+
+
+class _Relu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        lib = _lib.load()
+        _require(a)
+        a = _c(a)
+        out = torch.empty_like(a)
+        _lib.check(lib.viai_relu_fwd(a.data_ptr(), out.data_ptr(), a.numel(), _stream()), "viai_relu_fwd")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (out,) = ctx.saved_tensors
+        g = _c(g)
+        d = torch.empty_like(g)
+        _lib.check(lib.viai_relu_bwd(g.data_ptr(), out.data_ptr(), d.data_ptr(), g.numel(), _stream()), "viai_relu_bwd")
+        return d
+
+
+class _Outer(torch.autograd.Function):
+    """Conv1d1x1(1, C) on a scalar signal: y[p][c] = x[p]*w[c] + b[c]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.load()
+        _require(x, w, b)
+        x, w, b = _c(x), _c(w), _c(b)
+        Cc = w.numel()
+        rows = x.numel()
+        y = torch.empty(x.shape[:3] + (Cc,), device=x.device, dtype=torch.float32)
+        _lib.check(lib.viai_outer_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), rows, Cc, _stream()), "viai_outer_fwd")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        Cc, rows = w.numel(), x.numel()
+        part = torch.empty(2 * Cc * lib.viai_outer_bwd_blocks(rows), device=dy.device, dtype=torch.float32)
+        dw, db = torch.empty_like(w), torch.empty(Cc, device=dy.device, dtype=torch.float32)
+        _lib.check(lib.viai_outer_bwd(dy.data_ptr(), x.data_ptr(), part.data_ptr(), dw.data_ptr(), db.data_ptr(), rows, Cc, 0, _stream()), "viai_outer_bwd")
+        return None, dw, db
+
+
+class _Upsample(torch.autograd.Function):
+    """ConvTranspose2d(1,1,(KH,S),stride (1,S),padding ((KH-1)/2,0)) + ReLU on (B,F,T) (wavenet.py:153-164)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.load()
+        _require(x, w, b)
+        x, w, b = _c(x), _c(w), _c(b)
+        B, Fq, T = x.shape
+        KH, S = w.shape[2], w.shape[3]
+        y = torch.empty((B, Fq, T * S), device=x.device, dtype=torch.float32)
+        _lib.check(lib.viai_upsample_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, Fq, T, KH, S, _stream()), "viai_upsample_fwd")
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        B, Fq, T = x.shape
+        KH, S = w.shape[2], w.shape[3]
+        part = torch.empty((KH * 16 + 1) * lib.viai_upsample_bwd_blocks(), device=dy.device, dtype=torch.float32)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw, db = torch.empty_like(w), torch.empty(1, device=dy.device, dtype=torch.float32)
+        _lib.check(lib.viai_upsample_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), part.data_ptr(), _ptr(dx), dw.data_ptr(),
+                                         db.data_ptr(), B, Fq, T, KH, S, 0, _stream()), "viai_upsample_bwd")
+        return dx, dw, db
+
+
+class _MoLLoss(torch.autograd.Function):
+    """DiscretizedMixturelogisticLoss: masked mean of the MoL negative log-likelihood (loss_functions.py:43-62)."""
+
+    @staticmethod
+    def forward(ctx, yhat, y, mask, num_classes, log_scale_min):
+        lib = _lib.load()
+        _require(yhat, y, mask)
+        yhat, y = _c(yhat), _c(y)
+        mask = _c(mask) if mask is not None else None
+        pitch = yhat.shape[-1]
+        rows = yhat.numel() // pitch
+        dev = yhat.device
+        loss_rows = torch.empty(rows, device=dev, dtype=torch.float32)
+        wrow = torch.empty(rows, device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        dyh = torch.empty_like(yhat) if yhat.requires_grad else None
+        _lib.check(lib.viai_mol_loss(yhat.data_ptr(), y.data_ptr(), _ptr(mask), loss_rows.data_ptr(), wrow.data_ptr(), loss.data_ptr(),
+                                     _ptr(dyh), rows, pitch, 10, float(num_classes), float(log_scale_min), _stream()), "viai_mol_loss")
+        ctx.dyh = dyh
+        ctx.mark_non_differentiable(loss_rows)
+        return loss, loss_rows
+
+    @staticmethod
+    def backward(ctx, g, _g2):
+        lib = _lib.load()
+        d = ctx.dyh
+        g = _c(g)
+        _lib.check(lib.viai_scale_by_scalar(d.data_ptr(), g.data_ptr(), d.numel(), _stream()), "viai_scale_by_scalar")
+        return d, None, None, None, None
+
+
+def mol_loss(yhat_nhwc, y, mask=None, num_classes=65536, log_scale_min=math.log(1e-14)):
+    """yhat_nhwc: (B,1,T,P>=30) rows [logit|mean|log_scale]x10; y: (B,T[,1]) targets in [-1,1]; mask (B,T[,1])."""
+    loss, _ = _MoLLoss.apply(yhat_nhwc, y.reshape(-1), None if mask is None else mask.reshape(-1), num_classes, log_scale_min)
+    return loss
+
+
+def mol_sample(yhat_nhwc, u1, u2, log_scale_min=-7.0):
+    """sample_from_discretized_mix_logistic with injected uniforms u1 (rows,10), u2 (rows,)."""
+    lib = _lib.load()
+    yh = _c(yhat_nhwc)
+    pitch = yh.shape[-1]
+    rows = yh.numel() // pitch
+    out = torch.empty(rows, device=yh.device, dtype=torch.float32)
+    _lib.check(lib.viai_mol_sample(yh.data_ptr(), _c(u1).data_ptr(), _c(u2).data_ptr(), out.data_ptr(), rows, pitch, 10,
+                                   float(log_scale_min), _stream()), "viai_mol_sample")
+    return out
+
+
+# ----------------------------------------------------------------------------- modules
+def _wn(m, on):
+    return nn.utils.weight_norm(m) if on else m
+
+
+def Conv1d(in_channels, out_channels, kernel_size=1, padding=0, dilation=1, bias=True, weight_normalization=True,
+           dropout=0, std_mul=1.0):
+    """modules.py:30-41 (parameter holder; the arithmetic is viai_conv2d_* with kh = 1)."""
+    m = nn.Conv1d(in_channels, out_channels, kernel_size, padding=padding, dilation=dilation, bias=bias)
+    if weight_normalization:
+        std = math.sqrt((std_mul * (1.0 - dropout)) / (m.kernel_size[0] * in_channels))
+        m.weight.data.normal_(mean=0, std=std)
+        m.bias.data.zero_()
+    return _wn(m, weight_normalization)
+
+
+def Conv1d1x1(in_channels, out_channels, bias=True, weight_normalization=True):
+    return Conv1d(in_channels, out_channels, 1, 0, 1, bias, weight_normalization)
+
+
+def conv1d_apply(x, m, act=ACT_NONE, causal_crop=False):
+    """x (B,1,T,Cin) -> (B,1,T',Cout) with holder m (nn.Conv1d, maybe weight-normed)."""
+    w = normed_weight(m).unsqueeze(2)                         # (Cout,Cin,1,k)
+    k, d, p = m.kernel_size[0], m.dilation[0], m.padding[0]
+    return ops.conv_bn_act(x, w, m.bias, None, kernel=(1, k), stride=(1, 1), padding=(0, p), dilation=(1, d),
+                           padding2=(-1, 0 if causal_crop else -1), act=act)
+
+
+class ResidualConv1dGLU(nn.Module):
+    """modules.py:84-216."""
+
+    def __init__(self, residual_channels, gate_channels, kernel_size, skip_out_channels=None, cin_channels=-1, gin_channels=-1,
+                 dropout=1 - 0.95, padding=None, dilation=1, causal=True, bias=True, weight_normalization=True):
+        super().__init__()
+        self.dropout = dropout
+        skip_out_channels = residual_channels if skip_out_channels is None else skip_out_channels
+        if padding is None:
+            padding = (kernel_size - 1) * dilation if causal else (kernel_size - 1) // 2 * dilation
+        self.causal = causal
+        self.conv = Conv1d(residual_channels, gate_channels, kernel_size, padding=padding, dilation=dilation, bias=bias,
+                           weight_normalization=weight_normalization)
+        self.conv1x1c = Conv1d1x1(cin_channels, gate_channels, bias, weight_normalization) if cin_channels > 0 else None
+        self.conv1x1g = Conv1d1x1(gin_channels, gate_channels, bias, weight_normalization) if gin_channels > 0 else None
+        self.conv1x1_out = Conv1d1x1(gate_channels // 2, residual_channels, bias, weight_normalization)
+        self.conv1x1_skip = Conv1d1x1(gate_channels // 2, skip_out_channels, bias, weight_normalization)
+
+    def forward_nhwc(self, x, c=None, g=None):
+        residual = x
+        if self.training and self.dropout > 0:
+            x = torch.nn.functional.dropout(x, p=self.dropout, training=True)   # RNG-dependent: parity tests use dropout = 0
+        y = conv1d_apply(x, self.conv, causal_crop=self.causal)                 # (B,1,T,gate)  modules.py:176-181
+        yc = None
+        if c is not None:
+            yc = conv1d_apply(c, self.conv1x1c)                                 # :187-191
+        if g is not None:
+            yg = conv1d_apply(g, self.conv1x1g)                                 # :194-198
+            yc = yg if yc is None else yc + yg
+        z = _GLU.apply(y, yc)                                                   # :201
+        s = conv1d_apply(z, self.conv1x1_skip)                                  # :204
+        out = conv1d_apply(z, self.conv1x1_out)                                 # :207
+        return add_scale(out, residual, math.sqrt(0.5)), s                      # :209
+
+
+class WaveNet(nn.Module):
+    """wavenet.py:62-393 (scalar_input=True / mixture-of-logistics output is the reference's configuration)."""
+
+    def __init__(self, out_channels=30, layers=24, stacks=4, residual_channels=512, gate_channels=512, skip_out_channels=256,
+                 kernel_size=3, dropout=1 - 0.95, cin_channels=80, gin_channels=-1, n_speakers=None, weight_normalization=True,
+                 upsample_conditional_features=True, upsample_scales=(4, 4, 4, 4), freq_axis_kernel_size=3, scalar_input=True,
+                 use_speaker_embedding=True):
+        super().__init__()
+        assert layers % stacks == 0
+        self.scalar_input, self.out_channels, self.cin_channels = scalar_input, out_channels, cin_channels
+        per = layers // stacks
+        self.first_conv = Conv1d1x1(1 if scalar_input else out_channels, residual_channels, True, weight_normalization)
+        self.conv_layers = nn.ModuleList([
+            ResidualConv1dGLU(residual_channels, gate_channels, kernel_size, skip_out_channels, cin_channels, gin_channels, dropout,
+                              dilation=2 ** (i % per), bias=True, weight_normalization=weight_normalization) for i in range(layers)])
+        self.last_conv_layers = nn.ModuleList([nn.ReLU(inplace=True), Conv1d1x1(skip_out_channels, skip_out_channels, True, weight_normalization),
+                                               nn.ReLU(inplace=True), Conv1d1x1(skip_out_channels, out_channels, True, weight_normalization)])
+        self.embed_speakers = None
+        if gin_channels > 0 and use_speaker_embedding:
+            self.embed_speakers = nn.Embedding(n_speakers, gin_channels)
+            self.embed_speakers.weight.data.normal_(0, 0.1)
+        self.upsample_conv = None
+        if upsample_conditional_features:
+            self.upsample_conv = nn.ModuleList()
+            for s in upsample_scales:
+                m = nn.ConvTranspose2d(1, 1, (freq_axis_kernel_size, s), padding=((freq_axis_kernel_size - 1) // 2, 0), dilation=1, stride=(1, s))
+                m.weight.data.fill_(1.0 / freq_axis_kernel_size)
+                m.bias.data.zero_()
+                self.upsample_conv.append(_wn(m, weight_normalization))
+                self.upsample_conv.append(nn.ReLU(inplace=True))
+        self.receptive_field = (kernel_size - 1) * sum(2 ** (i % per) for i in range(layers)) + 1
+
+    def has_speaker_embedding(self):
+        return self.embed_speakers is not None
+
+    def local_conditioning_enabled(self):
+        return self.cin_channels > 0
+
+    def _upsample(self, c):
+        """c (B, cin, T') -> (B, cin, T) through the weight-normed transposed-conv stack (wavenet.py:208-215)."""
+        if c is None or self.upsample_conv is None:
+            return c
+        for m in self.upsample_conv:
+            if isinstance(m, nn.ReLU):
+                continue                                             # fused into the kernel
+            c = _Upsample.apply(c, normed_weight(m), m.bias)
+        return c
+
+    def _global(self, g, B, T):
+        if g is None:
+            return None
+        if self.embed_speakers is not None:
+            g = self.embed_speakers(g.view(B, -1)).transpose(1, 2)
+        g = g.unsqueeze(-1) if g.dim() == 2 else g
+        return g.expand(B, -1, T).transpose(1, 2).unsqueeze(1).contiguous()          # (B,1,T,gin)
+
+    def forward_nhwc(self, x, c=None, g=None):
+        """x (B,1,T) or (B,out,T); returns (B,1,T,P) with P = out_channels padded to a multiple of 4."""
+        B, _, T = x.size()
+        g_n = self._global(g, B, T)
+        c = self._upsample(c)
+        c_n = None
+        if c is not None:
+            assert c.size(-1) == T
+            c_n = c.transpose(1, 2).unsqueeze(1).contiguous()                         # (B,1,T,cin)
+        if self.scalar_input:
+            h = _Outer.apply(x.reshape(B, 1, T).contiguous(), normed_weight(self.first_conv).reshape(-1), self.first_conv.bias)
+        else:
+            h = conv1d_apply(x.transpose(1, 2).unsqueeze(1).contiguous(), self.first_conv)
+        skips = None
+        for f in self.conv_layers:
+            h, s = f.forward_nhwc(h, c_n, g_n)
+            skips = s if skips is None else add_scale(skips, s, math.sqrt(0.5))       # wavenet.py:222-226
+        h = _Relu.apply(skips)
+        h = conv1d_apply(h, self.last_conv_layers[1], act=ACT_RELU)
+        last = self.last_conv_layers[3]
+        w = normed_weight(last)
+        pad = (-self.out_channels) % 4
+        bias = last.bias
+        if pad:                                                                       # 30 -> 32 output rows (16-byte rows)
+            w = torch.cat((w, w.new_zeros((pad,) + tuple(w.shape[1:]))), 0)
+            bias = torch.cat((bias, bias.new_zeros(pad)), 0)
+        return ops.conv_bn_act(h, w.unsqueeze(2), bias, None, kernel=(1, 1), stride=(1, 1), padding=(0, 0))
+
+    def forward(self, x, c=None, g=None, softmax=False):
+        y = self.forward_nhwc(x, c, g)                                                # (B,1,T,P)
+        y = y[..., :self.out_channels].squeeze(1).transpose(1, 2)                     # (B, out, T) view
+        return torch.softmax(y, dim=1) if softmax else y
+
+    def clear_buffer(self):
+        pass                                                                          # incremental state lives in IncrementalState
+
+    def make_generation_fast_(self):
+        def rm(m):
+            try:
+                nn.utils.remove_weight_norm(m)
+            except ValueError:
+                return
+        self.apply(rm)
+
+
+class DiscretizedMixturelogisticLoss(nn.Module):
+    """loss_functions.py:43-62; input (B, C, T) or the NHWC tensor of WaveNet.forward_nhwc, target (B, T, 1)."""
+
+    def __init__(self, quantize_channels=65536, log_scale_min=math.log(1e-14)):
+        super().__init__()
+        self.quantize_channels, self.log_scale_min = quantize_channels, log_scale_min
+
+    def forward(self, input, target, lengths=None, mask=None, max_len=None):
+        if lengths is None and mask is None:
+            raise RuntimeError("Should provide either lengths or mask")
+        if mask is None:
+            ml = int(lengths.max()) if max_len is None else max_len
+            mask = (torch.arange(ml, device=lengths.device)[None, :] < lengths[:, None]).float().unsqueeze(-1)
+        if input.dim() == 3:                                                          # (B, C, T) -> NHWC rows, padded to 32
+            B, Cc, T = input.shape
+            yh = torch.nn.functional.pad(input.transpose(1, 2), (0, (-Cc) % 4)).reshape(B, 1, T, -1).contiguous()
+        else:
+            yh = input
+        return mol_loss(yh, target, mask, self.quantize_channels, self.log_scale_min)
