@@ -191,6 +191,28 @@ int viai_scale_by_scalar(float* d, const float* gscale, long n, void* stream);
 int viai_mol_sample(const float* yhat, const float* u1, const float* u2, float* out, long rows, int pitch, int nr_mix,
                     float log_scale_min, void* stream);
 
+/* Incremental synthesis, ONE time step (wavenet.py:322-357 loop body; conv.py:17-46 linearised convolutions).
+ * Weights are plain (weight norm already applied) and linearised: w_conv[g][j*C + ci] = w[g][ci][j].
+ * `step` is a device int (time index, advanced by the call); ring buffers are (B, ring_len, C) zero-initialised,
+ * ring_len > 2*dilation.  All arguments are static across steps, so the call can be captured in a hipGraph.
+ * B in {1,2,4,8}.  cond: (B, T, cin) up-sampled conditioning; u1 (B,T,out_ch/3), u2 (B,T): uniforms for the
+ * sampler; test_inputs (B, n_test) teacher-forced prefix; out (B, T).                                       */
+typedef struct viai_wn_layer {
+    const float *w_conv, *b_conv, *w_c, *b_c, *w_out, *b_out, *w_skip, *b_skip;
+    float* ring;
+    int dilation, ring_len;
+} viai_wn_layer;
+typedef struct viai_wn_synth {
+    int B, C, G, S, cin, n_layers, out_ch, T, n_test;
+    float log_scale_min;
+    const viai_wn_layer* layers;            /* HOST array of n_layers descriptors (device pointers inside) */
+    const float *w_first, *b_first, *w_l1, *b_l1, *w_l2, *b_l2;
+    const float *cond, *test_inputs, *u1, *u2;
+    float *out, *z, *skips, *yhat_dbg;      /* z: (B, G/2), skips: (B, S) scratch; yhat_dbg optional (B,T,out_ch) */
+    int* step;
+} viai_wn_synth;
+int viai_wavenet_synth_step(const viai_wn_synth* s, void* stream);
+
 /* ------------------------------------------------------------ mask / optimizer
  * s_in = s * mask, mask (N, T) broadcast over frequency (the missing
  * AudioModel.set_inputs; figure misc/pipeline2.png)                             */

@@ -89,3 +89,35 @@ def test_mol_loss_edge_branches_against_oracle():
     out.backward()
     g = rows.grad[..., :30].reshape(B, T, 30).transpose(1, 2)
     assert relerr(g, a.grad) < 1e-4
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_incremental_forward_matches_reference_golden(use_graph, golden_dir):
+    """free-running synthesis (4 teacher-forced samples, then fed back) with the sampler's uniforms injected:
+    the reference's incremental_forward output, sample for sample."""
+    gold = np.load(golden_dir + "/wavenet.npz")
+    cfg = W.WNConfig
+    B, Tg = 2, 32
+    cg = O.cf_uniform("wn.cg", (B, cfg.cin_channels, Tg // 16), 0, 1)
+    v1 = O.cf_uniform("wn.v1", (B, Tg, 10), 1e-5, 1 - 1e-5)
+    v2 = O.cf_uniform("wn.v2", (B, Tg), 1e-5, 1 - 1e-5)
+    tin = O.cf_uniform("wn.tin", (B, 1, 4), -1, 1)
+    net = build().eval()
+    gen = net.incremental_forward(None, c=cg.cuda(), g=None, T=Tg, test_inputs=tin.cuda(), softmax=False, quantize=False,
+                                  log_scale_min=-7.0, uniforms=(v1, v2), use_graph=use_graph)
+    assert tuple(gen.shape) == (B, 1, Tg)
+    assert relerr(gen, gold["gen"]) < 2e-4, relerr(gen, gold["gen"])
+
+
+def test_incremental_equals_batch_forward_under_teacher_forcing():
+    """upstream invariant (SURVEY.md §4 i): with every input teacher-forced, the step-by-step logits equal forward()."""
+    cfg = W.WNConfig
+    B, T = 2, 48
+    x = O.cf_uniform("tf.x", (B, 1, T), -1, 1)
+    c = O.cf_uniform("tf.c", (B, cfg.cin_channels, T // 16), 0, 1)
+    net = build().eval()
+    yh = net(x.cuda(), c.cuda())                                   # (B,30,T), logits at t from inputs <= t
+    xin = torch.cat((torch.zeros(B, 1, 1), x[:, :, :-1]), 2)       # incremental step t consumes x_in[t]
+    yh_shift = net(xin.cuda(), c.cuda())
+    _, logits = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=xin.cuda(), log_scale_min=-7.0, use_graph=True, return_logits=True)
+    assert relerr(logits.transpose(1, 2), yh_shift) < 1e-4

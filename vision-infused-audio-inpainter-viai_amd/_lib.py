@@ -26,6 +26,20 @@ class Conv2dDesc(C.Structure):
         "N", "IH", "IW", "C1", "C2", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "transposed", "dh", "dw", "ph2", "pw2")]
 
 
+class WnLayer(C.Structure):
+    """mirror of `viai_wn_layer`."""
+    _fields_ = [(n, C.c_void_p) for n in ("w_conv", "b_conv", "w_c", "b_c", "w_out", "b_out", "w_skip", "b_skip", "ring")] + \
+               [("dilation", C.c_int), ("ring_len", C.c_int)]
+
+
+class WnSynth(C.Structure):
+    """mirror of `viai_wn_synth`."""
+    _fields_ = [(n, C.c_int) for n in ("B", "C", "G", "S", "cin", "n_layers", "out_ch", "T", "n_test")] + [("log_scale_min", C.c_float)] + \
+               [("layers", C.POINTER(WnLayer))] + \
+               [(n, C.c_void_p) for n in ("w_first", "b_first", "w_l1", "b_l1", "w_l2", "b_l2", "cond", "test_inputs", "u1", "u2",
+                                          "out", "z", "skips", "yhat_dbg", "step")]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_long
@@ -88,6 +102,7 @@ SIGNATURES = {
     "viai_mol_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _P]),
     "viai_scale_by_scalar": (_I, [_P, _P, _L, _P]),
     "viai_mol_sample": (_I, [_P, _P, _P, _P, _L, _I, _I, _F, _P]),
+    "viai_wavenet_synth_step": (_I, [C.POINTER(WnSynth), _P]),
     "viai_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "viai_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _D, _D, _D, _F, _P]),
     "viai_colsum_blocks": (_I, [_L, _I]),

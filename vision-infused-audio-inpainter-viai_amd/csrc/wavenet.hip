@@ -457,3 +457,183 @@ extern "C" int viai_mol_sample(const float* yhat, const float* u1, const float* 
     VIAI_LAUNCH(mol_sample_kernel<10>, dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, yhat, u1, u2, out, rows, pitch, log_scale_min);
     return viai_launch_status();
 }
+
+// =====================================================================================================
+// Incremental synthesis (wavenet.py:237-364, conv.py:17-46).  One time step = first conv + per layer two
+// GEMV-batch kernels (gate, then out/skip) + head (two 1x1 layers + MoL sample).  The time index lives in
+// DEVICE memory (`step`), ring-buffer slots are derived from it inside the kernels, so every launch has static
+// arguments and one step can be captured once into a hipGraph and replayed T times.
+// Linearised weights: Wlin[g][j*C + ci] = w[g][ci][j] (conv.py:53-57), taps j = 0..2 read x[t-(2-j)*d].
+namespace {
+
+constexpr int WN_MAXB = 8;
+
+// x0[b][:] = cur[b] * w_first + b_first -> ring0[slot(t)];  cur = test_inputs[t] | out[t-1] | 0
+__global__ __launch_bounds__(256) void wn_first_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ test_inputs,
+                                                       int n_test, const float* __restrict__ out, float* __restrict__ ring, int ring_len,
+                                                       const int* __restrict__ step, int B, int C, int T) {
+    const int t = *step;
+    const int slot = t % ring_len;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * C; i += gridDim.x * 256) {
+        int b = i / C, c = i % C;
+        float cur = (t < n_test) ? test_inputs[(size_t)b * n_test + t] : (t > 0 ? out[(size_t)b * T + t - 1] : 0.f);
+        ring[((size_t)b * ring_len + slot) * C + c] = cur * w[c] + bias[c];
+    }
+}
+
+// gate: z[b][h] = tanh(A) * sigmoid(Bv),  A/Bv = rows h / h+H of (Wlin . [x(t-2d); x(t-d); x(t)] + b + Wc . c_t + bc)
+template <int NB>
+__global__ __launch_bounds__(256) void wn_gate_kernel(const float* __restrict__ ring, int ring_len, int dil, const float* __restrict__ wlin,
+                                                      const float* __restrict__ bconv, const float* __restrict__ wc, const float* __restrict__ bc,
+                                                      const float* __restrict__ cond, float* __restrict__ z, const int* __restrict__ step,
+                                                      int C, int H, int cin, int T) {
+    const int t = *step;
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (h >= H) return;
+    const int K = 3 * C;
+    float a[NB], g[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { a[b] = 0.f; g[b] = 0.f; }
+    const float* wa = wlin + (size_t)h * K;
+    const float* wg = wlin + (size_t)(h + H) * K;
+    for (int k = lane * 4; k < K; k += 256) {
+        const int j = k / C, ci = k - j * C;
+        int tt = t - (2 - j) * dil;
+        const f32x4 va = *reinterpret_cast<const f32x4*>(wa + k), vg = *reinterpret_cast<const f32x4*>(wg + k);
+        if (tt >= 0) {
+            const int slot = tt % ring_len;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(ring + ((size_t)b * ring_len + slot) * C + ci);
+                a[b] += x[0] * va[0] + x[1] * va[1] + x[2] * va[2] + x[3] * va[3];
+                g[b] += x[0] * vg[0] + x[1] * vg[1] + x[2] * vg[2] + x[3] * vg[3];
+            }
+        }
+    }
+    if (wc != nullptr)
+        for (int k = lane * 4; k < cin; k += 256) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(wc + (size_t)h * cin + k), vg = *reinterpret_cast<const f32x4*>(wc + (size_t)(h + H) * cin + k);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(cond + ((size_t)b * T + t) * cin + k);
+                a[b] += x[0] * va[0] + x[1] * va[1] + x[2] * va[2] + x[3] * va[3];
+                g[b] += x[0] * vg[0] + x[1] * vg[1] + x[2] * vg[2] + x[3] * vg[3];
+            }
+        }
+    const float ba = bconv[h] + (bc ? bc[h] : 0.f), bg = bconv[h + H] + (bc ? bc[h + H] : 0.f);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float sa = wave_sum(a[b]) + ba, sg = wave_sum(g[b]) + bg;
+        if (lane == 0) z[(size_t)b * H + h] = tanhf(sa) * (1.f / (1.f + expf(-sg)));
+    }
+}
+
+// out/skip: o < C: x_next[b][o] = (Wout[o].z + bout[o] + x_t[b][o]) * sqrt(.5) -> next ring;  o >= C: skip accumulate
+template <int NB>
+__global__ __launch_bounds__(256) void wn_out_kernel(const float* __restrict__ z, const float* __restrict__ wout, const float* __restrict__ bout,
+                                                     const float* __restrict__ wskip, const float* __restrict__ bskip,
+                                                     const float* __restrict__ ring, int ring_len, float* __restrict__ next_ring, int next_len,
+                                                     float* __restrict__ skips, int first, const int* __restrict__ step, int C, int H, int S) {
+    const int t = *step;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= C + S) return;
+    const float* w = o < C ? wout + (size_t)o * H : wskip + (size_t)(o - C) * H;
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    for (int k = lane * 4; k < H; k += 256) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(z + (size_t)b * H + k);
+            acc[b] += x[0] * wv[0] + x[1] * wv[1] + x[2] * wv[2] + x[3] * wv[3];
+        }
+    }
+    const float r5 = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float v = wave_sum(acc[b]);
+        if (lane == 0) {
+            if (o < C) {
+                float res = ring[((size_t)b * ring_len + (t % ring_len)) * C + o];
+                if (next_ring) next_ring[((size_t)b * next_len + (t % next_len)) * C + o] = (v + bout[o] + res) * r5;
+            } else {
+                float s = v + bskip[o - C];
+                float* p = skips + (size_t)b * S + (o - C);
+                *p = first ? s : (*p + s) * r5;
+            }
+        }
+    }
+}
+
+// head: relu -> W1 -> relu -> W2 -> MoL sample with injected uniforms -> out[b][t]; one block per stream
+__global__ __launch_bounds__(256) void wn_head_kernel(const float* __restrict__ skips, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ u1,
+                                                      const float* __restrict__ u2, float* __restrict__ out, float* __restrict__ yhat_dbg,
+                                                      const int* __restrict__ step, int S, int OC, int T, float log_scale_min) {
+    extern __shared__ float sm[];          // [S] relu(skips), [S] hidden, [OC] logits
+    float* xin = sm; float* hid = sm + S; float* yo = sm + 2 * S;
+    const int b = blockIdx.x, t = *step, tid = threadIdx.x;
+    for (int k = tid; k < S; k += 256) { float v = skips[(size_t)b * S + k]; xin[k] = v > 0.f ? v : 0.f; }
+    __syncthreads();
+    for (int h = tid; h < S; h += 256) {
+        float acc = b1[h];
+        for (int k = 0; k < S; ++k) acc += w1[(size_t)h * S + k] * xin[k];
+        hid[h] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    for (int o = tid; o < OC; o += 256) {
+        float acc = b2[o];
+        for (int k = 0; k < S; ++k) acc += w2[(size_t)o * S + k] * hid[k];
+        yo[o] = acc;
+        if (yhat_dbg) yhat_dbg[((size_t)b * T + t) * OC + o] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int K = OC / 3;
+        float best = -INFINITY; int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            float v = yo[k] - logf(-logf(u1[((size_t)b * T + t) * K + k]));
+            if (v > best) { best = v; arg = k; }
+        }
+        const float m = yo[K + arg], ls = fmaxf(yo[2 * K + arg], log_scale_min), u = u2[(size_t)b * T + t];
+        float x = m + expf(ls) * (logf(u) - logf(1.f - u));
+        out[(size_t)b * T + t] = fminf(fmaxf(x, -1.f), 1.f);
+    }
+}
+
+__global__ void wn_tick_kernel(int* step) { *step += 1; }
+
+template <int NB>
+int wn_step_impl(const viai_wn_synth* s, hipStream_t st) {
+    const int C = s->C, H = s->G / 2, S = s->S;
+    const viai_wn_layer* L = s->layers;
+    VIAI_LAUNCH(wn_first_kernel, dim3((s->B * C + 255) / 256), dim3(256), 0, st, s->w_first, s->b_first, s->test_inputs, s->n_test, s->out,
+                L[0].ring, L[0].ring_len, s->step, s->B, C, s->T);
+    for (int l = 0; l < s->n_layers; ++l) {
+        VIAI_LAUNCH(wn_gate_kernel<NB>, dim3((H + 3) / 4), dim3(256), 0, st, L[l].ring, L[l].ring_len, L[l].dilation, L[l].w_conv, L[l].b_conv,
+                    L[l].w_c, L[l].b_c, s->cond, s->z, s->step, C, H, s->cin, s->T);
+        const bool last = (l == s->n_layers - 1);
+        VIAI_LAUNCH(wn_out_kernel<NB>, dim3((C + S + 3) / 4), dim3(256), 0, st, s->z, L[l].w_out, L[l].b_out, L[l].w_skip, L[l].b_skip,
+                    L[l].ring, L[l].ring_len, last ? (float*)nullptr : L[l + 1].ring, last ? 1 : L[l + 1].ring_len, s->skips, l == 0 ? 1 : 0,
+                    s->step, C, H, S);
+    }
+    VIAI_LAUNCH(wn_head_kernel, dim3(s->B), dim3(256), (2 * S + s->out_ch) * sizeof(float), st, s->skips, s->w_l1, s->b_l1, s->w_l2, s->b_l2,
+                s->u1, s->u2, s->out, s->yhat_dbg, s->step, S, s->out_ch, s->T, s->log_scale_min);
+    VIAI_LAUNCH(wn_tick_kernel, dim3(1), dim3(1), 0, st, s->step);
+    return viai_launch_status();
+}
+
+}  // namespace
+
+extern "C" int viai_wavenet_synth_step(const viai_wn_synth* s, void* stream) {
+    if (!s || s->B < 1 || s->B > WN_MAXB || s->C % 4 || (s->G / 2) % 4 || s->cin % 4 || s->out_ch % 3 || s->n_layers < 1) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    switch (s->B) {
+    case 1: return wn_step_impl<1>(s, st);
+    case 2: return wn_step_impl<2>(s, st);
+    case 4: return wn_step_impl<4>(s, st);
+    case 8: return wn_step_impl<8>(s, st);
+    default: return (int)hipErrorInvalidValue;
+    }
+}

@@ -383,7 +383,103 @@ class WaveNet(nn.Module):
         return torch.softmax(y, dim=1) if softmax else y
 
     def clear_buffer(self):
-        pass                                                                          # incremental state lives in IncrementalState
+        pass                                      # incremental state (ring buffers) is local to incremental_forward
+
+    @torch.no_grad()
+    def incremental_forward(self, initial_input=None, c=None, g=None, T=100, test_inputs=None, tqdm=lambda x: x, softmax=True,
+                            quantize=True, log_scale_min=-7.0, uniforms=None, use_graph=True, return_logits=False):
+        """Sample-by-sample synthesis (wavenet.py:237-364) for the scalar-input / MoL configuration.
+
+        Each time step is ONE call of `viai_wavenet_synth_step` (first conv, 2 GEMV-batch kernels per layer, head +
+        MoL sample); the time index lives on the device, so the step is captured once into a HIP graph and replayed.
+        `uniforms=(u1 (B,T,10), u2 (B,T))` injects the sampler's two uniform draws (parity tests); default torch.rand."""
+        import ctypes as Ct
+        lib = _lib.load()
+        if not self.scalar_input:
+            raise NotImplementedError("incremental_forward: scalar-input (mixture of logistics) WaveNet only")
+        if g is not None:
+            raise NotImplementedError("incremental_forward: global conditioning is not built yet")
+        dev = self.first_conv.bias.device
+        if test_inputs is not None:
+            if test_inputs.size(1) == 1:
+                test_inputs = test_inputs.transpose(1, 2)                             # -> (B, n, 1)
+            B = test_inputs.size(0)
+            T = test_inputs.size(1) if T is None else max(int(T), test_inputs.size(1))
+            tin = test_inputs.reshape(B, -1).to(dev).float().contiguous()
+        else:
+            B = c.size(0) if c is not None else 1
+            tin = None
+        T = int(T)
+        if B not in (1, 2, 4, 8):
+            raise NotImplementedError("incremental_forward: batch must be 1, 2, 4 or 8 streams")
+        cond = None
+        if c is not None:
+            cu = self._upsample(c.to(dev).float())
+            assert cu.size(-1) == T
+            cond = cu.transpose(1, 2).contiguous()                                    # (B, T, cin)
+        if uniforms is None:
+            u1 = torch.empty(B, T, self.out_channels // 3, device=dev).uniform_(1e-5, 1.0 - 1e-5)
+            u2 = torch.empty(B, T, device=dev).uniform_(1e-5, 1.0 - 1e-5)
+        else:
+            u1, u2 = uniforms[0].to(dev).float().contiguous(), uniforms[1].to(dev).float().contiguous()
+        Cc = self.first_conv.bias.numel()
+        f0 = self.conv_layers[0]
+        G, S = f0.conv.bias.numel(), f0.conv1x1_skip.bias.numel()
+        keep = []                                                                     # keep tensors alive
+
+        def t(x):
+            x = x.detach().float().contiguous()
+            keep.append(x)
+            return x.data_ptr()
+        layers = (_lib.WnLayer * len(self.conv_layers))()
+        for i, f in enumerate(self.conv_layers):
+            d = f.conv.dilation[0]
+            ring = torch.zeros(B, 2 * d + 1, Cc, device=dev)
+            keep.append(ring)
+            L = layers[i]
+            L.w_conv = t(normed_weight(f.conv).permute(0, 2, 1).reshape(G, -1))       # linearised (conv.py:53-57)
+            L.b_conv = t(f.conv.bias)
+            L.w_c = t(normed_weight(f.conv1x1c).reshape(G, -1)) if (f.conv1x1c is not None and cond is not None) else None
+            L.b_c = t(f.conv1x1c.bias) if (f.conv1x1c is not None and cond is not None) else None
+            L.w_out, L.b_out = t(normed_weight(f.conv1x1_out).reshape(Cc, -1)), t(f.conv1x1_out.bias)
+            L.w_skip, L.b_skip = t(normed_weight(f.conv1x1_skip).reshape(S, -1)), t(f.conv1x1_skip.bias)
+            L.ring, L.dilation, L.ring_len = ring.data_ptr(), d, 2 * d + 1
+        out = torch.zeros(B, T, device=dev)
+        logits = torch.zeros(B, T, self.out_channels, device=dev) if return_logits else None
+        z = torch.zeros(B, G // 2, device=dev)
+        skips = torch.zeros(B, S, device=dev)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        st = _lib.WnSynth()
+        st.B, st.C, st.G, st.S, st.cin, st.n_layers, st.out_ch, st.T = B, Cc, G, S, (cond.size(2) if cond is not None else 4), len(self.conv_layers), self.out_channels, T
+        st.n_test = tin.size(1) if tin is not None else 0
+        st.log_scale_min = float(log_scale_min)
+        st.layers = layers
+        st.w_first, st.b_first = t(normed_weight(self.first_conv).reshape(-1)), t(self.first_conv.bias)
+        st.w_l1, st.b_l1 = t(normed_weight(self.last_conv_layers[1]).reshape(S, -1)), t(self.last_conv_layers[1].bias)
+        st.w_l2, st.b_l2 = t(normed_weight(self.last_conv_layers[3]).reshape(self.out_channels, -1)), t(self.last_conv_layers[3].bias)
+        st.cond = cond.data_ptr() if cond is not None else None
+        st.test_inputs = tin.data_ptr() if tin is not None else None
+        st.u1, st.u2, st.out, st.z, st.skips, st.step = u1.data_ptr(), u2.data_ptr(), out.data_ptr(), z.data_ptr(), skips.data_ptr(), step.data_ptr()
+        st.yhat_dbg = logits.data_ptr() if logits is not None else None
+        ref = Ct.byref(st)
+        if use_graph and T > 2:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _lib.check(lib.viai_wavenet_synth_step(ref, torch.cuda.current_stream().cuda_stream), "viai_wavenet_synth_step")   # step 0 (warm-up)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                _lib.check(lib.viai_wavenet_synth_step(ref, torch.cuda.current_stream().cuda_stream), "viai_wavenet_synth_step")   # captured: step 1
+            for _ in tqdm(range(T - 1)):
+                graph.replay()
+        else:
+            for _ in tqdm(range(T)):
+                _lib.check(lib.viai_wavenet_synth_step(ref, torch.cuda.current_stream().cuda_stream), "viai_wavenet_synth_step")
+        torch.cuda.current_stream().synchronize()
+        del keep
+        res = out.unsqueeze(1)                                                        # (B, 1, T) like the reference
+        return (res, logits) if return_logits else res
 
     def make_generation_fast_(self):
         def rm(m):
