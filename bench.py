@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-layer conv timing table to stderr")
+    ap.add_argument("--config", choices=["audio", "av", "av_msd"], default="audio",
+                    help="audio = BASELINE configs[1] (the metric); av = configs[2] (+ResNet-18 visual branch, N = T/4 frames); "
+                         "av_msd = configs[3] model (+3-scale D).  Non-default configs print the same JSON shape without roofline")
     ap.add_argument("--cpu-batch", type=int, default=2, help="clips per CPU-baseline step (bounded sample)")
     return ap.parse_args()
 
@@ -191,13 +194,23 @@ def main():
     hp = StepConfig()
     hp.cin_channels, hp.max_mel_lengths, hp.batch_size = args.bins, args.frames, args.batch
     torch.manual_seed(1234)                               # identical init on every rank (DDP semantics)
+    if args.config != "audio":
+        hp.use_video, hp.lambda_contrast = True, 0.1
+        hp.num_D = 3 if args.config == "av_msd" else 1
+        args.no_roofline = args.no_cpu_baseline = True
     model = AudioModel(hp, device=dev, use_graph=not args.no_graph)
     ddp.broadcast_arena(model.arena_G.flat)
     ddp.broadcast_arena(model.arena_D.flat)
 
     s = synth.mel_batch(args.batch, args.bins, args.frames, "bench.s", rank).to(dev)
     mask = synth.time_mask(args.batch, args.frames, "bench.mask", rank).to(dev)
-    model.set_inputs(s, mask)
+    if args.config != "audio":
+        nf = args.frames // 4
+        video = synth.uniform("bench.video.r%d" % rank, (args.batch, nf, 3, 224, 224), -1, 1).to(dev)
+        flow = synth.uniform("bench.flow.r%d" % rank, (args.batch, nf, 2, 224, 224), -1, 1).to(dev)
+        model.set_inputs(s, mask, video=video, flow=flow)
+    else:
+        model.set_inputs(s, mask)
 
     def barrier():
         if world > 1:
@@ -221,8 +234,12 @@ def main():
         "metric": METRIC, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: audio-only MelEncoder+MelDecoder G + MelDiscriminator (PatchGAN) D train step, "
-                               "%dx%d mel, batch %d per GPU, BCE-GAN + 100*L1, Adam(2e-4, 0.5, 0.999)" % (args.bins, args.frames, args.batch),
+        "config": {"workload": ("configs[1]: audio-only MelEncoder+MelDecoder G + MelDiscriminator (PatchGAN) D train step, "
+                                "%dx%d mel, batch %d per GPU, BCE-GAN + 100*L1, Adam(2e-4, 0.5, 0.999)" % (args.bins, args.frames, args.batch))
+                   if args.config == "audio" else
+                   ("configs[%d] (NOT the metric config): vision-infused G (2x ResNet-18 on %d frames/clip, tiled into the bottleneck) + %s, "
+                    "%dx%d mel, batch %d per GPU" % (2 if args.config == "av" else 3, args.frames // 4,
+                                                      "PatchGAN D" if args.config == "av" else "3-scale D", args.bins, args.frames, args.batch)),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                    "launch": "eager" if args.no_graph else "hipGraph replay (3 segments)",
                    "algorithmic_gflop_per_step": 1208.0, "step_tflops": round(1208.0 * 1e-3 / (ms_per_step * 1e-3), 2),

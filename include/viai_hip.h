@@ -131,6 +131,9 @@ int viai_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int N
 /* nn.AvgPool2d(7) on a 7x7 map: mean over the P = H*W positions */
 int viai_avgpool_hw_fwd(const float* x, float* y, int N, int P, int C, void* stream);
 int viai_avgpool_hw_bwd(const float* dy, float* dx, int N, int P, int C, void* stream);
+/* F.avg_pool2d(x, k, s, p, count_include_pad=False): input pyramid of the multi-scale discriminator (cfg 4) */
+int viai_avgpool2d_fwd(const float* x, float* y, int N, int IH, int IW, int C, int k, int s, int p, void* stream);
+int viai_avgpool2d_bwd(const float* dy, float* dx, int N, int IH, int IW, int C, int k, int s, int p, void* stream);
 /* BasicBlock join: out = relu(a + b); backward d = g * (out > 0) (same for both addends) */
 int viai_add_relu_fwd(const float* a, const float* b, float* out, long n, void* stream);
 int viai_relu_bwd(const float* g, const float* out, float* d, long n, void* stream);

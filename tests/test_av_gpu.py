@@ -92,3 +92,26 @@ def test_domain_dis(golden_dir):
     y.mean().backward()
     for k in ("conv1.weight", "fc1.weight", "fc1.bias", "fc2.weight"):
         assert relerr(O.digest(dict(D.named_parameters())[k].grad), gold["dom_dis.g.%s.dg" % k]) < 1e-4, k
+
+
+def test_multiscale_discriminator_is_a_composition_of_reference_discriminators():
+    """cfg 4: k MelDiscriminators on the avg_pool2d(3,2,1,count_include_pad=False) pyramid == oracle composition."""
+    from viai_amd import networks as N
+    x = O.cf_uniform("msd.x", (2, 1, 64, 96)).requires_grad_(True)
+    D = N.MultiScaleDiscriminator(num_D=3).cuda()
+    sds = [O.disc_state("D%d." % i) for i in range(3)]
+    for i in range(3):
+        D._modules["scale%d" % i].load_state_dict(sds[i])
+    xg = x.detach().cuda().requires_grad_(True)
+    outs = D(xg)
+    loss = sum(o.mean() for o in outs)
+    loss.backward()
+    cur, ref_loss = x, 0
+    for i in range(3):
+        ro = O.disc_forward(sds[i], cur)
+        assert tuple(outs[i].shape) == tuple(ro.shape)
+        assert relerr(outs[i], ro) < 1e-4, i
+        ref_loss = ref_loss + ro.mean()
+        cur = torch.nn.functional.avg_pool2d(cur, 3, 2, 1, count_include_pad=False)
+    ref_loss.backward()
+    assert relerr(xg.grad, x.grad) < 5e-3

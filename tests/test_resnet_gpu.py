@@ -139,3 +139,24 @@ def test_av_generator_step_end_to_end():
     assert torch.isfinite(loss).item()
     for p in (V.image_single_model.conv1.weight, V.flow_single_model.layer4[1].conv2.weight, G.deconv1_1_1.weight, E.conv5.weight):
         assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
+
+
+def test_audiomodel_av_multiscale_step_runs_and_trains():
+    """BASELINE configs[2]/[3] plumbing: AudioModel(use_video, num_D=3): one full step moves every trainable arena."""
+    from viai_amd.model import AudioModel, StepConfig
+    hp = StepConfig()
+    hp.cin_channels, hp.max_mel_lengths = 128, 32
+    hp.use_video, hp.num_D, hp.lambda_contrast = True, 2, 0.1
+    m = AudioModel(hp, device="cuda")
+    B, F_bins, T = 1, 128, 32                                     # N = T/4 = 8 frames, bottleneck 1 x 2
+    s = O.cf_uniform("avm.s", (B, 1, F_bins, T))
+    video = O.cf_uniform("avm.v", (B, 8, 3, 224, 224), -1, 1)
+    flow = O.cf_uniform("avm.f", (B, 8, 2, 224, 224), -1, 1)
+    g0, d0 = m.arena_G.flat.clone(), m.arena_D.flat.clone()
+    m.set_inputs(s, O.make_mask(B, T, "avm.m"), video=video, flow=flow)
+    m.optimize_parameters(0)
+    v = m.get_loss_items()
+    assert all(np.isfinite(v))
+    assert float((m.arena_G.flat - g0).abs().max()) > 0 and float((m.arena_D.flat - d0).abs().max()) > 0
+    vp = dict(m.VideoEncoder.named_parameters())["image_single_model.conv1.weight"]
+    assert float(vp.grad.abs().sum()) > 0                          # gradients reach the visual branch through the arena

@@ -76,6 +76,8 @@ SIGNATURES = {
     "viai_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "viai_avgpool_hw_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "viai_avgpool_hw_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "viai_avgpool2d_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "viai_avgpool2d_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "viai_add_relu_fwd": (_I, [_P, _P, _P, _L, _P]),
     "viai_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
     "viai_reduce_blocks": (_I, [_L]),

@@ -223,6 +223,46 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restr
     }
 }
 
+// F.avg_pool2d(x, k, s, p, count_include_pad=False) on NHWC: the pix2pixHD input pyramid of a multi-scale
+// discriminator (BASELINE cfg 4; composition of reference MelDiscriminators)
+__global__ __launch_bounds__(256) void avgpool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int N, int IH, int IW, int OH, int OW, int C, int k, int st, int pd) {
+    const long total = (long)N * OH * OW * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int c = (int)(i % C); long r = i / C;
+        int ox = (int)(r % OW); r /= OW;
+        int oy = (int)(r % OH); int n = (int)(r / OH);
+        float s = 0.f; int cnt = 0;
+        for (int a = 0; a < k; ++a) {
+            int iy = oy * st - pd + a;
+            if ((unsigned)iy >= (unsigned)IH) continue;
+            for (int b = 0; b < k; ++b) {
+                int ix = ox * st - pd + b;
+                if ((unsigned)ix >= (unsigned)IW) continue;
+                s += x[(((size_t)n * IH + iy) * IW + ix) * C + c]; ++cnt;
+            }
+        }
+        y[i] = s / (float)cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                            int N, int IH, int IW, int OH, int OW, int C, int k, int st, int pd) {
+    const long total = (long)N * IH * IW * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int c = (int)(i % C); long r = i / C;
+        int ix = (int)(r % IW); r /= IW;
+        int iy = (int)(r % IH); int n = (int)(r / IH);
+        float acc = 0.f;
+        for (int oy = max(0, (iy + pd - k + st) / st); oy <= min(OH - 1, (iy + pd) / st); ++oy)
+            for (int ox = max(0, (ix + pd - k + st) / st); ox <= min(OW - 1, (ix + pd) / st); ++ox) {
+                int y0 = max(oy * st - pd, 0), y1 = min(oy * st - pd + k, IH), x0 = max(ox * st - pd, 0), x1 = min(ox * st - pd + k, IW);
+                acc += dy[(((size_t)n * OH + oy) * OW + ox) * C + c] / (float)((y1 - y0) * (x1 - x0));
+            }
+        dx[i] = acc;
+    }
+}
+
 inline int ew_blocks(long n) {
     long b = (n + 255) / 256;
     if (b > 8192) b = 8192;
@@ -303,5 +343,17 @@ extern "C" int viai_relu_bwd(const float* g, const float* out, float* d, long n,
 extern "C" int viai_nchw_to_nhwc4(const float* x, float* y, long N, int C, long HW, void* stream) {
     if (C < 1 || C > 4) return (int)hipErrorInvalidValue;
     VIAI_LAUNCH(nchw_to_nhwc4_kernel, dim3(ew_blocks(N * HW)), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<f32x4*>(y), N, C, HW);
+    return viai_launch_status();
+}
+
+extern "C" int viai_avgpool2d_fwd(const float* x, float* y, int N, int IH, int IW, int C, int k, int s, int p, void* stream) {
+    int OH = (IH + 2 * p - k) / s + 1, OW = (IW + 2 * p - k) / s + 1;
+    VIAI_LAUNCH(avgpool2d_fwd_kernel, dim3(ew_blocks((long)N * OH * OW * C)), dim3(256), 0, (hipStream_t)stream, x, y, N, IH, IW, OH, OW, C, k, s, p);
+    return viai_launch_status();
+}
+
+extern "C" int viai_avgpool2d_bwd(const float* dy, float* dx, int N, int IH, int IW, int C, int k, int s, int p, void* stream) {
+    int OH = (IH + 2 * p - k) / s + 1, OW = (IW + 2 * p - k) / s + 1;
+    VIAI_LAUNCH(avgpool2d_bwd_kernel, dim3(ew_blocks((long)N * IH * IW * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, IH, IW, OH, OW, C, k, s, p);
     return viai_launch_status();
 }

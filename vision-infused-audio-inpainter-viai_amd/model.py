@@ -27,7 +27,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .networks import MelDecoder, MelDiscriminator, MelEncoder, to_nchw_view
+from .networks import (ImageEmbedding2, MelDecoder, MelDecoderImage, MelDiscriminator, MelEncoder, MultiScaleDiscriminator,
+                       to_nchw_view)
 
 
 class StepConfig:
@@ -42,6 +43,12 @@ class StepConfig:
     max_mel_lengths = 256       # frames T
     name = "viai"
     save_optimizer_state = True
+    # BASELINE configs[2] / configs[3] (declared adaptations):
+    use_video = False           # ResNet-18 ImageEmbedding2 fused into the G bottleneck through MelDecoderImage; when the
+                                # bottleneck height h > 1 (F = 256) the video feature is TILED over h
+    num_D = 1                   # > 1: multi-scale D = num_D MelDiscriminators on an avg-pool pyramid
+    lambda_contrast = 0.0       # weight of L2ContrastiveLoss(audio bottleneck, video feature)  (`EmbeddingL2_item`)
+    contrast_margin = 1.0
 
 
 class FlatArena:
@@ -144,12 +151,15 @@ class AudioModel:
         self.device = torch.device(device) if device is not None else torch.device("cuda")
         if self.device.type != "cuda":
             raise RuntimeError("AudioModel runs on an MI355X (HIP kernels); there is no CPU path")
+        self.use_video = bool(getattr(hp, "use_video", False))
+        self.num_D = int(getattr(hp, "num_D", 1))
         self.Mel_Encoder = MelEncoder(hp).to(self.device)
-        self.Mel_Decoder = MelDecoder(hp).to(self.device)
-        self.netD = MelDiscriminator().to(self.device)
-        self.VideoEncoder = None
+        self.Mel_Decoder = (MelDecoderImage(hp) if self.use_video else MelDecoder(hp)).to(self.device)
+        self.netD = (MultiScaleDiscriminator(self.num_D) if self.num_D > 1 else MelDiscriminator()).to(self.device)
+        self.VideoEncoder = ImageEmbedding2(hp).to(self.device) if self.use_video else None
+        self.video = self.flow = None
         self.cfg = StepConfig()
-        for k in ("lr", "beta1", "beta2", "eps", "lambda_l1", "use_lsgan"):
+        for k in ("lr", "beta1", "beta2", "eps", "lambda_l1", "use_lsgan", "lambda_contrast", "contrast_margin"):
             if hasattr(hp, k):
                 setattr(self.cfg, k, getattr(hp, k))
         self._build_optimizers()
@@ -176,6 +186,8 @@ class AudioModel:
         c = self.cfg
         g_named = [("E." + n, p) for n, p in self.Mel_Encoder.named_parameters()] + \
                   [("G." + n, p) for n, p in self.Mel_Decoder.named_parameters()]
+        if self.VideoEncoder is not None:
+            g_named += [("V." + n, p) for n, p in self.VideoEncoder.named_parameters()]
         d_named = [("D." + n, p) for n, p in self.netD.named_parameters()]
         self.arena_G = FlatArena(g_named)
         self.arena_D = FlatArena(d_named)
@@ -198,9 +210,22 @@ class AudioModel:
         self.blank_length = max(T // 4, 1)
         return self.blank_length
 
-    def set_inputs(self, data, mask=None):
-        """data: the loader's 8-tuple (audio_loader.py:532; mel `c` is element 2, (B,C,T)) or a mel tensor
-        (B,F,T)/(B,1,F,T) in [0,1].  Copies into static device buffers (graph-replay safe)."""
+    def set_inputs(self, data, mask=None, video=None, flow=None):
+        """data: the loader's 8-tuple (audio_loader.py:532: video, flow, c (B,C,T), x, y, g, lengths, paths) or a mel
+        tensor (B,F,T)/(B,1,F,T) in [0,1].  Copies into static device buffers (graph-replay safe)."""
+        if isinstance(data, (tuple, list)):
+            video = data[0] if video is None else video
+            flow = data[1] if flow is None else flow
+        if self.use_video:
+            if video is None or flow is None:
+                raise ValueError("use_video: set_inputs needs the video (B,N,3,224,224) and flow (B,N,2,224,224) blocks")
+            video = video.to(self.device, dtype=torch.float32)
+            flow = flow.to(self.device, dtype=torch.float32)
+            if self.video is None or self.video.shape != video.shape:
+                self.video, self.flow = torch.empty_like(video), torch.empty_like(flow)
+                self._graphs = None
+            self.video.copy_(video)
+            self.flow.copy_(flow)
         mel = data[2] if isinstance(data, (tuple, list)) else data
         if mel.dim() == 3:
             mel = mel.unsqueeze(1)
@@ -218,7 +243,33 @@ class AudioModel:
 
     def _gan(self, pred, real):
         t = 1.0 if real else 0.0
+        if isinstance(pred, (list, tuple)):                  # multi-scale D: mean of the per-scale losses
+            tot = None
+            for p in pred:
+                l = ops.mse_mean(p, t) if self.cfg.use_lsgan else ops.bce_mean(p, t)
+                tot = l if tot is None else tot + l
+            return tot / float(len(pred))
         return ops.mse_mean(pred, t) if self.cfg.use_lsgan else ops.bce_mean(pred, t)
+
+    def _generate(self, s_nhwc):
+        """E (+ E_v) + G forward on NHWC; returns fake (B,F,T,1) and the contrastive term (or None)."""
+        B, F, T, _ = s_nhwc.shape
+        s_in = ops.mask_mul(s_nhwc, self.mask)
+        feats = self.Mel_Encoder.forward_nhwc(s_in.view(B, F, T))
+        if not self.use_video:
+            return self.Mel_Decoder.forward_nhwc(feats, (F, T)), None
+        f_v, _fea = self.VideoEncoder(self.video, self.flow)                 # (B,256,1,N/4), (B,512,N)
+        h, w = feats[-1].shape[1], feats[-1].shape[2]
+        if f_v.shape[3] != w:
+            raise ValueError("use_video: need N = T/4 frames per clip (video steps %d != bottleneck steps %d)" % (f_v.shape[3], w))
+        fv_nhwc = f_v.permute(0, 2, 3, 1)                                     # (B,1,w,256)
+        head = self.Mel_Decoder._head_av(feats, fv_nhwc.expand(B, h, w, 256).permute(0, 3, 1, 2))   # tiled over h (declared adaptation)
+        fake = self.Mel_Decoder.forward_nhwc(feats, (F, T), head=head)
+        lc = None
+        if self.cfg.lambda_contrast > 0:
+            f_a = feats[-1].mean(dim=1).reshape(B * w, 256)
+            lc = ops.l2_contrastive(f_a.contiguous(), fv_nhwc.reshape(B * w, 256).contiguous(), self.cfg.contrast_margin, False)
+        return fake, lc
 
     def _seg_forward_dstep(self):
         s = self.mel
@@ -226,9 +277,7 @@ class AudioModel:
         s_nhwc = s.view(B, F, T, 1)
         self.optimizer_D.zero_grad()
         self.optimizer_G.zero_grad()
-        s_in = ops.mask_mul(s_nhwc, self.mask)
-        feats = self.Mel_Encoder.forward_nhwc(s_in.view(B, F, T))
-        fake = self.Mel_Decoder.forward_nhwc(feats, (F, T))            # (B,F,T,1)
+        fake, self._lc = self._generate(s_nhwc)                        # (B,F,T,1)
         self._fake = fake
         self.fake = to_nchw_view(fake)
         self.netD.requires_grad_(True)
@@ -250,6 +299,9 @@ class AudioModel:
         loss_gan = self._gan(pred, True)
         loss_l1 = ops.l1_mean(self._fake, s.view(B, F, T, 1))
         loss_g = loss_gan + self.cfg.lambda_l1 * loss_l1
+        if self._lc is not None:
+            loss_g = loss_g + self.cfg.lambda_contrast * self._lc
+            self.EmbeddingL2 = self._lc.detach()
         loss_g.backward()
         self.netD.requires_grad_(True)
         self.losses[1].copy_(loss_g.detach())

@@ -288,6 +288,30 @@ class MelDiscriminator(nn.Module):
         return to_nchw_view(self.forward_nhwc(to_nhwc(input)))
 
 
+class MultiScaleDiscriminator(nn.Module):
+    """BASELINE cfg 4 "multi-scale D".  The reference has NO such class; following SURVEY.md §8d it is defined as
+    k reference `MelDiscriminator`s applied to the 1x, 1/2x, 1/4x ... inputs obtained with
+    avg_pool2d(3, stride 2, padding 1, count_include_pad=False) (pix2pixHD convention).  forward returns the list
+    of the k PatchGAN maps; state_dict keys are `scale{i}.<MelDiscriminator keys>`."""
+
+    def __init__(self, num_D=3, input_nc=1, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.num_D = num_D
+        for i in range(num_D):
+            self.add_module("scale%d" % i, MelDiscriminator(input_nc, ndf, n_layers, norm_layer))
+
+    def forward_nhwc(self, x):
+        outs = []
+        for i in range(self.num_D):
+            outs.append(self._modules["scale%d" % i].forward_nhwc(x))
+            if i + 1 < self.num_D:
+                x = ops.avgpool2d(x, 3, 2, 1)
+        return outs
+
+    def forward(self, input):
+        return [to_nchw_view(o) for o in self.forward_nhwc(to_nhwc(input))]
+
+
 class Inpainting_Dis(nn.Module):
     """joint mel x video sync discriminator (Discriminator_Networks.py:53-87): mel path 3x[Conv3x3 s2 BN LReLU]
     -> Conv(256,256,(10,1)); video path Conv1d(512,256,3,s2,p1) BN1d LReLU on fea_cat; cat on C ->

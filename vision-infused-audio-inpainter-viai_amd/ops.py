@@ -228,13 +228,13 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
         if not training and not track:
             cfg["training"] = True
         if DIRECT_GRAD:
-            cfg["gt"] = tuple(p.grad if (p is not None and p.requires_grad and p.grad is not None) else None
+            cfg["gt"] = tuple(p.grad if (p is not None and p.is_leaf and p.requires_grad and p.grad is not None) else None
                               for p in (weight, bias, bn.weight, bn.bias))
         return _ConvBnAct.apply(x, x2, weight, bias, bn.weight, bn.bias,
                                 bn.running_mean if track else None, bn.running_var if track else None,
                                 bn.num_batches_tracked if (track and cfg["training"]) else None, cfg)
     if DIRECT_GRAD:
-        cfg["gt"] = tuple(p.grad if (p is not None and p.requires_grad and p.grad is not None) else None
+        cfg["gt"] = tuple(p.grad if (p is not None and p.is_leaf and p.requires_grad and p.grad is not None) else None
                           for p in (weight, bias, None, None))
     return _ConvBnAct.apply(x, x2, weight, bias, None, None, None, None, None, cfg)
 
@@ -382,6 +382,35 @@ class _MaxPool(torch.autograd.Function):
 
 def maxpool(x, k=3, s=2, p=1):
     return _MaxPool.apply(x, int(k), int(s), int(p))
+
+
+class _AvgPool2d(torch.autograd.Function):
+    """F.avg_pool2d(x, k, s, p, count_include_pad=False) on NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        lib = _lib.load()
+        _require(x)
+        x = _c(x)
+        N, IH, IW, Cc = x.shape
+        OH, OW = (IH + 2 * p - k) // s + 1, (IW + 2 * p - k) // s + 1
+        y = torch.empty((N, OH, OW, Cc), device=x.device, dtype=torch.float32)
+        _lib.check(lib.viai_avgpool2d_fwd(x.data_ptr(), y.data_ptr(), N, IH, IW, Cc, k, s, p, _stream()), "viai_avgpool2d_fwd")
+        ctx.dims = (N, IH, IW, Cc, k, s, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        N, IH, IW, Cc, k, s, p = ctx.dims
+        dy = _c(dy)
+        dx = torch.empty((N, IH, IW, Cc), device=dy.device, dtype=torch.float32)
+        _lib.check(lib.viai_avgpool2d_bwd(dy.data_ptr(), dx.data_ptr(), N, IH, IW, Cc, k, s, p, _stream()), "viai_avgpool2d_bwd")
+        return dx, None, None, None
+
+
+def avgpool2d(x, k=3, s=2, p=1):
+    return _AvgPool2d.apply(x, int(k), int(s), int(p))
 
 
 class _AvgPoolHW(torch.autograd.Function):
