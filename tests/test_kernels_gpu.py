@@ -303,3 +303,29 @@ def test_ganloss_module_matches_reference_semantics():
         for real in (False, True):
             out = crit(p.cuda(), real)
             assert abs(out.item() - O.gan_loss(p, real, lsgan).item()) < 1e-5
+
+
+def test_bf16x3_path_is_fp32_grade():
+    """Large layers run on the split-bf16 ("bf16x3") MFMA kernel (csrc/conv_igemm_bf3.hip).  Its error against an
+    fp64 evaluation must stay at the fp32 level: within 4x of the CPU fp32 convolution's own rounding error
+    (the exact-fp32 MFMA kernel, a strictly sequential fmaf chain over K, sits at ~2-4x itself)."""
+    from viai_amd import ops
+    N, C, H, W, Co = 2, 128, 256, 256, 128           # 1024 tiles of 128x128, forward AND data gradient -> bf16x3 path
+    x = O.cf_uniform("b3.x", (N, C, H, W), -1, 1)
+    w = O.cf_std("b3.w", (Co, C, 1, 3), 0.05)
+    gy = O.cf_uniform("b3.gy", (N, Co, H, W), -1, 1)
+
+    def run(dt):
+        xs, ws = x.clone().to(dt).requires_grad_(True), w.clone().to(dt).requires_grad_(True)
+        y = F.conv2d(xs, ws, None, stride=1, padding=(0, 1))
+        gx, gw = torch.autograd.grad(y, [xs, ws], grad_outputs=gy.to(dt))
+        return y.detach(), gx, gw
+    truth, cpu32 = run(torch.float64), run(torch.float32)
+    xg = nhwc(x).requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    yg = ops.conv_bn_act(xg, wg, None, None, kernel=(1, 3), stride=(1, 1), padding=(0, 1))
+    yg.backward(nhwc(gy))
+    for nm, h, c32, t in zip(("fwd", "dgrad", "wgrad"), (nchw(yg), nchw(xg.grad), wg.grad), cpu32, truth):
+        e, c = relerr(h, t), relerr(c32, t)
+        print("%s: hip err %.2e, cpu fp32 err %.2e" % (nm, e, c))
+        assert e < 4 * c + 1e-7, (nm, e, c)

@@ -3,6 +3,8 @@
 // streaming kernels for the Cin == 1 / Cout == 1 layers.
 #include "viai_common.h"
 #include "viai_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 // direct kernels (conv_direct.hip)
 int viai_cin1_fwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, float* y, float* stat, int act, hipStream_t st);
@@ -44,6 +46,33 @@ static inline bool valid(const viai_conv2d* c) {
     viai_conv2d_out_hw(c, &oh, &ow);
     return oh > 0 && ow > 0;
 }
+// ---- math mode of the contraction-shaped layers ------------------------------------------------------
+// default: "bf16x3" split-bf16 MFMA (fp32-grade accuracy, 2.67x the fp32-MFMA ceiling) wherever the
+// 128x128 tile applies; VIAI_MATH=fp32 forces the exact-fp32 MFMA kernels everywhere.
+static bool bf3_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VIAI_MATH"); v = (e && (!strcmp(e, "fp32") || !strcmp(e, "f32"))) ? 0 : 1; }
+    return v == 1;
+}
+static bool use_bf3_shape(long M, int n_out, int k_in) {
+    return bf3_enabled() && n_out > 64 && (k_in % 8) == 0 && viai_igemm_tile_m(M, n_out) == 128;
+}
+static bool use_bf3_fwd(const viai_conv2d* c) {
+    if (kind_of(c) != K_IGEMM) return false;
+    int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
+    return use_bf3_shape((long)c->N * oh * ow, c->Cout, cin_of(c));
+}
+static bool use_bf3_dgrad(const viai_conv2d* c) {
+    if (kind_of(c) != K_IGEMM) return false;
+    for (int a_ = 0; a_ < c->sh; ++a_)
+        for (int b_ = 0; b_ < c->sw; ++b_) {
+            ConvGeom g; int nt = viai_geom_dgrad_class(c, a_, b_, &g);
+            if (g.SH <= 0 || g.SW <= 0 || nt == 0) continue;
+            if (!use_bf3_shape((long)g.N * g.SH * g.SW, cin_of(c), c->Cout)) return false;
+        }
+    return true;
+}
+
 extern "C" int viai_abi_version(void) { return VIAI_ABI_VERSION; }
 
 extern "C" int viai_conv2d_out_hw(const viai_conv2d* c, int* OH, int* OW) {
@@ -59,7 +88,8 @@ extern "C" int viai_conv2d_out_hw(const viai_conv2d* c, int* OH, int* OW) {
 
 extern "C" size_t viai_conv2d_packed_floats(const viai_conv2d* c) {
     if (kind_of(c) == K_RUN) return (size_t)c->Cout * c->kh * 32;
-    return (size_t)c->Cout * cin_of(c) * c->kh * c->kw;
+    size_t n = (size_t)c->Cout * cin_of(c) * c->kh * c->kw;
+    return (kind_of(c) == K_IGEMM && bf3_enabled()) ? n + (n + 1) / 2 : n;      // room for three bf16 planes
 }
 
 static void geom_base(const viai_conv2d* c, ConvGeom* g) {
@@ -159,6 +189,10 @@ extern "C" int viai_conv2d_pack_fwd(const viai_conv2d* c, const float* w, float*
         return viai_launch_status();
     }
     default:
+        if (use_bf3_fwd(c)) {
+            if (c->transposed) return viai_pack_weight_bf3(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, (hipStream_t)stream);
+            return viai_pack_weight_bf3(w, wp, c->Cout, Cin, T, (long)Cin * T, T, (hipStream_t)stream);
+        }
         if (c->transposed) return viai_pack_weight(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, stream);
         return viai_pack_weight(w, wp, c->Cout, Cin, T, (long)Cin * T, T, stream);
     }
@@ -173,6 +207,10 @@ extern "C" int viai_conv2d_pack_dgrad(const viai_conv2d* c, const float* w, floa
     case K_COUT1:
         return viai_conv2d_pack_fwd(c, w, wp, stream);     // the streaming kernels share one image
     default:            // wp[ci][t][co]
+        if (use_bf3_dgrad(c)) {
+            if (c->transposed) return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, (hipStream_t)stream);
+            return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, (hipStream_t)stream);
+        }
         if (c->transposed) return viai_pack_weight(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, stream);
         return viai_pack_weight(w, wp, Cin, c->Cout, T, T, (long)Cin * T, stream);
     }
@@ -209,6 +247,7 @@ extern "C" int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float
     if (kind_of(c) == K_RUN) { geom_run(c, &a.g); a.C1 = 32; a.C2 = 0; }
     else viai_geom_fwd(c, &a.g);
     a.M = a.g.N * a.g.OH * a.g.OW;
+    if (use_bf3_fwd(c)) return viai_conv_igemm_bf3_launch(a, st);
     return viai_conv_igemm_launch(a, st);
 }
 
@@ -231,6 +270,7 @@ extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const fl
             if (dx2 && hipMemsetAsync(dx2, 0, px * c->C2 * sizeof(float), st) != hipSuccess) return (int)hipErrorInvalidValue;
         }
     }
+    const bool bf3 = use_bf3_dgrad(c);
     for (int a_ = 0; a_ < c->sh; ++a_)
         for (int b_ = 0; b_ < c->sw; ++b_) {
             ConvArgs a{};
@@ -241,7 +281,7 @@ extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const fl
             if (a.g.SH <= 0 || a.g.SW <= 0) continue;
             if (nt == 0) continue;                            // zero-filled above
             a.M = a.g.N * a.g.SH * a.g.SW;
-            int e = viai_conv_igemm_launch(a, st);
+            int e = bf3 ? viai_conv_igemm_bf3_launch(a, st) : viai_conv_igemm_launch(a, st);
             if (e) return e;
         }
     return 0;

@@ -1,0 +1,343 @@
+// Implicit-GEMM convolution on the bf16 matrix cores with fp32-grade accuracy ("bf16x3" split), gfx950.
+//
+// Every fp32 operand is split into three bf16 terms  a = a1 + a2 + a3  (a1 = bf16(a), a2 = bf16(a - a1),
+// a3 = bf16(a - a1 - a2); 3 x 8 = 24 significand bits, i.e. the whole fp32 value) and the product a*b is
+// accumulated in fp32 from the six partial products whose weight is >= 2^-16 relative:
+//     a1b1 + a1b2 + a2b1 + a1b3 + a3b1 + a2b2          (dropped: a2b3, a3b2, a3b3 <= 2^-23 |ab|)
+// on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense): 6 bf16 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64
+// cycles per 32x32x16 block, a 2.67x higher MFMA ceiling (416 TFLOP/s fp32-equivalent) at the rounding-error
+// level of the exact-fp32 kernel (tests/test_kernels_gpu.py measures both against fp64).
+//
+// Same gather-GEMM structure as conv_igemm.hip (tap tables, buffer loads with hardware zero fill, XCD remap,
+// BN partial statistics in the epilogue).  Differences: weights arrive pre-split as three bf16 planes
+// (viai_conv2d_pack_* does it once per use), activations are split while being staged into LDS, LDS holds bf16
+// planes [plane][row][32 + 8 pad] (80-byte rows: conflict-free ds_read_b128 operand fetches).
+#include "viai_common.h"
+#include "viai_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// split two floats into three packed bf16 pairs (round-to-nearest at every level)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16(r0, r1);
+    float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xffff0000u);
+    p3 = cvt_pk_bf16(s0, s1);
+}
+
+constexpr int BF3_BK = 32;
+constexpr int BF3_PITCH = 80;          // bytes per LDS row: 32 bf16 + 8 pad
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_bf3_kernel(const ConvArgs a) {
+    constexpr int BK = BF3_BK;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int BN = 32 * TN * WN;
+    constexpr int NA = BM / 32;                         // A float4 per thread per chunk (8 quads per row)
+    constexpr int NBQ = (3 * BN * 4) / 256;             // B 16-byte pieces per thread per chunk
+    constexpr int APLANE = BM * BF3_PITCH, BPLANE = BN * BF3_PITCH;
+    static_assert(WM * WN == 4 && (3 * BN * 4) % 256 == 0, "config");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* As = smem_b;                         // [3][BM][80]
+    unsigned char* Bs = smem_b + 3 * APLANE;            // [3][BN][80]
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bn = bid % a.nblk_n, bm = bid / a.nblk_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int Cin = a.C1 + a.C2;
+
+    const int q = tid & 7, r0 = tid >> 3;
+    int pixbase[NA], iy0[NA], ix0[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int m = m0 + r0 + 32 * j;
+        if (m < a.M) {
+            int ox = m % g.SW; int t = m / g.SW; int oy = t % g.SH; int n = t / g.SH;
+            iy0[j] = oy * g.my; ix0[j] = ox * g.mx;
+            pixbase[j] = (n * g.IH + iy0[j]) * g.IW + ix0[j];
+        } else { iy0[j] = -100000; ix0[j] = -100000; pixbase[j] = 0; }
+    }
+    constexpr int OOB = 0x7fffffff;
+    // B pieces: idx = tid + 256*j -> (plane, row, 16-byte quad)
+    const long wplane = (long)a.Cout * g.wtaps * Cin * 2;            // bytes per bf16 plane
+    int bsrc[NBQ], bdst[NBQ];
+#pragma unroll
+    for (int j = 0; j < NBQ; ++j) {
+        int idx = tid + 256 * j;
+        int plane = idx / (BN * 4), rem = idx % (BN * 4), row = rem >> 2, q16 = rem & 3;
+        int co = n0 + row;
+        bsrc[j] = (co < a.Cout) ? (int)(plane * wplane + ((long)co * g.wtaps * Cin) * 2 + q16 * 16) : OOB;
+        bdst[j] = plane * BPLANE + row * BF3_PITCH + q16 * 16;
+    }
+    const long in_pixels = (long)g.N * g.IH * g.IW;
+    const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * a.C1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in), 0,
+                                                                             (int)(in_pixels * (a.in2 ? a.C2 : a.C1) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(3 * wplane), 0x00020000);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int cchunks = (Cin + BK - 1) / BK;
+    const int nchunks = g.ntaps * cchunks;
+
+    u32x4 areg[NA], breg[NBQ];
+    auto gload = [&](int t_, int c0_) {
+        const int t = __builtin_amdgcn_readfirstlane(t_);
+        const int c0 = __builtin_amdgcn_readfirstlane(c0_);
+        const int dyt = g.dy[t], dxt = g.dx[t];
+        const int toff = dyt * g.IW + dxt;
+        const bool first = c0 < a.C1;
+        const int cs = first ? a.C1 : a.C2;
+        const int coff = (first ? c0 : c0 - a.C1) + q * 4;
+        const bool kin = (c0 + q * 4 < Cin);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            int iy = iy0[j] + dyt, ix = ix0[j] + dxt;
+            bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW && kin;
+            int off = ok ? ((pixbase[j] + toff) * cs + coff) * 4 : OOB;
+            areg[j] = first ? __builtin_amdgcn_raw_buffer_load_b128(rs_in1, off, 0, 0)
+                            : __builtin_amdgcn_raw_buffer_load_b128(rs_in2, off, 0, 0);
+        }
+        const int woff = (g.ws[t] * Cin + c0) * 2;
+#pragma unroll
+        for (int j = 0; j < NBQ; ++j) {
+            int idx = tid + 256 * j;
+            int q16 = idx & 3;
+            bool kb = (c0 + q16 * 8 < Cin);
+            breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (bsrc[j] == OOB || !kb) ? OOB : bsrc[j] + woff, 0, 0);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const f32x4 v = __builtin_bit_cast(f32x4, areg[j]);
+            unsigned a1, a2, a3, b1, b2, b3;
+            split3_pair(v[0], v[1], a1, a2, a3);
+            split3_pair(v[2], v[3], b1, b2, b3);
+            const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
+            unsigned char* d = As + (r0 + 32 * j) * BF3_PITCH + q * 8;
+            *reinterpret_cast<u32x2*>(d) = p1;
+            *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+            *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+        }
+#pragma unroll
+        for (int j = 0; j < NBQ; ++j) *reinterpret_cast<u32x4*>(Bs + bdst[j]) = breg[j];
+    };
+
+    int t_next = 0, c_next = 0;
+    gload(0, 0);
+    lstore();
+    c_next = BK;
+    if (c_next >= Cin) { c_next = 0; t_next = 1; }
+    __syncthreads();
+
+    const int aoff = (wm * TM * 32 + (lane & 31)) * BF3_PITCH + 16 * (lane >> 5);
+    const int boff = (wn * TN * 32 + (lane & 31)) * BF3_PITCH + 16 * (lane >> 5);
+
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const bool more = (kc + 1 < nchunks);
+        if (more) {
+            gload(t_next, c_next);
+            c_next += BK;
+            if (c_next >= Cin) { c_next = 0; ++t_next; }
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + aoff + i * 32 * BF3_PITCH + ks * 32));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bf[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * BPLANE + boff + j * 32 * BF3_PITCH + ks * 32));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();                 // every wave is done reading this chunk
+        if (more) lstore();
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue (same as conv_igemm.hip)
+    const int half = lane >> 5, col = lane & 31;
+    float bv[TN];
+    int co[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        co[j] = n0 + (wn * TN + j) * 32 + col;
+        bv[j] = (a.bias != nullptr && co[j] < a.Cout) ? a.bias[co[j]] : 0.f;
+    }
+    const bool ident = (g.ly == 1 && g.lx == 1 && g.SH == g.OH && g.SW == g.OW);
+    const int oc2 = a.Cout - a.OC1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int m = m0 + (wm * TM + i) * 32 + row;
+            if (m < a.M) {
+                size_t opix;
+                if (ident) opix = (size_t)m;
+                else {
+                    int ox = m % g.SW; int t = m / g.SW; int oy = t % g.SH; int n = t / g.SH;
+                    opix = ((size_t)n * g.OH + (oy * g.ly + g.ay)) * g.OW + (ox * g.lx + g.ax);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v = acc[i][j][e] + bv[j];
+                    if (a.stat == nullptr) v = viai_act(v, a.act, a.slope);
+                    acc[i][j][e] = v;
+                    if (co[j] < a.Cout) {
+                        if (co[j] < a.OC1) a.out[opix * a.OC1 + co[j]] = v;
+                        else a.out2[opix * oc2 + (co[j] - a.OC1)] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (a.stat != nullptr) {
+        float* red = reinterpret_cast<float*>(smem_b);
+        const int cnt = min(BM, a.M - m0);
+        float s[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    int m = m0 + (wm * TM + i) * 32 + row;
+                    t += (m < a.M) ? acc[i][j][e] : 0.f;
+                }
+            t += __shfl_xor(t, 32, 64);
+            s[j] = t;
+        }
+        if (half == 0)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) red[wm * BN + (wn * TN + j) * 32 + col] = s[j];
+        __syncthreads();
+        float mean[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[w * BN + (wn * TN + j) * 32 + col];
+            mean[j] = t / (float)cnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    int m = m0 + (wm * TM + i) * 32 + row;
+                    float d = acc[i][j][e] - mean[j];
+                    t += (m < a.M) ? d * d : 0.f;
+                }
+            t += __shfl_xor(t, 32, 64);
+            s[j] = t;
+        }
+        if (half == 0)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) red[wm * BN + (wn * TN + j) * 32 + col] = s[j];
+        __syncthreads();
+        if (wm == 0 && half == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (co[j] < a.Cout) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) t += red[w * BN + (wn * TN + j) * 32 + col];
+                    a.stat[(size_t)co[j] * a.nblk_m + bm] = mean[j];
+                    a.stat[(size_t)(a.Cout + co[j]) * a.nblk_m + bm] = t;
+                }
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// planes[p][no][t][ki] (bf16) from w[no*s_no + ki*s_ki + t]; same RNE split as the kernel's activations
+__global__ void pack_weight_bf3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+                                       long s_no, long s_ki) {
+    const long total = (long)n_out * taps * k_in;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int ki = (int)(i % k_in); long r = i / k_in; int t = (int)(r % taps); int no = (int)(r / taps);
+        float x = w[no * s_no + ki * s_ki + t];
+        unsigned short h1 = bf16_rne(x);
+        float r1 = x - __uint_as_float((unsigned)h1 << 16);
+        unsigned short h2 = bf16_rne(r1);
+        float r2 = r1 - __uint_as_float((unsigned)h2 << 16);
+        wp[i] = h1; wp[total + i] = h2; wp[2 * total + i] = bf16_rne(r2);
+    }
+}
+
+}  // namespace
+
+int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
+    const int Cin = a.C1 + a.C2;
+    if (Cin % 8 != 0 || (a.C2 > 0 && a.C1 % 32 != 0)) return (int)hipErrorInvalidValue;
+    if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
+    constexpr int BM = 128, BN = 128;
+    a.nblk_m = (a.M + BM - 1) / BM;
+    a.nblk_n = (a.Cout + BN - 1) / BN;
+    size_t lds = (size_t)3 * (BM + BN) * BF3_PITCH;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf3_kernel<2, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    VIAI_LAUNCH((conv_igemm_bf3_kernel<2, 2, 2, 2>), dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
+    return viai_launch_status();
+}
+
+int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, hipStream_t st) {
+    long total = (long)n_out * taps * k_in;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    VIAI_LAUNCH(pack_weight_bf3_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
+    return viai_launch_status();
+}

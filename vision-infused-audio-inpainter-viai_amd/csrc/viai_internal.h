@@ -30,6 +30,8 @@ struct WgradArgs {
 
 int viai_conv_igemm_launch(ConvArgs& a, hipStream_t st);
 int viai_igemm_tile_m(long M, int n_out);
+int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st);
+int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, hipStream_t st);
 int viai_wgrad_mfma_launch(WgradArgs& a, int ksplit, hipStream_t st);
 int viai_wgrad_pick_ksplit(int Cout, int Cin, int ntaps, long M);
 
