@@ -55,7 +55,8 @@ static bool bf3_enabled() {
     return v == 1;
 }
 static bool use_bf3_shape(long M, int n_out, int k_in) {
-    return bf3_enabled() && n_out > 64 && (k_in % 8) == 0 && viai_igemm_tile_m(M, n_out) == 128;
+    (void)M; (void)n_out;
+    return bf3_enabled() && (k_in % 8) == 0;
 }
 static bool use_bf3_fwd(const viai_conv2d* c) {
     if (kind_of(c) != K_IGEMM) return false;

@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_kernel(const ConvArgs a) {
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int NA = BM / 32;                         // A float4 per thread per chunk (8 quads per row)
-    constexpr int NBQ = (3 * BN * 4) / 256;             // B 16-byte pieces per thread per chunk
+    constexpr int NBQ = (3 * BN * 4 + 255) / 256;       // B 16-byte pieces per thread per chunk
     constexpr int APLANE = BM * BF3_PITCH, BPLANE = BN * BF3_PITCH;
-    static_assert(WM * WN == 4 && (3 * BN * 4) % 256 == 0, "config");
+    static_assert(WM * WN == 4, "config");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* As = smem_b;                         // [3][BM][80]
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_kernel(const ConvArgs a) {
         int idx = tid + 256 * j;
         int plane = idx / (BN * 4), rem = idx % (BN * 4), row = rem >> 2, q16 = rem & 3;
         int co = n0 + row;
-        bsrc[j] = (co < a.Cout) ? (int)(plane * wplane + ((long)co * g.wtaps * Cin) * 2 + q16 * 16) : OOB;
-        bdst[j] = plane * BPLANE + row * BF3_PITCH + q16 * 16;
+        bsrc[j] = (idx < 3 * BN * 4 && co < a.Cout) ? (int)(plane * wplane + ((long)co * g.wtaps * Cin) * 2 + q16 * 16) : OOB;
+        bdst[j] = (idx < 3 * BN * 4) ? plane * BPLANE + row * BF3_PITCH + q16 * 16 : -1;
     }
     const long in_pixels = (long)g.N * g.IH * g.IW;
     const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * a.C1 * 4), 0x00020000);
@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_kernel(const ConvArgs a) {
             *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
         }
 #pragma unroll
-        for (int j = 0; j < NBQ; ++j) *reinterpret_cast<u32x4*>(Bs + bdst[j]) = breg[j];
+        for (int j = 0; j < NBQ; ++j)
+            if ((3 * BN * 4) % 256 == 0 || bdst[j] >= 0) *reinterpret_cast<u32x4*>(Bs + bdst[j]) = breg[j];
     };
 
     int t_next = 0, c_next = 0;
@@ -317,21 +318,31 @@ __global__ void pack_weight_bf3_kernel(const float* __restrict__ w, unsigned sho
 
 }  // namespace
 
+template <int TM, int TN, int WM, int WN>
+static int launch_bf3(ConvArgs& a, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    a.nblk_m = (a.M + BM - 1) / BM;
+    a.nblk_n = (a.Cout + BN - 1) / BN;
+    size_t lds = (size_t)3 * (BM + BN) * BF3_PITCH;
+    if (lds < (size_t)WM * BN * sizeof(float)) lds = (size_t)WM * BN * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf3_kernel<TM, TN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    VIAI_LAUNCH((conv_igemm_bf3_kernel<TM, TN, WM, WN>), dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
+    return viai_launch_status();
+}
+
 int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
     const int Cin = a.C1 + a.C2;
     if (Cin % 8 != 0 || (a.C2 > 0 && a.C1 % 32 != 0)) return (int)hipErrorInvalidValue;
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
-    constexpr int BM = 128, BN = 128;
-    a.nblk_m = (a.M + BM - 1) / BM;
-    a.nblk_n = (a.Cout + BN - 1) / BN;
-    size_t lds = (size_t)3 * (BM + BN) * BF3_PITCH;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf3_kernel<2, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    VIAI_LAUNCH((conv_igemm_bf3_kernel<2, 2, 2, 2>), dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
-    return viai_launch_status();
+    const int bm = viai_igemm_tile_m(a.M, a.Cout);           // same tile rule as the fp32 kernels (BN partial geometry)
+    if (bm == 64) return launch_bf3<1, 1, 2, 2>(a, st);
+    if (a.Cout > 64) return launch_bf3<2, 2, 2, 2>(a, st);
+    if (a.Cout > 32) return launch_bf3<2, 1, 2, 2>(a, st);
+    return launch_bf3<1, 1, 4, 1>(a, st);
 }
 
 int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, hipStream_t st) {
