@@ -56,8 +56,12 @@ static bool bf3_enabled() {
 }
 static bool use_bf3_shape(long M, int n_out, int k_in) {
     (void)M; (void)n_out;
-    return bf3_enabled() && (k_in % 8) == 0;
+    return bf3_enabled() && (k_in % 16) == 0;
 }
+// GEMM rows that decide the bf16x3 weight layout (pack and launch must agree; dgrad uses its largest parity class)
+static long bf3_rows_fwd(const viai_conv2d* c) { int oh, ow; viai_conv2d_out_hw(c, &oh, &ow); return (long)c->N * oh * ow; }
+static long bf3_rows_dgrad(const viai_conv2d* c) { return (long)c->N * ((c->IH + c->sh - 1) / c->sh) * ((c->IW + c->sw - 1) / c->sw); }
+
 static bool use_bf3_fwd(const viai_conv2d* c) {
     if (kind_of(c) != K_IGEMM) return false;
     int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
@@ -90,7 +94,12 @@ extern "C" int viai_conv2d_out_hw(const viai_conv2d* c, int* OH, int* OW) {
 extern "C" size_t viai_conv2d_packed_floats(const viai_conv2d* c) {
     if (kind_of(c) == K_RUN) return (size_t)c->Cout * c->kh * 32;
     size_t n = (size_t)c->Cout * cin_of(c) * c->kh * c->kw;
-    return (kind_of(c) == K_IGEMM && bf3_enabled()) ? n + (n + 1) / 2 : n;      // room for three bf16 planes
+    if (kind_of(c) == K_IGEMM && bf3_enabled()) {                                  // room for fragment-major bf16 planes (fwd or dgrad form)
+        size_t f = viai_bf3_packed_floats(c->Cout, cin_of(c), c->kh * c->kw), d = viai_bf3_packed_floats(cin_of(c), c->Cout, c->kh * c->kw);
+        size_t m = f > d ? f : d;
+        return m > n ? m : n;
+    }
+    return n;
 }
 
 static void geom_base(const viai_conv2d* c, ConvGeom* g) {
@@ -191,8 +200,9 @@ extern "C" int viai_conv2d_pack_fwd(const viai_conv2d* c, const float* w, float*
     }
     default:
         if (use_bf3_fwd(c)) {
-            if (c->transposed) return viai_pack_weight_bf3(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, (hipStream_t)stream);
-            return viai_pack_weight_bf3(w, wp, c->Cout, Cin, T, (long)Cin * T, T, (hipStream_t)stream);
+            const long M = bf3_rows_fwd(c);
+            if (c->transposed) return viai_pack_weight_bf3(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, M, (hipStream_t)stream);
+            return viai_pack_weight_bf3(w, wp, c->Cout, Cin, T, (long)Cin * T, T, M, (hipStream_t)stream);
         }
         if (c->transposed) return viai_pack_weight(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, stream);
         return viai_pack_weight(w, wp, c->Cout, Cin, T, (long)Cin * T, T, stream);
@@ -209,8 +219,9 @@ extern "C" int viai_conv2d_pack_dgrad(const viai_conv2d* c, const float* w, floa
         return viai_conv2d_pack_fwd(c, w, wp, stream);     // the streaming kernels share one image
     default:            // wp[ci][t][co]
         if (use_bf3_dgrad(c)) {
-            if (c->transposed) return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, (hipStream_t)stream);
-            return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, (hipStream_t)stream);
+            const long M = bf3_rows_dgrad(c);
+            if (c->transposed) return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, M, (hipStream_t)stream);
+            return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, M, (hipStream_t)stream);
         }
         if (c->transposed) return viai_pack_weight(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, stream);
         return viai_pack_weight(w, wp, Cin, c->Cout, T, T, (long)Cin * T, stream);
@@ -248,7 +259,7 @@ extern "C" int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float
     if (kind_of(c) == K_RUN) { geom_run(c, &a.g); a.C1 = 32; a.C2 = 0; }
     else viai_geom_fwd(c, &a.g);
     a.M = a.g.N * a.g.OH * a.g.OW;
-    if (use_bf3_fwd(c)) return viai_conv_igemm_bf3_launch(a, st);
+    if (use_bf3_fwd(c)) { a.wfrag = viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout); return viai_conv_igemm_bf3_launch(a, st); }
     return viai_conv_igemm_launch(a, st);
 }
 
@@ -282,6 +293,7 @@ extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const fl
             if (a.g.SH <= 0 || a.g.SW <= 0) continue;
             if (nt == 0) continue;                            // zero-filled above
             a.M = a.g.N * a.g.SH * a.g.SW;
+            a.wfrag = bf3 && viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c));
             int e = bf3 ? viai_conv_igemm_bf3_launch(a, st) : viai_conv_igemm_launch(a, st);
             if (e) return e;
         }
@@ -342,7 +354,7 @@ extern "C" int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const flo
         viai_geom_fwd(c, &a.g);
         int ks = viai_wgrad_pick_ksplit(c->Cout, Cin, T, M);
         used = (size_t)ks * viai_conv2d_packed_floats(c);
-        e = viai_wgrad_mfma_launch(a, ks, st);
+        e = (bf3_enabled() && viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2)) ? viai_wgrad_bf3_launch(a, ks, st) : viai_wgrad_mfma_launch(a, ks, st);
         if (e) return e;
         if (c->transposed) e = viai_wgrad_reduce(ws, dw, ks, T, c->Cout, Cin, T, (long)c->Cout * T, accumulate, st);
         else e = viai_wgrad_reduce(ws, dw, ks, T, c->Cout, Cin, (long)Cin * T, T, accumulate, st);

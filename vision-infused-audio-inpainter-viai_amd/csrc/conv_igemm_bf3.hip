@@ -14,32 +14,298 @@
 // planes [plane][row][32 + 8 pad] (80-byte rows: conflict-free ds_read_b128 operand fetches).
 #include "viai_common.h"
 #include "viai_internal.h"
+#include "viai_bf3.h"
+#include <cstdlib>
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+// Shared epilogue: bias + activation (or raw output + per-block BatchNorm partial statistics), NHWC stores with the
+// dgrad parity-class scatter and the two-destination (virtual concat) split.  Same contract as conv_igemm.hip.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void bf3_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem_b, int lane, int wm, int wn,
+                                             int m0, int n0, int bm) {
+    constexpr int BM = 32 * TM * WM;
+    constexpr int BN = 32 * TN * WN;
+    const ConvGeom& g = a.g;
+
+    const int half = lane >> 5, col = lane & 31;
+    float bv[TN];
+    int co[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        co[j] = n0 + (wn * TN + j) * 32 + col;
+        bv[j] = (a.bias != nullptr && co[j] < a.Cout) ? a.bias[co[j]] : 0.f;
+    }
+    const bool ident = (g.ly == 1 && g.lx == 1 && g.SH == g.OH && g.SW == g.OW);
+    const int oc2 = a.Cout - a.OC1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int m = m0 + (wm * TM + i) * 32 + row;
+            if (m < a.M) {
+                size_t opix;
+                if (ident) opix = (size_t)m;
+                else {
+                    int ox = m % g.SW; int t = m / g.SW; int oy = t % g.SH; int n = t / g.SH;
+                    opix = ((size_t)n * g.OH + (oy * g.ly + g.ay)) * g.OW + (ox * g.lx + g.ax);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v = acc[i][j][e] + bv[j];
+                    if (a.stat == nullptr) v = viai_act(v, a.act, a.slope);
+                    acc[i][j][e] = v;
+                    if (co[j] < a.Cout) {
+                        if (co[j] < a.OC1) a.out[opix * a.OC1 + co[j]] = v;
+                        else a.out2[opix * oc2 + (co[j] - a.OC1)] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (a.stat != nullptr) {
+        float* red = reinterpret_cast<float*>(smem_b);
+        const int cnt = min(BM, a.M - m0);
+        float s[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    int m = m0 + (wm * TM + i) * 32 + row;
+                    t += (m < a.M) ? acc[i][j][e] : 0.f;
+                }
+            t += __shfl_xor(t, 32, 64);
+            s[j] = t;
+        }
+        if (half == 0)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) red[wm * BN + (wn * TN + j) * 32 + col] = s[j];
+        __syncthreads();
+        float mean[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[w * BN + (wn * TN + j) * 32 + col];
+            mean[j] = t / (float)cnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    int m = m0 + (wm * TM + i) * 32 + row;
+                    float d = acc[i][j][e] - mean[j];
+                    t += (m < a.M) ? d * d : 0.f;
+                }
+            t += __shfl_xor(t, 32, 64);
+            s[j] = t;
+        }
+        if (half == 0)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) red[wm * BN + (wn * TN + j) * 32 + col] = s[j];
+        __syncthreads();
+        if (wm == 0 && half == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (co[j] < a.Cout) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) t += red[w * BN + (wn * TN + j) * 32 + col];
+                    a.stat[(size_t)co[j] * a.nblk_m + bm] = mean[j];
+                    a.stat[(size_t)(a.Cout + co[j]) * a.nblk_m + bm] = t;
+                }
+        }
+    }
 }
 
-// split two floats into three packed bf16 pairs (round-to-nearest at every level)
-__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = cvt_pk_bf16(x0, x1);
-    float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
-    p2 = cvt_pk_bf16(r0, r1);
-    float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xffff0000u);
-    p3 = cvt_pk_bf16(s0, s1);
-}
-
-constexpr int BF3_BK = 32;
-constexpr int BF3_PITCH = 80;          // bytes per LDS row: 32 bf16 + 8 pad
+// Weights never touch LDS: viai_conv2d_pack_* stores them "fragment-major" -- for every (plane, 32-channel output
+// tile, tap, 16-deep k-step) the 64 lanes' 16-byte MFMA B fragments are contiguous (1 KiB), so a wave fetches a
+// B operand with ONE fully coalesced buffer_load_dwordx4 (L1/L2-resident, shared by every block) one k-step
+// ahead of its use.  LDS holds only the activation planes, double-buffered: one barrier per 32-deep chunk and
+// the split + LDS stores of chunk k+1 overlap the MFMAs of chunk k.
 
 template <int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_bf3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs a) {
+    constexpr int BK = BF3_BK;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int BN = 32 * TN * WN;
+    constexpr int APLANE = BM * BF3_PITCH;
+    constexpr int STAGE = 3 * APLANE;
+    constexpr int NA = BM / 32;                         // A float4 per thread per chunk (8 quads per row)
+    static_assert(WM * WN == 4, "config");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][3][BM][80]
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bn = bid % a.nblk_n, bm = bid / a.nblk_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int Cin = a.C1 + a.C2;
+
+    const int q = tid & 7, r0 = tid >> 3;
+    int pixbase[NA], iy0[NA], ix0[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int m = m0 + r0 + 32 * j;
+        if (m < a.M) {
+            int ox = m % g.SW; int t = m / g.SW; int oy = t % g.SH; int n = t / g.SH;
+            iy0[j] = oy * g.my; ix0[j] = ox * g.mx;
+            pixbase[j] = (n * g.IH + iy0[j]) * g.IW + ix0[j];
+        } else { iy0[j] = -100000; ix0[j] = -100000; pixbase[j] = 0; }
+    }
+    constexpr int OOB = 0x7fffffff;
+    const int k16 = Cin / 16;                                        // 16-deep k-steps per tap
+    const int NT = (a.Cout + 31) / 32;                               // 32-channel output tiles in the packed weights
+    const int frag_plane = NT * g.wtaps * k16 * 1024;                // bytes per bf16 plane (fragment-major)
+    int bbase[TN];                                                   // byte offset of this wave's n-tiles (+ lane)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int nt = (n0 >> 5) + wn * TN + j;
+        bbase[j] = (nt < NT) ? nt * g.wtaps * k16 * 1024 + lane * 16 : OOB;
+    }
+    const long in_pixels = (long)g.N * g.IH * g.IW;
+    const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * a.C1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in), 0,
+                                                                             (int)(in_pixels * (a.in2 ? a.C2 : a.C1) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 3 * frag_plane, 0x00020000);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int cchunks = (Cin + BK - 1) / BK;
+    const int nchunks = g.ntaps * cchunks;
+
+    u32x4 areg[NA];
+    auto gloadA = [&](int t_, int c0_) {
+        const int t = __builtin_amdgcn_readfirstlane(t_);
+        const int c0 = __builtin_amdgcn_readfirstlane(c0_);
+        const int dyt = g.dy[t], dxt = g.dx[t];
+        const int toff = dyt * g.IW + dxt;
+        const bool first = c0 < a.C1;
+        const int cs = first ? a.C1 : a.C2;
+        const int coff = (first ? c0 : c0 - a.C1) + q * 4;
+        const bool kin = (c0 + q * 4 < Cin);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            int iy = iy0[j] + dyt, ix = ix0[j] + dxt;
+            bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW && kin;
+            int off = ok ? ((pixbase[j] + toff) * cs + coff) * 4 : OOB;
+            areg[j] = first ? __builtin_amdgcn_raw_buffer_load_b128(rs_in1, off, 0, 0)
+                            : __builtin_amdgcn_raw_buffer_load_b128(rs_in2, off, 0, 0);
+        }
+    };
+    // B fragments of one 16-deep k-step: (tap t, channel offset c) -> 3 planes x TN tiles
+    auto gloadB = [&](u32x4 (&bf)[TN][3], int t_, int c_) {
+        const int t = __builtin_amdgcn_readfirstlane(t_);
+        const int c = __builtin_amdgcn_readfirstlane(c_);
+        const bool okk = (t < g.ntaps) && (c < Cin);
+        const int koff = okk ? (g.ws[t] * k16 + (c >> 4)) * 1024 : 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bf[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (bbase[j] == OOB || !okk) ? OOB : p * frag_plane + bbase[j] + koff, 0, 0);
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* As = smem_b + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const f32x4 v = __builtin_bit_cast(f32x4, areg[j]);
+            unsigned a1, a2, a3, b1, b2, b3;
+            split3_pair(v[0], v[1], a1, a2, a3);
+            split3_pair(v[2], v[3], b1, b2, b3);
+            const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
+            unsigned char* d = As + (r0 + 32 * j) * BF3_PITCH + q * 8;
+            *reinterpret_cast<u32x2*>(d) = p1;
+            *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+            *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+        }
+    };
+
+    int t_cur = 0, c_cur = 0;                 // chunk being computed
+    int t_next = 0, c_next = BK;              // next chunk
+    if (c_next >= Cin) { c_next = 0; t_next = 1; }
+    gloadA(0, 0);
+    u32x4 bf0[TN][3], bf1[TN][3];
+    gloadB(bf0, 0, 0);
+    lstore(0);
+    __syncthreads();
+
+    const int aoff = (wm * TM * 32 + (lane & 31)) * BF3_PITCH + 16 * (lane >> 5);
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};     // six partial products, smallest first
+
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const bool more = (kc + 1 < nchunks);
+        const int cur = kc & 1;
+        if (more) gloadA(t_next, c_next);
+        const unsigned char* As = smem_b + cur * STAGE + aoff;
+        // ---- k-step 0 of this chunk (B fragments in bf0); fetch k-step 1's B fragments meanwhile
+        gloadB(bf1, t_cur, c_cur + 16);
+        {
+            bf16x8 af[TM][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + i * 32 * BF3_PITCH));
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]], __builtin_bit_cast(bf16x8, bf0[j][PB[pr]]), acc[i][j], 0, 0, 0);
+        }
+        // ---- k-step 1 (bf1); fetch the next chunk's k-step 0 fragments meanwhile
+        gloadB(bf0, more ? t_next : g.ntaps, c_next);
+        {
+            bf16x8 af[TM][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + i * 32 * BF3_PITCH + 32));
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]], __builtin_bit_cast(bf16x8, bf1[j][PB[pr]]), acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        t_cur = t_next; c_cur = c_next;
+        c_next += BK;
+        if (c_next >= Cin) { c_next = 0; ++t_next; }
+    }
+
+    bf3_epilogue<TM, TN, WM, WN>(a, acc, smem_b, lane, wm, wn, m0, n0, bm);
+}
+
+// Variant for narrow / small tiles: weights as three row-major bf16 planes [plane][co][tap][ci], staged through LDS
+// next to the activation planes (one LDS stage, two barriers per chunk).
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_bf3_lds_kernel(const ConvArgs a) {
     constexpr int BK = BF3_BK;
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
@@ -194,105 +460,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---------------------------------------------------------------- epilogue (same as conv_igemm.hip)
-    const int half = lane >> 5, col = lane & 31;
-    float bv[TN];
-    int co[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        co[j] = n0 + (wn * TN + j) * 32 + col;
-        bv[j] = (a.bias != nullptr && co[j] < a.Cout) ? a.bias[co[j]] : 0.f;
-    }
-    const bool ident = (g.ly == 1 && g.lx == 1 && g.SH == g.OH && g.SW == g.OW);
-    const int oc2 = a.Cout - a.OC1;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-            const int m = m0 + (wm * TM + i) * 32 + row;
-            if (m < a.M) {
-                size_t opix;
-                if (ident) opix = (size_t)m;
-                else {
-                    int ox = m % g.SW; int t = m / g.SW; int oy = t % g.SH; int n = t / g.SH;
-                    opix = ((size_t)n * g.OH + (oy * g.ly + g.ay)) * g.OW + (ox * g.lx + g.ax);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float v = acc[i][j][e] + bv[j];
-                    if (a.stat == nullptr) v = viai_act(v, a.act, a.slope);
-                    acc[i][j][e] = v;
-                    if (co[j] < a.Cout) {
-                        if (co[j] < a.OC1) a.out[opix * a.OC1 + co[j]] = v;
-                        else a.out2[opix * oc2 + (co[j] - a.OC1)] = v;
-                    }
-                }
-            }
-        }
-    }
-    if (a.stat != nullptr) {
-        float* red = reinterpret_cast<float*>(smem_b);
-        const int cnt = min(BM, a.M - m0);
-        float s[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-                    int m = m0 + (wm * TM + i) * 32 + row;
-                    t += (m < a.M) ? acc[i][j][e] : 0.f;
-                }
-            t += __shfl_xor(t, 32, 64);
-            s[j] = t;
-        }
-        if (half == 0)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) red[wm * BN + (wn * TN + j) * 32 + col] = s[j];
-        __syncthreads();
-        float mean[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) t += red[w * BN + (wn * TN + j) * 32 + col];
-            mean[j] = t / (float)cnt;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-                    int m = m0 + (wm * TM + i) * 32 + row;
-                    float d = acc[i][j][e] - mean[j];
-                    t += (m < a.M) ? d * d : 0.f;
-                }
-            t += __shfl_xor(t, 32, 64);
-            s[j] = t;
-        }
-        if (half == 0)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) red[wm * BN + (wn * TN + j) * 32 + col] = s[j];
-        __syncthreads();
-        if (wm == 0 && half == 0) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (co[j] < a.Cout) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int w = 0; w < WM; ++w) t += red[w * BN + (wn * TN + j) * 32 + col];
-                    a.stat[(size_t)co[j] * a.nblk_m + bm] = mean[j];
-                    a.stat[(size_t)(a.Cout + co[j]) * a.nblk_m + bm] = t;
-                }
-        }
-    }
+    bf3_epilogue<TM, TN, WM, WN>(a, acc, smem_b, lane, wm, wn, m0, n0, bm);
 }
 
 __device__ __forceinline__ unsigned short bf16_rne(float x) {
@@ -301,8 +469,27 @@ __device__ __forceinline__ unsigned short bf16_rne(float x) {
     return (unsigned short)(u >> 16);
 }
 
+// fragment-major bf16 planes from w[no*s_no + ki*s_ki + t]:
+//   dst[p][nt][t][kq][lane][e],  lane = kg*32 + j, e < 8:  value(no = nt*32 + j, k = kq*16 + kg*8 + e), zero for no >= n_out
+__global__ void pack_weight_bf3_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+                                       long s_no, long s_ki) {
+    const int NT = (n_out + 31) / 32, k16 = k_in / 16;
+    const long plane = (long)NT * taps * k16 * 512;                  // bf16 elements per plane
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        int e = (int)(i & 7); int lane = (int)((i >> 3) & 63); long r = i >> 9;
+        int kq = (int)(r % k16); r /= k16; int t = (int)(r % taps); int nt = (int)(r / taps);
+        int no = nt * 32 + (lane & 31), ki = kq * 16 + (lane >> 5) * 8 + e;
+        float x = (no < n_out) ? w[no * s_no + ki * s_ki + t] : 0.f;
+        unsigned short h1 = bf16_rne(x);
+        float r1 = x - __uint_as_float((unsigned)h1 << 16);
+        unsigned short h2 = bf16_rne(r1);
+        float r2 = r1 - __uint_as_float((unsigned)h2 << 16);
+        wp[i] = h1; wp[plane + i] = h2; wp[2 * plane + i] = bf16_rne(r2);
+    }
+}
+
 // planes[p][no][t][ki] (bf16) from w[no*s_no + ki*s_ki + t]; same RNE split as the kernel's activations
-__global__ void pack_weight_bf3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+__global__ void pack_weight_bf3_planar_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
                                        long s_no, long s_ki) {
     const long total = (long)n_out * taps * k_in;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -318,37 +505,51 @@ __global__ void pack_weight_bf3_kernel(const float* __restrict__ w, unsigned sho
 
 }  // namespace
 
-template <int TM, int TN, int WM, int WN>
+template <bool FRAG, int TM, int TN, int WM, int WN>
 static int launch_bf3(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     a.nblk_m = (a.M + BM - 1) / BM;
     a.nblk_n = (a.Cout + BN - 1) / BN;
-    size_t lds = (size_t)3 * (BM + BN) * BF3_PITCH;
+    size_t lds = FRAG ? (size_t)2 * 3 * BM * BF3_PITCH : (size_t)3 * (BM + BN) * BF3_PITCH;
     if (lds < (size_t)WM * BN * sizeof(float)) lds = (size_t)WM * BN * sizeof(float);
+    auto kern = FRAG ? conv_igemm_bf3_frag_kernel<TM, TN, WM, WN> : conv_igemm_bf3_lds_kernel<TM, TN, WM, WN>;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf3_kernel<TM, TN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    VIAI_LAUNCH((conv_igemm_bf3_kernel<TM, TN, WM, WN>), dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
+    VIAI_LAUNCH(kern, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
     return viai_launch_status();
 }
 
+// Weight layout rule (must agree between pack and launch): wide tiles read fragment-major weights straight from
+// global memory, narrow / small tiles (where all four waves would fetch the same fragments) stage planar weights in LDS.
+bool viai_bf3_frag_layout(long M, int n_out) { return viai_igemm_tile_m(M, n_out) == 128 && n_out > 64; }
+
 int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
     const int Cin = a.C1 + a.C2;
-    if (Cin % 8 != 0 || (a.C2 > 0 && a.C1 % 32 != 0)) return (int)hipErrorInvalidValue;
+    if (Cin % 16 != 0 || (a.C2 > 0 && a.C1 % 32 != 0)) return (int)hipErrorInvalidValue;
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
     const int bm = viai_igemm_tile_m(a.M, a.Cout);           // same tile rule as the fp32 kernels (BN partial geometry)
-    if (bm == 64) return launch_bf3<1, 1, 2, 2>(a, st);
-    if (a.Cout > 64) return launch_bf3<2, 2, 2, 2>(a, st);
-    if (a.Cout > 32) return launch_bf3<2, 1, 2, 2>(a, st);
-    return launch_bf3<1, 1, 4, 1>(a, st);
+    if (a.wfrag) return launch_bf3<true, 2, 2, 2, 2>(a, st);
+    if (bm == 64) return launch_bf3<false, 1, 1, 2, 2>(a, st);
+    if (a.Cout > 64) return launch_bf3<false, 2, 2, 2, 2>(a, st);
+    if (a.Cout > 32) return launch_bf3<false, 2, 1, 2, 2>(a, st);
+    return launch_bf3<false, 1, 1, 4, 1>(a, st);
 }
 
-int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, hipStream_t st) {
-    long total = (long)n_out * taps * k_in;
+size_t viai_bf3_packed_floats(int n_out, int k_in, int taps) {
+    size_t elems = (size_t)((n_out + 31) / 32) * 32 * taps * k_in;       // bf16 elements per plane (either layout fits)
+    return (3 * elems + 1) / 2;
+}
+
+int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, long M, hipStream_t st) {
+    if (k_in % 16 != 0) return (int)hipErrorInvalidValue;
+    const bool frag = viai_bf3_frag_layout(M, n_out);
+    long total = (long)(frag ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    VIAI_LAUNCH(pack_weight_bf3_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
+    if (frag) VIAI_LAUNCH(pack_weight_bf3_frag_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
+    else VIAI_LAUNCH(pack_weight_bf3_planar_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
     return viai_launch_status();
 }
