@@ -25,7 +25,13 @@ import torch  # noqa: E402
 
 METRIC = "masked mel-spectrogram clips/sec (G+D train step, 256x256 b16) at 1/2/4/8 GPUs"
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-DOMINANT = "conv_igemm_kernel<32,2,2,2,2> (128x128x32 fp32-MFMA implicit-GEMM conv, fwd + dgrad)"
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
+# The default conv math is the bf16x3 split (csrc/conv_igemm_bf3.hip): every fp32 MAC costs six bf16 MFMA MACs, so the
+# ceiling for ALGORITHMIC fp32 flops on that kernel is the bf16 peak / 6.  VIAI_MATH=fp32 selects the exact-fp32 MFMA kernel.
+BF3 = os.environ.get("VIAI_MATH", "") != "fp32"
+PEAK = MFMA_BF16_PEAK_TFLOPS / 6.0 if BF3 else MFMA_F32_PEAK_TFLOPS
+DOMINANT = ("conv_igemm_bf3_frag_kernel<2,2,2,2> (128x128x32 bf16x3 split-MFMA implicit-GEMM conv, fp32-grade accuracy, fwd + dgrad)"
+            if BF3 else "conv_igemm_kernel<32,2,2,2,2> (128x128x32 fp32-MFMA implicit-GEMM conv, fwd + dgrad)")
 
 
 def parse():
@@ -116,6 +122,8 @@ class KernelTimer:
             cin = d.C1 + d.C2
             if cin == 1 or d.Cout == 1:
                 return "direct", 1
+            if BF3 and cin > 32 and d.Cout > 32 and not (d.C2 > 0 and d.C1 % 64):
+                return "wgrad_bf3", 1                # mirror of viai_wgrad_bf3_ok (csrc/conv_wgrad_bf3.hip)
             return "wgrad_mfma", 1
 
         wrap("viai_conv2d_fwd", fam_fwd)
@@ -242,6 +250,8 @@ def main():
                                                       "PatchGAN D" if args.config == "av" else "3-scale D", args.bins, args.frames, args.batch)),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                    "launch": "eager" if args.no_graph else "hipGraph replay (3 segments)",
+                   "math": "fp32 tensors; conv GEMMs on bf16 MFMA with the 3-term split (six partial products, fp32 accumulate, error vs fp64 <= exact-fp32 kernel)"
+                           if BF3 else "exact fp32 MFMA",
                    "algorithmic_gflop_per_step": 1208.0, "step_tflops": round(1208.0 * 1e-3 / (ms_per_step * 1e-3), 2),
                    "loss_d": round(losses[0], 5), "loss_g": round(losses[1], 5)},
     }
@@ -266,12 +276,18 @@ def main():
         f, t, n = fam["igemm128x128"]
         ach = f / t * 1e-12
         out["roofline"] = {
-            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+            "bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAK, 1), "unit": "TFLOP/s",
+            "frac": round(ach / PEAK, 4), "traffic": None,
+            "peak_note": ("algorithmic fp32 flops against the dense bf16 MFMA peak (2500) / 6 partial products per MAC; "
+                          "the same flops are %.2fx the fp32-MFMA peak (157.3)" % (ach / MFMA_F32_PEAK_TFLOPS)) if BF3
+                         else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
             "kernel": DOMINANT, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream around each call, %d instrumented eager steps after the timed region" % nprof,
-            "launch_family_rule": "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
+            "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<2,2,2,2>; igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2> (small-M layers); "
+                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; wgrad_bf3 = wgrad_bf3_kernel<*>; "
+                                   "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers)") if BF3 else
+                                  "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},
             "conv_tflops_by_kernel": {k: round(v[0] / v[1] * 1e-12, 2) for k, v in sorted(fam.items()) if v[1] > 0},
             "conv_ms_per_step": round(tot_t / nprof * 1e3, 3),

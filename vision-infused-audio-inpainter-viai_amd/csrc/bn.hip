@@ -146,26 +146,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 }
 
-// sums over the row-block partials (fp64), 32 channels x 8 partial lanes per block.  Emits
+// sums over the row-block partials (fp64, fixed order), 4 channels x 64 partial lanes per block.  Emits
 //   sums[0][c] = k0, sums[1][c] = k1  with  dy = scale*dpre + k1*(y-mean) + k0   (training-mode BN backward:
 //   dy = scale*(dpre - s1/M - xhat*s2/M), xhat = (y-mean)*invstd), plus dgamma = s2, dbeta = s1.
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, long M,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ scale, int training,
                                                            float* sums, float* dgamma, float* dbeta, int accumulate) {
-    __shared__ double r1[8][32], r2[8][32];
-    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double r1[64][4], r2[64][4];
+    const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int b = pl; b < nblk; b += 8) {
+    if (c < C) {
+        int b = pl;
+        for (; b + 192 < nblk; b += 256) {               // 8 independent loads in flight per lane
+            float a0 = part[((size_t)b * 2 + 0) * C + c], b0 = part[((size_t)b * 2 + 1) * C + c];
+            float a1 = part[((size_t)(b + 64) * 2 + 0) * C + c], b1 = part[((size_t)(b + 64) * 2 + 1) * C + c];
+            float a2 = part[((size_t)(b + 128) * 2 + 0) * C + c], b2 = part[((size_t)(b + 128) * 2 + 1) * C + c];
+            float a3 = part[((size_t)(b + 192) * 2 + 0) * C + c], b3 = part[((size_t)(b + 192) * 2 + 1) * C + c];
+            s1 += (double)a0; s1 += (double)a1; s1 += (double)a2; s1 += (double)a3;
+            s2 += (double)b0; s2 += (double)b1; s2 += (double)b2; s2 += (double)b3;
+        }
+        for (; b < nblk; b += 64) {
             s1 += (double)part[((size_t)b * 2 + 0) * C + c];
             s2 += (double)part[((size_t)b * 2 + 1) * C + c];
         }
+    }
     r1[pl][cl] = s1; r2[pl][cl] = s2;
     __syncthreads();
     if (pl == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { s1 += r1[k][cl]; s2 += r2[k][cl]; }
+        for (int k = 1; k < 64; ++k) { s1 += r1[k][cl]; s2 += r2[k][cl]; }
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
         if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
         if (training) {
@@ -246,9 +256,13 @@ extern "C" int viai_bn_act_fwd(const float* y, const float* scale, const float* 
 }
 
 extern "C" int viai_bn_bwd_blocks(long M, int C) {
-    (void)C;
-    long b = (M + 511) / 512;
-    if (b > 1024) b = 1024;
+    // ~2048 row blocks for large tensors, but never fewer rows per block than one unrolled pass of the reduce
+    // kernel covers (256 threads = C/4 channel quads x pixel lanes, 4 rows in flight per lane)
+    long rows_min = 4096 / (C > 0 ? C : 1);
+    if (rows_min < 4) rows_min = 4;
+    long rows = (M + 2047) / 2048;
+    if (rows < rows_min) rows = rows_min;
+    long b = (M + rows - 1) / rows;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -262,7 +276,7 @@ extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mea
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
     VIAI_LAUNCH(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope);
-    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1);
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1);
     if (dy != nullptr) {
         long n4 = M * C / 4;
         VIAI_LAUNCH(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz),
