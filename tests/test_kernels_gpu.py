@@ -45,6 +45,14 @@ CONV_CASES = [
     ("E.conv1-tiny", 2, 80, 32, 1, 32, (3, 3), (2, 2), (1, 1), False, False),
     ("G.cb3-tiny", 2, 10, 8, 128, 64, (3, 3), (1, 1), (1, 1), True, False),
     ("D.conv1-wide", 1, 8, 300, 1, 64, (1, 4), (1, 2), (0, 1), False, False),
+    # LDS-resident-tile ("halo") kernel shapes: 32/64 channels, stride 1, extent a multiple of 8 x 16
+    ("halo32", 2, 16, 32, 32, 32, (3, 3), (1, 1), (1, 1), False, True),
+    ("halo32T", 2, 24, 16, 32, 32, (3, 3), (1, 1), (1, 1), True, False),
+    ("halo64", 1, 8, 48, 64, 64, (3, 3), (1, 1), (1, 1), False, False),
+    ("halo32to64", 2, 16, 16, 32, 64, (3, 3), (1, 1), (1, 1), False, True),
+    ("halo64to32T", 2, 8, 32, 64, 32, (3, 3), (1, 1), (1, 1), True, True),
+    ("halo48out", 1, 16, 16, 32, 48, (3, 3), (1, 1), (1, 1), False, False),
+    ("halo1x3", 2, 8, 64, 32, 32, (1, 3), (1, 1), (0, 1), False, False),
 ]
 
 

@@ -62,6 +62,23 @@ static bool use_bf3_shape(long M, int n_out, int k_in) {
 static long bf3_rows_fwd(const viai_conv2d* c) { int oh, ow; viai_conv2d_out_hw(c, &oh, &ow); return (long)c->N * oh * ow; }
 static long bf3_rows_dgrad(const viai_conv2d* c) { return (long)c->N * ((c->IH + c->sh - 1) / c->sh) * ((c->IW + c->sw - 1) / c->sw); }
 
+static bool use_bf3_fwd(const viai_conv2d* c);
+static bool use_bf3_dgrad(const viai_conv2d* c);
+// LDS-resident-tile kernel (conv_halo_bf3.hip) for the small-channel stride-1 layers
+static bool halo_fwd(const viai_conv2d* c) {
+    if (!use_bf3_fwd(c)) return false;
+    ConvGeom g{}; viai_geom_fwd(c, &g);
+    return viai_conv_halo_ok(g, c->C1, c->C2, c->Cout);
+}
+static bool halo_dgrad(const viai_conv2d* c) {
+    if (!use_bf3_dgrad(c) || c->sh != 1 || c->sw != 1) return false;
+    ConvGeom g{}; if (viai_geom_dgrad_class(c, 0, 0, &g) == 0) return false;
+    return viai_conv_halo_ok(g, c->Cout, 0, cin_of(c));
+}
+// weight layout of the bf16x3 kernels: fragment-major for the wide-tile and halo kernels, planar otherwise
+static bool frag_fwd(const viai_conv2d* c) { return halo_fwd(c) || viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout); }
+static bool frag_dgrad(const viai_conv2d* c) { return halo_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c)); }
+
 static bool use_bf3_fwd(const viai_conv2d* c) {
     if (kind_of(c) != K_IGEMM) return false;
     int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
@@ -166,6 +183,7 @@ int viai_geom_dgrad_class(const viai_conv2d* c, int a, int b, ConvGeom* g) {
     g->SH = (c->IH - a + c->sh - 1) / c->sh;
     g->SW = (c->IW - b + c->sw - 1) / c->sw;
     g->my = g->mx = 1;
+    g->run = 0;
     g->wtaps = c->kh * c->kw;
     int nt = 0;
     for (int r = 0; r < c->kh; ++r)
@@ -200,7 +218,7 @@ extern "C" int viai_conv2d_pack_fwd(const viai_conv2d* c, const float* w, float*
     }
     default:
         if (use_bf3_fwd(c)) {
-            const long M = bf3_rows_fwd(c);
+            const int M = frag_fwd(c);
             if (c->transposed) return viai_pack_weight_bf3(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, M, (hipStream_t)stream);
             return viai_pack_weight_bf3(w, wp, c->Cout, Cin, T, (long)Cin * T, T, M, (hipStream_t)stream);
         }
@@ -219,7 +237,7 @@ extern "C" int viai_conv2d_pack_dgrad(const viai_conv2d* c, const float* w, floa
         return viai_conv2d_pack_fwd(c, w, wp, stream);     // the streaming kernels share one image
     default:            // wp[ci][t][co]
         if (use_bf3_dgrad(c)) {
-            const long M = bf3_rows_dgrad(c);
+            const int M = frag_dgrad(c);
             if (c->transposed) return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, M, (hipStream_t)stream);
             return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, M, (hipStream_t)stream);
         }
@@ -234,7 +252,7 @@ extern "C" int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_
     int oh, ow;
     viai_conv2d_out_hw(c, &oh, &ow);
     long M = (long)c->N * oh * ow;
-    const int bm = (kind_of(c) == K_COUT1) ? 128 : viai_igemm_tile_m(M, c->Cout);
+    const int bm = (kind_of(c) == K_COUT1 || halo_fwd(c)) ? 128 : viai_igemm_tile_m(M, c->Cout);
     *rows_per_blk = bm;
     *nblk = (int)((M + bm - 1) / bm);
     return 0;
@@ -259,7 +277,11 @@ extern "C" int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float
     if (kind_of(c) == K_RUN) { geom_run(c, &a.g); a.C1 = 32; a.C2 = 0; }
     else viai_geom_fwd(c, &a.g);
     a.M = a.g.N * a.g.OH * a.g.OW;
-    if (use_bf3_fwd(c)) { a.wfrag = viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout); return viai_conv_igemm_bf3_launch(a, st); }
+    if (use_bf3_fwd(c)) {
+        a.wfrag = frag_fwd(c);
+        if (halo_fwd(c)) return viai_conv_halo_bf3_launch(a, st);
+        return viai_conv_igemm_bf3_launch(a, st);
+    }
     return viai_conv_igemm_launch(a, st);
 }
 
@@ -293,8 +315,8 @@ extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const fl
             if (a.g.SH <= 0 || a.g.SW <= 0) continue;
             if (nt == 0) continue;                            // zero-filled above
             a.M = a.g.N * a.g.SH * a.g.SW;
-            a.wfrag = bf3 && viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c));
-            int e = bf3 ? viai_conv_igemm_bf3_launch(a, st) : viai_conv_igemm_launch(a, st);
+            a.wfrag = bf3 && frag_dgrad(c);
+            int e = (bf3 && halo_dgrad(c)) ? viai_conv_halo_bf3_launch(a, st) : bf3 ? viai_conv_igemm_bf3_launch(a, st) : viai_conv_igemm_launch(a, st);
             if (e) return e;
         }
     return 0;

@@ -1,0 +1,289 @@
+// Stride-1 small-channel convolution with an LDS-resident input tile ("halo" kernel), bf16x3 split MFMA, gfx950.
+//
+// The gather-GEMM kernels re-read (and re-split into bf16 terms) every input pixel once per tap.  For the 32/64
+// channel 3x3 layers at 256x256 / 128x128 that repetition -- not the MFMAs -- is the bound.  Here a block owns an
+// 8 x 16 output tile: it loads the (8+2) x (16+2) input patch ONCE (coalesced float4 rows, hardware zero fill for
+// the padding), splits it into three bf16 planes in LDS and then walks the taps: the A operand of tap (dy, dx) is
+// the same LDS tile read at a per-lane row offset.  Weights are fetched fragment-major straight from global
+// memory (see conv_igemm_bf3.hip).  Same epilogue contract as the other conv kernels (bias/act or BN partials).
+// Reference call sites: the 32/64-channel 3x3 stride-1 Conv2d / ConvTranspose2d layers of
+// Inpainting_Networks.py:60-110 (MelEncoder/MelDecoder) and their autograd data gradients.
+#include "viai_common.h"
+#include "viai_internal.h"
+#include "viai_bf3.h"
+
+namespace {
+
+constexpr int HT_H = 8, HT_W = 16;                 // output tile (128 pixels = 4 waves x 32 MFMA rows)
+
+constexpr int HT_HH = HT_H + 2, HT_HW = HT_W + 2, HT_HP = HT_HH * HT_HW;   // staged patch: 10 x 18 pixels (taps span <= 3 x 3)
+
+template <int CIN, int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 && TN == 1) ? 3 : 2))) void conv_halo_bf3_kernel(const ConvArgs a, int hy0, int hx0, int ntiles) {
+    constexpr int PITCH = CIN * 2 + 16;             // bytes per LDS pixel row (80 / 144: conflict-free ds_read_b128)
+    constexpr int Q = CIN / 4;                      // float4 per pixel
+    constexpr int NL = (HT_HP * Q + 255) / 256;     // float4 per thread
+    constexpr int KS = CIN / 16;                    // 16-deep k-steps per tap
+    constexpr int BN = 32 * TN;
+    constexpr int PLANE = HT_HP * PITCH;            // bytes per bf16 plane: an immediate offset of the ds_reads
+    constexpr int KH = 2, U = KS / KH;              // weight prefetch unit = KH k-steps of one tap
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [3][HP][PITCH]
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = g.OW / HT_W, tiles_y = g.OH / HT_H;
+
+    constexpr int OOB = 0x7fffffff;
+    const long in_pixels = (long)g.N * g.IH * g.IW;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * CIN * 4), 0x00020000);
+    const int NT = (a.Cout + 31) / 32;
+    const int frag_plane = NT * g.wtaps * KS * 1024;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 3 * frag_plane, 0x00020000);
+
+    // patch staging: thread -> channel quad q of patch pixels h0 + (256 / Q) * j
+    const int h0 = tid / Q, q = tid % Q;
+    int poff[NL], prc[NL];                          // in-image byte offset relative to the patch origin; (row << 8) | col
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int h = h0 + (256 / Q) * j;
+        const int hr = h / HT_HW, hc = h - hr * HT_HW;
+        poff[j] = (hr * g.IW + hc) * CIN * 4 + q * 16;
+        prc[j] = h < HT_HP ? (hr << 8) | hc : -1;
+    }
+    u32x4 reg[NL];
+    auto load_patch = [&](int tile) {               // tile is wave-uniform; loads land in reg[] while the MFMAs run
+        const int tx = tile % tiles_x; int r = tile / tiles_x;
+        const int ty = r % tiles_y, n = r / tiles_y;
+        const int py = ty * HT_H + hy0, px = tx * HT_W + hx0;
+        const int pbase = ((n * g.IH + py) * g.IW + px) * CIN * 4;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int iy = py + (prc[j] >> 8), ix = px + (prc[j] & 255);
+            const bool ok = prc[j] >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+            reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? pbase + poff[j] : OOB, 0, 0);
+        }
+    };
+    auto store_patch = [&]() {                      // split into three bf16 planes on the way into LDS
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            if (prc[j] >= 0) {
+                const f32x4 v = __builtin_bit_cast(f32x4, reg[j]);
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3_pair(v[0], v[1], a1, a2, a3);
+                split3_pair(v[2], v[3], b1, b2, b3);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
+                unsigned char* d = smem_h + (h0 + (256 / Q) * j) * PITCH + q * 8;
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + PLANE) = p2;
+                *reinterpret_cast<u32x2*>(d + 2 * PLANE) = p3;
+            }
+        }
+    };
+
+    // weights: fragment-major planes [p][nt][tap][kq][lane] x 16 B; the lane part is the only per-lane offset
+    int bvoff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bvoff[j] = (j < NT) ? j * g.wtaps * KS * 1024 + lane * 16 : OOB;
+    const int nunits = g.ntaps * U;
+    auto gloadB = [&](u32x4 (&bf)[KH][TN][3], int u_) {
+        const int u = __builtin_amdgcn_readfirstlane(u_);
+        if (u < nunits) {
+            const int t = u / U, k0 = (u % U) * KH;
+            const int soff = (g.ws[t] * KS + k0) * 1024;
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        bf[ks][j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bvoff[j], soff + ks * 1024 + p * frag_plane, 0);
+        }
+    };
+
+    // MFMA row i = lane & 31 -> tile pixel (2 * wave + (i >> 4), i & 15)
+    const int pr = 2 * wave + ((lane & 31) >> 4), pc = lane & 15;
+    const unsigned char* abase = smem_h + ((pr - hy0) * HT_HW + (pc - hx0)) * PITCH + 16 * (lane >> 5);
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    const int half = lane >> 5, col = lane & 31;
+    float bv[TN];
+    int co[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        co[j] = j * 32 + col;
+        bv[j] = (a.bias != nullptr && co[j] < a.Cout) ? a.bias[co[j]] : 0.f;
+    }
+    const int oc2 = a.Cout - a.OC1;
+
+    // persistent over tiles: block b takes logical tiles b, b + grid, ... (XCD-contiguous after the remap)
+    constexpr bool PREF = !(CIN == 64 && TN == 2);      // next patch prefetched into registers during the MFMAs (register budget)
+    int it = blockIdx.x;
+    if (PREF && it < ntiles) load_patch(xcd_remap(it, ntiles));
+    for (; it < ntiles; it += gridDim.x) {
+        const int tile = xcd_remap(it, ntiles);
+        if (!PREF) load_patch(tile);
+        store_patch();
+        __syncthreads();
+        u32x4 bfa[KH][TN][3], bfb[KH][TN][3];           // two units of weight fragments in flight
+        gloadB(bfa, 0);
+        gloadB(bfb, 1);
+        if (PREF && it + (int)gridDim.x < ntiles) load_patch(xcd_remap(it + gridDim.x, ntiles));
+
+        // NC independent accumulation chains per output tile: a dependent MFMA cannot issue until its predecessor
+        // retires, so a single chain would run the matrix pipe at half rate
+        constexpr int NC = 2;
+        f32x16 accc[TN][NC];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accc[j][c][e] = 0.f;
+        auto mma = [&](u32x4 (&bf)[KH][TN][3], int u_) {
+            const int u = __builtin_amdgcn_readfirstlane(u_);
+            const int t = u / U, k0 = (u % U) * KH;
+            const unsigned char* As = abase + (g.dy[t] * HT_HW + g.dx[t]) * PITCH + k0 * 32;
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * PLANE + ks * 32));
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        accc[j][k % NC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], __builtin_bit_cast(bf16x8, bf[ks][j][PB[k]]), accc[j][k % NC], 0, 0, 0);
+            }
+        };
+#pragma unroll 1
+        for (int u = 0; u < nunits; u += 2) {
+            mma(bfa, u);
+            gloadB(bfa, u + 2);
+            if (u + 1 < nunits) {
+                mma(bfb, u + 1);
+                gloadB(bfb, u + 3);
+            }
+        }
+        f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            acc[j] = accc[j][0];
+#pragma unroll
+            for (int c = 1; c < NC; ++c) acc[j] += accc[j][c];
+        }
+
+        // ------------------------------------------------------------ epilogue of this tile
+        const int tx = tile % tiles_x; int r_ = tile / tiles_x;
+        const int ty = r_ % tiles_y, n = r_ / tiles_y;
+        const int oy0 = ty * HT_H, ox0 = tx * HT_W;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int oy = oy0 + 2 * wave + (row >> 4), ox = ox0 + (row & 15);
+            const size_t opix = ((size_t)n * g.OH + oy) * g.OW + ox;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v = acc[j][e] + bv[j];
+                if (a.stat == nullptr) v = viai_act(v, a.act, a.slope);
+                acc[j][e] = v;
+                if (co[j] < a.Cout) {
+                    if (co[j] < a.OC1) a.out[opix * a.OC1 + co[j]] = v;
+                    else a.out2[opix * oc2 + (co[j] - a.OC1)] = v;
+                }
+            }
+        }
+        __syncthreads();                  // every wave is done reading the patch
+        if (a.stat != nullptr) {          // block-local (mean, M2) over the 128 pixels of this tile
+            float* red = reinterpret_cast<float*>(smem_h);          // [4 waves][BN]
+            float s[TN], mean[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[j][e];
+                t += __shfl_xor(t, 32, 64);
+                s[j] = t;
+            }
+            if (half == 0)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) red[wave * BN + co[j]] = s[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mean[j] = (red[co[j]] + red[BN + co[j]] + red[2 * BN + co[j]] + red[3 * BN + co[j]]) * (1.f / 128.f);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { float d = acc[j][e] - mean[j]; t += d * d; }
+                t += __shfl_xor(t, 32, 64);
+                s[j] = t;
+            }
+            if (half == 0)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) red[wave * BN + co[j]] = s[j];
+            __syncthreads();
+            if (wave == 0 && half == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (co[j] < a.Cout) {
+                        float t = red[co[j]] + red[BN + co[j]] + red[2 * BN + co[j]] + red[3 * BN + co[j]];
+                        a.stat[(size_t)co[j] * a.nblk_m + tile] = mean[j];
+                        a.stat[(size_t)(a.Cout + co[j]) * a.nblk_m + tile] = t;
+                    }
+            }
+            __syncthreads();              // red[] is overwritten by the next patch
+        }
+    }
+}
+
+template <int CIN, int TN>
+int launch_halo(ConvArgs& a, int hy0, int hx0, hipStream_t st) {
+    constexpr int PITCH = CIN * 2 + 16;
+    size_t lds = (size_t)3 * HT_HP * PITCH;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bf3_kernel<CIN, TN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    a.nblk_m = a.M / 128;
+    a.nblk_n = 1;
+    int per_cu = (int)((160 * 1024) / lds);                  // resident blocks per CU (LDS-limited), persistent over the tiles
+    if (per_cu > 4) per_cu = 4;
+    int grid = 256 * per_cu;
+    if (grid > a.nblk_m) grid = a.nblk_m;
+    VIAI_LAUNCH((conv_halo_bf3_kernel<CIN, TN>), dim3(grid), dim3(256), lds, st, a, hy0, hx0, a.nblk_m);
+    return viai_launch_status();
+}
+
+}  // namespace
+
+// Shapes the halo kernel takes: one source of 32 or 64 channels, <= 64 output channels, unit stride in both the
+// gather and the scatter, taps within a 3 x 3 window, output extent a multiple of the 8 x 16 tile.
+bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout) {
+    if (C2 != 0 || (C1 != 32 && C1 != 64) || Cout > 64 || Cout < 1) return false;
+    if (g.run || g.ly != 1 || g.lx != 1 || g.my != 1 || g.mx != 1 || g.SH != g.OH || g.SW != g.OW) return false;
+    if (g.OH % HT_H != 0 || g.OW % HT_W != 0 || g.ntaps < 1) return false;
+    int y0 = g.dy[0], y1 = g.dy[0], x0 = g.dx[0], x1 = g.dx[0];
+    for (int t = 1; t < g.ntaps; ++t) {
+        y0 = g.dy[t] < y0 ? g.dy[t] : y0; y1 = g.dy[t] > y1 ? g.dy[t] : y1;
+        x0 = g.dx[t] < x0 ? g.dx[t] : x0; x1 = g.dx[t] > x1 ? g.dx[t] : x1;
+    }
+    return (y1 - y0) <= 2 && (x1 - x0) <= 2;
+}
+
+int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st) {
+    const ConvGeom& g = a.g;
+    if (!viai_conv_halo_ok(g, a.C1, a.C2, a.Cout)) return (int)hipErrorInvalidValue;
+    if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
+    int y0 = g.dy[0], y1 = g.dy[0], x0 = g.dx[0], x1 = g.dx[0];
+    for (int t = 1; t < g.ntaps; ++t) {
+        y0 = g.dy[t] < y0 ? g.dy[t] : y0; y1 = g.dy[t] > y1 ? g.dy[t] : y1;
+        x0 = g.dx[t] < x0 ? g.dx[t] : x0; x1 = g.dx[t] > x1 ? g.dx[t] : x1;
+    }
+    const bool wide = a.Cout > 32;
+    if (a.C1 == 32) return wide ? launch_halo<32, 2>(a, y0, x0, st) : launch_halo<32, 1>(a, y0, x0, st);
+    return wide ? launch_halo<64, 2>(a, y0, x0, st) : launch_halo<64, 1>(a, y0, x0, st);
+}

@@ -543,9 +543,8 @@ size_t viai_bf3_packed_floats(int n_out, int k_in, int taps) {
     return (3 * elems + 1) / 2;
 }
 
-int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, long M, hipStream_t st) {
+int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, int frag, hipStream_t st) {
     if (k_in % 16 != 0) return (int)hipErrorInvalidValue;
-    const bool frag = viai_bf3_frag_layout(M, n_out);
     long total = (long)(frag ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
