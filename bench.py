@@ -105,16 +105,29 @@ class KernelTimer:
             ow = (d.IW - 1 - 2 * d.pw + d.kw) if d.transposed else (d.IW + 2 * d.pw - d.kw) // d.sw + 1
             return d.N * oh * ow
 
+        def halo_ok(c_in, c2, c_out, d, oh, ow):     # mirror of viai_conv_halo_ok (csrc/conv_halo_bf3.hip)
+            return (BF3 and c2 == 0 and c_in in (32, 64) and c_out <= 64 and d.sh == 1 and d.sw == 1
+                    and d.kh <= 3 and d.kw <= 3 and oh % 8 == 0 and ow % 16 == 0)
+
+        def out_hw(d):
+            oh = (d.IH - 1 - 2 * d.ph + d.kh) if d.transposed else (d.IH + 2 * d.ph - d.kh) // d.sh + 1
+            ow = (d.IW - 1 - 2 * d.pw + d.kw) if d.transposed else (d.IW + 2 * d.pw - d.kw) // d.sw + 1
+            return oh, ow
+
         def fam_fwd(d):
             cin = d.C1 + d.C2
             if cin == 1 or d.Cout == 1:
                 return "direct", 1
+            if halo_ok(d.C1, d.C2, d.Cout, d, *out_hw(d)):
+                return "halo", 1
             return igemm_name(out_pixels(d), d.Cout), 1
 
         def fam_dgrad(d):
             cin = d.C1 + d.C2
             if cin == 1 or d.Cout == 1:
                 return "direct", 1
+            if halo_ok(d.Cout, 0, cin, d, d.IH, d.IW):
+                return "halo", 1
             ncls = d.sh * d.sw                        # one launch per output parity class
             return igemm_name(-(-(d.N * d.IH * d.IW) // ncls), cin), ncls
 
@@ -285,13 +298,24 @@ def main():
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream around each call, %d instrumented eager steps after the timed region" % nprof,
             "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<2,2,2,2>; igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2> (small-M layers); "
-                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; wgrad_bf3 = wgrad_bf3_kernel<*>; "
+                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo = conv_halo_bf3_kernel<*> (32/64-channel stride-1 layers); wgrad_bf3 = wgrad_bf3_kernel<*>; "
                                    "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers)") if BF3 else
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},
             "conv_tflops_by_kernel": {k: round(v[0] / v[1] * 1e-12, 2) for k, v in sorted(fam.items()) if v[1] > 0},
             "conv_ms_per_step": round(tot_t / nprof * 1e3, 3),
         }
+        # memory-side traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
+        # number comes from the committed counter summary of the same kernel on its largest layer (D.conv3)
+        pmc = os.path.join(ROOT, "profiles", "r01_d_pmc_dconv3.json")
+        if BF3 and os.path.exists(pmc):
+            for k, v in json.load(open(pmc)).items():
+                if "conv_igemm_bf3_frag_kernel" in k and "hbm_bytes" in v:
+                    out["roofline"]["traffic"] = round(v["hbm_bytes"])
+                    out["roofline"]["traffic_note"] = (
+                        "bytes per launch on D.conv3 (fwd/dgrad average; algorithmic 57 MB in + 50 MB out): 2*FETCH_SIZE + WRITE_SIZE from "
+                        "profiles/r01_d_pmc_dconv3.json (tools/profile_layer.py under rocprofv3 --pmc); these L2 memory-side "
+                        "counters include Infinity-Cache hits, i.e. they are L2-miss traffic, an upper bound on HBM bytes")
         del m2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)

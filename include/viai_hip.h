@@ -56,7 +56,8 @@ typedef struct viai_conv2d {
 
 /* output extent (torch formulas) */
 int viai_conv2d_out_hw(const viai_conv2d* c, int* OH, int* OW);
-/* floats needed for one packed copy of the weights (forward or dgrad form) */
+/* floats needed for one packed copy of the weights (forward or dgrad form).  The packed image is opaque:
+ * fp32 [Cout][taps][Cin], or three bf16 planes (row-major or MFMA-fragment-major) for the bf16x3 kernels. */
 size_t viai_conv2d_packed_floats(const viai_conv2d* c);
 /* repack torch-layout weights for the forward / data-gradient kernels */
 int viai_conv2d_pack_fwd(const viai_conv2d* c, const float* w, float* wp, void* stream);

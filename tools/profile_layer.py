@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Run ONE conv layer (forward + backward) a few times so rocprofv3 can attribute counters to its kernels.
+
+    rocprofv3 --kernel-trace --stats -d out -- python tools/profile_layer.py            # D.conv3 of cfg 2
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -- python tools/profile_layer.py   # one --pmc pass per counter set
+    python tools/profile_layer.py --shape 16 256 256 32 32 --transposed                 # a halo-kernel layer
+
+Default = D.conv3 (Discriminator_Networks.py:44, 256 -> 512 channels, 3x3, on the 64 x 32 map of a 256 x 256 mel at batch 16),
+the layer that holds 51 % of the step's FLOPs and runs on the dominant kernel of bench.py's roofline."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from viai_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shape", type=int, nargs=5, default=[16, 64, 32, 256, 512], metavar=("N", "H", "W", "CIN", "COUT"))
+ap.add_argument("--transposed", action="store_true")
+ap.add_argument("--iters", type=int, default=10)
+a = ap.parse_args()
+N, H, W, Ci, Co = a.shape
+x = (torch.rand(N, H, W, Ci, device="cuda") * 2 - 1).requires_grad_(True)
+wshape = (Ci, Co, 3, 3) if a.transposed else (Co, Ci, 3, 3)
+w = ((torch.rand(*wshape, device="cuda") - 0.5) * 0.1).requires_grad_(True)
+for _ in range(a.iters):
+    y = ops.conv_bn_act(x, w, None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1), transposed=a.transposed)
+    y.backward(torch.ones_like(y))
+torch.cuda.synchronize()
+print("ok", tuple(y.shape))
