@@ -1,0 +1,57 @@
+// Sustained-rate probe for v_mfma_f32_32x32x16_bf16 on gfx950 (no memory traffic): what the matrix pipes deliver
+// under continuous load, i.e. the practical ceiling the conv kernels are priced against in DESIGN.md section 3.3.
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o gpurun_out/mfma_peak && gpurun_out/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NACC>
+__global__ __launch_bounds__(256) void probe(float* out, int iters) {
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(threadIdx.x & 3); b[e] = (__bf16)1.0f; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NACC>
+void run(const char* name, int blocks_per_cu) {
+    const int iters = 4000, blocks = 256 * blocks_per_cu;
+    float* out; hipMalloc(&out, (size_t)blocks * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    probe<NACC><<<blocks, 256>>>(out, 10);
+    hipDeviceSynchronize();
+    float best = 1e30f, worst = 0.f;
+    for (int rep = 0; rep < 8; ++rep) {
+        hipEventRecord(e0);
+        probe<NACC><<<blocks, 256>>>(out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+        if (ms > worst) worst = ms;
+    }
+    double flops = (double)blocks * 4 * iters * 8 * NACC * 32768.0;
+    printf("%s: %d blocks/CU, %d chains/wave: best %.1f TFLOP/s, sustained (slowest of 8) %.1f TFLOP/s\n", name, blocks_per_cu, NACC,
+           flops / (best * 1e-3) * 1e-12, flops / (worst * 1e-3) * 1e-12);
+    hipFree(out);
+}
+
+int main() {
+    run<1>("bf16 32x32x16", 1);
+    run<2>("bf16 32x32x16", 1);
+    run<4>("bf16 32x32x16", 1);
+    run<4>("bf16 32x32x16", 2);
+    run<2>("bf16 32x32x16", 2);
+    run<1>("bf16 32x32x16", 2);
+    run<1>("bf16 32x32x16", 4);
+    return 0;
+}

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
     constexpr int BN = 32 * TN * WN;
     constexpr int APLANE = BM * BF3_PITCH;
     constexpr int STAGE = 3 * APLANE;
+    constexpr int SPLIT_VALU_PER_MFMA = 4;
     constexpr int NA = BM / 32;                         // A float4 per thread per chunk (8 quads per row)
     static_assert(WM * WN == 4, "config");
 
@@ -178,9 +179,6 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
         bbase[j] = (nt < NT) ? nt * g.wtaps * k16 * 1024 + lane * 16 : OOB;
     }
     const long in_pixels = (long)g.N * g.IH * g.IW;
-    const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * a.C1 * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in), 0,
-                                                                             (int)(in_pixels * (a.in2 ? a.C2 : a.C1) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 3 * frag_plane, 0x00020000);
 
     f32x16 acc[TM][TN];
@@ -194,23 +192,40 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
     const int cchunks = (Cin + BK - 1) / BK;
     const int nchunks = g.ntaps * cchunks;
 
-    u32x4 areg[NA];
-    auto gloadA = [&](int t_, int c0_) {
+    // per-row tap validity (bit t set: tap t reads inside the image), so the K loop only tests a bit
+    unsigned tapok[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        unsigned m = 0;
+        for (int t = 0; t < g.ntaps; ++t) {
+            int iy = iy0[j] + g.dy[t], ix = ix0[j] + g.dx[t];
+            m |= ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) ? (1u << t) : 0u;
+        }
+        tapok[j] = m;
+    }
+
+    // Software pipeline, three stages deep: while the MFMAs of chunk k run, the raw fp32 rows of chunk k+1 (loaded
+    // during chunk k-1) are split into bf16 planes and stored to the other LDS stage, and the loads of chunk k+2 are
+    // in flight.  The split is ~90 VALU instructions per chunk; issued between the MFMAs they cost nothing.
+    auto gloadA = [&](u32x4 (&raw)[NA], int t_, int c0_) {
         const int t = __builtin_amdgcn_readfirstlane(t_);
         const int c0 = __builtin_amdgcn_readfirstlane(c0_);
-        const int dyt = g.dy[t], dxt = g.dx[t];
-        const int toff = dyt * g.IW + dxt;
+        const bool live = t < g.ntaps;
+        const int tt = live ? t : 0;
+        const int toff = g.dy[tt] * g.IW + g.dx[tt];
         const bool first = c0 < a.C1;
         const int cs = first ? a.C1 : a.C2;
         const int coff = (first ? c0 : c0 - a.C1) + q * 4;
-        const bool kin = (c0 + q * 4 < Cin);
+        const bool kin = live && (c0 + q * 4 < Cin);
+        // descriptor of the source this chunk reads, built from scalar selects (a branch here would split the basic
+        // block and with it the MFMA / VALU interleave below)
+        const float* src = first ? a.in : a.in2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(in_pixels * cs * 4), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            int iy = iy0[j] + dyt, ix = ix0[j] + dxt;
-            bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW && kin;
-            int off = ok ? ((pixbase[j] + toff) * cs + coff) * 4 : OOB;
-            areg[j] = first ? __builtin_amdgcn_raw_buffer_load_b128(rs_in1, off, 0, 0)
-                            : __builtin_amdgcn_raw_buffer_load_b128(rs_in2, off, 0, 0);
+            const bool ok = kin && ((tapok[j] >> tt) & 1u);
+            const int off = ok ? ((pixbase[j] + toff) * cs + coff) * 4 : OOB;
+            raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         }
     };
     // B fragments of one 16-deep k-step: (tap t, channel offset c) -> 3 planes x TN tiles
@@ -218,18 +233,19 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
         const int t = __builtin_amdgcn_readfirstlane(t_);
         const int c = __builtin_amdgcn_readfirstlane(c_);
         const bool okk = (t < g.ntaps) && (c < Cin);
-        const int koff = okk ? (g.ws[t] * k16 + (c >> 4)) * 1024 : 0;
+        const int tt = t < g.ntaps ? t : 0;                          // unconditional table read: no branch in the K loop
+        const int koff = (g.ws[tt] * k16 + (c >> 4)) * 1024;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                bf[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (bbase[j] == OOB || !okk) ? OOB : p * frag_plane + bbase[j] + koff, 0, 0);
+                bf[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (bbase[j] == OOB || !okk) ? OOB : bbase[j], koff + p * frag_plane, 0);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const u32x4 (&raw)[NA], int buf) {
         unsigned char* As = smem_b + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const f32x4 v = __builtin_bit_cast(f32x4, areg[j]);
+            const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
             unsigned a1, a2, a3, b1, b2, b3;
             split3_pair(v[0], v[1], a1, a2, a3);
             split3_pair(v[2], v[3], b1, b2, b3);
@@ -240,25 +256,27 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
             *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
         }
     };
+    auto advance = [&](int& t, int& c) { c += BK; if (c >= Cin) { c = 0; ++t; } };
 
-    int t_cur = 0, c_cur = 0;                 // chunk being computed
-    int t_next = 0, c_next = BK;              // next chunk
-    if (c_next >= Cin) { c_next = 0; t_next = 1; }
-    gloadA(0, 0);
+    int t_cur = 0, c_cur = 0;                 // chunk k (being multiplied)
+    int t_n1 = 0, c_n1 = 0;                   // chunk k+1 (being split)
+    advance(t_n1, c_n1);
+    int t_n2 = t_n1, c_n2 = c_n1;             // chunk k+2 (being loaded)
+    advance(t_n2, c_n2);
+    u32x4 rawA[NA], rawB[NA];
     u32x4 bf0[TN][3], bf1[TN][3];
+    gloadA(rawA, 0, 0);
     gloadB(bf0, 0, 0);
-    lstore(0);
+    gloadA(rawB, t_n1, c_n1);
+    lstore(rawA, 0);
     __syncthreads();
 
     const int aoff = (wm * TM * 32 + (lane & 31)) * BF3_PITCH + 16 * (lane >> 5);
     constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};     // six partial products, smallest first
 
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const bool more = (kc + 1 < nchunks);
-        const int cur = kc & 1;
-        if (more) gloadA(t_next, c_next);
+    auto step = [&](u32x4 (&rload)[NA], const u32x4 (&rconv)[NA], int cur) {
+        gloadA(rload, t_n2, c_n2);
         const unsigned char* As = smem_b + cur * STAGE + aoff;
-        // ---- k-step 0 of this chunk (B fragments in bf0); fetch k-step 1's B fragments meanwhile
         gloadB(bf1, t_cur, c_cur + 16);
         {
             bf16x8 af[TM][3];
@@ -275,8 +293,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]], __builtin_bit_cast(bf16x8, bf0[j][PB[pr]]), acc[i][j], 0, 0, 0);
         }
-        // ---- k-step 1 (bf1); fetch the next chunk's k-step 0 fragments meanwhile
-        gloadB(bf0, more ? t_next : g.ntaps, c_next);
+        gloadB(bf0, t_n1, c_n1);
         {
             bf16x8 af[TM][3];
 #pragma unroll
@@ -292,11 +309,21 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]], __builtin_bit_cast(bf16x8, bf1[j][PB[pr]]), acc[i][j], 0, 0, 0);
         }
-        if (more) lstore(cur ^ 1);
+        lstore(rconv, cur ^ 1);
+        // interleave: one MFMA, then a few of the split's VALU instructions, so the split runs in the MFMA shadow
+#pragma unroll
+        for (int i = 0; i < 12 * TM * TN; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, SPLIT_VALU_PER_MFMA, 0);
+        }
         __syncthreads();
-        t_cur = t_next; c_cur = c_next;
-        c_next += BK;
-        if (c_next >= Cin) { c_next = 0; ++t_next; }
+        t_cur = t_n1; c_cur = c_n1;
+        t_n1 = t_n2; c_n1 = c_n2;
+        advance(t_n2, c_n2);
+    };
+    for (int kc = 0; kc < nchunks; kc += 2) {
+        step(rawA, rawB, 0);
+        if (kc + 1 < nchunks) step(rawB, rawA, 1);
     }
 
     bf3_epilogue<TM, TN, WM, WN>(a, acc, smem_b, lane, wm, wn, m0, n0, bm);
