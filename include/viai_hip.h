@@ -244,6 +244,25 @@ int viai_stft_mel(const float* wav, const float* window, const float* basis_t, c
                   float* mel, int B, int n_samples, int fft, int hop, int n_mels, int frames,
                   float min_level_db, float ref_level_db, void* stream);
 
+/* -------------------------------------------------- callers either side of the path
+ * Batch assembly on the device, Data_loaders/audio_loader.py:185-245: frames uint8 [n][S][S][C] (RGB or
+ * (flow_x, flow_y), already resized to S x S) -> float NHWC4 [n][size][size][4] = (px - 127) / 128 after the
+ * left-right flip and the crop of rows [crop_x, +size) x columns [crop_y, +size).                           */
+int viai_frames_prep(const unsigned char* frames, float* out, long n, int S, int C, int size,
+                     int crop_x, int crop_y, int flip, void* stream);
+/* audio_loader.py:471-475,508,523: clip b = mel frames [3 + 4*start[b], +L) of c [T_total][D] -> c_out [B][D][L]
+ * (channel first), and samples [(3 + 4*start[b]) * hop, +L*hop) of x -> x_out [B][L*hop]; zero padded past the end. */
+int viai_slice_clips(const float* c, const float* x, const int* start, float* c_out, float* x_out,
+                     int B, int D, int L, int hop, long T_total, long samples, void* stream);
+/* loss_functions.py:65-76 ExponentialMovingAverage.update on a flat buffer: shadow -= (1 - decay) * (shadow - x) */
+int viai_ema_update(float* shadow, const float* x, long n, double decay, void* stream);
+/* utils/audio.py:135-144: out = 10 ^ ((clip(S, 0, 1) * -min_level_db + min_level_db) / 20)  (_denormalize, _db_to_amp) */
+int viai_mel_denorm_amp(const float* S, float* out, long n, float min_level_db, void* stream);
+/* utils/util.py:99-121 L2retrieval: for caption i, ranks[i] = position of clip i in the ascending order of
+ * |captions[i] - clips[j]|_2 over j, top1[i] = argmin_j; dist (optional) [n_captions][n_clips].             */
+int viai_l2_ranks(const float* clips, const float* captions, int n_clips, int n_captions, int dim,
+                  int* ranks, int* top1, float* dist, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,173 @@
+"""The callers either side of the train-step path: lr schedules, EMA, retrieval metrics,
+device batch assembly, inverse mel.  CPU tests pin oracle/pipeline_oracle.py and the host-side schedule functions to
+the reference-generated goldens (tests/golden/pipeline.npz, tools/make_goldens.py::pipeline_goldens); GPU tests
+compare the HIP kernels (through libviai_hip.so) with the oracle.  frames_prep / slice_clips / inv_mel are restated
+from Data_loaders/audio_loader.py:185-245,471-523 and utils/audio.py:135-144 (parity unpinned: those modules need
+cv2 / lws / librosa, absent in the build container) and additionally checked by direct index arithmetic here."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline_oracle as P
+from oracle import viai_oracle as O
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "pipeline.npz"))
+
+
+def test_lr_schedules_match_reference_golden(gold):
+    from viai_amd import lrschedule as L
+    for i, s in enumerate(gold["lr_steps"].tolist()):
+        for key, host, orc in (("lr_noam", L.noam_learning_rate_decay(1e-3, s, 2000), P.noam_learning_rate_decay(1e-3, s, 2000)),
+                               ("lr_step", L.step_learning_rate_decay(1e-3, s, 0.98, 50000), P.step_learning_rate_decay(1e-3, s, 0.98, 50000)),
+                               ("lr_cyclic", L.cyclic_cosine_annealing(1e-3, s, 200000, 5), P.cyclic_cosine_annealing(1e-3, s, 200000, 5))):
+            ref = float(gold[key][i])
+            assert abs(host - ref) <= 1e-13 * max(abs(ref), 1e-30), (key, s)
+            assert abs(float(orc) - ref) <= 1e-13 * max(abs(ref), 1e-30), (key, s)
+
+
+def test_oracle_ema_and_retrieval_match_reference_golden(gold):
+    for decay in (0.9999, 0.9):
+        sh = O.cf_uniform("ema.w0", (3, 50), -1, 1).numpy()
+        for i in range(5):
+            sh = P.ema_update(sh, O.cf_uniform("ema.x%d" % i, (3, 50), -1, 1).numpy(), decay)
+        assert np.abs(sh - gold["ema_%g" % decay]).max() <= 1e-7
+    clips, caps = _retrieval_inputs()
+    m, ranks, top1 = P.l2_retrieval(clips, caps)
+    assert np.array_equal(ranks, gold["ret_ranks"]) and np.array_equal(top1, gold["ret_top1"])
+    assert np.allclose(m, gold["ret_metrics"])
+
+
+def _retrieval_inputs():
+    W = O.cf_uniform("ret.W", (4, 256), -1, 1).numpy()
+    z = O.cf_uniform("ret.z", (96, 4), -1, 1).numpy()
+    clips = (z @ W).astype(np.float32)
+    caps = ((z + 0.5 * O.cf_uniform("ret.e", (96, 4), -1, 1).numpy()) @ W).astype(np.float32)
+    return clips, caps
+
+
+def test_oracle_batch_assembly_index_arithmetic():
+    # slice_clips: every element equals the documented source index (audio_loader.py:471-475)
+    T_total, D, hop, N = 120, 5, 7, 6
+    c = np.arange(T_total * D, dtype=np.float32).reshape(T_total, D)
+    x = np.arange(T_total * hop, dtype=np.float32)
+    cb, xb = P.slice_clips(c, x, [0, 10, 24], N, hop)
+    assert cb.shape == (3, D, 4 * N) and xb.shape == (3, 1, 4 * N * hop)
+    assert cb[1, 2, 3] == c[3 + 40 + 3, 2] and xb[1, 0, 11] == x[(3 + 40) * hop + 11]
+    assert cb[2, 0, 4 * N - 1] == 0.0 and cb[2, 0, 20] == c[3 + 96 + 20, 0]      # past the end -> zero padding
+    # frames_prep: flip then crop rows by crop_x and columns by crop_y
+    f = (np.arange(2 * 9 * 9 * 3) % 251).astype(np.uint8).reshape(2, 9, 9, 3)
+    out = P.frames_prep(f, 5, 2, 1, True)
+    assert out.shape == (2, 3, 5, 5)
+    assert out[1, 2, 3, 4] == np.float32((float(f[1, 2 + 3, 9 - 1 - (1 + 4), 2]) - 127.) / 128.)
+    out = P.frames_prep(f, 5, 2, 1, False)
+    assert out[0, 1, 0, 0] == np.float32((float(f[0, 2, 1, 1]) - 127.) / 128.)
+    # inverse mel: S = 1 -> 0 dB -> amplitude 1; S = 0 -> min_level_db
+    assert np.allclose(P.inv_mel_amplitude(np.array([1.0, 0.0, 0.5, 2.0, -1.0]), -100.0), [1.0, 1e-5, 10 ** -2.5, 1.0, 1e-5])
+
+
+def test_checkpoint_helpers_roundtrip_cpu(tmp_path):
+    """WaveNet-style checkpoint dict (utils/model_util.py:122-148) and the tolerant copy (utils/util.py:124-144)."""
+    from viai_amd import util as U
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+
+    class Ema:
+        shadow = {"0.weight": torch.full((3, 4), 7.0)}
+    paths = U.save_checkpoint(m, opt, 12, 3, str(tmp_path), 1, name="wn", ema=Ema())
+    assert os.path.basename(paths[0]) == "wn_checkpoint_step000000012.pth.tar"
+    assert os.path.basename(paths[1]) == "checkpoint_step000000012_ema.pth"
+    ck = torch.load(paths[0], weights_only=False)
+    assert set(ck) == {"model", "optimizer", "global_step", "global_epoch", "global_test_step"}
+    assert torch.load(paths[1], weights_only=False)["model"]["0.weight"].eq(7.0).all()
+    m2 = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(5, 2))          # second layer mismatches
+    prefixed = {"module." + k: v for k, v in ck["model"].items()}                    # DataParallel prefix
+    U.copy_state_dict(prefixed, m2, strip="module.")
+    assert torch.equal(m2[0].weight, m[0].weight) and torch.equal(m2[0].bias, m[0].bias)
+    assert tuple(m2[1].weight.shape) == (2, 5)                                       # shape mismatch: skipped, not an error
+    step, epoch, tstep = U.load_checkpoint(paths[0], m2, strip=None)
+    assert (step, epoch, tstep) == (12, 1, 3)
+
+
+# ------------------------------------------------------------------------------------------------ GPU (HIP kernels)
+@pytest.mark.gpu
+def test_ema_kernel_matches_reference_golden(gold):
+    from viai_amd.losses import ExponentialMovingAverage
+    for decay in (0.9999, 0.9):
+        ema = ExponentialMovingAverage(decay)
+        ema.register("w", O.cf_uniform("ema.w0", (3, 50), -1, 1).cuda())
+        for i in range(5):
+            ema.update("w", O.cf_uniform("ema.x%d" % i, (3, 50), -1, 1).cuda())
+        assert np.abs(ema.shadow["w"].cpu().numpy() - gold["ema_%g" % decay]).max() <= 1e-7
+
+
+@pytest.mark.gpu
+def test_l2_retrieval_kernel_matches_reference_golden(gold):
+    from viai_amd import util as U
+    clips, caps = _retrieval_inputs()
+    metrics, (ranks, top1) = U.L2retrieval(torch.from_numpy(clips).cuda(), torch.from_numpy(caps).cuda(), return_ranks=True)
+    assert np.array_equal(ranks, gold["ret_ranks"]) and np.array_equal(top1, gold["ret_top1"])       # bit-exact index work
+    assert np.allclose(metrics, gold["ret_metrics"])
+    r, t, d = U.l2_ranks(torch.from_numpy(clips).cuda(), torch.from_numpy(caps).cuda(), return_dist=True)
+    ref = np.sqrt(((caps[:, None, :].astype(np.float64) - clips[None].astype(np.float64)) ** 2).sum(-1))
+    assert np.abs(d.cpu().numpy() - ref).max() <= 1e-5 * ref.max()
+    # larger, random: every caption's own clip perturbed -> compare with the oracle
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(700, 64, generator=g)
+    b = a + 0.9 * torch.randn(700, 64, generator=g)
+    m2, r2, t2 = P.l2_retrieval(a.numpy(), b.numpy())
+    r, t = U.l2_ranks(a.cuda(), b.cuda())
+    assert np.array_equal(r.cpu().numpy(), r2) and np.array_equal(t.cpu().numpy(), t2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flip", [False, True])
+def test_frames_prep_kernel_matches_oracle(flip):
+    from viai_amd import batch
+    g = torch.Generator().manual_seed(1)
+    for C, S, size, cx, cy in ((3, 40, 32, 5, 8), (2, 40, 32, 0, 0), (3, 256, 224, 31, 7)):
+        f = torch.randint(0, 256, (2, 3, S, S, C), generator=g, dtype=torch.uint8)
+        want = P.frames_prep(f.numpy(), size, cx, cy, flip)
+        got = batch.frames_prep(f.cuda(), size, cx, cy, flip, nchw=True)
+        assert tuple(got.shape) == want.shape
+        assert np.array_equal(got.cpu().numpy(), want)                 # (px - 127) / 128 is exact in fp32
+        nhwc4 = batch.frames_prep(f.cuda(), size, cx, cy, flip)
+        assert tuple(nhwc4.shape) == (6, size, size, 4) and float(nhwc4[..., C:].abs().max()) == 0.0
+        assert np.array_equal(nhwc4[..., :C].permute(0, 3, 1, 2).cpu().numpy().reshape(want.shape), want)
+
+
+@pytest.mark.gpu
+def test_slice_clips_kernel_matches_oracle():
+    from viai_amd import batch
+    g = torch.Generator().manual_seed(2)
+    T_total, D, hop, N = 300, 80, 256, 13
+    c = torch.rand(T_total, D, generator=g)
+    x = torch.rand(T_total * hop, generator=g) * 2 - 1
+    starts = [0, 17, 40, 62]                          # the last clip runs past the end -> zero padding
+    want_c, want_x = P.slice_clips(c.numpy(), x.numpy(), starts, N, hop)
+    got_c, got_x = batch.slice_clips(c.cuda(), x.cuda(), starts, N, hop)
+    assert np.array_equal(got_c.cpu().numpy(), want_c) and np.array_equal(got_x.cpu().numpy(), want_x)
+
+
+@pytest.mark.gpu
+def test_inv_mel_amplitude_kernel_matches_oracle():
+    from viai_amd import audio
+    S = torch.cat([O.cf_uniform("inv.S", (2, 80, 50), -0.2, 1.2).flatten(), torch.tensor([0.0, 1.0, 0.5])])
+    got = audio.inv_mel_amplitude(S.cuda(), -100.0).cpu().numpy().astype(np.float64)
+    want = P.inv_mel_amplitude(S.numpy(), -100.0)
+    assert np.abs(got / want - 1).max() <= 1e-5          # fp32 exp10 vs float64 power
+
+
+@pytest.mark.gpu
+def test_lr_schedule_reaches_the_device_adam_state():
+    from viai_amd import lrschedule as L
+    from viai_amd.model import FlatArena, FusedAdam
+    p = torch.nn.Parameter(torch.ones(8, device="cuda"))
+    arena = FlatArena([("p", p)])
+    opt = FusedAdam(arena, 1e-3, (0.9, 0.999), 1e-8)
+    lr = L.apply_schedule(opt, L.noam_learning_rate_decay, 1e-3, 100, warmup_steps=2000)
+    assert abs(float(opt.state[1]) - lr) <= 1e-18 and abs(lr - 1e-3 * 2000 ** 0.5 * 101 * 2000 ** -1.5) < 1e-15

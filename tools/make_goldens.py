@@ -423,10 +423,57 @@ def layer_goldens():
     print("layers -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def pipeline_goldens():
+    """The callers either side of the path: lr schedules, EMA, retrieval metrics, produced by
+    the reference's own functions and checked against oracle/pipeline_oracle.py."""
+    from utils import lrschedule as RefLR
+    from utils import util as RefUtil
+    from oracle import pipeline_oracle as P
+    out = {}
+    steps = np.array([0, 1, 7, 1999, 2000, 2001, 49999, 50000, 123456, 1000000], dtype=np.int64)
+    out["lr_steps"] = steps
+    out["lr_noam"] = np.array([RefLR.noam_learning_rate_decay(1e-3, int(s), 2000) for s in steps])
+    out["lr_step"] = np.array([RefLR.step_learning_rate_decay(1e-3, int(s), 0.98, 50000) for s in steps])
+    out["lr_cyclic"] = np.array([RefLR.cyclic_cosine_annealing(1e-3, int(s), 200000, 5) for s in steps])
+    for k, f in (("lr_noam", lambda s: P.noam_learning_rate_decay(1e-3, s, 2000)),
+                 ("lr_step", lambda s: P.step_learning_rate_decay(1e-3, s, 0.98, 50000)),
+                 ("lr_cyclic", lambda s: P.cyclic_cosine_annealing(1e-3, s, 200000, 5))):
+        assert np.allclose(out[k], [f(int(s)) for s in steps], rtol=1e-14, atol=0)
+    # ExponentialMovingAverage (loss_functions.py:65-76): 5 updates at decay 0.9999 and 0.9
+    for decay in (0.9999, 0.9):
+        ema = RefLoss.ExponentialMovingAverage(decay)
+        ema.register("w", O.cf_uniform("ema.w0", (3, 50), -1, 1))
+        sh = O.cf_uniform("ema.w0", (3, 50), -1, 1).numpy()
+        for i in range(5):
+            x = O.cf_uniform("ema.x%d" % i, (3, 50), -1, 1)
+            ema.update("w", x)
+            sh = P.ema_update(sh, x.numpy(), decay)
+        out["ema_%g" % decay] = ema.shadow["w"].numpy()
+        assert np.abs(sh - out["ema_%g" % decay]).max() <= 1e-7
+    # L2retrieval (utils/util.py:99-121): captions = noisy copies of the clips, so ranks are spread out
+    W = O.cf_uniform("ret.W", (4, 256), -1, 1).numpy()                 # embeddings on a 4-d subspace: ranks spread out
+    z = O.cf_uniform("ret.z", (96, 4), -1, 1).numpy()
+    clips = (z @ W).astype(np.float32)
+    caps = ((z + 0.5 * O.cf_uniform("ret.e", (96, 4), -1, 1).numpy()) @ W).astype(np.float32)
+    metrics, (ranks, top1) = RefUtil.L2retrieval(clips, caps, return_ranks=True)
+    out["ret_metrics"] = np.array(metrics, dtype=np.float64)
+    out["ret_ranks"], out["ret_top1"] = ranks.astype(np.int64), top1.astype(np.int64)
+    m2, r2, t2 = P.l2_retrieval(clips, caps)
+    assert np.array_equal(r2, ranks) and np.array_equal(t2, top1) and np.allclose(m2, metrics)
+    assert len(set(ranks.tolist())) > 5, "degenerate retrieval golden"
+    path = os.path.join(OUT, "pipeline.npz")
+    np.savez_compressed(path, **out)
+    print("pipeline -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--pipeline-only" in sys.argv:
+        pipeline_goldens()
+        sys.exit(0)
     torch.set_num_threads(os.cpu_count())
     layer_goldens()
+    pipeline_goldens()
     adam_goldens()
     av_goldens()
     resnet_goldens()

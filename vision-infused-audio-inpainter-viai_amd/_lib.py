@@ -111,6 +111,11 @@ SIGNATURES = {
     "viai_colsum": (_I, [_P, _L, _I, _P, _P, _I, _P]),
     "viai_axpy": (_I, [_F, _P, _P, _L, _P]),
     "viai_stft_mel": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "viai_frames_prep": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "viai_slice_clips": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _P]),
+    "viai_ema_update": (_I, [_P, _P, _L, _D, _P]),
+    "viai_mel_denorm_amp": (_I, [_P, _P, _L, _F, _P]),
+    "viai_l2_ranks": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
 }
 
 _lib = None

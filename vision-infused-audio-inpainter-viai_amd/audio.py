@@ -90,3 +90,15 @@ class MelFrontEnd:
                                      c.num_mels, frames, float(c.min_level_db), float(c.ref_level_db),
                                      torch.cuda.current_stream().cuda_stream), "viai_stft_mel")
         return out
+
+
+def inv_mel_amplitude(S, min_level_db=None):
+    """`_db_to_amp(_denormalize(S))` of utils/audio.py:135-144 in one pass: the normalised mel the generator emits
+    -> linear amplitudes (the step after the path; the vocoder consumes the normalised mel directly)."""
+    from .ops import _require, _stream
+    _require(S)
+    S = S if S.is_contiguous() else S.contiguous()
+    out = torch.empty_like(S)
+    db = float(AudioConfig.min_level_db if min_level_db is None else min_level_db)
+    _lib.check(_lib.load().viai_mel_denorm_amp(S.data_ptr(), out.data_ptr(), S.numel(), db, _stream()), "viai_mel_denorm_amp")
+    return out

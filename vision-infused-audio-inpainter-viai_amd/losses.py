@@ -44,3 +44,25 @@ class L2ContrastiveLoss(nn.Module):
 
     def forward(self, feature1, feature2):
         return ops.l2_contrastive(feature1, feature2, self.margin, self.max_violation)
+
+
+class ExponentialMovingAverage(object):
+    """loss_functions.py:65-76, same methods; the update is one HIP kernel per registered tensor (register the flat
+    parameter arena of a model once and the whole model is averaged by a single launch)."""
+
+    def __init__(self, decay):
+        self.decay = decay
+        self.shadow = {}
+
+    def register(self, name, val):
+        self.shadow[name] = val.detach().clone()
+
+    def update(self, name, x):
+        assert name in self.shadow
+        from . import _lib
+        from .ops import _require, _stream
+        sh = self.shadow[name]
+        x = x.detach()
+        _require(sh, x)
+        x = x if x.is_contiguous() else x.contiguous()
+        _lib.check(_lib.load().viai_ema_update(sh.data_ptr(), x.data_ptr(), sh.numel(), float(self.decay), _stream()), "viai_ema_update")
