@@ -96,6 +96,8 @@ class KernelTimer:
             return 128 if b >= 512 else 64
 
         def igemm_name(M, n_out):
+            if BF3 and n_out > 32 and not (tile_m(M, n_out) == 128 and n_out > 64) and -(-M // 64) * -(-n_out // 64) < 512:
+                return "igemm_sk32x32"               # mirror of viai_bf3_sk_ok (csrc/conv_igemm_bf3.hip)
             if tile_m(M, n_out) == 64:
                 return "igemm64x64"
             return "igemm128x128" if n_out > 64 else ("igemm128x64" if n_out > 32 else "igemm128x32")
@@ -297,7 +299,7 @@ def main():
             "kernel": DOMINANT, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream around each call, %d instrumented eager steps after the timed region" % nprof,
-            "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<2,2,2,2>; igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2> (small-M layers); "
+            "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<2,2,2,2>; igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel (small-M layers, waves split K); "
                                    "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo = conv_halo_bf3_kernel<*> (32/64-channel stride-1 layers); wgrad_bf3 = wgrad_bf3_kernel<*>; "
                                    "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers)") if BF3 else
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",

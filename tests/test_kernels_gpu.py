@@ -53,6 +53,9 @@ CONV_CASES = [
     ("halo64to32T", 2, 8, 32, 64, 32, (3, 3), (1, 1), (1, 1), True, True),
     ("halo48out", 1, 16, 16, 32, 48, (3, 3), (1, 1), (1, 1), False, False),
     ("halo1x3", 2, 8, 64, 32, 32, (1, 3), (1, 1), (0, 1), False, False),
+    # big enough that the 64x64-tile LDS-weight kernel (not the small-M split-K kernel) takes the layer
+    ("lds64x64", 4, 64, 64, 64, 128, (3, 3), (1, 1), (1, 1), False, False),
+    ("lds64x64-s2T", 2, 128, 64, 128, 96, (3, 3), (1, 1), (1, 1), True, True),
 ]
 
 

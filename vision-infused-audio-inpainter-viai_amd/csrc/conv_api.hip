@@ -77,6 +77,9 @@ static bool halo_dgrad(const viai_conv2d* c) {
 }
 // weight layout of the bf16x3 kernels: fragment-major for the wide-tile and halo kernels, planar otherwise
 static bool frag_fwd(const viai_conv2d* c) { return halo_fwd(c) || viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout); }
+static bool sk_fwd(const viai_conv2d* c) {
+    return use_bf3_fwd(c) && !frag_fwd(c) && viai_bf3_sk_ok(bf3_rows_fwd(c), c->Cout, c->C1, c->C2);
+}
 static bool frag_dgrad(const viai_conv2d* c) { return halo_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c)); }
 
 static bool use_bf3_fwd(const viai_conv2d* c) {
@@ -252,7 +255,7 @@ extern "C" int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_
     int oh, ow;
     viai_conv2d_out_hw(c, &oh, &ow);
     long M = (long)c->N * oh * ow;
-    const int bm = (kind_of(c) == K_COUT1 || halo_fwd(c)) ? 128 : viai_igemm_tile_m(M, c->Cout);
+    const int bm = (kind_of(c) == K_COUT1 || halo_fwd(c)) ? 128 : sk_fwd(c) ? 32 : viai_igemm_tile_m(M, c->Cout);
     *rows_per_blk = bm;
     *nblk = (int)((M + bm - 1) / bm);
     return 0;
@@ -280,6 +283,7 @@ extern "C" int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float
     if (use_bf3_fwd(c)) {
         a.wfrag = frag_fwd(c);
         if (halo_fwd(c)) return viai_conv_halo_bf3_launch(a, st);
+        a.sk = sk_fwd(c);
         return viai_conv_igemm_bf3_launch(a, st);
     }
     return viai_conv_igemm_launch(a, st);
@@ -316,6 +320,7 @@ extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const fl
             if (nt == 0) continue;                            // zero-filled above
             a.M = a.g.N * a.g.SH * a.g.SW;
             a.wfrag = bf3 && frag_dgrad(c);
+            a.sk = bf3 && !a.wfrag && viai_bf3_sk_ok(a.M, a.Cout, a.C1, 0);
             int e = (bf3 && halo_dgrad(c)) ? viai_conv_halo_bf3_launch(a, st) : bf3 ? viai_conv_igemm_bf3_launch(a, st) : viai_conv_igemm_launch(a, st);
             if (e) return e;
         }

@@ -490,6 +490,202 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_lds_kernel(const ConvArgs 
     bf3_epilogue<TM, TN, WM, WN>(a, acc, smem_b, lane, wm, wn, m0, n0, bm);
 }
 
+// Variant for layers with few output tiles (small M): 32 x 32 tile, 64-deep chunks, and the block's four waves split
+// K -- wave w multiplies k-step w of every chunk -- so a layer with M = 512 ... 32768 pixels still fills the chip
+// (16x more blocks than 64 x 64 tiles x 4 waves would give per wave-tile) and the epilogue (bias / activation /
+// BatchNorm partials) stays fused: the four partial accumulators are summed through LDS and wave 0 finishes the tile.
+// Planar weights [plane][co][tap][ci] staged through LDS, one stage, register-prefetched global loads.
+__global__ __launch_bounds__(256) void conv_igemm_bf3_sk_kernel(const ConvArgs a) {
+    constexpr int BM = 32, BN = 32, BK = 64;
+    constexpr int PITCH = BK * 2 + 16;                  // 144-byte rows: conflict-free ds_read_b128
+    constexpr int APLANE = BM * PITCH, BPLANE = BN * PITCH;
+    constexpr int NA = 2, NBQ = 3;                      // A float4 / B 16-byte pieces per thread per chunk
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* As = smem_b;                         // [3][32][144]
+    unsigned char* Bs = smem_b + 3 * APLANE;            // [3][32][144]
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bn = bid % a.nblk_n, bm = bid / a.nblk_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int Cin = a.C1 + a.C2;
+
+    const int q = tid & 15, r0 = tid >> 4;              // A: row r0 + 16 j, channel quad q (16 quads = 64 channels)
+    int pixbase[NA];
+    unsigned tapok[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int m = m0 + r0 + 16 * j;
+        unsigned msk = 0;
+        pixbase[j] = 0;
+        if (m < a.M) {
+            int ox = m % g.SW; int t = m / g.SW; int oy = t % g.SH; int n = t / g.SH;
+            int iy0 = oy * g.my, ix0 = ox * g.mx;
+            pixbase[j] = (n * g.IH + iy0) * g.IW + ix0;
+            for (int tt = 0; tt < g.ntaps; ++tt) {
+                int iy = iy0 + g.dy[tt], ix = ix0 + g.dx[tt];
+                msk |= ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) ? (1u << tt) : 0u;
+            }
+        }
+        tapok[j] = msk;
+    }
+    constexpr int OOB = 0x7fffffff;
+    const long wplane = (long)a.Cout * g.wtaps * Cin * 2;            // bytes per bf16 plane
+    int bsrc[NBQ], bdst[NBQ];
+#pragma unroll
+    for (int j = 0; j < NBQ; ++j) {                                  // idx -> (plane, row, 16-byte piece of the 128-byte k row)
+        int idx = tid + 256 * j;
+        int plane = idx >> 8, rem = idx & 255, row = rem >> 3, q16 = rem & 7;
+        int co = n0 + row;
+        bsrc[j] = (co < a.Cout) ? (int)(plane * wplane + ((long)co * g.wtaps * Cin) * 2 + q16 * 16) : OOB;
+        bdst[j] = plane * BPLANE + row * PITCH + q16 * 16;
+    }
+    const long in_pixels = (long)g.N * g.IH * g.IW;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(3 * wplane), 0x00020000);
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+
+    const int cchunks = (Cin + BK - 1) / BK;
+    const int nchunks = g.ntaps * cchunks;
+
+    // global loads run one chunk ahead of the MFMAs (a three-deep register ring measured slower: the occupancy it costs
+    // the mid-sized layers outweighs the latency it hides on the smallest ones)
+    struct Regs { u32x4 a[NA]; u32x4 b[NBQ]; };
+    int t_ld = 0, c_ld = 0;                         // next chunk to load
+    auto gload = [&](Regs& R) {
+        const int t = __builtin_amdgcn_readfirstlane(t_ld);
+        const int c0 = __builtin_amdgcn_readfirstlane(c_ld);
+        const bool live = t < g.ntaps;
+        const int tt = live ? t : 0;
+        const int toff = g.dy[tt] * g.IW + g.dx[tt];
+        const bool first = c0 < a.C1;
+        const int cs = first ? a.C1 : a.C2;
+        const int coff = (first ? c0 : c0 - a.C1) + q * 4;
+        const bool kin = live && (c0 + q * 4 < Cin);
+        const float* src = first ? a.in : a.in2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(in_pixels * cs * 4), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const bool ok = kin && ((tapok[j] >> tt) & 1u);
+            R.a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? ((pixbase[j] + toff) * cs + coff) * 4 : OOB, 0, 0);
+        }
+        const int woff = (g.ws[tt] * Cin + c0) * 2;
+#pragma unroll
+        for (int j = 0; j < NBQ; ++j) {
+            const int q16 = (tid + 256 * j) & 7;
+            const bool kb = live && (c0 + q16 * 8 < Cin);
+            R.b[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (bsrc[j] == OOB || !kb) ? OOB : bsrc[j] + woff, 0, 0);
+        }
+        c_ld += BK;
+        if (c_ld >= Cin) { c_ld = 0; ++t_ld; }
+    };
+    auto lstore = [&](const Regs& R) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const f32x4 v = __builtin_bit_cast(f32x4, R.a[j]);
+            unsigned a1, a2, a3, b1, b2, b3;
+            split3_pair(v[0], v[1], a1, a2, a3);
+            split3_pair(v[2], v[3], b1, b2, b3);
+            const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
+            unsigned char* d = As + (r0 + 16 * j) * PITCH + q * 8;
+            *reinterpret_cast<u32x2*>(d) = p1;
+            *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+            *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+        }
+#pragma unroll
+        for (int j = 0; j < NBQ; ++j) *reinterpret_cast<u32x4*>(Bs + bdst[j]) = R.b[j];
+    };
+
+    Regs R;
+    gload(R);
+    lstore(R);
+    __syncthreads();
+
+    const int foff = (lane & 31) * PITCH + wave * 32 + 16 * (lane >> 5);      // this wave's k-step of the chunk
+    for (int kc = 0; kc < nchunks; ++kc) {
+        gload(R);                                           // next chunk (zero-filled past the last one)
+        bf16x8 af[3], bf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            af[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + foff));
+            bf[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * BPLANE + foff));
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc0, 0, 0, 0);     // smallest partial products first
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc1, 0, 0, 0);
+        __syncthreads();
+        lstore(R);
+        __syncthreads();
+    }
+
+    // ---- sum the four waves' partial tiles through LDS (fixed order), wave 0 finishes
+    f32x16 acc = acc0 + acc1;
+    float* red = reinterpret_cast<float*>(smem_b);              // [3][16][64]
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[((wave - 1) * 16 + e) * 64 + lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += red[(w * 16 + e) * 64 + lane];
+
+    const int half = lane >> 5, col = lane & 31;
+    const int co = n0 + col;
+    const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+    const bool ident = (g.ly == 1 && g.lx == 1 && g.SH == g.OH && g.SW == g.OW);
+    const int oc2 = a.Cout - a.OC1;
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int m = m0 + row;
+        float v = acc[e] + bv;
+        if (a.stat == nullptr) v = viai_act(v, a.act, a.slope);
+        acc[e] = v;
+        if (m < a.M) {
+            size_t opix;
+            if (ident) opix = (size_t)m;
+            else {
+                int ox = m % g.SW; int t = m / g.SW; int oy = t % g.SH; int n = t / g.SH;
+                opix = ((size_t)n * g.OH + (oy * g.ly + g.ay)) * g.OW + (ox * g.lx + g.ax);
+            }
+            sum += v;
+            if (co < a.Cout) {
+                if (co < a.OC1) a.out[opix * a.OC1 + co] = v;
+                else a.out2[opix * oc2 + (co - a.OC1)] = v;
+            }
+        }
+    }
+    if (a.stat != nullptr) {                 // block-local (mean, M2) over the tile's rows, inside one wave
+        const int cnt = min(BM, a.M - m0);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum / (float)cnt;
+        float m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            float d = acc[e] - mean;
+            m2 += (m0 + row < a.M) ? d * d : 0.f;
+        }
+        m2 += __shfl_xor(m2, 32, 64);
+        if (half == 0 && co < a.Cout) {
+            a.stat[(size_t)co * a.nblk_m + bm] = mean;
+            a.stat[(size_t)(a.Cout + co) * a.nblk_m + bm] = m2;
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned short bf16_rne(float x) {
     unsigned u = __float_as_uint(x);
     u += 0x7fffu + ((u >> 16) & 1u);
@@ -553,10 +749,29 @@ static int launch_bf3(ConvArgs& a, hipStream_t st) {
 // global memory, narrow / small tiles (where all four waves would fetch the same fragments) stage planar weights in LDS.
 bool viai_bf3_frag_layout(long M, int n_out) { return viai_igemm_tile_m(M, n_out) == 128 && n_out > 64; }
 
+// The split-K kernel takes the layers whose 64 x 64 tiling would leave most CUs idle.
+bool viai_bf3_sk_ok(long M, int n_out, int C1, int C2) {
+    if ((C1 + C2) % 16 != 0 || (C2 > 0 && C1 % 64 != 0)) return false;
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("VIAI_BF3_SK"); mode = e ? atoi(e) : 1; }
+    if (!mode) return false;
+    long b64 = ((M + 63) / 64) * ((n_out + 63) / 64);
+    return n_out > 32 && b64 < 512;
+}
+
+static int launch_bf3_sk(ConvArgs& a, hipStream_t st) {
+    a.nblk_m = (a.M + 31) / 32;
+    a.nblk_n = (a.Cout + 31) / 32;
+    constexpr int lds = 2 * 3 * 32 * (64 * 2 + 16);
+    VIAI_LAUNCH(conv_igemm_bf3_sk_kernel, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
+    return viai_launch_status();
+}
+
 int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
     const int Cin = a.C1 + a.C2;
     if (Cin % 16 != 0 || (a.C2 > 0 && a.C1 % 32 != 0)) return (int)hipErrorInvalidValue;
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
+    if (a.sk) return launch_bf3_sk(a, st);
     const int bm = viai_igemm_tile_m(a.M, a.Cout);           // same tile rule as the fp32 kernels (BN partial geometry)
     if (a.wfrag) return launch_bf3<true, 2, 2, 2, 2>(a, st);
     if (bm == 64) return launch_bf3<false, 1, 1, 2, 2>(a, st);

@@ -38,11 +38,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
     const int wmn = wave % (WM * WN);
     const int wm = wmn / WN, wn = wmn % WN;
 
-    int b = blockIdx.x;
+    // 1-D grid, XCD-aware: consecutive logical ids (all taps and channel tiles of one pixel slab) share an XCD's L2,
+    // so the slab of dy / x is fetched into ONE L2 instead of eight
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_slab = a.nblk_ci * a.nblk_co * a.g.ntaps;
+    const int z = b / per_slab; b -= z * per_slab;
     const int bci = b % a.nblk_ci; b /= a.nblk_ci;
     const int bco = b % a.nblk_co; b /= a.nblk_co;
     const int t = b;                        // tap index of this block
-    const int z = blockIdx.y;
     const int co0 = bco * BM, ci0 = bci * BN;
     const int Cin = a.C1 + a.C2;
 
@@ -213,7 +216,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    dim3 grid(a.nblk_co * a.nblk_ci * a.g.ntaps, a.ksplit);
+    dim3 grid(a.nblk_co * a.nblk_ci * a.g.ntaps * a.ksplit);
     VIAI_LAUNCH((wgrad_mfma_kernel<TM, TN, WM, WN>), grid, dim3(256), lds, st, a);
     return viai_launch_status();
 }

@@ -35,11 +35,14 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    int b = blockIdx.x;
+    // 1-D grid, XCD-aware: consecutive logical ids (all taps and channel tiles of one pixel slab) share an XCD's L2,
+    // so the slab of dy / x is fetched into ONE L2 instead of eight
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_slab = a.nblk_ci * a.nblk_co * a.g.ntaps;
+    const int z = b / per_slab; b -= z * per_slab;
     const int bci = b % a.nblk_ci; b /= a.nblk_ci;
     const int bco = b % a.nblk_co; b /= a.nblk_co;
     const int t = b;
-    const int z = blockIdx.y;
     const int co0 = bco * BM, ci0 = bci * BN;
     const int Cin = a.C1 + a.C2;
 
@@ -204,7 +207,7 @@ int launch_wgrad_bf3(WgradArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf3_kernel<TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    dim3 grid(a.nblk_co * a.nblk_ci * a.g.ntaps, a.ksplit);
+    dim3 grid(a.nblk_co * a.nblk_ci * a.g.ntaps * a.ksplit);
     VIAI_LAUNCH((wgrad_bf3_kernel<TM, TN>), grid, dim3(256), lds, st, a);
     return viai_launch_status();
 }

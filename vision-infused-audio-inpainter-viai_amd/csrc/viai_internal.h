@@ -16,6 +16,7 @@ struct ConvArgs {
     int act;              // fused activation (only when stat == null)
     float slope;
     int wfrag;            // bf16x3 only: 1 = weights packed fragment-major (viai_bf3_frag_layout)
+    int sk;               // bf16x3 only: 1 = 32x32-tile kernel whose four waves split K (viai_bf3_sk_ok)
     ConvGeom g;
 };
 
@@ -35,6 +36,7 @@ int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st);
 size_t viai_bf3_packed_floats(int n_out, int k_in, int taps);
 int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, int frag, hipStream_t st);
 bool viai_bf3_frag_layout(long M, int n_out);
+bool viai_bf3_sk_ok(long M, int n_out, int C1, int C2);
 bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout);
 int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st);
 int viai_wgrad_mfma_launch(WgradArgs& a, int ksplit, hipStream_t st);
