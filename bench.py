@@ -294,7 +294,9 @@ def main():
             "bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAK, 1), "unit": "TFLOP/s",
             "frac": round(ach / PEAK, 4), "traffic": None,
             "peak_note": ("algorithmic fp32 flops against the dense bf16 MFMA peak (2500) / 6 partial products per MAC; "
-                          "the same flops are %.2fx the fp32-MFMA peak (157.3)" % (ach / MFMA_F32_PEAK_TFLOPS)) if BF3
+                          "the same flops are %.2fx the fp32-MFMA peak (157.3); with random operands the pipes sustain 1810 "
+                          "(profiles/r01_e_mfma_probe.txt), i.e. %.2f of the sustained bf16x3 ceiling"
+                          % (ach / MFMA_F32_PEAK_TFLOPS, ach / (1810.0 / 6.0))) if BF3
                          else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
             "kernel": DOMINANT, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),

@@ -7,11 +7,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int NACC>
-__global__ __launch_bounds__(256) void probe(float* out, int iters) {
+__global__ __launch_bounds__(256) void probe(float* out, int iters, int dense) {
     f32x16 acc[NACC];
     for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     bf16x8 a, b;
-    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(threadIdx.x & 3); b[e] = (__bf16)1.0f; }
+    // operands: dense=0 -> small constants (few toggling bits), dense=1 -> pseudo-random full-mantissa values
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    for (int e = 0; e < 8; ++e) {
+        h = h * 1664525u + 1013904223u;
+        float ra = dense ? ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) : (float)(threadIdx.x & 3);
+        h = h * 1664525u + 1013904223u;
+        float rb = dense ? ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * 0.01f : 1.0f;
+        a[e] = (__bf16)ra; b[e] = (__bf16)rb;
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < 8; ++r)
@@ -24,23 +32,23 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters) {
 }
 
 template <int NACC>
-void run(const char* name, int blocks_per_cu) {
+void run(const char* name, int blocks_per_cu, int dense = 0) {
     const int iters = 4000, blocks = 256 * blocks_per_cu;
     float* out; hipMalloc(&out, (size_t)blocks * 256 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    probe<NACC><<<blocks, 256>>>(out, 10);
+    probe<NACC><<<blocks, 256>>>(out, 10, dense);
     hipDeviceSynchronize();
     float best = 1e30f, worst = 0.f;
     for (int rep = 0; rep < 8; ++rep) {
         hipEventRecord(e0);
-        probe<NACC><<<blocks, 256>>>(out, iters);
+        probe<NACC><<<blocks, 256>>>(out, iters, dense);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
         if (ms > worst) worst = ms;
     }
     double flops = (double)blocks * 4 * iters * 8 * NACC * 32768.0;
-    printf("%s: %d blocks/CU, %d chains/wave: best %.1f TFLOP/s, sustained (slowest of 8) %.1f TFLOP/s\n", name, blocks_per_cu, NACC,
+    printf("%s (%s operands): %d blocks/CU, %d chains/wave: best %.1f TFLOP/s, sustained (slowest of 8) %.1f TFLOP/s\n", name, dense ? "random" : "constant", blocks_per_cu, NACC,
            flops / (best * 1e-3) * 1e-12, flops / (worst * 1e-3) * 1e-12);
     hipFree(out);
 }
@@ -53,5 +61,8 @@ int main() {
     run<2>("bf16 32x32x16", 2);
     run<1>("bf16 32x32x16", 2);
     run<1>("bf16 32x32x16", 4);
+    run<4>("bf16 32x32x16", 2, 1);
+    run<4>("bf16 32x32x16", 2, 1);
+    run<1>("bf16 32x32x16", 4, 1);
     return 0;
 }
