@@ -311,15 +311,17 @@ def main():
         }
         # memory-side traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
         # number comes from the committed counter summary of the same kernel on its largest layer (D.conv3)
-        pmc = os.path.join(ROOT, "profiles", "r01_d_pmc_dconv3.json")
-        if BF3 and os.path.exists(pmc):
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dconv3.json")))
+        pmc = cands[-1] if cands else ""
+        if BF3 and pmc:
             for k, v in json.load(open(pmc)).items():
                 if "conv_igemm_bf3_frag_kernel" in k and "hbm_bytes" in v:
                     out["roofline"]["traffic"] = round(v["hbm_bytes"])
                     out["roofline"]["traffic_note"] = (
                         "bytes per launch on D.conv3 (fwd/dgrad average; algorithmic 57 MB in + 50 MB out): 2*FETCH_SIZE + WRITE_SIZE from "
-                        "profiles/r01_d_pmc_dconv3.json (tools/profile_layer.py under rocprofv3 --pmc); these L2 memory-side "
-                        "counters include Infinity-Cache hits, i.e. they are L2-miss traffic, an upper bound on HBM bytes")
+                        "profiles/%s (tools/profile_layer.py under rocprofv3 --pmc); these L2 memory-side "
+                        "counters include Infinity-Cache hits, i.e. they are L2-miss traffic, an upper bound on HBM bytes") % os.path.basename(pmc)
         del m2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
