@@ -333,15 +333,46 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// out[c] (+)= sum_p x[p][c]; one block per channel-group sweep
+// out[c] (+)= sum_p x[p][c]: per-block partial sums over a row range.  C % 4 == 0: float4 loads, 256 threads =
+// channel quads x pixel lanes, four rows in flight per lane (HBM-bound streaming reduce); otherwise a scalar sweep.
 __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, float* __restrict__ part,
                                                           long M, int C, long rows_per_blk) {
-    __shared__ float red[256];
+    __shared__ f32x4 red4[256];
     const int tid = threadIdx.x;
     const long r0 = blockIdx.x * rows_per_blk;
     long r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
+    if ((C & 3) == 0) {
+        const int CG = C / 4;
+        for (int g0 = 0; g0 < CG; g0 += 256) {
+            const int cgw = min(256, CG - g0);
+            const int pg = 256 / cgw;
+            const int cg = tid % cgw, pl = tid / cgw;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (pl < pg) {
+                const float* col = x + (size_t)(g0 + cg) * 4;
+                for (long r = r0 + pl; r < r1; r += 4L * pg) {
+                    f32x4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        long rr = r + (long)u * pg;
+                        v[u] = rr < r1 ? *reinterpret_cast<const f32x4*>(col + rr * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    s += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+            }
+            red4[tid] = s;
+            __syncthreads();
+            if (tid < cgw) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < pg; ++k) t += red4[k * cgw + tid];
+                *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + (size_t)(g0 + tid) * 4) = t;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    float* red = reinterpret_cast<float*>(red4);
     for (int c0 = 0; c0 < C; c0 += 256) {
-        // thread layout: tid -> (row lane, channel) so that consecutive tids read consecutive channels
         int cw = min(256, C - c0);
         int rl = 256 / cw;                // row lanes
         int c = tid % cw, rr = tid / cw;
@@ -359,12 +390,20 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
     }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C, int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// fixed-order fp64 sum of the block partials: 16 channels x 16 partial lanes per block
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C, int accumulate) {
+    __shared__ double red[16][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * C + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+    if (c < C)
+        for (int b = pl; b < nblk; b += 16) s += (double)part[(size_t)b * C + c];
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int k = 1; k < 16; ++k) s += red[k][cl];
+        out[c] = accumulate ? out[c] + (float)s : (float)s;
+    }
 }
 
 DirectArgs make_args(const viai_conv2d* c) {
@@ -533,9 +572,12 @@ int viai_cout1_wgrad(const viai_conv2d* c, const float* x, const float* dy, floa
 }
 
 extern "C" int viai_colsum_blocks(long M, int C) {
-    (void)C;
-    long b = (M + 2047) / 2048;
-    if (b > 1024) b = 1024;
+    // ~2048 row blocks for large tensors, never fewer rows than one unrolled pass of the reduce covers
+    long rows_min = 4096 / (C > 0 ? C : 1);
+    if (rows_min < 4) rows_min = 4;
+    long rows = (M + 2047) / 2048;
+    if (rows < rows_min) rows = rows_min;
+    long b = (M + rows - 1) / rows;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -544,6 +586,6 @@ extern "C" int viai_colsum(const float* x, long M, int C, float* part, float* ou
     int nb = viai_colsum_blocks(M, C);
     long rpb = (M + nb - 1) / nb;
     VIAI_LAUNCH(colsum_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, part, M, C, rpb);
-    VIAI_LAUNCH(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, out, nb, C, accumulate);
+    VIAI_LAUNCH(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, out, nb, C, accumulate);
     return viai_launch_status();
 }
