@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 2
+#define VIAI_ABI_VERSION 3
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -205,6 +205,8 @@ typedef struct viai_wn_layer {
     const float *w_conv, *b_conv, *w_c, *b_c, *w_out, *b_out, *w_skip, *b_skip;
     float* ring;
     int dilation, ring_len;
+    const float* g_add;     /* optional [B][G]: the time-invariant gate contribution of global conditioning,
+                               conv1x1g(embed_speakers(g)) + bias (modules.py:195-199); NULL without it (ABI v3) */
 } viai_wn_layer;
 typedef struct viai_wn_synth {
     int B, C, G, S, cin, n_layers, out_ch, T, n_test;

@@ -29,6 +29,14 @@ class WNConfig:
     cin_channels = 80
     upsample_scales = (4, 4)
     freq_axis_kernel_size = 3
+    gin_channels = -1           # > 0: global (speaker) conditioning through an embedding of n_speakers rows
+    n_speakers = None
+
+
+class WNConfigG(WNConfig):
+    """the small configuration with global conditioning (wavenet.py:146-151, modules.py:140-145)."""
+    gin_channels = 8
+    n_speakers = 3
 
 
 def wavenet_state(cfg=WNConfig, tag="WN."):
@@ -45,10 +53,14 @@ def wavenet_state(cfg=WNConfig, tag="WN."):
         p = "conv_layers.%d." % i
         conv(p + "conv", cfg.gate_channels, cfg.residual_channels, cfg.kernel_size)
         conv(p + "conv1x1c", cfg.gate_channels, cfg.cin_channels, 1)
+        if cfg.gin_channels > 0:
+            conv(p + "conv1x1g", cfg.gate_channels, cfg.gin_channels, 1)
         conv(p + "conv1x1_out", cfg.residual_channels, cfg.gate_channels // 2, 1)
         conv(p + "conv1x1_skip", cfg.skip_out_channels, cfg.gate_channels // 2, 1)
     conv("last_conv_layers.1", cfg.skip_out_channels, cfg.skip_out_channels, 1)
     conv("last_conv_layers.3", cfg.out_channels, cfg.skip_out_channels, 1)
+    if cfg.gin_channels > 0:
+        sd["embed_speakers.weight"] = cf_std(tag + "embed", (cfg.n_speakers, cfg.gin_channels), 0.1)
     for j, s in enumerate(cfg.upsample_scales):
         n = "upsample_conv.%d" % (2 * j)
         v = cf_uniform(tag + n + ".v", (1, 1, cfg.freq_axis_kernel_size, s), 0.1, 0.5)
@@ -65,10 +77,14 @@ def wn_weight(sd, name):
     return v * (g / n)
 
 
-def wavenet_forward(sd, x, c, cfg=WNConfig):
-    """WaveNet.forward, scalar input, local conditioning with up-sampling, eval-mode dropout
-    (wavenet.py:177-235; ResidualConv1dGLU._forward modules.py:162-210)."""
+def wavenet_forward(sd, x, c, cfg=WNConfig, g=None):
+    """WaveNet.forward, scalar input, local conditioning with up-sampling, optional global conditioning by speaker id
+    g (B,) or (B, 1), eval-mode dropout (wavenet.py:177-235; ResidualConv1dGLU._forward modules.py:162-210)."""
     B, _, T = x.shape
+    g_bct = None
+    if g is not None:                                                        # wavenet.py:198-206
+        e = F.embedding(g.view(B, -1), sd["embed_speakers.weight"]).transpose(1, 2)      # (B, gin, 1)
+        g_bct = e.expand(B, -1, T)
     c = c.unsqueeze(1)                                                       # :210
     for j, s in enumerate(cfg.upsample_scales):                              # :211-212
         n = "upsample_conv.%d" % (2 * j)
@@ -86,6 +102,10 @@ def wavenet_forward(sd, x, c, cfg=WNConfig):
         a, b = y.split(y.shape[1] // 2, dim=1)
         yc = F.conv1d(c, wn_weight(sd, p + "conv1x1c"), sd[p + "conv1x1c.bias"])
         ca, cb = yc.split(yc.shape[1] // 2, dim=1)
+        if g_bct is not None:                                                # modules.py:195-199
+            yg = F.conv1d(g_bct, wn_weight(sd, p + "conv1x1g"), sd[p + "conv1x1g.bias"])
+            ga, gb = yg.split(yg.shape[1] // 2, dim=1)
+            ca, cb = ca + ga, cb + gb
         z = torch.tanh(a + ca) * torch.sigmoid(b + cb)                       # :201
         s = F.conv1d(z, wn_weight(sd, p + "conv1x1_skip"), sd[p + "conv1x1_skip.bias"])
         o = F.conv1d(z, wn_weight(sd, p + "conv1x1_out"), sd[p + "conv1x1_out.bias"])
@@ -143,7 +163,7 @@ def mol_sample(y, u1, u2, log_scale_min=-7.0):
     return torch.clamp(x, -1., 1.)
 
 
-def incremental_forward(sd, c, T, u1, u2, cfg=WNConfig, test_inputs=None, log_scale_min=-7.0):
+def incremental_forward(sd, c, T, u1, u2, cfg=WNConfig, test_inputs=None, log_scale_min=-7.0, g=None):
     """WaveNet.incremental_forward (wavenet.py:237-364) by definition of causality: sample t depends only on
     samples < t, so it equals running the batch forward on the growing prefix (O(T^2); tiny T only)."""
     B = c.shape[0]
@@ -156,6 +176,6 @@ def incremental_forward(sd, c, T, u1, u2, cfg=WNConfig, test_inputs=None, log_sc
         elif t > 0:
             cur = out[:, 0, t - 1]
         x[:, 0, t] = cur
-        y = wavenet_forward(sd, x, c, cfg)[:, :, t:t + 1]
+        y = wavenet_forward(sd, x, c, cfg, g)[:, :, t:t + 1]
         out[:, 0, t] = mol_sample(y, u1[:, t:t + 1], u2[:, t:t + 1], log_scale_min)[:, 0]
     return out

@@ -1,6 +1,7 @@
 """GPU parity of the WaveNet vocoder path (teacher-forced forward/backward, MoL loss + sampler, incremental
 synthesis) against the oracle and the goldens produced by the reference's wavenet_vocoder package."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -121,3 +122,39 @@ def test_incremental_equals_batch_forward_under_teacher_forcing():
     yh_shift = net(xin.cuda(), c.cuda())
     _, logits = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=xin.cuda(), log_scale_min=-7.0, use_graph=True, return_logits=True)
     assert relerr(logits.transpose(1, 2), yh_shift) < 1e-4
+
+
+@pytest.mark.gpu
+def test_global_conditioning_matches_reference_golden(golden_dir):
+    """speaker-id global conditioning (wavenet.py:198-206,284-290; modules.py:140-145,195-199): teacher-forced
+    forward and incremental synthesis against the reference's outputs (tests/golden/wavenet_g.npz)."""
+    from viai_amd.wavenet import WaveNet
+    cfg = W.WNConfigG
+    gold = np.load(os.path.join(golden_dir, "wavenet_g.npz"))
+    net = WaveNet(out_channels=cfg.out_channels, layers=cfg.layers, stacks=cfg.stacks, residual_channels=cfg.residual_channels,
+                  gate_channels=cfg.gate_channels, skip_out_channels=cfg.skip_out_channels, kernel_size=cfg.kernel_size, dropout=0.0,
+                  cin_channels=cfg.cin_channels, gin_channels=cfg.gin_channels, n_speakers=cfg.n_speakers,
+                  upsample_scales=list(cfg.upsample_scales), freq_axis_kernel_size=cfg.freq_axis_kernel_size)
+    sd = W.wavenet_state(cfg)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    B, T = 2, 48
+    x = O.cf_uniform("wng.x", (B, 1, T), -1, 1).cuda()
+    c = O.cf_uniform("wng.c", (B, cfg.cin_channels, T // 16), 0, 1).cuda()
+    g = torch.tensor([[2], [0]], dtype=torch.long).cuda()
+    with torch.no_grad():
+        yh = net(x, c, g)
+    assert relerr(yh.cpu(), torch.from_numpy(gold["yhat"])) < 1e-4
+    Tg = 32
+    cg = O.cf_uniform("wng.cg", (B, cfg.cin_channels, Tg // 16), 0, 1).cuda()
+    v1 = O.cf_uniform("wng.v1", (B, Tg, 10), 1e-5, 1 - 1e-5)
+    v2 = O.cf_uniform("wng.v2", (B, Tg), 1e-5, 1 - 1e-5)
+    tin = O.cf_uniform("wng.tin", (B, 1, 3), -1, 1)
+    for use_graph in (False, True):
+        gen = net.incremental_forward(None, c=cg, g=g, T=Tg, test_inputs=tin, uniforms=(v1, v2), use_graph=use_graph, log_scale_min=-7.0)
+        assert tuple(gen.shape) == (B, 1, Tg)
+        assert relerr(gen.cpu(), torch.from_numpy(gold["gen"])) < 2e-3, relerr(gen.cpu(), torch.from_numpy(gold["gen"]))
+    # and the speaker matters
+    gen2 = net.incremental_forward(None, c=cg, g=torch.tensor([[1], [1]]).cuda(), T=Tg, test_inputs=tin, uniforms=(v1, v2), log_scale_min=-7.0)
+    assert relerr(gen2.cpu(), torch.from_numpy(gold["gen"])) > 1e-2

@@ -363,6 +363,55 @@ def wavenet_goldens():
     print("wavenet -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def wavenet_g_goldens():
+    """WaveNet with global (speaker) conditioning: teacher-forced forward and incremental_forward from the reference."""
+    import Config  # noqa: F401
+    from oracle import wavenet_oracle as W
+    cfg = W.WNConfigG
+    from wavenet_vocoder import wavenet as RW
+    net = RW.WaveNet(out_channels=cfg.out_channels, layers=cfg.layers, stacks=cfg.stacks, residual_channels=cfg.residual_channels,
+                     gate_channels=cfg.gate_channels, skip_out_channels=cfg.skip_out_channels, kernel_size=cfg.kernel_size, dropout=0.0,
+                     cin_channels=cfg.cin_channels, gin_channels=cfg.gin_channels, n_speakers=cfg.n_speakers, weight_normalization=True,
+                     upsample_conditional_features=True, upsample_scales=list(cfg.upsample_scales),
+                     freq_axis_kernel_size=cfg.freq_axis_kernel_size, scalar_input=True)
+    sd = W.wavenet_state(cfg)
+    assert list(net.state_dict().keys()) == list(sd.keys()), set(net.state_dict()) ^ set(sd)
+    load_into(net, sd)
+    net.eval()
+    out = OrderedDict()
+    B, T = 2, 48
+    x = O.cf_uniform("wng.x", (B, 1, T), -1, 1)
+    c = O.cf_uniform("wng.c", (B, cfg.cin_channels, T // 16), 0, 1)
+    g = torch.tensor([[2], [0]], dtype=torch.long)
+    with torch.no_grad():
+        yh = net(x, c, g)
+    assert relerr(W.wavenet_forward(sd, x, c, cfg, g), yh) < 1e-5
+    out["yhat"] = yh.numpy()
+    Tg = 32
+    cg = O.cf_uniform("wng.cg", (B, cfg.cin_channels, Tg // 16), 0, 1)
+    v1 = O.cf_uniform("wng.v1", (B, Tg, 10), 1e-5, 1 - 1e-5)
+    v2 = O.cf_uniform("wng.v2", (B, Tg), 1e-5, 1 - 1e-5)
+    tin = O.cf_uniform("wng.tin", (B, 1, 3), -1, 1)
+    seq = []
+    for t in range(Tg):
+        seq += [v1[:, t:t + 1, :].reshape(B, 1, 10), v2[:, t:t + 1].reshape(B, 1)]
+    orig = torch.Tensor.uniform_
+    torch.Tensor.uniform_ = lambda self, a=0, b=1: self.copy_(seq.pop(0).reshape(self.shape))
+    try:
+        with torch.no_grad():
+            # B comes from test_inputs in the reference (wavenet.py:264-275): teacher-force the first 3 samples
+            gen = net.incremental_forward(initial_input=None, c=cg, g=g, T=Tg, test_inputs=tin, tqdm=lambda z: z, softmax=False,
+                                          quantize=False, log_scale_min=-7.0)
+    finally:
+        torch.Tensor.uniform_ = orig
+    ogen = W.incremental_forward(sd, cg, Tg, v1, v2, cfg, test_inputs=tin, g=g)
+    assert tuple(gen.shape) == (B, 1, Tg) and relerr(ogen, gen) < 1e-4, relerr(ogen, gen)
+    out["gen"] = gen.numpy()
+    path = os.path.join(OUT, "wavenet_g.npz")
+    np.savez_compressed(path, **out)
+    print("wavenet_g -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def adam_goldens():
     """torch.optim.Adam known-answer vectors (what the missing AudioModel's
     optimizer_G/optimizer_D are, utils/util.py:149-150)."""
@@ -471,6 +520,9 @@ if __name__ == "__main__":
     if "--pipeline-only" in sys.argv:
         pipeline_goldens()
         sys.exit(0)
+    if "--wavenet-g-only" in sys.argv:
+        wavenet_g_goldens()
+        sys.exit(0)
     torch.set_num_threads(os.cpu_count())
     layer_goldens()
     pipeline_goldens()
@@ -478,6 +530,7 @@ if __name__ == "__main__":
     av_goldens()
     resnet_goldens()
     wavenet_goldens()
+    wavenet_g_goldens()
     run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
     run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]
     if "--cfg2" in sys.argv:

@@ -29,7 +29,7 @@ class Conv2dDesc(C.Structure):
 class WnLayer(C.Structure):
     """mirror of `viai_wn_layer`."""
     _fields_ = [(n, C.c_void_p) for n in ("w_conv", "b_conv", "w_c", "b_c", "w_out", "b_out", "w_skip", "b_skip", "ring")] + \
-               [("dilation", C.c_int), ("ring_len", C.c_int)]
+               [("dilation", C.c_int), ("ring_len", C.c_int), ("g_add", C.c_void_p)]
 
 
 class WnSynth(C.Structure):
@@ -149,7 +149,7 @@ def load() -> C.CDLL:
             raise ViaiLibraryError("libviai_hip.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.viai_abi_version() != 2:
+    if lib.viai_abi_version() != 3:
         raise ViaiLibraryError("libviai_hip.so ABI version mismatch")
     _lib = lib
     return lib

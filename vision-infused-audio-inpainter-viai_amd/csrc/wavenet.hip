@@ -485,8 +485,8 @@ __global__ __launch_bounds__(256) void wn_first_kernel(const float* __restrict__
 template <int NB>
 __global__ __launch_bounds__(256) void wn_gate_kernel(const float* __restrict__ ring, int ring_len, int dil, const float* __restrict__ wlin,
                                                       const float* __restrict__ bconv, const float* __restrict__ wc, const float* __restrict__ bc,
-                                                      const float* __restrict__ cond, float* __restrict__ z, const int* __restrict__ step,
-                                                      int C, int H, int cin, int T) {
+                                                      const float* __restrict__ cond, const float* __restrict__ gadd, float* __restrict__ z,
+                                                      const int* __restrict__ step, int C, int H, int cin, int T) {
     const int t = *step;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (h >= H) return;
@@ -524,6 +524,7 @@ __global__ __launch_bounds__(256) void wn_gate_kernel(const float* __restrict__ 
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         float sa = wave_sum(a[b]) + ba, sg = wave_sum(g[b]) + bg;
+        if (gadd != nullptr) { sa += gadd[(size_t)b * 2 * H + h]; sg += gadd[(size_t)b * 2 * H + h + H]; }
         if (lane == 0) z[(size_t)b * H + h] = tanhf(sa) * (1.f / (1.f + expf(-sg)));
     }
 }
@@ -612,7 +613,7 @@ int wn_step_impl(const viai_wn_synth* s, hipStream_t st) {
                 L[0].ring, L[0].ring_len, s->step, s->B, C, s->T);
     for (int l = 0; l < s->n_layers; ++l) {
         VIAI_LAUNCH(wn_gate_kernel<NB>, dim3((H + 3) / 4), dim3(256), 0, st, L[l].ring, L[l].ring_len, L[l].dilation, L[l].w_conv, L[l].b_conv,
-                    L[l].w_c, L[l].b_c, s->cond, s->z, s->step, C, H, s->cin, s->T);
+                    L[l].w_c, L[l].b_c, s->cond, L[l].g_add, s->z, s->step, C, H, s->cin, s->T);
         const bool last = (l == s->n_layers - 1);
         VIAI_LAUNCH(wn_out_kernel<NB>, dim3((C + S + 3) / 4), dim3(256), 0, st, s->z, L[l].w_out, L[l].b_out, L[l].w_skip, L[l].b_skip,
                     L[l].ring, L[l].ring_len, last ? (float*)nullptr : L[l + 1].ring, last ? 1 : L[l + 1].ring_len, s->skips, l == 0 ? 1 : 0,

@@ -397,8 +397,6 @@ class WaveNet(nn.Module):
         lib = _lib.load()
         if not self.scalar_input:
             raise NotImplementedError("incremental_forward: scalar-input (mixture of logistics) WaveNet only")
-        if g is not None:
-            raise NotImplementedError("incremental_forward: global conditioning is not built yet")
         dev = self.first_conv.bias.device
         if test_inputs is not None:
             if test_inputs.size(1) == 1:
@@ -422,6 +420,10 @@ class WaveNet(nn.Module):
             u2 = torch.empty(B, T, device=dev).uniform_(1e-5, 1.0 - 1e-5)
         else:
             u1, u2 = uniforms[0].to(dev).float().contiguous(), uniforms[1].to(dev).float().contiguous()
+        g_vec = None
+        if g is not None:                                                            # wavenet.py:284-290: time-invariant
+            g = g.to(dev)
+            g_vec = (self.embed_speakers(g.view(B, -1)).transpose(1, 2) if self.embed_speakers is not None else g.float().view(B, -1, 1)).contiguous()
         Cc = self.first_conv.bias.numel()
         f0 = self.conv_layers[0]
         G, S = f0.conv.bias.numel(), f0.conv1x1_skip.bias.numel()
@@ -444,6 +446,10 @@ class WaveNet(nn.Module):
             L.w_out, L.b_out = t(normed_weight(f.conv1x1_out).reshape(Cc, -1)), t(f.conv1x1_out.bias)
             L.w_skip, L.b_skip = t(normed_weight(f.conv1x1_skip).reshape(S, -1)), t(f.conv1x1_skip.bias)
             L.ring, L.dilation, L.ring_len = ring.data_ptr(), d, 2 * d + 1
+            # global conditioning adds conv1x1g(g) + bias to the gate pre-activation at every step (modules.py:195-199):
+            # computed once per layer by the HIP 1x1 conv and handed to the step kernel as a per-stream constant
+            L.g_add = (t(conv1d_apply(g_vec.transpose(1, 2).reshape(B, 1, 1, -1).contiguous(), f.conv1x1g).reshape(B, G))
+                       if (g_vec is not None and f.conv1x1g is not None) else None)
         out = torch.zeros(B, T, device=dev)
         logits = torch.zeros(B, T, self.out_channels, device=dev) if return_logits else None
         z = torch.zeros(B, G // 2, device=dev)
