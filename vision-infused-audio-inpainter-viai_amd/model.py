@@ -179,6 +179,11 @@ class AudioModel:
         self.losses = torch.zeros(5, device=self.device)      # loss_D, loss_G, loss_G_GAN, loss_L1, loss_D_real
         self.mel = self.mask = self.fake = None
         self.use_graph = bool(use_graph)
+        # weight gradients trail on a side stream (ops.WGRAD_STREAM) in eager mode: -3.5 % step time on one MI355X.  Inside
+        # a captured hipGraph the fork/join edges cost more than the overlap returns (+2 %), so graph mode stays on one
+        # stream.  VIAI_WGRAD_STREAM=0/1 overrides.
+        side = os.environ.get("VIAI_WGRAD_STREAM", "0" if self.use_graph else "1") != "0"
+        self._wgrad_stream = torch.cuda.Stream(device=self.device) if side else None
         self._graphs = None
 
     # ------------------------------------------------------------------ setup
@@ -286,6 +291,7 @@ class AudioModel:
         loss_fake, loss_real = self._gan(pred_fake, False), self._gan(pred_real, True)
         loss_d = 0.5 * (loss_fake + loss_real)
         loss_d.backward()
+        ops.join_wgrad()
         self.losses[0].copy_(loss_d.detach())
         self.losses[4].copy_(loss_real.detach())
 
@@ -303,6 +309,7 @@ class AudioModel:
             loss_g = loss_g + self.cfg.lambda_contrast * self._lc
             self.EmbeddingL2 = self._lc.detach()
         loss_g.backward()
+        ops.join_wgrad()
         self.netD.requires_grad_(True)
         self.losses[1].copy_(loss_g.detach())
         self.losses[2].copy_(loss_gan.detach())
@@ -341,10 +348,11 @@ class AudioModel:
     def optimize_parameters(self, global_step=0):
         """one G+D train step (train_whole_sync.py:76)."""
         prev, ops.DIRECT_GRAD = ops.DIRECT_GRAD, True      # gradients land in the arenas in place
+        prev_s, ops.WGRAD_STREAM = ops.WGRAD_STREAM, self._wgrad_stream
         try:
             self._optimize_parameters()
         finally:
-            ops.DIRECT_GRAD = prev
+            ops.DIRECT_GRAD, ops.WGRAD_STREAM = prev, prev_s
 
     def _optimize_parameters(self):
         if self.use_graph:
@@ -366,11 +374,12 @@ class AudioModel:
     def forward_backward_no_update(self):
         """the step WITHOUT the two Adam updates (parity target, see oracle.step_no_update)."""
         prev, ops.DIRECT_GRAD = ops.DIRECT_GRAD, True
+        prev_s, ops.WGRAD_STREAM = ops.WGRAD_STREAM, self._wgrad_stream
         try:
             self._seg_forward_dstep()
             self._seg_dupdate_gstep(update=False)
         finally:
-            ops.DIRECT_GRAD = prev
+            ops.DIRECT_GRAD, ops.WGRAD_STREAM = prev, prev_s
 
     def test(self):
         """forward only (train_whole_sync.py:79-80; caller wraps in no_grad)."""

@@ -26,6 +26,20 @@ BN_EPS = 1e-5
 # (accumulate mode) and autograd gets None for it: no per-parameter torch add launches.
 DIRECT_GRAD = False
 
+# Weight gradients on a side stream (set by model.AudioModel together with DIRECT_GRAD): the wgrad of a layer only
+# feeds the optimizer, so it is launched on WGRAD_STREAM behind an event and overlaps the rest of the backward chain
+# (the HBM-bound BatchNorm-backward kernels leave the matrix pipes idle; the MFMA-bound wgrad fills them).  The
+# operands are kept alive in _deferred until join_wgrad() makes the main stream wait for the side stream.
+WGRAD_STREAM = None
+_deferred = []
+
+
+def join_wgrad():
+    """main stream waits for every deferred weight-gradient launch; call before the gradients are consumed."""
+    if WGRAD_STREAM is not None and _deferred:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+    _deferred.clear()
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -190,7 +204,18 @@ class _ConvBnAct(torch.autograd.Function):
                 else:
                     db = torch.empty(Cout, device=dev, dtype=torch.float32)
             want_db = db is not None and not shadowed
-            if acc_w == acc_b or not want_db:
+            if WGRAD_STREAM is not None and acc_w and (acc_b or not want_db):
+                # in-place accumulation into the arenas: nothing flows back through autograd, so the launch can trail
+                ev = torch.cuda.Event()
+                ev.record()
+                WGRAD_STREAM.wait_event(ev)
+                with torch.cuda.stream(WGRAD_STREAM):
+                    ws = torch.empty(d["ws_floats"], device=dev, dtype=torch.float32)
+                    _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                     dw.data_ptr(), db.data_ptr() if want_db else 0, 1, WGRAD_STREAM.cuda_stream),
+                               "viai_conv2d_wgrad")
+                _deferred.append((x, x2, dy, ws, weight))
+            elif acc_w == acc_b or not want_db:
                 _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
                                                  dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0, st),
                            "viai_conv2d_wgrad")
