@@ -132,6 +132,9 @@ class KernelTimer:
                 return "direct", 1
             if halo_ok(d.Cout, 0, cin, d, d.IH, d.IW):
                 return "halo", 1
+            if (BF3 and not d.transposed and (d.kh, d.kw, d.sh, d.sw, d.ph, d.pw) == (3, 3, 2, 2, 1, 1) and d.IH % 2 == 0 and d.IW % 2 == 0
+                    and d.Cout % 32 == 0 and cin % 64 == 0 and -(-(d.N * (d.IH // 2) * (d.IW // 2)) // 128) * (cin // 64) >= 256):
+                return "dgrad_s2", 1                 # mirror of viai_dgrad_s2_ok (csrc/conv_dgrad_s2_bf3.hip)
             ncls = d.sh * d.sw                        # one launch per output parity class
             return igemm_name(-(-(d.N * d.IH * d.IW) // ncls), cin), ncls
 
@@ -305,7 +308,7 @@ def main():
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream around each call, %d instrumented eager steps after the timed region" % nprof,
             "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<2,2,2,2>; igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel (small-M layers, waves split K); "
-                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo = conv_halo_bf3_kernel<*> (32/64-channel stride-1 layers); wgrad_bf3 = wgrad_bf3_kernel<*>; "
+                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo = conv_halo_bf3_kernel<*> (32/64-channel stride-1 layers); dgrad_s2 = conv_dgrad_s2_bf3_kernel (3x3 stride-2 data gradient, four parity classes fused); wgrad_bf3 = wgrad_bf3_kernel<*>; "
                                    "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers)") if BF3 else
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},

@@ -54,6 +54,9 @@ CONV_CASES = [
     ("halo48out", 1, 16, 16, 32, 48, (3, 3), (1, 1), (1, 1), False, False),
     ("halo1x3", 2, 8, 64, 32, 32, (1, 3), (1, 1), (0, 1), False, False),
     # big enough that the 64x64-tile LDS-weight kernel (not the small-M split-K kernel) takes the layer
+    # fused-class stride-2 dgrad (needs >= 256 tiles of 128 base pixels x 64 channels): two channel blocks / ragged M
+    ("D.conv2_2", 4, 128, 128, 128, 64, (3, 3), (2, 2), (1, 1), False, False),
+    ("s2-ragged-M", 3, 214, 206, 64, 32, (3, 3), (2, 2), (1, 1), False, True),
     ("lds64x64", 4, 64, 64, 64, 128, (3, 3), (1, 1), (1, 1), False, False),
     ("lds64x64-s2T", 2, 128, 64, 128, 96, (3, 3), (1, 1), (1, 1), True, True),
 ]

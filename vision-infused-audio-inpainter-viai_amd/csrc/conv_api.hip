@@ -80,7 +80,8 @@ static bool frag_fwd(const viai_conv2d* c) { return halo_fwd(c) || viai_bf3_frag
 static bool sk_fwd(const viai_conv2d* c) {
     return use_bf3_fwd(c) && !frag_fwd(c) && viai_bf3_sk_ok(bf3_rows_fwd(c), c->Cout, c->C1, c->C2);
 }
-static bool frag_dgrad(const viai_conv2d* c) { return halo_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c)); }
+static bool s2_dgrad(const viai_conv2d* c) { return use_bf3_dgrad(c) && viai_dgrad_s2_ok(c); }     // fused parity classes (conv_dgrad_s2_bf3.hip)
+static bool frag_dgrad(const viai_conv2d* c) { return halo_dgrad(c) || s2_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c)); }
 
 static bool use_bf3_fwd(const viai_conv2d* c) {
     if (kind_of(c) != K_IGEMM) return false;
@@ -309,6 +310,16 @@ extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const fl
         }
     }
     const bool bf3 = use_bf3_dgrad(c);
+    if (s2_dgrad(c)) {                                     // all four parity classes in one launch
+        ConvArgs a{};
+        a.in = dy; a.wp = wp; a.out = dx; a.out2 = dx2;
+        a.C1 = c->Cout; a.C2 = 0; a.Cout = cin_of(c); a.OC1 = c->C1;
+        int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
+        a.g.N = c->N; a.g.IH = oh; a.g.IW = ow; a.g.OH = c->IH; a.g.OW = c->IW;
+        a.M = c->N * (c->IH / 2) * (c->IW / 2);
+        a.wfrag = 1;
+        return viai_conv_dgrad_s2_bf3_launch(a, st);
+    }
     for (int a_ = 0; a_ < c->sh; ++a_)
         for (int b_ = 0; b_ < c->sw; ++b_) {
             ConvArgs a{};

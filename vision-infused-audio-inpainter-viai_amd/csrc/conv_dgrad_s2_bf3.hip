@@ -1,0 +1,199 @@
+// Data gradient of the 3x3 / stride 2 / pad 1 convolutions (D.conv2_1, D.conv2_2, E.conv3-5) with the four output
+// parity classes fused in one block, bf16x3 split MFMA, gfx950.
+//
+// dx(2by+a, 2bx+b) gathers dy at the "base" pixel (by, bx) shifted by (sy, sx) in {0,1}^2:
+//     a = 0: (sy = 0, r = 1)            a = 1: (sy = 1, r = 0), (sy = 0, r = 2)        (same for b / sx / s)
+// so nine (shift, class) pairs carry the nine taps.  Launched one class at a time (conv_igemm_bf3.hip) the short K
+// loops (1, 2, 2, 4 taps) leave the prologue / epilogue and nine separate loads + bf16 splits of the dy tile
+// dominant: 72-97 TFLOP/s.  Here a block owns 128 base pixels x 64 input channels x ALL FOUR classes (8 accumulator
+// tiles per wave): each of the four shifted dy tiles is loaded and split once per K chunk and multiplied into every
+// class that uses it, weights come fragment-major straight from global memory, and the epilogue writes 2 x 2 pixel
+// quads.  Reference call sites: autograd of nn.Conv2d(.., 3, stride=2, padding=1) in Discriminator_Networks.py:23-31
+// and Inpainting_Networks.py:58-63.
+#include "viai_common.h"
+#include "viai_internal.h"
+#include "viai_bf3.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void conv_dgrad_s2_bf3_kernel(const ConvArgs a) {
+    constexpr int BK = BF3_BK, BM = 128, TM = 2, NA = BM / 32;
+    constexpr int APLANE = BM * BF3_PITCH, STAGE = 3 * APLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][3][128][80]
+
+    const ConvGeom& g = a.g;                      // N, IH/IW = dy extent, OH/OW = dx extent
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bn = bid % a.nblk_n, bm = bid / a.nblk_n;
+    const int m0 = bm * BM;
+    const int K = a.C1;                           // dy channels (conv Cout)
+    const int BH = g.OH / 2, BW = g.OW / 2;       // base lattice
+
+    const int q = tid & 7, r0 = tid >> 3;
+    int pbase[NA], by_[NA], bx_[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int m = m0 + r0 + 32 * j;
+        if (m < a.M) {
+            int bx = m % BW; int t = m / BW; int by = t % BH; int n = t / BH;
+            by_[j] = by; bx_[j] = bx;
+            pbase[j] = (n * g.IH + by) * g.IW + bx;
+        } else { by_[j] = 1 << 20; bx_[j] = 1 << 20; pbase[j] = 0; }
+    }
+    constexpr int OOB = 0x7fffffff;
+    const int k16 = K / 16;
+    const int NT = (a.Cout + 31) / 32;
+    const int frag_plane = NT * 9 * k16 * 1024;
+    const int nt = bn * 2 + wn;                                      // this wave's 32-channel tile (of every class)
+    const int bvoff = (nt < NT) ? nt * 9 * k16 * 1024 + lane * 16 : OOB;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((long)g.N * g.IH * g.IW * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 3 * frag_plane, 0x00020000);
+
+    f32x16 acc[4][TM];                            // [class a*2+b][row tile]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][i][e] = 0.f;
+
+    const int kchunks = K / BK;
+    const int nchunks = 4 * kchunks;              // chunk = (shift, 32 channels)
+
+    u32x4 raw[NA];
+    auto gloadA = [&](int chunk_) {
+        const int chunk = __builtin_amdgcn_readfirstlane(chunk_);
+        const bool live = chunk < nchunks;
+        const int sh = live ? chunk / kchunks : 0, c0 = (chunk - sh * kchunks) * BK;
+        const int sy = sh >> 1, sx = sh & 1;
+        const int toff = sy * g.IW + sx;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const bool ok = live && (by_[j] + sy < g.IH) && (bx_[j] + sx < g.IW);
+            raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? ((pbase[j] + toff) * K + c0 + q * 4) * 4 : OOB, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* As = smem_b + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
+            unsigned a1, a2, a3, b1, b2, b3;
+            split3_pair(v[0], v[1], a1, a2, a3);
+            split3_pair(v[2], v[3], b1, b2, b3);
+            const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
+            unsigned char* d = As + (r0 + 32 * j) * BF3_PITCH + q * 8;
+            *reinterpret_cast<u32x2*>(d) = p1;
+            *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+            *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+        }
+    };
+    // weights of (tap, 16-deep k-step kq): three planes of this wave's channel tile
+    auto gloadB = [&](u32x4 (&bf)[3], int tap, int kq) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            bf[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bvoff, (tap * k16 + kq) * 1024 + p * frag_plane, 0);
+    };
+
+    gloadA(0);
+    lstore(0);
+    gloadA(1);
+    __syncthreads();
+
+    const int aoff = (wm * TM * 32 + (lane & 31)) * BF3_PITCH + 16 * (lane >> 5);
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+
+    // one (class, k-step) unit: B fragments were fetched into `bf`; the next unit's are requested before the MFMAs
+    auto mma = [&](f32x16 (&ac)[TM], const bf16x8 (&af)[TM][3], const u32x4 (&bf)[3]) {
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                ac[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]], __builtin_bit_cast(bf16x8, bf[PB[pr]]), ac[i], 0, 0, 0);
+    };
+
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int cur = kc & 1;
+        const int sh = __builtin_amdgcn_readfirstlane(kc / kchunks), c0q = (kc - sh * kchunks) * (BK / 16);
+        const int sy = sh >> 1, sx = sh & 1;
+        const unsigned char* As = smem_b + cur * STAGE + aoff;
+        // classes served by this shift: a in {sy ? 1 : 0, 1}, b likewise; tap row r = (a == 0) ? 1 : (sy ? 0 : 2)
+        const int na = sy ? 1 : 2, nb = sx ? 1 : 2;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 af[TM][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + i * 32 * BF3_PITCH + ks * 32));
+            u32x4 bfA[3], bfB[3];
+            // unit order: (a, b) = (1,1), then (1,0) / (0,1), then (0,0) as far as the shift allows
+            {
+                const int r = sy ? 0 : 2, s = sx ? 0 : 2;
+                gloadB(bfA, r * 3 + s, c0q + ks);                       // class (1,1): every shift
+                if (nb == 2) gloadB(bfB, r * 3 + 1, c0q + ks);          // class (1,0): sx == 0
+                mma(acc[3], af, bfA);
+                if (na == 2) gloadB(bfA, 1 * 3 + s, c0q + ks);          // class (0,1): sy == 0
+                if (nb == 2) mma(acc[2], af, bfB);
+                if (na == 2 && nb == 2) gloadB(bfB, 1 * 3 + 1, c0q + ks);   // class (0,0): shift (0,0) only
+                if (na == 2) mma(acc[1], af, bfA);
+                if (na == 2 && nb == 2) mma(acc[0], af, bfB);
+            }
+        }
+        __syncthreads();
+        lstore(cur ^ 1);
+        gloadA(kc + 2);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue: four classes, 2 x 2 pixel quads
+    const int half = lane >> 5, col = lane & 31;
+    const int co = nt * 32 + col;
+    const int oc2 = a.Cout - a.OC1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int m = m0 + (wm * TM + i) * 32 + row;
+            if (m < a.M && co < a.Cout) {
+                int bx = m % BW; int t = m / BW; int by = t % BH; int n = t / BH;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const size_t opix = ((size_t)n * g.OH + 2 * by + (c >> 1)) * g.OW + 2 * bx + (c & 1);
+                    if (co < a.OC1) a.out[opix * a.OC1 + co] = acc[c][i][e];
+                    else a.out2[opix * oc2 + (co - a.OC1)] = acc[c][i][e];
+                }
+            }
+        }
+}
+
+}  // namespace
+
+// conv: 3x3, stride (2,2), pad 1, no dilation, even input extent; channel counts that tile (K % 32, Cin % 64)
+bool viai_dgrad_s2_ok(const viai_conv2d* c) {
+    if (c->transposed || c->kh != 3 || c->kw != 3 || c->sh != 2 || c->sw != 2 || c->ph != 1 || c->pw != 1) return false;
+    if ((c->dh > 1) || (c->dw > 1) || (c->ph2 >= 0 && c->ph2 != 1) || (c->pw2 >= 0 && c->pw2 != 1)) return false;
+    if ((c->IH & 1) || (c->IW & 1) || c->Cout % 32 != 0 || (c->C1 + c->C2) % 64 != 0) return false;
+    if (c->C2 > 0 && c->C1 % 32 != 0) return false;
+    // enough 128-pixel x 64-channel tiles to occupy the chip; smaller layers go class by class through the split-K kernel
+    long blocks = (((long)c->N * (c->IH / 2) * (c->IW / 2) + 127) / 128) * ((c->C1 + c->C2) / 64);
+    return blocks >= 256;
+}
+
+int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st) {
+    // a.g: N, IH/IW = dy extent, OH/OW = dx extent; a.C1 = conv Cout (K), a.Cout = conv Cin, a.M = N * (OH/2) * (OW/2)
+    a.nblk_m = (a.M + 127) / 128;
+    a.nblk_n = (a.Cout + 63) / 64;
+    constexpr int lds = 2 * 3 * 128 * BF3_PITCH;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_bf3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
+    return viai_launch_status();
+}

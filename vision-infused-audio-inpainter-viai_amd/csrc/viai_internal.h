@@ -39,6 +39,8 @@ bool viai_bf3_frag_layout(long M, int n_out);
 bool viai_bf3_sk_ok(long M, int n_out, int C1, int C2);
 bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout);
 int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st);
+bool viai_dgrad_s2_ok(const viai_conv2d* c);
+int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st);
 int viai_wgrad_mfma_launch(WgradArgs& a, int ksplit, hipStream_t st);
 int viai_wgrad_bf3_launch(WgradArgs& a, int ksplit, hipStream_t st);
 bool viai_wgrad_bf3_ok(int Cout, int C1, int C2);
