@@ -13,6 +13,7 @@
 // nn.ConvTranspose2d listed in include/viai_hip.h.
 #include "viai_common.h"
 #include "viai_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -229,7 +230,12 @@ int viai_wgrad_pick_ksplit(int Cout, int Cin, int ntaps, long M) {
     int bm = tile_of(Cout), bn = tile_of(Cin);
     long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * ntaps;
     long chunks = (M + BKP - 1) / BKP;
-    long ks = 1024 / tiles;                        // just under two full rounds of 2 blocks/CU x 256 CUs
+    // blocks per launch: one round of 2 blocks/CU x 256 CUs.  The weight gradients run on a side stream next to the
+    // main backward chain, so a second round buys nothing and every extra K slab costs reduce traffic (measured:
+    // 512 beats 1024 by 1 %, 256 loses 4 %).
+    static long target = -1;
+    if (target < 0) { const char* e = getenv("VIAI_WGRAD_BLOCKS"); target = e ? atol(e) : 512; if (target < 64) target = 64; }
+    long ks = target / tiles;
     long maxks = chunks / 8; if (maxks < 1) maxks = 1;  // at least 8 chunks (256 pixels) per block
     if (ks > maxks) ks = maxks;
     if (ks > 512) ks = 512;
