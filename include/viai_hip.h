@@ -62,6 +62,18 @@ size_t viai_conv2d_packed_floats(const viai_conv2d* c);
 /* repack torch-layout weights for the forward / data-gradient kernels */
 int viai_conv2d_pack_fwd(const viai_conv2d* c, const float* w, float* wp, void* stream);
 int viai_conv2d_pack_dgrad(const viai_conv2d* c, const float* w, float* wp, void* stream);
+/* Batched weight packing: every bf16x3 weight image of a model in one launch (the weights change once per optimizer
+ * step; ~60 five-microsecond pack launches per step otherwise sit on the critical path).  viai_conv2d_pack_job fills
+ * one job (returns 1 if this layer's image is not a bf16x3 image: pack it with viai_conv2d_pack_fwd / _dgrad); the
+ * caller sets blk0 to the running sum of nblk, uploads the array and launches it with viai_pack_jobs_run.      */
+typedef struct viai_pack_job {
+    const void* w; void* wp;
+    int n_out, k_in, taps, frag;
+    long s_no, s_ki;
+    int blk0, nblk;
+} viai_pack_job;
+int viai_conv2d_pack_job(const viai_conv2d* c, int dgrad, const float* w, float* wp, viai_pack_job* job);
+int viai_pack_jobs_run(const viai_pack_job* jobs_dev, int njobs, int total_blocks, void* stream);
 /* BatchNorm partial-statistics geometry of the forward kernel: number of row
  * blocks and rows per block; stat_part holds 2*Cout*nblk floats.                */
 int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_per_blk);

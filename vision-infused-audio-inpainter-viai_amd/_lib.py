@@ -26,6 +26,12 @@ class Conv2dDesc(C.Structure):
         "N", "IH", "IW", "C1", "C2", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "transposed", "dh", "dw", "ph2", "pw2")]
 
 
+class PackJob(C.Structure):
+    """mirror of `viai_pack_job`."""
+    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("n_out", C.c_int), ("k_in", C.c_int), ("taps", C.c_int), ("frag", C.c_int),
+                ("s_no", C.c_long), ("s_ki", C.c_long), ("blk0", C.c_int), ("nblk", C.c_int)]
+
+
 class WnLayer(C.Structure):
     """mirror of `viai_wn_layer`."""
     _fields_ = [(n, C.c_void_p) for n in ("w_conv", "b_conv", "w_c", "b_c", "w_out", "b_out", "w_skip", "b_skip", "ring")] + \
@@ -111,6 +117,8 @@ SIGNATURES = {
     "viai_colsum": (_I, [_P, _L, _I, _P, _P, _I, _P]),
     "viai_axpy": (_I, [_F, _P, _P, _L, _P]),
     "viai_stft_mel": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "viai_conv2d_pack_job": (_I, [_CP, _I, _P, _P, C.POINTER(PackJob)]),
+    "viai_pack_jobs_run": (_I, [_P, _I, _I, _P]),
     "viai_frames_prep": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "viai_slice_clips": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _P]),
     "viai_ema_update": (_I, [_P, _P, _L, _D, _P]),

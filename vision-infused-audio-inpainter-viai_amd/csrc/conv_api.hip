@@ -250,6 +250,24 @@ extern "C" int viai_conv2d_pack_dgrad(const viai_conv2d* c, const float* w, floa
     }
 }
 
+// Job descriptor of this layer's bf16x3 weight image for viai_pack_jobs_run; returns 1 when the layer's pack is not a
+// bf16x3 image (streaming / fp32 kernels: pack it with viai_conv2d_pack_fwd / _dgrad as before).
+extern "C" int viai_conv2d_pack_job(const viai_conv2d* c, int dgrad, const float* w, float* wp, viai_pack_job* job) {
+    if (!valid(c) || job == nullptr) return (int)hipErrorInvalidValue;
+    if (kind_of(c) != K_IGEMM) return 1;
+    const int T = c->kh * c->kw, Cin = cin_of(c);
+    if (!dgrad) {
+        if (!use_bf3_fwd(c)) return 1;
+        const int frag = frag_fwd(c);
+        if (c->transposed) return viai_pack_job_bf3(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, frag, job);
+        return viai_pack_job_bf3(w, wp, c->Cout, Cin, T, (long)Cin * T, T, frag, job);
+    }
+    if (!use_bf3_dgrad(c)) return 1;
+    const int frag = frag_dgrad(c);
+    if (c->transposed) return viai_pack_job_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, frag, job);
+    return viai_pack_job_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, frag, job);
+}
+
 extern "C" int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_per_blk) {
     if (!valid(c)) return (int)hipErrorInvalidValue;
     if (kind_of(c) == K_CIN1) return viai_cin1_stat_geom(c, nblk, rows_per_blk);

@@ -694,11 +694,12 @@ __device__ __forceinline__ unsigned short bf16_rne(float x) {
 
 // fragment-major bf16 planes from w[no*s_no + ki*s_ki + t]:
 //   dst[p][nt][t][kq][lane][e],  lane = kg*32 + j, e < 8:  value(no = nt*32 + j, k = kq*16 + kg*8 + e), zero for no >= n_out
-__global__ void pack_weight_bf3_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
-                                       long s_no, long s_ki) {
+// (blk / nblk: this block's index and the number of blocks working on the image)
+__device__ __forceinline__ void pack_frag_body(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+                                               long s_no, long s_ki, int blk, int nblk) {
     const int NT = (n_out + 31) / 32, k16 = k_in / 16;
     const long plane = (long)NT * taps * k16 * 512;                  // bf16 elements per plane
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+    for (long i = blk * (long)blockDim.x + threadIdx.x; i < plane; i += (long)nblk * blockDim.x) {
         int e = (int)(i & 7); int lane = (int)((i >> 3) & 63); long r = i >> 9;
         int kq = (int)(r % k16); r /= k16; int t = (int)(r % taps); int nt = (int)(r / taps);
         int no = nt * 32 + (lane & 31), ki = kq * 16 + (lane >> 5) * 8 + e;
@@ -712,10 +713,10 @@ __global__ void pack_weight_bf3_frag_kernel(const float* __restrict__ w, unsigne
 }
 
 // planes[p][no][t][ki] (bf16) from w[no*s_no + ki*s_ki + t]; same RNE split as the kernel's activations
-__global__ void pack_weight_bf3_planar_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
-                                       long s_no, long s_ki) {
+__device__ __forceinline__ void pack_planar_body(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+                                                 long s_no, long s_ki, int blk, int nblk) {
     const long total = (long)n_out * taps * k_in;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = blk * (long)blockDim.x + threadIdx.x; i < total; i += (long)nblk * blockDim.x) {
         int ki = (int)(i % k_in); long r = i / k_in; int t = (int)(r % taps); int no = (int)(r / taps);
         float x = w[no * s_no + ki * s_ki + t];
         unsigned short h1 = bf16_rne(x);
@@ -724,6 +725,28 @@ __global__ void pack_weight_bf3_planar_kernel(const float* __restrict__ w, unsig
         float r2 = r1 - __uint_as_float((unsigned)h2 << 16);
         wp[i] = h1; wp[total + i] = h2; wp[2 * total + i] = bf16_rne(r2);
     }
+}
+
+__global__ void pack_weight_bf3_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+                                            long s_no, long s_ki) {
+    pack_frag_body(w, wp, n_out, k_in, taps, s_no, s_ki, blockIdx.x, gridDim.x);
+}
+__global__ void pack_weight_bf3_planar_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+                                              long s_no, long s_ki) {
+    pack_planar_body(w, wp, n_out, k_in, taps, s_no, s_ki, blockIdx.x, gridDim.x);
+}
+
+// every bf16x3 weight image of a model in ONE launch: a table of jobs, block -> job by its block range
+__global__ void pack_jobs_kernel(const viai_pack_job* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                                      // last job whose first block is <= b (wave-uniform)
+        int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const viai_pack_job j = jobs[lo];
+    if (j.frag) pack_frag_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
+    else pack_planar_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
 }
 
 }  // namespace
@@ -783,6 +806,23 @@ int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
 size_t viai_bf3_packed_floats(int n_out, int k_in, int taps) {
     size_t elems = (size_t)((n_out + 31) / 32) * 32 * taps * k_in;       // bf16 elements per plane (either layout fits)
     return (3 * elems + 1) / 2;
+}
+
+int viai_pack_job_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, int frag, viai_pack_job* job) {
+    if (k_in % 16 != 0) return (int)hipErrorInvalidValue;
+    long total = (long)(frag ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
+    long blocks = (total + 1023) / 1024;                   // four elements per thread
+    if (blocks > 64) blocks = 64;
+    if (blocks < 1) blocks = 1;
+    job->w = w; job->wp = wp; job->n_out = n_out; job->k_in = k_in; job->taps = taps; job->frag = frag ? 1 : 0;
+    job->s_no = s_no; job->s_ki = s_ki; job->blk0 = 0; job->nblk = (int)blocks;
+    return 0;
+}
+
+extern "C" int viai_pack_jobs_run(const viai_pack_job* jobs_dev, int njobs, int total_blocks, void* stream) {
+    if (njobs < 1 || total_blocks < 1 || jobs_dev == nullptr) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(pack_jobs_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    return viai_launch_status();
 }
 
 int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, int frag, hipStream_t st) {

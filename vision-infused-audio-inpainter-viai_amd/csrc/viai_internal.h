@@ -35,6 +35,7 @@ int viai_igemm_tile_m(long M, int n_out);
 int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st);
 size_t viai_bf3_packed_floats(int n_out, int k_in, int taps);
 int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, int frag, hipStream_t st);
+int viai_pack_job_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, int frag, viai_pack_job* job);
 bool viai_bf3_frag_layout(long M, int n_out);
 bool viai_bf3_sk_ok(long M, int n_out, int C1, int C2);
 bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout);

@@ -104,6 +104,7 @@ class FusedAdam:
     def step(self, grad_scale=1.0):
         ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.state,
                       self.betas[0], self.betas[1], self.eps, grad_scale)
+        ops.weights_changed(self.arena.params, owner=self)     # the kernel wrote the arena: re-pack every conv weight image in one launch
 
     # torch.optim.Adam-compatible (de)serialisation so utils/util.py:149-150 style checkpoints interchange
     def state_dict(self):
@@ -207,6 +208,14 @@ class AudioModel:
             own = mod.state_dict()
             for k, v in sd.items():
                 own[k].copy_(v.to(own[k].device))
+        self.weights_changed()
+
+    def weights_changed(self):
+        """Parameters were written outside the optimizers (checkpoint load, manual surgery): re-pack the conv weight
+        images now.  Eager steps would notice through the tensor versions; a captured graph contains no per-layer pack
+        launches (the optimizers' batched re-pack is what it replays), so it relies on this call."""
+        ops.weights_changed(self.arena_G.params, owner=self.optimizer_G)
+        ops.weights_changed(self.arena_D.params, owner=self.optimizer_D)
 
     # ------------------------------------------------------------- step pieces
     def get_blank_space_length(self, global_step):
@@ -471,4 +480,5 @@ class AudioModel:
             for k, v in ck[key].items():
                 if k in own and tuple(own[k].shape) == tuple(v.shape):
                     own[k].copy_(v)
+        self.weights_changed()
         return self

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -65,6 +67,102 @@ def _c(t):
 
 _desc_cache = {}
 
+# ---------------------------------------------------------------------------------------------- packed-weight cache
+# The conv kernels read weights from a packed image (bf16x3 planes, fragment- or row-major) that has to be rebuilt
+# whenever the weights change: once per optimizer step.  Parameters get a persistent image per (layer descriptor,
+# forward / data-gradient form), stamped with (WEIGHT_EPOCH, tensor version); a conv call re-packs only if the stamp
+# is stale.  model.FusedAdam bumps WEIGHT_EPOCH (its kernel writes the arena behind autograd's back) and calls
+# repack(), which rebuilds every registered image of its parameters in ONE launch (viai_pack_jobs_run) instead of
+# ~60 small launches spread over the step's critical path.  In-place torch updates bump the tensor version and are
+# caught by the stamp.  Non-parameter weights (e.g. weight-normed tensors recomputed every call) are packed per call.
+WEIGHT_EPOCH = 0
+_packs = {}        # (data_ptr, form, id(desc dict)) -> entry
+_packs_by_ptr = {}  # data_ptr -> [entries]
+
+
+def _stamp(weight):
+    return (WEIGHT_EPOCH, weight._version)
+
+
+def _packed(weight, d, form, st):
+    """packed image of `weight` for descriptor d; form 0 = forward, 1 = data gradient."""
+    lib = _lib.load()
+    fn = lib.viai_conv2d_pack_dgrad if form else lib.viai_conv2d_pack_fwd
+    if not isinstance(weight, torch.nn.Parameter):
+        wp = torch.empty(d["packed"], device=weight.device, dtype=torch.float32)
+        _lib.check(fn(d["ref"], weight.data_ptr(), wp.data_ptr(), st), "viai_conv2d_pack")
+        return wp
+    key = (weight.data_ptr(), form, id(d))
+    e = _packs.get(key)
+    if e is None or e["w"]() is not weight:
+        e = {"w": weakref.ref(weight), "wp": torch.empty(d["packed"], device=weight.device, dtype=torch.float32), "d": d, "form": form,
+             "stamp": None, "ptr": weight.data_ptr()}
+        _packs[key] = e
+        lst = [x for x in _packs_by_ptr.get(e["ptr"], []) if x["w"]() is weight and not (x["form"] == form and x["d"] is d)]
+        lst.append(e)
+        _packs_by_ptr[e["ptr"]] = lst
+    stamp = _stamp(weight)
+    if e["stamp"] != stamp:
+        _lib.check(fn(d["ref"], weight.data_ptr(), e["wp"].data_ptr(), st), "viai_conv2d_pack")
+        e["stamp"] = stamp
+    return e["wp"]
+
+
+_job_tables = {}   # id(params list owner) -> (signature, device table, njobs, total_blocks, singles)
+
+
+def repack(params, owner=None):
+    """Rebuild, in one launch, every registered packed image of `params` (call right after the weights changed and
+    WEIGHT_EPOCH was bumped).  Images that are not bf16x3 images (streaming / fp32 kernels) are re-packed one by one."""
+    lib = _lib.load()
+    st = _stream()
+    entries = []
+    for p in params:
+        for e in _packs_by_ptr.get(p.data_ptr(), ()):
+            if e["w"]() is p:
+                entries.append((p, e))
+    if not entries:
+        return 0
+    sig = tuple((e["ptr"], e["form"], id(e["d"]), e["wp"].data_ptr()) for _, e in entries)
+    key = id(owner) if owner is not None else id(params)
+    tab = _job_tables.get(key)
+    if tab is None or tab[0] != sig:
+        jobs, singles, blk = [], [], 0
+        for p, e in entries:
+            j = _lib.PackJob()
+            r = lib.viai_conv2d_pack_job(e["d"]["ref"], e["form"], p.data_ptr(), e["wp"].data_ptr(), C.byref(j))
+            if r == 0:
+                j.blk0 = blk
+                blk += j.nblk
+                jobs.append(j)
+            elif r == 1:
+                singles.append((p, e))
+            else:
+                _lib.check(r, "viai_conv2d_pack_job")
+        dev_tab = None
+        if jobs:
+            arr = (_lib.PackJob * len(jobs))(*jobs)
+            dev_tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(entries[0][0].device)
+        tab = (sig, dev_tab, len(jobs), blk, singles)
+        _job_tables[key] = tab
+    _, dev_tab, njobs, total, singles = tab
+    if njobs:
+        _lib.check(lib.viai_pack_jobs_run(dev_tab.data_ptr(), njobs, total, st), "viai_pack_jobs_run")
+    for p, e in singles:
+        fn = lib.viai_conv2d_pack_dgrad if e["form"] else lib.viai_conv2d_pack_fwd
+        _lib.check(fn(e["d"]["ref"], p.data_ptr(), e["wp"].data_ptr(), st), "viai_conv2d_pack")
+    for p, e in entries:
+        e["stamp"] = _stamp(p)
+    return len(entries)
+
+
+def weights_changed(params=None, owner=None):
+    """Call after writing parameters behind autograd's back (raw kernels, arena copies); with `params`, re-packs now."""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+    if params is not None:
+        repack(list(params), owner)
+
 
 def conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed, dh=1, dw=1, ph2=-1, pw2=-1):
     key = (N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed, dh, dw, ph2, pw2)
@@ -115,8 +213,7 @@ class _ConvBnAct(torch.autograd.Function):
         dev = x.device
         OH, OW = d["OH"], d["OW"]
         M = N * OH * OW
-        wp = torch.empty(d["packed"], device=dev, dtype=torch.float32)
-        _lib.check(lib.viai_conv2d_pack_fwd(d["ref"], weight.data_ptr(), wp.data_ptr(), st), "viai_conv2d_pack_fwd")
+        wp = _packed(weight, d, 0, st)
         has_bn = gamma is not None
         act = cfg["act"]
         training = cfg["training"]
@@ -230,8 +327,7 @@ class _ConvBnAct(torch.autograd.Function):
             if acc_b:
                 db = None
         if need_x or need_x2:
-            wp = torch.empty(d["packed"], device=dev, dtype=torch.float32)
-            _lib.check(lib.viai_conv2d_pack_dgrad(d["ref"], weight.data_ptr(), wp.data_ptr(), st), "viai_conv2d_pack_dgrad")
+            wp = _packed(weight, d, 1, st)
             dx = torch.empty((N, IH, IW, C1), device=dev, dtype=torch.float32)
             dx2 = torch.empty((N, IH, IW, C2), device=dev, dtype=torch.float32) if C2 > 0 else None
             _lib.check(lib.viai_conv2d_dgrad(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), st),
