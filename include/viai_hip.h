@@ -64,7 +64,8 @@ int viai_conv2d_pack_fwd(const viai_conv2d* c, const float* w, float* wp, void* 
 int viai_conv2d_pack_dgrad(const viai_conv2d* c, const float* w, float* wp, void* stream);
 /* Batched weight packing: every bf16x3 weight image of a model in one launch (the weights change once per optimizer
  * step; ~60 five-microsecond pack launches per step otherwise sit on the critical path).  viai_conv2d_pack_job fills
- * one job (returns 1 if this layer's image is not a bf16x3 image: pack it with viai_conv2d_pack_fwd / _dgrad); the
+ * one job (frag: 0 = row-major bf16x3 planes, 1 = fragment-major bf16x3 planes, 2 = fp32 [n_out][tap][k_in]; returns 1
+ * for the row-run image of the 7x7 image-input conv: pack that one with viai_conv2d_pack_fwd); the
  * caller sets blk0 to the running sum of nblk, uploads the array and launches it with viai_pack_jobs_run.      */
 typedef struct viai_pack_job {
     const void* w; void* wp;

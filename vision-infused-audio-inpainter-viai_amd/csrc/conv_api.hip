@@ -250,20 +250,23 @@ extern "C" int viai_conv2d_pack_dgrad(const viai_conv2d* c, const float* w, floa
     }
 }
 
-// Job descriptor of this layer's bf16x3 weight image for viai_pack_jobs_run; returns 1 when the layer's pack is not a
-// bf16x3 image (streaming / fp32 kernels: pack it with viai_conv2d_pack_fwd / _dgrad as before).
+// Job descriptor of this layer's weight image for viai_pack_jobs_run; returns 1 for the one image kind that is not
+// batched (row-run mode of the image-input 7x7 conv: pack it with viai_conv2d_pack_fwd).
 extern "C" int viai_conv2d_pack_job(const viai_conv2d* c, int dgrad, const float* w, float* wp, viai_pack_job* job) {
     if (!valid(c) || job == nullptr) return (int)hipErrorInvalidValue;
-    if (kind_of(c) != K_IGEMM) return 1;
     const int T = c->kh * c->kw, Cin = cin_of(c);
+    switch (kind_of(c)) {                    // same cases as viai_conv2d_pack_fwd / _dgrad; frag = 2: fp32 [no][t][ki]
+    case K_RUN: return 1;
+    case K_CIN1: return viai_pack_job_bf3(w, wp, c->Cout, 1, T, c->transposed ? T : (long)T, c->transposed ? (long)c->Cout * T : T, 2, job);
+    case K_COUT1: return viai_pack_job_bf3(w, wp, 1, Cin, T, 0, T, 2, job);
+    default: break;
+    }
     if (!dgrad) {
-        if (!use_bf3_fwd(c)) return 1;
-        const int frag = frag_fwd(c);
+        const int frag = use_bf3_fwd(c) ? (frag_fwd(c) ? 1 : 0) : 2;
         if (c->transposed) return viai_pack_job_bf3(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, frag, job);
         return viai_pack_job_bf3(w, wp, c->Cout, Cin, T, (long)Cin * T, T, frag, job);
     }
-    if (!use_bf3_dgrad(c)) return 1;
-    const int frag = frag_dgrad(c);
+    const int frag = use_bf3_dgrad(c) ? (frag_dgrad(c) ? 1 : 0) : 2;
     if (c->transposed) return viai_pack_job_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, frag, job);
     return viai_pack_job_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, frag, job);
 }

@@ -745,7 +745,15 @@ __global__ void pack_jobs_kernel(const viai_pack_job* __restrict__ jobs, int njo
         if (jobs[mid].blk0 <= b) lo = mid; else hi = mid - 1;
     }
     const viai_pack_job j = jobs[lo];
-    if (j.frag) pack_frag_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
+    if (j.frag == 2) {                                     // fp32 [no][t][ki] image of the streaming / exact-fp32 kernels
+        const long total = (long)j.n_out * j.taps * j.k_in;
+        const float* w = (const float*)j.w;
+        float* wp = (float*)j.wp;
+        for (long i = (b - j.blk0) * (long)blockDim.x + threadIdx.x; i < total; i += (long)j.nblk * blockDim.x) {
+            int ki = (int)(i % j.k_in); long r = i / j.k_in; int t = (int)(r % j.taps); int no = (int)(r / j.taps);
+            wp[i] = w[no * j.s_no + ki * j.s_ki + t];
+        }
+    } else if (j.frag) pack_frag_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
     else pack_planar_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
 }
 
@@ -809,12 +817,12 @@ size_t viai_bf3_packed_floats(int n_out, int k_in, int taps) {
 }
 
 int viai_pack_job_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, int frag, viai_pack_job* job) {
-    if (k_in % 16 != 0) return (int)hipErrorInvalidValue;
-    long total = (long)(frag ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
+    if (frag != 2 && k_in % 16 != 0) return (int)hipErrorInvalidValue;
+    long total = (long)(frag == 1 ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
     long blocks = (total + 1023) / 1024;                   // four elements per thread
     if (blocks > 64) blocks = 64;
     if (blocks < 1) blocks = 1;
-    job->w = w; job->wp = wp; job->n_out = n_out; job->k_in = k_in; job->taps = taps; job->frag = frag ? 1 : 0;
+    job->w = w; job->wp = wp; job->n_out = n_out; job->k_in = k_in; job->taps = taps; job->frag = frag;
     job->s_no = s_no; job->s_ki = s_ki; job->blk0 = 0; job->nblk = (int)blocks;
     return 0;
 }

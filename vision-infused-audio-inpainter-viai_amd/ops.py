@@ -80,8 +80,12 @@ _packs = {}        # (data_ptr, form, id(desc dict)) -> entry
 _packs_by_ptr = {}  # data_ptr -> [entries]
 
 
+_ptr_epoch = {}     # data_ptr -> epoch of the last out-of-band write to that parameter (per parameter: one optimizer's
+                    # step must not invalidate the images of the other optimizer's weights)
+
+
 def _stamp(weight):
-    return (WEIGHT_EPOCH, weight._version)
+    return (WEIGHT_EPOCH, _ptr_epoch.get(weight.data_ptr(), 0), weight._version)
 
 
 def _packed(weight, d, form, st):
@@ -159,9 +163,14 @@ def repack(params, owner=None):
 def weights_changed(params=None, owner=None):
     """Call after writing parameters behind autograd's back (raw kernels, arena copies); with `params`, re-packs now."""
     global WEIGHT_EPOCH
-    WEIGHT_EPOCH += 1
-    if params is not None:
-        repack(list(params), owner)
+    if params is None:
+        WEIGHT_EPOCH += 1                      # unknown extent: every cached image is stale
+        return
+    params = list(params)
+    for p in params:
+        k = p.data_ptr()
+        _ptr_epoch[k] = _ptr_epoch.get(k, 0) + 1
+    repack(params, owner)
 
 
 def conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed, dh=1, dw=1, ph2=-1, pw2=-1):
