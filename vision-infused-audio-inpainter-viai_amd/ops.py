@@ -67,6 +67,20 @@ def _c(t):
 
 _desc_cache = {}
 
+# Scratch buffers (BatchNorm partials, split-K slabs) are dead as soon as the call that fills them has queued its
+# last kernel, and kernels on one stream run in order: one growing buffer per (stream, purpose) replaces an
+# allocator round trip per layer and direction.
+_scratch_pool = {}
+
+
+def _scratch(tag, n, dev, stream=None):
+    key = (tag, dev.index, (stream if stream is not None else torch.cuda.current_stream()).cuda_stream)
+    t = _scratch_pool.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
+        _scratch_pool[key] = t
+    return t
+
 # ---------------------------------------------------------------------------------------------- packed-weight cache
 # The conv kernels read weights from a packed image (bf16x3 planes, fragment- or row-major) that has to be rebuilt
 # whenever the weights change: once per optimizer step.  Parameters get a persistent image per (layer descriptor,
@@ -230,7 +244,7 @@ class _ConvBnAct(torch.autograd.Function):
             y = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
             coef = torch.empty((4, Cout), device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
             if training:
-                stat = torch.empty(2 * Cout * d["nblk"], device=dev, dtype=torch.float32)
+                stat = _scratch("stat", 2 * Cout * d["nblk"], dev)
                 _lib.check(lib.viai_conv2d_fwd(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
                                                y.data_ptr(), stat.data_ptr(), ACT_NONE, st), "viai_conv2d_fwd")
                 _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, Cout, gamma.data_ptr(),
@@ -275,8 +289,8 @@ class _ConvBnAct(torch.autograd.Function):
         dgamma = dbeta = None
         if ctx.has_bn:
             nblk = lib.viai_bn_bwd_blocks(M, Cout)
-            part = torch.empty(2 * Cout * nblk, device=dev, dtype=torch.float32)
-            sums = torch.empty(2 * Cout, device=dev, dtype=torch.float32)
+            part = _scratch("bnpart", 2 * Cout * nblk, dev)
+            sums = _scratch("bnsums", 2 * Cout, dev)
             acc_bn = gt[2] is not None and gt[3] is not None and need_g and need_be
             if acc_bn:
                 pg, pb = gt[2], gt[3]
@@ -297,7 +311,7 @@ class _ConvBnAct(torch.autograd.Function):
                                                     0.2, st), "viai_act_bwd_from_output")
         dw = db = dx = dx2 = None
         if need_w or (need_b and ctx.has_bias):
-            ws = torch.empty(d["ws_floats"], device=dev, dtype=torch.float32)
+            ws = None
             shadowed = ctx.has_bn and cfg["training"]     # bias in front of train-mode BN: gradient is exactly 0
             acc_w = gt[0] is not None and need_w
             dw = gt[0] if acc_w else torch.empty_like(weight)
@@ -316,16 +330,18 @@ class _ConvBnAct(torch.autograd.Function):
                 ev.record()
                 WGRAD_STREAM.wait_event(ev)
                 with torch.cuda.stream(WGRAD_STREAM):
-                    ws = torch.empty(d["ws_floats"], device=dev, dtype=torch.float32)
+                    ws = _scratch("wgrad", d["ws_floats"], dev, WGRAD_STREAM)
                     _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
                                                      dw.data_ptr(), db.data_ptr() if want_db else 0, 1, WGRAD_STREAM.cuda_stream),
                                "viai_conv2d_wgrad")
-                _deferred.append((x, x2, dy, ws, weight))
+                _deferred.append((x, x2, dy, weight))
             elif acc_w == acc_b or not want_db:
+                ws = _scratch("wgrad", d["ws_floats"], dev)
                 _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
                                                  dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0, st),
                            "viai_conv2d_wgrad")
             else:   # mixed modes (only outside AudioModel): two calls keep the accumulate flag consistent
+                ws = _scratch("wgrad", d["ws_floats"], dev)
                 _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
                                                  dw.data_ptr(), 0, 1 if acc_w else 0, st), "viai_conv2d_wgrad")
                 part_b = torch.empty(lib.viai_colsum_blocks(M, Cout) * Cout, device=dev, dtype=torch.float32)
