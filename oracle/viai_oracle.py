@@ -566,8 +566,8 @@ def train_step(E, G, D, optG, optD, s, mask, cfg=StepConfig):
     feats = encoder_forward(Er, s_in.reshape(s.shape[0], s.shape[2], s.shape[3]))
     fake = decoder_forward(Gr, feats, s.shape)
     # ---- D step
+    pred_real = disc_forward(Dr, s)                    # declared order: real first, then fake (BN running statistics)
     pred_fake_d = disc_forward(Dr, fake.detach())
-    pred_real = disc_forward(Dr, s)
     loss_d_fake = gan_loss(pred_fake_d, False, cfg.use_lsgan)
     loss_d_real = gan_loss(pred_real, True, cfg.use_lsgan)
     loss_d = 0.5 * (loss_d_fake + loss_d_real)
@@ -623,8 +623,8 @@ def step_no_update(E, G, D, s, mask, cfg=StepConfig):
     s_in = s * mask
     feats = encoder_forward(Er, s_in.reshape(s.shape[0], s.shape[2], s.shape[3]))
     fake = decoder_forward(Gr, feats, s.shape)
+    pred_real = disc_forward(Dr, s)                    # declared order: real first, then fake (BN running statistics)
     pred_fake_d = disc_forward(Dr, fake.detach())
-    pred_real = disc_forward(Dr, s)
     loss_d = 0.5 * (gan_loss(pred_fake_d, False, cfg.use_lsgan) + gan_loss(pred_real, True, cfg.use_lsgan))
     dkeys = param_keys(Dr)
     dgrads = dict(zip(dkeys, torch.autograd.grad(loss_d, [Dr[k] for k in dkeys])))

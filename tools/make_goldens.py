@@ -77,8 +77,8 @@ def ref_step(E, G, D, optG, optD, gan, s, mask, update=True):
     for p in D.parameters():
         p.requires_grad_(True)
     optD.zero_grad()
+    pred_real = D(s)                                   # declared order: real first, then fake (BN running statistics)
     pred_fake_d = D(fake.detach())
-    pred_real = D(s)
     loss_d = 0.5 * (gan(pred_fake_d, False) + gan(pred_real, True))
     loss_d.backward()
     cap["grads_D"] = {k: p.grad.clone() for k, p in D.named_parameters()}

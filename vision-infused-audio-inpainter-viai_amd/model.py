@@ -185,6 +185,8 @@ class AudioModel:
         # stream.  VIAI_WGRAD_STREAM=0/1 overrides.
         side = os.environ.get("VIAI_WGRAD_STREAM", "0" if self.use_graph else "1") != "0"
         self._wgrad_stream = torch.cuda.Stream(device=self.device) if side else None
+        dreal = os.environ.get("VIAI_DREAL_STREAM", "0" if self.use_graph else "1") != "0"
+        self._dreal_stream = torch.cuda.Stream(device=self.device) if dreal else None
         self._graphs = None
 
     # ------------------------------------------------------------------ setup
@@ -291,15 +293,39 @@ class AudioModel:
         s_nhwc = s.view(B, F, T, 1)
         self.optimizer_D.zero_grad()
         self.optimizer_G.zero_grad()
+        self.netD.requires_grad_(True)
+        main = torch.cuda.current_stream()
+        side = self._dreal_stream
+        # D on the real clip needs nothing from the generator: in eager mode its forward AND backward run on a second
+        # stream next to the E+G forward (whose BatchNorm / streaming kernels leave the matrix pipes idle, and vice
+        # versa).  loss_D = 0.5 * (loss_fake + loss_real) is back-propagated as two halves; each parameter gradient is
+        # the sum of the two contributions in either order (two addends: bitwise commutative).  The declared order of
+        # the BatchNorm running-statistics updates is real first, then fake.
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pred_real = self.netD.forward_nhwc(s_nhwc)
+                fwd_done = torch.cuda.Event()
+                fwd_done.record(side)
+                loss_real = self._gan(pred_real, True)
+                (0.5 * loss_real).backward()
+        else:
+            pred_real = self.netD.forward_nhwc(s_nhwc)
+            loss_real = self._gan(pred_real, True)
         fake, self._lc = self._generate(s_nhwc)                        # (B,F,T,1)
         self._fake = fake
         self.fake = to_nchw_view(fake)
-        self.netD.requires_grad_(True)
+        if side is not None:
+            main.wait_event(fwd_done)                                  # running statistics: real before fake
         pred_fake = self.netD.forward_nhwc(fake.detach())
-        pred_real = self.netD.forward_nhwc(s_nhwc)
-        loss_fake, loss_real = self._gan(pred_fake, False), self._gan(pred_real, True)
-        loss_d = 0.5 * (loss_fake + loss_real)
-        loss_d.backward()
+        loss_fake = self._gan(pred_fake, False)
+        if side is not None:
+            main.wait_stream(side)                                     # real-branch gradients are in the arena
+            (0.5 * loss_fake).backward()
+            loss_d = 0.5 * (loss_fake.detach() + loss_real.detach())
+        else:
+            loss_d = 0.5 * (loss_fake + loss_real)
+            loss_d.backward()
         ops.join_wgrad()
         self.losses[0].copy_(loss_d.detach())
         self.losses[4].copy_(loss_real.detach())
