@@ -279,3 +279,64 @@ def test_packed_weight_cache_follows_every_kind_of_weight_update(use_graph):
         a.forward_backward_no_update()
         ref3.forward_backward_no_update()
         assert relerr(a.fake, ref3.fake) < 1e-5
+
+
+def test_gradient_exchange_over_rccl_is_wired_into_the_step():
+    """one-rank RCCL group on the GPU box: the two all-reduce points of the step (ddp.py, model._allreduce) run on the
+    real backend, between the side-stream joins and the Adam kernels, and leave a one-rank result unchanged.  (The
+    world-size-2 semantics are covered on CPU by tests/test_ddp_gloo.py.)"""
+    import torch.distributed as dist
+    from viai_amd.model import AudioModel, StepConfig
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    try:
+        hp = StepConfig()
+        hp.cin_channels, hp.max_mel_lengths = 80, 32
+        s = O.cf_uniform("rc.s", (2, 1, 80, 32), 0, 1).cuda()
+        mask = O.make_mask(2, 32, "rc.mask").cuda()
+        outs = []
+        for force, graph in ((False, False), (True, False), (True, True)):
+            m = AudioModel(hp, device="cuda", use_graph=graph)
+            m.load_states(O.encoder_state(), O.decoder_state(), O.disc_state())
+            m._force_allreduce = force
+            m.set_inputs(s, mask)
+            for i in range(3):
+                m.optimize_parameters(i)
+            torch.cuda.synchronize()
+            outs.append((m.fake.detach().clone(), m.arena_D.flat.clone(), m.arena_G.flat.clone()))
+        # eager: the exchange of a one-rank group is the identity and the three-stream step is deterministic -> bitwise equal
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+        # graph mode captured after two warm-up steps (model._capture): a different point of the trajectory; it must run
+        assert all(bool(torch.isfinite(t).all()) for t in outs[2])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_stream_step_is_bitwise_the_single_stream_step(monkeypatch):
+    """Weight gradients on a side stream and D(real) on a third stream only reorder launches in time: every
+    accumulation keeps its order (event-ordered streams), so losses, gradients and parameters after three steps are
+    bit-identical to the fully serial step -- with no host synchronisation between the steps."""
+    from viai_amd.model import AudioModel, StepConfig
+    hp = StepConfig()
+    hp.cin_channels, hp.max_mel_lengths = 80, 32
+    s = O.cf_uniform("st.s", (2, 1, 80, 32), 0, 1).cuda()
+    mask = O.make_mask(2, 32, "st.mask").cuda()
+
+    def run(wgrad, dreal):
+        monkeypatch.setenv("VIAI_WGRAD_STREAM", wgrad)
+        monkeypatch.setenv("VIAI_DREAL_STREAM", dreal)
+        m = AudioModel(hp, device="cuda", use_graph=False)
+        assert (m._wgrad_stream is not None) == (wgrad == "1") and (m._dreal_stream is not None) == (dreal == "1")
+        m.load_states(O.encoder_state(), O.decoder_state(), O.disc_state())
+        m.set_inputs(s, mask)
+        for i in range(3):
+            m.optimize_parameters(i)
+        torch.cuda.synchronize()
+        return [m.fake.detach().clone(), m.losses.clone(), m.arena_D.grad.clone(), m.arena_G.grad.clone(),
+                m.arena_D.flat.clone(), m.arena_G.flat.clone()]
+    serial = run("0", "0")
+    for cfg in (("1", "0"), ("1", "1"), ("1", "1")):
+        for a, b in zip(serial, run(*cfg)):
+            assert torch.equal(a, b), cfg
