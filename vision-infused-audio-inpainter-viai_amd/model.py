@@ -322,6 +322,7 @@ class AudioModel:
         loss_fake = self._gan(pred_fake, False)
         if side is not None:
             main.wait_stream(side)                                     # real-branch gradients are in the arena
+            loss_real.record_stream(main)                              # allocated on `side`, read below on main
             (0.5 * loss_fake).backward()
             loss_d = 0.5 * (loss_fake.detach() + loss_real.detach())
         else:
