@@ -29,8 +29,10 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 # The default conv math is the bf16x3 split (csrc/conv_igemm_bf3.hip): every fp32 MAC costs six bf16 MFMA MACs, so the
 # ceiling for ALGORITHMIC fp32 flops on that kernel is the bf16 peak / 6.  VIAI_MATH=fp32 selects the exact-fp32 MFMA kernel.
 BF3 = os.environ.get("VIAI_MATH", "") != "fp32"
+F16X2 = BF3 and os.environ.get("VIAI_F16X2", "1") != "0"     # wide forward layers: f16x2 split (three partial products)
 PEAK = MFMA_BF16_PEAK_TFLOPS / 6.0 if BF3 else MFMA_F32_PEAK_TFLOPS
-DOMINANT = ("conv_igemm_bf3_frag_kernel<2,2,2,2> (128x128x32 bf16x3 split-MFMA implicit-GEMM conv, fp32-grade accuracy, fwd + dgrad)"
+DOMINANT = ("conv_igemm_bf3_frag_kernel<3,2,2,2,2> (128x128x32 bf16x3 split-MFMA implicit-GEMM conv, fp32-grade accuracy; data-gradient launches"
+            + ("" if F16X2 else " and forward launches") + ")"
             if BF3 else "conv_igemm_kernel<32,2,2,2,2> (128x128x32 fp32-MFMA implicit-GEMM conv, fwd + dgrad)")
 
 
@@ -129,7 +131,8 @@ class KernelTimer:
                 return "direct", 1
             if halo_ok(d.C1, d.C2, d.Cout, d, *out_hw(d)):
                 return "halo", 1
-            return igemm_name(out_pixels(d), d.Cout), 1
+            nm = igemm_name(out_pixels(d), d.Cout)
+            return (nm + "_f16x2" if (F16X2 and nm == "igemm128x128") else nm), 1      # conv_igemm_bf3_frag_kernel<2,...>
 
         def fam_dgrad(d):
             cin = d.C1 + d.C2
@@ -275,7 +278,7 @@ def main():
                                                       "PatchGAN D" if args.config == "av" else "3-scale D", args.bins, args.frames, args.batch)),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                    "launch": "hipGraph replay (3 segments)" if args.graph else "eager, weight gradients on a side stream",
-                   "math": "fp32 tensors; conv GEMMs on bf16 MFMA with the 3-term split (six partial products, fp32 accumulate, error vs fp64 <= exact-fp32 kernel)"
+                   "math": "fp32 tensors; conv GEMMs on the 16-bit matrix cores with fp32 accumulate: bf16x3 split (six partial products) for gradients and narrow layers, f16x2 split (three partial products, power-of-two pre-scaling) for the wide forward layers; error vs fp64 at the level of fp32 arithmetic"
                            if BF3 else "exact fp32 MFMA",
                    "algorithmic_gflop_per_step": 1208.0, "step_tflops": round(1208.0 * 1e-3 / (ms_per_step * 1e-3), 2),
                    "loss_d": round(losses[0], 5), "loss_g": round(losses[1], 5)},
@@ -327,7 +330,7 @@ def main():
             "kernel": DOMINANT, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream of each call (main stream, or the weight-gradient side stream), %d instrumented steps of the same eager step after the timed region" % nprof,
-            "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<2,2,2,2>; igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel (small-M layers, waves split K); "
+            "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<3,2,2,2,2> (bf16x3); igemm128x128_f16x2 = conv_igemm_bf3_frag_kernel<2,2,2,2,2> (forward, f16x2 split: ceiling 2500/3); igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel (small-M layers, waves split K); "
                                    "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo = conv_halo_bf3_kernel<*> (32/64-channel stride-1 layers); dgrad_s2 = conv_dgrad_s2_bf3_kernel (3x3 stride-2 data gradient, four parity classes fused); wgrad_bf3 = wgrad_bf3_kernel<*>; "
                                    "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers)") if BF3 else
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
@@ -343,13 +346,15 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dconv3.json")))
         pmc = cands[-1] if cands else ""
         if BF3 and pmc:
-            for k, v in json.load(open(pmc)).items():
+            items = sorted(json.load(open(pmc)).items(), key=lambda kv: "frag_kernel<3" not in kv[0])     # the bf16x3 instance first
+            for k, v in items:
                 if "conv_igemm_bf3_frag_kernel" in k and "hbm_bytes" in v:
                     out["roofline"]["traffic"] = round(v["hbm_bytes"])
                     out["roofline"]["traffic_note"] = (
                         "bytes per launch on D.conv3 (fwd/dgrad average; algorithmic 57 MB in + 50 MB out): 2*FETCH_SIZE + WRITE_SIZE from "
                         "profiles/%s (tools/profile_layer.py under rocprofv3 --pmc); these L2 memory-side "
                         "counters include Infinity-Cache hits, i.e. they are L2-miss traffic, an upper bound on HBM bytes") % os.path.basename(pmc)
+                    break
         del m2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)

@@ -343,3 +343,27 @@ def test_bf16x3_path_is_fp32_grade():
         e, c = relerr(h, t), relerr(c32, t)
         print("%s: hip err %.2e, cpu fp32 err %.2e" % (nm, e, c))
         assert e < 4 * c + 1e-7, (nm, e, c)
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.01, 100.0])
+def test_f16x2_forward_is_fp32_grade(scale):
+    """Wide forward layers run the f16x2 split (two fp16 terms per operand, three partial products, power-of-two
+    pre-scaling): against an fp64 evaluation the result must be as accurate as fp32 arithmetic, for activations of
+    ordinary size and two decades either side.  Shape chosen so the fragment-major 128x128 kernel takes the layer."""
+    from viai_amd import ops
+    N, H, W, Ci, Co = 16, 64, 64, 64, 128
+    x = (O.cf_uniform("f16.x", (N, Ci, H, W), -1, 2).clamp(min=0) * scale)           # ReLU-like: a third zeros
+    w = O.cf_std("f16.w", (Co, Ci, 3, 3), 0.05)
+    truth = F.conv2d(x.double(), w.double(), None, padding=1)
+    cpu32 = F.conv2d(x, w, None, padding=1)
+    y = ops.conv_bn_act(nhwc(x), w.cuda(), None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
+    e_hip, e_cpu = relerr(nchw(y), truth), relerr(cpu32, truth)
+    assert e_hip < 3 * e_cpu + 1e-7, (scale, e_hip, e_cpu)
+
+
+def test_f16x2_saturates_instead_of_nan():
+    from viai_amd import ops
+    x = torch.full((16, 64, 64, 64), 1.0e4)                                          # x * 16 overflows fp16
+    w = O.cf_std("f16.w", (128, 64, 3, 3), 0.05)
+    y = ops.conv_bn_act(x.cuda(), w.cuda(), None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
+    assert bool(torch.isfinite(y).all())

@@ -76,7 +76,17 @@ static bool halo_dgrad(const viai_conv2d* c) {
     return viai_conv_halo_ok(g, c->Cout, 0, cin_of(c));
 }
 // weight layout of the bf16x3 kernels: fragment-major for the wide-tile and halo kernels, planar otherwise
-static bool frag_fwd(const viai_conv2d* c) { return halo_fwd(c) || viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout); }
+static bool f16x2_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_F16X2"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+// forward weight layout: 0 planar bf16x3, 1 fragment-major bf16x3, 3 fragment-major f16x2 (wide-tile forward kernel)
+static int frag_fwd(const viai_conv2d* c) {
+    if (halo_fwd(c)) return 1;
+    if (viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout)) return f16x2_enabled() ? 3 : 1;
+    return 0;
+}
 static bool sk_fwd(const viai_conv2d* c) {
     return use_bf3_fwd(c) && !frag_fwd(c) && viai_bf3_sk_ok(bf3_rows_fwd(c), c->Cout, c->C1, c->C2);
 }
@@ -262,7 +272,7 @@ extern "C" int viai_conv2d_pack_job(const viai_conv2d* c, int dgrad, const float
     default: break;
     }
     if (!dgrad) {
-        const int frag = use_bf3_fwd(c) ? (frag_fwd(c) ? 1 : 0) : 2;
+        const int frag = use_bf3_fwd(c) ? frag_fwd(c) : 2;
         if (c->transposed) return viai_pack_job_bf3(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, frag, job);
         return viai_pack_job_bf3(w, wp, c->Cout, Cin, T, (long)Cin * T, T, frag, job);
     }

@@ -135,13 +135,15 @@ __device__ __forceinline__ void bf3_epilogue(const ConvArgs& a, f32x16 (&acc)[TM
 // ahead of its use.  LDS holds only the activation planes, double-buffered: one barrier per 32-deep chunk and
 // the split + LDS stores of chunk k+1 overlap the MFMAs of chunk k.
 
-template <int TM, int TN, int WM, int WN>
+// NP = 3: bf16x3 split (six partial products); NP = 2: f16x2 split (three partial products, forward launches, viai_bf3.h)
+template <int NP, int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs a) {
     constexpr int BK = BF3_BK;
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int APLANE = BM * BF3_PITCH;
-    constexpr int STAGE = 3 * APLANE;
+    constexpr int STAGE = NP * APLANE;
+    constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int SPLIT_VALU_PER_MFMA = 4;
     constexpr int NA = BM / 32;                         // A float4 per thread per chunk (8 quads per row)
     static_assert(WM * WN == 4, "config");
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
         bbase[j] = (nt < NT) ? nt * g.wtaps * k16 * 1024 + lane * 16 : OOB;
     }
     const long in_pixels = (long)g.N * g.IH * g.IW;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 3 * frag_plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, NP * frag_plane, 0x00020000);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
         }
     };
     // B fragments of one 16-deep k-step: (tap t, channel offset c) -> 3 planes x TN tiles
-    auto gloadB = [&](u32x4 (&bf)[TN][3], int t_, int c_) {
+    auto gloadB = [&](u32x4 (&bf)[TN][NP], int t_, int c_) {
         const int t = __builtin_amdgcn_readfirstlane(t_);
         const int c = __builtin_amdgcn_readfirstlane(c_);
         const bool okk = (t < g.ntaps) && (c < Cin);
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 bf[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (bbase[j] == OOB || !okk) ? OOB : bbase[j], koff + p * frag_plane, 0);
     };
     auto lstore = [&](const u32x4 (&raw)[NA], int buf) {
@@ -246,14 +248,23 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
-            unsigned a1, a2, a3, b1, b2, b3;
-            split3_pair(v[0], v[1], a1, a2, a3);
-            split3_pair(v[2], v[3], b1, b2, b3);
-            const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
             unsigned char* d = As + (r0 + 32 * j) * BF3_PITCH + q * 8;
-            *reinterpret_cast<u32x2*>(d) = p1;
-            *reinterpret_cast<u32x2*>(d + APLANE) = p2;
-            *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+            if constexpr (NP == 3) {
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3_pair(v[0], v[1], a1, a2, a3);
+                split3_pair(v[2], v[3], b1, b2, b3);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+                *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+            } else {
+                unsigned a1, a2, b1, b2;
+                split2_pair(v[0] * F16_ASCALE, v[1] * F16_ASCALE, a1, a2);
+                split2_pair(v[2] * F16_ASCALE, v[3] * F16_ASCALE, b1, b2);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+            }
         }
     };
     auto advance = [&](int& t, int& c) { c += BK; if (c >= Cin) { c = 0; ++t; } };
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
     int t_n2 = t_n1, c_n2 = c_n1;             // chunk k+2 (being loaded)
     advance(t_n2, c_n2);
     u32x4 rawA[NA], rawB[NA];
-    u32x4 bf0[TN][3], bf1[TN][3];
+    u32x4 bf0[TN][NP], bf1[TN][NP];
     gloadA(rawA, 0, 0);
     gloadB(bf0, 0, 0);
     gloadA(rawB, t_n1, c_n1);
@@ -272,47 +283,52 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
     __syncthreads();
 
     const int aoff = (wm * TM * 32 + (lane & 31)) * BF3_PITCH + 16 * (lane >> 5);
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};     // six partial products, smallest first
+    // partial products, smallest first: bf16x3 a2b2 a3b1 a1b3 a2b1 a1b2 a1b1; f16x2 a2b1 a1b2 a1b1
+    constexpr int PA[6] = {NP == 3 ? 1 : 1, NP == 3 ? 2 : 0, 0, 1, 0, 0}, PB[6] = {NP == 3 ? 1 : 0, NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
+    auto mfma = [](const u32x4& x, const u32x4& y, const f32x16& c) {
+        if constexpr (NP == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+    };
 
     auto step = [&](u32x4 (&rload)[NA], const u32x4 (&rconv)[NA], int cur) {
         gloadA(rload, t_n2, c_n2);
         const unsigned char* As = smem_b + cur * STAGE + aoff;
         gloadB(bf1, t_cur, c_cur + 16);
         {
-            bf16x8 af[TM][3];
+            u32x4 af[TM][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    af[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + i * 32 * BF3_PITCH));
+                for (int p = 0; p < NP; ++p)
+                    af[i][p] = *reinterpret_cast<const u32x4*>(As + p * APLANE + i * 32 * BF3_PITCH);
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
+            for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]], __builtin_bit_cast(bf16x8, bf0[j][PB[pr]]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma(af[i][PA[pr]], bf0[j][PB[pr]], acc[i][j]);
         }
         gloadB(bf0, t_n1, c_n1);
         {
-            bf16x8 af[TM][3];
+            u32x4 af[TM][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    af[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + i * 32 * BF3_PITCH + 32));
+                for (int p = 0; p < NP; ++p)
+                    af[i][p] = *reinterpret_cast<const u32x4*>(As + p * APLANE + i * 32 * BF3_PITCH + 32);
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
+            for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]], __builtin_bit_cast(bf16x8, bf1[j][PB[pr]]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma(af[i][PA[pr]], bf1[j][PB[pr]], acc[i][j]);
         }
         lstore(rconv, cur ^ 1);
         // interleave: one MFMA, then a few of the split's VALU instructions, so the split runs in the MFMA shadow
 #pragma unroll
-        for (int i = 0; i < 12 * TM * TN; ++i) {
+        for (int i = 0; i < 2 * NPROD * TM * TN; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, SPLIT_VALU_PER_MFMA, 0);
         }
@@ -326,6 +342,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
         if (kc + 1 < nchunks) step(rawB, rawA, 1);
     }
 
+    if constexpr (NP == 2) {                     // undo the operand scales (exact powers of two)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] *= 1.0f / (F16_ASCALE * F16_WSCALE);
+    }
     bf3_epilogue<TM, TN, WM, WN>(a, acc, smem_b, lane, wm, wn, m0, n0, bm);
 }
 
@@ -727,9 +749,29 @@ __device__ __forceinline__ void pack_planar_body(const float* __restrict__ w, un
     }
 }
 
+// fragment-major f16x2 planes (forward f16x2 kernels): same geometry as pack_frag_body, two fp16 terms of w * F16_WSCALE
+__device__ __forceinline__ void pack_frag16_body(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+                                                 long s_no, long s_ki, int blk, int nblk) {
+    const int NT = (n_out + 31) / 32, k16 = k_in / 16;
+    const long plane = (long)NT * taps * k16 * 512;
+    for (long i = blk * (long)blockDim.x + threadIdx.x; i < plane; i += (long)nblk * blockDim.x) {
+        int e = (int)(i & 7); int lane = (int)((i >> 3) & 63); long r = i >> 9;
+        int kq = (int)(r % k16); r /= k16; int t = (int)(r % taps); int nt = (int)(r / taps);
+        int no = nt * 32 + (lane & 31), ki = kq * 16 + (lane >> 5) * 8 + e;
+        float x = (no < n_out) ? w[no * s_no + ki * s_ki + t] * F16_WSCALE : 0.f;
+        _Float16 h1 = (_Float16)x;
+        _Float16 h2 = (_Float16)(x - (float)h1);
+        wp[i] = __builtin_bit_cast(unsigned short, h1); wp[plane + i] = __builtin_bit_cast(unsigned short, h2);
+    }
+}
+
 __global__ void pack_weight_bf3_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
                                             long s_no, long s_ki) {
     pack_frag_body(w, wp, n_out, k_in, taps, s_no, s_ki, blockIdx.x, gridDim.x);
+}
+__global__ void pack_weight_f16_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+                                            long s_no, long s_ki) {
+    pack_frag16_body(w, wp, n_out, k_in, taps, s_no, s_ki, blockIdx.x, gridDim.x);
 }
 __global__ void pack_weight_bf3_planar_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
                                               long s_no, long s_ki) {
@@ -753,20 +795,21 @@ __global__ void pack_jobs_kernel(const viai_pack_job* __restrict__ jobs, int njo
             int ki = (int)(i % j.k_in); long r = i / j.k_in; int t = (int)(r % j.taps); int no = (int)(r / j.taps);
             wp[i] = w[no * j.s_no + ki * j.s_ki + t];
         }
-    } else if (j.frag) pack_frag_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
+    } else if (j.frag == 3) pack_frag16_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
+    else if (j.frag) pack_frag_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
     else pack_planar_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
 }
 
 }  // namespace
 
-template <bool FRAG, int TM, int TN, int WM, int WN>
+template <bool FRAG, int TM, int TN, int WM, int WN, int NP = 3>
 static int launch_bf3(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     a.nblk_m = (a.M + BM - 1) / BM;
     a.nblk_n = (a.Cout + BN - 1) / BN;
-    size_t lds = FRAG ? (size_t)2 * 3 * BM * BF3_PITCH : (size_t)3 * (BM + BN) * BF3_PITCH;
+    size_t lds = FRAG ? (size_t)2 * NP * BM * BF3_PITCH : (size_t)3 * (BM + BN) * BF3_PITCH;
     if (lds < (size_t)WM * BN * sizeof(float)) lds = (size_t)WM * BN * sizeof(float);
-    auto kern = FRAG ? conv_igemm_bf3_frag_kernel<TM, TN, WM, WN> : conv_igemm_bf3_lds_kernel<TM, TN, WM, WN>;
+    auto kern = FRAG ? conv_igemm_bf3_frag_kernel<NP, TM, TN, WM, WN> : conv_igemm_bf3_lds_kernel<TM, TN, WM, WN>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -804,6 +847,7 @@ int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
     if (a.sk) return launch_bf3_sk(a, st);
     const int bm = viai_igemm_tile_m(a.M, a.Cout);           // same tile rule as the fp32 kernels (BN partial geometry)
+    if (a.wfrag == 3) return launch_bf3<true, 2, 2, 2, 2, 2>(a, st);            // f16x2 weights (forward)
     if (a.wfrag) return launch_bf3<true, 2, 2, 2, 2>(a, st);
     if (bm == 64) return launch_bf3<false, 1, 1, 2, 2>(a, st);
     if (a.Cout > 64) return launch_bf3<false, 2, 2, 2, 2>(a, st);
@@ -818,7 +862,7 @@ size_t viai_bf3_packed_floats(int n_out, int k_in, int taps) {
 
 int viai_pack_job_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, int frag, viai_pack_job* job) {
     if (frag != 2 && k_in % 16 != 0) return (int)hipErrorInvalidValue;
-    long total = (long)(frag == 1 ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
+    long total = (long)((frag == 1 || frag == 3) ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
     long blocks = (total + 1023) / 1024;                   // four elements per thread
     if (blocks > 64) blocks = 64;
     if (blocks < 1) blocks = 1;
@@ -838,7 +882,8 @@ int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps
     long total = (long)(frag ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    if (frag) VIAI_LAUNCH(pack_weight_bf3_frag_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
+    if (frag == 3) VIAI_LAUNCH(pack_weight_f16_frag_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
+    else if (frag) VIAI_LAUNCH(pack_weight_bf3_frag_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
     else VIAI_LAUNCH(pack_weight_bf3_planar_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
     return viai_launch_status();
 }

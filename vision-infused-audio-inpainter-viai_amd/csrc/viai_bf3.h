@@ -22,3 +22,29 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& p1, un
 
 constexpr int BF3_BK = 32;                          // reduction elements per staged chunk (two 16-deep MFMA k-steps)
 constexpr int BF3_PITCH = 80;                       // bytes per LDS row: 32 bf16 + 8 pad (conflict-free ds_read_b128)
+
+// ---- f16x2 split (forward convolutions): a * S = h1 + h2 in two fp16 terms (2 x 11 = 22 significand bits), three partial
+// products h1w1 + h1w2 + h2w1 on v_mfma_f32_32x32x16_f16 -- half the MFMA work of bf16x3.  fp16 has a narrow exponent
+// range, so the operands are pre-scaled by exact powers of two (activations F16_ASCALE, weights F16_WSCALE in the pack
+// kernel) and the accumulator is scaled back in the epilogue; measured error vs fp64 equals the fp32 kernels' for O(1)
+// activations (BatchNorm outputs, mel inputs).  Gradients span too many decades for static scales: the backward
+// kernels stay on bf16x3.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float F16_ASCALE = 16.0f, F16_WSCALE = 256.0f;
+
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float f16_lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float f16_hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+
+// two floats (already scaled) -> two packed fp16 pairs.  Values beyond the fp16 range saturate (|x| * F16_ASCALE > 65504,
+// i.e. activations above ~4094: far outside anything a normalised network produces) instead of turning into inf / NaN.
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& p1, unsigned& p2) {
+    x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
+    x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
+    p1 = cvt_pk_f16(x0, x1);
+    p2 = cvt_pk_f16(x0 - f16_lo(p1), x1 - f16_hi(p1));
+}
