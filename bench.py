@@ -154,8 +154,18 @@ class KernelTimer:
                 return "wgrad_bf3", 1                # mirror of viai_wgrad_bf3_ok (csrc/conv_wgrad_bf3.hip)
             return "wgrad_mfma", 1
 
+        def fam_dgrad_f16(d):                        # viai_conv2d_dgrad_f16: the f16x2 instances of the same kernels
+            f, n = fam_dgrad(d)
+            return f + "_f16x2", n
+
         wrap("viai_conv2d_fwd", fam_fwd)
         wrap("viai_conv2d_dgrad", fam_dgrad)
+        def fam_wgrad_f16(d):
+            f, n = fam_wgrad(d)
+            return f + "_f16x2", n
+
+        wrap("viai_conv2d_dgrad_f16", fam_dgrad_f16)
+        wrap("viai_conv2d_wgrad_f16", fam_wgrad_f16)
         wrap("viai_conv2d_wgrad", fam_wgrad)
 
     def per_layer(self):
@@ -301,8 +311,15 @@ def main():
             print("\n".join(kt.per_layer()), file=sys.stderr)
         kt.uninstall()
         tot_t = sum(v[1] for v in fam.values())
-        f, t, n = fam["igemm128x128"]
+        # dominant kernel: the 128x128 fragment-major implicit-GEMM kernel; its bf16x3 and f16x2 instances are different
+        # kernels with different ceilings (2500/6 and 2500/3): report the one that holds more of the step
+        cands = [k for k in ("igemm128x128", "igemm128x128_f16x2") if k in fam]
+        dom = max(cands, key=lambda k: fam[k][1])
+        f, t, n = fam[dom]
         ach = f / t * 1e-12
+        peak = MFMA_BF16_PEAK_TFLOPS / 3.0 if dom.endswith("f16x2") else PEAK
+        dom_name = (("conv_igemm_bf3_frag_kernel<2,2,2,2,2> (128x128x32 f16x2 split-MFMA implicit-GEMM conv: two fp16 terms per operand, three "
+                     "partial products, fp32 accumulate, fp32-grade accuracy; forward and data-gradient launches)") if dom.endswith("f16x2") else DOMINANT)
         # the same kernel with nothing running beside it (weight gradients back on the main stream): what the kernel
         # itself reaches, without the time-sharing the as-run figure above includes
         alone = None
@@ -314,24 +331,24 @@ def main():
             kt1.install()
             for i in range(min(nprof, 5)):
                 m2.optimize_parameters(i)
-            f1, t1, n1 = kt1.summary()["igemm128x128"]
+            f1, t1, n1 = kt1.summary()[dom]
             kt1.uninstall()
             m2._wgrad_stream = side
-            alone = {"achieved": round(f1 / t1 * 1e-12, 2), "frac": round(f1 / t1 * 1e-12 / PEAK, 4), "avg_launch_us": round(t1 / n1 * 1e6, 2),
+            alone = {"achieved": round(f1 / t1 * 1e-12, 2), "frac": round(f1 / t1 * 1e-12 / peak, 4), "avg_launch_us": round(t1 / n1 * 1e6, 2),
                      "note": "single-stream pass: the dominant kernel without the concurrent weight-gradient stream"}
         out["roofline"] = {
-            "bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAK, 1), "unit": "TFLOP/s",
-            "frac": round(ach / PEAK, 4), "traffic": None,
-            "peak_note": ("algorithmic fp32 flops against the dense bf16 MFMA peak (2500) / 6 partial products per MAC; "
+            "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": None,
+            "peak_note": ("algorithmic fp32 flops against the dense 16-bit MFMA peak (2500) / %d partial products per MAC; "
                           "the same flops are %.2fx the fp32-MFMA peak (157.3); with random operands the pipes sustain 1810 "
-                          "(profiles/r01_e_mfma_probe.txt), i.e. %.2f of the sustained bf16x3 ceiling"
-                          % (ach / MFMA_F32_PEAK_TFLOPS, ach / (1810.0 / 6.0))) if BF3
+                          "(profiles/r01_e_mfma_probe.txt), i.e. %.2f of the sustained ceiling"
+                          % (3 if dom.endswith("f16x2") else 6, ach / MFMA_F32_PEAK_TFLOPS, ach / (1810.0 / (3.0 if dom.endswith("f16x2") else 6.0)))) if BF3
                          else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
-            "kernel": DOMINANT, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
+            "kernel": dom_name, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream of each call (main stream, or the weight-gradient side stream), %d instrumented steps of the same eager step after the timed region" % nprof,
             "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<3,2,2,2,2> (bf16x3); igemm128x128_f16x2 = conv_igemm_bf3_frag_kernel<2,2,2,2,2> (forward, f16x2 split: ceiling 2500/3); igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel (small-M layers, waves split K); "
-                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo = conv_halo_bf3_kernel<*> (32/64-channel stride-1 layers); dgrad_s2 = conv_dgrad_s2_bf3_kernel (3x3 stride-2 data gradient, four parity classes fused); wgrad_bf3 = wgrad_bf3_kernel<*>; "
+                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo = conv_halo_bf3_kernel<*> (32/64-channel stride-1 layers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> (3x3 stride-2 data gradient, four parity classes fused); wgrad_bf3 = wgrad_bf3_kernel<*>; "
                                    "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers)") if BF3 else
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},
@@ -343,10 +360,11 @@ def main():
         # memory-side traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
         # number comes from the committed counter summary of the same kernel on its largest layer (D.conv3)
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dconv3.json")))
-        pmc = cands[-1] if cands else ""
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dconv3.json")))
+        pmc = pmcs[-1] if pmcs else ""
         if BF3 and pmc:
-            items = sorted(json.load(open(pmc)).items(), key=lambda kv: "frag_kernel<3" not in kv[0])     # the bf16x3 instance first
+            want = "frag_kernel<2" if dom.endswith("f16x2") else "frag_kernel<3"
+            items = sorted(json.load(open(pmc)).items(), key=lambda kv: want not in kv[0])                  # the reported instance first
             for k, v in items:
                 if "conv_igemm_bf3_frag_kernel" in k and "hbm_bytes" in v:
                     out["roofline"]["traffic"] = round(v["hbm_bytes"])

@@ -85,11 +85,24 @@ int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float* x2, const
 /* dx (++ dx2) = conv_backward_data(dy, w) */
 int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const float* wp_dgrad,
                       float* dx, float* dx2, void* stream);
+/* f16x2 data gradient for the layers whose data gradient runs on the wide-tile kernel (viai_conv2d_dgrad_f16_ok): half the
+ * MFMA work of the bf16x3 form.  fp16 has a narrow exponent range and gradients span many decades, so the kernel scales dy
+ * by a power of two derived ON THE DEVICE from dy_amax = max |dy| (one float, written by viai_bn_act_bwd_amax).
+ * Weights: viai_conv2d_pack_dgrad_f16 (or viai_conv2d_pack_job with dgrad = 2).                                        */
+int viai_conv2d_dgrad_f16_ok(const viai_conv2d* c);
+int viai_conv2d_pack_dgrad_f16(const viai_conv2d* c, const float* w, float* wp, void* stream);
+int viai_conv2d_dgrad_f16(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2,
+                          const float* dy_amax, void* stream);
 /* dw (torch layout) = conv_backward_weight(x ++ x2, dy); dw += if accumulate.
  * db (optional, [Cout]) = sum of dy.  ws: scratch of viai_conv2d_wgrad_ws_bytes. */
 size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c);
 int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
                       float* ws, float* dw, float* db, int accumulate, void* stream);
+/* f16x2 form of the weight gradient (viai_conv2d_wgrad_f16_ok: layers with more than 32 channels on both sides): dy is
+ * scaled on the device from dy_amax = max |dy| (viai_bn_act_bwd_amax), x by a static power of two                     */
+int viai_conv2d_wgrad_f16_ok(const viai_conv2d* c);
+int viai_conv2d_wgrad_f16(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
+                          float* ws, float* dw, float* db, int accumulate, const float* dy_amax, void* stream);
 
 /* generic weight repack used by the two pack entry points (exposed for tests):
  * wp[no][t][ki] = w[no*s_no + ki*s_ki + t]                                       */
@@ -122,6 +135,11 @@ int viai_bn_act_bwd(const float* dz, const float* y, const float* mean, const fl
                     const float* scale, const float* shift, float* part, float* sums,
                     float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
                     int training, void* stream);
+/* the same, and *amax (one float, zero-initialised by the caller) receives max |dy| */
+int viai_bn_act_bwd_amax(const float* dz, const float* y, const float* mean, const float* invstd,
+                         const float* scale, const float* shift, float* part, float* sums,
+                         float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
+                         int training, float* amax, void* stream);
 /* elementwise activation backward for layers without BN (sigmoid heads):
  * dx = dz * act'(.) expressed through the activation OUTPUT z                    */
 int viai_act_bwd_from_output(const float* dz, const float* z, float* dx, long n, int act,

@@ -367,3 +367,33 @@ def test_f16x2_saturates_instead_of_nan():
     w = O.cf_std("f16.w", (128, 64, 3, 3), 0.05)
     y = ops.conv_bn_act(x.cuda(), w.cuda(), None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
     assert bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("gscale", [1.0, 1e-6, 1e4])
+def test_f16x2_backward_is_fp32_grade_at_any_gradient_scale(gscale):
+    """The data- and weight-gradient kernels of the wide layers use the f16x2 split with a power-of-two operand scale
+    derived on the device from max |dy| (written by the BatchNorm-backward kernel): gradients six decades smaller or four
+    larger must come out as accurate, against fp64, as fp32 arithmetic makes them.  Conv -> BN(train) (no activation: a
+    ReLU kink within rounding of zero flips a derivative and would measure luck, not kernels), 128 -> 128 channels at
+    16 x 64 x 64 so that the wide-tile dgrad and the bf16x3-class wgrad kernels take the layer."""
+    from viai_amd import ops
+    N, C, H, W, Co = 16, 128, 64, 64, 128
+    x = O.cf_uniform("fb.x", (N, C, H, W), 0, 1)
+    w = O.cf_std("fb.w", (Co, C, 3, 3), 0.03)
+    gy = O.cf_uniform("fb.gy", (N, Co, H, W), -1, 1) * gscale
+    g = O.cf_uniform("fb.g", (Co,), 0.8, 1.2)
+    b = O.cf_uniform("fb.b", (Co,), -0.1, 0.1)
+
+    def run(dt):
+        xs, ws, gs, bs = [t.clone().to(dt).requires_grad_(True) for t in (x, w, g, b)]
+        z = F.batch_norm(F.conv2d(xs, ws, None, padding=1), None, None, gs, bs, True, 0.1, 1e-5)
+        return torch.autograd.grad(z, [xs, ws], grad_outputs=gy.to(dt))
+    truth, cpu32 = run(torch.float64), run(torch.float32)
+    bn = torch.nn.BatchNorm2d(Co).cuda().train()
+    bn.weight.data.copy_(g); bn.bias.data.copy_(b)
+    xg = nhwc(x).requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    zg = ops.conv_bn_act(xg, wg, None, bn, kernel=(3, 3), stride=(1, 1), padding=(1, 1), act=ops.ACT_NONE)
+    zg.backward(nhwc(gy))
+    for nm, h, c32, t in zip(("dx", "dw"), (nchw(xg.grad), wg.grad), cpu32, truth):
+        assert relerr(h, t) < 5 * relerr(c32, t) + 1e-6, (gscale, nm, relerr(h, t), relerr(c32, t))

@@ -72,6 +72,12 @@ SIGNATURES = {
     "viai_bn_act_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "viai_bn_bwd_blocks": (_I, [_L, _I]),
     "viai_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
+    "viai_bn_act_bwd_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P, _P]),
+    "viai_conv2d_dgrad_f16_ok": (_I, [_CP]),
+    "viai_conv2d_wgrad_f16_ok": (_I, [_CP]),
+    "viai_conv2d_wgrad_f16": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "viai_conv2d_pack_dgrad_f16": (_I, [_CP, _P, _P, _P]),
+    "viai_conv2d_dgrad_f16": (_I, [_CP, _P, _P, _P, _P, _P, _P]),
     "viai_act_bwd_from_output": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "viai_bilinear_ac_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "viai_bilinear_ac_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const f32x4* __restrict__ dz, const f32x4* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ sums, f32x4* __restrict__ dy,
-    long n4, int C, int act, float slope) {
+    long n4, int C, int act, float slope, float* __restrict__ amax) {
     const unsigned c4n = (unsigned)(C / 4);
+    float mx = 0.f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
         const int c = (int)((unsigned long)i % c4n) * 4;
         f32x4 g = dz[i], v = y[i], o;
@@ -204,8 +205,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             float dp = g[e] * act_grad(v[e] * sc[e] + sh[e], act, slope);
             // (y - mean) first: keeps the fp32 rounding error relative to the centred value
             o[e] = sc[e] * dp + (k1[e] * (v[e] - mu[e]) + k0[e]);
+            mx = fmaxf(mx, fabsf(o[e]));
         }
         dy[i] = o;
+    }
+    if (amax != nullptr) {           // max |dy| of the tensor: the consumers' f16x2 operand scale (order-independent, deterministic)
+        __shared__ float wmax[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            // one atomic per block at most, and none once a larger value is already there (plain read first: 8192 blocks
+            // hammering one address with atomics measured +0.9 ms per step)
+            if (mx > 0.f && __float_as_uint(mx) > __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(amax)))
+                atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
+        }
     }
 }
 
@@ -267,10 +283,11 @@ extern "C" int viai_bn_bwd_blocks(long M, int C) {
     return (int)b;
 }
 
-extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mean, const float* invstd,
+// amax (optional, one zero-initialised float): receives max |dy| -- the operand scale of the f16x2 backward kernels
+extern "C" int viai_bn_act_bwd_amax(const float* dz, const float* y, const float* mean, const float* invstd,
                                const float* scale, const float* shift, float* part, float* sums,
                                float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
-                               int training, void* stream) {
+                               int training, float* amax, void* stream) {
     if (C % 4 != 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = viai_bn_bwd_blocks(M, C);
@@ -281,9 +298,16 @@ extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mea
         long n4 = M * C / 4;
         VIAI_LAUNCH(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz),
                            reinterpret_cast<const f32x4*>(y), mean, scale, shift, sums, reinterpret_cast<f32x4*>(dy),
-                           n4, C, act, slope);
+                           n4, C, act, slope, amax);
     }
     return viai_launch_status();
+}
+
+extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mean, const float* invstd,
+                               const float* scale, const float* shift, float* part, float* sums,
+                               float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
+                               int training, void* stream) {
+    return viai_bn_act_bwd_amax(dz, y, mean, invstd, scale, shift, part, sums, dgamma, dbeta, dy, M, C, act, slope, training, nullptr, stream);
 }
 
 extern "C" int viai_act_bwd_from_output(const float* dz, const float* z, float* dx, long n, int act, float slope, void* stream) {

@@ -64,6 +64,8 @@ static long bf3_rows_dgrad(const viai_conv2d* c) { return (long)c->N * ((c->IH +
 
 static bool use_bf3_fwd(const viai_conv2d* c);
 static bool use_bf3_dgrad(const viai_conv2d* c);
+static bool s2_dgrad(const viai_conv2d* c);
+static bool f16x2_enabled();
 // LDS-resident-tile kernel (conv_halo_bf3.hip) for the small-channel stride-1 layers
 static bool halo_fwd(const viai_conv2d* c) {
     if (!use_bf3_fwd(c)) return false;
@@ -86,6 +88,11 @@ static int frag_fwd(const viai_conv2d* c) {
     if (halo_fwd(c)) return 1;
     if (viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout)) return f16x2_enabled() ? 3 : 1;
     return 0;
+}
+// data gradient on the f16x2 wide-tile kernel (needs the abs-max of dy): the layers whose classes run on the fragment-major kernel
+static bool dgrad_f16(const viai_conv2d* c) {
+    if (!f16x2_enabled() || !use_bf3_dgrad(c) || halo_dgrad(c)) return false;
+    return s2_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c));
 }
 static bool sk_fwd(const viai_conv2d* c) {
     return use_bf3_fwd(c) && !frag_fwd(c) && viai_bf3_sk_ok(bf3_rows_fwd(c), c->Cout, c->C1, c->C2);
@@ -276,7 +283,8 @@ extern "C" int viai_conv2d_pack_job(const viai_conv2d* c, int dgrad, const float
         if (c->transposed) return viai_pack_job_bf3(w, wp, c->Cout, Cin, T, T, (long)c->Cout * T, frag, job);
         return viai_pack_job_bf3(w, wp, c->Cout, Cin, T, (long)Cin * T, T, frag, job);
     }
-    const int frag = use_bf3_dgrad(c) ? (frag_dgrad(c) ? 1 : 0) : 2;
+    if (dgrad == 2 && !dgrad_f16(c)) return (int)hipErrorInvalidValue;
+    const int frag = dgrad == 2 ? 3 : use_bf3_dgrad(c) ? (frag_dgrad(c) ? 1 : 0) : 2;
     if (c->transposed) return viai_pack_job_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, frag, job);
     return viai_pack_job_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, frag, job);
 }
@@ -321,7 +329,30 @@ extern "C" int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float
     return viai_conv_igemm_launch(a, st);
 }
 
+static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2, const float* amax, void* stream);
+
 extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2, void* stream) {
+    return dgrad_impl(c, dy, wp, dx, dx2, nullptr, stream);
+}
+
+// f16x2 data gradient: 1 if this layer has one (then pack with viai_conv2d_pack_dgrad_f16 and pass the abs-max of dy)
+extern "C" int viai_conv2d_dgrad_f16_ok(const viai_conv2d* c) { return (valid(c) && kind_of(c) == K_IGEMM && dgrad_f16(c)) ? 1 : 0; }
+
+extern "C" int viai_conv2d_pack_dgrad_f16(const viai_conv2d* c, const float* w, float* wp, void* stream) {
+    if (!viai_conv2d_dgrad_f16_ok(c)) return (int)hipErrorInvalidValue;
+    const int T = c->kh * c->kw, Cin = cin_of(c);
+    if (c->transposed) return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, 3, (hipStream_t)stream);
+    return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, 3, (hipStream_t)stream);
+}
+
+// dy_amax: device float holding max |dy| (viai_bn_act_bwd_amax): the f16x2 operand scale is derived from it on the device
+extern "C" int viai_conv2d_dgrad_f16(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2,
+                                     const float* dy_amax, void* stream) {
+    if (!viai_conv2d_dgrad_f16_ok(c) || dy_amax == nullptr) return (int)hipErrorInvalidValue;
+    return dgrad_impl(c, dy, wp, dx, dx2, dy_amax, stream);
+}
+
+static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2, const float* amax, void* stream) {
     if (!valid(c) || (c->C2 > 0) != (dx2 != nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     switch (kind_of(c)) {
@@ -348,7 +379,8 @@ extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const fl
         int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
         a.g.N = c->N; a.g.IH = oh; a.g.IW = ow; a.g.OH = c->IH; a.g.OW = c->IW;
         a.M = c->N * (c->IH / 2) * (c->IW / 2);
-        a.wfrag = 1;
+        a.wfrag = amax != nullptr ? 3 : 1;
+        a.amax = amax;
         return viai_conv_dgrad_s2_bf3_launch(a, st);
     }
     for (int a_ = 0; a_ < c->sh; ++a_)
@@ -362,6 +394,7 @@ extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const fl
             if (nt == 0) continue;                            // zero-filled above
             a.M = a.g.N * a.g.SH * a.g.SW;
             a.wfrag = bf3 && frag_dgrad(c);
+            if (amax != nullptr) { a.wfrag = 3; a.amax = amax; }       // f16x2 weights + dynamic operand scale
             a.sk = bf3 && !a.wfrag && viai_bf3_sk_ok(a.M, a.Cout, a.C1, 0);
             int e = (bf3 && halo_dgrad(c)) ? viai_conv_halo_bf3_launch(a, st) : bf3 ? viai_conv_igemm_bf3_launch(a, st) : viai_conv_igemm_launch(a, st);
             if (e) return e;
@@ -392,8 +425,27 @@ extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
     return fl * sizeof(float);
 }
 
+static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
+                      float* ws, float* dw, float* db, int accumulate, const float* amax, void* stream);
+
 extern "C" int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
                                  float* ws, float* dw, float* db, int accumulate, void* stream) {
+    return wgrad_impl(c, x, x2, dy, ws, dw, db, accumulate, nullptr, stream);
+}
+
+// f16x2 weight gradient (layers on the bf16x3 wgrad kernel): dy scaled on the device from dy_amax = max |dy|, x by the
+// static activation scale; 1 from viai_conv2d_wgrad_f16_ok if the layer has this form
+extern "C" int viai_conv2d_wgrad_f16_ok(const viai_conv2d* c) {
+    return (valid(c) && kind_of(c) == K_IGEMM && f16x2_enabled() && bf3_enabled() && viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2)) ? 1 : 0;
+}
+extern "C" int viai_conv2d_wgrad_f16(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
+                                     float* ws, float* dw, float* db, int accumulate, const float* dy_amax, void* stream) {
+    if (!viai_conv2d_wgrad_f16_ok(c) || dy_amax == nullptr) return (int)hipErrorInvalidValue;
+    return wgrad_impl(c, x, x2, dy, ws, dw, db, accumulate, dy_amax, stream);
+}
+
+static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
+                      float* ws, float* dw, float* db, int accumulate, const float* amax, void* stream) {
     if (!valid(c) || (c->C2 > 0) != (x2 != nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
@@ -420,6 +472,7 @@ extern "C" int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const flo
     default: {
         WgradArgs a{};
         a.x = x; a.x2 = x2; a.dy = dy; a.ws = ws; a.C1 = c->C1; a.C2 = c->C2; a.Cout = c->Cout; a.M = (int)M;
+        a.amax = amax;
         viai_geom_fwd(c, &a.g);
         int ks = viai_wgrad_pick_ksplit(c->Cout, Cin, T, M);
         used = (size_t)ks * viai_conv2d_packed_floats(c);

@@ -16,12 +16,16 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void conv_dgrad_s2_bf3_kernel(const ConvArgs a) {
+// NP = 3: bf16x3 (six partial products); NP = 2: f16x2 (three, dy scaled by a power of two derived from a.amax)
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_dgrad_s2_bf3_kernel(const ConvArgs a) {
     constexpr int BK = BF3_BK, BM = 128, TM = 2, NA = BM / 32;
-    constexpr int APLANE = BM * BF3_PITCH, STAGE = 3 * APLANE;
+    constexpr int APLANE = BM * BF3_PITCH, STAGE = NP * APLANE;
+    constexpr int NPROD = NP == 3 ? 6 : 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][3][128][80]
 
     const ConvGeom& g = a.g;                      // N, IH/IW = dy extent, OH/OW = dx extent
+    const float ascale = (NP == 2) ? f16_scale_from_amax(a.amax) : 1.f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_s2_bf3_kernel(const ConvArgs a
     const int nt = bn * 2 + wn;                                      // this wave's 32-channel tile (of every class)
     const int bvoff = (nt < NT) ? nt * 9 * k16 * 1024 + lane * 16 : OOB;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((long)g.N * g.IH * g.IW * K * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 3 * frag_plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, NP * frag_plane, 0x00020000);
 
     f32x16 acc[4][TM];                            // [class a*2+b][row tile]
 #pragma unroll
@@ -80,20 +84,29 @@ __global__ __launch_bounds__(256) void conv_dgrad_s2_bf3_kernel(const ConvArgs a
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
-            unsigned a1, a2, a3, b1, b2, b3;
-            split3_pair(v[0], v[1], a1, a2, a3);
-            split3_pair(v[2], v[3], b1, b2, b3);
-            const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
             unsigned char* d = As + (r0 + 32 * j) * BF3_PITCH + q * 8;
-            *reinterpret_cast<u32x2*>(d) = p1;
-            *reinterpret_cast<u32x2*>(d + APLANE) = p2;
-            *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+            if constexpr (NP == 3) {
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3_pair(v[0], v[1], a1, a2, a3);
+                split3_pair(v[2], v[3], b1, b2, b3);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+                *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+            } else {
+                unsigned a1, a2, b1, b2;
+                split2_pair(v[0] * ascale, v[1] * ascale, a1, a2);
+                split2_pair(v[2] * ascale, v[3] * ascale, b1, b2);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+            }
         }
     };
     // weights of (tap, 16-deep k-step kq): three planes of this wave's channel tile
-    auto gloadB = [&](u32x4 (&bf)[3], int tap, int kq) {
+    auto gloadB = [&](u32x4 (&bf)[NP], int tap, int kq) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
             bf[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bvoff, (tap * k16 + kq) * 1024 + p * frag_plane, 0);
     };
 
@@ -103,15 +116,17 @@ __global__ __launch_bounds__(256) void conv_dgrad_s2_bf3_kernel(const ConvArgs a
     __syncthreads();
 
     const int aoff = (wm * TM * 32 + (lane & 31)) * BF3_PITCH + 16 * (lane >> 5);
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int PA[6] = {1, NP == 3 ? 2 : 0, 0, 1, 0, 0}, PB[6] = {NP == 3 ? 1 : 0, NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
 
     // one (class, k-step) unit: B fragments were fetched into `bf`; the next unit's are requested before the MFMAs
-    auto mma = [&](f32x16 (&ac)[TM], const bf16x8 (&af)[TM][3], const u32x4 (&bf)[3]) {
+    auto mma = [&](f32x16 (&ac)[TM], const u32x4 (&af)[TM][NP], const u32x4 (&bf)[NP]) {
 #pragma unroll
-        for (int pr = 0; pr < 6; ++pr)
+        for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                ac[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]], __builtin_bit_cast(bf16x8, bf[PB[pr]]), ac[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (NP == 3) ac[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][PA[pr]]), __builtin_bit_cast(bf16x8, bf[PB[pr]]), ac[i], 0, 0, 0);
+                else ac[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][PA[pr]]), __builtin_bit_cast(f16x8, bf[PB[pr]]), ac[i], 0, 0, 0);
+            }
     };
 
     for (int kc = 0; kc < nchunks; ++kc) {
@@ -123,13 +138,13 @@ __global__ __launch_bounds__(256) void conv_dgrad_s2_bf3_kernel(const ConvArgs a
         const int na = sy ? 1 : 2, nb = sx ? 1 : 2;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 af[TM][3];
+            u32x4 af[TM][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    af[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + i * 32 * BF3_PITCH + ks * 32));
-            u32x4 bfA[3], bfB[3];
+                for (int p = 0; p < NP; ++p)
+                    af[i][p] = *reinterpret_cast<const u32x4*>(As + p * APLANE + i * 32 * BF3_PITCH + ks * 32);
+            u32x4 bfA[NP], bfB[NP];
             // unit order: (a, b) = (1,1), then (1,0) / (0,1), then (0,0) as far as the shift allows
             {
                 const int r = sy ? 0 : 2, s = sx ? 0 : 2;
@@ -149,6 +164,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_s2_bf3_kernel(const ConvArgs a
         __syncthreads();
     }
 
+    const float inv = (NP == 2) ? 1.0f / (ascale * F16_WSCALE) : 1.0f;      // applied at the store: scaling the 128 accumulators in place costs a second register set
     // ---------------------------------------------------------------- epilogue: four classes, 2 x 2 pixel quads
     const int half = lane >> 5, col = lane & 31;
     const int co = nt * 32 + col;
@@ -164,8 +180,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_s2_bf3_kernel(const ConvArgs a
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const size_t opix = ((size_t)n * g.OH + 2 * by + (c >> 1)) * g.OW + 2 * bx + (c & 1);
-                    if (co < a.OC1) a.out[opix * a.OC1 + co] = acc[c][i][e];
-                    else a.out2[opix * oc2 + (co - a.OC1)] = acc[c][i][e];
+                    if (co < a.OC1) a.out[opix * a.OC1 + co] = acc[c][i][e] * inv;
+                    else a.out2[opix * oc2 + (co - a.OC1)] = acc[c][i][e] * inv;
                 }
             }
         }
@@ -191,9 +207,11 @@ int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st) {
     constexpr int lds = 2 * 3 * 128 * BF3_PITCH;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_bf3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_bf3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_bf3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
+    if (a.amax != nullptr) VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<2>, dim3(a.nblk_m * a.nblk_n), dim3(256), 2 * 2 * 128 * BF3_PITCH, st, a);   // f16x2
+    else VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<3>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
     return viai_launch_status();
 }

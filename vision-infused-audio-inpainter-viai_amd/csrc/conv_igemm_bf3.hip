@@ -151,6 +151,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][3][BM][80]
 
     const ConvGeom& g = a.g;
+    // f16x2 operand scale: static for forward activations, derived from the producer's abs-max for gradients
+    const float ascale = (NP == 2 && a.amax != nullptr) ? f16_scale_from_amax(a.amax) : F16_ASCALE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -259,8 +261,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
                 *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
             } else {
                 unsigned a1, a2, b1, b2;
-                split2_pair(v[0] * F16_ASCALE, v[1] * F16_ASCALE, a1, a2);
-                split2_pair(v[2] * F16_ASCALE, v[3] * F16_ASCALE, b1, b2);
+                split2_pair(v[0] * ascale, v[1] * ascale, a1, a2);
+                split2_pair(v[2] * ascale, v[3] * ascale, b1, b2);
                 const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
                 *reinterpret_cast<u32x2*>(d) = p1;
                 *reinterpret_cast<u32x2*>(d + APLANE) = p2;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] *= 1.0f / (F16_ASCALE * F16_WSCALE);
+            for (int j = 0; j < TN; ++j) acc[i][j] *= 1.0f / (ascale * F16_WSCALE);
     }
     bf3_epilogue<TM, TN, WM, WN>(a, acc, smem_b, lane, wm, wn, m0, n0, bm);
 }

@@ -17,9 +17,11 @@ namespace {
 
 constexpr int WB_BKP = 32;     // pixels per staged chunk
 
-template <int TM, int TN>
+// NP = 3: bf16x3 (six partial products); NP = 2: f16x2 (three; dy scaled by a power of two from a.amax, x by F16_ASCALE)
+template <int NP, int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
     constexpr int WM = 2, WN = 2;
+    constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int BM = 32 * TM * WM;       // Cout tile
     constexpr int BN = 32 * TN * WN;       // Cin tile
     constexpr int QA = BM / 4, QB = BN / 4;             // channel quads per pixel row
@@ -28,9 +30,10 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
     unsigned char* As = smem_w;                         // [3][BM][80]
-    unsigned char* Bs = smem_w + 3 * APLANE;            // [3][BN][80]
+    unsigned char* Bs = smem_w + NP * APLANE;           // [NP][BN][80]
 
     const ConvGeom& g = a.g;
+    const float dscale = (NP == 2) ? f16_scale_from_amax(a.amax) : 1.f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -109,19 +112,21 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
         }
     };
     // transpose + split in registers: pk[c][plane] holds the thread's pixels of channel c as packed bf16
-    unsigned pka[4][3][NA / 2], pkb[4][3][NB / 2];
+    unsigned pka[4][NP][NA / 2], pkb[4][NP][NB / 2];
     auto convert = [&]() {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
             for (int h = 0; h < NA / 2; ++h) {
                 const f32x4 v0 = __builtin_bit_cast(f32x4, dreg[2 * h]), v1 = __builtin_bit_cast(f32x4, dreg[2 * h + 1]);
-                split3_pair(v0[c], v1[c], pka[c][0][h], pka[c][1][h], pka[c][2][h]);
+                if constexpr (NP == 3) split3_pair(v0[c], v1[c], pka[c][0][h], pka[c][1][h], pka[c][2][h]);
+                else split2_pair(v0[c] * dscale, v1[c] * dscale, pka[c][0][h], pka[c][1][h]);
             }
 #pragma unroll
             for (int h = 0; h < NB / 2; ++h) {
                 const f32x4 v0 = __builtin_bit_cast(f32x4, xreg[2 * h]), v1 = __builtin_bit_cast(f32x4, xreg[2 * h + 1]);
-                split3_pair(v0[c], v1[c], pkb[c][0][h], pkb[c][1][h], pkb[c][2][h]);
+                if constexpr (NP == 3) split3_pair(v0[c], v1[c], pkb[c][0][h], pkb[c][1][h], pkb[c][2][h]);
+                else split2_pair(v0[c] * F16_ASCALE, v1[c] * F16_ASCALE, pkb[c][0][h], pkb[c][1][h]);
             }
         }
     };
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 unsigned char* da = As + p * APLANE + (qa * 4 + c) * BF3_PITCH + pa0 * 2;
                 if (NA == 4) { const u32x2 v = {pka[c][p][0], pka[c][p][NA / 2 - 1]}; *reinterpret_cast<u32x2*>(da) = v; }
                 else *reinterpret_cast<unsigned*>(da) = pka[c][p][0];
@@ -147,31 +152,33 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
     __syncthreads();
     const int aoff = (wm * TM * 32 + (lane & 31)) * BF3_PITCH + 16 * (lane >> 5);
     const int boff = (wn * TN * 32 + (lane & 31)) * BF3_PITCH + 16 * (lane >> 5);
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int PA[6] = {1, NP == 3 ? 2 : 0, 0, 1, 0, 0}, PB[6] = {NP == 3 ? 1 : 0, NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
 
     for (int c = chunk0; c < chunk1; ++c) {
         const bool more = (c + 1 < chunk1);
         if (more) gload(c + 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[TM][3], bf[TN][3];
+            u32x4 af[TM][NP], bf[TN][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    af[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + aoff + i * 32 * BF3_PITCH + ks * 32));
+                for (int p = 0; p < NP; ++p)
+                    af[i][p] = *reinterpret_cast<const u32x4*>(As + p * APLANE + aoff + i * 32 * BF3_PITCH + ks * 32);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bf[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * BPLANE + boff + j * 32 * BF3_PITCH + ks * 32));
+                for (int p = 0; p < NP; ++p)
+                    bf[j][p] = *reinterpret_cast<const u32x4*>(Bs + p * BPLANE + boff + j * 32 * BF3_PITCH + ks * 32);
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
+            for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]], bf[j][PB[pr]], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][PA[pr]]), __builtin_bit_cast(bf16x8, bf[j][PB[pr]]), acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][PA[pr]]), __builtin_bit_cast(f16x8, bf[j][PB[pr]]), acc[i][j], 0, 0, 0);
+                    }
         }
         if (more) convert();
         __syncthreads();
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
         __syncthreads();
     }
 
+    const float inv = (NP == 2) ? 1.0f / (dscale * F16_ASCALE) : 1.0f;
     const int half = lane >> 5, col = lane & 31;
     float* dst = a.ws + ((size_t)z * g.wtaps + g.ws[t]) * a.Cout * Cin;
 #pragma unroll
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
             for (int e = 0; e < 16; ++e) {
                 int row = (e & 3) + 8 * (e >> 2) + 4 * half;
                 int co = co0 + (wm * TM + i) * 32 + row;
-                if (co < a.Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[i][j][e];
+                if (co < a.Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[i][j][e] * inv;
             }
         }
 }
@@ -204,11 +212,13 @@ int launch_wgrad_bf3(WgradArgs& a, hipStream_t st) {
     size_t lds = (size_t)3 * (BM + BN) * BF3_PITCH;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf3_kernel<TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf3_kernel<3, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf3_kernel<2, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid(a.nblk_co * a.nblk_ci * a.g.ntaps * a.ksplit);
-    VIAI_LAUNCH((wgrad_bf3_kernel<TM, TN>), grid, dim3(256), lds, st, a);
+    if (a.amax != nullptr) VIAI_LAUNCH((wgrad_bf3_kernel<2, TM, TN>), grid, dim3(256), (size_t)2 * (BM + BN) * BF3_PITCH, st, a);   // f16x2
+    else VIAI_LAUNCH((wgrad_bf3_kernel<3, TM, TN>), grid, dim3(256), lds, st, a);
     return viai_launch_status();
 }
 

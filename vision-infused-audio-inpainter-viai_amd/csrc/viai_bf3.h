@@ -48,3 +48,12 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& p1, un
     p1 = cvt_pk_f16(x0, x1);
     p2 = cvt_pk_f16(x0 - f16_lo(p1), x1 - f16_hi(p1));
 }
+
+// dynamic f16x2 operand scale from a device-side abs-max: the power of two that puts max |x| in [2^13, 2^14)
+__device__ __forceinline__ float f16_scale_from_amax(const float* amax) {
+    const unsigned bits = __float_as_uint(*amax);
+    if (bits == 0u) return 1.f;
+    int field = 127 + 14 - ((int)((bits >> 23) & 255u) - 126);          // 2^(14 - e), amax < 2^e
+    field = field < 1 ? 1 : (field > 254 ? 254 : field);
+    return __uint_as_float((unsigned)field << 23);
+}

@@ -17,6 +17,7 @@ struct ConvArgs {
     float slope;
     int wfrag;            // bf16x3 only: 1 = weights packed fragment-major (viai_bf3_frag_layout)
     int sk;               // bf16x3 only: 1 = 32x32-tile kernel whose four waves split K (viai_bf3_sk_ok)
+    const float* amax;    // f16x2 launches: device scalar max |gathered tensor| (dynamic operand scale, data gradients); null = static F16_ASCALE
     ConvGeom g;
 };
 
@@ -24,6 +25,7 @@ struct WgradArgs {
     const float* x; const float* x2;   // forward input (virtual concat C1 + C2)
     const float* dy;                   // [M][Cout]
     float* ws;                         // [ksplit][wtaps][Cout][Cin]
+    const float* amax;                 // f16x2 launch: device scalar max |dy| (dynamic operand scale); null = bf16x3
     int C1, C2, Cout;
     int M;
     int nblk_co, nblk_ci, ksplit, chunks_per_split;

@@ -292,6 +292,7 @@ class AudioModel:
         s = self.mel
         B, _, F, T = s.shape
         s_nhwc = s.view(B, F, T, 1)
+        ops.begin_step(self.device)                    # re-arm the abs-max slots of the f16x2 backward kernels (one fill)
         self.optimizer_D.zero_grad()
         self.optimizer_G.zero_grad()
         self.netD.requires_grad_(True)

@@ -12,6 +12,7 @@ There is no CPU path: a non-CUDA tensor or a missing library raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import weakref
 
@@ -34,6 +35,7 @@ DIRECT_GRAD = False
 # operands are kept alive in _deferred until join_wgrad() makes the main stream wait for the side stream.
 WGRAD_STREAM = None
 _deferred = []
+F16_BACKWARD = os.environ.get("VIAI_F16_BACKWARD", "1") != "0"     # f16x2 data gradients (dynamic per-tensor scale)
 
 
 def join_wgrad():
@@ -72,6 +74,34 @@ _desc_cache = {}
 # allocator round trip per layer and direction.
 _scratch_pool = {}
 
+# abs-max slots for the f16x2 backward kernels: the BatchNorm-backward apply kernel atomically maxes |dy| into a
+# zero-initialised float that the data-gradient kernel turns into its power-of-two operand scale.  A ring of slots
+# is zeroed by ONE fill per step (begin_step, called by model.AudioModel); callers that never call begin_step get a
+# fresh zeroed scalar per layer instead.
+_amax_ring = None
+_amax_next = 0
+_amax_managed = False
+
+
+def begin_step(device=None):
+    """start of a training step: re-arm the abs-max slots (one fill launch)."""
+    global _amax_ring, _amax_next, _amax_managed
+    if _amax_ring is None:
+        _amax_ring = torch.zeros(1024, device=device if device is not None else "cuda", dtype=torch.float32)
+    else:
+        _amax_ring.zero_()
+    _amax_next = 0
+    _amax_managed = True
+
+
+def _amax_slot(dev):
+    global _amax_next
+    if _amax_managed and _amax_ring is not None and _amax_ring.device == dev and _amax_next < _amax_ring.numel():
+        t = _amax_ring[_amax_next:_amax_next + 1]
+        _amax_next += 1
+        return t
+    return torch.zeros(1, device=dev, dtype=torch.float32)
+
 
 def _scratch(tag, n, dev, stream=None):
     key = (tag, dev.index, (stream if stream is not None else torch.cuda.current_stream()).cuda_stream)
@@ -103,9 +133,9 @@ def _stamp(weight):
 
 
 def _packed(weight, d, form, st):
-    """packed image of `weight` for descriptor d; form 0 = forward, 1 = data gradient."""
+    """packed image of `weight` for descriptor d; form 0 = forward, 1 = data gradient, 2 = f16x2 data gradient."""
     lib = _lib.load()
-    fn = lib.viai_conv2d_pack_dgrad if form else lib.viai_conv2d_pack_fwd
+    fn = (lib.viai_conv2d_pack_fwd, lib.viai_conv2d_pack_dgrad, lib.viai_conv2d_pack_dgrad_f16)[form]
     if not isinstance(weight, torch.nn.Parameter):
         wp = torch.empty(d["packed"], device=weight.device, dtype=torch.float32)
         _lib.check(fn(d["ref"], weight.data_ptr(), wp.data_ptr(), st), "viai_conv2d_pack")
@@ -167,7 +197,7 @@ def repack(params, owner=None):
     if njobs:
         _lib.check(lib.viai_pack_jobs_run(dev_tab.data_ptr(), njobs, total, st), "viai_pack_jobs_run")
     for p, e in singles:
-        fn = lib.viai_conv2d_pack_dgrad if e["form"] else lib.viai_conv2d_pack_fwd
+        fn = (lib.viai_conv2d_pack_fwd, lib.viai_conv2d_pack_dgrad, lib.viai_conv2d_pack_dgrad_f16)[e["form"]]
         _lib.check(fn(e["d"]["ref"], p.data_ptr(), e["wp"].data_ptr(), st), "viai_conv2d_pack")
     for p, e in entries:
         e["stamp"] = _stamp(p)
@@ -287,6 +317,7 @@ class _ConvBnAct(torch.autograd.Function):
         need_x, need_x2, need_w, need_b, need_g, need_be = ctx.needs_input_grad[:6]
         gt = cfg.get("gt") or (None, None, None, None)       # in-place gradient targets (arena views)
         dgamma = dbeta = None
+        amax = None
         if ctx.has_bn:
             nblk = lib.viai_bn_bwd_blocks(M, Cout)
             part = _scratch("bnpart", 2 * Cout * nblk, dev)
@@ -299,10 +330,18 @@ class _ConvBnAct(torch.autograd.Function):
                 dbeta = torch.empty(Cout, device=dev, dtype=torch.float32) if need_be else None
                 pg, pb = dgamma, dbeta
             dy = torch.empty_like(dz)
-            _lib.check(lib.viai_bn_act_bwd(dz.data_ptr(), y_or_z.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
-                                           coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
-                                           _ptr(pg), _ptr(pb), dy.data_ptr(), M, Cout, act, 0.2,
-                                           (1 if cfg["training"] else 0) | (2 if acc_bn else 0), st), "viai_bn_act_bwd")
+            f16d = d.get("dgrad_f16")
+            if f16d is None:
+                f16d = d["dgrad_f16"] = bool(lib.viai_conv2d_dgrad_f16_ok(d["ref"]))
+            f16w = d.get("wgrad_f16")
+            if f16w is None:
+                f16w = d["wgrad_f16"] = bool(lib.viai_conv2d_wgrad_f16_ok(d["ref"]))
+            # max |dy|: operand scale of the f16x2 data- and weight-gradient kernels
+            amax = _amax_slot(dev) if (F16_BACKWARD and ((f16d and need_x) or (f16w and need_w))) else None
+            _lib.check(lib.viai_bn_act_bwd_amax(dz.data_ptr(), y_or_z.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                                coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
+                                                _ptr(pg), _ptr(pb), dy.data_ptr(), M, Cout, act, 0.2,
+                                                (1 if cfg["training"] else 0) | (2 if acc_bn else 0), _ptr(amax), st), "viai_bn_act_bwd")
         elif act == ACT_NONE:
             dy = dz
         else:
@@ -331,15 +370,25 @@ class _ConvBnAct(torch.autograd.Function):
                 WGRAD_STREAM.wait_event(ev)
                 with torch.cuda.stream(WGRAD_STREAM):
                     ws = _scratch("wgrad", d["ws_floats"], dev, WGRAD_STREAM)
-                    _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                     dw.data_ptr(), db.data_ptr() if want_db else 0, 1, WGRAD_STREAM.cuda_stream),
-                               "viai_conv2d_wgrad")
-                _deferred.append((x, x2, dy, weight))
+                    if amax is not None and d["wgrad_f16"]:
+                        _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                             dw.data_ptr(), db.data_ptr() if want_db else 0, 1, amax.data_ptr(),
+                                                             WGRAD_STREAM.cuda_stream), "viai_conv2d_wgrad_f16")
+                    else:
+                        _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                         dw.data_ptr(), db.data_ptr() if want_db else 0, 1, WGRAD_STREAM.cuda_stream),
+                                   "viai_conv2d_wgrad")
+                _deferred.append((x, x2, dy, weight, amax))
             elif acc_w == acc_b or not want_db:
                 ws = _scratch("wgrad", d["ws_floats"], dev)
-                _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                 dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0, st),
-                           "viai_conv2d_wgrad")
+                if amax is not None and d["wgrad_f16"]:
+                    _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                         dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0,
+                                                         amax.data_ptr(), st), "viai_conv2d_wgrad_f16")
+                else:
+                    _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                     dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0, st),
+                               "viai_conv2d_wgrad")
             else:   # mixed modes (only outside AudioModel): two calls keep the accumulate flag consistent
                 ws = _scratch("wgrad", d["ws_floats"], dev)
                 _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
@@ -352,11 +401,16 @@ class _ConvBnAct(torch.autograd.Function):
             if acc_b:
                 db = None
         if need_x or need_x2:
-            wp = _packed(weight, d, 1, st)
             dx = torch.empty((N, IH, IW, C1), device=dev, dtype=torch.float32)
             dx2 = torch.empty((N, IH, IW, C2), device=dev, dtype=torch.float32) if C2 > 0 else None
-            _lib.check(lib.viai_conv2d_dgrad(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), st),
-                       "viai_conv2d_dgrad")
+            if amax is not None and d["dgrad_f16"]:
+                wp = _packed(weight, d, 2, st)
+                _lib.check(lib.viai_conv2d_dgrad_f16(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), amax.data_ptr(), st),
+                           "viai_conv2d_dgrad_f16")
+            else:
+                wp = _packed(weight, d, 1, st)
+                _lib.check(lib.viai_conv2d_dgrad(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), st),
+                           "viai_conv2d_dgrad")
         return dx, dx2, dw, db, dgamma, dbeta, None, None, None, None
 
 
