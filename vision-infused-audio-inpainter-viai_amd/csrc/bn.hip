@@ -72,20 +72,53 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
     mean_o[c] = rm[c]; invstd_o[c] = invstd; scale_o[c] = g * invstd; shift_o[c] = b - rm[c] * g * invstd;
 }
 
+// z = act(scale*y + shift).  FIXED: 256 % (C/4) == 0 -> one channel quad per thread, coefficients loaded once (see
+// bn_bwd_apply_kernel); four independent 16-byte loads in flight per thread.
+template <int ACT, bool FIXED>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, f32x4* __restrict__ z,
-                                                         long n4, int C, int act, float slope) {
-    const int c4n = C / 4;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
-        int c = (int)(i % c4n) * 4;
-        f32x4 v = y[i];
-        f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-        f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+                                                         long n4, int C, float slope) {
+    const unsigned c4n = (unsigned)(C / 4);
+    const long stride = (long)gridDim.x * 256L;
+    long i = blockIdx.x * 256L + threadIdx.x;
+    unsigned cq = (unsigned)((unsigned long)i % c4n);
+    const unsigned cstep = (unsigned)((unsigned long)stride % c4n);
+    f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cq * 4), sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
+    auto one = [&](const f32x4& v) {
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = viai_act(v[e] * sc[e] + sh[e], act, slope);
-        z[i] = o;
+        for (int e = 0; e < 4; ++e) o[e] = viai_act(v[e] * sc[e] + sh[e], ACT, slope);
+        return o;
+    };
+    auto next = [&]() {
+        if constexpr (!FIXED) {
+            cq += cstep; if (cq >= c4n) cq -= c4n;
+            sc = *reinterpret_cast<const f32x4*>(scale + cq * 4); sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
+        }
+    };
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = y[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { z[i + u * stride] = one(v[u]); next(); }
     }
+    for (; i < n4; i += stride) { z[i] = one(y[i]); next(); }
+}
+
+template <bool FIXED>
+int launch_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z, long n4, int C, int act, float slope, hipStream_t st) {
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), blk(256);
+    auto a0 = reinterpret_cast<const f32x4*>(y); auto a1 = reinterpret_cast<f32x4*>(z);
+    switch (act) {
+    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_RELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope); break;
+    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_LRELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope); break;
+    case VIAI_ACT_SIGMOID: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_SIGMOID, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope); break;
+    default: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_NONE, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope); break;
+    }
+    return viai_launch_status();
 }
 
 __device__ __forceinline__ float act_grad(float pre, int act, float slope) {
@@ -153,7 +186,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ scale, int training,
                                                            float* sums, float* dgamma, float* dbeta, int accumulate) {
-    __shared__ double r1[64][4], r2[64][4];
+    __shared__ double r1[4][4], r2[4][4];
     const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
@@ -172,10 +205,14 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
             s2 += (double)part[((size_t)b * 2 + 1) * C + c];
         }
     }
-    r1[pl][cl] = s1; r2[pl][cl] = s2;
+    // fixed-order tree: across the 16 partial lanes of a wave by shuffles, then across the four waves through LDS
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if ((threadIdx.x & 63) < 4) { r1[threadIdx.x >> 6][cl] = s1; r2[threadIdx.x >> 6][cl] = s2; }
     __syncthreads();
     if (pl == 0 && c < C) {
-        for (int k = 1; k < 64; ++k) { s1 += r1[k][cl]; s2 += r2[k][cl]; }
+        s1 = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
+        s2 = (r2[0][cl] + r2[1][cl]) + (r2[2][cl] + r2[3][cl]);
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
         if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
         if (training) {
@@ -188,27 +225,51 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
     }
 }
 
+// dy = scale*dpre + k1*(y-mean) + k0, and max |dy| for the f16x2 consumers.  FIXED: 256 % (C/4) == 0, so a thread keeps one
+// channel quad for its whole grid-stride walk and the five coefficient vectors are loaded once; otherwise the quad index
+// advances by (stride mod C/4) with one conditional subtract.  Four independent element pairs are in flight per thread (the
+// first version recomputed a 64-bit modulo and reloaded 80 bytes of coefficients per 32 bytes of data: 2.0 TB/s).
+template <int ACT, bool FIXED>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const f32x4* __restrict__ dz, const f32x4* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ sums, f32x4* __restrict__ dy,
-    long n4, int C, int act, float slope, float* __restrict__ amax) {
+    long n4, int C, float slope, float* __restrict__ amax) {
     const unsigned c4n = (unsigned)(C / 4);
+    const long stride = (long)gridDim.x * 256L;
+    long i = blockIdx.x * 256L + threadIdx.x;
+    unsigned cq = (unsigned)((unsigned long)i % c4n);
+    const unsigned cstep = (unsigned)((unsigned long)stride % c4n);
+    f32x4 sc, sh, k0, k1, mu;
+    auto coeffs = [&](unsigned q) {
+        const int c = (int)q * 4;
+        sc = *reinterpret_cast<const f32x4*>(scale + c); sh = *reinterpret_cast<const f32x4*>(shift + c);
+        k0 = *reinterpret_cast<const f32x4*>(sums + c); k1 = *reinterpret_cast<const f32x4*>(sums + C + c);
+        mu = *reinterpret_cast<const f32x4*>(mean + c);
+    };
+    coeffs(cq);
     float mx = 0.f;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
-        const int c = (int)((unsigned long)i % c4n) * 4;
-        f32x4 g = dz[i], v = y[i], o;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
-        const f32x4 k0 = *reinterpret_cast<const f32x4*>(sums + c), k1 = *reinterpret_cast<const f32x4*>(sums + C + c);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+    auto one = [&](const f32x4& g, const f32x4& v) {
+        f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float dp = g[e] * act_grad(v[e] * sc[e] + sh[e], act, slope);
+            float dp = g[e] * act_grad(v[e] * sc[e] + sh[e], ACT, slope);
             // (y - mean) first: keeps the fp32 rounding error relative to the centred value
             o[e] = sc[e] * dp + (k1[e] * (v[e] - mu[e]) + k0[e]);
             mx = fmaxf(mx, fabsf(o[e]));
         }
-        dy[i] = o;
+        return o;
+    };
+    auto next = [&]() {
+        if constexpr (!FIXED) { cq += cstep; if (cq >= c4n) cq -= c4n; coeffs(cq); }
+    };
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        f32x4 g[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { g[u] = dz[i + u * stride]; v[u] = y[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { dy[i + u * stride] = one(g[u], v[u]); next(); }
     }
+    for (; i < n4; i += stride) { dy[i] = one(dz[i], y[i]); next(); }
     if (amax != nullptr) {           // max |dy| of the tensor: the consumers' f16x2 operand scale (order-independent, deterministic)
         __shared__ float wmax[4];
 #pragma unroll
@@ -223,6 +284,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
                 atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
         }
     }
+}
+
+template <bool FIXED>
+int launch_bn_bwd_apply(const float* dz, const float* y, const float* mean, const float* scale, const float* shift, const float* sums,
+                        float* dy, long n4, int C, int act, float slope, float* amax, hipStream_t st) {
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), blk(256);
+    auto a0 = reinterpret_cast<const f32x4*>(dz); auto a1 = reinterpret_cast<const f32x4*>(y); auto a2 = reinterpret_cast<f32x4*>(dy);
+    switch (act) {
+    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_RELU, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax); break;
+    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_LRELU, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax); break;
+    case VIAI_ACT_SIGMOID: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_SIGMOID, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax); break;
+    default: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_NONE, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax); break;
+    }
+    return viai_launch_status();
 }
 
 __global__ void act_bwd_out_kernel(const float* __restrict__ dz, const float* __restrict__ z, float* __restrict__ dx,
@@ -266,17 +343,20 @@ extern "C" int viai_bn_act_fwd(const float* y, const float* scale, const float* 
                                long M, int C, int act, float slope, void* stream) {
     if (C % 4 != 0) return (int)hipErrorInvalidValue;
     long n4 = M * C / 4;
-    VIAI_LAUNCH(bn_act_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const f32x4*>(y), scale, shift, reinterpret_cast<f32x4*>(z), n4, C, act, slope);
-    return viai_launch_status();
+    const int c4n = C / 4;
+    if (256 % c4n == 0) return launch_bn_act_fwd<true>(y, scale, shift, z, n4, C, act, slope, (hipStream_t)stream);
+    return launch_bn_act_fwd<false>(y, scale, shift, z, n4, C, act, slope, (hipStream_t)stream);
 }
 
 extern "C" int viai_bn_bwd_blocks(long M, int C) {
-    // ~2048 row blocks for large tensors, but never fewer rows per block than one unrolled pass of the reduce
-    // kernel covers (256 threads = C/4 channel quads x pixel lanes, 4 rows in flight per lane)
+    // ~512 row blocks for large tensors (two per CU, eight 16-byte loads in flight per lane: enough to cover HBM latency; more
+    // blocks only lengthen the partial array the final kernel walks), but never fewer rows per block than one unrolled pass of
+    // the reduce kernel covers (256 threads = C/4 channel quads x pixel lanes, 4 rows in flight per lane)
+    static long target = 0;
+    if (target == 0) { const char* e = getenv("VIAI_BN_BWD_BLOCKS"); target = e ? atol(e) : 512; if (target < 1) target = 512; }
     long rows_min = 4096 / (C > 0 ? C : 1);
     if (rows_min < 4) rows_min = 4;
-    long rows = (M + 2047) / 2048;
+    long rows = (M + target - 1) / target;
     if (rows < rows_min) rows = rows_min;
     long b = (M + rows - 1) / rows;
     if (b < 1) b = 1;
@@ -296,9 +376,9 @@ extern "C" int viai_bn_act_bwd_amax(const float* dz, const float* y, const float
     VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1);
     if (dy != nullptr) {
         long n4 = M * C / 4;
-        VIAI_LAUNCH(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz),
-                           reinterpret_cast<const f32x4*>(y), mean, scale, shift, sums, reinterpret_cast<f32x4*>(dy),
-                           n4, C, act, slope, amax);
+        const int c4n = C / 4;
+        if (c4n > 0 && 256 % c4n == 0) return launch_bn_bwd_apply<true>(dz, y, mean, scale, shift, sums, dy, n4, C, act, slope, amax, st);
+        return launch_bn_bwd_apply<false>(dz, y, mean, scale, shift, sums, dy, n4, C, act, slope, amax, st);
     }
     return viai_launch_status();
 }

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 
     const ConvGeom& g = a.g;                      // N, IH/IW = dy extent, OH/OW = dx extent
     const float ascale = (NP == 2) ? f16_scale_from_amax(a.amax) : 1.f;
+    const float alim = f16_clamp_for_scale(ascale);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                 *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
             } else {
                 unsigned a1, a2, b1, b2;
-                split2_pair(v[0] * ascale, v[1] * ascale, a1, a2);
-                split2_pair(v[2] * ascale, v[3] * ascale, b1, b2);
+                split2_pair(v[0], v[1], ascale, alim, a1, a2);
+                split2_pair(v[2], v[3], ascale, alim, b1, b2);
                 const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
                 *reinterpret_cast<u32x2*>(d) = p1;
                 *reinterpret_cast<u32x2*>(d + APLANE) = p2;

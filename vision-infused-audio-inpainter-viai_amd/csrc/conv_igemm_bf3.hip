@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
     const ConvGeom& g = a.g;
     // f16x2 operand scale: static for forward activations, derived from the producer's abs-max for gradients
     const float ascale = (NP == 2 && a.amax != nullptr) ? f16_scale_from_amax(a.amax) : F16_ASCALE;
+    const float alim = f16_clamp_for_scale(ascale);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -220,15 +221,18 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
         const bool first = c0 < a.C1;
         const int cs = first ? a.C1 : a.C2;
         const int coff = (first ? c0 : c0 - a.C1) + q * 4;
-        const bool kin = live && (c0 + q * 4 < Cin);
-        // descriptor of the source this chunk reads, built from scalar selects (a branch here would split the basic
-        // block and with it the MFMA / VALU interleave below)
+        // no selects and no && below: the compiler turns them into branches (and sinks the address multiply into them), which
+        // splits the K loop's basic block, forces s_waitcnt vmcnt(0) at the joins and breaks the MFMA / VALU interleave.
+        // An element outside the image / beyond Cin / past the last tap gets offset bits 0x7fffffff OR-ed in: out of range
+        // for the descriptor, so the load returns zeros.
+        const int dead_s = live ? 0 : OOB;                                        // scalar
+        const int dead_l = ((Cin - 1 - (c0 + q * 4)) >> 31) & OOB;               // per lane: channel quad beyond Cin
         const float* src = first ? a.in : a.in2;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(in_pixels * cs * 4), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const bool ok = kin && ((tapok[j] >> tt) & 1u);
-            const int off = ok ? ((pixbase[j] + toff) * cs + coff) * 4 : OOB;
+            const int dead_t = (int)(((tapok[j] >> tt) & 1u) - 1u) & OOB;        // tap outside the image for this row
+            const int off = (((pixbase[j] + toff) * cs + coff) * 4) | dead_t | dead_l | dead_s;
             raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         }
     };
@@ -236,14 +240,14 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
     auto gloadB = [&](u32x4 (&bf)[TN][NP], int t_, int c_) {
         const int t = __builtin_amdgcn_readfirstlane(t_);
         const int c = __builtin_amdgcn_readfirstlane(c_);
-        const bool okk = (t < g.ntaps) && (c < Cin);
+        const int dead = ((t < g.ntaps) & (c < Cin)) ? 0 : OOB;      // scalar; OR-ed into the offset: zeros past the end
         const int tt = t < g.ntaps ? t : 0;                          // unconditional table read: no branch in the K loop
         const int koff = (g.ws[tt] * k16 + (c >> 4)) * 1024;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int p = 0; p < NP; ++p)
-                bf[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (bbase[j] == OOB || !okk) ? OOB : bbase[j], koff + p * frag_plane, 0);
+                bf[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bbase[j] | dead, koff + p * frag_plane, 0);
     };
     auto lstore = [&](const u32x4 (&raw)[NA], int buf) {
         unsigned char* As = smem_b + buf * STAGE;
@@ -261,8 +265,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
                 *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
             } else {
                 unsigned a1, a2, b1, b2;
-                split2_pair(v[0] * ascale, v[1] * ascale, a1, a2);
-                split2_pair(v[2] * ascale, v[3] * ascale, b1, b2);
+                split2_pair(v[0], v[1], ascale, alim, a1, a2);
+                split2_pair(v[2], v[3], ascale, alim, b1, b2);
                 const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
                 *reinterpret_cast<u32x2*>(d) = p1;
                 *reinterpret_cast<u32x2*>(d + APLANE) = p2;
@@ -277,9 +281,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
     int t_n2 = t_n1, c_n2 = c_n1;             // chunk k+2 (being loaded)
     advance(t_n2, c_n2);
     u32x4 rawA[NA], rawB[NA];
-    u32x4 bf0[TN][NP], bf1[TN][NP];
+    // weight fragments: bf16x3 fetches one k-step (24 MFMAs) ahead; f16x2 has half the MFMAs per k-step, too few to cover an
+    // L2 round trip, so it fetches one whole chunk ahead into a second pair of fragment sets
+    constexpr bool BDEEP = NP == 2;
+    u32x4 bf0[TN][NP], bf1[TN][NP], bg0[BDEEP ? TN : 1][NP], bg1[BDEEP ? TN : 1][NP];
     gloadA(rawA, 0, 0);
     gloadB(bf0, 0, 0);
+    if constexpr (BDEEP) gloadB(bf1, 0, 16);
     gloadA(rawB, t_n1, c_n1);
     lstore(rawA, 0);
     __syncthreads();
@@ -292,10 +300,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
         else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
     };
 
-    auto step = [&](u32x4 (&rload)[NA], const u32x4 (&rconv)[NA], int cur) {
+    auto step = [&](u32x4 (&rload)[NA], const u32x4 (&rconv)[NA], int cur, u32x4 (&bf0)[TN][NP], u32x4 (&bf1)[TN][NP],
+                    u32x4 (&bn0)[BDEEP ? TN : 1][NP], u32x4 (&bn1)[BDEEP ? TN : 1][NP]) {
         gloadA(rload, t_n2, c_n2);
         const unsigned char* As = smem_b + cur * STAGE + aoff;
-        gloadB(bf1, t_cur, c_cur + 16);
+        if constexpr (BDEEP) { gloadB(bn0, t_n1, c_n1); gloadB(bn1, t_n1, c_n1 + 16); }
+        else gloadB(bf1, t_cur, c_cur + 16);
         {
             u32x4 af[TM][NP];
 #pragma unroll
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = mfma(af[i][PA[pr]], bf0[j][PB[pr]], acc[i][j]);
         }
-        gloadB(bf0, t_n1, c_n1);
+        if constexpr (!BDEEP) gloadB(bf0, t_n1, c_n1);
         {
             u32x4 af[TM][NP];
 #pragma unroll
@@ -339,10 +349,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
         t_n1 = t_n2; c_n1 = c_n2;
         advance(t_n2, c_n2);
     };
-    for (int kc = 0; kc < nchunks; kc += 2) {
-        step(rawA, rawB, 0);
-        if (kc + 1 < nchunks) step(rawB, rawA, 1);
+    // two chunks per trip (the register sets swap roles), the odd last chunk peeled: no branch inside the loop
+    for (int kc = 0; kc + 1 < nchunks; kc += 2) {
+        step(rawA, rawB, 0, bf0, bf1, bg0, bg1);
+        if constexpr (BDEEP) step(rawB, rawA, 1, bg0, bg1, bf0, bf1);
+        else step(rawB, rawA, 1, bf0, bf1, bg0, bg1);
     }
+    if (nchunks & 1) step(rawA, rawB, 0, bf0, bf1, bg0, bg1);
 
     if constexpr (NP == 2) {                     // undo the operand scales (exact powers of two)
 #pragma unroll
@@ -402,9 +415,6 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_lds_kernel(const ConvArgs 
         bdst[j] = (idx < 3 * BN * 4) ? plane * BPLANE + row * BF3_PITCH + q16 * 16 : -1;
     }
     const long in_pixels = (long)g.N * g.IH * g.IW;
-    const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * a.C1 * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in), 0,
-                                                                             (int)(in_pixels * (a.in2 ? a.C2 : a.C1) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(3 * wplane), 0x00020000);
 
     f32x16 acc[TM][TN];
@@ -427,22 +437,24 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_lds_kernel(const ConvArgs 
         const bool first = c0 < a.C1;
         const int cs = first ? a.C1 : a.C2;
         const int coff = (first ? c0 : c0 - a.C1) + q * 4;
-        const bool kin = (c0 + q * 4 < Cin);
+        // masks, not selects / &&: see conv_igemm_bf3_frag_kernel (an invalid element gets 0x7fffffff OR-ed into its offset)
+        const int dead_l = ((Cin - 1 - (c0 + q * 4)) >> 31) & OOB;
+        const float* src = first ? a.in : a.in2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(in_pixels * cs * 4), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            int iy = iy0[j] + dyt, ix = ix0[j] + dxt;
-            bool ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW && kin;
-            int off = ok ? ((pixbase[j] + toff) * cs + coff) * 4 : OOB;
-            areg[j] = first ? __builtin_amdgcn_raw_buffer_load_b128(rs_in1, off, 0, 0)
-                            : __builtin_amdgcn_raw_buffer_load_b128(rs_in2, off, 0, 0);
+            const int iy = iy0[j] + dyt, ix = ix0[j] + dxt;
+            const int dead_t = (((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix) >> 31) & OOB;     // any of the four negative: outside
+            const int off = (((pixbase[j] + toff) * cs + coff) * 4) | dead_t | dead_l;
+            areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         }
         const int woff = (g.ws[t] * Cin + c0) * 2;
 #pragma unroll
         for (int j = 0; j < NBQ; ++j) {
             int idx = tid + 256 * j;
             int q16 = idx & 3;
-            bool kb = (c0 + q16 * 8 < Cin);
-            breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (bsrc[j] == OOB || !kb) ? OOB : bsrc[j] + woff, 0, 0);
+            const int dead_b = ((Cin - 1 - (c0 + q16 * 8)) >> 31) & OOB;
+            breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)((unsigned)bsrc[j] + (unsigned)woff) | dead_b | (bsrc[j] == OOB ? OOB : 0), 0, 0);
         }
     };
     auto lstore = [&]() {
@@ -590,20 +602,21 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_sk_kernel(const ConvArgs a
         const bool first = c0 < a.C1;
         const int cs = first ? a.C1 : a.C2;
         const int coff = (first ? c0 : c0 - a.C1) + q * 4;
-        const bool kin = live && (c0 + q * 4 < Cin);
+        const int dead_s = live ? 0 : OOB;
+        const int dead_l = ((Cin - 1 - (c0 + q * 4)) >> 31) & OOB;
         const float* src = first ? a.in : a.in2;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(in_pixels * cs * 4), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const bool ok = kin && ((tapok[j] >> tt) & 1u);
-            R.a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? ((pixbase[j] + toff) * cs + coff) * 4 : OOB, 0, 0);
+            const int dead_t = (int)(((tapok[j] >> tt) & 1u) - 1u) & OOB;
+            R.a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (((pixbase[j] + toff) * cs + coff) * 4) | dead_t | dead_l | dead_s, 0, 0);
         }
         const int woff = (g.ws[tt] * Cin + c0) * 2;
 #pragma unroll
         for (int j = 0; j < NBQ; ++j) {
             const int q16 = (tid + 256 * j) & 7;
-            const bool kb = live && (c0 + q16 * 8 < Cin);
-            R.b[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (bsrc[j] == OOB || !kb) ? OOB : bsrc[j] + woff, 0, 0);
+            const int dead_b = (((Cin - 1 - (c0 + q16 * 8)) >> 31) & OOB) | dead_s;
+            R.b[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)((unsigned)bsrc[j] + (unsigned)woff) | dead_b | (bsrc[j] == OOB ? OOB : 0), 0, 0);
         }
         c_ld += BK;
         if (c_ld >= Cin) { c_ld = 0; ++t_ld; }

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
 
     const ConvGeom& g = a.g;
     const float dscale = (NP == 2) ? f16_scale_from_amax(a.amax) : 1.f;
+    const float dlim = f16_clamp_for_scale(dscale), xscale = F16_ASCALE, xlim = 65504.f / F16_ASCALE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -120,13 +121,13 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
             for (int h = 0; h < NA / 2; ++h) {
                 const f32x4 v0 = __builtin_bit_cast(f32x4, dreg[2 * h]), v1 = __builtin_bit_cast(f32x4, dreg[2 * h + 1]);
                 if constexpr (NP == 3) split3_pair(v0[c], v1[c], pka[c][0][h], pka[c][1][h], pka[c][2][h]);
-                else split2_pair(v0[c] * dscale, v1[c] * dscale, pka[c][0][h], pka[c][1][h]);
+                else split2_pair(v0[c], v1[c], dscale, dlim, pka[c][0][h], pka[c][1][h]);
             }
 #pragma unroll
             for (int h = 0; h < NB / 2; ++h) {
                 const f32x4 v0 = __builtin_bit_cast(f32x4, xreg[2 * h]), v1 = __builtin_bit_cast(f32x4, xreg[2 * h + 1]);
                 if constexpr (NP == 3) split3_pair(v0[c], v1[c], pkb[c][0][h], pkb[c][1][h], pkb[c][2][h]);
-                else split2_pair(v0[c] * F16_ASCALE, v1[c] * F16_ASCALE, pkb[c][0][h], pkb[c][1][h]);
+                else split2_pair(v0[c], v1[c], xscale, xlim, pkb[c][0][h], pkb[c][1][h]);
             }
         }
     };

@@ -40,14 +40,20 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
 __device__ __forceinline__ float f16_lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
 __device__ __forceinline__ float f16_hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
 
-// two floats (already scaled) -> two packed fp16 pairs.  Values beyond the fp16 range saturate (|x| * F16_ASCALE > 65504,
-// i.e. activations above ~4094: far outside anything a normalised network produces) instead of turning into inf / NaN.
-__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& p1, unsigned& p2) {
-    x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
-    x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
-    p1 = cvt_pk_f16(x0, x1);
-    p2 = cvt_pk_f16(x0 - f16_lo(p1), x1 - f16_hi(p1));
+// two floats -> two packed fp16 pairs (p1 = the leading fp16 terms of x0*S, x1*S; p2 = the fp16 remainders), S a power of two
+// held in a scalar register, L = 65504 / S.  Six instructions: the clamp (values beyond the fp16 range saturate instead of
+// turning into inf / NaN: with the static activation scale that is |x| > ~4094, far outside anything a normalised network
+// produces), then v_fma_mixlo/hi_f16 does scale + round, and scale + subtract-leading-term + round, in one fma each (the
+// scaling is exact, so the remainder x*S - h1 is formed without rounding before the single conversion to fp16).
+__device__ __forceinline__ void split2_pair(float x0, float x1, float S, float L, unsigned& p1, unsigned& p2) {
+    x0 = __builtin_amdgcn_fmed3f(x0, -L, L);
+    x1 = __builtin_amdgcn_fmed3f(x1, -L, L);
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(p1) : "v"(x0), "s"(S));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(p1) : "v"(x1), "s"(S));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(p2) : "v"(x0), "s"(S), "v"(p1));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(p2) : "v"(x1), "s"(S), "v"(p1));
 }
+__device__ __forceinline__ float f16_clamp_for_scale(float S) { return 65504.f / S; }
 
 // dynamic f16x2 operand scale from a device-side abs-max: the power of two that puts max |x| in [2^13, 2^14)
 __device__ __forceinline__ float f16_scale_from_amax(const float* amax) {
