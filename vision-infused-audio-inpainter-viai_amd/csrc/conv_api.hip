@@ -77,6 +77,17 @@ static bool halo_dgrad(const viai_conv2d* c) {
     ConvGeom g{}; if (viai_geom_dgrad_class(c, 0, 0, &g) == 0) return false;
     return viai_conv_halo_ok(g, c->Cout, 0, cin_of(c));
 }
+// f16x2 halo kernel with the filter in registers (32 -> <= 32 channels, full 3 x 3 window)
+static bool halo16_fwd(const viai_conv2d* c) {
+    if (!f16x2_enabled() || !halo_fwd(c)) return false;
+    ConvGeom g{}; viai_geom_fwd(c, &g);
+    return viai_conv_halo16_ok(g, c->C1, c->C2, c->Cout);
+}
+static bool halo16_dgrad(const viai_conv2d* c) {
+    if (!f16x2_enabled() || !halo_dgrad(c)) return false;
+    ConvGeom g{}; viai_geom_dgrad_class(c, 0, 0, &g);
+    return viai_conv_halo16_ok(g, c->Cout, 0, cin_of(c));
+}
 // weight layout of the bf16x3 kernels: fragment-major for the wide-tile and halo kernels, planar otherwise
 static bool f16x2_enabled() {
     static int on = -1;
@@ -85,13 +96,14 @@ static bool f16x2_enabled() {
 }
 // forward weight layout: 0 planar bf16x3, 1 fragment-major bf16x3, 3 fragment-major f16x2 (wide-tile forward kernel)
 static int frag_fwd(const viai_conv2d* c) {
-    if (halo_fwd(c)) return 1;
+    if (halo_fwd(c)) return halo16_fwd(c) ? 3 : 1;
     if (viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout)) return f16x2_enabled() ? 3 : 1;
     return 0;
 }
 // data gradient on the f16x2 wide-tile kernel (needs the abs-max of dy): the layers whose classes run on the fragment-major kernel
 static bool dgrad_f16(const viai_conv2d* c) {
-    if (!f16x2_enabled() || !use_bf3_dgrad(c) || halo_dgrad(c)) return false;
+    if (!f16x2_enabled() || !use_bf3_dgrad(c)) return false;
+    if (halo_dgrad(c)) return halo16_dgrad(c);
     return s2_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c));
 }
 static bool sk_fwd(const viai_conv2d* c) {

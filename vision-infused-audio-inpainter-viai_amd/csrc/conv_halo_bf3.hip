@@ -238,6 +238,156 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
     }
 }
 
+// f16x2 variant for 32 -> (<= 32) channel 3 x 3 layers, weights resident in REGISTERS.  The bf16x3 kernel above streams every
+// weight fragment from L2 once per tile and wave (54 KB per 128 pixels: at 2048+ tiles that stream, not the MFMAs or HBM, is
+// the bound).  With two fp16 planes the whole filter is 9 taps x 2 k-steps x 2 planes = 36 fragments = 144 VGPRs, fetched once
+// per persistent block; a tile is then: patch (10 x 18 x 32 fp32, prefetched during the previous tile) -> split into two fp16
+// planes in LDS -> 54 MFMAs per wave whose A operands are ds_read_b128 at compile-time offsets -> epilogue.
+struct HaloSlots { int s[9]; };                    // weight slot of window position (row * 3 + col)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_f16_c32_kernel(const ConvArgs a, int hy0, int hx0, int ntiles, HaloSlots slots) {
+    constexpr int CIN = 32, PITCH = 80, Q = 8, KS = 2;
+    constexpr int NL = (HT_HP * Q + 255) / 256;     // 6 float4 per thread
+    constexpr int PLANE = HT_HP * PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [2][HP][PITCH]
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = g.OW / HT_W, tiles_y = g.OH / HT_H;
+    const float ascale = a.amax != nullptr ? f16_scale_from_amax(a.amax) : F16_ASCALE;
+    const float alim = f16_clamp_for_scale(ascale);
+
+    constexpr int OOB = 0x7fffffff;
+    const long in_pixels = (long)g.N * g.IH * g.IW;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * CIN * 4), 0x00020000);
+    const int frag_plane = g.wtaps * KS * 1024;      // one 32-channel output tile
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 2 * frag_plane, 0x00020000);
+
+    // the whole filter, once per block: wf[position][k-step][plane]
+    u32x4 wf[9][KS][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                wf[t][ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, (slots.s[t] * KS + ks) * 1024 + p * frag_plane, 0);
+
+    const int h0 = tid / Q, q = tid % Q;
+    int poff[NL], prc[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int h = h0 + (256 / Q) * j;
+        const int hr = h / HT_HW, hc = h - hr * HT_HW;
+        poff[j] = (hr * g.IW + hc) * CIN * 4 + q * 16;
+        prc[j] = h < HT_HP ? (hr << 8) | hc : -1;
+    }
+    u32x4 reg[NL];
+    auto load_patch = [&](int tile) {
+        const int tx = tile % tiles_x; int r = tile / tiles_x;
+        const int ty = r % tiles_y, n = r / tiles_y;
+        const int py = ty * HT_H + hy0, px = tx * HT_W + hx0;
+        const int pbase = ((n * g.IH + py) * g.IW + px) * CIN * 4;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int iy = py + (prc[j] >> 8), ix = px + (prc[j] & 255);
+            const int dead = (((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | prc[j]) >> 31) & OOB;
+            reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (pbase + poff[j]) | dead, 0, 0);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            if (prc[j] >= 0) {
+                const f32x4 v = __builtin_bit_cast(f32x4, reg[j]);
+                unsigned a1, a2, b1, b2;
+                split2_pair(v[0], v[1], ascale, alim, a1, a2);
+                split2_pair(v[2], v[3], ascale, alim, b1, b2);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
+                unsigned char* d = smem_h + (h0 + (256 / Q) * j) * PITCH + q * 8;
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + PLANE) = p2;
+            }
+        }
+    };
+
+    // MFMA row i = lane & 31 -> tile pixel (2 * wave + (i >> 4), i & 15); the patch origin is the window's top-left tap
+    const int pr = 2 * wave + ((lane & 31) >> 4), pc = lane & 15;
+    const unsigned char* abase = smem_h + (pr * HT_HW + pc) * PITCH + 16 * (lane >> 5);
+    const int half = lane >> 5, col = lane & 31;
+    const float bv = (a.bias != nullptr && col < a.Cout) ? a.bias[col] : 0.f;
+    const int oc2 = a.Cout - a.OC1;
+    const float inv = 1.0f / (ascale * F16_WSCALE);
+
+    int it = blockIdx.x;
+    if (it < ntiles) load_patch(xcd_remap(it, ntiles));
+    for (; it < ntiles; it += gridDim.x) {
+        const int tile = xcd_remap(it, ntiles);
+        store_patch();
+        __syncthreads();
+        if (it + (int)gridDim.x < ntiles) load_patch(xcd_remap(it + gridDim.x, ntiles));
+
+        // two accumulation chains, alternating: a dependent MFMA waits for its predecessor to retire
+        f32x16 c0, c1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { c0[e] = 0.f; c1[e] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const unsigned char* As = abase + ((t / 3) * HT_HW + (t % 3)) * PITCH + ks * 32;
+                const f16x8 a1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(As));
+                const f16x8 a2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(As + PLANE));
+                const f16x8 b1 = __builtin_bit_cast(f16x8, wf[t][ks][0]), b2 = __builtin_bit_cast(f16x8, wf[t][ks][1]);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, c0, 0, 0, 0);      // small terms on one chain
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, c0, 0, 0, 0);
+            }
+        f32x16 acc = (c0 + c1) * inv;
+
+        const int tx = tile % tiles_x; int r_ = tile / tiles_x;
+        const int ty = r_ % tiles_y, n = r_ / tiles_y;
+        const int oy0 = ty * HT_H, ox0 = tx * HT_W;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int oy = oy0 + 2 * wave + (row >> 4), ox = ox0 + (row & 15);
+            const size_t opix = ((size_t)n * g.OH + oy) * g.OW + ox;
+            float v = acc[e] + bv;
+            if (a.stat == nullptr) v = viai_act(v, a.act, a.slope);
+            acc[e] = v;
+            if (col < a.Cout) {
+                if (col < a.OC1) a.out[opix * a.OC1 + col] = v;
+                else a.out2[opix * oc2 + (col - a.OC1)] = v;
+            }
+        }
+        __syncthreads();                  // every wave is done reading the patch
+        if (a.stat != nullptr) {          // block-local (mean, M2) over the 128 pixels of this tile
+            float* red = reinterpret_cast<float*>(smem_h);          // [4 waves][32]
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) t += acc[e];
+            t += __shfl_xor(t, 32, 64);
+            if (half == 0) red[wave * 32 + col] = t;
+            __syncthreads();
+            const float mean = (red[col] + red[32 + col] + red[64 + col] + red[96 + col]) * (1.f / 128.f);
+            __syncthreads();
+            t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { float d = acc[e] - mean; t += d * d; }
+            t += __shfl_xor(t, 32, 64);
+            if (half == 0) red[wave * 32 + col] = t;
+            __syncthreads();
+            if (wave == 0 && half == 0 && col < a.Cout) {
+                a.stat[(size_t)col * a.nblk_m + tile] = mean;
+                a.stat[(size_t)(a.Cout + col) * a.nblk_m + tile] = red[col] + red[32 + col] + red[64 + col] + red[96 + col];
+            }
+            __syncthreads();              // red[] is overwritten by the next patch
+        }
+    }
+}
+
 template <int CIN, int TN>
 int launch_halo(ConvArgs& a, int hy0, int hx0, hipStream_t st) {
     constexpr int PITCH = CIN * 2 + 16;
@@ -274,10 +424,36 @@ bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout) {
     return (y1 - y0) <= 2 && (x1 - x0) <= 2;
 }
 
+// f16x2 register-resident-filter variant: 32 input channels, <= 32 output channels, all nine positions of a 3 x 3 window
+bool viai_conv_halo16_ok(const ConvGeom& g, int C1, int C2, int Cout) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_HALO16"); on = e ? atoi(e) : 1; }
+    if (!on || !viai_conv_halo_ok(g, C1, C2, Cout) || C1 != 32 || Cout > 32 || g.ntaps != 9) return false;
+    int y0 = g.dy[0], x0 = g.dx[0];
+    for (int t = 1; t < 9; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) seen |= 1u << ((g.dy[t] - y0) * 3 + (g.dx[t] - x0));
+    return seen == 0x1ffu;
+}
+
 int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st) {
     const ConvGeom& g = a.g;
     if (!viai_conv_halo_ok(g, a.C1, a.C2, a.Cout)) return (int)hipErrorInvalidValue;
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
+    if (a.wfrag == 3) {                                        // f16x2 fragment-major weights
+        if (!viai_conv_halo16_ok(g, a.C1, a.C2, a.Cout)) return (int)hipErrorInvalidValue;
+        int y0 = g.dy[0], x0 = g.dx[0];
+        for (int t = 1; t < 9; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
+        HaloSlots sl;
+        for (int t = 0; t < 9; ++t) sl.s[(g.dy[t] - y0) * 3 + (g.dx[t] - x0)] = g.ws[t];
+        const size_t lds = (size_t)2 * HT_HP * 80;
+        a.nblk_m = a.M / 128;
+        a.nblk_n = 1;
+        int grid = 256 * 2;
+        if (grid > a.nblk_m) grid = a.nblk_m;
+        VIAI_LAUNCH(conv_halo_f16_c32_kernel, dim3(grid), dim3(256), lds, st, a, y0, x0, a.nblk_m, sl);
+        return viai_launch_status();
+    }
     int y0 = g.dy[0], y1 = g.dy[0], x0 = g.dx[0], x1 = g.dx[0];
     for (int t = 1; t < g.ntaps; ++t) {
         y0 = g.dy[t] < y0 ? g.dy[t] : y0; y1 = g.dy[t] > y1 ? g.dy[t] : y1;
