@@ -361,6 +361,25 @@ def test_f16x2_forward_is_fp32_grade(scale):
     assert e_hip < 3 * e_cpu + 1e-7, (scale, e_hip, e_cpu)
 
 
+def test_f16x2_forward_on_the_128x256_tile():
+    """256-multiple output channels and >= 256 tiles: the eight-wave 128 x 256 variant of the wide kernel takes the layer
+    (conv_igemm_bf3.hip, viai_conv_igemm_bf3_launch).  Same fp32-grade bound against fp64, with a BatchNorm partial-statistics
+    epilogue checked through the normalised output."""
+    from viai_amd import ops
+    N, H, W, Ci, Co = 8, 64, 64, 64, 256
+    x = O.cf_uniform("w4.x", (N, Ci, H, W), -1, 1)
+    w = O.cf_std("w4.w", (Co, Ci, 3, 3), 0.05)
+    truth = F.conv2d(x.double(), w.double(), None, padding=1)
+    cpu32 = F.conv2d(x, w, None, padding=1)
+    y = ops.conv_bn_act(nhwc(x), w.cuda(), None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
+    e_hip, e_cpu = relerr(nchw(y), truth), relerr(cpu32, truth)
+    assert e_hip < 3 * e_cpu + 1e-7, (e_hip, e_cpu)
+    bn = torch.nn.BatchNorm2d(Co).cuda()
+    yb = ops.conv_bn_act(nhwc(x), w.cuda(), None, bn, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
+    tb = F.batch_norm(truth, None, None, None, None, True, 0.1, 1e-5)
+    assert relerr(nchw(yb), tb) < 1e-5
+
+
 def test_f16x2_saturates_instead_of_nan():
     from viai_amd import ops
     x = torch.full((16, 64, 64, 64), 1.0e4)                                          # x * 16 overflows fp16

@@ -137,7 +137,7 @@ __device__ __forceinline__ void bf3_epilogue(const ConvArgs& a, f32x16 (&acc)[TM
 
 // NP = 3: bf16x3 split (six partial products); NP = 2: f16x2 split (three partial products, forward launches, viai_bf3.h)
 template <int NP, int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf3_frag_kernel(const ConvArgs a) {
     constexpr int BK = BF3_BK;
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
@@ -145,8 +145,9 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
     constexpr int STAGE = NP * APLANE;
     constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int SPLIT_VALU_PER_MFMA = 4;
-    constexpr int NA = BM / 32;                         // A float4 per thread per chunk (8 quads per row)
-    static_assert(WM * WN == 4, "config");
+    constexpr int RP = 8 * WM * WN;                     // A rows staged per pass (8 threads = 8 channel quads per row)
+    constexpr int NA = BM / RP;                         // A float4 per thread per chunk
+    static_assert(BM % RP == 0, "config");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2][3][BM][80]
 
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
     int pixbase[NA], iy0[NA], ix0[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        int m = m0 + r0 + 32 * j;
+        int m = m0 + r0 + RP * j;
         if (m < a.M) {
             int ox = m % g.SW; int t = m / g.SW; int oy = t % g.SH; int n = t / g.SH;
             iy0[j] = oy * g.my; ix0[j] = ox * g.mx;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_frag_kernel(const ConvArgs
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
-            unsigned char* d = As + (r0 + 32 * j) * BF3_PITCH + q * 8;
+            unsigned char* d = As + (r0 + RP * j) * BF3_PITCH + q * 8;
             if constexpr (NP == 3) {
                 unsigned a1, a2, a3, b1, b2, b3;
                 split3_pair(v[0], v[1], a1, a2, a3);
@@ -824,13 +825,15 @@ static int launch_bf3(ConvArgs& a, hipStream_t st) {
     a.nblk_n = (a.Cout + BN - 1) / BN;
     size_t lds = FRAG ? (size_t)2 * NP * BM * BF3_PITCH : (size_t)3 * (BM + BN) * BF3_PITCH;
     if (lds < (size_t)WM * BN * sizeof(float)) lds = (size_t)WM * BN * sizeof(float);
-    auto kern = FRAG ? conv_igemm_bf3_frag_kernel<NP, TM, TN, WM, WN> : conv_igemm_bf3_lds_kernel<TM, TN, WM, WN>;
+    void (*kern)(const ConvArgs);
+    if constexpr (FRAG) kern = conv_igemm_bf3_frag_kernel<NP, TM, TN, WM, WN>;
+    else kern = conv_igemm_bf3_lds_kernel<TM, TN, WM, WN>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    VIAI_LAUNCH(kern, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
+    VIAI_LAUNCH(kern, dim3(a.nblk_m * a.nblk_n), dim3(64 * WM * WN), lds, st, a);
     return viai_launch_status();
 }
 
@@ -862,7 +865,14 @@ int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
     if (a.sk) return launch_bf3_sk(a, st);
     const int bm = viai_igemm_tile_m(a.M, a.Cout);           // same tile rule as the fp32 kernels (BN partial geometry)
-    if (a.wfrag == 3) return launch_bf3<true, 2, 2, 2, 2, 2>(a, st);            // f16x2 weights (forward)
+    if (a.wfrag == 3) {                                                        // f16x2 weights
+        // 128 x 256 tile (eight waves) where the layer is wide and tall enough: every staged activation row then feeds 256
+        // output channels, halving the load / split / LDS-store work per MFMA
+        static int wn4 = -1;
+        if (wn4 < 0) { const char* e = getenv("VIAI_F16_WN4"); wn4 = e ? atoi(e) : 1; }
+        if (wn4 && a.Cout % 256 == 0 && ((a.M + 127) / 128) * (a.Cout / 256) >= 256) return launch_bf3<true, 2, 2, 2, 4, 2>(a, st);
+        return launch_bf3<true, 2, 2, 2, 2, 2>(a, st);
+    }
     if (a.wfrag) return launch_bf3<true, 2, 2, 2, 2>(a, st);
     if (bm == 64) return launch_bf3<false, 1, 1, 2, 2>(a, st);
     if (a.Cout > 64) return launch_bf3<false, 2, 2, 2, 2>(a, st);
