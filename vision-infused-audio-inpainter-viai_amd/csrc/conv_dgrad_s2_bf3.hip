@@ -74,10 +74,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         const int sh = live ? chunk / kchunks : 0, c0 = (chunk - sh * kchunks) * BK;
         const int sy = sh >> 1, sx = sh & 1;
         const int toff = sy * g.IW + sx;
+        const int dead_s = live ? 0 : OOB;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const bool ok = live && (by_[j] + sy < g.IH) && (bx_[j] + sx < g.IW);
-            raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? ((pbase[j] + toff) * K + c0 + q * 4) * 4 : OOB, 0, 0);
+        for (int j = 0; j < NA; ++j) {               // offset masks instead of selects: no branches in the K loop (conv_igemm_bf3.hip)
+            const int dead = (((g.IH - 1 - (by_[j] + sy)) | (g.IW - 1 - (bx_[j] + sx))) >> 31) & OOB;
+            raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (((pbase[j] + toff) * K + c0 + q * 4) * 4) | dead | dead_s, 0, 0);
         }
     };
     auto lstore = [&](int buf) {
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                 if (na == 2 && nb == 2) mma(acc[0], af, bfB);
             }
         }
-        __syncthreads();
+        // the other stage was last read in the previous iteration, which ended with a barrier: no barrier before the stores
         lstore(cur ^ 1);
         gloadA(kc + 2);
         __syncthreads();
