@@ -111,6 +111,10 @@ class KernelTimer:
                 return "igemm64x64"
             return "igemm128x128" if n_out > 64 else ("igemm128x64" if n_out > 32 else "igemm128x32")
 
+        def wide_f16(M, n_out):                   # mirror of viai_conv_igemm_bf3_launch: the eight-wave 128 x 256 tile where it fits
+            wn4 = os.environ.get("VIAI_F16_WN4", "1") != "0"
+            return "igemm128x256_f16x2" if (wn4 and n_out % 256 == 0 and -(-M // 128) * (n_out // 256) >= 256) else "igemm128x128_f16x2"
+
         def out_pixels(d):
             oh = (d.IH - 1 - 2 * d.ph + d.kh) if d.transposed else (d.IH + 2 * d.ph - d.kh) // d.sh + 1
             ow = (d.IW - 1 - 2 * d.pw + d.kw) if d.transposed else (d.IW + 2 * d.pw - d.kw) // d.sw + 1
@@ -119,6 +123,9 @@ class KernelTimer:
         def halo_ok(c_in, c2, c_out, d, oh, ow):     # mirror of viai_conv_halo_ok (csrc/conv_halo_bf3.hip)
             return (BF3 and c2 == 0 and c_in in (32, 64) and c_out <= 64 and d.sh == 1 and d.sw == 1
                     and d.kh <= 3 and d.kw <= 3 and oh % 8 == 0 and ow % 16 == 0)
+
+        def halo16(c_in, c_out, d):                  # mirror of viai_conv_halo16_ok: filter-in-registers f16x2 variant
+            return F16X2 and os.environ.get("VIAI_HALO16", "1") != "0" and c_in == 32 and c_out <= 32 and d.kh == 3 and d.kw == 3
 
         def out_hw(d):
             oh = (d.IH - 1 - 2 * d.ph + d.kh) if d.transposed else (d.IH + 2 * d.ph - d.kh) // d.sh + 1
@@ -130,9 +137,9 @@ class KernelTimer:
             if cin == 1 or d.Cout == 1:
                 return "direct", 1
             if halo_ok(d.C1, d.C2, d.Cout, d, *out_hw(d)):
-                return "halo", 1
+                return ("halo_f16x2" if halo16(d.C1, d.Cout, d) else "halo"), 1
             nm = igemm_name(out_pixels(d), d.Cout)
-            return (nm + "_f16x2" if (F16X2 and nm == "igemm128x128") else nm), 1      # conv_igemm_bf3_frag_kernel<2,...>
+            return (wide_f16(out_pixels(d), d.Cout) if (F16X2 and nm == "igemm128x128") else nm), 1      # conv_igemm_bf3_frag_kernel<2,...>
 
         def fam_dgrad(d):
             cin = d.C1 + d.C2
@@ -156,6 +163,8 @@ class KernelTimer:
 
         def fam_dgrad_f16(d):                        # viai_conv2d_dgrad_f16: the f16x2 instances of the same kernels
             f, n = fam_dgrad(d)
+            if f == "igemm128x128":
+                return wide_f16(-(-(d.N * d.IH * d.IW) // n), d.C1 + d.C2), n
             return f + "_f16x2", n
 
         wrap("viai_conv2d_fwd", fam_fwd)
@@ -313,13 +322,14 @@ def main():
         tot_t = sum(v[1] for v in fam.values())
         # dominant kernel: the 128x128 fragment-major implicit-GEMM kernel; its bf16x3 and f16x2 instances are different
         # kernels with different ceilings (2500/6 and 2500/3): report the one that holds more of the step
-        cands = [k for k in ("igemm128x128", "igemm128x128_f16x2") if k in fam]
+        cands = [k for k in ("igemm128x128", "igemm128x128_f16x2", "igemm128x256_f16x2") if k in fam]
         dom = max(cands, key=lambda k: fam[k][1])
         f, t, n = fam[dom]
         ach = f / t * 1e-12
         peak = MFMA_BF16_PEAK_TFLOPS / 3.0 if dom.endswith("f16x2") else PEAK
-        dom_name = (("conv_igemm_bf3_frag_kernel<2,2,2,2,2> (128x128x32 f16x2 split-MFMA implicit-GEMM conv: two fp16 terms per operand, three "
-                     "partial products, fp32 accumulate, fp32-grade accuracy; forward and data-gradient launches)") if dom.endswith("f16x2") else DOMINANT)
+        dom_name = (("conv_igemm_bf3_frag_kernel<2,2,2,2,%d> (128x%dx32 f16x2 split-MFMA implicit-GEMM conv, %s waves: two fp16 terms per operand, three "
+                     "partial products, fp32 accumulate, fp32-grade accuracy; forward and data-gradient launches)"
+                     % ((4, 256, "eight") if dom.startswith("igemm128x256") else (2, 128, "four"))) if dom.endswith("f16x2") else DOMINANT)
         # the same kernel with nothing running beside it (weight gradients back on the main stream): what the kernel
         # itself reaches, without the time-sharing the as-run figure above includes
         alone = None
@@ -347,8 +357,8 @@ def main():
             "kernel": dom_name, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream of each call (main stream, or the weight-gradient side stream), %d instrumented steps of the same eager step after the timed region" % nprof,
-            "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<3,2,2,2,2> (bf16x3); igemm128x128_f16x2 = conv_igemm_bf3_frag_kernel<2,2,2,2,2> (forward, f16x2 split: ceiling 2500/3); igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel (small-M layers, waves split K); "
-                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo = conv_halo_bf3_kernel<*> (32/64-channel stride-1 layers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> (3x3 stride-2 data gradient, four parity classes fused); wgrad_bf3 = wgrad_bf3_kernel<*>; "
+            "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<3,2,2,2,2> (bf16x3); igemm128x128_f16x2 / igemm128x256_f16x2 = conv_igemm_bf3_frag_kernel<2,2,2,2,2> / <2,2,2,2,4> (f16x2 split: ceiling 2500/3; the 128x256 eight-wave tile where Cout % 256 == 0 and it still yields >= 256 blocks); igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel (small-M layers, waves split K); "
+                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo = conv_halo_bf3_kernel<*> (32/64-channel stride-1 layers), halo_f16x2 = conv_halo_f16_c32_kernel (32 -> <=32 channels, filter in registers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> (3x3 stride-2 data gradient, four parity classes fused); wgrad_bf3 = wgrad_bf3_kernel<*>; "
                                    "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers)") if BF3 else
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},
@@ -363,7 +373,7 @@ def main():
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dconv3.json")))
         pmc = pmcs[-1] if pmcs else ""
         if BF3 and pmc:
-            want = "frag_kernel<2" if dom.endswith("f16x2") else "frag_kernel<3"
+            want = ("frag_kernel<2, 2, 2, 2, 4" if dom.startswith("igemm128x256") else "frag_kernel<2") if dom.endswith("f16x2") else "frag_kernel<3"
             items = sorted(json.load(open(pmc)).items(), key=lambda kv: want not in kv[0])                  # the reported instance first
             for k, v in items:
                 if "conv_igemm_bf3_frag_kernel" in k and "hbm_bytes" in v:

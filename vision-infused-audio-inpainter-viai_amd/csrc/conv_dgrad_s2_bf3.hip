@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         __syncthreads();
     }
 
+    const float inv_bw = 1.0f / (float)BW, inv_bh = 1.0f / (float)BH;
     const float inv = (NP == 2) ? 1.0f / (ascale * F16_WSCALE) : 1.0f;      // applied at the store: scaling the 128 accumulators in place costs a second register set
     // ---------------------------------------------------------------- epilogue: four classes, 2 x 2 pixel quads
     const int half = lane >> 5, col = lane & 31;
@@ -178,7 +179,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
             const int m = m0 + (wm * TM + i) * 32 + row;
             if (m < a.M && co < a.Cout) {
-                int bx = m % BW; int t = m / BW; int by = t % BH; int n = t / BH;
+                // m < 2^22 (viai_dgrad_s2_ok): float reciprocal + one correction step instead of four integer divisions per
+                // row -- with K = 128 the divisions of this epilogue were 70 % of the kernel's VALU instructions
+                int t = (int)((float)m * inv_bw); int bx = m - t * BW;
+                if (bx < 0) { --t; bx += BW; } else if (bx >= BW) { ++t; bx -= BW; }
+                int n = (int)((float)t * inv_bh); int by = t - n * BH;
+                if (by < 0) { --n; by += BH; } else if (by >= BH) { ++n; by -= BH; }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const size_t opix = ((size_t)n * g.OH + 2 * by + (c >> 1)) * g.OW + 2 * bx + (c & 1);
@@ -198,6 +204,7 @@ bool viai_dgrad_s2_ok(const viai_conv2d* c) {
     if ((c->IH & 1) || (c->IW & 1) || c->Cout % 32 != 0 || (c->C1 + c->C2) % 64 != 0) return false;
     if (c->C2 > 0 && c->C1 % 32 != 0) return false;
     // enough 128-pixel x 64-channel tiles to occupy the chip; smaller layers go class by class through the split-K kernel
+    if ((long)c->N * (c->IH / 2) * (c->IW / 2) >= (1L << 22)) return false;      // epilogue index arithmetic in fp32
     long blocks = (((long)c->N * (c->IH / 2) * (c->IW / 2) + 127) / 128) * ((c->C1 + c->C2) / 64);
     return blocks >= 256;
 }
