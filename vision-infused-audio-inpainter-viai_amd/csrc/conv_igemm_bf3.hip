@@ -15,6 +15,10 @@
 #include "viai_common.h"
 #include "viai_internal.h"
 #include "viai_bf3.h"
+// timing ablation of the wide kernel: bit 0 no weight-fragment loads, bit 1 no activation loads, bit 2 no split / LDS stores
+#ifndef VIAI_ABL
+#define VIAI_ABL 0
+#endif
 #include <cstdlib>
 
 namespace {
@@ -234,7 +238,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf3_frag_kernel(const
         for (int j = 0; j < NA; ++j) {
             const int dead_t = (int)(((tapok[j] >> tt) & 1u) - 1u) & OOB;        // tap outside the image for this row
             const int off = (((pixbase[j] + toff) * cs + coff) * 4) | dead_t | dead_l | dead_s;
+#if VIAI_ABL & 2
+            raw[j] = u32x4{(unsigned)off, 0u, 0u, 0u};
+#else
             raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+#endif
         }
     };
     // B fragments of one 16-deep k-step: (tap t, channel offset c) -> 3 planes x TN tiles
@@ -248,7 +256,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf3_frag_kernel(const
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int p = 0; p < NP; ++p)
+#if VIAI_ABL & 1
+                bf[j][p] = u32x4{(unsigned)lane, (unsigned)koff, 0x3c003c00u, 0x3c003c00u};
+#else
                 bf[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bbase[j] | dead, koff + p * frag_plane, 0);
+#endif
     };
     auto lstore = [&](const u32x4 (&raw)[NA], int buf) {
         unsigned char* As = smem_b + buf * STAGE;
@@ -338,7 +350,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf3_frag_kernel(const
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = mfma(af[i][PA[pr]], bf1[j][PB[pr]], acc[i][j]);
         }
+#if !(VIAI_ABL & 4)
         lstore(rconv, cur ^ 1);
+#endif
         // interleave: one MFMA, then a few of the split's VALU instructions, so the split runs in the MFMA shadow
 #pragma unroll
         for (int i = 0; i < 2 * NPROD * TM * TN; ++i) {
@@ -870,7 +884,9 @@ int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
         // output channels, halving the load / split / LDS-store work per MFMA
         static int wn4 = -1;
         if (wn4 < 0) { const char* e = getenv("VIAI_F16_WN4"); wn4 = e ? atoi(e) : 1; }
-        if (wn4 && a.Cout % 256 == 0 && ((a.M + 127) / 128) * (a.Cout / 256) >= 256) return launch_bf3<true, 2, 2, 2, 4, 2>(a, st);
+        if (wn4 && a.Cout % 256 == 0 && ((a.M + 127) / 128) * (a.Cout / 256) >= 256) {
+            return launch_bf3<true, 2, 2, 2, 4, 2>(a, st);
+        }
         return launch_bf3<true, 2, 2, 2, 2, 2>(a, st);
     }
     if (a.wfrag) return launch_bf3<true, 2, 2, 2, 2>(a, st);
