@@ -235,6 +235,65 @@ __global__ __launch_bounds__(256) void cout1_fwd_kernel(const DirectArgs a) {
     }
 }
 
+// Row-run form for 3 x 3 / pad 1 (output width a multiple of L): a lane group computes L consecutive output pixels of one row from
+// the (L + 2) x 3 input vectors it fetches up front (all loads in flight at once), so every input vector is fetched
+// 3 (L + 2) / L times instead of nine, and the pixel index is decoded once per run.  FWD: tap offsets ascend with the tap index (Conv2d).
+template <int LPP, int CPL, int L, bool FWD>
+__global__ __launch_bounds__(256) void cout1_fwd_run_kernel(const DirectArgs a) {
+    constexpr int KH = 3, KW = 3;
+    const int cl = threadIdx.x % LPP;
+    f32x4 wv[KH * KW][CPL];
+#pragma unroll
+    for (int t = 0; t < KH * KW; ++t)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) wv[t][c] = *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.Cin + (c * LPP + cl) * 4);
+    const float bias = a.bias ? a.bias[0] : 0.f;
+    constexpr int GPB = 256 / LPP;                                  // lane groups (= runs in flight) per block
+    const int rpr = a.OW / L, nruns = a.N * a.OH * rpr;
+    for (int run = blockIdx.x * GPB + threadIdx.x / LPP; run < nruns; run += gridDim.x * GPB) {
+        const int rx = run % rpr; int r_ = run / rpr; const int oy = r_ % a.OH, n = r_ / a.OH;
+        const int ox0 = rx * L;
+        const float* rowp[KH]; bool rowok[KH];
+#pragma unroll
+        for (int r = 0; r < KH; ++r) {
+            const int iy = oy + tap_dy(a, r);
+            rowok[r] = (unsigned)iy < (unsigned)a.IH;
+            rowp[r] = a.x + ((size_t)(n * a.IH + (rowok[r] ? iy : 0)) * a.IW) * a.Cin + cl * 4;
+        }
+        auto column = [&](f32x4 (&col)[KH][CPL], int ix) {           // input column ix of the three rows (zeros outside)
+            const bool cok = (unsigned)ix < (unsigned)a.IW;
+#pragma unroll
+            for (int r = 0; r < KH; ++r)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(rowp[r] + (size_t)(cok ? ix : 0) * a.Cin + c * LPP * 4);
+                    col[r][c] = (cok & rowok[r]) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        };
+        f32x4 win[L + 2][KH][CPL];                                  // input columns ox0 - 1 .. ox0 + L, all requested up front
+#pragma unroll
+        for (int j = 0; j < L + 2; ++j) column(win[j], ox0 - 1 + j);
+#pragma unroll
+        for (int p = 0; p < L; ++p) {
+            float accv = 0.f;
+#pragma unroll
+            for (int r = 0; r < KH; ++r)
+#pragma unroll
+                for (int q = 0; q < KW; ++q) {
+                    const int j = FWD ? q : KW - 1 - q;              // window column of tap q: ix = ox + tap_dx(q)
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        const f32x4 xv = win[p + j][r][c], w = wv[r * KW + q][c];
+                        accv += xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3];
+                    }
+                }
+#pragma unroll
+            for (int o = LPP / 2; o > 0; o >>= 1) accv += __shfl_xor(accv, o, 64);
+            if (cl == 0) a.y[(size_t)(n * a.OH + oy) * a.OW + ox0 + p] = viai_act(accv + bias, a.act, a.slope);
+        }
+    }
+}
+
 // dx[q][ci] = sum_t dy[o_t(q)] * wp[t][ci]; thread = (pixel lane, fixed channel quad)
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void cout1_dgrad_kernel(const DirectArgs a) {
@@ -261,6 +320,51 @@ __global__ __launch_bounds__(256) void cout1_dgrad_kernel(const DirectArgs a) {
             }
         }
         *reinterpret_cast<f32x4*>(a.dx + (size_t)q * a.Cin + c4 * 4) = v;
+    }
+}
+
+// Row-run form of the Cout = 1 data gradient (3 x 3 / pad 1, width a multiple of L): the (L + 2) x 3 dy values of a run of L input
+// pixels are fetched once, then every pixel is 9 float4 FMAs and one float4 store.
+template <int L, bool FWD>
+__global__ __launch_bounds__(256) void cout1_dgrad_run_kernel(const DirectArgs a) {
+    constexpr int KH = 3, KW = 3, WN_ = L + KW - 1;
+    const int c4n = a.Cin / 4;              // divides 256
+    const int c4 = threadIdx.x % c4n;
+    f32x4 wv[KH * KW];
+#pragma unroll
+    for (int t = 0; t < KH * KW; ++t) wv[t] = *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.Cin + c4 * 4);
+    const int gpb = 256 / c4n;
+    const int rpr = a.IW / L, nruns = a.N * a.IH * rpr;
+    for (int run = blockIdx.x * gpb + threadIdx.x / c4n; run < nruns; run += gridDim.x * gpb) {
+        const int rx = run % rpr; int r_ = run / rpr; const int iy = r_ % a.IH, n = r_ / a.IH;
+        const int ix0 = rx * L;
+        float win[KH][WN_];                                         // win[r][j] = dy(oy_r, ix0 - 1 + j)
+#pragma unroll
+        for (int r = 0; r < KH; ++r) {
+            const int oy = iy - tap_dy(a, r);
+            const bool yok = (unsigned)oy < (unsigned)a.OH;
+            const float* row = a.dy + (size_t)(n * a.OH + (yok ? oy : 0)) * a.OW;
+#pragma unroll
+            for (int j = 0; j < WN_; ++j) {
+                const int ox = ix0 - 1 + j;
+                const bool ok = yok & ((unsigned)ox < (unsigned)a.OW);
+                const float v = row[ok ? ox : 0];
+                win[r][j] = ok ? v : 0.f;
+            }
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(a.dx + ((size_t)(n * a.IH + iy) * a.IW + ix0) * a.Cin + c4 * 4);
+#pragma unroll
+        for (int p = 0; p < L; ++p) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < KH; ++r)
+#pragma unroll
+                for (int s_ = 0; s_ < KW; ++s_) {
+                    const int j = p + (FWD ? (KW - 1 - s_) : s_);    // ox = ix - tap_dx(s): column ox - ix0 + 1
+                    v += wv[r * KW + s_] * win[r][j];
+                }
+            dst[(size_t)p * c4n] = v;
+        }
     }
 }
 
@@ -303,30 +407,107 @@ __global__ __launch_bounds__(256) void cout1_wgrad_kernel(const DirectArgs a, in
     }
 }
 
-// dw[co*s_co + ci*s_ci + t] (+)= sum_z ws[z][t][co][ci];  64 outputs x 4 z-lanes per block, fixed order
+// Row-run form of the same sum (image width a multiple of L): a thread walks runs of L consecutive input pixels of one row.
+// The (L + KW - 1) x KH dy values a run touches are fetched into registers once, so the pixel loop is one float4 load of x
+// and KH*KW float4 FMAs per pixel -- no integer division, no conditional dy load per tap and pixel (the per-pixel form above
+// issued 10 vector-memory instructions and ~100 index instructions per KB of x: 322 us on the 16 x 256 x 256 x 32 layer whose
+// 134 MB stream in 27 us).  Thread (cg, pg) takes runs base + pg + PG * i; partial sums as above.
+// FWD: tap offsets ascend with s (Conv2d); otherwise they descend (ConvTranspose2d) -- keeps every window index a constant
+template <int KH, int KW, int L, bool FWD>
+__global__ __launch_bounds__(256) void cout1_wgrad_run_kernel(const DirectArgs a, int runs_per_lane) {
+    constexpr int T = KH * KW, WN_ = L + KW - 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [PG][T][Cin]
+    const int CG = a.Cin / 4;
+    const int PG = 256 / CG;
+    const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rpr = a.IW / L;                                       // runs per row
+    const int nruns = a.N * a.IH * rpr;
+    // window column j of a run holds dy at ox = ix0 + j - (KW - 1) + lo, where lo = min over taps of -tap_dx; tap s reads
+    // column (pixel index) + off[s]
+    const int dx_first = tap_dx(a, 0), dx_last = tap_dx(a, KW - 1);
+    const int dxmax = dx_first > dx_last ? dx_first : dx_last;    // taps are dx_first + s * step, step = +-1
+    for (int i = 0; i < runs_per_lane; ++i) {
+        const int run = (blockIdx.x * runs_per_lane + i) * PG + pg;
+        if (run >= nruns) break;
+        const int rx = run % rpr; int r_ = run / rpr; const int iy = r_ % a.IH, n = r_ / a.IH;
+        const int ix0 = rx * L;
+        float win[KH][WN_];                                         // win[r][j] = dy(oy_r, ix0 - dxmax + j)
+#pragma unroll
+        for (int r = 0; r < KH; ++r) {
+            const int oy = iy - tap_dy(a, r);
+            const bool yok = (unsigned)oy < (unsigned)a.OH;
+            const float* row = a.dy + (size_t)(n * a.OH + (yok ? oy : 0)) * a.OW;
+#pragma unroll
+            for (int j = 0; j < WN_; ++j) {
+                const int ox = ix0 - dxmax + j;
+                const bool ok = yok & ((unsigned)ox < (unsigned)a.OW);
+                const float v = row[ok ? ox : 0];
+                win[r][j] = ok ? v : 0.f;
+            }
+        }
+        const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.IH + iy) * a.IW + ix0) * a.Cin + cg * 4);
+#pragma unroll
+        for (int p0 = 0; p0 < L; p0 += 4) {
+            f32x4 xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] = xp[(size_t)(p0 + u) * CG];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < KH; ++r)
+#pragma unroll
+                    for (int s_ = 0; s_ < KW; ++s_) {
+                        // ox = ix - tap_dx(s), column = ox - ix0 + dxmax: p + KW-1-s (ascending taps) or p + s (descending)
+                        const int jo = FWD ? (KW - 1 - s_) : s_;
+                        const int j = (p0 + u) + jo;
+                        acc[r * KW + s_] += xv[u] * win[r][j];
+                    }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) *reinterpret_cast<f32x4*>(smem + ((size_t)pg * T + t) * a.Cin + cg * 4) = acc[t];
+    __syncthreads();
+    for (int i = tid; i < T * a.Cin; i += 256) {
+        float s = 0.f;
+        for (int k = 0; k < PG; ++k) s += smem[(size_t)k * T * a.Cin + i];
+        a.ws[(size_t)blockIdx.x * T * a.Cin + i] = s;
+    }
+}
+
+// dw[co*s_co + ci*s_ci + t] (+)= sum_z ws[z][t][co][ci];  (256 / ZL) outputs x ZL z-lanes per block, fixed order.
+// ZL = 4 for the big weight tensors (bandwidth-bound: 64 consecutive outputs per load instruction); ZL = 32 when there are
+// few outputs but many slabs (the Cin = 1 / Cout = 1 / 32-channel layers: 288 ... 9216 outputs x up to 2048 slabs, where four
+// lanes walking 512 slabs each took longer than the gradient kernel itself).
+template <int ZL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nz, int T,
                                                            int Cout, int Cin, long s_co, long s_ci, int accumulate) {
-    __shared__ float red[4][64];
+    constexpr int NO = 256 / ZL;
+    __shared__ float red[ZL][NO];
     const long total = (long)T * Cout * Cin;
-    const int il = threadIdx.x & 63, zl = threadIdx.x >> 6;
-    const long i = blockIdx.x * 64L + il;
+    const int il = threadIdx.x % NO, zl = threadIdx.x / NO;
+    const long i = blockIdx.x * (long)NO + il;
     float s = 0.f;
     if (i < total) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int z = zl;
-        for (; z + 12 < nz; z += 16) {
+        for (; z + 3 * ZL < nz; z += 4 * ZL) {
             s0 += ws[(size_t)z * total + i];
-            s1 += ws[(size_t)(z + 4) * total + i];
-            s2 += ws[(size_t)(z + 8) * total + i];
-            s3 += ws[(size_t)(z + 12) * total + i];
+            s1 += ws[(size_t)(z + ZL) * total + i];
+            s2 += ws[(size_t)(z + 2 * ZL) * total + i];
+            s3 += ws[(size_t)(z + 3 * ZL) * total + i];
         }
-        for (; z < nz; z += 4) s0 += ws[(size_t)z * total + i];
+        for (; z < nz; z += ZL) s0 += ws[(size_t)z * total + i];
         s = (s0 + s1) + (s2 + s3);
     }
     red[zl][il] = s;
     __syncthreads();
     if (zl == 0 && i < total) {
-        s = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < ZL; k += 4) s += (red[k][il] + red[k + 1][il]) + (red[k + 2][il] + red[k + 3][il]);
         int ci = (int)(i % Cin); long r = i / Cin; int co = (int)(r % Cout); int t = (int)(r / Cout);
         long o = co * s_co + ci * s_ci + t;
         dw[o] = accumulate ? dw[o] + s : s;
@@ -479,8 +660,10 @@ static int direct_wgrad_blocks(long pixels) {
 int viai_wgrad_reduce(const float* ws, float* dw, int nz, int T, int Cout, int Cin, long s_co, long s_ci,
                       int accumulate, hipStream_t st) {
     long total = (long)T * Cout * Cin;
-    int blocks = (int)((total + 63) / 64);
-    VIAI_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, nz, T, Cout, Cin, s_co, s_ci, accumulate);
+    if (total <= 16384 && nz >= 128)
+        VIAI_LAUNCH(wgrad_reduce_kernel<32>, dim3((int)((total + 7) / 8)), dim3(256), 0, st, ws, dw, nz, T, Cout, Cin, s_co, s_ci, accumulate);
+    else
+        VIAI_LAUNCH(wgrad_reduce_kernel<4>, dim3((int)((total + 63) / 64)), dim3(256), 0, st, ws, dw, nz, T, Cout, Cin, s_co, s_ci, accumulate);
     return viai_launch_status();
 }
 
@@ -519,6 +702,22 @@ int viai_cout1_fwd(const viai_conv2d* c, const float* x, const float* wp, const 
     long nb = ((long)a.M * lpp + 255) / 256;
     if (nb > 16384) nb = 16384;
     const int blocks = (int)nb;
+    static int runk = -1;
+    if (runk < 0) { const char* e_ = getenv("VIAI_COUT1_RUN"); runk = e_ ? atoi(e_) : 1; }
+    if (runk && c->kh == 3 && c->kw == 3 && c->ph == 1 && c->pw == 1 && a.OW % 4 == 0 && a.OW == a.IW && a.OH == a.IH) {
+        const int L = cin == 512 ? 2 : 4;                            // (L + 2) x 3 x CPL float4 of window registers
+        long nr = (long)a.N * a.OH * (a.OW / L);
+        long nb2 = (nr * lpp + 255) / 256;
+        if (nb2 > 8192) nb2 = 8192;
+        const dim3 g2((unsigned)nb2), b2(256);
+#define RUN(LPP_, CPL_, L_)                                                                                                    \
+        do { if (a.transposed) VIAI_LAUNCH((cout1_fwd_run_kernel<LPP_, CPL_, L_, false>), g2, b2, 0, st, a);                   \
+             else VIAI_LAUNCH((cout1_fwd_run_kernel<LPP_, CPL_, L_, true>), g2, b2, 0, st, a); } while (0)
+        if (cin == 32) RUN(8, 1, 4); else if (cin == 64) RUN(16, 1, 4); else if (cin == 128) RUN(32, 1, 4);
+        else if (cin == 256) RUN(64, 1, 4); else if (cin == 512) RUN(64, 2, 2); else return (int)hipErrorInvalidValue;
+#undef RUN
+        return viai_launch_status();
+    }
 #define CALL(KH, KW)                                                                                              \
     if (cin == 32) VIAI_LAUNCH((cout1_fwd_kernel<8, 1, KH, KW>), dim3(blocks), dim3(256), 0, st, a);              \
     else if (cin == 64) VIAI_LAUNCH((cout1_fwd_kernel<16, 1, KH, KW>), dim3(blocks), dim3(256), 0, st, a);        \
@@ -540,6 +739,16 @@ int viai_cout1_dgrad(const viai_conv2d* c, const float* dy, const float* wp, flo
     long nb = (total + 255) / 256;
     if (nb > 8192) nb = 8192;
     const int blocks = (int)nb;
+    static int runk = -1;
+    if (runk < 0) { const char* e_ = getenv("VIAI_COUT1_RUN"); runk = e_ ? atoi(e_) : 1; }
+    constexpr int L = 8;
+    if (runk && c->kh == 3 && c->kw == 3 && c->ph == 1 && c->pw == 1 && a.IW % L == 0 && a.OW == a.IW && a.OH == a.IH) {
+        long nb2 = ((long)a.N * a.IH * (a.IW / L) * (a.Cin / 4) + 255) / 256;
+        if (nb2 > 4096) nb2 = 4096;
+        if (a.transposed) VIAI_LAUNCH((cout1_dgrad_run_kernel<L, false>), dim3((unsigned)nb2), dim3(256), 0, st, a);
+        else VIAI_LAUNCH((cout1_dgrad_run_kernel<L, true>), dim3((unsigned)nb2), dim3(256), 0, st, a);
+        return viai_launch_status();
+    }
 #define CALL(KH, KW) VIAI_LAUNCH((cout1_dgrad_kernel<KH, KW>), dim3(blocks), dim3(256), 0, st, a)
     VIAI_WINDOW_DISPATCH(c, CALL);
 #undef CALL
@@ -562,9 +771,19 @@ int viai_cout1_wgrad(const viai_conv2d* c, const float* x, const float* dy, floa
     int ppb = (int)((q + nb - 1) / nb);
     int pg = 256 / (a.Cin / 4);
     size_t lds = (size_t)pg * T * a.Cin * sizeof(float);
+    static int runk = -1;
+    if (runk < 0) { const char* e_ = getenv("VIAI_COUT1_RUN"); runk = e_ ? atoi(e_) : 1; }
+    constexpr int L = 16;
+    if (runk && c->kh == 3 && c->kw == 3 && a.IW % L == 0 && c->ph == 1 && c->pw == 1) {
+        const long nruns = (long)a.N * a.IH * (a.IW / L);
+        const int rpl = (int)((nruns + (long)nb * pg - 1) / ((long)nb * pg));      // runs per pixel lane, so that nb slabs cover all runs
+        if (a.transposed) VIAI_LAUNCH((cout1_wgrad_run_kernel<3, 3, L, false>), dim3(nb), dim3(256), lds, st, a, rpl);
+        else VIAI_LAUNCH((cout1_wgrad_run_kernel<3, 3, L, true>), dim3(nb), dim3(256), lds, st, a, rpl);
+    } else {
 #define CALL(KH, KW) VIAI_LAUNCH((cout1_wgrad_kernel<KH, KW>), dim3(nb), dim3(256), lds, st, a, ppb)
-    VIAI_WINDOW_DISPATCH(c, CALL);
+        VIAI_WINDOW_DISPATCH(c, CALL);
 #undef CALL
+    }
     int e = viai_launch_status();
     if (e) return e;
     // conv [1][Cin][kh][kw] and convT [Cin][1][kh][kw] both flatten to ci*T + t
