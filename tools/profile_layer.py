@@ -20,16 +20,21 @@ ap.add_argument("--shape", type=int, nargs=5, default=[16, 64, 32, 256, 512], me
 ap.add_argument("--transposed", action="store_true")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--bn", action="store_true", help="BatchNorm + LeakyReLU behind the conv: the backward then takes the f16x2 gradient kernels")
-ap.add_argument("--stride", type=int, default=1)
+ap.add_argument("--stride", type=int, nargs="+", default=[1])
+ap.add_argument("--kernel", type=int, nargs=2, default=[3, 3])
+ap.add_argument("--pad", type=int, nargs=2, default=None)
 a = ap.parse_args()
 N, H, W, Ci, Co = a.shape
 x = (torch.rand(N, H, W, Ci, device="cuda") * 2 - 1).requires_grad_(True)
-wshape = (Ci, Co, 3, 3) if a.transposed else (Co, Ci, 3, 3)
+kh, kw = a.kernel
+sh, sw = (a.stride * 2)[:2]
+pad = tuple(a.pad) if a.pad else (kh // 2, kw // 2)
+wshape = (Ci, Co, kh, kw) if a.transposed else (Co, Ci, kh, kw)
 w = ((torch.rand(*wshape, device="cuda") - 0.5) * 0.1).requires_grad_(True)
 bn = torch.nn.BatchNorm2d(Co).cuda() if a.bn else None
 for _ in range(a.iters):
     ops.begin_step(x.device)
-    y = ops.conv_bn_act(x, w, None, bn, kernel=(3, 3), stride=(a.stride, a.stride), padding=(1, 1), transposed=a.transposed,
+    y = ops.conv_bn_act(x, w, None, bn, kernel=(kh, kw), stride=(sh, sw), padding=pad, transposed=a.transposed,
                         act=ops.ACT_LRELU if a.bn else ops.ACT_NONE)
     y.backward(torch.rand_like(y) - 0.5)
 torch.cuda.synchronize()

@@ -24,6 +24,13 @@ struct DirectArgs {
 __device__ __forceinline__ int tap_dy(const DirectArgs& a, int r) { return a.transposed ? a.ph - r : r - a.ph; }
 __device__ __forceinline__ int tap_dx(const DirectArgs& a, int s) { return a.transposed ? a.pw - s : s - a.pw; }
 
+// q / d and q % d for 0 <= q < 2^24 by a float reciprocal and one correction step (an integer division is ~30 instructions)
+__device__ __forceinline__ void fast_divmod(int q, int d, float inv_d, int& quo, int& rem) {
+    quo = (int)((float)q * inv_d);
+    rem = q - quo * d;
+    if (rem < 0) { --quo; rem += d; } else if (rem >= d) { ++quo; rem -= d; }
+}
+
 // All kernels are templated on the (compile-time) kernel window KH x KW so that tap offsets, validity
 // tests and the weight registers are resolved at compile time (a runtime tap loop costs ~30 VALU
 // instructions of integer division per tap per pixel and made these kernels VALU-bound).
@@ -110,9 +117,12 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
 }
 
 // dx[q] = sum_t sum_co dy[o_t(q)][co] * w[co][t]   (Cin == 1), LPP = Cout/4 lanes per input pixel
-template <int LPP, int KH, int KW>
+// SH, SW: the strides as compile-time constants (0 = use a.sh / a.sw): the tap validity test divides by them per tap and
+// pixel, and a runtime integer division is ~30 instructions
+template <int LPP, int KH, int KW, int SH = 0, int SW = 0>
 __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
     constexpr int T = KH * KW;
+    const int sh = SH ? SH : a.sh, sw = SW ? SW : a.sw;
     const int cl = threadIdx.x % LPP;
     f32x4 wv[T];
 #pragma unroll
@@ -122,22 +132,26 @@ __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
     }
     const int total = a.N * a.IH * a.IW;
     const int qstep = gridDim.x * (256 / LPP);
+    const bool small = total < (1 << 24);
+    const float inv_iw = 1.0f / (float)a.IW, inv_ih = 1.0f / (float)a.IH;
     for (int q = blockIdx.x * (256 / LPP) + threadIdx.x / LPP; q < total + (256 / LPP); q += qstep) {
         float accv = 0.f;
         const bool live = q < total;
         if (live) {
-            int ix = q % a.IW; int r_ = q / a.IW; int iy = r_ % a.IH; int n = r_ / a.IH;
+            int ix, r_, iy, n;
+            if (small) { fast_divmod(q, a.IW, inv_iw, r_, ix); fast_divmod(r_, a.IH, inv_ih, n, iy); }
+            else { ix = q % a.IW; r_ = q / a.IW; iy = r_ % a.IH; n = r_ / a.IH; }
 #pragma unroll
             for (int r = 0; r < KH; ++r) {
                 const int ny = iy - tap_dy(a, r);
-                if (ny < 0 || ny % a.sh != 0) continue;
-                const int oy = ny / a.sh;
+                if (ny < 0 || ny % sh != 0) continue;
+                const int oy = ny / sh;
                 if (oy >= a.OH) continue;
 #pragma unroll
                 for (int s_ = 0; s_ < KW; ++s_) {
                     const int nx = ix - tap_dx(a, s_);
-                    if (nx < 0 || nx % a.sw != 0) continue;
-                    const int ox = nx / a.sw;
+                    if (nx < 0 || nx % sw != 0) continue;
+                    const int ox = nx / sw;
                     if (ox >= a.OW) continue;
                     f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.Cout + cl * 4);
                     const f32x4 w = wv[r * KW + s_];
@@ -638,8 +652,19 @@ int viai_cin1_dgrad(const viai_conv2d* c, const float* dy, const float* w, float
     long tot = (long)a.N * a.IH * a.IW;
     int lpp = c->Cout / 4;
     long nb = (tot * lpp + 255) / 256;
-    if (nb > 8192) nb = 8192;
+    // 4096 blocks measured best on D.conv1 (2048 ... 8192 within 4 %; 32768+ slower: every block reloads the filter)
+    static long cap = 0;
+    if (!cap) { const char* e_ = getenv("VIAI_CIN1_DGRAD_BLOCKS"); cap = e_ ? atol(e_) : 4096; }
+    if (nb > cap) nb = cap;
     int blocks = (int)nb;
+    if (c->kh == 1 && c->kw == 4 && c->sh == 1 && c->sw == 2 && lpp == 16) {          // D.conv1
+        VIAI_LAUNCH((cin1_dgrad_kernel<16, 1, 4, 1, 2>), dim3(blocks), dim3(256), 0, st, a);
+        return viai_launch_status();
+    }
+    if (c->kh == 3 && c->kw == 3 && c->sh == 2 && c->sw == 2 && lpp == 8) {           // E.conv1
+        VIAI_LAUNCH((cin1_dgrad_kernel<8, 3, 3, 2, 2>), dim3(blocks), dim3(256), 0, st, a);
+        return viai_launch_status();
+    }
 #define CALL(KH, KW)                                                                                            \
     if (lpp == 8) VIAI_LAUNCH((cin1_dgrad_kernel<8, KH, KW>), dim3(blocks), dim3(256), 0, st, a);               \
     else if (lpp == 16) VIAI_LAUNCH((cin1_dgrad_kernel<16, KH, KW>), dim3(blocks), dim3(256), 0, st, a);        \
