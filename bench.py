@@ -159,6 +159,9 @@ class KernelTimer:
                 return "direct", 1
             if BF3 and cin > 32 and d.Cout > 32 and not (d.C2 > 0 and d.C1 % 64):
                 return "wgrad_bf3", 1                # mirror of viai_wgrad_bf3_ok (csrc/conv_wgrad_bf3.hip)
+            if (os.environ.get("VIAI_WGRAD32", "1") != "0" and d.C2 == 0 and cin <= 32 and d.Cout <= 32 and d.sh == 1 and d.sw == 1
+                    and d.kh <= 3 and d.kw <= 3 and out_hw(d)[1] % 32 == 0):
+                return "wgrad32_all_taps", 1         # mirror of viai_wgrad32_ok (csrc/conv_wgrad.hip)
             return "wgrad_mfma", 1
 
         def fam_dgrad_f16(d):                        # viai_conv2d_dgrad_f16: the f16x2 instances of the same kernels
@@ -359,7 +362,7 @@ def main():
             "how": "HIP events on the launch stream of each call (main stream, or the weight-gradient side stream), %d instrumented steps of the same eager step after the timed region" % nprof,
             "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<3,2,2,2,2> (bf16x3); igemm128x128_f16x2 / igemm128x256_f16x2 = conv_igemm_bf3_frag_kernel<2,2,2,2,2> / <2,2,2,2,4> (f16x2 split: ceiling 2500/3; the 128x256 eight-wave tile where Cout % 256 == 0 and it still yields >= 256 blocks); igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel (small-M layers, waves split K); "
                                    "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo = conv_halo_bf3_kernel<*> (32/64-channel stride-1 layers), halo_f16x2 = conv_halo_f16_c32_kernel (32 -> <=32 channels, filter in registers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> (3x3 stride-2 data gradient, four parity classes fused); wgrad_bf3 = wgrad_bf3_kernel<*>; "
-                                   "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers)") if BF3 else
+                                   "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers); wgrad32_all_taps = wgrad32_halo_kernel (fp32 MFMA, <= 32 x <= 32 channels, stride 1: all taps per block)") if BF3 else
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},
             "conv_tflops_by_kernel": {k: round(v[0] / v[1] * 1e-12, 2) for k, v in sorted(fam.items()) if v[1] > 0},

@@ -58,6 +58,10 @@ CONV_CASES = [
     ("D.conv2_2", 4, 128, 128, 128, 64, (3, 3), (2, 2), (1, 1), False, False),
     ("s2-ragged-M", 3, 214, 206, 64, 32, (3, 3), (2, 2), (1, 1), False, True),
     ("lds64x64", 4, 64, 64, 64, 128, (3, 3), (1, 1), (1, 1), False, False),
+    # all-taps weight-gradient kernel of the <= 32 x <= 32 channel stride-1 layers (output width a multiple of 32)
+    ("wg32", 2, 8, 64, 32, 32, (3, 3), (1, 1), (1, 1), False, True),
+    ("wg32T", 3, 5, 96, 32, 32, (3, 3), (1, 1), (1, 1), True, False),
+    ("wg32-16to24", 1, 4, 32, 16, 24, (3, 3), (1, 1), (1, 1), False, False),
     ("lds64x64-s2T", 2, 128, 64, 128, 96, (3, 3), (1, 1), (1, 1), True, True),
 ]
 

@@ -414,6 +414,17 @@ static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, fl
     return 0;
 }
 
+// weight-gradient split-K of the igemm-class layers: the all-taps 32-channel kernel has its own rule (one slab per block)
+static bool wgrad32(const viai_conv2d* c) {
+    if (kind_of(c) != K_IGEMM) return false;
+    ConvGeom g{}; viai_geom_fwd(c, &g);
+    return viai_wgrad32_ok(g, c->Cout, c->C1, c->C2);
+}
+static int wgrad_ksplit(const viai_conv2d* c, long M) {
+    if (wgrad32(c)) return viai_wgrad32_ksplit(M);
+    return viai_wgrad_pick_ksplit(c->Cout, cin_of(c), c->kh * c->kw, M);
+}
+
 extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
     if (!valid(c)) return 0;
     size_t fl;
@@ -428,7 +439,7 @@ extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
     default: {
         int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
         long M = (long)c->N * oh * ow;
-        int ks = viai_wgrad_pick_ksplit(c->Cout, cin_of(c), c->kh * c->kw, M);
+        int ks = wgrad_ksplit(c, M);
         fl = (size_t)ks * viai_conv2d_packed_floats(c);
     } }
     // + column-sum partials for the bias gradient
@@ -486,9 +497,10 @@ static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, con
         a.x = x; a.x2 = x2; a.dy = dy; a.ws = ws; a.C1 = c->C1; a.C2 = c->C2; a.Cout = c->Cout; a.M = (int)M;
         a.amax = amax;
         viai_geom_fwd(c, &a.g);
-        int ks = viai_wgrad_pick_ksplit(c->Cout, Cin, T, M);
+        int ks = wgrad_ksplit(c, M);
         used = (size_t)ks * viai_conv2d_packed_floats(c);
-        e = (bf3_enabled() && viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2)) ? viai_wgrad_bf3_launch(a, ks, st) : viai_wgrad_mfma_launch(a, ks, st);
+        e = wgrad32(c) ? viai_wgrad32_launch(a, ks, st)
+          : (bf3_enabled() && viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2)) ? viai_wgrad_bf3_launch(a, ks, st) : viai_wgrad_mfma_launch(a, ks, st);
         if (e) return e;
         if (c->transposed) e = viai_wgrad_reduce(ws, dw, ks, T, c->Cout, Cin, T, (long)c->Cout * T, accumulate, st);
         else e = viai_wgrad_reduce(ws, dw, ks, T, c->Cout, Cin, (long)Cin * T, T, accumulate, st);

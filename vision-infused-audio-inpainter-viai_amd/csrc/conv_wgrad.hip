@@ -202,6 +202,123 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
     }
 }
 
+// All-taps kernel for the <= 32 x <= 32 channel stride-1 layers (3 x 3 window, output width a multiple of 32).  The per-tap
+// kernel above re-reads the dy and x tiles of a pixel chunk once per tap (nine blocks, 72 KB per 32-pixel chunk through L2
+// and the vector-memory path: 57 TFLOP/s).  Here a block owns a slab of 32-pixel row chunks and ALL taps: per chunk it stages
+// the dy tile (32 px x 32 co) and the 3 x 34 pixel x patch once (17 KB), and tap t's B operand is the same patch read at a
+// row / column offset -- v_mfma_f32_32x32x2_f32 takes ONE value per lane, so a shifted read is just another LDS address.
+// The four waves split the chunk's 16 k-steps; nine accumulator tiles per wave (144 registers).
+struct Wg32Taps { int off[9]; int slot[9]; int nt; int y0, x0; };
+
+// FULL: all nine taps present (no per-tap branch in the K loop)
+template <bool FULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad32_halo_kernel(const WgradArgs a, const Wg32Taps tp) {
+    constexpr int PW = 34, PR = 3;                   // patch: 3 rows x 34 pixels
+    constexpr int DS_F = 32 * 32, XS_F = PR * PW * 32, STAGE_F = DS_F + XS_F;
+    constexpr int NX = (PR * PW * 8 + 255) / 256;    // x float4 per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];           // [2][Ds | Xs], reused by the final reduction
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int z = blockIdx.x;
+    const int Cin = a.C1;
+    constexpr int OOB = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)g.N * g.IH * g.IW * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((long)a.M * a.Cout * 4), 0x00020000);
+    const int chunk0 = z * a.chunks_per_split;
+    const int nchunks_total = a.M / 32;
+    int chunk1 = chunk0 + a.chunks_per_split;
+    if (chunk1 > nchunks_total) chunk1 = nchunks_total;
+    const int cpr = g.OW / 32;                       // chunks per output row
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // staging roles: dy float4 (pixel tid >> 3, channel quad tid & 7); x float4 idx = tid + 256 j -> (row, patch column, quad)
+    const int dpx = tid >> 3, dq = tid & 7;
+    const int ddead = (dq * 4 < a.Cout) ? 0 : OOB;
+    int xr[NX], xc[NX], xq[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int idx = tid + 256 * j;
+        xr[j] = idx / (PW * 8); const int rem = idx % (PW * 8); xc[j] = rem >> 3; xq[j] = rem & 7;
+        if (idx >= PR * PW * 8 || xq[j] * 4 >= Cin) xr[j] = -1;
+    }
+    u32x4 dreg, xreg[NX];
+    auto gload = [&](int chunk_) {
+        const int chunk = __builtin_amdgcn_readfirstlane(chunk_);
+        const int cx = chunk % cpr; int r = chunk / cpr; const int oy = r % g.OH, n = r / g.OH;
+        const int ox0 = cx * 32;
+        dreg = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (((chunk * 32 + dpx) * a.Cout + dq * 4) * 4) | ddead, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int iy = oy + tp.y0 + xr[j], ix = ox0 + tp.x0 + xc[j];
+            const int dead = (((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | xr[j]) >> 31) & OOB;
+            xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ((((n * g.IH + iy) * g.IW + ix) * Cin + xq[j] * 4) * 4) | dead, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* Ds = smem + buf * STAGE_F;
+        *reinterpret_cast<u32x4*>(Ds + dpx * 32 + dq * 4) = dreg;
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+            if (xr[j] >= 0) *reinterpret_cast<u32x4*>(Ds + DS_F + (xr[j] * PW + xc[j]) * 32 + xq[j] * 4) = xreg[j];
+    };
+    if (chunk0 < chunk1) { gload(chunk0); lstore(0); }
+    __syncthreads();
+    const int half = lane >> 5, col = lane & 31;
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = __builtin_amdgcn_readfirstlane(tp.off[t < tp.nt ? t : 0]);
+    for (int c = chunk0; c < chunk1; ++c) {
+        const int cur = (c - chunk0) & 1;
+        if (c + 1 < chunk1) gload(c + 1);
+        const float* Db = smem + cur * STAGE_F + col;
+        const float* Xb = Db + DS_F;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int p = 2 * (s * 4 + wave) + half;            // this lane's pixel of the k-step
+            const float af = Db[p * 32];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (FULL || t < tp.nt) {
+                    const float bf = Xb[p * 32 + toff[t]];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t], 0, 0, 0);
+                }
+        }
+        if (c + 1 < chunk1) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    // waves 1..3 hand their partial tiles to wave 0 through LDS, one tap at a time (fixed order)
+    float* red = smem;                               // [3][16][64]
+    float* dst0 = a.ws + (size_t)z * g.wtaps * a.Cout * Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t < tp.nt) {
+            if (wave > 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[((wave - 1) * 16 + e) * 64 + lane] = acc[t][e];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                float* dst = dst0 + (size_t)tp.slot[t] * a.Cout * Cin;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[t][e];
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) v += red[(w * 16 + e) * 64 + lane];
+                    const int co = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if (co < a.Cout && col < Cin) dst[(size_t)co * Cin + col] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int TM, int TN, int WM, int WN>
 int launch_wgrad(WgradArgs& a, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, WK = 4 / (WM * WN);
@@ -223,6 +340,56 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+// layers the all-taps 32-channel kernel takes
+bool viai_wgrad32_ok(const ConvGeom& g, int Cout, int C1, int C2) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_WGRAD32"); on = e ? atoi(e) : 1; }
+    if (!on || C2 != 0 || Cout > 32 || C1 > 32 || Cout % 4 != 0 || C1 % 4 != 0 || g.run) return false;
+    if (g.mx != 1 || g.my != 1 || g.ly != 1 || g.lx != 1 || g.SH != g.OH || g.SW != g.OW || g.OW % 32 != 0 || g.ntaps < 1 || g.ntaps > 9) return false;
+    int y0 = g.dy[0], y1 = g.dy[0], x0 = g.dx[0], x1 = g.dx[0];
+    for (int t = 1; t < g.ntaps; ++t) {
+        y0 = g.dy[t] < y0 ? g.dy[t] : y0; y1 = g.dy[t] > y1 ? g.dy[t] : y1;
+        x0 = g.dx[t] < x0 ? g.dx[t] : x0; x1 = g.dx[t] > x1 ? g.dx[t] : x1;
+    }
+    return (y1 - y0) <= 2 && (x1 - x0) <= 2;
+}
+
+// split-K for that kernel: one slab per block, ONE block per CU -- the weight gradients trail on a side stream next to the main
+// chain, and at 200 registers per lane a second resident block per CU only displaces the main chain's kernels (same-box A/B:
+// 512 blocks 9.29 ms/step, 256 blocks 9.35 vs 9.40 without the kernel; standalone it is 85 -> 61 us on 16 x 128 x 128 x 32)
+int viai_wgrad32_ksplit(long M) {
+    long chunks = M / 32;
+    long ks = chunks / 4;                  // >= 4 chunks per block
+    static long cap = 0;
+    if (!cap) { const char* e = getenv("VIAI_WGRAD32_BLOCKS"); cap = e ? atol(e) : 256; if (cap < 1) cap = 256; }
+    if (ks > cap) ks = cap;
+    if (ks < 1) ks = 1;
+    return (int)ks;
+}
+
+int viai_wgrad32_launch(WgradArgs& a, int ksplit, hipStream_t st) {
+    const ConvGeom& g = a.g;
+    if (!viai_wgrad32_ok(g, a.Cout, a.C1, a.C2)) return (int)hipErrorInvalidValue;
+    Wg32Taps tp{};
+    int y0 = g.dy[0], x0 = g.dx[0];
+    for (int t = 1; t < g.ntaps; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
+    tp.nt = g.ntaps; tp.y0 = y0; tp.x0 = x0;
+    for (int t = 0; t < g.ntaps; ++t) { tp.off[t] = ((g.dy[t] - y0) * 34 + (g.dx[t] - x0)) * 32; tp.slot[t] = g.ws[t]; }
+    const long chunks = a.M / 32;
+    a.ksplit = ksplit;
+    a.chunks_per_split = (int)((chunks + ksplit - 1) / ksplit);
+    constexpr int lds = 2 * (32 * 32 + 3 * 34 * 32) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad32_halo_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad32_halo_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    if (g.ntaps == 9) VIAI_LAUNCH(wgrad32_halo_kernel<true>, dim3(ksplit), dim3(256), lds, st, a, tp);
+    else VIAI_LAUNCH(wgrad32_halo_kernel<false>, dim3(ksplit), dim3(256), lds, st, a, tp);
+    return viai_launch_status();
+}
 
 static inline int tile_of(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
 

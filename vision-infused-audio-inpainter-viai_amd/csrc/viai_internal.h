@@ -46,6 +46,9 @@ int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st);
 bool viai_dgrad_s2_ok(const viai_conv2d* c);
 int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st);
 int viai_wgrad_mfma_launch(WgradArgs& a, int ksplit, hipStream_t st);
+bool viai_wgrad32_ok(const ConvGeom& g, int Cout, int C1, int C2);
+int viai_wgrad32_ksplit(long M);
+int viai_wgrad32_launch(WgradArgs& a, int ksplit, hipStream_t st);
 int viai_wgrad_bf3_launch(WgradArgs& a, int ksplit, hipStream_t st);
 bool viai_wgrad_bf3_ok(int Cout, int C1, int C2);
 int viai_wgrad_pick_ksplit(int Cout, int Cin, int ntaps, long M);
