@@ -66,6 +66,7 @@ static bool use_bf3_fwd(const viai_conv2d* c);
 static bool use_bf3_dgrad(const viai_conv2d* c);
 static bool s2_dgrad(const viai_conv2d* c);
 static bool f16x2_enabled();
+static bool frag_dgrad(const viai_conv2d* c);
 // LDS-resident-tile kernel (conv_halo_bf3.hip) for the small-channel stride-1 layers
 static bool halo_fwd(const viai_conv2d* c) {
     if (!use_bf3_fwd(c)) return false;
@@ -94,20 +95,28 @@ static bool f16x2_enabled() {
     if (on < 0) { const char* e = getenv("VIAI_F16X2"); on = e ? atoi(e) : 1; }
     return on != 0;
 }
-// forward weight layout: 0 planar bf16x3, 1 fragment-major bf16x3, 3 fragment-major f16x2 (wide-tile forward kernel)
+// f16x2 for the LDS-weight / split-K kernels too (planar fp16 planes); VIAI_F16_PLANAR=0 keeps them on bf16x3
+static bool planar16_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_F16_PLANAR"); on = e ? atoi(e) : 1; }
+    return on != 0 && f16x2_enabled();
+}
+// forward weight layout: 0 planar bf16x3, 1 fragment-major bf16x3, 3 fragment-major f16x2 (wide-tile / halo kernels), 4 planar f16x2
 static int frag_fwd(const viai_conv2d* c) {
     if (halo_fwd(c)) return halo16_fwd(c) ? 3 : 1;
     if (viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout)) return f16x2_enabled() ? 3 : 1;
-    return 0;
+    return planar16_enabled() ? 4 : 0;
 }
 // data gradient on the f16x2 wide-tile kernel (needs the abs-max of dy): the layers whose classes run on the fragment-major kernel
 static bool dgrad_f16(const viai_conv2d* c) {
     if (!f16x2_enabled() || !use_bf3_dgrad(c)) return false;
     if (halo_dgrad(c)) return halo16_dgrad(c);
+    if (!frag_dgrad(c)) return planar16_enabled();              // LDS-weight / split-K kernels: planar fp16 planes
     return s2_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c));
 }
 static bool sk_fwd(const viai_conv2d* c) {
-    return use_bf3_fwd(c) && !frag_fwd(c) && viai_bf3_sk_ok(bf3_rows_fwd(c), c->Cout, c->C1, c->C2);
+    const int lay = frag_fwd(c);                            // planar layouts only (bf16x3 or f16x2)
+    return use_bf3_fwd(c) && (lay == 0 || lay == 4) && viai_bf3_sk_ok(bf3_rows_fwd(c), c->Cout, c->C1, c->C2);
 }
 static bool s2_dgrad(const viai_conv2d* c) { return use_bf3_dgrad(c) && viai_dgrad_s2_ok(c); }     // fused parity classes (conv_dgrad_s2_bf3.hip)
 static bool frag_dgrad(const viai_conv2d* c) { return halo_dgrad(c) || s2_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c)); }
@@ -296,7 +305,7 @@ extern "C" int viai_conv2d_pack_job(const viai_conv2d* c, int dgrad, const float
         return viai_pack_job_bf3(w, wp, c->Cout, Cin, T, (long)Cin * T, T, frag, job);
     }
     if (dgrad == 2 && !dgrad_f16(c)) return (int)hipErrorInvalidValue;
-    const int frag = dgrad == 2 ? 3 : use_bf3_dgrad(c) ? (frag_dgrad(c) ? 1 : 0) : 2;
+    const int frag = dgrad == 2 ? (frag_dgrad(c) ? 3 : 4) : use_bf3_dgrad(c) ? (frag_dgrad(c) ? 1 : 0) : 2;
     if (c->transposed) return viai_pack_job_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, frag, job);
     return viai_pack_job_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, frag, job);
 }
@@ -353,8 +362,9 @@ extern "C" int viai_conv2d_dgrad_f16_ok(const viai_conv2d* c) { return (valid(c)
 extern "C" int viai_conv2d_pack_dgrad_f16(const viai_conv2d* c, const float* w, float* wp, void* stream) {
     if (!viai_conv2d_dgrad_f16_ok(c)) return (int)hipErrorInvalidValue;
     const int T = c->kh * c->kw, Cin = cin_of(c);
-    if (c->transposed) return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, 3, (hipStream_t)stream);
-    return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, 3, (hipStream_t)stream);
+    const int lay = frag_dgrad(c) ? 3 : 4;
+    if (c->transposed) return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, lay, (hipStream_t)stream);
+    return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, lay, (hipStream_t)stream);
 }
 
 // dy_amax: device float holding max |dy| (viai_bn_act_bwd_amax): the f16x2 operand scale is derived from it on the device
@@ -406,8 +416,8 @@ static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, fl
             if (nt == 0) continue;                            // zero-filled above
             a.M = a.g.N * a.g.SH * a.g.SW;
             a.wfrag = bf3 && frag_dgrad(c);
-            if (amax != nullptr) { a.wfrag = 3; a.amax = amax; }       // f16x2 weights + dynamic operand scale
-            a.sk = bf3 && !a.wfrag && viai_bf3_sk_ok(a.M, a.Cout, a.C1, 0);
+            if (amax != nullptr) { a.wfrag = frag_dgrad(c) ? 3 : 4; a.amax = amax; }       // f16x2 weights + dynamic operand scale
+            a.sk = bf3 && (a.wfrag == 0 || a.wfrag == 4) && viai_bf3_sk_ok(a.M, a.Cout, a.C1, 0);
             int e = (bf3 && halo_dgrad(c)) ? viai_conv_halo_bf3_launch(a, st) : bf3 ? viai_conv_igemm_bf3_launch(a, st) : viai_conv_igemm_launch(a, st);
             if (e) return e;
         }

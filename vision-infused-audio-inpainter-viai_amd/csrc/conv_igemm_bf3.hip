@@ -383,21 +383,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf3_frag_kernel(const
 
 // Variant for narrow / small tiles: weights as three row-major bf16 planes [plane][co][tap][ci], staged through LDS
 // next to the activation planes (one LDS stage, two barriers per chunk).
-template <int TM, int TN, int WM, int WN>
+// NP = 3: bf16x3; NP = 2: f16x2 (planar fp16 planes, operand scales as in the fragment-major kernel)
+template <int TM, int TN, int WM, int WN, int NP = 3>
 __global__ __launch_bounds__(256) void conv_igemm_bf3_lds_kernel(const ConvArgs a) {
     constexpr int BK = BF3_BK;
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int NA = BM / 32;                         // A float4 per thread per chunk (8 quads per row)
-    constexpr int NBQ = (3 * BN * 4 + 255) / 256;       // B 16-byte pieces per thread per chunk
+    constexpr int NBQ = (NP * BN * 4 + 255) / 256;      // B 16-byte pieces per thread per chunk
+    constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int APLANE = BM * BF3_PITCH, BPLANE = BN * BF3_PITCH;
     static_assert(WM * WN == 4, "config");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* As = smem_b;                         // [3][BM][80]
-    unsigned char* Bs = smem_b + 3 * APLANE;            // [3][BN][80]
+    unsigned char* Bs = smem_b + NP * APLANE;           // [NP][BN][80]
 
     const ConvGeom& g = a.g;
+    const float ascale = (NP == 2 && a.amax != nullptr) ? f16_scale_from_amax(a.amax) : F16_ASCALE;
+    const float alim = f16_clamp_for_scale(ascale);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -426,11 +430,11 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_lds_kernel(const ConvArgs 
         int idx = tid + 256 * j;
         int plane = idx / (BN * 4), rem = idx % (BN * 4), row = rem >> 2, q16 = rem & 3;
         int co = n0 + row;
-        bsrc[j] = (idx < 3 * BN * 4 && co < a.Cout) ? (int)(plane * wplane + ((long)co * g.wtaps * Cin) * 2 + q16 * 16) : OOB;
-        bdst[j] = (idx < 3 * BN * 4) ? plane * BPLANE + row * BF3_PITCH + q16 * 16 : -1;
+        bsrc[j] = (idx < NP * BN * 4 && co < a.Cout) ? (int)(plane * wplane + ((long)co * g.wtaps * Cin) * 2 + q16 * 16) : OOB;
+        bdst[j] = (idx < NP * BN * 4) ? plane * BPLANE + row * BF3_PITCH + q16 * 16 : -1;
     }
     const long in_pixels = (long)g.N * g.IH * g.IW;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(3 * wplane), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(NP * wplane), 0x00020000);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -476,18 +480,27 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_lds_kernel(const ConvArgs 
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const f32x4 v = __builtin_bit_cast(f32x4, areg[j]);
-            unsigned a1, a2, a3, b1, b2, b3;
-            split3_pair(v[0], v[1], a1, a2, a3);
-            split3_pair(v[2], v[3], b1, b2, b3);
-            const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
             unsigned char* d = As + (r0 + 32 * j) * BF3_PITCH + q * 8;
-            *reinterpret_cast<u32x2*>(d) = p1;
-            *reinterpret_cast<u32x2*>(d + APLANE) = p2;
-            *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+            if constexpr (NP == 3) {
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3_pair(v[0], v[1], a1, a2, a3);
+                split3_pair(v[2], v[3], b1, b2, b3);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+                *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+            } else {
+                unsigned a1, a2, b1, b2;
+                split2_pair(v[0], v[1], ascale, alim, a1, a2);
+                split2_pair(v[2], v[3], ascale, alim, b1, b2);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NBQ; ++j)
-            if ((3 * BN * 4) % 256 == 0 || bdst[j] >= 0) *reinterpret_cast<u32x4*>(Bs + bdst[j]) = breg[j];
+            if ((NP * BN * 4) % 256 == 0 || bdst[j] >= 0) *reinterpret_cast<u32x4*>(Bs + bdst[j]) = breg[j];
     };
 
     int t_next = 0, c_next = 0;
@@ -509,35 +522,40 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_lds_kernel(const ConvArgs 
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 af[TM][3], bf[TN][3];
+            u32x4 af[TM][NP], bf[TN][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    af[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + aoff + i * 32 * BF3_PITCH + ks * 32));
+                for (int p = 0; p < NP; ++p)
+                    af[i][p] = *reinterpret_cast<const u32x4*>(As + p * APLANE + aoff + i * 32 * BF3_PITCH + ks * 32);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bf[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * BPLANE + boff + j * 32 * BF3_PITCH + ks * 32));
+                for (int p = 0; p < NP; ++p)
+                    bf[j][p] = *reinterpret_cast<const u32x4*>(Bs + p * BPLANE + boff + j * 32 * BF3_PITCH + ks * 32);
+            // smallest terms first: bf16x3 a2b2 a3b1 a1b3 a2b1 a1b2 a1b1; f16x2 a2b1 a1b2 a1b1
+            constexpr int PA[6] = {1, NP == 3 ? 2 : 0, 0, 1, 0, 0}, PB[6] = {NP == 3 ? 1 : 0, NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pr = 0; pr < NPROD; ++pr) {
+                        if constexpr (NP == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][PA[pr]]), __builtin_bit_cast(bf16x8, bf[j][PB[pr]]), acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][PA[pr]]), __builtin_bit_cast(f16x8, bf[j][PB[pr]]), acc[i][j], 0, 0, 0);
+                    }
         }
         __syncthreads();                 // every wave is done reading this chunk
         if (more) lstore();
         __syncthreads();
     }
 
+    if constexpr (NP == 2) {                     // undo the operand scales (exact powers of two)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] *= 1.0f / (ascale * F16_WSCALE);
+    }
     bf3_epilogue<TM, TN, WM, WN>(a, acc, smem_b, lane, wm, wn, m0, n0, bm);
 }
 
@@ -546,17 +564,20 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_lds_kernel(const ConvArgs 
 // (16x more blocks than 64 x 64 tiles x 4 waves would give per wave-tile) and the epilogue (bias / activation /
 // BatchNorm partials) stays fused: the four partial accumulators are summed through LDS and wave 0 finishes the tile.
 // Planar weights [plane][co][tap][ci] staged through LDS, one stage, register-prefetched global loads.
+template <int NP>
 __global__ __launch_bounds__(256) void conv_igemm_bf3_sk_kernel(const ConvArgs a) {
     constexpr int BM = 32, BN = 32, BK = 64;
     constexpr int PITCH = BK * 2 + 16;                  // 144-byte rows: conflict-free ds_read_b128
     constexpr int APLANE = BM * PITCH, BPLANE = BN * PITCH;
-    constexpr int NA = 2, NBQ = 3;                      // A float4 / B 16-byte pieces per thread per chunk
+    constexpr int NA = 2, NBQ = NP;                     // A float4 / B 16-byte pieces per thread per chunk
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* As = smem_b;                         // [3][32][144]
-    unsigned char* Bs = smem_b + 3 * APLANE;            // [3][32][144]
+    unsigned char* Bs = smem_b + NP * APLANE;           // [NP][32][144]
 
     const ConvGeom& g = a.g;
+    const float ascale = (NP == 2 && a.amax != nullptr) ? f16_scale_from_amax(a.amax) : F16_ASCALE;
+    const float alim = f16_clamp_for_scale(ascale);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -595,7 +616,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_sk_kernel(const ConvArgs a
         bdst[j] = plane * BPLANE + row * PITCH + q16 * 16;
     }
     const long in_pixels = (long)g.N * g.IH * g.IW;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(3 * wplane), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(NP * wplane), 0x00020000);
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -640,14 +661,23 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_sk_kernel(const ConvArgs a
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const f32x4 v = __builtin_bit_cast(f32x4, R.a[j]);
-            unsigned a1, a2, a3, b1, b2, b3;
-            split3_pair(v[0], v[1], a1, a2, a3);
-            split3_pair(v[2], v[3], b1, b2, b3);
-            const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
             unsigned char* d = As + (r0 + 16 * j) * PITCH + q * 8;
-            *reinterpret_cast<u32x2*>(d) = p1;
-            *reinterpret_cast<u32x2*>(d + APLANE) = p2;
-            *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+            if constexpr (NP == 3) {
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3_pair(v[0], v[1], a1, a2, a3);
+                split3_pair(v[2], v[3], b1, b2, b3);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+                *reinterpret_cast<u32x2*>(d + 2 * APLANE) = p3;
+            } else {
+                unsigned a1, a2, b1, b2;
+                split2_pair(v[0], v[1], ascale, alim, a1, a2);
+                split2_pair(v[2], v[3], ascale, alim, b1, b2);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + APLANE) = p2;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NBQ; ++j) *reinterpret_cast<u32x4*>(Bs + bdst[j]) = R.b[j];
@@ -661,18 +691,30 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_sk_kernel(const ConvArgs a
     const int foff = (lane & 31) * PITCH + wave * 32 + 16 * (lane >> 5);      // this wave's k-step of the chunk
     for (int kc = 0; kc < nchunks; ++kc) {
         gload(R);                                           // next chunk (zero-filled past the last one)
-        bf16x8 af[3], bf[3];
+        u32x4 afr[NP], bfr[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            af[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * APLANE + foff));
-            bf[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * BPLANE + foff));
+        for (int p = 0; p < NP; ++p) {
+            afr[p] = *reinterpret_cast<const u32x4*>(As + p * APLANE + foff);
+            bfr[p] = *reinterpret_cast<const u32x4*>(Bs + p * BPLANE + foff);
         }
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc0, 0, 0, 0);     // smallest partial products first
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc1, 0, 0, 0);
+        if constexpr (NP == 3) {
+            bf16x8 af[3], bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) { af[p] = __builtin_bit_cast(bf16x8, afr[p]); bf[p] = __builtin_bit_cast(bf16x8, bfr[p]); }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc0, 0, 0, 0);     // smallest partial products first
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc1, 0, 0, 0);
+        } else {
+            f16x8 af[2], bf[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) { af[p] = __builtin_bit_cast(f16x8, afr[p]); bf[p] = __builtin_bit_cast(f16x8, bfr[p]); }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0], acc0, 0, 0, 0);
+        }
         __syncthreads();
         lstore(R);
         __syncthreads();
@@ -680,6 +722,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_sk_kernel(const ConvArgs a
 
     // ---- sum the four waves' partial tiles through LDS (fixed order), wave 0 finishes
     f32x16 acc = acc0 + acc1;
+    if constexpr (NP == 2) acc *= 1.0f / (ascale * F16_WSCALE);      // undo the operand scales (exact powers of two)
     float* red = reinterpret_cast<float*>(smem_b);              // [3][16][64]
     if (wave > 0) {
 #pragma unroll
@@ -779,6 +822,19 @@ __device__ __forceinline__ void pack_planar_body(const float* __restrict__ w, un
     }
 }
 
+// planes[p][no][t][ki] (fp16, two terms of w * F16_WSCALE): the planar image of the f16x2 LDS-weight / split-K kernels
+__device__ __forceinline__ void pack_planar16_body(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+                                                   long s_no, long s_ki, int blk, int nblk) {
+    const long total = (long)n_out * taps * k_in;
+    for (long i = blk * (long)blockDim.x + threadIdx.x; i < total; i += (long)nblk * blockDim.x) {
+        int ki = (int)(i % k_in); long r = i / k_in; int t = (int)(r % taps); int no = (int)(r / taps);
+        const float x = w[no * s_no + ki * s_ki + t] * F16_WSCALE;
+        const _Float16 h1 = (_Float16)x;
+        const _Float16 h2 = (_Float16)(x - (float)h1);
+        wp[i] = __builtin_bit_cast(unsigned short, h1); wp[total + i] = __builtin_bit_cast(unsigned short, h2);
+    }
+}
+
 // fragment-major f16x2 planes (forward f16x2 kernels): same geometry as pack_frag_body, two fp16 terms of w * F16_WSCALE
 __device__ __forceinline__ void pack_frag16_body(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
                                                  long s_no, long s_ki, int blk, int nblk) {
@@ -803,6 +859,10 @@ __global__ void pack_weight_f16_frag_kernel(const float* __restrict__ w, unsigne
                                             long s_no, long s_ki) {
     pack_frag16_body(w, wp, n_out, k_in, taps, s_no, s_ki, blockIdx.x, gridDim.x);
 }
+__global__ void pack_weight_f16_planar_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
+                                              long s_no, long s_ki) {
+    pack_planar16_body(w, wp, n_out, k_in, taps, s_no, s_ki, blockIdx.x, gridDim.x);
+}
 __global__ void pack_weight_bf3_planar_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int n_out, int k_in, int taps,
                                               long s_no, long s_ki) {
     pack_planar_body(w, wp, n_out, k_in, taps, s_no, s_ki, blockIdx.x, gridDim.x);
@@ -825,7 +885,8 @@ __global__ void pack_jobs_kernel(const viai_pack_job* __restrict__ jobs, int njo
             int ki = (int)(i % j.k_in); long r = i / j.k_in; int t = (int)(r % j.taps); int no = (int)(r / j.taps);
             wp[i] = w[no * j.s_no + ki * j.s_ki + t];
         }
-    } else if (j.frag == 3) pack_frag16_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
+    } else if (j.frag == 4) pack_planar16_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
+    else if (j.frag == 3) pack_frag16_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
     else if (j.frag) pack_frag_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
     else pack_planar_body((const float*)j.w, (unsigned short*)j.wp, j.n_out, j.k_in, j.taps, j.s_no, j.s_ki, b - j.blk0, j.nblk);
 }
@@ -841,7 +902,7 @@ static int launch_bf3(ConvArgs& a, hipStream_t st) {
     if (lds < (size_t)WM * BN * sizeof(float)) lds = (size_t)WM * BN * sizeof(float);
     void (*kern)(const ConvArgs);
     if constexpr (FRAG) kern = conv_igemm_bf3_frag_kernel<NP, TM, TN, WM, WN>;
-    else kern = conv_igemm_bf3_lds_kernel<TM, TN, WM, WN>;
+    else kern = conv_igemm_bf3_lds_kernel<TM, TN, WM, WN, NP>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -869,7 +930,8 @@ static int launch_bf3_sk(ConvArgs& a, hipStream_t st) {
     a.nblk_m = (a.M + 31) / 32;
     a.nblk_n = (a.Cout + 31) / 32;
     constexpr int lds = 2 * 3 * 32 * (64 * 2 + 16);
-    VIAI_LAUNCH(conv_igemm_bf3_sk_kernel, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
+    if (a.wfrag == 4) VIAI_LAUNCH(conv_igemm_bf3_sk_kernel<2>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);       // planar f16x2 weights
+    else VIAI_LAUNCH(conv_igemm_bf3_sk_kernel<3>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
     return viai_launch_status();
 }
 
@@ -889,7 +951,13 @@ int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
         }
         return launch_bf3<true, 2, 2, 2, 2, 2>(a, st);
     }
-    if (a.wfrag) return launch_bf3<true, 2, 2, 2, 2>(a, st);
+    if (a.wfrag && a.wfrag != 4) return launch_bf3<true, 2, 2, 2, 2>(a, st);
+    if (a.wfrag == 4) {                                                        // planar f16x2 weights
+        if (bm == 64) return launch_bf3<false, 1, 1, 2, 2, 2>(a, st);
+        if (a.Cout > 64) return launch_bf3<false, 2, 2, 2, 2, 2>(a, st);
+        if (a.Cout > 32) return launch_bf3<false, 2, 1, 2, 2, 2>(a, st);
+        return launch_bf3<false, 1, 1, 4, 1, 2>(a, st);
+    }
     if (bm == 64) return launch_bf3<false, 1, 1, 2, 2>(a, st);
     if (a.Cout > 64) return launch_bf3<false, 2, 2, 2, 2>(a, st);
     if (a.Cout > 32) return launch_bf3<false, 2, 1, 2, 2>(a, st);
@@ -920,10 +988,11 @@ extern "C" int viai_pack_jobs_run(const viai_pack_job* jobs_dev, int njobs, int 
 
 int viai_pack_weight_bf3(const float* w, void* wp, int n_out, int k_in, int taps, long s_no, long s_ki, int frag, hipStream_t st) {
     if (k_in % 16 != 0) return (int)hipErrorInvalidValue;
-    long total = (long)(frag ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
+    long total = (long)((frag == 1 || frag == 3) ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    if (frag == 3) VIAI_LAUNCH(pack_weight_f16_frag_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
+    if (frag == 4) VIAI_LAUNCH(pack_weight_f16_planar_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
+    else if (frag == 3) VIAI_LAUNCH(pack_weight_f16_frag_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
     else if (frag) VIAI_LAUNCH(pack_weight_bf3_frag_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
     else VIAI_LAUNCH(pack_weight_bf3_planar_kernel, dim3(blocks), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wp), n_out, k_in, taps, s_no, s_ki);
     return viai_launch_status();
