@@ -103,14 +103,14 @@ static bool planar16_enabled() {
 }
 // forward weight layout: 0 planar bf16x3, 1 fragment-major bf16x3, 3 fragment-major f16x2 (wide-tile / halo kernels), 4 planar f16x2
 static int frag_fwd(const viai_conv2d* c) {
-    if (halo_fwd(c)) return halo16_fwd(c) ? 3 : 1;
+    if (halo_fwd(c)) return f16x2_enabled() ? 3 : 1;            // f16x2: filter in registers (32 -> <= 32 channels) or streamed
     if (viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout)) return f16x2_enabled() ? 3 : 1;
     return planar16_enabled() ? 4 : 0;
 }
 // data gradient on the f16x2 wide-tile kernel (needs the abs-max of dy): the layers whose classes run on the fragment-major kernel
 static bool dgrad_f16(const viai_conv2d* c) {
     if (!f16x2_enabled() || !use_bf3_dgrad(c)) return false;
-    if (halo_dgrad(c)) return halo16_dgrad(c);
+    if (halo_dgrad(c)) return true;
     if (!frag_dgrad(c)) return planar16_enabled();              // LDS-weight / split-K kernels: planar fp16 planes
     return s2_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c));
 }

@@ -18,8 +18,10 @@ constexpr int HT_H = 8, HT_W = 16;                 // output tile (128 pixels = 
 
 constexpr int HT_HH = HT_H + 2, HT_HW = HT_W + 2, HT_HP = HT_HH * HT_HW;   // staged patch: 10 x 18 pixels (taps span <= 3 x 3)
 
-template <int CIN, int TN>
+// NP = 3: bf16x3; NP = 2: f16x2 (two fp16 planes, three partial products; operand scale static or from a.amax)
+template <int CIN, int TN, int NP = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 && TN == 1) ? 3 : 2))) void conv_halo_bf3_kernel(const ConvArgs a, int hy0, int hx0, int ntiles) {
+    constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int PITCH = CIN * 2 + 16;             // bytes per LDS pixel row (80 / 144: conflict-free ds_read_b128)
     constexpr int Q = CIN / 4;                      // float4 per pixel
     constexpr int NL = (HT_HP * Q + 255) / 256;     // float4 per thread
@@ -31,6 +33,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [3][HP][PITCH]
 
     const ConvGeom& g = a.g;
+    const float ascale = (NP == 2 && a.amax != nullptr) ? f16_scale_from_amax(a.amax) : F16_ASCALE;
+    const float alim = f16_clamp_for_scale(ascale);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = g.OW / HT_W, tiles_y = g.OH / HT_H;
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)(in_pixels * CIN * 4), 0x00020000);
     const int NT = (a.Cout + 31) / 32;
     const int frag_plane = NT * g.wtaps * KS * 1024;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 3 * frag_plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, NP * frag_plane, 0x00020000);
 
     // patch staging: thread -> channel quad q of patch pixels h0 + (256 / Q) * j
     const int h0 = tid / Q, q = tid % Q;
@@ -70,14 +74,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
         for (int j = 0; j < NL; ++j) {
             if (prc[j] >= 0) {
                 const f32x4 v = __builtin_bit_cast(f32x4, reg[j]);
-                unsigned a1, a2, a3, b1, b2, b3;
-                split3_pair(v[0], v[1], a1, a2, a3);
-                split3_pair(v[2], v[3], b1, b2, b3);
-                const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
                 unsigned char* d = smem_h + (h0 + (256 / Q) * j) * PITCH + q * 8;
-                *reinterpret_cast<u32x2*>(d) = p1;
-                *reinterpret_cast<u32x2*>(d + PLANE) = p2;
-                *reinterpret_cast<u32x2*>(d + 2 * PLANE) = p3;
+                if constexpr (NP == 3) {
+                    unsigned a1, a2, a3, b1, b2, b3;
+                    split3_pair(v[0], v[1], a1, a2, a3);
+                    split3_pair(v[2], v[3], b1, b2, b3);
+                    const u32x2 p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3};
+                    *reinterpret_cast<u32x2*>(d) = p1;
+                    *reinterpret_cast<u32x2*>(d + PLANE) = p2;
+                    *reinterpret_cast<u32x2*>(d + 2 * PLANE) = p3;
+                } else {
+                    unsigned a1, a2, b1, b2;
+                    split2_pair(v[0], v[1], ascale, alim, a1, a2);
+                    split2_pair(v[2], v[3], ascale, alim, b1, b2);
+                    const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
+                    *reinterpret_cast<u32x2*>(d) = p1;
+                    *reinterpret_cast<u32x2*>(d + PLANE) = p2;
+                }
             }
         }
     };
@@ -87,7 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
 #pragma unroll
     for (int j = 0; j < TN; ++j) bvoff[j] = (j < NT) ? j * g.wtaps * KS * 1024 + lane * 16 : OOB;
     const int nunits = g.ntaps * U;
-    auto gloadB = [&](u32x4 (&bf)[KH][TN][3], int u_) {
+    auto gloadB = [&](u32x4 (&bf)[KH][TN][NP], int u_) {
         const int u = __builtin_amdgcn_readfirstlane(u_);
         if (u < nunits) {
             const int t = u / U, k0 = (u % U) * KH;
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
+                    for (int p = 0; p < NP; ++p)
                         bf[ks][j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bvoff[j], soff + ks * 1024 + p * frag_plane, 0);
         }
     };
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
     // MFMA row i = lane & 31 -> tile pixel (2 * wave + (i >> 4), i & 15)
     const int pr = 2 * wave + ((lane & 31) >> 4), pc = lane & 15;
     const unsigned char* abase = smem_h + ((pr - hy0) * HT_HW + (pc - hx0)) * PITCH + 16 * (lane >> 5);
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int PA[6] = {1, NP == 3 ? 2 : 0, 0, 1, 0, 0}, PB[6] = {NP == 3 ? 1 : 0, NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
     const int half = lane >> 5, col = lane & 31;
     float bv[TN];
     int co[TN];
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
         if (!PREF) load_patch(tile);
         store_patch();
         __syncthreads();
-        u32x4 bfa[KH][TN][3], bfb[KH][TN][3];           // two units of weight fragments in flight
+        u32x4 bfa[KH][TN][NP], bfb[KH][TN][NP];         // two units of weight fragments in flight
         gloadB(bfa, 0);
         gloadB(bfb, 1);
         if (PREF && it + (int)gridDim.x < ntiles) load_patch(xcd_remap(it + gridDim.x, ntiles));
@@ -140,20 +153,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
             for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) accc[j][c][e] = 0.f;
-        auto mma = [&](u32x4 (&bf)[KH][TN][3], int u_) {
+        auto mma = [&](u32x4 (&bf)[KH][TN][NP], int u_) {
             const int u = __builtin_amdgcn_readfirstlane(u_);
             const int t = u / U, k0 = (u % U) * KH;
             const unsigned char* As = abase + (g.dy[t] * HT_HW + g.dx[t]) * PITCH + k0 * 32;
 #pragma unroll
             for (int ks = 0; ks < KH; ++ks) {
-                bf16x8 af[3];
+                u32x4 af[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * PLANE + ks * 32));
+                for (int p = 0; p < NP; ++p) af[p] = *reinterpret_cast<const u32x4*>(As + p * PLANE + ks * 32);
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
+                for (int k = 0; k < NPROD; ++k)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        accc[j][k % NC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], __builtin_bit_cast(bf16x8, bf[ks][j][PB[k]]), accc[j][k % NC], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (NP == 3) accc[j][k % NC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[k]]), __builtin_bit_cast(bf16x8, bf[ks][j][PB[k]]), accc[j][k % NC], 0, 0, 0);
+                        else accc[j][k % NC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[PA[k]]), __builtin_bit_cast(f16x8, bf[ks][j][PB[k]]), accc[j][k % NC], 0, 0, 0);
+                    }
             }
         };
 #pragma unroll 1
@@ -171,6 +186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
             acc[j] = accc[j][0];
 #pragma unroll
             for (int c = 1; c < NC; ++c) acc[j] += accc[j][c];
+            if constexpr (NP == 2) acc[j] *= 1.0f / (ascale * F16_WSCALE);       // undo the operand scales (exact powers of two)
         }
 
         // ------------------------------------------------------------ epilogue of this tile
@@ -388,13 +404,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
 }
 
-template <int CIN, int TN>
+template <int CIN, int TN, int NP = 3>
 int launch_halo(ConvArgs& a, int hy0, int hx0, hipStream_t st) {
     constexpr int PITCH = CIN * 2 + 16;
-    size_t lds = (size_t)3 * HT_HP * PITCH;
+    size_t lds = (size_t)NP * HT_HP * PITCH;
+    if (lds < (size_t)4 * 32 * TN * sizeof(float)) lds = (size_t)4 * 32 * TN * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bf3_kernel<CIN, TN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bf3_kernel<CIN, TN, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
@@ -404,7 +421,7 @@ int launch_halo(ConvArgs& a, int hy0, int hx0, hipStream_t st) {
     if (per_cu > 4) per_cu = 4;
     int grid = 256 * per_cu;
     if (grid > a.nblk_m) grid = a.nblk_m;
-    VIAI_LAUNCH((conv_halo_bf3_kernel<CIN, TN>), dim3(grid), dim3(256), lds, st, a, hy0, hx0, a.nblk_m);
+    VIAI_LAUNCH((conv_halo_bf3_kernel<CIN, TN, NP>), dim3(grid), dim3(256), lds, st, a, hy0, hx0, a.nblk_m);
     return viai_launch_status();
 }
 
@@ -440,8 +457,14 @@ int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st) {
     const ConvGeom& g = a.g;
     if (!viai_conv_halo_ok(g, a.C1, a.C2, a.Cout)) return (int)hipErrorInvalidValue;
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
-    if (a.wfrag == 3) {                                        // f16x2 fragment-major weights
-        if (!viai_conv_halo16_ok(g, a.C1, a.C2, a.Cout)) return (int)hipErrorInvalidValue;
+    if (a.wfrag == 3 && !viai_conv_halo16_ok(g, a.C1, a.C2, a.Cout)) {      // f16x2, filter streamed from L2 (64-channel / wide layers)
+        int y0 = g.dy[0], x0 = g.dx[0];
+        for (int t = 1; t < g.ntaps; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
+        const bool wide = a.Cout > 32;
+        if (a.C1 == 32) return wide ? launch_halo<32, 2, 2>(a, y0, x0, st) : launch_halo<32, 1, 2>(a, y0, x0, st);
+        return wide ? launch_halo<64, 2, 2>(a, y0, x0, st) : launch_halo<64, 1, 2>(a, y0, x0, st);
+    }
+    if (a.wfrag == 3) {                                        // f16x2 fragment-major weights, filter in registers
         int y0 = g.dy[0], x0 = g.dx[0];
         for (int t = 1; t < 9; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
         HaloSlots sl;
