@@ -380,24 +380,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
         __syncthreads();                  // every wave is done reading the patch
         if (a.stat != nullptr) {          // block-local (mean, M2) over the 128 pixels of this tile
-            float* red = reinterpret_cast<float*>(smem_h);          // [4 waves][32]
+            // each wave: exact two-pass (mean, M2) of its 32 rows in registers; one LDS exchange; wave 0 merges the four with
+            // Chan's formula (equal counts).  One barrier instead of four per tile.
+            float* red = reinterpret_cast<float*>(smem_h);          // [4 waves][2][32]
             float t = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) t += acc[e];
             t += __shfl_xor(t, 32, 64);
-            if (half == 0) red[wave * 32 + col] = t;
-            __syncthreads();
-            const float mean = (red[col] + red[32 + col] + red[64 + col] + red[96 + col]) * (1.f / 128.f);
-            __syncthreads();
-            t = 0.f;
+            const float mw = t * (1.f / 32.f);
+            float m2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { float d = acc[e] - mean; t += d * d; }
-            t += __shfl_xor(t, 32, 64);
-            if (half == 0) red[wave * 32 + col] = t;
+            for (int e = 0; e < 16; ++e) { const float d = acc[e] - mw; m2 += d * d; }
+            m2 += __shfl_xor(m2, 32, 64);
+            if (half == 0) { red[(wave * 2 + 0) * 32 + col] = mw; red[(wave * 2 + 1) * 32 + col] = m2; }
             __syncthreads();
             if (wave == 0 && half == 0 && col < a.Cout) {
+                const float m0 = red[0 * 32 + col], m1 = red[2 * 32 + col], m2_ = red[4 * 32 + col], m3 = red[6 * 32 + col];
+                const float mean = 0.25f * ((m0 + m1) + (m2_ + m3));
+                float M2 = (red[1 * 32 + col] + red[3 * 32 + col]) + (red[5 * 32 + col] + red[7 * 32 + col]);
+                M2 += 32.f * (((m0 - mean) * (m0 - mean) + (m1 - mean) * (m1 - mean)) + ((m2_ - mean) * (m2_ - mean) + (m3 - mean) * (m3 - mean)));
                 a.stat[(size_t)col * a.nblk_m + tile] = mean;
-                a.stat[(size_t)(a.Cout + col) * a.nblk_m + tile] = red[col] + red[32 + col] + red[64 + col] + red[96 + col];
+                a.stat[(size_t)(a.Cout + col) * a.nblk_m + tile] = M2;
             }
             __syncthreads();              // red[] is overwritten by the next patch
         }
