@@ -13,6 +13,10 @@
 #include "viai_common.h"
 #include "viai_internal.h"
 #include "viai_bf3.h"
+// timing ablation: bit 0 no weight-fragment loads, bit 1 no dy loads, bit 2 no split / LDS stores, bit 3 no output stores
+#ifndef VIAI_ABL
+#define VIAI_ABL 0
+#endif
 
 namespace {
 
@@ -78,7 +82,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int j = 0; j < NA; ++j) {               // offset masks instead of selects: no branches in the K loop (conv_igemm_bf3.hip)
             const int dead = (((g.IH - 1 - (by_[j] + sy)) | (g.IW - 1 - (bx_[j] + sx))) >> 31) & OOB;
+#if VIAI_ABL & 2
+            raw[j] = u32x4{(unsigned)(pbase[j] + toff + dead + dead_s), 0u, 0u, 0u};
+#else
             raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (((pbase[j] + toff) * K + c0 + q * 4) * 4) | dead | dead_s, 0, 0);
+#endif
         }
     };
     auto lstore = [&](int buf) {
@@ -109,7 +117,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     auto gloadB = [&](u32x4 (&bf)[NP], int tap, int kq) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
+#if VIAI_ABL & 1
+            bf[p] = u32x4{(unsigned)lane, (unsigned)(tap + kq), 0x3c003c00u, 0x3c003c00u};
+#else
             bf[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bvoff, (tap * k16 + kq) * 1024 + p * frag_plane, 0);
+#endif
     };
 
     gloadA(0);
@@ -161,7 +173,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             }
         }
         // the other stage was last read in the previous iteration, which ended with a barrier: no barrier before the stores
+#if !(VIAI_ABL & 4)
         lstore(cur ^ 1);
+#endif
         gloadA(kc + 2);
         __syncthreads();
     }
@@ -188,8 +202,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const size_t opix = ((size_t)n * g.OH + 2 * by + (c >> 1)) * g.OW + 2 * bx + (c & 1);
+#if VIAI_ABL & 8
+                    if (acc[c][i][e] == 1.2345f) a.out[opix] = 0.f;
+#else
                     if (co < a.OC1) a.out[opix * a.OC1 + co] = acc[c][i][e] * inv;
                     else a.out2[opix * oc2 + (co - a.OC1)] = acc[c][i][e] * inv;
+#endif
                 }
             }
         }
