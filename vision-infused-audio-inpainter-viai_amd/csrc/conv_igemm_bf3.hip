@@ -683,14 +683,18 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_sk_kernel(const ConvArgs a
         for (int j = 0; j < NBQ; ++j) *reinterpret_cast<u32x4*>(Bs + bdst[j]) = R.b[j];
     };
 
-    Regs R;
+    // NP = 2: two register sets, so the loads run TWO chunks ahead (a chunk lasts ~0.45 us, about one L2 round trip: with one
+    // set every chunk waited for its rows); bf16x3 keeps one set (its larger sets cost the mid-sized layers their occupancy)
+    constexpr bool TWO = NP == 2;
+    Regs R, R2;
     gload(R);
     lstore(R);
+    gload(R);
+    if constexpr (TWO) gload(R2);
     __syncthreads();
 
     const int foff = (lane & 31) * PITCH + wave * 32 + 16 * (lane >> 5);      // this wave's k-step of the chunk
-    for (int kc = 0; kc < nchunks; ++kc) {
-        gload(R);                                           // next chunk (zero-filled past the last one)
+    auto step = [&](Regs& Rs) {                             // Rs holds chunk k+1; it is stored after the MFMAs of chunk k, then refilled
         u32x4 afr[NP], bfr[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -716,8 +720,15 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_sk_kernel(const ConvArgs a
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0], acc0, 0, 0, 0);
         }
         __syncthreads();
-        lstore(R);
+        lstore(Rs);
+        gload(Rs);                                          // chunk k+3 (two sets) or k+2 (zero-filled past the last one)
         __syncthreads();
+    };
+    if constexpr (TWO) {
+        for (int kc = 0; kc + 1 < nchunks; kc += 2) { step(R); step(R2); }
+        if (nchunks & 1) step(R);
+    } else {
+        for (int kc = 0; kc < nchunks; ++kc) step(R);
     }
 
     // ---- sum the four waves' partial tiles through LDS (fixed order), wave 0 finishes
