@@ -625,8 +625,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf3_sk_kernel(const ConvArgs a
     const int cchunks = (Cin + BK - 1) / BK;
     const int nchunks = g.ntaps * cchunks;
 
-    // global loads run one chunk ahead of the MFMAs (a three-deep register ring measured slower: the occupancy it costs
-    // the mid-sized layers outweighs the latency it hides on the smallest ones)
+    // global loads run one (bf16x3) or two (f16x2, see below) chunks ahead of the MFMAs; a three-deep ring of the larger
+    // bf16x3 sets measured slower: the occupancy it costs the mid-sized layers outweighs the latency it hides on the smallest
     struct Regs { u32x4 a[NA]; u32x4 b[NBQ]; };
     int t_ld = 0, c_ld = 0;                         // next chunk to load
     auto gload = [&](Regs& R) {
