@@ -127,6 +127,23 @@ class KernelTimer:
         def halo16(c_in, c_out, d):                  # mirror of viai_conv_halo16_ok: filter-in-registers f16x2 variant
             return F16X2 and os.environ.get("VIAI_HALO16", "1") != "0" and c_in == 32 and c_out <= 32 and d.kh == 3 and d.kw == 3
 
+        def halo_wide(c1, c2, c_out, oc1_split_ok, d, oh, ow):        # mirror of viai_conv_halo_wide_ok (csrc/conv_halo_bf3.hip)
+            if not F16X2 or os.environ.get("VIAI_HALO_WIDE", "1") == "0":
+                return None
+            if c1 % 32 or c2 % 32 or c1 < 32 or not oc1_split_ok or not (c_out in (32, 64) or c_out % 128 == 0):
+                return None
+            if c_out <= 64 and c1 + c2 <= 64 and c2 == 0:
+                return None
+            if (d.kh, d.kw, d.sh, d.sw) != (3, 3, 1, 1) or oh % 8 or ow % 16:
+                return None
+            tiles = d.N * (oh // 8) * (ow // 16)
+            if tiles * (c_out // 128 if c_out >= 128 else 1) < 192:
+                return None
+            if c_out <= 64:
+                return "halo_wide%d_f16x2" % c_out
+            wn4 = os.environ.get("VIAI_HALO_WIDE_WN4", "1") != "0" and c_out % 256 == 0 and tiles * (c_out // 256) >= 256
+            return "halo_wide256_f16x2" if wn4 else "halo_wide128_f16x2"
+
         def out_hw(d):
             oh = (d.IH - 1 - 2 * d.ph + d.kh) if d.transposed else (d.IH + 2 * d.ph - d.kh) // d.sh + 1
             ow = (d.IW - 1 - 2 * d.pw + d.kw) if d.transposed else (d.IW + 2 * d.pw - d.kw) // d.sw + 1
@@ -138,6 +155,9 @@ class KernelTimer:
                 return "direct", 1
             if halo_ok(d.C1, d.C2, d.Cout, d, *out_hw(d)):
                 return ("halo_f16x2" if F16X2 else "halo"), 1
+            hw = halo_wide(d.C1, d.C2, d.Cout, True, d, *out_hw(d))
+            if hw:
+                return hw, 1
             nm = igemm_name(out_pixels(d), d.Cout)
             if F16X2 and nm == "igemm128x128":
                 return wide_f16(out_pixels(d), d.Cout), 1                                               # conv_igemm_bf3_frag_kernel<2,...>
@@ -168,6 +188,10 @@ class KernelTimer:
 
         def fam_dgrad_f16(d):                        # viai_conv2d_dgrad_f16: the f16x2 instances of the same kernels
             f, n = fam_dgrad(d)
+            if f != "halo" and d.sh == 1 and d.sw == 1:
+                hw = halo_wide(d.Cout, 0, d.C1 + d.C2, d.C2 == 0 or d.C1 % 32 == 0, d, d.IH, d.IW)
+                if hw:
+                    return hw, 1
             if f == "igemm128x128":
                 return wide_f16(-(-(d.N * d.IH * d.IW) // n), d.C1 + d.C2), n
             return f + "_f16x2", n
@@ -328,12 +352,15 @@ def main():
         tot_t = sum(v[1] for v in fam.values())
         # dominant kernel: the 128x128 fragment-major implicit-GEMM kernel; its bf16x3 and f16x2 instances are different
         # kernels with different ceilings (2500/6 and 2500/3): report the one that holds more of the step
-        cands = [k for k in ("igemm128x128", "igemm128x128_f16x2", "igemm128x256_f16x2") if k in fam]
+        cands = [k for k in ("igemm128x128", "igemm128x128_f16x2", "igemm128x256_f16x2", "halo_wide256_f16x2", "halo_wide128_f16x2") if k in fam]
         dom = max(cands, key=lambda k: fam[k][1])
         f, t, n = fam[dom]
         ach = f / t * 1e-12
         peak = MFMA_BF16_PEAK_TFLOPS / 3.0 if dom.endswith("f16x2") else PEAK
-        dom_name = (("conv_igemm_bf3_frag_kernel<2,2,2,2,%d> (128x%dx32 f16x2 split-MFMA implicit-GEMM conv, %s waves: two fp16 terms per operand, three "
+        dom_name = (("conv_halo_wide_f16_kernel<2,%d,2,2> (stride-1 3x3 conv, 8x16-pixel x %d-channel tile, f16x2 split MFMA: the 10x18 input patch of a 32-channel "
+                     "chunk is staged once in LDS and read by all nine taps; weight fragments straight from global; forward and data-gradient launches of D.conv3)"
+                     % ((4, 256) if dom.startswith("halo_wide256") else (2, 128))) if dom.startswith("halo_wide") else
+                    ("conv_igemm_bf3_frag_kernel<2,2,2,2,%d> (128x%dx32 f16x2 split-MFMA implicit-GEMM conv, %s waves: two fp16 terms per operand, three "
                      "partial products, fp32 accumulate, fp32-grade accuracy; forward and data-gradient launches)"
                      % ((4, 256, "eight") if dom.startswith("igemm128x256") else (2, 128, "four"))) if dom.endswith("f16x2") else DOMINANT)
         # the same kernel with nothing running beside it (weight gradients back on the main stream): what the kernel
@@ -364,7 +391,7 @@ def main():
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream of each call (main stream, or the weight-gradient side stream), %d instrumented steps of the same eager step after the timed region" % nprof,
             "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<3,2,2,2,2> (bf16x3); igemm128x128_f16x2 / igemm128x256_f16x2 = conv_igemm_bf3_frag_kernel<2,2,2,2,2> / <2,2,2,2,4> (f16x2 split: ceiling 2500/3; the 128x256 eight-wave tile where Cout % 256 == 0 and it still yields >= 256 blocks); igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2[,NP]>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel<NP> (small-M layers, waves split K); a _f16x2 suffix on these = the NP = 2 instance (planar fp16 weight planes); "
-                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo[_f16x2] = conv_halo_bf3_kernel<CIN,TN,3|2> (32/64-channel stride-1 layers) and, for 32 -> <=32 channels, conv_halo_f16_c32_kernel (filter in registers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> (3x3 stride-2 data gradient, four parity classes fused); wgrad_bf3 = wgrad_bf3_kernel<*>; "
+                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo_wide{256,128,64,32}_f16x2 = conv_halo_wide_f16_kernel<2,4,2,2> / <2,2,2,2> / <2,2,2,1> / <4,1,1,1> (stride-1 3x3 layers with Cin >= 32: patch staged once per 32-channel chunk); halo[_f16x2] = conv_halo_bf3_kernel<CIN,TN,3|2> (32/64-channel stride-1 layers) and, for 32 -> <=32 channels, conv_halo_f16_c32_kernel (filter in registers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> (3x3 stride-2 data gradient, four parity classes fused); wgrad_bf3 = wgrad_bf3_kernel<*>; "
                                    "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers); wgrad32_all_taps = wgrad32_halo_kernel (fp32 MFMA, <= 32 x <= 32 channels, stride 1: all taps per block)") if BF3 else
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},
@@ -379,10 +406,10 @@ def main():
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dconv3.json")))
         pmc = pmcs[-1] if pmcs else ""
         if BF3 and pmc:
-            want = ("frag_kernel<2, 2, 2, 2, 4" if dom.startswith("igemm128x256") else "frag_kernel<2") if dom.endswith("f16x2") else "frag_kernel<3"
+            want = ("halo_wide_f16_kernel" if dom.startswith("halo_wide") else "frag_kernel<2, 2, 2, 2, 4" if dom.startswith("igemm128x256") else "frag_kernel<2") if dom.endswith("f16x2") else "frag_kernel<3"
             items = sorted(json.load(open(pmc)).items(), key=lambda kv: want not in kv[0])                  # the reported instance first
             for k, v in items:
-                if "conv_igemm_bf3_frag_kernel" in k and "hbm_bytes" in v:
+                if ("conv_igemm_bf3_frag_kernel" in k or "conv_halo_wide_f16_kernel" in k) and "hbm_bytes" in v:
                     out["roofline"]["traffic"] = round(v["hbm_bytes"])
                     out["roofline"]["traffic_note"] = (
                         "bytes per launch on D.conv3 (fwd/dgrad average; algorithmic 57 MB in + 50 MB out): 2*FETCH_SIZE + WRITE_SIZE from "

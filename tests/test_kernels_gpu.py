@@ -94,9 +94,12 @@ def test_conv_fwd_bwd_matches_torch_cpu(case):
         assert relerr(bg.grad, b.grad) < 2e-5, name
 
 
-def test_conv_virtual_concat_matches_cat():
+@pytest.mark.parametrize("shape", [(2, 9, 12), (3, 64, 128)], ids=["small", "wide-halo-tiles"])
+def test_conv_virtual_concat_matches_cat(shape):
+    """second shape: 192 tiles of 8 x 16 pixels, so the wide halo kernel takes the forward (two sources, 32 outputs) and -- behind a
+    BatchNorm in the networks -- the two-destination data gradient; without BN here the backward runs the bf16x3 kernels"""
     from viai_amd import ops
-    N, H, W = 2, 9, 12
+    N, H, W = shape
     x1 = O.cf_uniform("cc.x1", (N, 64, H, W), -1, 1).requires_grad_(True)
     x2 = O.cf_uniform("cc.x2", (N, 64, H, W), -1, 1).requires_grad_(True)
     w = O.cf_std("cc.w", (128, 32, 3, 3), 0.1).requires_grad_(True)
@@ -111,6 +114,40 @@ def test_conv_virtual_concat_matches_cat():
     assert relerr(nchw(a.grad), x1.grad) < 2e-5
     assert relerr(nchw(b.grad), x2.grad) < 2e-5
     assert relerr(wg.grad, w.grad) < 2e-5
+
+
+@pytest.mark.parametrize("cfg", [(128, 0, 32), (64, 64, 32), (32, 0, 128), (96, 0, 64), (64, 64, 128)], ids=["128to32", "cat64+64to32", "32to128", "96to64", "cat64+64to128"])
+def test_wide_halo_kernel_fwd_and_f16_backward_against_fp64(cfg):
+    """stride-1 3 x 3 transposed conv + BatchNorm(eval) at 3 x 64 x 128 (192 tiles): forward, data gradient (one or two
+    destinations) and weight gradient of the layers the wide halo kernel takes, against an fp64 evaluation."""
+    from viai_amd import ops
+    C1, C2, Co = cfg
+    N, H, W = 3, 64, 128
+    x1 = O.cf_uniform("wh.x1", (N, C1, H, W), -1, 1)
+    x2 = O.cf_uniform("wh.x2", (N, C2, H, W), -1, 1) if C2 else None
+    w = O.cf_std("wh.w", (C1 + C2, Co, 3, 3), 0.05)
+    g_, b_ = O.cf_uniform("wh.g", (Co,), 0.5, 1.5), O.cf_uniform("wh.b", (Co,), -0.5, 0.5)
+    rm, rv = O.cf_uniform("wh.rm", (Co,), -0.1, 0.1), O.cf_uniform("wh.rv", (Co,), 0.5, 1.5)
+    gy = O.cf_uniform("wh.gy", (N, Co, H, W), -1, 1)
+    xs = [t.double().requires_grad_(True) for t in ((x1, x2) if C2 else (x1,))]
+    wd = w.double().requires_grad_(True)
+    y = F.batch_norm(F.conv_transpose2d(torch.cat(xs, 1), wd, None, stride=1, padding=1), rm.double(), rv.double(), g_.double(), b_.double(), False, 0.1, 1e-5)
+    y.backward(gy.double())
+    bn = torch.nn.BatchNorm2d(Co).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(g_); bn.bias.copy_(b_); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.eval()
+    a = nhwc(x1).requires_grad_(True)
+    b2 = nhwc(x2).requires_grad_(True) if C2 else None
+    wg = w.cuda().requires_grad_(True)
+    ops.begin_step(a.device)
+    yg = ops.conv_bn_act(a, wg, None, bn, kernel=(3, 3), stride=(1, 1), padding=(1, 1), transposed=True, x2=b2, act=ops.ACT_NONE, training=False)
+    assert relerr(nchw(yg), y) < 3e-6
+    yg.backward(nhwc(gy))
+    assert relerr(nchw(a.grad), xs[0].grad) < 3e-6
+    if C2:
+        assert relerr(nchw(b2.grad), xs[1].grad) < 3e-6
+    assert relerr(wg.grad, wd.grad) < 3e-6
 
 
 @pytest.mark.parametrize("act", ["lrelu", "relu"])

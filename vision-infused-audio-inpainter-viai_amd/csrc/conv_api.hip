@@ -95,6 +95,21 @@ static bool f16x2_enabled() {
     if (on < 0) { const char* e = getenv("VIAI_F16X2"); on = e ? atoi(e) : 1; }
     return on != 0;
 }
+// wide halo kernel (conv_halo_bf3.hip, f16x2 fragment-major weights): stride-1 3 x 3 layers with Cin >= 32 and 32 / 64 / 128k outputs
+static bool halo_wide_fwd(const viai_conv2d* c) {
+    if (!f16x2_enabled() || !use_bf3_fwd(c)) return false;
+    ConvArgs a{};
+    viai_geom_fwd(c, &a.g);
+    a.C1 = c->C1; a.C2 = c->C2; a.Cout = c->Cout; a.OC1 = c->Cout; a.M = a.g.N * a.g.OH * a.g.OW;
+    return viai_conv_halo_wide_ok(a);
+}
+static bool halo_wide_dgrad(const viai_conv2d* c) {
+    if (!f16x2_enabled() || !use_bf3_dgrad(c) || c->sh != 1 || c->sw != 1) return false;
+    ConvArgs a{};
+    if (viai_geom_dgrad_class(c, 0, 0, &a.g) == 0) return false;
+    a.C1 = c->Cout; a.C2 = 0; a.Cout = cin_of(c); a.OC1 = c->C1; a.M = a.g.N * a.g.SH * a.g.SW;
+    return viai_conv_halo_wide_ok(a);
+}
 // f16x2 for the LDS-weight / split-K kernels too (planar fp16 planes); VIAI_F16_PLANAR=0 keeps them on bf16x3
 static bool planar16_enabled() {
     static int on = -1;
@@ -105,12 +120,14 @@ static bool planar16_enabled() {
 static int frag_fwd(const viai_conv2d* c) {
     if (halo_fwd(c)) return f16x2_enabled() ? 3 : 1;            // f16x2: filter in registers (32 -> <= 32 channels) or streamed
     if (viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout)) return f16x2_enabled() ? 3 : 1;
+    if (halo_wide_fwd(c)) return 3;
     return planar16_enabled() ? 4 : 0;
 }
 // data gradient on the f16x2 wide-tile kernel (needs the abs-max of dy): the layers whose classes run on the fragment-major kernel
 static bool dgrad_f16(const viai_conv2d* c) {
     if (!f16x2_enabled() || !use_bf3_dgrad(c)) return false;
     if (halo_dgrad(c)) return true;
+    if (halo_wide_dgrad(c)) return true;
     if (!frag_dgrad(c)) return planar16_enabled();              // LDS-weight / split-K kernels: planar fp16 planes
     return s2_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c));
 }
@@ -120,6 +137,8 @@ static bool sk_fwd(const viai_conv2d* c) {
 }
 static bool s2_dgrad(const viai_conv2d* c) { return use_bf3_dgrad(c) && viai_dgrad_s2_ok(c); }     // fused parity classes (conv_dgrad_s2_bf3.hip)
 static bool frag_dgrad(const viai_conv2d* c) { return halo_dgrad(c) || s2_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c)); }
+// layout of the f16x2 data-gradient image: fragment-major also for the wide halo kernel's layers
+static bool frag_dgrad16(const viai_conv2d* c) { return frag_dgrad(c) || halo_wide_dgrad(c); }
 
 static bool use_bf3_fwd(const viai_conv2d* c) {
     if (kind_of(c) != K_IGEMM) return false;
@@ -305,7 +324,7 @@ extern "C" int viai_conv2d_pack_job(const viai_conv2d* c, int dgrad, const float
         return viai_pack_job_bf3(w, wp, c->Cout, Cin, T, (long)Cin * T, T, frag, job);
     }
     if (dgrad == 2 && !dgrad_f16(c)) return (int)hipErrorInvalidValue;
-    const int frag = dgrad == 2 ? (frag_dgrad(c) ? 3 : 4) : use_bf3_dgrad(c) ? (frag_dgrad(c) ? 1 : 0) : 2;
+    const int frag = dgrad == 2 ? (frag_dgrad16(c) ? 3 : 4) : use_bf3_dgrad(c) ? (frag_dgrad(c) ? 1 : 0) : 2;
     if (c->transposed) return viai_pack_job_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, frag, job);
     return viai_pack_job_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, frag, job);
 }
@@ -316,7 +335,7 @@ extern "C" int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_
     int oh, ow;
     viai_conv2d_out_hw(c, &oh, &ow);
     long M = (long)c->N * oh * ow;
-    const int bm = (kind_of(c) == K_COUT1 || halo_fwd(c)) ? 128 : sk_fwd(c) ? 32 : viai_igemm_tile_m(M, c->Cout);
+    const int bm = (kind_of(c) == K_COUT1 || halo_fwd(c) || halo_wide_fwd(c)) ? 128 : sk_fwd(c) ? 32 : viai_igemm_tile_m(M, c->Cout);
     *rows_per_blk = bm;
     *nblk = (int)((M + bm - 1) / bm);
     return 0;
@@ -362,7 +381,7 @@ extern "C" int viai_conv2d_dgrad_f16_ok(const viai_conv2d* c) { return (valid(c)
 extern "C" int viai_conv2d_pack_dgrad_f16(const viai_conv2d* c, const float* w, float* wp, void* stream) {
     if (!viai_conv2d_dgrad_f16_ok(c)) return (int)hipErrorInvalidValue;
     const int T = c->kh * c->kw, Cin = cin_of(c);
-    const int lay = frag_dgrad(c) ? 3 : 4;
+    const int lay = frag_dgrad16(c) ? 3 : 4;
     if (c->transposed) return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, (long)c->Cout * T, T, lay, (hipStream_t)stream);
     return viai_pack_weight_bf3(w, wp, Cin, c->Cout, T, T, (long)Cin * T, lay, (hipStream_t)stream);
 }
@@ -416,7 +435,7 @@ static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, fl
             if (nt == 0) continue;                            // zero-filled above
             a.M = a.g.N * a.g.SH * a.g.SW;
             a.wfrag = bf3 && frag_dgrad(c);
-            if (amax != nullptr) { a.wfrag = frag_dgrad(c) ? 3 : 4; a.amax = amax; }       // f16x2 weights + dynamic operand scale
+            if (amax != nullptr) { a.wfrag = frag_dgrad16(c) ? 3 : 4; a.amax = amax; }       // f16x2 weights + dynamic operand scale
             a.sk = bf3 && (a.wfrag == 0 || a.wfrag == 4) && viai_bf3_sk_ok(a.M, a.Cout, a.C1, 0);
             int e = (bf3 && halo_dgrad(c)) ? viai_conv_halo_bf3_launch(a, st) : bf3 ? viai_conv_igemm_bf3_launch(a, st) : viai_conv_igemm_launch(a, st);
             if (e) return e;

@@ -11,6 +11,7 @@
 #include "viai_common.h"
 #include "viai_internal.h"
 #include "viai_bf3.h"
+#include <type_traits>
 
 namespace {
 
@@ -407,6 +408,231 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
 }
 
+// Wide-layer halo kernel (f16x2): the wide gather-GEMM kernel (conv_igemm_bf3.hip) loads and splits every input pixel once per
+// TAP; for a stride-1 3 x 3 layer that is nine times per output-channel block.  Here a block owns an 8 x 16 output tile and 64 * WN
+// output channels and walks K as (32-channel chunk, tap, k-step): per chunk the 10 x 18 pixel patch is loaded and split ONCE into
+// a two-stage LDS buffer and all nine taps read it at compile-time offsets -- 6x fewer activation loads / splits per MFMA, the
+// weight-fragment stream (fragment-major, straight from global, one (tap, k-step pair) ahead) unchanged.
+struct HaloWideSlots { int s[9]; };
+
+// WM x TM = 4 (the tile's eight rows = WM waves x TM row pairs); BN = 32 * TN * WN output channels per block:
+//   <2,2,2,2> / <2,4,2,2>: 128 / 256 channels (wide layers);  <2,2,2,1>: 64 channels;  <4,1,1,1>: 32 channels
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_wide_f16_kernel(const ConvArgs a, int hy0, int hx0, HaloWideSlots slots) {
+    static_assert(WM * TM == 4, "config");
+    constexpr int NP = 2, BN = 32 * TN * WN, NTHR = 64 * WM * WN;
+    constexpr int PITCH = 80, PLANE = HT_HP * PITCH, STAGE = NP * PLANE;
+    constexpr int RPP = NTHR / 8;                              // patch pixels staged per pass (8 lanes = 8 channel quads per pixel)
+    constexpr int NL = (HT_HP + RPP - 1) / RPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [2 stages][2 planes][180][80]
+
+    const ConvGeom& g = a.g;
+    const float ascale = a.amax != nullptr ? f16_scale_from_amax(a.amax) : F16_ASCALE;
+    const float alim = f16_clamp_for_scale(ascale);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bn = bid % a.nblk_n, tile = bid / a.nblk_n;
+    const int tiles_x = g.OW / HT_W, tiles_y = g.OH / HT_H;
+    const int tx = tile % tiles_x; const int r_ = tile / tiles_x; const int ty = r_ % tiles_y, n = r_ / tiles_y;
+    const int py = ty * HT_H + hy0, px = tx * HT_W + hx0;
+    const int Cin = a.C1 + a.C2, k16 = Cin / 16, nch = Cin / 32, nch1 = a.C1 / 32;        // chunks [0, nch1) read a.in, the rest a.in2 (virtual concat)
+    constexpr int OOB = 0x7fffffff;
+    const int NT = (a.Cout + 31) / 32;
+    const int frag_plane = NT * g.wtaps * k16 * 1024;
+    const long in_pixels = (long)g.N * g.IH * g.IW;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, NP * frag_plane, 0x00020000);
+
+    // patch staging: thread -> channel quad q of patch pixels h0 + RPP * j (pixel validity does not depend on the chunk)
+    const int h0 = tid >> 3, q = tid & 7;
+    int poff[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int h = h0 + RPP * j;
+        const int hr = h / HT_HW, hc = h - hr * HT_HW;
+        const int iy = py + hr, ix = px + hc;
+        const int dead = (((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | (HT_HP - 1 - h)) >> 31) & OOB;
+        poff[j] = ((n * g.IH + iy) * g.IW + ix) | dead;                          // pixel index (or out of range)
+    }
+    u32x4 raw[NL];
+    auto gloadA = [&](int chunk_) {
+        const int chunk = __builtin_amdgcn_readfirstlane(chunk_);
+        const int dead = chunk < nch ? 0 : OOB;
+        const bool first = chunk < nch1;
+        const int cs = first ? a.C1 : a.C2;                                      // channel stride of the source this chunk reads
+        const int c0 = first ? chunk : chunk - nch1;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? a.in : a.in2), 0, (int)(in_pixels * cs * 4), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int pd = poff[j] >> 31 | ((poff[j] == OOB) ? -1 : 0);           // all ones for an out-of-range pixel
+            raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((unsigned)poff[j] * (unsigned)cs + (unsigned)(q * 4)) * 4u) | (pd & OOB) | dead, dead ? 0 : c0 * 128, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int h = h0 + RPP * j;
+            if (h < HT_HP) {
+                const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
+                unsigned a1, a2, b1, b2;
+                split2_pair(v[0], v[1], ascale, alim, a1, a2);
+                split2_pair(v[2], v[3], ascale, alim, b1, b2);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
+                unsigned char* d = smem_h + buf * STAGE + h * PITCH + q * 8;
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + PLANE) = p2;
+            }
+        }
+    };
+    int bbase[TN], sl[9];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nt = bn * (BN / 32) + wn * TN + j;
+        bbase[j] = (nt < NT) ? nt * g.wtaps * k16 * 1024 + lane * 16 : OOB;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sl[t] = __builtin_amdgcn_readfirstlane(slots.s[t]);
+    // weight fragments of (position t, chunk cc): both k-steps
+    auto gloadB = [&](u32x4 (&b0)[TN][NP], u32x4 (&b1)[TN][NP], int t, int cc_) {
+        const int cc = __builtin_amdgcn_readfirstlane(cc_);
+        const int dead = cc < nch ? 0 : OOB;
+        const int soff = dead ? 0 : (sl[t] * k16 + cc * 2) * 1024;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                b0[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bbase[j] | dead, soff + p * frag_plane, 0);
+                b1[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bbase[j] | dead, soff + 1024 + p * frag_plane, 0);
+            }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // MFMA row r = lane & 31 of M-tile i -> tile pixel (2 (wm TM + i) + (r >> 4), r & 15); the patch origin is the window's top-left tap
+    const int aoff = ((wm * TM * 2 + ((lane & 31) >> 4)) * HT_HW + (lane & 15)) * PITCH + 16 * (lane >> 5);
+    u32x4 B0[2][TN][NP], B1[2][TN][NP];                   // two fragment sets (k-step 0 / 1 each), alternating per tap
+    gloadA(0);
+    gloadB(B0[0], B1[0], 0, 0);
+    lstore(0);
+    gloadA(1);
+    __syncthreads();
+
+    auto mma = [&](const unsigned char* As, const u32x4 (&b)[TN][NP]) {
+        u32x4 af[TM][NP];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(As + p * PLANE + i * 2 * HT_HW * PITCH);
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};        // smallest partial products first
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][PA[pr]]), __builtin_bit_cast(f16x8, b[j][PB[pr]]), acc[i][j], 0, 0, 0);
+    };
+    // one chunk: nine taps; P = fragment set of tap 0 (nine is odd, so the parity flips from chunk to chunk)
+    auto chunk = [&](int cc, auto P) {
+        constexpr int p0 = decltype(P)::value;
+        const unsigned char* S = smem_h + (cc & 1) * STAGE + aoff;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            constexpr int dummy = 0; (void)dummy;
+            const int cur = (p0 + t) & 1, nxt = cur ^ 1;
+            if (t + 1 < 9) gloadB(B0[nxt], B1[nxt], t + 1, cc);
+            else gloadB(B0[nxt], B1[nxt], 0, cc + 1);
+            const unsigned char* As = S + ((t / 3) * HT_HW + (t % 3)) * PITCH;
+            mma(As, B0[cur]);
+            mma(As + 32, B1[cur]);
+        }
+        lstore((cc & 1) ^ 1);                                  // chunk cc + 1 (loaded during this chunk) -> the other stage
+        gloadA(cc + 2);
+        __syncthreads();
+    };
+    for (int cc = 0; cc + 1 < nch; cc += 2) {
+        chunk(cc, std::integral_constant<int, 0>{});
+        chunk(cc + 1, std::integral_constant<int, 1>{});
+    }
+    if (nch & 1) chunk(nch - 1, std::integral_constant<int, 0>{});
+
+    // ---------------------------------------------------------------- epilogue
+    const float inv = 1.0f / (ascale * F16_WSCALE);
+    const int half = lane >> 5, col = lane & 31;
+    int co[TN]; float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        co[j] = bn * BN + (wn * TN + j) * 32 + col;
+        bv[j] = (a.bias != nullptr && co[j] < a.Cout) ? a.bias[co[j]] : 0.f;
+    }
+    const int oy0 = ty * HT_H, ox0 = tx * HT_W;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int oy = oy0 + 2 * (wm * TM + i) + (row >> 4), ox = ox0 + (row & 15);
+            const size_t opix = ((size_t)n * g.OH + oy) * g.OW + ox;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v = acc[i][j][e] * inv + bv[j];
+                if (a.stat == nullptr) v = viai_act(v, a.act, a.slope);
+                acc[i][j][e] = v;
+                if (co[j] < a.Cout) {
+                    if (co[j] < a.OC1) a.out[opix * a.OC1 + co[j]] = v;
+                    else a.out2[opix * (a.Cout - a.OC1) + (co[j] - a.OC1)] = v;
+                }
+            }
+        }
+    if (a.stat != nullptr) {          // (mean, M2) of the tile's 128 pixels per channel: per-wave two-pass over its rows, Chan merge of the WM waves
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_h);          // [WM][2][BN]
+        constexpr float RW = (float)(32 * TM);                  // rows per wave
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+            t += __shfl_xor(t, 32, 64);
+            const float mw = t * (1.f / RW);
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float d = acc[i][j][e] - mw; m2 += d * d; }
+            m2 += __shfl_xor(m2, 32, 64);
+            if (half == 0) {
+                red[(wm * 2 + 0) * BN + (wn * TN + j) * 32 + col] = mw;
+                red[(wm * 2 + 1) * BN + (wn * TN + j) * 32 + col] = m2;
+            }
+        }
+        __syncthreads();
+        if (wm == 0 && half == 0)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (co[j] < a.Cout) {
+                    const int c = (wn * TN + j) * 32 + col;
+                    float mean = 0.f, M2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) { mean += red[(w * 2) * BN + c]; M2 += red[(w * 2 + 1) * BN + c]; }
+                    mean *= 1.f / (float)WM;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) { const float d = red[(w * 2) * BN + c] - mean; M2 += RW * d * d; }
+                    a.stat[(size_t)co[j] * a.nblk_m + tile] = mean;
+                    a.stat[(size_t)(a.Cout + co[j]) * a.nblk_m + tile] = M2;
+                }
+    }
+}
+
 template <int CIN, int TN, int NP = 3>
 int launch_halo(ConvArgs& a, int hy0, int hx0, hipStream_t st) {
     constexpr int PITCH = CIN * 2 + 16;
@@ -488,4 +714,56 @@ int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st) {
     const bool wide = a.Cout > 32;
     if (a.C1 == 32) return wide ? launch_halo<32, 2>(a, y0, x0, st) : launch_halo<32, 1>(a, y0, x0, st);
     return wide ? launch_halo<64, 2>(a, y0, x0, st) : launch_halo<64, 1>(a, y0, x0, st);
+}
+
+// Stride-1 3 x 3 layers for the kernel above: one source with Cin a multiple of 32, one destination with 32, 64 or a multiple of 128
+// channels, the full window, output extent a multiple of the 8 x 16 tile, and enough tiles to occupy the chip (smaller layers stay
+// on the split-K / 64 x 64 kernels).  The fragment-major f16x2 weight image is a consequence of this predicate: conv_api.hip asks it
+// when it packs, viai_conv_igemm_bf3_launch when it launches.
+bool viai_conv_halo_wide_ok(const ConvArgs& a) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_HALO_WIDE"); on = e ? atoi(e) : 1; }
+    const ConvGeom& g = a.g;
+    if (!on || a.C1 % 32 != 0 || a.C2 % 32 != 0 || a.C1 < 32 || (a.OC1 != a.Cout && a.OC1 % 32 != 0)) return false;
+    if (!(a.Cout == 32 || a.Cout == 64 || a.Cout % 128 == 0)) return false;
+    if (a.Cout <= 64 && a.C1 + a.C2 <= 64 && a.C2 == 0) return false;              // the small-channel halo kernels take these
+    if (g.run || g.ly != 1 || g.lx != 1 || g.my != 1 || g.mx != 1 || g.SH != g.OH || g.SW != g.OW || g.ntaps != 9) return false;
+    if (g.OH % HT_H != 0 || g.OW % HT_W != 0) return false;
+    const long tiles = (long)g.N * (g.OH / HT_H) * (g.OW / HT_W);
+    if (tiles * (a.Cout >= 128 ? a.Cout / 128 : 1) < 192) return false;
+    int y0 = g.dy[0], x0 = g.dx[0];
+    for (int t = 1; t < 9; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        const int r = g.dy[t] - y0, c = g.dx[t] - x0;
+        if (r > 2 || c > 2) return false;
+        seen |= 1u << (r * 3 + c);
+    }
+    return seen == 0x1ffu;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_halo_wide(ConvArgs& a, int y0, int x0, const HaloWideSlots& sl, hipStream_t st) {
+    constexpr int lds = 2 * 2 * HT_HP * 80;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_wide_f16_kernel<WM, WN, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    a.nblk_n = (a.Cout + 32 * TN * WN - 1) / (32 * TN * WN);
+    VIAI_LAUNCH((conv_halo_wide_f16_kernel<WM, WN, TM, TN>), dim3(a.nblk_m * a.nblk_n), dim3(64 * WM * WN), lds, st, a, y0, x0, sl);
+    return viai_launch_status();
+}
+
+int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
+    const ConvGeom& g = a.g;
+    if (!viai_conv_halo_wide_ok(a)) return (int)hipErrorInvalidValue;
+    int y0 = g.dy[0], x0 = g.dx[0];
+    for (int t = 1; t < 9; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
+    HaloWideSlots sl;
+    for (int t = 0; t < 9; ++t) sl.s[(g.dy[t] - y0) * 3 + (g.dx[t] - x0)] = g.ws[t];
+    a.nblk_m = a.M / 128;
+    if (a.Cout == 32) return launch_halo_wide<4, 1, 1, 1>(a, y0, x0, sl, st);
+    if (a.Cout == 64) return launch_halo_wide<2, 2, 2, 1>(a, y0, x0, sl, st);
+    static int wn4 = -1;
+    if (wn4 < 0) { const char* e = getenv("VIAI_HALO_WIDE_WN4"); wn4 = e ? atoi(e) : 1; }
+    if (wn4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<2, 4, 2, 2>(a, y0, x0, sl, st);
+    return launch_halo_wide<2, 2, 2, 2>(a, y0, x0, sl, st);
 }

@@ -953,6 +953,7 @@ int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
     if (a.sk) return launch_bf3_sk(a, st);
     const int bm = viai_igemm_tile_m(a.M, a.Cout);           // same tile rule as the fp32 kernels (BN partial geometry)
     if (a.wfrag == 3) {                                                        // f16x2 weights
+        if (viai_conv_halo_wide_ok(a)) return viai_conv_halo_wide_launch(a, st);   // stride-1 3 x 3: patch staged once per chunk, not once per tap
         // 128 x 256 tile (eight waves) where the layer is wide and tall enough: every staged activation row then feeds 256
         // output channels, halving the load / split / LDS-store work per MFMA
         static int wn4 = -1;

@@ -43,6 +43,8 @@ bool viai_bf3_sk_ok(long M, int n_out, int C1, int C2);
 bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout);
 bool viai_conv_halo16_ok(const ConvGeom& g, int C1, int C2, int Cout);
 int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st);
+bool viai_conv_halo_wide_ok(const ConvArgs& a);
+int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st);
 bool viai_dgrad_s2_ok(const viai_conv2d* c);
 int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st);
 int viai_wgrad_mfma_launch(WgradArgs& a, int ksplit, hipStream_t st);
