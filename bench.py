@@ -171,7 +171,7 @@ class KernelTimer:
                 return "halo", 1
             if (BF3 and not d.transposed and (d.kh, d.kw, d.sh, d.sw, d.ph, d.pw) == (3, 3, 2, 2, 1, 1) and d.IH % 2 == 0 and d.IW % 2 == 0
                     and d.Cout % 32 == 0 and cin % 64 == 0 and -(-(d.N * (d.IH // 2) * (d.IW // 2)) // 128) * (cin // 64) >= 256):
-                return "dgrad_s2", 1                 # mirror of viai_dgrad_s2_ok (csrc/conv_dgrad_s2_bf3.hip)
+                return "dgrad_s2", 1                 # mirror of viai_dgrad_s2_ok (csrc/conv_dgrad_s2_bf3.hip); f16x2: the patch-staged kernel where the base lattice tiles in 8 x 16
             ncls = d.sh * d.sw                        # one launch per output parity class
             return igemm_name(-(-(d.N * d.IH * d.IW) // ncls), cin), ncls
 
@@ -391,7 +391,7 @@ def main():
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream of each call (main stream, or the weight-gradient side stream), %d instrumented steps of the same eager step after the timed region" % nprof,
             "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<3,2,2,2,2> (bf16x3); igemm128x128_f16x2 / igemm128x256_f16x2 = conv_igemm_bf3_frag_kernel<2,2,2,2,2> / <2,2,2,2,4> (f16x2 split: ceiling 2500/3; the 128x256 eight-wave tile where Cout % 256 == 0 and it still yields >= 256 blocks); igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2[,NP]>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel<NP> (small-M layers, waves split K); a _f16x2 suffix on these = the NP = 2 instance (planar fp16 weight planes); "
-                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo_wide{256,128,64,32}_f16x2 = conv_halo_wide_f16_kernel<2,4,2,2> / <2,2,2,2> / <2,2,2,1> / <4,1,1,1> (stride-1 3x3 layers with Cin >= 32: patch staged once per 32-channel chunk); halo[_f16x2] = conv_halo_bf3_kernel<CIN,TN,3|2> (32/64-channel stride-1 layers) and, for 32 -> <=32 channels, conv_halo_f16_c32_kernel (filter in registers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> (3x3 stride-2 data gradient, four parity classes fused); wgrad_bf3 = wgrad_bf3_kernel<*>; "
+                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo_wide{256,128,64,32}_f16x2 = conv_halo_wide_f16_kernel<2,4,2,2> / <2,2,2,2> / <2,2,2,1> / <4,1,1,1> (stride-1 3x3 layers with Cin >= 32: patch staged once per 32-channel chunk); halo[_f16x2] = conv_halo_bf3_kernel<CIN,TN,3|2> (32/64-channel stride-1 layers) and, for 32 -> <=32 channels, conv_halo_f16_c32_kernel (filter in registers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> / conv_dgrad_s2_patch_kernel (3x3 stride-2 data gradient, four parity classes fused; the patch kernel stages the dy patch once per 32-channel chunk); wgrad_bf3 = wgrad_bf3_kernel<*>; "
                                    "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers); wgrad32_all_taps = wgrad32_halo_kernel (fp32 MFMA, <= 32 x <= 32 channels, stride 1: all taps per block)") if BF3 else
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},

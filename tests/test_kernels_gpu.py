@@ -116,6 +116,33 @@ def test_conv_virtual_concat_matches_cat(shape):
     assert relerr(wg.grad, w.grad) < 2e-5
 
 
+def test_patch_staged_stride2_dgrad_against_fp64():
+    """3 x 3 stride-2 conv + BatchNorm(eval), 4 x 128 x 128 x 128 -> 64: 256 blocks of the fused-class data gradient, base lattice
+    64 x 64 = a multiple of the 8 x 16 tile, so the patch-staged f16x2 kernel (conv_dgrad_s2_patch_kernel) computes dx."""
+    from viai_amd import ops
+    N, Ci, Co, H, W = 4, 128, 64, 128, 128
+    x = O.cf_uniform("s2p.x", (N, Ci, H, W), -1, 1)
+    w = O.cf_std("s2p.w", (Co, Ci, 3, 3), 0.05)
+    g_, b_ = O.cf_uniform("s2p.g", (Co,), 0.5, 1.5), O.cf_uniform("s2p.b", (Co,), -0.5, 0.5)
+    rm, rv = O.cf_uniform("s2p.rm", (Co,), -0.1, 0.1), O.cf_uniform("s2p.rv", (Co,), 0.5, 1.5)
+    gy = O.cf_uniform("s2p.gy", (N, Co, H // 2, W // 2), -1, 1)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y = F.batch_norm(F.conv2d(xd, wd, None, stride=2, padding=1), rm.double(), rv.double(), g_.double(), b_.double(), False, 0.1, 1e-5)
+    y.backward(gy.double())
+    bn = torch.nn.BatchNorm2d(Co).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(g_); bn.bias.copy_(b_); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.eval()
+    a = nhwc(x).requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    ops.begin_step(a.device)
+    yg = ops.conv_bn_act(a, wg, None, bn, kernel=(3, 3), stride=(2, 2), padding=(1, 1), act=ops.ACT_NONE, training=False)
+    assert relerr(nchw(yg), y) < 3e-6
+    yg.backward(nhwc(gy))
+    assert relerr(nchw(a.grad), xd.grad) < 3e-6
+    assert relerr(wg.grad, wd.grad) < 3e-6
+
+
 @pytest.mark.parametrize("cfg", [(128, 0, 32), (64, 64, 32), (32, 0, 128), (96, 0, 64), (64, 64, 128)], ids=["128to32", "cat64+64to32", "32to128", "96to64", "cat64+64to128"])
 def test_wide_halo_kernel_fwd_and_f16_backward_against_fp64(cfg):
     """stride-1 3 x 3 transposed conv + BatchNorm(eval) at 3 x 64 x 128 (192 tiles): forward, data gradient (one or two

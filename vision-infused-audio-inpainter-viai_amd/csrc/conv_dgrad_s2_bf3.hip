@@ -13,6 +13,7 @@
 #include "viai_common.h"
 #include "viai_internal.h"
 #include "viai_bf3.h"
+#include <type_traits>
 // timing ablation: bit 0 no weight-fragment loads, bit 1 no dy loads, bit 2 no split / LDS stores, bit 3 no output stores
 #ifndef VIAI_ABL
 #define VIAI_ABL 0
@@ -213,6 +214,152 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
 }
 
+// Patch-staged f16x2 variant (base lattice a multiple of 8 x 16): the kernel above loads and splits the dy tile once per SHIFT (four
+// times per 32-channel chunk, one barrier each, a wave-uniform branch per class).  Here a block owns an 8 x 16 tile of the base
+// lattice: per chunk the (8+1) x (16+1) dy patch is staged ONCE, the four shifts are four compile-time window offsets, and the nine
+// (shift, class, tap) units of a chunk are a static list -- one barrier per chunk, no branches in the K loop.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_dgrad_s2_patch_kernel(const ConvArgs a) {
+    constexpr int NP = 2, TM = 2, PITCH = 80, PH = 9, PW = 17, HP = PH * PW, PLANE = HP * PITCH, STAGE = NP * PLANE;
+    constexpr int NL = (HP * 8 + 255) / 256;         // float4 per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2 stages][2 planes][153][80]
+    const ConvGeom& g = a.g;                         // N, IH/IW = dy extent = base lattice, OH/OW = dx extent
+    const float ascale = f16_scale_from_amax(a.amax);
+    const float alim = f16_clamp_for_scale(ascale);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bn = bid % a.nblk_n, tile = bid / a.nblk_n;
+    const int tiles_x = g.IW / 16, tiles_y = g.IH / 8;
+    const int tx = tile % tiles_x; const int r_ = tile / tiles_x; const int ty = r_ % tiles_y, n = r_ / tiles_y;
+    const int by0 = ty * 8, bx0 = tx * 16;
+    const int K = a.C1, k16 = K / 16, nch = K / 32;
+    constexpr int OOB = 0x7fffffff;
+    const int NT = (a.Cout + 31) / 32;
+    const int frag_plane = NT * 9 * k16 * 1024;
+    const int nt = bn * 2 + wn;
+    const int bvoff = (nt < NT) ? nt * 9 * k16 * 1024 + lane * 16 : OOB;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((long)g.N * g.IH * g.IW * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, NP * frag_plane, 0x00020000);
+
+    const int h0 = tid >> 3, q = tid & 7;
+    int poff[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int h = h0 + 32 * j;
+        const int hr = h / PW, hc = h - hr * PW;
+        const int iy = by0 + hr, ix = bx0 + hc;
+        const int dead = (((g.IH - 1 - iy) | (g.IW - 1 - ix) | (HP - 1 - h)) >> 31) & OOB;
+        poff[j] = ((((n * g.IH + iy) * g.IW + ix) * K + q * 4) * 4) | dead;
+    }
+    u32x4 raw[NL];
+    auto gloadA = [&](int chunk_) {
+        const int chunk = __builtin_amdgcn_readfirstlane(chunk_);
+        const int dead = chunk < nch ? 0 : OOB;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, poff[j] | dead, dead ? 0 : chunk * 128, 0);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int h = h0 + 32 * j;
+            if (h < HP) {
+                const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
+                unsigned a1, a2, b1, b2;
+                split2_pair(v[0], v[1], ascale, alim, a1, a2);
+                split2_pair(v[2], v[3], ascale, alim, b1, b2);
+                const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
+                unsigned char* d = smem_b + buf * STAGE + h * PITCH + q * 8;
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + PLANE) = p2;
+            }
+        }
+    };
+    // the nine units of a chunk: (shift sy, sx) -> window offset; class (a, b) -> accumulator a * 2 + b; tap r * 3 + s
+    //   shift (0,0): (1,1) t8, (1,0) t7, (0,1) t5, (0,0) t4;  shift (0,1): (1,1) t6, (0,1) t3;  shift (1,0): (1,1) t2, (1,0) t1;  shift (1,1): (1,1) t0
+    constexpr int U_SH[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3}, U_CL[9] = {3, 2, 1, 0, 3, 1, 3, 2, 3}, U_TAP[9] = {8, 7, 5, 4, 6, 3, 2, 1, 0};
+    auto gloadB = [&](u32x4 (&b0)[NP], u32x4 (&b1)[NP], int u, int cc_) {
+        const int cc = __builtin_amdgcn_readfirstlane(cc_);
+        const int dead = cc < nch ? 0 : OOB;
+        const int soff = dead ? 0 : (U_TAP[u] * k16 + cc * 2) * 1024;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            b0[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bvoff | dead, soff + p * frag_plane, 0);
+            b1[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bvoff | dead, soff + 1024 + p * frag_plane, 0);
+        }
+    };
+    f32x16 acc[4][TM];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][i][e] = 0.f;
+
+    // MFMA row r = lane & 31 of M-tile i -> base pixel (2 (wm * TM + i) + (r >> 4), r & 15) of the tile
+    const int aoff = ((wm * TM * 2 + ((lane & 31) >> 4)) * PW + (lane & 15)) * PITCH + 16 * (lane >> 5);
+    u32x4 B0[2][NP], B1[2][NP];
+    gloadA(0);
+    gloadB(B0[0], B1[0], 0, 0);
+    lstore(0);
+    gloadA(1);
+    __syncthreads();
+    auto mma = [&](f32x16 (&ac)[TM], const unsigned char* As, const u32x4 (&b)[NP]) {
+        u32x4 af[TM][NP];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(As + p * PLANE + i * 2 * PW * PITCH);
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                ac[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][PA[pr]]), __builtin_bit_cast(f16x8, b[PB[pr]]), ac[i], 0, 0, 0);
+    };
+    auto chunk = [&](int cc, auto P) {
+        constexpr int p0 = decltype(P)::value;
+        const unsigned char* S = smem_b + (cc & 1) * STAGE + aoff;
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int cur = (p0 + u) & 1, nxt = cur ^ 1;
+            if (u + 1 < 9) gloadB(B0[nxt], B1[nxt], u + 1, cc);
+            else gloadB(B0[nxt], B1[nxt], 0, cc + 1);
+            const unsigned char* As = S + ((U_SH[u] >> 1) * PW + (U_SH[u] & 1)) * PITCH;
+            mma(acc[U_CL[u]], As, B0[cur]);
+            mma(acc[U_CL[u]], As + 32, B1[cur]);
+        }
+        lstore((cc & 1) ^ 1);
+        gloadA(cc + 2);
+        __syncthreads();
+    };
+    for (int cc = 0; cc + 1 < nch; cc += 2) {
+        chunk(cc, std::integral_constant<int, 0>{});
+        chunk(cc + 1, std::integral_constant<int, 1>{});
+    }
+    if (nch & 1) chunk(nch - 1, std::integral_constant<int, 0>{});
+
+    const float inv = 1.0f / (ascale * F16_WSCALE);
+    const int half = lane >> 5, col = lane & 31;
+    const int co = nt * 32 + col;
+    const int oc2 = a.Cout - a.OC1;
+    if (co < a.Cout) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                const int by = by0 + 2 * (wm * TM + i) + (row >> 4), bx = bx0 + (row & 15);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const size_t opix = ((size_t)n * g.OH + 2 * by + (c >> 1)) * g.OW + 2 * bx + (c & 1);
+                    if (co < a.OC1) a.out[opix * a.OC1 + co] = acc[c][i][e] * inv;
+                    else a.out2[opix * oc2 + (co - a.OC1)] = acc[c][i][e] * inv;
+                }
+            }
+    }
+}
+
 }  // namespace
 
 // conv: 3x3, stride (2,2), pad 1, no dilation, even input extent; channel counts that tile (K % 32, Cin % 64)
@@ -237,6 +384,15 @@ int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_bf3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_bf3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
+    }
+    static int patch = -1;
+    if (patch < 0) { const char* e = getenv("VIAI_S2_PATCH"); patch = e ? atoi(e) : 1; }
+    if (a.amax != nullptr && patch && a.g.IH % 8 == 0 && a.g.IW % 16 == 0 && a.g.OH == 2 * a.g.IH && a.g.OW == 2 * a.g.IW && a.C1 % 32 == 0) {
+        constexpr int lds_p = 2 * 2 * 9 * 17 * 80;
+        static bool attr_p = false;
+        if (!attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p); attr_p = true; }
+        VIAI_LAUNCH(conv_dgrad_s2_patch_kernel, dim3(a.nblk_m * a.nblk_n), dim3(256), lds_p, st, a);
+        return viai_launch_status();
     }
     if (a.amax != nullptr) VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<2>, dim3(a.nblk_m * a.nblk_n), dim3(256), 2 * 2 * 128 * BF3_PITCH, st, a);   // f16x2
     else VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<3>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
