@@ -114,7 +114,11 @@ def _scratch(tag, n, dev, stream=None):
     key = (tag, dev.index, stream.cuda_stream if stream is not None else _stream())
     t = _scratch_pool.get(key)
     if t is None or t.numel() < n:
-        t = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
+        if stream is not None:                      # allocate in the pool of the stream that will use it
+            with torch.cuda.stream(stream):
+                t = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
+        else:
+            t = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
         _scratch_pool[key] = t
     return t
 
@@ -375,16 +379,17 @@ class _ConvBnAct(torch.autograd.Function):
                 ev = torch.cuda.Event()
                 ev.record()
                 WGRAD_STREAM.wait_event(ev)
-                with torch.cuda.stream(WGRAD_STREAM):
-                    ws = _scratch("wgrad", d["ws_floats"], dev, WGRAD_STREAM)
-                    if amax is not None and d["wgrad_f16"]:
-                        _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                             dw.data_ptr(), db.data_ptr() if want_db else 0, 1, amax.data_ptr(),
-                                                             WGRAD_STREAM.cuda_stream), "viai_conv2d_wgrad_f16")
-                    else:
-                        _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                         dw.data_ptr(), db.data_ptr() if want_db else 0, 1, WGRAD_STREAM.cuda_stream),
-                                   "viai_conv2d_wgrad")
+                # (no `with torch.cuda.stream(...)` here: the launch takes the stream handle explicitly, and entering / leaving the
+                # context costs ~25 us of host time per layer)
+                ws = _scratch("wgrad", d["ws_floats"], dev, WGRAD_STREAM)
+                if amax is not None and d["wgrad_f16"]:
+                    _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                         dw.data_ptr(), db.data_ptr() if want_db else 0, 1, amax.data_ptr(),
+                                                         WGRAD_STREAM.cuda_stream), "viai_conv2d_wgrad_f16")
+                else:
+                    _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                     dw.data_ptr(), db.data_ptr() if want_db else 0, 1, WGRAD_STREAM.cuda_stream),
+                               "viai_conv2d_wgrad")
                 _deferred.append((x, x2, dy, weight, amax))
             elif acc_w == acc_b or not want_db:
                 ws = _scratch("wgrad", d["ws_floats"], dev)
