@@ -170,7 +170,7 @@ class KernelTimer:
             if halo_ok(d.Cout, 0, cin, d, d.IH, d.IW):
                 return "halo", 1
             if (BF3 and not d.transposed and (d.kh, d.kw, d.sh, d.sw, d.ph, d.pw) == (3, 3, 2, 2, 1, 1) and d.IH % 2 == 0 and d.IW % 2 == 0
-                    and d.Cout % 32 == 0 and cin % 64 == 0 and -(-(d.N * (d.IH // 2) * (d.IW // 2)) // 128) * (cin // 64) >= 256):
+                    and d.Cout % 32 == 0 and cin % 64 == 0 and -(-(d.N * (d.IH // 2) * (d.IW // 2)) // 128) * (cin // 64) >= (32 if ((d.IH // 2) % 8 == 0 and (d.IW // 2) % 16 == 0) else 256)):
                 return "dgrad_s2", 1                 # mirror of viai_dgrad_s2_ok (csrc/conv_dgrad_s2_bf3.hip); f16x2: the patch-staged kernel where the base lattice tiles in 8 x 16
             ncls = d.sh * d.sw                        # one launch per output parity class
             return igemm_name(-(-(d.N * d.IH * d.IW) // ncls), cin), ncls

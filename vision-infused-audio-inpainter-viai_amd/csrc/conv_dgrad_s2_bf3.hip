@@ -371,7 +371,12 @@ bool viai_dgrad_s2_ok(const viai_conv2d* c) {
     // enough 128-pixel x 64-channel tiles to occupy the chip; smaller layers go class by class through the split-K kernel
     if ((long)c->N * (c->IH / 2) * (c->IW / 2) >= (1L << 22)) return false;      // epilogue index arithmetic in fp32
     long blocks = (((long)c->N * (c->IH / 2) * (c->IW / 2) + 127) / 128) * ((c->C1 + c->C2) / 64);
-    return blocks >= 256;
+    // where the base lattice tiles in 8 x 16 (patch-staged kernel) even a fraction of a round beats four class-by-class launches of
+    // the split-K kernel (E.conv4 / E.conv5: 4 x ~30 us -> one ~25 us launch)
+    const bool tiles = ((c->IH / 2) % 8 == 0) && ((c->IW / 2) % 16 == 0);
+    static long small = -1;
+    if (small < 0) { const char* e = getenv("VIAI_S2_MIN_BLOCKS"); small = e ? atol(e) : 32; }
+    return blocks >= (tiles ? small : 256);
 }
 
 int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st) {
