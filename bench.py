@@ -138,7 +138,9 @@ class KernelTimer:
                 return None
             tiles = d.N * (oh // 8) * (ow // 16)
             if tiles * (c_out // 128 if c_out >= 128 else 1) < 192:
-                return None
+                if not (c_out >= 128 and tiles * (c_out // 64) >= int(os.environ.get("VIAI_HALO_WIDE_MIN64", "96"))):
+                    return None
+                return "halo_wide64_f16x2"
             if c_out <= 64:
                 return "halo_wide%d_f16x2" % c_out
             wn4 = os.environ.get("VIAI_HALO_WIDE_WN4", "1") != "0" and c_out % 256 == 0 and tiles * (c_out // 256) >= 256

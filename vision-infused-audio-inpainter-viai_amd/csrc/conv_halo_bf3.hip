@@ -730,7 +730,11 @@ bool viai_conv_halo_wide_ok(const ConvArgs& a) {
     if (g.run || g.ly != 1 || g.lx != 1 || g.my != 1 || g.mx != 1 || g.SH != g.OH || g.SW != g.OW || g.ntaps != 9) return false;
     if (g.OH % HT_H != 0 || g.OW % HT_W != 0) return false;
     const long tiles = (long)g.N * (g.OH / HT_H) * (g.OW / HT_W);
-    if (tiles * (a.Cout >= 128 ? a.Cout / 128 : 1) < 192) return false;
+    // small maps: 64-channel blocks double the block count (the 16 x 32 maps of G.convblock2: 64 tiles -> 128 / 256 blocks, each
+    // with half the K-loop work of a 128-channel block) -- still better than the split-K kernel those layers ran on
+    static long min64 = -1;
+    if (min64 < 0) { const char* e = getenv("VIAI_HALO_WIDE_MIN64"); min64 = e ? atol(e) : 96; }
+    if (tiles * (a.Cout >= 128 ? a.Cout / 128 : 1) < 192 && !(a.Cout >= 128 && tiles * (a.Cout / 64) >= min64)) return false;
     int y0 = g.dy[0], x0 = g.dx[0];
     for (int t = 1; t < 9; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
     unsigned seen = 0;
@@ -761,7 +765,7 @@ int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
     for (int t = 0; t < 9; ++t) sl.s[(g.dy[t] - y0) * 3 + (g.dx[t] - x0)] = g.ws[t];
     a.nblk_m = a.M / 128;
     if (a.Cout == 32) return launch_halo_wide<4, 1, 1, 1>(a, y0, x0, sl, st);
-    if (a.Cout == 64) return launch_halo_wide<2, 2, 2, 1>(a, y0, x0, sl, st);
+    if (a.Cout == 64 || (long)a.nblk_m * (a.Cout / 128) < 192) return launch_halo_wide<2, 2, 2, 1>(a, y0, x0, sl, st);
     static int wn4 = -1;
     if (wn4 < 0) { const char* e = getenv("VIAI_HALO_WIDE_WN4"); wn4 = e ? atoi(e) : 1; }
     if (wn4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<2, 4, 2, 2>(a, y0, x0, sl, st);
