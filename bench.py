@@ -134,13 +134,18 @@ class KernelTimer:
                 return None
             if c_out <= 64 and c1 + c2 <= 64 and c2 == 0:
                 return None
-            if (d.kh, d.kw, d.sh, d.sw) != (3, 3, 1, 1) or oh % 8 or ow % 16:
+            s2 = (d.sh, d.sw) == (2, 2) and not d.transposed and os.environ.get("VIAI_HALO_WIDE_S2", "1") != "0"
+            if (d.kh, d.kw) != (3, 3) or not ((d.sh, d.sw) == (1, 1) or s2) or oh % 8 or ow % 16:
+                return None
+            if s2 and (c2 != 0 or c_out % 128):
                 return None
             tiles = d.N * (oh // 8) * (ow // 16)
             if tiles * (c_out // 128 if c_out >= 128 else 1) < 192:
                 if not (c_out >= 128 and tiles * (c_out // 64) >= int(os.environ.get("VIAI_HALO_WIDE_MIN64", "96"))):
                     return None
-                return "halo_wide64_f16x2"
+                return "halo_wide_s2_f16x2" if s2 else "halo_wide64_f16x2"
+            if s2:
+                return "halo_wide_s2_f16x2"
             if c_out <= 64:
                 return "halo_wide%d_f16x2" % c_out
             wn4 = os.environ.get("VIAI_HALO_WIDE_WN4", "1") != "0" and c_out % 256 == 0 and tiles * (c_out // 256) >= 256
@@ -393,7 +398,7 @@ def main():
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream of each call (main stream, or the weight-gradient side stream), %d instrumented steps of the same eager step after the timed region" % nprof,
             "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<3,2,2,2,2> (bf16x3); igemm128x128_f16x2 / igemm128x256_f16x2 = conv_igemm_bf3_frag_kernel<2,2,2,2,2> / <2,2,2,2,4> (f16x2 split: ceiling 2500/3; the 128x256 eight-wave tile where Cout % 256 == 0 and it still yields >= 256 blocks); igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2[,NP]>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel<NP> (small-M layers, waves split K); a _f16x2 suffix on these = the NP = 2 instance (planar fp16 weight planes); "
-                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo_wide{256,128,64,32}_f16x2 = conv_halo_wide_f16_kernel<2,4,2,2> / <2,2,2,2> / <2,2,2,1> / <4,1,1,1> (stride-1 3x3 layers with Cin >= 32: patch staged once per 32-channel chunk); halo[_f16x2] = conv_halo_bf3_kernel<CIN,TN,3|2> (32/64-channel stride-1 layers) and, for 32 -> <=32 channels, conv_halo_f16_c32_kernel (filter in registers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> / conv_dgrad_s2_patch_kernel (3x3 stride-2 data gradient, four parity classes fused; the patch kernel stages the dy patch once per 32-channel chunk); wgrad_bf3 = wgrad_bf3_kernel<*>; "
+                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo_wide{256,128,64,32}_f16x2 = conv_halo_wide_f16_kernel<2,4,2,2> / <2,2,2,2> / <2,2,2,1> / <4,1,1,1> (stride-1 3x3 layers with Cin >= 32: patch staged once per 32-channel chunk), halo_wide_s2_f16x2 = its <2,4,2,{2,1},2> instances (stride-2 forward, four parity sub-patches); halo[_f16x2] = conv_halo_bf3_kernel<CIN,TN,3|2> (32/64-channel stride-1 layers) and, for 32 -> <=32 channels, conv_halo_f16_c32_kernel (filter in registers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> / conv_dgrad_s2_patch_kernel (3x3 stride-2 data gradient, four parity classes fused; the patch kernel stages the dy patch once per 32-channel chunk); wgrad_bf3 = wgrad_bf3_kernel<*>; "
                                    "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers); wgrad32_all_taps = wgrad32_halo_kernel (fp32 MFMA, <= 32 x <= 32 channels, stride 1: all taps per block)") if BF3 else
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},

@@ -27,6 +27,7 @@ def dot(a, b):
 FULL_LAYERS = [
     ("D.conv3 (128x256 wide tile, f16x2 wgrad)", 16, 64, 32, 256, 512, (3, 3), (1, 1), (1, 1), False),
     ("D.conv2_2 (fused stride-2 dgrad)", 16, 128, 64, 128, 256, (3, 3), (2, 2), (1, 1), False),
+    ("D.conv2_1 (stride-2 forward on the parity-sub-patch kernel, 128 outputs)", 16, 256, 128, 64, 128, (3, 3), (2, 2), (1, 1), False),
     ("G 32->32 @256x256 (register-filter halo, all-taps wgrad)", 16, 256, 256, 32, 32, (3, 3), (1, 1), (1, 1), True),
     ("G 64->64 @64x128 (streamed-filter halo)", 16, 64, 128, 64, 64, (3, 3), (1, 1), (1, 1), True),
     ("E deep 512->512 @8x8 (split-K)", 16, 8, 8, 512, 512, (3, 3), (1, 1), (1, 1), False),

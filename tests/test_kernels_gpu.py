@@ -116,6 +116,23 @@ def test_conv_virtual_concat_matches_cat(shape):
     assert relerr(wg.grad, w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("co", [128, 256])
+def test_stride2_forward_patch_kernel_against_fp64(co):
+    """3 x 3 stride-2 conv at 4 x 128 x 256 x 64 -> co (256 tiles of 8 x 16 outputs): the parity-sub-patch instance of the wide halo
+    kernel computes the forward (with BatchNorm partials: train-mode BN behind it), checked against fp64."""
+    from viai_amd import ops
+    N, Ci, H, W = 4, 64, 128, 256
+    x = O.cf_uniform("s2f.x", (N, Ci, H, W), -1, 1)
+    w = O.cf_std("s2f.w", (co, Ci, 3, 3), 0.05)
+    truth = F.conv2d(x.double(), w.double(), None, stride=2, padding=1)
+    y = ops.conv_bn_act(nhwc(x), w.cuda(), None, None, kernel=(3, 3), stride=(2, 2), padding=(1, 1))
+    assert relerr(nchw(y), truth) < 3e-6
+    bn = torch.nn.BatchNorm2d(co).cuda()
+    yb = ops.conv_bn_act(nhwc(x), w.cuda(), None, bn, kernel=(3, 3), stride=(2, 2), padding=(1, 1))
+    tb = F.batch_norm(truth, None, None, None, None, True, 0.1, 1e-5)
+    assert relerr(nchw(yb), tb) < 1e-5
+
+
 def test_patch_staged_stride2_dgrad_against_fp64():
     """3 x 3 stride-2 conv + BatchNorm(eval), 4 x 128 x 128 x 128 -> 64: 256 blocks of the fused-class data gradient, base lattice
     64 x 64 = a multiple of the 8 x 16 tile, so the patch-staged f16x2 kernel (conv_dgrad_s2_patch_kernel) computes dx."""

@@ -417,13 +417,20 @@ struct HaloWideSlots { int s[9]; };
 
 // WM x TM = 4 (the tile's eight rows = WM waves x TM row pairs); BN = 32 * TN * WN output channels per block:
 //   <2,2,2,2> / <2,4,2,2>: 128 / 256 channels (wide layers);  <2,2,2,1>: 64 channels;  <4,1,1,1>: 32 channels
-template <int WM, int WN, int TM, int TN>
+// S = 2: 3 x 3 STRIDE-2 forward conv.  The (17 x 33) input patch of the tile is stored as four parity sub-patches
+//   P[py][px][r][c] = patch(2 r + py, 2 c + px), so that window position (ty, tx) of output pixel (r, c) is sub-patch (ty & 1, tx & 1) at
+//   (r + (ty >> 1), c + (tx >> 1)): consecutive output pixels read consecutive 80-byte rows, as in the stride-1 case.  One LDS stage (98 KB).
+template <int WM, int WN, int TM, int TN, int S = 1>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_wide_f16_kernel(const ConvArgs a, int hy0, int hx0, HaloWideSlots slots) {
     static_assert(WM * TM == 4, "config");
     constexpr int NP = 2, BN = 32 * TN * WN, NTHR = 64 * WM * WN;
-    constexpr int PITCH = 80, PLANE = HT_HP * PITCH, STAGE = NP * PLANE;
+    constexpr int PH = S == 2 ? 17 : HT_HH, PW = S == 2 ? 33 : HT_HW, NPIX = PH * PW;            // staged patch (input pixels)
+    constexpr int SUBW = 17, SUB = 9 * SUBW;                                                   // S = 2: one parity sub-patch
+    constexpr int ROW = S == 2 ? SUBW : HT_HW;                                                 // LDS pixel slots per (sub-)patch row
+    constexpr int SLOTS = S == 2 ? 4 * SUB : HT_HP;
+    constexpr int PITCH = 80, PLANE = SLOTS * PITCH, STAGE = NP * PLANE, NSTAGE = S == 2 ? 1 : 2;
     constexpr int RPP = NTHR / 8;                              // patch pixels staged per pass (8 lanes = 8 channel quads per pixel)
-    constexpr int NL = (HT_HP + RPP - 1) / RPP;
+    constexpr int NL = (NPIX + RPP - 1) / RPP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];   // [2 stages][2 planes][180][80]
 
     const ConvGeom& g = a.g;
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     const int bn = bid % a.nblk_n, tile = bid / a.nblk_n;
     const int tiles_x = g.OW / HT_W, tiles_y = g.OH / HT_H;
     const int tx = tile % tiles_x; const int r_ = tile / tiles_x; const int ty = r_ % tiles_y, n = r_ / tiles_y;
-    const int py = ty * HT_H + hy0, px = tx * HT_W + hx0;
+    const int py = ty * HT_H * S + hy0, px = tx * HT_W * S + hx0;
     const int Cin = a.C1 + a.C2, k16 = Cin / 16, nch = Cin / 32, nch1 = a.C1 / 32;        // chunks [0, nch1) read a.in, the rest a.in2 (virtual concat)
     constexpr int OOB = 0x7fffffff;
     const int NT = (a.Cout + 31) / 32;
@@ -450,9 +457,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
         const int h = h0 + RPP * j;
-        const int hr = h / HT_HW, hc = h - hr * HT_HW;
+        const int hr = h / PW, hc = h - hr * PW;
         const int iy = py + hr, ix = px + hc;
-        const int dead = (((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | (HT_HP - 1 - h)) >> 31) & OOB;
+        const int dead = (((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | (NPIX - 1 - h)) >> 31) & OOB;
         poff[j] = ((n * g.IH + iy) * g.IW + ix) | dead;                          // pixel index (or out of range)
     }
     u32x4 raw[NL];
@@ -473,13 +480,15 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             const int h = h0 + RPP * j;
-            if (h < HT_HP) {
+            if (h < NPIX) {
+                const int hr = h / PW, hc = h - hr * PW;
+                const int slot = S == 2 ? ((hr & 1) * 2 + (hc & 1)) * SUB + (hr >> 1) * SUBW + (hc >> 1) : h;
                 const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
                 unsigned a1, a2, b1, b2;
                 split2_pair(v[0], v[1], ascale, alim, a1, a2);
                 split2_pair(v[2], v[3], ascale, alim, b1, b2);
                 const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
-                unsigned char* d = smem_h + buf * STAGE + h * PITCH + q * 8;
+                unsigned char* d = smem_h + buf * STAGE + slot * PITCH + q * 8;
                 *reinterpret_cast<u32x2*>(d) = p1;
                 *reinterpret_cast<u32x2*>(d + PLANE) = p2;
             }
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // MFMA row r = lane & 31 of M-tile i -> tile pixel (2 (wm TM + i) + (r >> 4), r & 15); the patch origin is the window's top-left tap
-    const int aoff = ((wm * TM * 2 + ((lane & 31) >> 4)) * HT_HW + (lane & 15)) * PITCH + 16 * (lane >> 5);
+    const int aoff = ((wm * TM * 2 + ((lane & 31) >> 4)) * ROW + (lane & 15)) * PITCH + 16 * (lane >> 5);
     u32x4 B0[2][TN][NP], B1[2][TN][NP];                   // two fragment sets (k-step 0 / 1 each), alternating per tap
     gloadA(0);
     gloadB(B0[0], B1[0], 0, 0);
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(As + p * PLANE + i * 2 * HT_HW * PITCH);
+            for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(As + p * PLANE + i * 2 * ROW * PITCH);
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};        // smallest partial products first
 #pragma unroll
         for (int pr = 0; pr < 3; ++pr)
@@ -542,18 +551,21 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     // one chunk: nine taps; P = fragment set of tap 0 (nine is odd, so the parity flips from chunk to chunk)
     auto chunk = [&](int cc, auto P) {
         constexpr int p0 = decltype(P)::value;
-        const unsigned char* S = smem_h + (cc & 1) * STAGE + aoff;
+        const unsigned char* Sb = smem_h + (NSTAGE == 2 ? (cc & 1) * STAGE : 0) + aoff;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             constexpr int dummy = 0; (void)dummy;
             const int cur = (p0 + t) & 1, nxt = cur ^ 1;
             if (t + 1 < 9) gloadB(B0[nxt], B1[nxt], t + 1, cc);
             else gloadB(B0[nxt], B1[nxt], 0, cc + 1);
-            const unsigned char* As = S + ((t / 3) * HT_HW + (t % 3)) * PITCH;
+            constexpr int dummy2 = 0; (void)dummy2;
+            const int toff = S == 2 ? (((t / 3) & 1) * 2 + ((t % 3) & 1)) * SUB + ((t / 3) >> 1) * SUBW + ((t % 3) >> 1) : (t / 3) * HT_HW + (t % 3);
+            const unsigned char* As = Sb + toff * PITCH;
             mma(As, B0[cur]);
             mma(As + 32, B1[cur]);
         }
-        lstore((cc & 1) ^ 1);                                  // chunk cc + 1 (loaded during this chunk) -> the other stage
+        if constexpr (NSTAGE == 1) __syncthreads();            // one stage: every wave is done reading chunk cc
+        lstore(NSTAGE == 2 ? (cc & 1) ^ 1 : 0);                // chunk cc + 1 (loaded during this chunk) -> the other stage
         gloadA(cc + 2);
         __syncthreads();
     };
@@ -727,8 +739,13 @@ bool viai_conv_halo_wide_ok(const ConvArgs& a) {
     if (!on || a.C1 % 32 != 0 || a.C2 % 32 != 0 || a.C1 < 32 || (a.OC1 != a.Cout && a.OC1 % 32 != 0)) return false;
     if (!(a.Cout == 32 || a.Cout == 64 || a.Cout % 128 == 0)) return false;
     if (a.Cout <= 64 && a.C1 + a.C2 <= 64 && a.C2 == 0) return false;              // the small-channel halo kernels take these
-    if (g.run || g.ly != 1 || g.lx != 1 || g.my != 1 || g.mx != 1 || g.SH != g.OH || g.SW != g.OW || g.ntaps != 9) return false;
+    if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2) || g.SH != g.OH || g.SW != g.OW || g.ntaps != 9) return false;
     if (g.OH % HT_H != 0 || g.OW % HT_W != 0) return false;
+    if (g.my == 2) {                                               // stride-2 forward: eight-wave instances only, one source
+        static int s2 = -1;
+        if (s2 < 0) { const char* e = getenv("VIAI_HALO_WIDE_S2"); s2 = e ? atoi(e) : 1; }
+        if (!s2 || a.C2 != 0 || a.Cout % 128 != 0 || a.OC1 != a.Cout) return false;
+    }
     const long tiles = (long)g.N * (g.OH / HT_H) * (g.OW / HT_W);
     // small maps: 64-channel blocks double the block count (the 16 x 32 maps of G.convblock2: 64 tiles -> 128 / 256 blocks, each
     // with half the K-loop work of a 128-channel block) -- still better than the split-K kernel those layers ran on
@@ -746,13 +763,13 @@ bool viai_conv_halo_wide_ok(const ConvArgs& a) {
     return seen == 0x1ffu;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int S = 1>
 static int launch_halo_wide(ConvArgs& a, int y0, int x0, const HaloWideSlots& sl, hipStream_t st) {
-    constexpr int lds = 2 * 2 * HT_HP * 80;
+    constexpr int lds = S == 2 ? 2 * 4 * 9 * 17 * 80 : 2 * 2 * HT_HP * 80;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_wide_f16_kernel<WM, WN, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_wide_f16_kernel<WM, WN, TM, TN, S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
     a.nblk_n = (a.Cout + 32 * TN * WN - 1) / (32 * TN * WN);
-    VIAI_LAUNCH((conv_halo_wide_f16_kernel<WM, WN, TM, TN>), dim3(a.nblk_m * a.nblk_n), dim3(64 * WM * WN), lds, st, a, y0, x0, sl);
+    VIAI_LAUNCH((conv_halo_wide_f16_kernel<WM, WN, TM, TN, S>), dim3(a.nblk_m * a.nblk_n), dim3(64 * WM * WN), lds, st, a, y0, x0, sl);
     return viai_launch_status();
 }
 
@@ -764,6 +781,7 @@ int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
     HaloWideSlots sl;
     for (int t = 0; t < 9; ++t) sl.s[(g.dy[t] - y0) * 3 + (g.dx[t] - x0)] = g.ws[t];
     a.nblk_m = a.M / 128;
+    if (g.my == 2) return (a.Cout % 256 == 0) ? launch_halo_wide<2, 4, 2, 2, 2>(a, y0, x0, sl, st) : launch_halo_wide<2, 4, 2, 1, 2>(a, y0, x0, sl, st);
     if (a.Cout == 32) return launch_halo_wide<4, 1, 1, 1>(a, y0, x0, sl, st);
     if (a.Cout == 64 || (long)a.nblk_m * (a.Cout / 128) < 192) return launch_halo_wide<2, 2, 2, 1>(a, y0, x0, sl, st);
     static int wn4 = -1;
