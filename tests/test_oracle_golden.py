@@ -135,3 +135,26 @@ def test_mask_policy():
     assert tuple(m.shape) == (8, 1, 1, 256)
     assert torch.all((m == 0) | (m == 1))
     assert torch.all(m.sum(dim=3) == 256 - 64)
+
+
+def test_oracle_reproduces_reference_digests_at_benchmark_size(golden_dir):
+    """BASELINE.json configs[1] (16 x 256 x 256): the oracle's forward tensors / losses / BatchNorm statistics against the digests
+    the reference's modules produced (tools/make_goldens.py --cfg2-only).  ~20 s of CPU; this is also the function bench.py's
+    cpu_baseline leg times."""
+    g = np.load(golden_dir + "/step_cfg2.npz")
+    B, F_bins, T, _ = [int(v) for v in g["meta"]]
+    assert (B, F_bins, T) == (16, 256, 256)
+    s = O.cf_uniform("s.cfg2", (B, 1, F_bins, T))
+    mask = O.make_mask(B, T, "mask.cfg2")
+    E, G, D = O.encoder_state(), O.decoder_state(), O.disc_state()
+    cap = O.step_no_update(E, G, D, s, mask)
+    for k in ("fake", "pred_fake_d", "pred_real", "pred_fake_g"):
+        assert relerr(O.digest(cap[k]), g["nu.%s.dg" % k]) < 5e-5, k
+    for i, f in enumerate(cap["feats"]):
+        assert relerr(O.digest(f), g["nu.feat%d.dg" % i]) < 5e-5
+    for k in ("loss_d", "loss_g", "loss_g_gan", "loss_l1"):
+        assert abs(cap[k].item() - float(g["nu." + k])) < 2e-5 * abs(float(g["nu." + k])), k
+    for sd, nm in ((E, "E"), (G, "G"), (D, "D")):
+        for k, v in sd.items():
+            if "running_" in k:
+                assert relerr(v, g["nu.state.%s.%s" % (nm, k)]) < 1e-4, k
