@@ -652,6 +652,103 @@ def step_no_update(E, G, D, s, mask, cfg=StepConfig):
     }
 
 
+# --------------------------------------------------------------------------
+# the vision-infused step (BASELINE.json configs[2] / configs[3])
+# --------------------------------------------------------------------------
+# DECLARED ADAPTATIONS (the reference has neither the model class nor a multi-scale D):
+#  * video feature: ImageEmbedding2 returns f_v (B,256,1,w), w = N/4 = T/16.  MelDecoderImage.forward does
+#    `video_net.view(B,-1,h,w)` (New_Inpainting_Networks.py:119), which only works for bottleneck height h == 1.  For
+#    F = 256 (h == 2) f_v is TILED over the bottleneck height: v[b,c,i,j] = f_v[b,c,0,j] for every row i.
+#  * sync term: L2ContrastiveLoss(margin, max_violation=False) (loss_functions.py:113-148) between the audio bottleneck averaged
+#    over its height, one row per (clip, time step): f_a (B*w, 256), and f_v laid out the same way.
+#  * multi-scale D: num_D reference MelDiscriminators on the pyramid x, pool(x), pool(pool(x)) ... with
+#    pool = avg_pool2d(3, stride 2, padding 1, count_include_pad=False); the GAN loss is the MEAN of the per-scale losses.
+
+def msd_state(num_D, tag="D"):
+    """state of `num_D` MelDiscriminators, keys `scale{i}.<MelDiscriminator key>`."""
+    sd = OrderedDict()
+    for i in range(num_D):
+        for k, v in disc_state(tag="%s%d." % (tag, i)).items():
+            sd["scale%d.%s" % (i, k)] = v
+    return sd
+
+
+def msd_forward(sd, x, num_D, training=True):
+    outs = []
+    for i in range(num_D):
+        pre = "scale%d." % i
+        sub = _PrefixView(sd, pre)
+        outs.append(disc_forward(sub, x, training))
+        if i + 1 < num_D:
+            x = F.avg_pool2d(x, 3, 2, 1, count_include_pad=False)
+    return outs
+
+
+class _PrefixView(dict):
+    """sd[prefix + k] seen as sub[k]; writes (BatchNorm buffers) go through to the parent dict's tensors."""
+
+    def __init__(self, sd, prefix):
+        super().__init__((k[len(prefix):], v) for k, v in sd.items() if k.startswith(prefix))
+
+
+def av_generate(E, G, V, s, mask, video, flow, lambda_contrast=0.0, margin=1.0):
+    """E_a + E_v + MelDecoderImage forward of the vision-infused step; returns fake, feats, f_v, contrastive term."""
+    B = s.shape[0]
+    feats = encoder_forward(E, (s * mask).reshape(B, s.shape[2], s.shape[3]))
+    f_v, _fea = image_embedding2_forward(V, video, flow)                       # (B,256,1,w)
+    h, w = feats[-1].shape[2], feats[-1].shape[3]
+    assert f_v.shape[3] == w, "need N = T/4 frames"
+    tiled = f_v.expand(B, 256, h, w).contiguous()                              # declared adaptation: tiled over h
+    fake = decoder_variant_forward(G, "image", feats, s.shape, tiled)
+    lc = None
+    if lambda_contrast > 0:
+        f_a = feats[-1].mean(dim=2).permute(0, 2, 1).reshape(B * w, 256)
+        f_vv = f_v.reshape(B, 256, w).permute(0, 2, 1).reshape(B * w, 256)
+        lc = l2_contrastive(f_a, f_vv, margin, False)
+    return fake, feats, f_v, lc
+
+
+def av_step_no_update(E, G, D, V, s, mask, video, flow, num_D=1, lambda_contrast=0.0, margin=1.0, cfg=StepConfig):
+    """the declared G+D step (see step_no_update) with the visual branch and a multi-scale D; E, G (MelDecoderImage layout),
+    D (msd_state layout when num_D > 1, disc_state otherwise), V (image_embedding2_state) are updated in place (BN buffers)."""
+    Er, Gr, Dr, Vr = _leafify(E), _leafify(G), _leafify(D), _leafify(V)
+
+    def dis(sd, x):
+        return msd_forward(sd, x, num_D) if num_D > 1 else [disc_forward(sd, x)]
+
+    def gan(preds, real):
+        return sum(gan_loss(p, real, cfg.use_lsgan) for p in preds) / float(len(preds))
+    fake, feats, f_v, lc = av_generate(Er, Gr, Vr, s, mask, video, flow, lambda_contrast, margin)
+    pred_real = dis(Dr, s)
+    pred_fake_d = dis(Dr, fake.detach())
+    loss_d = 0.5 * (gan(pred_fake_d, False) + gan(pred_real, True))
+    dkeys = param_keys(Dr)
+    dgrads = dict(zip(dkeys, torch.autograd.grad(loss_d, [Dr[k] for k in dkeys])))
+    Df = OrderedDict((k, v.detach()) for k, v in Dr.items())
+    pred_fake_g = dis(Df, fake)
+    loss_g_gan = gan(pred_fake_g, True)
+    loss_l1 = l1_loss(fake, s)
+    loss_g = loss_g_gan + cfg.lambda_l1 * loss_l1
+    if lc is not None:
+        loss_g = loss_g + lambda_contrast * lc
+    ek, gk, vk = param_keys(Er), param_keys(Gr), param_keys(Vr)
+    leaves = [Er[k] for k in ek] + [Gr[k] for k in gk] + [Vr[k] for k in vk]
+    gg = torch.autograd.grad(loss_g, leaves, allow_unused=True)
+    with torch.no_grad():
+        for sd, r in ((E, Er), (G, Gr), (D, Df), (V, Vr)):
+            for k in sd:
+                sd[k].copy_(r[k].detach())
+    return {
+        "fake": fake.detach(), "feats": [f.detach() for f in feats], "f_v": f_v.detach(),
+        "pred_fake_d": [p.detach() for p in pred_fake_d], "pred_real": [p.detach() for p in pred_real],
+        "pred_fake_g": [p.detach() for p in pred_fake_g],
+        "loss_d": loss_d.detach(), "loss_g": loss_g.detach(), "loss_g_gan": loss_g_gan.detach(), "loss_l1": loss_l1.detach(),
+        "loss_contrast": (lc.detach() if lc is not None else torch.zeros(())),
+        "grads_D": dgrads, "grads_E": dict(zip(ek, gg[:len(ek)])), "grads_G": dict(zip(gk, gg[len(ek):len(ek) + len(gk)])),
+        "grads_V": dict(zip(vk, gg[len(ek) + len(gk):])),
+    }
+
+
 def new_optimizers(E, G, D, cfg=StepConfig):
     EG = OrderedDict([("E." + k, v) for k, v in E.items()] + [("G." + k, v) for k, v in G.items()])
     return Adam(EG, cfg), Adam(D, cfg)

@@ -414,6 +414,113 @@ def wavenet_g_goldens():
     print("wavenet_g -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+AV_CASE = dict(B=2, F=256, T=32, NF=8, num_D=2, lambda_contrast=0.1, margin=1.0)
+
+
+def av_step_goldens():
+    """The vision-infused step (BASELINE.json configs[2] / [3]) composed from the REFERENCE's modules -- MelEncoder,
+    ImageEmbedding2, MelDecoderImage, num_D MelDiscriminators, GANLoss, L2ContrastiveLoss -- with the adaptations declared in
+    oracle/viai_oracle.py (f_v tiled over the bottleneck height, avg-pool pyramid, mean of the per-scale GAN losses), at
+    B2 x 256 x 32 with 8 frames per clip (bottleneck 2 x 2: the tiling is exercised)."""
+    from networks import Image_Embedding as RefIE
+    c = AV_CASE
+    B, F_bins, T, NF, num_D = c["B"], c["F"], c["T"], c["NF"], c["num_D"]
+    lam_c, margin = c["lambda_contrast"], c["margin"]
+    s = O.cf_uniform("avstep.s", (B, 1, F_bins, T))
+    mask = O.make_mask(B, T, "avstep.mask")
+    video = O.cf_uniform("avstep.video", (B, NF, 3, 224, 224), -1, 1)
+    flow = O.cf_uniform("avstep.flow", (B, NF, 2, 224, 224), -1, 1)
+    RefEnc.hparams.cin_channels = F_bins
+    E = load_into(RefEnc.MelEncoder(), O.encoder_state()); E.hparams.cin_channels = F_bins
+    G = load_into(RefDec.MelDecoderImage(), O.decoder_variant_state("image"))
+    V = load_into(RefIE.ImageEmbedding2(), O.image_embedding2_state())
+    msd = O.msd_state(num_D)
+    Ds = [load_into(RefDis.MelDiscriminator(), O._PrefixView(msd, "scale%d." % i)) for i in range(num_D)]
+    for m in [E, G, V] + Ds:
+        m.train()
+    gan = RefLoss.GANLoss(use_lsgan=False, device=torch.device("cpu"))
+    _cuda = torch.cuda.is_available
+    torch.cuda.is_available = lambda: False          # loss_functions.py:139 calls .cuda() if available
+    l2c = RefLoss.L2ContrastiveLoss(margin=margin, max_violation=False)
+
+    def dis(x):
+        outs = []
+        for i, D in enumerate(Ds):
+            outs.append(D(x))
+            if i + 1 < num_D:
+                x = torch.nn.functional.avg_pool2d(x, 3, 2, 1, count_include_pad=False)
+        return outs
+
+    def gan_ms(preds, real):
+        return sum(gan(p, real) for p in preds) / float(len(preds))
+    feats = E((s * mask).view(B, F_bins, T))
+    f_v, _fea = V(video, flow)
+    h, w = feats[-1].shape[2], feats[-1].shape[3]
+    assert (h, w) == (2, 2) and tuple(f_v.shape) == (B, 256, 1, w)
+    fake = G(feats, s.size(), f_v.expand(B, 256, h, w).contiguous())
+    f_a = feats[-1].mean(dim=2).permute(0, 2, 1).reshape(B * w, 256)
+    f_vv = f_v.reshape(B, 256, w).permute(0, 2, 1).reshape(B * w, 256)
+    lc = l2c(f_a, f_vv)
+    pred_real = dis(s)
+    pred_fake_d = dis(fake.detach())
+    loss_d = 0.5 * (gan_ms(pred_fake_d, False) + gan_ms(pred_real, True))
+    loss_d.backward()
+    grads_D = {"scale%d.%s" % (i, k): p.grad.clone() for i, D in enumerate(Ds) for k, p in D.named_parameters()}
+    for D in Ds:
+        for p in D.parameters():
+            p.requires_grad_(False)
+    pred_fake_g = dis(fake)
+    loss_g_gan = gan_ms(pred_fake_g, True)
+    loss_l1 = torch.nn.functional.l1_loss(fake, s)
+    loss_g = loss_g_gan + LAMBDA_L1 * loss_l1 + lam_c * lc
+    loss_g.backward()
+    torch.cuda.is_available = _cuda
+    # ---- the oracle's composition reproduces it
+    oE, oG, oD, oV = O.encoder_state(), O.decoder_variant_state("image"), O.msd_state(num_D), O.image_embedding2_state()
+    ocap = O.av_step_no_update(oE, oG, oD, oV, s, mask, video, flow, num_D, lam_c, margin)
+    assert relerr(ocap["fake"], fake) < 5e-5, relerr(ocap["fake"], fake)
+    assert relerr(ocap["f_v"], f_v) < 5e-5
+    for k, ref in (("loss_d", loss_d), ("loss_g", loss_g), ("loss_l1", loss_l1), ("loss_contrast", lc)):
+        assert abs(ocap[k].item() - ref.item()) < 5e-5 * abs(ref.item()), (k, ocap[k].item(), ref.item())
+    for a, b in zip(ocap["pred_fake_g"], pred_fake_g):
+        assert relerr(a, b) < 5e-5
+    out = OrderedDict()
+    out["meta"] = np.array([B, F_bins, T, NF, num_D], dtype=np.int64)
+    out["lambda_contrast"], out["margin"] = np.float64(lam_c), np.float64(margin)
+    out["fake"] = fake.detach().numpy(); out["f_v"] = f_v.detach().numpy()
+    for i in range(num_D):
+        out["pred_real%d" % i] = pred_real[i].detach().numpy()
+        out["pred_fake_d%d" % i] = pred_fake_d[i].detach().numpy()
+        out["pred_fake_g%d" % i] = pred_fake_g[i].detach().numpy()
+    for k, v in (("loss_d", loss_d), ("loss_g", loss_g), ("loss_g_gan", loss_g_gan), ("loss_l1", loss_l1), ("loss_contrast", lc)):
+        out[k] = np.float64(v.item())
+    worst = 0.0
+    for grp, named, ogr in (("grads_D", grads_D.items(), ocap["grads_D"]),
+                            ("grads_E", ((k, p.grad) for k, p in E.named_parameters()), ocap["grads_E"]),
+                            ("grads_G", ((k, p.grad) for k, p in G.named_parameters()), ocap["grads_G"]),
+                            ("grads_V", ((k, p.grad) for k, p in V.named_parameters()), ocap["grads_V"])):
+        for k, g in named:
+            if g is None:
+                assert ogr[k] is None, (grp, k)
+                continue
+            if float(g.abs().max()) < 1e-6:          # bias in front of a train-mode BatchNorm: true gradient 0
+                continue
+            e = relerr(ogr[k], g); worst = max(worst, e)
+            assert e < 3e-2, (grp, k, e)
+            out["%s.%s.dg" % (grp, k)] = O.digest(g)
+    for nm, mod in (("E", E), ("G", G), ("V", V)):
+        for k, v in mod.state_dict().items():
+            if "running_" in k:
+                out["state.%s.%s" % (nm, k)] = v.numpy().copy()
+    for i, D in enumerate(Ds):
+        for k, v in D.state_dict().items():
+            if "running_" in k:
+                out["state.D.scale%d.%s" % (i, k)] = v.numpy().copy()
+    path = os.path.join(OUT, "step_av.npz")
+    np.savez_compressed(path, **out)
+    print("av step -> %s (%.1f KB); worst oracle-vs-reference gradient rel err %.2e" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024, worst))
+
+
 def adam_goldens():
     """torch.optim.Adam known-answer vectors (what the missing AudioModel's
     optimizer_G/optimizer_D are, utils/util.py:149-150)."""
@@ -525,6 +632,10 @@ if __name__ == "__main__":
     if "--wavenet-g-only" in sys.argv:
         wavenet_g_goldens()
         sys.exit(0)
+    if "--av-step-only" in sys.argv:
+        torch.set_num_threads(os.cpu_count())
+        av_step_goldens()
+        sys.exit(0)
     if "--cfg2-only" in sys.argv:
         torch.set_num_threads(os.cpu_count())
         run_case("cfg2", 16, 256, 256, 1, full=False)  # BASELINE.json configs[1], the benchmark size (digests only)
@@ -537,6 +648,7 @@ if __name__ == "__main__":
     resnet_goldens()
     wavenet_goldens()
     wavenet_g_goldens()
+    av_step_goldens()
     run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
     run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]
     if "--cfg2" in sys.argv:

@@ -178,7 +178,7 @@ class AudioModel:
         self.loss_mel_L1_item = 0.0
         self.mel_net_norm = None
         self.video_net_norm = None
-        self.losses = torch.zeros(5, device=self.device)      # loss_D, loss_G, loss_G_GAN, loss_L1, loss_D_real
+        self.losses = torch.zeros(6, device=self.device)      # loss_D, loss_G, loss_G_GAN, loss_L1, loss_D_real, EmbeddingL2
         self.mel = self.mask = self.fake = None
         self.use_graph = bool(use_graph)
         # weight gradients trail on a side stream (ops.WGRAD_STREAM) in eager mode: -3.5 % step time on one MI355X.  Inside
@@ -203,9 +203,11 @@ class AudioModel:
         self.optimizer_G = FusedAdam(self.arena_G, c.lr, (c.beta1, c.beta2), c.eps)
         self.optimizer_D = FusedAdam(self.arena_D, c.lr, (c.beta1, c.beta2), c.eps)
 
-    def load_states(self, E=None, G=None, D=None):
+    def load_states(self, E=None, G=None, D=None, V=None):
         """load state_dicts (e.g. the oracle's closed-form tables) without breaking the arenas."""
-        for mod, sd in ((self.Mel_Encoder, E), (self.Mel_Decoder, G), (self.netD, D)):
+        if V is not None and self.VideoEncoder is None:
+            raise ValueError("a VideoEncoder state was given but the model was built without use_video")
+        for mod, sd in ((self.Mel_Encoder, E), (self.Mel_Decoder, G), (self.netD, D), (self.VideoEncoder, V)):
             if sd is None:
                 continue
             own = mod.state_dict()
@@ -268,13 +270,15 @@ class AudioModel:
             return tot / float(len(pred))
         return ops.mse_mean(pred, t) if self.cfg.use_lsgan else ops.bce_mean(pred, t)
 
-    def _generate(self, s_nhwc):
-        """E (+ E_v) + G forward on NHWC; returns fake (B,F,T,1) and the contrastive term (or None)."""
+    def _generate(self, s_nhwc, want_feats=False):
+        """E (+ E_v) + G forward on NHWC; returns fake (B,F,T,1) and the contrastive term (or None)
+        [+ the encoder maps and the video feature (B,256,1,T/16) when `want_feats`]."""
         B, F, T, _ = s_nhwc.shape
         s_in = ops.mask_mul(s_nhwc, self.mask)
         feats = self.Mel_Encoder.forward_nhwc(s_in.view(B, F, T))
         if not self.use_video:
-            return self.Mel_Decoder.forward_nhwc(feats, (F, T)), None
+            fake = self.Mel_Decoder.forward_nhwc(feats, (F, T))
+            return (fake, None, feats, None) if want_feats else (fake, None)
         f_v, _fea = self.VideoEncoder(self.video, self.flow)                 # (B,256,1,N/4), (B,512,N)
         h, w = feats[-1].shape[1], feats[-1].shape[2]
         if f_v.shape[3] != w:
@@ -286,7 +290,7 @@ class AudioModel:
         if self.cfg.lambda_contrast > 0:
             f_a = feats[-1].mean(dim=1).reshape(B * w, 256)
             lc = ops.l2_contrastive(f_a.contiguous(), fv_nhwc.reshape(B * w, 256).contiguous(), self.cfg.contrast_margin, False)
-        return fake, lc
+        return (fake, lc, feats, f_v) if want_feats else (fake, lc)
 
     def _seg_forward_dstep(self):
         s = self.mel
@@ -346,6 +350,7 @@ class AudioModel:
         if self._lc is not None:
             loss_g = loss_g + self.cfg.lambda_contrast * self._lc
             self.EmbeddingL2 = self._lc.detach()
+            self.losses[5].copy_(self.EmbeddingL2)
         loss_g.backward()
         ops.join_wgrad()
         self.netD.requires_grad_(True)
@@ -364,8 +369,12 @@ class AudioModel:
     def _capture(self):
         """three HIP graphs split at the two gradient all-reduce points."""
         segs = (self._seg_forward_dstep, self._seg_dupdate_gstep, self._seg_gupdate)
-        # warm-up on a side stream (allocator + lazy init), restoring state afterwards is NOT needed for
-        # throughput runs; callers that need exact step counts should capture before training starts.
+        # Warm-up on a side stream (allocator + lazy init).  The warm-up runs two REAL steps (both Adam updates, the
+        # BatchNorm running statistics) without any gradient exchange, so everything a step mutates is snapshotted first
+        # and put back afterwards: a (re-)capture -- first step, or a new input shape -- then leaves parameters, Adam
+        # moments / step counters and BatchNorm buffers exactly where they were, on every rank.
+        snap = self._mutable_state()
+        saved = [t.clone() for t in snap]
         st = torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
@@ -373,6 +382,9 @@ class AudioModel:
                 for f in segs:
                     f()
         torch.cuda.current_stream().wait_stream(st)
+        for t, v in zip(snap, saved):
+            t.copy_(v)
+        self.weights_changed()
         graphs = []
         pool = None
         for f in segs:
@@ -382,6 +394,17 @@ class AudioModel:
             pool = g.pool()
             graphs.append(g)
         self._graphs = graphs
+
+    def _mutable_state(self):
+        """every device tensor a train step writes and the next step reads: parameter arenas, Adam moments and step
+        state, BatchNorm buffers."""
+        ts = []
+        for opt in (self.optimizer_G, self.optimizer_D):
+            ts += [opt.arena.flat, opt.exp_avg, opt.exp_avg_sq, opt.state]
+        for mod in (self.Mel_Encoder, self.Mel_Decoder, self.netD, self.VideoEncoder):
+            if mod is not None:
+                ts += [b for b in mod.buffers()]
+        return ts
 
     def optimize_parameters(self, global_step=0):
         """one G+D train step (train_whole_sync.py:76)."""
@@ -420,19 +443,31 @@ class AudioModel:
             ops.DIRECT_GRAD, ops.WGRAD_STREAM = prev, prev_s
 
     def test(self):
-        """forward only (train_whole_sync.py:79-80; caller wraps in no_grad)."""
+        """forward only (train_whole_sync.py:79-80,159-183: the caller sets `model.train = 0` and wraps in no_grad).
+        Runs the SAME generator path as the train step (`_generate`: with `use_video` the video feature goes through
+        `deconv1_1_1`).  With `self.train == 0` the modules are put in eval mode for the call (running BatchNorm
+        statistics, buffers untouched) and restored afterwards."""
         s = self.mel
         B, _, F, T = s.shape
-        with torch.no_grad():
-            s_in = ops.mask_mul(s.view(B, F, T, 1), self.mask)
-            feats = self.Mel_Encoder.forward_nhwc(s_in.view(B, F, T))
-            fake = self.Mel_Decoder.forward_nhwc(feats, (F, T))
-            self.fake = to_nchw_view(fake)
-            self.losses[3].copy_(ops.l1_mean(fake, s.view(B, F, T, 1)))
-            bott = feats[-1]                                   # (B, h, T/16, 256)
-            emb = bott.mean(dim=(1, 2))
-            self.mel_net_norm = torch.nn.functional.normalize(emb, p=2, dim=1)
-            self.video_net_norm = self.mel_net_norm
+        mods = [m for m in (self.Mel_Encoder, self.Mel_Decoder, self.VideoEncoder) if m is not None]
+        was = [m.training for m in mods]
+        if not self.train:
+            for m in mods:
+                m.eval()
+        try:
+            with torch.no_grad():
+                fake, _lc, feats, f_v = self._generate(s.view(B, F, T, 1), want_feats=True)
+                self.fake = to_nchw_view(fake)
+                self.losses[3].copy_(ops.l1_mean(fake, s.view(B, F, T, 1)))
+                emb = feats[-1].mean(dim=(1, 2))                   # bottleneck (B, h, T/16, 256) -> (B, 256)
+                self.mel_net_norm = torch.nn.functional.normalize(emb, p=2, dim=1)
+                # the retrieval metrics of the reference loop (utils/util.py:99-121) pair the audio embedding with the
+                # VIDEO embedding; without a visual branch there is nothing to pair it with
+                self.video_net_norm = (torch.nn.functional.normalize(f_v.mean(dim=(2, 3)), p=2, dim=1)
+                                       if f_v is not None else None)
+        finally:
+            for m, t in zip(mods, was):
+                m.train(t)
         return self.fake
 
     # ------------------------------------------------------------ bookkeeping
@@ -440,8 +475,8 @@ class AudioModel:
         """host sync point (train_whole_sync.py:85)."""
         v = self.losses.tolist()
         self.loss_D_item, self.loss_G_item, self.loss_G_GAN_item, self.loss_mel_L1_item = v[0], v[1], v[2], v[3]
-        self.reconstruct_loss_item = 0.0
-        self.EmbeddingL2_item = 0.0
+        self.reconstruct_loss_item = v[3]                      # the L1 reconstruction term (train_whole_sync.py:98 accumulates it)
+        self.EmbeddingL2_item = v[5] if (self.use_video and self.cfg.lambda_contrast > 0) else 0.0
         return v
 
     def get_current_errors(self):
@@ -476,23 +511,33 @@ class AudioModel:
     def save_inpainting_checkpoint(self, global_step, global_test_step, checkpoint_dir, epoch, hparams=None):
         """same dict layout as utils/util.py:146-162."""
         hp = hparams if hparams is not None else self.hparams
-        os.makedirs(checkpoint_dir, exist_ok=True)
         path = os.path.join(checkpoint_dir, getattr(hp, "name", "viai") + "_checkpoint_step{:09d}.pth.tar".format(global_step))
+        if self.world > 1 and torch.distributed.get_rank(self.pg) != 0:
+            return path                                     # replicas are identical: rank 0 writes, the others do not race it
+        os.makedirs(checkpoint_dir, exist_ok=True)
         keep = getattr(hp, "save_optimizer_state", True)
 
         def cpu_sd(m):
             return OrderedDict((k, v.detach().cpu().clone()) for k, v in m.state_dict().items())
-        torch.save({
-            "Mel_Encoder": cpu_sd(self.Mel_Encoder), "Mel_Decoder": cpu_sd(self.Mel_Decoder), "netD": cpu_sd(self.netD),
-            "optimizer_G": self.optimizer_G.state_dict() if keep else None,
-            "optimizer_D": self.optimizer_D.state_dict() if keep else None,
-            "global_step": global_step, "global_epoch": epoch, "global_test_step": global_test_step,
-        }, path)
+        ck = OrderedDict([
+            ("Mel_Encoder", cpu_sd(self.Mel_Encoder)), ("Mel_Decoder", cpu_sd(self.Mel_Decoder)), ("netD", cpu_sd(self.netD)),
+            ("optimizer_G", self.optimizer_G.state_dict() if keep else None),
+            ("optimizer_D", self.optimizer_D.state_dict() if keep else None),
+            ("global_step", global_step), ("global_epoch", epoch), ("global_test_step", global_test_step),
+        ])
+        if self.VideoEncoder is not None:
+            # utils/util.py:148 has this entry commented out -- there the visual branch was not in this optimizer; here it is
+            # trained by optimizer_G (whose state dict indexes its parameters too), so a resume needs its weights and buffers
+            ck["VideoEncoder"] = cpu_sd(self.VideoEncoder)
+        torch.save(ck, path)
         return path
 
     def load_inpainting_checkpoint(self, path, reset_optimizer=False):
         ck = torch.load(path, map_location="cpu", weights_only=False)
-        self.load_states(ck["Mel_Encoder"], ck["Mel_Decoder"], ck["netD"])
+        if self.VideoEncoder is not None and "VideoEncoder" not in ck and not reset_optimizer:
+            raise KeyError("checkpoint has no 'VideoEncoder' entry: optimizer_G's moments would not belong to the freshly "
+                           "initialised visual branch (pass reset_optimizer=True to load E/G/D only)")
+        self.load_states(ck["Mel_Encoder"], ck["Mel_Decoder"], ck["netD"], ck.get("VideoEncoder") if self.VideoEncoder is not None else None)
         if not reset_optimizer:
             if ck.get("optimizer_G") is not None:
                 self.optimizer_G.load_state_dict(ck["optimizer_G"])
