@@ -39,6 +39,17 @@ class WNConfigG(WNConfig):
     n_speakers = 3
 
 
+class WNConfigFull(WNConfig):
+    """the reference's own size (24 layers / 4 stacks / 512 residual + gate / 256 skip channels,
+    up-sampling [4,4,4,4] = hop 256; 24.7 M parameters): BASELINE.json configs[4]."""
+    layers = 24
+    stacks = 4
+    residual_channels = 512
+    gate_channels = 512
+    skip_out_channels = 256
+    upsample_scales = (4, 4, 4, 4)
+
+
 def wavenet_state(cfg=WNConfig, tag="WN."):
     """state_dict of WaveNet with weight normalisation (keys: *.weight_g, *.weight_v, *.bias)."""
     sd = OrderedDict()

@@ -171,3 +171,90 @@ def test_lr_schedule_reaches_the_device_adam_state():
     opt = FusedAdam(arena, 1e-3, (0.9, 0.999), 1e-8)
     lr = L.apply_schedule(opt, L.noam_learning_rate_decay, 1e-3, 100, warmup_steps=2000)
     assert abs(float(opt.state[1]) - lr) <= 1e-18 and abs(lr - 1e-3 * 2000 ** 0.5 * 101 * 2000 ** -1.5) < 1e-15
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# checkpoint interchange against what the REFERENCE writes (utils/util.py:146-162)
+# ------------------------------------------------------------------------------------------------------------------
+
+def _describe(v):
+    """same structure walk as tools/make_goldens.py::checkpoint_structure_golden"""
+    from collections import OrderedDict
+    if torch.is_tensor(v):
+        return {"tensor": list(v.shape), "dtype": str(v.dtype).replace("torch.", "")}
+    if isinstance(v, dict):
+        return {"dict": [[k if isinstance(k, str) else int(k), _describe(x)] for k, x in v.items()], "ordered": isinstance(v, OrderedDict)}
+    if isinstance(v, (list, tuple)):
+        return {type(v).__name__: [_describe(x) for x in v]}
+    return {type(v).__name__: v}
+
+
+def _ref_structure(golden_dir):
+    import json
+    with open(os.path.join(golden_dir, "checkpoint_structure.json")) as f:
+        return json.load(f)
+
+
+def test_optimizer_state_dict_has_the_reference_layout_cpu(golden_dir):
+    """FusedAdam.state_dict() over the flat arena == the torch.optim.Adam state_dict inside a checkpoint written by the reference's
+    save_inpainting_checkpoint: same param_group keys and values, same per-parameter entries (none for the never-reached
+    convblock1.*), same tensor shapes / dtypes, `step` as a 0-d float tensor.  (CPU: only the host-side container logic.)"""
+    from viai_amd import networks as N
+    from viai_amd.model import FlatArena, FusedAdam
+    ref = dict(_ref_structure(golden_dir)["checkpoint"]["dict"])
+    E, G, D = N.MelEncoder(), N.MelDecoder(), N.MelDiscriminator()
+    g_named = [("E." + n, p) for n, p in E.named_parameters()] + [("G." + n, p) for n, p in G.named_parameters()]
+    arena = FlatArena(g_named)
+    dead = [i for i, n in enumerate(arena.names) if n.startswith("G.convblock1.")]
+    opt = FusedAdam(arena, 2e-4, (0.5, 0.999), 1e-8, dead)
+    assert opt.state_dict()["state"] == {}                                   # before the first step torch has no state either
+    opt.state[0] = 1.0
+    assert _describe(opt.state_dict()) == ref["optimizer_G"]
+    optD = FusedAdam(FlatArena([("D." + n, p) for n, p in D.named_parameters()]), 2e-4, (0.5, 0.999), 1e-8)
+    optD.state[0] = 1.0
+    assert _describe(optD.state_dict()) == ref["optimizer_D"]
+    for mod, key in ((E, "Mel_Encoder"), (G, "Mel_Decoder"), (D, "netD")):
+        assert _describe(mod.state_dict()) == ref[key], key
+    # and the reverse direction: a torch.optim.Adam accepts it
+    tE, tG = N.MelEncoder(), N.MelDecoder()
+    topt = torch.optim.Adam(list(tE.parameters()) + list(tG.parameters()), lr=1e-3)
+    topt.load_state_dict(opt.state_dict())
+    assert topt.param_groups[0]["lr"] == 2e-4 and len(topt.state) == len(opt.state_dict()["state"])
+
+
+@pytest.mark.gpu
+def test_checkpoint_file_has_the_reference_structure_and_reference_style_files_load(tmp_path, golden_dir):
+    """AudioModel.save_inpainting_checkpoint after one step writes the SAME structure (top-level key order, file name, module
+    state_dict keys / shapes / dtypes, optimizer layout, python scalar types) as the reference's save_inpainting_checkpoint did
+    for its own modules (tests/golden/checkpoint_structure.json); a checkpoint assembled the reference's way (torch modules'
+    state_dicts + torch.optim.Adam.state_dict()) loads and continues bit-identically to the model it was taken from."""
+    from viai_amd.model import AudioModel, StepConfig
+    ref = _ref_structure(golden_dir)
+    hp = StepConfig()
+    hp.cin_channels, hp.max_mel_lengths, hp.name = 80, 32, "viai_golden"
+    s = O.cf_uniform("s.tiny", (2, 1, 80, 32))
+    mask = O.make_mask(2, 32, "mask.tiny")
+    a = AudioModel(hp, device="cuda")
+    a.load_states(O.encoder_state(), O.decoder_state(), O.disc_state())
+    a.set_inputs(s, mask)
+    a.optimize_parameters(0)
+    path = a.save_inpainting_checkpoint(7, 3, str(tmp_path), 2)
+    assert os.path.basename(path) == ref["file_name"]
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert _describe(ck) == ref["checkpoint"]
+    # reference-style file: plain torch containers.  torch.optim.Adam round-trips our optimizer state, then writes it its own way
+    import collections
+    tparams = [torch.nn.Parameter(p.detach().cpu().clone()) for p in a.arena_G.params]
+    topt = torch.optim.Adam(tparams, lr=1e-3)
+    topt.load_state_dict(ck["optimizer_G"])
+    ck2 = collections.OrderedDict(ck)
+    ck2["optimizer_G"] = topt.state_dict()
+    p2 = os.path.join(str(tmp_path), "ref_style.pth.tar")
+    torch.save(dict(ck2), p2)
+    b = AudioModel(hp, device="cuda")
+    assert b.load_inpainting_checkpoint(p2) == (7, 2, 3)
+    b.set_inputs(s, mask)
+    a.optimize_parameters(1)
+    b.optimize_parameters(1)
+    torch.cuda.synchronize()
+    assert torch.equal(a.arena_G.flat, b.arena_G.flat) and torch.equal(a.arena_D.flat, b.arena_D.flat)

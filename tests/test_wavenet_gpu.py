@@ -158,3 +158,31 @@ def test_global_conditioning_matches_reference_golden(golden_dir):
     # and the speaker matters
     gen2 = net.incremental_forward(None, c=cg, g=torch.tensor([[1], [1]]).cuda(), T=Tg, test_inputs=tin, uniforms=(v1, v2), log_scale_min=-7.0)
     assert relerr(gen2.cpu(), torch.from_numpy(gold["gen"])) > 1e-2
+
+
+def test_reference_size_wavenet_matches_reference_digests(golden_dir):
+    """BASELINE.json configs[4] model size (24 layers / 4 stacks / 512 / 512 / 256 channels, hop 256: wavenet.py:62-175 selects other
+    conv tiles -- K = 1536 -- than the 64-channel test config): teacher-forced forward, MoL loss and gradient digests at B1, T = 1024
+    against tests/golden/wavenet_full.npz (tools/make_goldens.py --wavenet-full-only, the reference's wavenet_vocoder package)."""
+    from viai_amd.wavenet import DiscretizedMixturelogisticLoss
+    gold = np.load(golden_dir + "/wavenet_full.npz")
+    cfg = W.WNConfigFull
+    B, T = [int(v) for v in gold["meta"]]
+    x = O.cf_uniform("wnf.x", (B, 1, T), -1, 1)
+    c = O.cf_uniform("wnf.c", (B, cfg.cin_channels, T // 256), 0, 1)
+    y = O.cf_uniform("wnf.y", (B, T, 1), -1, 1)
+    net = build(cfg).train()
+    assert sum(p.numel() for p in net.parameters()) == 24737396
+    yh = net(x.cuda(), c.cuda())
+    assert tuple(yh.shape) == (B, 30, T)
+    assert relerr(yh[:, :, -64:], gold["yhat_tail"]) < 1e-4
+    assert relerr(O.digest(yh.contiguous(), 256), gold["yhat.dg"]) < 1e-4
+    loss = DiscretizedMixturelogisticLoss()(yh, y.cuda(), mask=torch.ones(B, T, 1).cuda())
+    assert abs(loss.item() - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
+    loss.backward()
+    params = dict(net.named_parameters())
+    for k in gold.files:
+        if k.startswith("g."):
+            dg, ref = O.digest(params[k[2:-3]].grad), gold[k]
+            assert abs(dg[2] - ref[2]) < 2e-3 * ref[2], (k, dg[2], ref[2])
+            assert np.linalg.norm(dg[3:] - ref[3:]) < 4e-3 * np.linalg.norm(ref[3:]), k

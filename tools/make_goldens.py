@@ -365,6 +365,49 @@ def wavenet_goldens():
     print("wavenet -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def wavenet_full_goldens():
+    """WaveNet at the REFERENCE's size (24 layers / 4 stacks / 512 / 512 / 256, hop 256; SURVEY.md section 8c "one full-size
+    digest"): teacher-forced forward, MoL loss and gradient digests at B1, T = 1024 from the reference's wavenet_vocoder."""
+    import Config  # noqa: F401
+    from oracle import wavenet_oracle as W
+    cfg = W.WNConfigFull
+    from wavenet_vocoder import wavenet as RW, mixture as RM
+    net = RW.WaveNet(out_channels=cfg.out_channels, layers=cfg.layers, stacks=cfg.stacks, residual_channels=cfg.residual_channels,
+                     gate_channels=cfg.gate_channels, skip_out_channels=cfg.skip_out_channels, kernel_size=cfg.kernel_size, dropout=0.0,
+                     cin_channels=cfg.cin_channels, gin_channels=-1, n_speakers=None, weight_normalization=True,
+                     upsample_conditional_features=True, upsample_scales=list(cfg.upsample_scales),
+                     freq_axis_kernel_size=cfg.freq_axis_kernel_size, scalar_input=True)
+    sd = W.wavenet_state(cfg)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    assert sum(p.numel() for p in net.parameters()) == 24737396           # SURVEY.md section 8a [probe]
+    load_into(net, sd)
+    net.train()
+    B, T = 1, 1024
+    x = O.cf_uniform("wnf.x", (B, 1, T), -1, 1)
+    c = O.cf_uniform("wnf.c", (B, cfg.cin_channels, T // 256), 0, 1)
+    y = O.cf_uniform("wnf.y", (B, T, 1), -1, 1)
+    yh = net(x, c)
+    losses = RM.discretized_mix_logistic_loss(yh, y, num_classes=65536, log_scale_min=float(np.log(1e-14)), reduce=False)
+    loss = losses.mean()
+    loss.backward()
+    oyh = W.wavenet_forward(sd, x, c, cfg)
+    assert relerr(oyh, yh) < 1e-5, relerr(oyh, yh)
+    assert abs(W.mol_loss(oyh, y, torch.ones(B, T, 1)).item() - loss.item()) < 1e-5 * abs(loss.item())
+    out = OrderedDict()
+    out["meta"] = np.array([B, T], dtype=np.int64)
+    out["yhat.dg"] = O.digest(yh, 256)
+    out["yhat_tail"] = yh.detach()[:, :, -64:].numpy()
+    out["loss"] = np.float64(loss.item())
+    params = dict(net.named_parameters())
+    for k in ("first_conv.weight_g", "conv_layers.0.conv.weight_v", "conv_layers.11.conv.weight_g", "conv_layers.23.conv.weight_v",
+              "conv_layers.23.conv1x1c.weight_v", "conv_layers.12.conv1x1_skip.bias", "conv_layers.5.conv1x1_out.weight_v",
+              "last_conv_layers.1.weight_v", "last_conv_layers.3.weight_v", "upsample_conv.0.weight_v", "upsample_conv.6.bias"):
+        out["g.%s.dg" % k] = O.digest(params[k].grad)
+    path = os.path.join(OUT, "wavenet_full.npz")
+    np.savez_compressed(path, **out)
+    print("wavenet_full -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def wavenet_g_goldens():
     """WaveNet with global (speaker) conditioning: teacher-forced forward and incremental_forward from the reference."""
     import Config  # noqa: F401
@@ -521,6 +564,40 @@ def av_step_goldens():
     print("av step -> %s (%.1f KB); worst oracle-vs-reference gradient rel err %.2e" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024, worst))
 
 
+def checkpoint_structure_golden():
+    """The `.pth.tar` dictionary the REFERENCE's own `utils/util.save_inpainting_checkpoint` (utils/util.py:146-162) writes for a
+    model holding reference MelEncoder / MelDecoder / MelDiscriminator modules and two torch.optim.Adam optimizers after one
+    step: captured as a STRUCTURE (key order, tensor shapes / dtypes, optimizer state_dict layout, python types of the scalars) in
+    tests/golden/checkpoint_structure.json.  The file itself (69 MB of closed-form weights) is not kept."""
+    import json
+    import tempfile
+    from utils import util as RefUtil
+    E, G, D, optG, optD, gan = fresh(80)
+    s = O.cf_uniform("s.tiny", (2, 1, 80, 32))
+    ref_step(E, G, D, optG, optD, gan, s, O.make_mask(2, 32, "mask.tiny"), update=True)
+    model = types.SimpleNamespace(Mel_Encoder=E, Mel_Decoder=G, netD=D, optimizer_G=optG, optimizer_D=optD)
+    hp = types.SimpleNamespace(name="viai_golden", save_optimizer_state=True)
+
+    def describe(v):
+        if torch.is_tensor(v):
+            return {"tensor": list(v.shape), "dtype": str(v.dtype).replace("torch.", "")}
+        if isinstance(v, dict):
+            return {"dict": [[k if isinstance(k, str) else int(k), describe(x)] for k, x in v.items()], "ordered": isinstance(v, OrderedDict)}
+        if isinstance(v, (list, tuple)):
+            return {type(v).__name__: [describe(x) for x in v]}
+        return {type(v).__name__: v}
+    with tempfile.TemporaryDirectory() as td:
+        RefUtil.save_inpainting_checkpoint(model, 7, 3, td, 2, hparams=hp)
+        files = os.listdir(td)
+        assert files == ["viai_golden_checkpoint_step000000007.pth.tar"], files
+        ck = torch.load(os.path.join(td, files[0]), map_location="cpu", weights_only=False)
+    out = {"file_name": files[0], "checkpoint": describe(ck)}
+    path = os.path.join(OUT, "checkpoint_structure.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=None, separators=(",", ":"))
+    print("checkpoint structure -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def adam_goldens():
     """torch.optim.Adam known-answer vectors (what the missing AudioModel's
     optimizer_G/optimizer_D are, utils/util.py:149-150)."""
@@ -632,6 +709,13 @@ if __name__ == "__main__":
     if "--wavenet-g-only" in sys.argv:
         wavenet_g_goldens()
         sys.exit(0)
+    if "--wavenet-full-only" in sys.argv:
+        torch.set_num_threads(os.cpu_count())
+        wavenet_full_goldens()
+        sys.exit(0)
+    if "--checkpoint-only" in sys.argv:
+        checkpoint_structure_golden()
+        sys.exit(0)
     if "--av-step-only" in sys.argv:
         torch.set_num_threads(os.cpu_count())
         av_step_goldens()
@@ -648,7 +732,9 @@ if __name__ == "__main__":
     resnet_goldens()
     wavenet_goldens()
     wavenet_g_goldens()
+    wavenet_full_goldens()
     av_step_goldens()
+    checkpoint_structure_golden()
     run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
     run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]
     if "--cfg2" in sys.argv:

@@ -87,8 +87,12 @@ class FusedAdam:
     """torch.optim.Adam semantics (no amsgrad / weight decay) as one HIP kernel over a FlatArena.
     The step counter and bias corrections live on the device (graph-replayable)."""
 
-    def __init__(self, arena: FlatArena, lr, betas, eps):
+    def __init__(self, arena: FlatArena, lr, betas, eps, stateless=()):
+        """`stateless`: indices of parameters the forward never reaches (e.g. MelDecoder.convblock1.*): torch.optim.Adam keeps
+        no state for a parameter whose .grad stays None, and neither does state_dict() here (their gradient is exactly zero, so
+        the kernel leaves them and their moments untouched anyway)."""
         self.arena = arena
+        self.stateless = frozenset(int(i) for i in stateless)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.exp_avg = torch.zeros_like(arena.flat)
         self.exp_avg_sq = torch.zeros_like(arena.flat)
@@ -110,12 +114,16 @@ class FusedAdam:
     def state_dict(self):
         step = float(self.state[0].item())
         st = {}
-        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
-            n = p.numel()
-            st[i] = {"step": torch.tensor(step), "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
-                     "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
-        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
-                 "params": list(range(len(self.arena.params)))}
+        if step > 0:                                      # torch creates the per-parameter state lazily, at the first step
+            for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+                if i in self.stateless:
+                    continue
+                n = p.numel()
+                st[i] = {"step": torch.tensor(step), "exp_avg": self.exp_avg[o:o + n].view(p.shape).detach().cpu().clone(),
+                         "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).detach().cpu().clone()}
+        # the param_group of the installed torch.optim.Adam (its key set differs between torch versions), with our values
+        group = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=self.lr, betas=self.betas, eps=self.eps).state_dict()["param_groups"][0]
+        group["params"] = list(range(len(self.arena.params)))
         return {"state": st, "param_groups": [group]}
 
     def load_state_dict(self, sd):
@@ -200,7 +208,10 @@ class AudioModel:
         d_named = [("D." + n, p) for n, p in self.netD.named_parameters()]
         self.arena_G = FlatArena(g_named)
         self.arena_D = FlatArena(d_named)
-        self.optimizer_G = FusedAdam(self.arena_G, c.lr, (c.beta1, c.beta2), c.eps)
+        dead = tuple("G." + p for p in getattr(self.Mel_Decoder, "UNUSED_PREFIXES", ())) + \
+            tuple("V." + p for p in getattr(self.VideoEncoder, "UNUSED_PREFIXES", ()))
+        stateless = [i for i, n in enumerate(self.arena_G.names) if n.startswith(dead)] if dead else []
+        self.optimizer_G = FusedAdam(self.arena_G, c.lr, (c.beta1, c.beta2), c.eps, stateless)
         self.optimizer_D = FusedAdam(self.arena_D, c.lr, (c.beta1, c.beta2), c.eps)
 
     def load_states(self, E=None, G=None, D=None, V=None):
@@ -529,7 +540,7 @@ class AudioModel:
             # utils/util.py:148 has this entry commented out -- there the visual branch was not in this optimizer; here it is
             # trained by optimizer_G (whose state dict indexes its parameters too), so a resume needs its weights and buffers
             ck["VideoEncoder"] = cpu_sd(self.VideoEncoder)
-        torch.save(ck, path)
+        torch.save(dict(ck), path)          # a plain dict, as utils/util.py:150 writes
         return path
 
     def load_inpainting_checkpoint(self, path, reset_optimizer=False):

@@ -152,6 +152,8 @@ class MelDecoder(nn.Module):
     skip concat with e2 at the third scale, Sigmoid (New_Inpainting_Networks.py:48-89).
     `convblock1` exists for state_dict parity but is never used by forward (as in the reference)."""
 
+    UNUSED_PREFIXES = ("convblock1.",)        # registered, never reached by forward: .grad stays None in the reference
+
     def __init__(self, hparams=hparams, norm_layer=None):
         super().__init__()
         norm_layer = norm_layer if norm_layer is not None else getattr(hparams, "normlayer", nn.BatchNorm2d)
@@ -197,6 +199,8 @@ class MelDecoderImage(MelDecoder):
     """AV decoder: the video feature (B,256,1,T/16) is concatenated to the bottleneck on C and
     `deconv1_1_1` (512->256) replaces `deconv1_1` (New_Inpainting_Networks.py:92-143).  `deconv1_1(+_bn)`
     stay in the state_dict (unused by forward, exactly as in the reference); `convblock1` does not exist."""
+
+    UNUSED_PREFIXES = ("deconv1_1.", "deconv1_1_bn.")
 
     def __init__(self, hparams=hparams, norm_layer=None):
         super().__init__(hparams, norm_layer)
@@ -471,6 +475,8 @@ class _ImageEmbeddingBase(nn.Module):
 class ImageEmbedding2(_ImageEmbeddingBase):
     """E_v (networks/Image_Embedding.py:174-200): RGB ResNet-18 + flow ResNet-18 per frame -> cat -> Conv1d(512,512,3,2,1)
     -> Conv1d(512,256,3,2,1); returns (out (B,256,1,N/4), fea_cat (B,512,N)).  bn_1 / bn_2 exist but are unused."""
+
+    UNUSED_PREFIXES = ("bn_1.", "bn_2.")
 
     def __init__(self, hparams=hparams):
         super().__init__()
