@@ -50,6 +50,12 @@ class WNConfigFull(WNConfig):
     upsample_scales = (4, 4, 4, 4)
 
 
+class WNConfigOneHot(WNConfig):
+    """the small configuration with one-hot (mu-law, 256 classes) input and softmax-logit output (`scalar_input=False`)."""
+    out_channels = 256
+    scalar_input = False
+
+
 def wavenet_state(cfg=WNConfig, tag="WN."):
     """state_dict of WaveNet with weight normalisation (keys: *.weight_g, *.weight_v, *.bias)."""
     sd = OrderedDict()
@@ -59,7 +65,7 @@ def wavenet_state(cfg=WNConfig, tag="WN."):
         sd[name + ".bias"] = cf_uniform(tag + name + ".b", (cout,), -0.05, 0.05)
         sd[name + ".weight_g"] = (v.reshape(cout, -1).norm(dim=1) * cf_uniform(tag + name + ".g", (cout,), 0.8, 1.2)).reshape(cout, 1, 1)
         sd[name + ".weight_v"] = v
-    conv("first_conv", cfg.residual_channels, 1, 1)
+    conv("first_conv", cfg.residual_channels, 1 if getattr(cfg, "scalar_input", True) else cfg.out_channels, 1)   # wavenet.py:116-119
     for i in range(cfg.layers):
         p = "conv_layers.%d." % i
         conv(p + "conv", cfg.gate_channels, cfg.residual_channels, cfg.kernel_size)

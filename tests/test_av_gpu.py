@@ -230,3 +230,47 @@ def test_av_test_mode_uses_the_trained_generator_path_and_leaves_buffers_alone()
     fv, _ = O.image_embedding2_forward(sdV, video.flip(1) * 0.5, flow, training=False)
     ofake = O.decoder_variant_forward(sdG, "image", feats, s.shape, fv.expand(B, 256, feats[-1].shape[2], feats[-1].shape[3]).contiguous(), training=False)
     assert relerr(f1, ofake) < 2e-4
+
+
+def test_instance_norm_branch_matches_reference_modules(golden_dir):
+    """`norm_layer=nn.InstanceNorm2d` (Discriminator_Networks.py:10-14, New_Inpainting_Networks.py:12-16, Inpainting_Networks.py:50-56:
+    the convs then carry a bias, the encoder's norms are affine) against outputs of the reference's modules
+    (tests/golden/instnorm.npz, tools/make_goldens.py --instnorm-only)."""
+    from collections import OrderedDict
+    from viai_amd import networks as N
+    gold = np.load(golden_dir + "/instnorm.npz")
+    IN = torch.nn.InstanceNorm2d
+    D = N.MelDiscriminator(norm_layer=IN)
+    base = O.disc_state()
+    sd = OrderedDict((k, base[k] if k in base else O.cf_uniform("in.D." + k, tuple(v.shape), -0.1, 0.1)) for k, v in D.state_dict().items())
+    assert list(sd.keys()) == ["conv1.weight", "conv1.bias", "conv2_1.weight", "conv2_1.bias", "conv2_2.weight", "conv2_2.bias",
+                               "conv3.weight", "conv3.bias", "conv4.weight", "conv4.bias"]
+    D.load_state_dict(sd); D = D.cuda().train()
+    y = D(O.cf_uniform("in.x", (2, 1, 32, 64)).cuda())
+    assert relerr(y, gold["D.out"]) < 1e-4
+    y.mean().backward()
+    for k in ("conv1.weight", "conv2_2.weight", "conv3.weight", "conv4.weight", "conv4.bias"):
+        dg, ref = O.digest(dict(D.named_parameters())[k].grad), gold["D.g.%s.dg" % k]
+        assert abs(dg[2] - ref[2]) < 2e-3 * ref[2] and np.linalg.norm(dg[3:] - ref[3:]) < 4e-3 * np.linalg.norm(ref[3:]), k
+    assert float(D.conv3.bias.grad.abs().max()) < 1e-6 and float(np.abs(gold["D.g.conv3.bias.dg"][1])) < 1e-3   # bias before a norm: zero gradient
+    blk = N.TransConvBlock(32, 16, "9", nums=2, norm_layer=IN)
+    bsd = OrderedDict((k, O.cf_std("in.blk." + k, tuple(v.shape), 0.1)) for k, v in blk.state_dict().items())
+    assert list(bsd.keys()) == ["conv9_0.weight", "conv9_0.bias", "conv9_1.weight", "conv9_1.bias"]
+    blk.load_state_dict(bsd); blk = blk.cuda().train()
+    xb = O.cf_uniform("in.xb", (2, 32, 8, 16), -1, 1).cuda().requires_grad_(True)
+    yb = blk(xb)
+    assert relerr(yb, gold["blk.out"]) < 1e-4
+    yb.pow(2).mean().backward()
+    assert relerr(xb.grad, gold["blk.dx"]) < 2e-3 and relerr(blk.conv9_1.weight.grad, gold["blk.g.conv9_1.weight"]) < 2e-3
+    E = N.MelEncoder(norm_layer=IN)
+    ebase = O.encoder_state()
+    esd = OrderedDict((k, ebase[k] if k in ebase else O.cf_uniform("in.E." + k, tuple(v.shape), -0.1, 0.1)) for k, v in E.state_dict().items())
+    assert "conv1.bias" in esd and "bn1.weight" in esd and "bn1.running_mean" not in esd
+    E.load_state_dict(esd); E = E.cuda().train()
+    fe = E(O.cf_uniform("in.xe", (2, 96, 32)).cuda())
+    for i in (0, 3):
+        assert relerr(fe[i], gold["E.feat%d" % i]) < 1e-4, i
+    sum(f.pow(2).mean() for f in fe).backward()
+    assert relerr(E.bn2.weight.grad, gold["E.g.bn2.weight"]) < 2e-3
+    dg, ref = O.digest(E.conv3.weight.grad), gold["E.g.conv3.weight.dg"]
+    assert abs(dg[2] - ref[2]) < 2e-3 * ref[2]

@@ -408,6 +408,42 @@ def wavenet_full_goldens():
     print("wavenet_full -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def wavenet_onehot_goldens():
+    """WaveNet with one-hot (mu-law) input, `scalar_input=False` (wavenet.py:116-119,177-235): teacher-forced forward and the
+    gradients of a cross-entropy loss, from the reference's module.  (`forward(softmax=True)` raises a TypeError in the
+    reference -- `self.softmax(x, dim=1)`, wavenet.py:233 -- so only the logits path exists to compare.)"""
+    import Config  # noqa: F401
+    from oracle import wavenet_oracle as W
+    cfg = W.WNConfigOneHot
+    from wavenet_vocoder import wavenet as RW
+    net = RW.WaveNet(out_channels=cfg.out_channels, layers=cfg.layers, stacks=cfg.stacks, residual_channels=cfg.residual_channels,
+                     gate_channels=cfg.gate_channels, skip_out_channels=cfg.skip_out_channels, kernel_size=cfg.kernel_size, dropout=0.0,
+                     cin_channels=cfg.cin_channels, gin_channels=-1, n_speakers=None, weight_normalization=True,
+                     upsample_conditional_features=True, upsample_scales=list(cfg.upsample_scales),
+                     freq_axis_kernel_size=cfg.freq_axis_kernel_size, scalar_input=False)
+    sd = W.wavenet_state(cfg)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    load_into(net, sd)
+    net.train()
+    B, T = 2, 64
+    idx = (O.cf_uniform("wno.idx", (B, T), 0, 1) * cfg.out_channels).long().clamp(max=cfg.out_channels - 1)
+    x = torch.nn.functional.one_hot(idx, cfg.out_channels).float().transpose(1, 2).contiguous()        # (B, 256, T)
+    c = O.cf_uniform("wno.c", (B, cfg.cin_channels, T // 16), 0, 1)
+    tgt = (O.cf_uniform("wno.tgt", (B, T), 0, 1) * cfg.out_channels).long().clamp(max=cfg.out_channels - 1)
+    yh = net(x, c)
+    loss = torch.nn.functional.cross_entropy(yh, tgt)
+    loss.backward()
+    oyh = W.wavenet_forward(sd, x, c, cfg)
+    assert relerr(oyh, yh) < 1e-5, relerr(oyh, yh)
+    out = OrderedDict()
+    out["yhat"] = yh.detach().numpy(); out["loss"] = np.float64(loss.item())
+    for k in ("first_conv.weight_v", "first_conv.weight_g", "conv_layers.2.conv.weight_v", "last_conv_layers.3.weight_v", "last_conv_layers.3.bias"):
+        out["g.%s" % k] = dict(net.named_parameters())[k].grad.numpy().copy()
+    path = os.path.join(OUT, "wavenet_onehot.npz")
+    np.savez_compressed(path, **out)
+    print("wavenet_onehot -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def wavenet_g_goldens():
     """WaveNet with global (speaker) conditioning: teacher-forced forward and incremental_forward from the reference."""
     import Config  # noqa: F401
@@ -598,6 +634,49 @@ def checkpoint_structure_golden():
     print("checkpoint structure -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def instnorm_goldens():
+    """the `norm_layer=nn.InstanceNorm2d` branch of the reference constructors (Discriminator_Networks.py:10-14,
+    New_Inpainting_Networks.py:12-16, Inpainting_Networks.py:50-52): reference modules, closed-form weights."""
+    out = OrderedDict()
+    IN = torch.nn.InstanceNorm2d
+    D = RefDis.MelDiscriminator(norm_layer=IN)
+    base = O.disc_state()                                     # use_bias = (norm_layer == InstanceNorm2d): the convs carry a bias (:14)
+    sd = OrderedDict((k, base[k] if k in base else O.cf_uniform("in.D." + k, tuple(v.shape), -0.1, 0.1)) for k, v in D.state_dict().items())
+    assert list(sd.keys()) == ["conv1.weight", "conv1.bias", "conv2_1.weight", "conv2_1.bias", "conv2_2.weight", "conv2_2.bias",
+                               "conv3.weight", "conv3.bias", "conv4.weight", "conv4.bias"]
+    load_into(D, sd); D.train()
+    x = O.cf_uniform("in.x", (2, 1, 32, 64))
+    y = D(x)
+    y.mean().backward()
+    out["D.out"] = y.detach().numpy()
+    for k in ("conv1.weight", "conv2_2.weight", "conv3.weight", "conv4.weight", "conv4.bias", "conv3.bias"):
+        out["D.g.%s.dg" % k] = O.digest(dict(D.named_parameters())[k].grad)
+    blk = RefDec.TransConvBlock(32, 16, "9", nums=2, norm_layer=IN)
+    bsd = OrderedDict((k, O.cf_std("in.blk." + k, tuple(v.shape), 0.1)) for k, v in blk.state_dict().items())
+    assert list(bsd.keys()) == ["conv9_0.weight", "conv9_0.bias", "conv9_1.weight", "conv9_1.bias"]
+    load_into(blk, bsd); blk.train()
+    xb = O.cf_uniform("in.xb", (2, 32, 8, 16), -1, 1).requires_grad_(True)
+    yb = blk(xb)
+    yb.pow(2).mean().backward()
+    out["blk.out"] = yb.detach().numpy(); out["blk.dx"] = xb.grad.numpy().copy()
+    out["blk.g.conv9_1.weight"] = blk.conv9_1.weight.grad.numpy().copy()
+    RefEnc.hparams.cin_channels = 96
+    E = RefEnc.MelEncoder(norm_layer=IN)                      # affine=True: gamma / beta are parameters (Inpainting_Networks.py:56)
+    ebase = O.encoder_state()
+    esd = OrderedDict((k, ebase[k] if k in ebase else O.cf_uniform("in.E." + k, tuple(v.shape), -0.1, 0.1)) for k, v in E.state_dict().items())
+    assert "conv1.bias" in esd and "bn1.weight" in esd and "bn1.running_mean" not in esd
+    load_into(E, esd); E.train()
+    xe = O.cf_uniform("in.xe", (2, 96, 32))
+    fe = E(xe)
+    sum(f.pow(2).mean() for f in fe).backward()
+    for i in (0, 3):
+        out["E.feat%d" % i] = fe[i].detach().numpy()
+    out["E.g.bn2.weight"] = E.bn2.weight.grad.numpy().copy(); out["E.g.conv3.weight.dg"] = O.digest(E.conv3.weight.grad)
+    path = os.path.join(OUT, "instnorm.npz")
+    np.savez_compressed(path, **out)
+    print("instnorm -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def adam_goldens():
     """torch.optim.Adam known-answer vectors (what the missing AudioModel's
     optimizer_G/optimizer_D are, utils/util.py:149-150)."""
@@ -709,9 +788,15 @@ if __name__ == "__main__":
     if "--wavenet-g-only" in sys.argv:
         wavenet_g_goldens()
         sys.exit(0)
+    if "--wavenet-onehot-only" in sys.argv:
+        wavenet_onehot_goldens()
+        sys.exit(0)
     if "--wavenet-full-only" in sys.argv:
         torch.set_num_threads(os.cpu_count())
         wavenet_full_goldens()
+        sys.exit(0)
+    if "--instnorm-only" in sys.argv:
+        instnorm_goldens()
         sys.exit(0)
     if "--checkpoint-only" in sys.argv:
         checkpoint_structure_golden()
@@ -733,7 +818,9 @@ if __name__ == "__main__":
     wavenet_goldens()
     wavenet_g_goldens()
     wavenet_full_goldens()
+    wavenet_onehot_goldens()
     av_step_goldens()
+    instnorm_goldens()
     checkpoint_structure_golden()
     run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
     run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]

@@ -55,15 +55,49 @@ def _pair(v):
 
 
 def _check_norm(norm_layer):
-    if norm_layer is not nn.BatchNorm2d:
-        raise NotImplementedError("the HIP path implements nn.BatchNorm2d (the reference's hparams.normlayer); got %r" % (norm_layer,))
+    """`norm_layer` of the reference constructors (Inpainting_Networks.py:52, New_Inpainting_Networks.py:16,
+    Discriminator_Networks.py:14): nn.BatchNorm2d (hparams.normlayer, the trained configuration) or nn.InstanceNorm2d."""
+    if norm_layer not in (nn.BatchNorm2d, nn.InstanceNorm2d):
+        raise NotImplementedError("the HIP path implements nn.BatchNorm2d and nn.InstanceNorm2d; got %r" % (norm_layer,))
+
+
+class _InstanceNormHolder:
+    """What ops.conv_bn_act reads from a norm module, for an nn.InstanceNorm2d: instance statistics are batch statistics of a
+    one-sample batch, so the layer runs the conv + BatchNorm(train) kernels once per sample (no running statistics; gamma / beta
+    are the module's when affine, constant 1 / 0 otherwise)."""
+    track_running_stats = False
+    running_mean = running_var = num_batches_tracked = None
+    training = True
+
+    def __init__(self, inorm, device):
+        if inorm.track_running_stats:
+            raise NotImplementedError("InstanceNorm2d(track_running_stats=True)")
+        self.eps, self.momentum = inorm.eps, 0.1
+        c = inorm.num_features
+        self.weight = inorm.weight if inorm.affine else torch.ones(c, device=device)
+        self.bias = inorm.bias if inorm.affine else torch.zeros(c, device=device)
+
+
+def _instance_norm_layer(x, conv, inorm, act, x2, transposed):
+    h = getattr(inorm, "_viai_holder", None)
+    if h is None or h.weight.device != x.device:
+        h = _InstanceNormHolder(inorm, x.device)
+        object.__setattr__(inorm, "_viai_holder", h)
+    if inorm.affine:
+        h.weight, h.bias = inorm.weight, inorm.bias
+    outs = [ops.conv_bn_act(x[i:i + 1], conv.weight, conv.bias, h, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
+                            padding=_pair(conv.padding), transposed=transposed, act=act,
+                            x2=(x2[i:i + 1] if x2 is not None else None), training=True) for i in range(x.shape[0])]
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
 def fused_layer(x, conv, bn, act, x2=None, training=True):
-    """conv (nn.Conv2d | nn.ConvTranspose2d holder) -> bn (nn.BatchNorm2d holder | None) -> act, on NHWC."""
+    """conv (nn.Conv2d | nn.ConvTranspose2d holder) -> bn (nn.BatchNorm2d | nn.InstanceNorm2d holder | None) -> act, on NHWC."""
     transposed = isinstance(conv, nn.ConvTranspose2d)
     if transposed and _pair(conv.stride) != (1, 1):
         raise NotImplementedError("ConvTranspose2d stride != 1")
+    if isinstance(bn, nn.InstanceNorm2d):
+        return _instance_norm_layer(x, conv, bn, act, x2, transposed)
     return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
                            padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2,
                            training=(bn.training if bn is not None else training))
@@ -80,10 +114,11 @@ class TransConvBlock(nn.Module):
         if not isinstance(name, str):
             raise Exception("name should be str")
         self.nums, self.name = nums, name
+        use_bias = norm_layer is nn.InstanceNorm2d          # New_Inpainting_Networks.py:17
         c = inplanes
         for i in range(nums):
             self.add_module("conv%s_%d" % (name, i),
-                            nn.ConvTranspose2d(c, outplanes, kernel_size=kernel_size, stride=stride, padding=padding, bias=False))
+                            nn.ConvTranspose2d(c, outplanes, kernel_size=kernel_size, stride=stride, padding=padding, bias=use_bias))
             self.add_module("conv%s_%d_bn" % (name, i), norm_layer(outplanes))
             c = outplanes
         self.initial()
@@ -118,8 +153,9 @@ class MelEncoder(nn.Module):
         super().__init__()
         _check_norm(norm_layer)
         self.hparams = hparams
+        use_bias = norm_layer is nn.InstanceNorm2d          # Inpainting_Networks.py:52
         for i in range(5):
-            self.add_module("conv%d" % (i + 1), nn.Conv2d(self.WIDTHS[i], self.WIDTHS[i + 1], (3, 3), self.STRIDES[i], (1, 1), bias=False))
+            self.add_module("conv%d" % (i + 1), nn.Conv2d(self.WIDTHS[i], self.WIDTHS[i + 1], (3, 3), self.STRIDES[i], (1, 1), bias=use_bias))
             self.add_module("bn%d" % (i + 1), norm_layer(self.WIDTHS[i + 1], affine=True))
         self.initial()
 
@@ -269,17 +305,18 @@ class MelDiscriminator(nn.Module):
         _check_norm(norm_layer)
         self.n_layers = n_layers
         self.use_sigmoid = True
-        self.conv1 = nn.Conv2d(input_nc, ndf, kernel_size=(1, 4), stride=(1, 2), padding=(0, 1), bias=False)
+        use_bias = norm_layer is nn.InstanceNorm2d          # Discriminator_Networks.py:14
+        self.conv1 = nn.Conv2d(input_nc, ndf, kernel_size=(1, 4), stride=(1, 2), padding=(0, 1), bias=use_bias)
         self.bn1 = norm_layer(ndf)
         nf_mult = 1
         for n in range(1, n_layers):
             nf_prev, nf_mult = nf_mult, min(2 ** n, 8)
-            self.add_module("conv2_%d" % n, nn.Conv2d(ndf * nf_prev, ndf * nf_mult, kernel_size=(3, 3), stride=2, padding=1, bias=False))
+            self.add_module("conv2_%d" % n, nn.Conv2d(ndf * nf_prev, ndf * nf_mult, kernel_size=(3, 3), stride=2, padding=1, bias=use_bias))
             self.add_module("norm_%d" % n, norm_layer(ndf * nf_mult))
         nf_prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
-        self.conv3 = nn.Conv2d(ndf * nf_prev, ndf * nf_mult, kernel_size=3, stride=1, padding=1, bias=False)
+        self.conv3 = nn.Conv2d(ndf * nf_prev, ndf * nf_mult, kernel_size=3, stride=1, padding=1, bias=use_bias)
         self.norm3 = norm_layer(ndf * nf_mult)
-        self.conv4 = nn.Conv2d(ndf * nf_mult, 1, kernel_size=3, stride=1, padding=1, bias=False)
+        self.conv4 = nn.Conv2d(ndf * nf_mult, 1, kernel_size=3, stride=1, padding=1, bias=use_bias)
 
     def forward_nhwc(self, x):
         net = fused_layer(x, self.conv1, self.bn1, ACT_LRELU)
