@@ -32,7 +32,11 @@ def _worker(rank, world, port, out_dir):
     x = synth.uniform("ddp.x", (4, 6), -1, 1, ) if False else synth.mel_batch(4, 2, 3, "ddp.x", rank).reshape(4, 6)
     arena.zero_grad()
     net(x).pow(2).mean().backward()
-    ddp.allreduce_mean_(arena.grad)
+    # the product step exchanges the arena in BUCKETS: in-place sum-all-reduce of contiguous views (model._reduce_range)
+    half = arena.size // 2
+    ddp.all_reduce_sum_(arena.grad[half:])
+    ddp.all_reduce_sum_(arena.grad[:half])
+    arena.grad.div_(w)
     torch.save({"flat": arena.flat.clone(), "grad": arena.grad.clone(), "x": x}, os.path.join(out_dir, "r%d.pt" % rank))
     t = ddp.barrier_max_ms(float(rank + 1))
     assert t == float(world)

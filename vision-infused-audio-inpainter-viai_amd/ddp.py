@@ -51,6 +51,21 @@ def allreduce_mean_(flat_grad: torch.Tensor, group=None, scale_in_optimizer=Fals
     return flat_grad
 
 
+def all_reduce_sum_(t: torch.Tensor, group=None):
+    """in-place sum-all-reduce of a (view of a) flat gradient arena on the CURRENT stream.
+    RCCL ("nccl" backend): the collective is enqueued behind the current stream and the current stream waits for it -- the
+    host does not block.  gloo (CPU tests, and the two-processes-on-one-GPU test): staged through host memory, blocking."""
+    if not dist.is_initialized():
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def barrier_max_ms(elapsed_ms: float, device=None) -> float:
     """max over ranks of a per-rank time (bench contract)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -197,6 +197,10 @@ class AudioModel:
         dreal = os.environ.get("VIAI_DREAL_STREAM", "0" if self.use_graph else "1") != "0"
         self._dreal_stream = torch.cuda.Stream(device=self.device) if dreal else None
         self._graphs = None
+        self._comm = None                  # data-parallel exchange stream (created on first use)
+        self._g_update_pending = False     # the G exchange + Adam(G) + re-pack of the previous step are still on _comm
+        self._skip_exchange = False        # bench.py: measure the step without the collectives (comm_ms_exposed)
+        self._plan_exchange()
 
     # ------------------------------------------------------------------ setup
     def _build_optimizers(self):
@@ -214,10 +218,92 @@ class AudioModel:
         self.optimizer_G = FusedAdam(self.arena_G, c.lr, (c.beta1, c.beta2), c.eps, stateless)
         self.optimizer_D = FusedAdam(self.arena_D, c.lr, (c.beta1, c.beta2), c.eps)
 
+    def _plan_exchange(self):
+        """Gradient buckets of the data-parallel exchange: contiguous ranges of the flat gradient arenas in the order the
+        backward pass completes them.  An EARLY bucket (trigger parameter, lo, hi) goes to RCCL from a gradient-ready hook
+        (ops.GRAD_HOOKS) as soon as the layer owning the trigger has queued its gradients -- the rest of the backward chain
+        runs beside the collective; the LATE ranges follow after the last weight gradient.
+          D  (6.2 MB):  early [conv3.weight .. end) = conv3 + norm3 + conv4, 76 % of the bytes, ready after the second layer of
+                        the backward chain;  late [0 .. conv3.weight)
+          G (16.7 MB):  early [convblock3 .. end of G), then [G start .. convblock3) at deconv1_1;  late = E (+ the visual branch).
+        The G exchange, Adam(E,G) and the weight re-pack stay on the exchange stream and overlap the NEXT step's D(real) forward +
+        backward, which reads none of them (see _seg_forward_dstep)."""
+        aD, aG = self.arena_D, self.arena_G
+
+        def off(arena, name):
+            return arena.offsets[arena.names.index(name)]
+        self._early_D, self._late_D = [], [(0, aD.size)]
+        if self.num_D == 1:
+            o = off(aD, "D.conv3.weight")
+            self._early_D, self._late_D = [("D.conv3.weight", o, aD.size)], [(0, o)]
+        g_lo = off(aG, next(n for n in aG.names if n.startswith("G.")))
+        v_names = [n for n in aG.names if n.startswith("V.")]
+        g_hi = off(aG, v_names[0]) if v_names else aG.size
+        c3 = off(aG, "G.convblock3.conv3_0.weight")
+        head = "G.deconv1_1_1.weight" if self.use_video else "G.deconv1_1.weight"
+        self._early_G = [("G.convblock3.conv3_0.weight", c3, g_hi), (head, g_lo, c3)]
+        self._late_G = [(0, g_lo)] + ([(g_hi, aG.size)] if g_hi < aG.size else [])
+
+    def _exchanging(self):
+        return (self.world > 1 or self._force_allreduce) and not self._skip_exchange
+
+    def _overlapped(self):
+        """bucketed exchange from inside the step (eager mode); graph mode exchanges between its captured segments instead"""
+        return self._exchanging() and not self.use_graph
+
+    def _comm_stream(self):
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=self.device)
+        return self._comm
+
+    def _reduce_range(self, arena, lo, hi):
+        """sum-all-reduce of arena.grad[lo:hi] on the exchange stream, behind everything queued so far on the current stream
+        and on the weight-gradient stream (in-place on the arena: no packing copies)."""
+        from . import ddp
+        comm = self._comm_stream()
+        comm.wait_stream(torch.cuda.current_stream())
+        if ops.WGRAD_STREAM is not None:
+            comm.wait_stream(ops.WGRAD_STREAM)
+        with torch.cuda.stream(comm):
+            ddp.all_reduce_sum_(arena.grad[lo:hi], self.pg)
+
+    def _arm_hooks(self, arena, early, fire_at=1):
+        """register the early buckets of `arena` as gradient-ready hooks; `fire_at` = which invocation of the trigger layer's
+        backward completes its gradient (2 when both halves of loss_D are back-propagated in one pass)."""
+        ops.GRAD_HOOKS.clear()
+        if not self._overlapped():
+            return
+        for name, lo, hi in early:
+            p = arena.params[arena.names.index(name)]
+            state = {"n": fire_at}
+
+            def hook(state=state, lo=lo, hi=hi):
+                state["n"] -= 1
+                if state["n"] == 0:
+                    self._reduce_range(arena, lo, hi)
+            ops.GRAD_HOOKS[p.data_ptr()] = hook
+
+    def _finish_exchange(self, arena, late):
+        """after the backward pass: the late ranges, then hand the reduced gradients back to the main stream."""
+        ops.GRAD_HOOKS.clear()
+        if not self._overlapped():
+            return False
+        for lo, hi in late:
+            self._reduce_range(arena, lo, hi)
+        return True
+
+    def sync_pending_update(self):
+        """the main stream waits for the deferred G exchange + Adam(E,G) + re-pack of the previous step (no host sync).  Called at
+        the point of the next step that first touches E / G, and by everything that reads parameters between steps."""
+        if self._g_update_pending:
+            torch.cuda.current_stream().wait_stream(self._comm)
+            self._g_update_pending = False
+
     def load_states(self, E=None, G=None, D=None, V=None):
         """load state_dicts (e.g. the oracle's closed-form tables) without breaking the arenas."""
         if V is not None and self.VideoEncoder is None:
             raise ValueError("a VideoEncoder state was given but the model was built without use_video")
+        self.sync_pending_update()
         for mod, sd in ((self.Mel_Encoder, E), (self.Mel_Decoder, G), (self.netD, D), (self.VideoEncoder, V)):
             if sd is None:
                 continue
@@ -227,6 +313,10 @@ class AudioModel:
         self.weights_changed()
 
     def weights_changed(self):
+        self.sync_pending_update()
+        self._weights_changed()
+
+    def _weights_changed(self):
         """Parameters were written outside the optimizers (checkpoint load, manual surgery): re-pack the conv weight
         images now.  Eager steps would notice through the tensor versions; a captured graph contains no per-layer pack
         launches (the optimizers' batched re-pack is what it replays), so it relies on this call."""
@@ -309,7 +399,6 @@ class AudioModel:
         s_nhwc = s.view(B, F, T, 1)
         ops.begin_step(self.device)                    # re-arm the abs-max slots of the f16x2 backward kernels (one fill)
         self.optimizer_D.zero_grad()
-        self.optimizer_G.zero_grad()
         self.netD.requires_grad_(True)
         main = torch.cuda.current_stream()
         side = self._dreal_stream
@@ -329,6 +418,10 @@ class AudioModel:
         else:
             pred_real = self.netD.forward_nhwc(s_nhwc)
             loss_real = self._gan(pred_real, True)
+        # everything above reads D only: it ran beside the previous step's G exchange + Adam(E,G) + re-pack (data parallel);
+        # E / G and their gradient arena are touched from here on
+        self.sync_pending_update()
+        self.optimizer_G.zero_grad()
         fake, self._lc = self._generate(s_nhwc)                        # (B,F,T,1)
         self._fake = fake
         self.fake = to_nchw_view(fake)
@@ -339,12 +432,16 @@ class AudioModel:
         if side is not None:
             main.wait_stream(side)                                     # real-branch gradients are in the arena
             loss_real.record_stream(main)                              # allocated on `side`, read below on main
+            self._arm_hooks(self.arena_D, self._early_D, 1)
             (0.5 * loss_fake).backward()
             loss_d = 0.5 * (loss_fake.detach() + loss_real.detach())
         else:
             loss_d = 0.5 * (loss_fake + loss_real)
+            self._arm_hooks(self.arena_D, self._early_D, 2)
             loss_d.backward()
         ops.join_wgrad()
+        if self._finish_exchange(self.arena_D, self._late_D):
+            main.wait_stream(self._comm)                               # Adam(D) and the G step need the reduced D gradients
         self.losses[0].copy_(loss_d.detach())
         self.losses[4].copy_(loss_real.detach())
 
@@ -362,8 +459,10 @@ class AudioModel:
             loss_g = loss_g + self.cfg.lambda_contrast * self._lc
             self.EmbeddingL2 = self._lc.detach()
             self.losses[5].copy_(self.EmbeddingL2)
+        self._arm_hooks(self.arena_G, self._early_G, 1)
         loss_g.backward()
         ops.join_wgrad()
+        self._g_exchanged = self._finish_exchange(self.arena_G, self._late_G)
         self.netD.requires_grad_(True)
         self.losses[1].copy_(loss_g.detach())
         self.losses[2].copy_(loss_gan.detach())
@@ -371,11 +470,21 @@ class AudioModel:
         self._pred_fake_g = pred
 
     def _seg_gupdate(self):
-        self.optimizer_G.step(1.0 / self.world)
+        if getattr(self, "_g_exchanged", False) and not self.use_graph:
+            # Adam(E,G) + the batched weight re-pack stay on the exchange stream behind the collective; the main stream picks them
+            # up at the first use of E / G in the next step (sync_pending_update)
+            with torch.cuda.stream(self._comm):
+                self.optimizer_G.step(1.0 / self.world)
+            self._g_update_pending = True
+            self._g_exchanged = False
+        else:
+            self.optimizer_G.step(1.0 / self.world)
 
     def _allreduce(self, arena):
-        if self.world > 1 or self._force_allreduce:
-            torch.distributed.all_reduce(arena.grad, group=self.pg)
+        """graph mode only: blocking whole-arena exchange between the captured segments."""
+        if self._exchanging():
+            from . import ddp
+            ddp.all_reduce_sum_(arena.grad, self.pg)
 
     def _capture(self):
         """three HIP graphs split at the two gradient all-reduce points."""
@@ -437,27 +546,31 @@ class AudioModel:
             self._allreduce(self.arena_G)
             g2.replay()
         else:
-            self._seg_forward_dstep()
-            self._allreduce(self.arena_D)
-            self._seg_dupdate_gstep()
-            self._allreduce(self.arena_G)
+            self._seg_forward_dstep()          # D exchange: early bucket from inside the backward, the rest at its end
+            self._seg_dupdate_gstep()          # G exchange: two early buckets + the encoder range
             self._seg_gupdate()
 
     def forward_backward_no_update(self):
-        """the step WITHOUT the two Adam updates (parity target, see oracle.step_no_update)."""
+        """the step WITHOUT the two Adam updates (parity target, see oracle.step_no_update).  In a process group the gradient
+        arenas hold the all-reduced SUMS afterwards (the 1/N lives in the Adam kernel)."""
         prev, ops.DIRECT_GRAD = ops.DIRECT_GRAD, True
         prev_s, ops.WGRAD_STREAM = ops.WGRAD_STREAM, self._wgrad_stream
         try:
             self._seg_forward_dstep()
             self._seg_dupdate_gstep(update=False)
+            if getattr(self, "_g_exchanged", False):
+                torch.cuda.current_stream().wait_stream(self._comm)
+                self._g_exchanged = False
         finally:
             ops.DIRECT_GRAD, ops.WGRAD_STREAM = prev, prev_s
+            ops.GRAD_HOOKS.clear()
 
     def test(self):
         """forward only (train_whole_sync.py:79-80,159-183: the caller sets `model.train = 0` and wraps in no_grad).
         Runs the SAME generator path as the train step (`_generate`: with `use_video` the video feature goes through
         `deconv1_1_1`).  With `self.train == 0` the modules are put in eval mode for the call (running BatchNorm
         statistics, buffers untouched) and restored afterwards."""
+        self.sync_pending_update()
         s = self.mel
         B, _, F, T = s.shape
         mods = [m for m in (self.Mel_Encoder, self.Mel_Decoder, self.VideoEncoder) if m is not None]
@@ -522,6 +635,7 @@ class AudioModel:
     def save_inpainting_checkpoint(self, global_step, global_test_step, checkpoint_dir, epoch, hparams=None):
         """same dict layout as utils/util.py:146-162."""
         hp = hparams if hparams is not None else self.hparams
+        self.sync_pending_update()
         path = os.path.join(checkpoint_dir, getattr(hp, "name", "viai") + "_checkpoint_step{:09d}.pth.tar".format(global_step))
         if self.world > 1 and torch.distributed.get_rank(self.pg) != 0:
             return path                                     # replicas are identical: rank 0 writes, the others do not race it

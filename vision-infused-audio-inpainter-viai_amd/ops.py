@@ -37,6 +37,12 @@ WGRAD_STREAM = None
 _deferred = []
 F16_BACKWARD = os.environ.get("VIAI_F16_BACKWARD", "1") != "0"     # f16x2 data gradients (dynamic per-tensor scale)
 
+# Gradient-ready hooks (set by model.AudioModel for the data-parallel exchange): {weight.data_ptr(): callable}.  The callable runs
+# right after the backward of the layer owning that weight has queued its LAST gradient launch (weight gradient on WGRAD_STREAM,
+# BatchNorm gamma / beta gradients on the current stream), i.e. every parameter gradient of that layer and of all layers behind it
+# in the network is queued: the bucket they form can go to RCCL while the rest of the backward chain still runs.
+GRAD_HOOKS = {}
+
 
 def join_wgrad():
     """main stream waits for every deferred weight-gradient launch; call before the gradients are consumed."""
@@ -412,6 +418,10 @@ class _ConvBnAct(torch.autograd.Function):
                 dw = None
             if acc_b:
                 db = None
+            if GRAD_HOOKS:
+                hook = GRAD_HOOKS.get(weight.data_ptr())
+                if hook is not None:
+                    hook()
         if need_x or need_x2:
             dx = torch.empty((N, IH, IW, C1), device=dev, dtype=torch.float32)
             dx2 = torch.empty((N, IH, IW, C2), device=dev, dtype=torch.float32) if C2 > 0 else None
