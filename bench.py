@@ -8,7 +8,9 @@ A "step" is one full G+D train step on one batch of
 synthetic MUSICES-shaped masked mel-spectrograms resident in HBM:
 E+G forward, 3x D forward, D backward x2, D-frozen dgrad, G+E backward, 2x Adam.
 Workload = BASELINE.json configs[1]: audio-only G + PatchGAN D, 256x256 mel,
-batch 16 per GPU, fp32 (exact-fp32 MFMA).  Rank 0 prints ONE JSON line.
+batch 16 per GPU; fp32 tensors, conv products on the 16-bit matrix cores through the
+f16x2 / bf16x3 operand splits with fp32 accumulation (the `config.math` string of the
+JSON line is generated from the switches in effect).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -34,6 +36,47 @@ PEAK = MFMA_BF16_PEAK_TFLOPS / 6.0 if BF3 else MFMA_F32_PEAK_TFLOPS
 DOMINANT = ("conv_igemm_bf3_frag_kernel<3,2,2,2,2> (128x128x32 bf16x3 split-MFMA implicit-GEMM conv, fp32-grade accuracy; data-gradient launches"
             + ("" if F16X2 else " and forward launches") + ")"
             if BF3 else "conv_igemm_kernel<32,2,2,2,2> (128x128x32 fp32-MFMA implicit-GEMM conv, fwd + dgrad)")
+
+
+# kernel behind each launch family of KernelTimer (the mirror predicates above decide the family of a call)
+FAMILY_KERNELS = {
+    "wgrad_patch_f16x2": "wgrad_patch_f16_kernel<4> (csrc/conv_wgrad_patch.hip: weight gradient of the stride-1 3x3 layers with >= 128 x 64 channels; all nine taps per block, "
+                         "dy rows + x patch staged once per 64 pixels as [pixel][channel] fp16 planes, MFMA operands through ds_read_b64_tr_b16; f16x2 split)",
+    "wgrad_bf3_f16x2": "wgrad_bf3_kernel<2,TM,TN> (csrc/conv_wgrad_bf3.hip: weight gradient, one block per tap x Cout tile x Cin tile, tiles transposed into LDS; f16x2 split)",
+    "wgrad_bf3": "wgrad_bf3_kernel<3,TM,TN> (bf16x3 weight gradient)",
+    "wgrad_mfma": "wgrad_mfma_kernel<*> (exact fp32 MFMA weight gradient, <= 32-channel layers)",
+    "wgrad32_all_taps": "wgrad32_halo_kernel (exact fp32 MFMA, <= 32 x <= 32 channels, stride 1: all taps per block)",
+    "halo_wide256_f16x2": "conv_halo_wide_f16_kernel<2,4,2,2> (stride-1 3x3 conv, 8x16-pixel x 256-channel tile, f16x2 split MFMA: the 10x18 input patch of a 32-channel chunk is "
+                          "staged once in LDS and read by all nine taps; weight fragments straight from global; forward and data-gradient launches of D.conv3)",
+    "halo_wide128_f16x2": "conv_halo_wide_f16_kernel<2,2,2,2> (as above, 128-channel tile)",
+    "halo_wide64_f16x2": "conv_halo_wide_f16_kernel<2,2,2,1> (64-channel tile)", "halo_wide32_f16x2": "conv_halo_wide_f16_kernel<4,1,1,1> (32-channel tile)",
+    "halo_wide_s2_f16x2": "conv_halo_wide_f16_kernel<2,4,2,{2,1},2> (stride-2 forward, four parity sub-patches)",
+    "halo_f16x2": "conv_halo_f16_c32_kernel / conv_halo_bf3_kernel<CIN,TN,2> (32/64-channel stride-1 layers, f16x2)",
+    "halo": "conv_halo_bf3_kernel<CIN,TN,3> (32/64-channel stride-1 layers, bf16x3)",
+    "dgrad_s2_f16x2": "conv_dgrad_s2_patch_kernel (3x3 stride-2 data gradient, four parity classes fused, dy patch staged once per 32-channel chunk; f16x2)",
+    "dgrad_s2": "conv_dgrad_s2_bf3_kernel<3> (3x3 stride-2 data gradient, bf16x3)",
+    "igemm128x256_f16x2": "conv_igemm_bf3_frag_kernel<2,2,2,2,4> (128x256x32 f16x2 gather-GEMM conv, eight waves)",
+    "igemm128x128_f16x2": "conv_igemm_bf3_frag_kernel<2,2,2,2,2> (128x128x32 f16x2 gather-GEMM conv)",
+    "igemm128x128": "conv_igemm_bf3_frag_kernel<3,2,2,2,2> (128x128x32 bf16x3 gather-GEMM conv)",
+}
+PMC_KERNEL_OF = {"wgrad_patch_f16x2": "wgrad_patch_f16_kernel", "wgrad_bf3_f16x2": "wgrad_bf3_kernel", "halo_wide256_f16x2": "conv_halo_wide_f16_kernel",
+                 "halo_wide128_f16x2": "conv_halo_wide_f16_kernel", "igemm128x256_f16x2": "frag_kernel<2, 2, 2, 2, 4", "igemm128x128_f16x2": "frag_kernel<2", "igemm128x128": "frag_kernel<3"}
+
+
+def math_string():
+    """what the conv kernels compute in, from the switches in effect (csrc/conv_api.hip reads the same environment)"""
+    if not BF3:
+        return "VIAI_MATH=fp32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32) in every conv kernel"
+    f16b = os.environ.get("VIAI_F16_BACKWARD", "1") != "0"
+    if F16X2:
+        return ("fp32 tensors and fp32 accumulation; conv products on the fp16 matrix cores through the f16x2 operand split (two fp16 terms per fp32 "
+                "operand = 22 significand bits, three partial products, power-of-two pre-scaling: static x16 for activations / x256 for weights, "
+                "per-tensor from max|dy| for gradients) in the forward%s kernels of every layer with > 1 channel on both sides; bf16x3 (three bf16 "
+                "terms, six partial products) where no BatchNorm produces the gradient scale%s; exact fp32 MFMA in the <= 32-channel weight gradients; "
+                "plain fp32 FMA in the Cin = 1 / Cout = 1 streaming convs; measured 2.7-2.9e-7 relative vs fp64 per layer (CPU fp32: 1.8e-7); "
+                "activations saturate at |x| > 4094 (tests/test_kernels_gpu.py::test_f16x2_saturates_instead_of_nan)"
+                % (", data-gradient and weight-gradient" if f16b else "", "" if f16b else " and in every backward kernel (VIAI_F16_BACKWARD=0)"))
+    return "fp32 tensors and fp32 accumulation; conv products on the bf16 matrix cores through the bf16x3 split (six partial products) (VIAI_F16X2=0)"
 
 
 def parse():
@@ -207,6 +250,11 @@ class KernelTimer:
         wrap("viai_conv2d_dgrad", fam_dgrad)
         def fam_wgrad_f16(d):
             f, n = fam_wgrad(d)
+            oh, ow = out_hw(d)
+            if (f == "wgrad_bf3" and os.environ.get("VIAI_WGRAD_PATCH", "1") != "0" and (d.kh, d.kw, d.sh, d.sw) == (3, 3, 1, 1)
+                    and d.Cout % 128 == 0 and d.C1 % 64 == 0 and d.C2 % 64 == 0 and oh % 8 == 0 and ow % 16 == 0
+                    and d.N * (oh // 8) * (ow // 16) >= 64):
+                return "wgrad_patch_f16x2", n        # mirror of viai_wgrad_patch_ok (csrc/conv_wgrad_patch.hip)
             return f + "_f16x2", n
 
         wrap("viai_conv2d_dgrad_f16", fam_dgrad_f16)
@@ -239,17 +287,14 @@ class KernelTimer:
 
 
 def cpu_baseline(args):
-    """The oracle's train step on the host cores: a BOUNDED sample of the same workload (same 256x256 shape,
-    `cpu_batch` clips per step).  Threads = min(cores this process may run on, 16): torch's CPU convolutions stop
-    scaling (and collapse under oversubscription) far below the 256 logical CPUs a GPU box reports."""
+    """The oracle's train step on the host cores, same step and SAME workload as the GPU line: 16 clips of 256 x 256 per step
+    (SURVEY.md section 8d), all cores the process may run on handed to torch (`cores`), best of the steps that fit ~20 s.
+    A 2-clip step at 16 threads -- where torch's CPU convolutions are most efficient per clip -- is reported beside it."""
     from oracle import viai_oracle as O
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count()
-    threads = max(1, min(avail, 16))
-    torch.set_num_threads(threads)
-    B = args.cpu_batch
 
     def one_step(b, f, t, tag):
         s = O.cf_uniform(tag + ".s", (b, 1, f, t))
@@ -259,14 +304,63 @@ def cpu_baseline(args):
         t0 = time.perf_counter()
         O.train_step(E, G, D, oG, oD, s, mask)
         return time.perf_counter() - t0
-    one_step(1, 80, 32, "bench.cpu.warm")                       # library warm-up at a tiny shape (untimed)
-    times = [one_step(B, args.bins, args.frames, "bench.cpu")]
-    while sum(times) < 10.0 and len(times) < 64:                # ~10-20 s of CPU work in total, whatever the host's speed
-        times.append(one_step(B, args.bins, args.frames, "bench.cpu"))
-    dt = min(times)
-    return {"value": round(B / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": "oracle/viai_oracle.train_step (torch CPU fp32, %d threads), %d clips of %dx%d per step, best of %d step(s) (%.1f s of CPU work), %.2f s/step"
-                      % (threads, B, args.bins, args.frames, len(times), sum(times), dt)}
+
+    def sample(b, threads, budget_s, max_steps):
+        torch.set_num_threads(threads)
+        one_step(1, 80, 32, "bench.cpu.warm")                   # library warm-up at a tiny shape (untimed)
+        times = [one_step(b, args.bins, args.frames, "bench.cpu")]
+        while sum(times) < budget_s and len(times) < max_steps:
+            times.append(one_step(b, args.bins, args.frames, "bench.cpu"))
+        return min(times), len(times), sum(times)
+    full_threads = max(1, avail)
+    dt, n, tot = sample(args.batch, full_threads, 15.0, 8)
+    out = {"value": round(args.batch / dt, 4), "unit": "clips/s", "cores": full_threads, "kind": "port",
+           "sample": "oracle/viai_oracle.train_step (torch CPU fp32, %d threads = every core this process may use), %d clips of %dx%d per step "
+                     "(the GPU line's workload), best of %d step(s) (%.1f s of CPU work), %.2f s/step"
+                     % (full_threads, args.batch, args.bins, args.frames, n, tot, dt)}
+    t2 = max(1, min(avail, 16))
+    dt2, n2, tot2 = sample(args.cpu_batch, t2, 6.0, 64)
+    out["small_batch"] = {"value": round(args.cpu_batch / dt2, 4), "unit": "clips/s", "cores": t2,
+                          "sample": "%d clips per step at %d threads, best of %d step(s) (%.1f s)" % (args.cpu_batch, t2, n2, tot2)}
+    return out
+
+
+def front_end_stages(dev, batch, bins, frames):
+    """north_star: achieved HBM GB/s of the STFT / mask stages.  Algorithmic bytes: STFT -> mel reads the
+    waveform (4 B x 65 536 samples per clip) and writes the mel (4 B x F x T); the mask multiply reads and writes the mel once."""
+    from viai_amd import ops, synth
+    from viai_amd.audio import AudioConfig, MelFrontEnd
+
+    class Cfg(AudioConfig):
+        num_mels = bins
+    n_samples = 65536
+    fe = MelFrontEnd(Cfg)
+    wav = synth.waveform(batch, n_samples).to(dev)
+    mel = synth.mel_batch(batch, bins, frames, "bench.stage.s", 0).to(dev)
+    mask = synth.time_mask(batch, frames, "bench.stage.mask", 0).to(dev)
+
+    def timed(fn, n=50):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / n
+    with torch.no_grad():
+        t_fe = timed(lambda: fe(wav))
+        t_mk = timed(lambda: ops.mask_mul(mel, mask))
+    fr = fe.num_frames(n_samples)
+    b_fe = batch * (n_samples * 4 + bins * fr * 4)
+    b_mk = 2 * 4 * batch * bins * frames
+    return {"stft_mel_gbps": round(b_fe / t_fe * 1e-9, 1), "stft_mel_us": round(t_fe * 1e6, 1), "stft_mel_frac_of_hbm_peak": round(b_fe / t_fe / 8e12, 4),
+            "mask_gbps": round(b_mk / t_mk * 1e-9, 1), "mask_us": round(t_mk * 1e6, 1), "mask_frac_of_hbm_peak": round(b_mk / t_mk / 8e12, 4),
+            "note": "HIP events around 50 back-to-back launches, inputs resident in HBM; algorithmic bytes: STFT->mel = waveform in (%d samples/clip) + mel out "
+                    "(%d x %d), mask = mel in + out; both stages are far smaller than the GPU's caches at this batch, so the figure is launch-/latency-bound, "
+                    "not a sustained-bandwidth measurement" % (n_samples, bins, fr)}
 
 
 def main():
@@ -348,8 +442,7 @@ def main():
                                                       "PatchGAN D" if args.config == "av" else "3-scale D", args.bins, args.frames, args.batch)),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                    "launch": "hipGraph replay (3 segments)" if args.graph else "eager, weight gradients on a side stream",
-                   "math": "fp32 tensors; conv GEMMs on the 16-bit matrix cores with fp32 accumulate: bf16x3 split (six partial products) for gradients and narrow layers, f16x2 split (three partial products, power-of-two pre-scaling) for the wide forward layers; error vs fp64 at the level of fp32 arithmetic"
-                           if BF3 else "exact fp32 MFMA",
+                   "math": math_string(),
                    "host_enqueue_ms_per_step": round(enqueue_ms / args.steps, 3), "algorithmic_gflop_per_step": 1208.0, "step_tflops": round(1208.0 * 1e-3 / (ms_per_step * 1e-3), 2),
                    "loss_d": round(losses[0], 5), "loss_g": round(losses[1], 5)},
     }
@@ -377,19 +470,18 @@ def main():
             print("\n".join(kt.per_layer()), file=sys.stderr)
         kt.uninstall()
         tot_t = sum(v[1] for v in fam.values())
-        # dominant kernel: the 128x128 fragment-major implicit-GEMM kernel; its bf16x3 and f16x2 instances are different
-        # kernels with different ceilings (2500/6 and 2500/3): report the one that holds more of the step
-        cands = [k for k in ("igemm128x128", "igemm128x128_f16x2", "igemm128x256_f16x2", "halo_wide256_f16x2", "halo_wide128_f16x2") if k in fam]
+        # dominant kernel = the MFMA kernel family that holds the most time of the step, whichever it is; each family is priced
+        # against the ceiling of ITS arithmetic: f16x2 = 2500 / 3 partial products, bf16x3 = 2500 / 6, exact fp32 MFMA = 157.3
+        def peak_of(k):
+            if k in ("wgrad_mfma", "wgrad32_all_taps") or not BF3:
+                return MFMA_F32_PEAK_TFLOPS
+            return MFMA_BF16_PEAK_TFLOPS / 3.0 if k.endswith("f16x2") else MFMA_BF16_PEAK_TFLOPS / 6.0
+        cands = [k for k in fam if k != "direct"]                      # "direct" = the Cin = 1 / Cout = 1 streaming convs (HBM-bound, no MFMA)
         dom = max(cands, key=lambda k: fam[k][1])
         f, t, n = fam[dom]
         ach = f / t * 1e-12
-        peak = MFMA_BF16_PEAK_TFLOPS / 3.0 if dom.endswith("f16x2") else PEAK
-        dom_name = (("conv_halo_wide_f16_kernel<2,%d,2,2> (stride-1 3x3 conv, 8x16-pixel x %d-channel tile, f16x2 split MFMA: the 10x18 input patch of a 32-channel "
-                     "chunk is staged once in LDS and read by all nine taps; weight fragments straight from global; forward and data-gradient launches of D.conv3)"
-                     % ((4, 256) if dom.startswith("halo_wide256") else (2, 128))) if dom.startswith("halo_wide") else
-                    ("conv_igemm_bf3_frag_kernel<2,2,2,2,%d> (128x%dx32 f16x2 split-MFMA implicit-GEMM conv, %s waves: two fp16 terms per operand, three "
-                     "partial products, fp32 accumulate, fp32-grade accuracy; forward and data-gradient launches)"
-                     % ((4, 256, "eight") if dom.startswith("igemm128x256") else (2, 128, "four"))) if dom.endswith("f16x2") else DOMINANT)
+        peak = peak_of(dom)
+        dom_name = FAMILY_KERNELS.get(dom, dom)
         # the same kernel with nothing running beside it (weight gradients back on the main stream): what the kernel
         # itself reaches, without the time-sharing the as-run figure above includes
         alone = None
@@ -412,8 +504,10 @@ def main():
             "peak_note": ("algorithmic fp32 flops against the dense 16-bit MFMA peak (2500) / %d partial products per MAC; "
                           "the same flops are %.2fx the fp32-MFMA peak (157.3); with random operands the pipes sustain 1810 "
                           "(profiles/r01_e_mfma_probe.txt), i.e. %.2f of the sustained ceiling"
-                          % (3 if dom.endswith("f16x2") else 6, ach / MFMA_F32_PEAK_TFLOPS, ach / (1810.0 / (3.0 if dom.endswith("f16x2") else 6.0)))) if BF3
-                         else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
+                          % (3 if dom.endswith("f16x2") else 6, ach / MFMA_F32_PEAK_TFLOPS, ach / (1810.0 / (3.0 if dom.endswith("f16x2") else 6.0))))
+                         if peak != MFMA_F32_PEAK_TFLOPS else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
+            "dominant_rule": "the MFMA kernel family with the largest share of the summed conv-launch time of the step (conv_time_share_by_kernel); "
+                             "frac_by_kernel prices every family against its own ceiling",
             "kernel": dom_name, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream of each call (main stream, or the weight-gradient side stream), %d instrumented steps of the same eager step after the timed region" % nprof,
@@ -423,6 +517,8 @@ def main():
                                   "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},
             "conv_tflops_by_kernel": {k: round(v[0] / v[1] * 1e-12, 2) for k, v in sorted(fam.items()) if v[1] > 0},
+            "frac_by_kernel": {k: round(v[0] / v[1] * 1e-12 / peak_of(k), 3) for k, v in sorted(fam.items()) if v[1] > 0 and k != "direct"},
+            "conv_frac_whole_step": round(sum(v[0] for v in fam.values()) / tot_t * 1e-12 / (MFMA_BF16_PEAK_TFLOPS / 3.0), 4),
             "conv_ms_per_step": round(tot_t / nprof * 1e3, 3),
         }
         if alone is not None:
@@ -433,17 +529,19 @@ def main():
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dconv3.json")))
         pmc = pmcs[-1] if pmcs else ""
         if BF3 and pmc:
-            want = ("halo_wide_f16_kernel" if dom.startswith("halo_wide") else "frag_kernel<2, 2, 2, 2, 4" if dom.startswith("igemm128x256") else "frag_kernel<2") if dom.endswith("f16x2") else "frag_kernel<3"
-            items = sorted(json.load(open(pmc)).items(), key=lambda kv: want not in kv[0])                  # the reported instance first
-            for k, v in items:
-                if ("conv_igemm_bf3_frag_kernel" in k or "conv_halo_wide_f16_kernel" in k) and "hbm_bytes" in v:
-                    out["roofline"]["traffic"] = round(v["hbm_bytes"])
-                    out["roofline"]["traffic_note"] = (
-                        "bytes per launch on D.conv3 (fwd/dgrad average; algorithmic 57 MB in + 50 MB out): 2*FETCH_SIZE + WRITE_SIZE from "
-                        "profiles/%s (tools/profile_layer.py under rocprofv3 --pmc); these L2 memory-side "
-                        "counters include Infinity-Cache hits, i.e. they are L2-miss traffic, an upper bound on HBM bytes") % os.path.basename(pmc)
-                    break
+            want = PMC_KERNEL_OF.get(dom)
+            if want:
+                for k, v in json.load(open(pmc)).items():
+                    if want in k and "hbm_bytes" in v:
+                        out["roofline"]["traffic"] = round(v["hbm_bytes"])
+                        out["roofline"]["traffic_note"] = (
+                            "bytes per launch of this kernel on D.conv3 (algorithmic: x 33.6 MB + dy 67.1 MB + dw 4.7 MB for the weight gradient; 57 MB in + 50 MB out for "
+                            "forward / data gradient): 2*FETCH_SIZE + WRITE_SIZE from profiles/%s (tools/profile_layer.py under rocprofv3 --pmc); these L2 memory-side "
+                            "counters include Infinity-Cache hits, i.e. they are L2-miss traffic, an upper bound on HBM bytes") % os.path.basename(pmc)
+                        break
         del m2
+    if rank == 0 and args.config == "audio" and not args.no_roofline:
+        out["stages"] = front_end_stages(dev, args.batch, args.bins, args.frames)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -453,6 +453,12 @@ static int wgrad_ksplit(const viai_conv2d* c, long M) {
     if (wgrad32(c)) return viai_wgrad32_ksplit(M);
     return viai_wgrad_pick_ksplit(c->Cout, cin_of(c), c->kh * c->kw, M);
 }
+// the all-taps patch kernel (f16x2 launches of the stride-1 3 x 3 layers with >= 128 x 64 channels)
+static bool wgrad_patch(const viai_conv2d* c) {
+    if (kind_of(c) != K_IGEMM || !f16x2_enabled() || !bf3_enabled() || !viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2)) return false;
+    ConvGeom g{}; viai_geom_fwd(c, &g);
+    return viai_wgrad_patch_ok(g, c->Cout, c->C1, c->C2);
+}
 
 extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
     if (!valid(c)) return 0;
@@ -469,6 +475,11 @@ extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
         int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
         long M = (long)c->N * oh * ow;
         int ks = wgrad_ksplit(c, M);
+        if (wgrad_patch(c)) {                                  // workspace covers both forms (with / without the abs-max scale)
+            ConvGeom g{}; viai_geom_fwd(c, &g);
+            int kp = viai_wgrad_patch_ksplit(g, c->Cout, cin_of(c));
+            if (kp > ks) ks = kp;
+        }
         fl = (size_t)ks * viai_conv2d_packed_floats(c);
     } }
     // + column-sum partials for the bias gradient
@@ -527,8 +538,11 @@ static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, con
         a.amax = amax;
         viai_geom_fwd(c, &a.g);
         int ks = wgrad_ksplit(c, M);
+        const bool patch = amax != nullptr && wgrad_patch(c);
+        if (patch) ks = viai_wgrad_patch_ksplit(a.g, c->Cout, Cin);
         used = (size_t)ks * viai_conv2d_packed_floats(c);
-        e = wgrad32(c) ? viai_wgrad32_launch(a, ks, st)
+        e = patch ? viai_wgrad_patch_launch(a, st)
+          : wgrad32(c) ? viai_wgrad32_launch(a, ks, st)
           : (bf3_enabled() && viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2)) ? viai_wgrad_bf3_launch(a, ks, st) : viai_wgrad_mfma_launch(a, ks, st);
         if (e) return e;
         if (c->transposed) e = viai_wgrad_reduce(ws, dw, ks, T, c->Cout, Cin, T, (long)c->Cout * T, accumulate, st);

@@ -343,7 +343,7 @@ class AudioModel:
             flow = flow.to(self.device, dtype=torch.float32)
             if self.video is None or self.video.shape != video.shape:
                 self.video, self.flow = torch.empty_like(video), torch.empty_like(flow)
-                self._graphs = None
+                self._drop_graphs()
             self.video.copy_(video)
             self.flow.copy_(flow)
         mel = data[2] if isinstance(data, (tuple, list)) else data
@@ -357,9 +357,17 @@ class AudioModel:
         if self.mel is None or self.mel.shape != mel.shape:
             self.mel = torch.empty_like(mel)
             self.mask = torch.empty_like(mask)
-            self._graphs = None
+            self._drop_graphs()
         self.mel.copy_(mel)
         self.mask.copy_(mask)
+
+    def _drop_graphs(self):
+        """new input shape: the captured graphs are stale.  They may still be replaying (steps are asynchronous) and a hipGraphExec
+        must not be destroyed while in flight, so this is one of the few places that waits for the device."""
+        if self._graphs is not None:
+            torch.cuda.synchronize(self.device)
+            self._graphs = None
+            ops.drop_scratch()            # scratch buffers allocated while capturing live in the dead graphs' private memory pool
 
     def _gan(self, pred, real):
         t = 1.0 if real else 0.0

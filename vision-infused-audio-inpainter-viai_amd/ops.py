@@ -116,6 +116,12 @@ def _amax_slot(dev):
     return torch.zeros(1, device=dev, dtype=torch.float32)
 
 
+def drop_scratch():
+    """forget every pooled scratch buffer (the next use re-allocates).  Needed when captured hipGraphs are dropped: buffers first
+    requested during a capture were allocated from that graph's private pool."""
+    _scratch_pool.clear()
+
+
 def _scratch(tag, n, dev, stream=None):
     key = (tag, dev.index, stream.cuda_stream if stream is not None else _stream())
     t = _scratch_pool.get(key)
