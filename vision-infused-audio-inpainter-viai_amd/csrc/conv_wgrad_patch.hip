@@ -105,24 +105,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             xraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
         }
     };
-    auto put = [&](unsigned char* d, int plane, const u32x4& raw, float S, float L) {
+    // split + store of one staged float4 in two halves (unit 0: channels 0, 1; unit 1: channels 2, 3 + the two 8-byte LDS stores), so the
+    // work can be dealt out between the taps of a k-step, a few instructions at a time
+    unsigned hp1, hp2;
+    auto put_unit = [&](unsigned char* d, int plane, const u32x4& raw, float S, float L, int unit) {
         const f32x4 v = __builtin_bit_cast(f32x4, raw);
-        unsigned a1, a2, b1, b2;
-        split2_pair(v[0], v[1], S, L, a1, a2);
-        split2_pair(v[2], v[3], S, L, b1, b2);
-        const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
-        *reinterpret_cast<u32x2*>(d) = p1;
-        *reinterpret_cast<u32x2*>(d + plane) = p2;
+        if (unit == 0) {
+            split2_pair(v[0], v[1], S, L, hp1, hp2);
+        } else {
+            unsigned b1, b2;
+            split2_pair(v[2], v[3], S, L, b1, b2);
+            const u32x2 p1 = {hp1, b1}, p2 = {hp2, b2};
+            *reinterpret_cast<u32x2*>(d) = p1;
+            *reinterpret_cast<u32x2*>(d + plane) = p2;
+        }
     };
-    // part `part` of HR: item `part` of each operand (spreads the split / store work over the k-steps of a stage)
-    auto lstore = [&](int buf, int part) {
+    // part `part` of a stage = item `part` of each operand; unit 0..1 = the dy item, 2..3 = the x item
+    auto lstore_unit = [&](int buf, int part, int unit) {
         unsigned char* base = smem_p + buf * STAGE;
+        if (unit < 2) {
 #pragma unroll
-        for (int j = 0; j < ND; ++j)
-            if (j == part) put(base + d_lds + j * 16 * WP_DROW, DPLANE, draw[j], dscale, dlim);
+            for (int j = 0; j < ND; ++j)
+                if (j == part) put_unit(base + d_lds + j * 16 * WP_DROW, DPLANE, draw[j], dscale, dlim, unit);
+        } else {
 #pragma unroll
-        for (int j = 0; j < NX; ++j)
-            if (j == part && xp0 + 32 * j < XPIX) put(base + 2 * DPLANE + x_lds + j * 32 * WP_XPITCH, XPLANE, xraw[j], xscale, xlim);
+            for (int j = 0; j < NX; ++j)
+                if (j == part && xp0 + 32 * j < XPIX) put_unit(base + 2 * DPLANE + x_lds + j * 32 * WP_XPITCH, XPLANE, xraw[j], xscale, xlim, unit - 2);
+        }
+    };
+    auto lstore = [&](int buf, int part) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lstore_unit(buf, part, u);
     };
 
     f32x16 acc[9];
@@ -150,7 +163,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         b[0] = frag(bp, WP_XPITCH);
         b[1] = frag(bp + XPLANE, WP_XPITCH);
     };
-    auto kstep = [&](const unsigned char* S, int r) {
+    // A wave's three MFMAs of a tap accumulate into the same registers: they must issue back to back (the accumulator is forwarded;
+    // ONE instruction between them costs ~43 cycles, MI355X_MICROARCH.md), while instructions between MFMAs on different accumulators
+    // hide behind the running MFMA.  So the fragment reads of the next tap and a slice of the staging work (`fill`) sit BETWEEN the
+    // taps, fenced by scheduling barriers.
+    auto kstep = [&](const unsigned char* S, int r, auto&& fill) {
         f16x8 af[2], bq[2][2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) af[p] = frag(S + a_lane + p * DPLANE + r * 16 * WP_DROW, WP_DROW);
@@ -158,10 +175,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (t + 1 < 9) bfrag(S, r, t + 1, bq[(t + 1) & 1]);
-            // smallest partial products first: dy2 x1, dy1 x2, dy1 x1
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bq[t & 1][0], acc[t], 0, 0, 0);
+            fill(t);
+            __builtin_amdgcn_sched_barrier(0);
+            // small partial products first (dy1 x2, dy2 x1, then dy1 x1).  The FIRST MFMA takes the fragment that was read LAST
+            // (LDS returns in order), so the single wait sits in front of the triple, not inside it
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bq[t & 1][1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bq[t & 1][0], acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bq[t & 1][0], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -174,16 +195,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (nst > 1) gload(1);
     }
     __syncthreads();
-    for (int s = 0; s < nst; ++s) {
-        const bool more = s + 1 < nst;
+    for (int s = 0; s + 1 < nst; ++s) {
         const unsigned char* S = smem_p + (s & 1) * STAGE;
 #pragma unroll
-        for (int r = 0; r < HR; ++r) {
-            kstep(S, r);
-            if (more) lstore((s & 1) ^ 1, r);
-        }
+        for (int r = 0; r < HR; ++r)
+            kstep(S, r, [&](int t) {
+                if ((t & 1) && t < 8) lstore_unit((s & 1) ^ 1, r, t >> 1);       // units 0..3 behind taps 1, 3, 5, 7
+            });
         if (s + 2 < nst) gload(s + 2);
         __syncthreads();
+    }
+    if (nst > 0) {                                  // last stage: nothing left to stage
+        const unsigned char* S = smem_p + ((nst - 1) & 1) * STAGE;
+#pragma unroll
+        for (int r = 0; r < HR; ++r) kstep(S, r, [&](int) {});
     }
 
     // ---- epilogue: G slab [z][slot][co][ci]
