@@ -160,6 +160,48 @@ def test_patch_staged_stride2_dgrad_against_fp64():
     assert relerr(wg.grad, wd.grad) < 3e-6
 
 
+@pytest.mark.parametrize("cfg", [(1, 128, 0, 256, False), (1, 64, 64, 128, True), (2, 64, 0, 128, False), (2, 96, 0, 256, False)],
+                         ids=["s1_128to256", "s1_cat64+64to128_T", "s2_64to128", "s2_96to256"])
+def test_patch_staged_weight_gradient_against_fp64(cfg):
+    """conv_wgrad_patch.hip (all nine taps per block, fragments through ds_read_b64_tr_b16): weight gradient of 3 x 3 layers with
+    Cout % 128 == 0 behind an eval-mode BatchNorm (the abs-max-scaled f16x2 path), stride 1 (plain and transposed, one and two
+    concatenated sources: 128 x 64 tile, eight waves) and stride 2 (128 x 32 tile, parity sub-patches), 2 x (64 x 64 output) = 64 tiles;
+    gradients of constant-free random tensors against an fp64 evaluation."""
+    from viai_amd import ops
+    S, C1, C2, Co, tr = cfg
+    N, OHW = 2, 64
+    H = W = OHW * S
+    Ci = C1 + C2
+    x = O.cf_uniform("wgp.x", (N, Ci, H, W), -1, 1)
+    w = O.cf_std("wgp.w", (Ci, Co, 3, 3) if tr else (Co, Ci, 3, 3), 0.05)
+    g_, b_ = O.cf_uniform("wgp.g", (Co,), 0.5, 1.5), O.cf_uniform("wgp.b", (Co,), -0.5, 0.5)
+    rm, rv = O.cf_uniform("wgp.rm", (Co,), -0.1, 0.1), O.cf_uniform("wgp.rv", (Co,), 0.5, 1.5)
+    gy = O.cf_uniform("wgp.gy", (N, Co, OHW, OHW), -1, 1) * 1e-3          # small gradients: the dynamic scale has work to do
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    conv = F.conv_transpose2d(xd, wd, None, stride=1, padding=1) if tr else F.conv2d(xd, wd, None, stride=S, padding=1)
+    y = F.batch_norm(conv, rm.double(), rv.double(), g_.double(), b_.double(), False, 0.1, 1e-5)
+    y.backward(gy.double())
+    bn = torch.nn.BatchNorm2d(Co).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(g_); bn.bias.copy_(b_); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.eval()
+    a = nhwc(x[:, :C1]).requires_grad_(True)
+    a2 = nhwc(x[:, C1:]).requires_grad_(True) if C2 else None
+    wg = w.cuda().requires_grad_(True)
+    ops.begin_step(a.device)
+    yg = ops.conv_bn_act(a, wg, None, bn, kernel=(3, 3), stride=(S, S), padding=(1, 1), transposed=tr, x2=a2, act=ops.ACT_NONE, training=False)
+    d = ops.conv_desc(N, H, W, C1, C2, Co, 3, 3, S, S, 1, 1, 1 if tr else 0)
+    from viai_amd import _lib
+    assert _lib.load().viai_conv2d_wgrad_f16_ok(d["ref"]) == 1
+    yg.backward(nhwc(gy))
+    assert relerr(nchw(yg), y) < 3e-6
+    assert relerr(wg.grad, wd.grad) < 3e-6
+    # every filter position separately (a tap / slot mix-up hides in the global norm of a smooth filter gradient)
+    for ky in range(3):
+        for kx in range(3):
+            assert relerr(wg.grad[:, :, ky, kx], wd.grad[:, :, ky, kx]) < 5e-6, (ky, kx)
+
+
 @pytest.mark.parametrize("cfg", [(128, 0, 32), (64, 64, 32), (32, 0, 128), (96, 0, 64), (64, 64, 128)], ids=["128to32", "cat64+64to32", "32to128", "96to64", "cat64+64to128"])
 def test_wide_halo_kernel_fwd_and_f16_backward_against_fp64(cfg):
     """stride-1 3 x 3 transposed conv + BatchNorm(eval) at 3 x 64 x 128 (192 tiles): forward, data gradient (one or two

@@ -1,4 +1,4 @@
-// Patch-staged weight gradient for the stride-1 3 x 3 layers (f16x2 split MFMA, gfx950).
+// Patch-staged weight gradient for the 3 x 3 layers, stride 1 and stride 2 (f16x2 split MFMA, gfx950).
 //
 //   G[t][co][ci] = sum over output pixels p of  dy[p][co] * x[p + t][ci]          (same contract as conv_wgrad_bf3.hip)
 //
@@ -16,6 +16,12 @@
 //   gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels] block, every lane receives
 //   the four pixels of ITS channel) -- two reads per 32 x 16 MFMA operand.
 //
+// Instances <S, BN, HR, NW>:
+//   <1, 64, 4, 8>  stride 1: 128 x 64 channel tile, 4 tile rows per stage, 8 waves (4 along Cout x 2 along Cin), two LDS stages, 1 block / CU
+//   <2, 32, 2, 4>  stride 2: a stride-2 layer reads a (2 HR + 1) x 33 input patch per HR x 16 output pixels (4.4x the pixels of the stride-1
+//                  case), so the Cin tile is 32 and a stage 2 tile rows; the patch is stored as four parity sub-patches
+//                  P[py][px][r][c] = patch(2 r + py, 2 c + px), so that the 16 pixels of a k-step are again 16 consecutive LDS rows for every
+//                  tap; 4 waves, 75 KB of LDS, 2 blocks / CU.
 // Split-K over tile ranges, deterministic slab reduce (viai_wgrad_reduce) as before.
 // Reference call sites: the autograd backward of nn.Conv2d(…, 3, 1, 1) / nn.ConvTranspose2d(…, 3, 1, 1)
 // (networks/Discriminator_Networks.py:30 conv3, networks/New_Inpainting_Networks.py:24 TransConvBlock).
@@ -25,27 +31,53 @@
 
 namespace {
 
-constexpr int WP_BM = 128, WP_BN = 64;              // Cout x Cin tile of a block
+constexpr int WP_BM = 128;                          // Cout tile of a block (4 waves x 32)
 constexpr int WP_TW = 16, WP_TH = 8;                // output pixel tile
-constexpr int WP_PC = WP_TW + 2;                    // x patch columns
 constexpr int WP_DROW = WP_BM * 2;                  // dy LDS row: 128 fp16 = 256 B, 64-byte groups XOR-swizzled by (pixel & 3)
-constexpr int WP_XPITCH = WP_BN * 2 + 64;           // x LDS row: 64 fp16 + 64 B pad = 192 B (four consecutive rows tile the 256-B bank row)
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct WgPatchSlots { int s[9]; };
 
-template <int HR>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_patch_f16_kernel(const WgradArgs a, int y0, int x0, WgPatchSlots slots) {
-    constexpr int DPIX = HR * WP_TW;                         // dy pixels per stage
-    constexpr int XPIX = (HR + 2) * WP_PC;                   // x patch pixels per stage
-    constexpr int DPLANE = DPIX * WP_DROW, XPLANE = XPIX * WP_XPITCH;
-    constexpr int STAGE = 2 * DPLANE + 2 * XPLANE;
-    constexpr int NTHR = 512;
-    constexpr int ND = DPIX * (WP_BM / 4) / NTHR;            // dy float4 items per thread and stage (= HR: one tile row each)
-    constexpr int NX = (XPIX * (WP_BN / 4) + NTHR - 1) / NTHR;   // x float4 items per thread and stage (last one partial)
+template <int S, int BN, int HR, int NW>
+struct WgCfg {
+    static constexpr int NTHR = 64 * NW;
+    static constexpr int WN = BN / 32;                               // waves along Cin
+    static constexpr int PW = S == 1 ? WP_TW + 2 : 2 * WP_TW + 1;    // x patch columns (input pixels)
+    static constexpr int PH = S == 1 ? HR + 2 : 2 * HR + 1;          // x patch rows
+    static constexpr int XPIX = PH * PW;
+    static constexpr int SUBW = 17;                                  // S = 2: columns of a parity sub-patch
+    // S = 2 sub-patch bases (tight): (py, px) = (0,0): (HR + 1) rows, (0,1): (HR + 1), (1,0): HR, (1,1): HR
+    static constexpr int XSLOTS = S == 1 ? XPIX : (4 * HR + 2) * SUBW;
+    static constexpr int XPITCH = BN == 64 ? 192 : 64;               // 64 ch: +64 B pad; 32 ch: four 64-B rows are exactly one 256-B bank row
+    static constexpr int DPIX = HR * WP_TW;
+    static constexpr int DPLANE = DPIX * WP_DROW, XPLANE = XSLOTS * XPITCH;
+    static constexpr int STAGE = 2 * DPLANE + 2 * XPLANE;
+    static constexpr int LDS = 2 * STAGE;
+    static constexpr int ND = DPIX * (WP_BM / 4) / NTHR;             // dy float4 items per thread and stage
+    static constexpr int XQ = BN / 4;                                // channel quads per x pixel
+    static constexpr int XPP = NTHR / XQ;                            // x pixels per staging pass
+    static constexpr int NX = (XPIX + XPP - 1) / XPP;                // x float4 items per thread and stage (last one partial)
+    static constexpr int UPK = 2 * (ND + NX) / HR;                   // staging units (half items) per k-step
+    static_assert(DPIX * (WP_BM / 4) % NTHR == 0 && (2 * (ND + NX)) % HR == 0 && NW / WN == 4, "config");
+    __host__ __device__ static constexpr int sub_base(int py, int px) {
+        return S == 1 ? 0 : (py == 0 ? px * (HR + 1) * SUBW : 2 * (HR + 1) * SUBW + px * HR * SUBW);
+    }
+    // LDS slot (row of the x planes) of patch pixel (pr, pc)
+    __host__ __device__ static constexpr int slot(int pr, int pc) {
+        return S == 1 ? pr * PW + pc : sub_base(pr & 1, pc & 1) + (pr >> 1) * SUBW + (pc >> 1);
+    }
+    // first slot of the 16 consecutive pixels tile row r reads at window position (ty, tx)
+    __host__ __device__ static constexpr int tap_slot(int r, int ty, int tx) {
+        return S == 1 ? (r + ty) * PW + tx : sub_base(ty & 1, tx & 1) + (r + (ty >> 1)) * SUBW + (tx >> 1);
+    }
+};
+
+template <int S, int BN, int HR, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_patch_f16_kernel(const WgradArgs a, int y0, int x0, WgPatchSlots slots) {
+    using C = WgCfg<S, BN, HR, NW>;
+    constexpr int DPLANE = C::DPLANE, XPLANE = C::XPLANE, STAGE = C::STAGE, ND = C::ND, NX = C::NX, XPITCH = C::XPITCH;
     constexpr int SPT = WP_TH / HR;                          // stages per tile
-    static_assert(ND == HR && NX <= HR, "staging parts");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];      // [2 stages]{dy plane 0, dy plane 1, x plane 0, x plane 1}
 
     const ConvGeom& g = a.g;
@@ -53,13 +85,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float xscale = F16_ASCALE, xlim = 65504.f / F16_ASCALE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                 // 32 output channels x 32 input channels per wave
+    const int wm = wave / C::WN, wn = wave % C::WN;          // 32 output channels x 32 input channels per wave
 
     int b = xcd_remap(blockIdx.x, gridDim.x);
     const int per_slab = a.nblk_ci * a.nblk_co;
     const int z = b / per_slab; b -= z * per_slab;
     const int bci = b % a.nblk_ci, bco = b / a.nblk_ci;
-    const int co0 = bco * WP_BM, ci0 = bci * WP_BN;
+    const int co0 = bco * WP_BM, ci0 = bci * BN;
     const int Cin = a.C1 + a.C2;
     const bool first = ci0 < a.C1;
     const int xcs = first ? a.C1 : a.C2;
@@ -77,13 +109,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nst = (tile1 - tile0) * SPT;
 
     // ---- staging maps (thread -> items; everything but the stage origin is fixed per thread)
-    // dy: item j = pixel (column tid >> 5 of tile row j), channel quad q = tid & 31
+    // dy: item j = stage pixel (tid >> 5) + (NTHR / 32) j, channel quad q = tid & 31
+    constexpr int PJ = C::NTHR / 32;
     const int dq = tid & 31, dp0 = tid >> 5;
-    const int d_goff = (dp0 * a.Cout + co0 + dq * 4) * 4;                                   // + stage origin + j rows
-    const int d_lds = dp0 * WP_DROW + (((dq >> 3) ^ (dp0 & 3)) * 64) + (dq & 7) * 8;         // + j * 16 * WP_DROW
-    // x: item j = patch pixel (tid >> 4) + 32 j, channel quad q = tid & 15
-    const int xq = tid & 15, xp0 = tid >> 4;
-    const int x_lds = xp0 * WP_XPITCH + xq * 8;                                              // + j * 32 * WP_XPITCH
+    const int d_goff = (dp0 * a.Cout + co0 + dq * 4) * 4;
+    const int d_lds = dp0 * WP_DROW + (((dq >> 3) ^ (dp0 & 3)) * 64) + (dq & 7) * 8;         // + j * PJ * WP_DROW   (PJ % 4 == 0: same swizzle)
+    // x: item j = patch pixel (tid / XQ) + XPP j, channel quad q = tid % XQ
+    const int xq = tid % C::XQ, xp0 = tid / C::XQ;
 
     u32x4 draw[ND], xraw[NX];
     auto gload = [&](int s_) {
@@ -93,49 +125,57 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int oy0 = ty * WP_TH + h * HR, ox0 = tx * WP_TW;
         const int dbase = ((n * g.OH + oy0) * g.OW + ox0) * a.Cout * 4;
 #pragma unroll
-        for (int j = 0; j < ND; ++j)
-            draw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, d_goff + j * g.OW * a.Cout * 4, dbase, 0);
-        const int iy0 = oy0 + y0, ix0 = ox0 + x0;
+        for (int j = 0; j < ND; ++j) {
+            constexpr int dummy = 0; (void)dummy;
+            const int row = (PJ * j) >> 4, dcol = (PJ * j) & 15;                 // dp0 < PJ <= 16: pixel dp0 + PJ j = (row, dp0 + dcol)
+            draw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, d_goff + (row * g.OW + dcol) * a.Cout * 4, dbase, 0);
+        }
+        const int iy0 = oy0 * S + y0, ix0 = ox0 * S + x0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const int pp = xp0 + 32 * j, ppr = (pp * 3641) >> 16;          // pp / 18 for pp < 128
-            const int iy = iy0 + ppr, ix = ix0 + pp - ppr * WP_PC;
-            const int dead = (((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | (XPIX - 1 - pp)) >> 31) & OOB;
+            const int pp = xp0 + C::XPP * j;
+            const int ppr = S == 1 ? (pp * 3641) >> 16 : (pp * 1986) >> 16;          // pp / PW (PW = 18: pp < 128; PW = 33: pp < 200)
+            const int iy = iy0 + ppr, ix = ix0 + pp - ppr * C::PW;
+            const int dead = (((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | (C::XPIX - 1 - pp)) >> 31) & OOB;
             const int off = ((((n * g.IH + iy) * g.IW + ix) * xcs + xoff + xq * 4) * 4) | dead;
             xraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
         }
     };
+    // LDS byte offset (within an x plane) of this thread's x item j.  Stride 1: affine in j.  Stride 2: recomputed at the store (a few
+    // integer instructions per item and stage) rather than held in NX registers next to 144 accumulators.
+    const int x_lds0 = xp0 * XPITCH + xq * 8;
+    auto x_lds = [&](int j) -> int {
+        if constexpr (S == 1) return x_lds0 + j * C::XPP * XPITCH;
+        const int pp = xp0 + C::XPP * j;
+        const int ppr = (pp * 1986) >> 16, ppc = pp - ppr * C::PW;
+        const int sl = ((ppr & 1) ? 2 * (HR + 1) * C::SUBW + (ppc & 1) * HR * C::SUBW : (ppc & 1) * (HR + 1) * C::SUBW) + (ppr >> 1) * C::SUBW + (ppc >> 1);
+        return sl * XPITCH + xq * 8;
+    };
     // split + store of one staged float4 in two halves (unit 0: channels 0, 1; unit 1: channels 2, 3 + the two 8-byte LDS stores), so the
     // work can be dealt out between the taps of a k-step, a few instructions at a time
     unsigned hp1, hp2;
-    auto put_unit = [&](unsigned char* d, int plane, const u32x4& raw, float S, float L, int unit) {
+    auto put_unit = [&](unsigned char* d, int plane, const u32x4& raw, float Sc, float L, int unit) {
         const f32x4 v = __builtin_bit_cast(f32x4, raw);
         if (unit == 0) {
-            split2_pair(v[0], v[1], S, L, hp1, hp2);
+            split2_pair(v[0], v[1], Sc, L, hp1, hp2);
         } else {
             unsigned b1, b2;
-            split2_pair(v[2], v[3], S, L, b1, b2);
+            split2_pair(v[2], v[3], Sc, L, b1, b2);
             const u32x2 p1 = {hp1, b1}, p2 = {hp2, b2};
             *reinterpret_cast<u32x2*>(d) = p1;
             *reinterpret_cast<u32x2*>(d + plane) = p2;
         }
     };
-    // part `part` of a stage = item `part` of each operand; unit 0..1 = the dy item, 2..3 = the x item
-    auto lstore_unit = [&](int buf, int part, int unit) {
+    // staging unit U of a stage (compile-time): item U >> 1 (dy items first, then x items), half U & 1
+    auto lstore_unit = [&](int buf, int U) {
         unsigned char* base = smem_p + buf * STAGE;
-        if (unit < 2) {
+        const int it = U >> 1, half = U & 1;
 #pragma unroll
-            for (int j = 0; j < ND; ++j)
-                if (j == part) put_unit(base + d_lds + j * 16 * WP_DROW, DPLANE, draw[j], dscale, dlim, unit);
-        } else {
+        for (int j = 0; j < ND; ++j)
+            if (it == j) put_unit(base + d_lds + j * PJ * WP_DROW, DPLANE, draw[j], dscale, dlim, half);
 #pragma unroll
-            for (int j = 0; j < NX; ++j)
-                if (j == part && xp0 + 32 * j < XPIX) put_unit(base + 2 * DPLANE + x_lds + j * 32 * WP_XPITCH, XPLANE, xraw[j], xscale, xlim, unit - 2);
-        }
-    };
-    auto lstore = [&](int buf, int part) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) lstore_unit(buf, part, u);
+        for (int j = 0; j < NX; ++j)
+            if (it == ND + j && (C::XPP * (j + 1) <= C::XPIX || xp0 + C::XPP * j < C::XPIX)) put_unit(base + 2 * DPLANE + (half ? x_lds(j) : 0), XPLANE, xraw[j], xscale, xlim, half);
     };
 
     f32x16 acc[9];
@@ -148,7 +188,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int grp = lane >> 4, li = lane & 15;
     const int m0 = 16 * (grp & 1), kb = 8 * (grp >> 1);
     const int a_lane = (kb + (li >> 2)) * WP_DROW + ((wm ^ (li >> 2)) * 64) + m0 * 2 + (li & 3) * 8;
-    const int b_lane = 2 * DPLANE + (kb + (li >> 2)) * WP_XPITCH + wn * 64 + m0 * 2 + (li & 3) * 8;
+    const int b_lane = 2 * DPLANE + (kb + (li >> 2)) * XPITCH + wn * 64 + m0 * 2 + (li & 3) * 8;
 
     auto frag = [&](const unsigned char* p, int rowpitch) -> f16x8 {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
@@ -156,25 +196,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     // one k-step (16 pixels = one tile row) of all nine taps.  The B fragments of tap t + 1 are fetched before the MFMAs of tap t
-    // (explicit two-deep pipeline); a scheduling barrier per tap keeps the compiler from hoisting all 36 reads of a k-step to its
-    // top, which costs 144 registers next to the 288 accumulators and spills.
-    auto bfrag = [&](const unsigned char* S, int r, int t, f16x8 (&b)[2]) {
-        const unsigned char* bp = S + b_lane + ((r + t / 3) * WP_PC + (t % 3)) * WP_XPITCH;
-        b[0] = frag(bp, WP_XPITCH);
-        b[1] = frag(bp + XPLANE, WP_XPITCH);
+    // (explicit two-deep pipeline).
+    auto bfrag = [&](const unsigned char* Sb, int r, int t, f16x8 (&bb)[2]) {
+        const unsigned char* bp = Sb + b_lane + C::tap_slot(r, t / 3, t % 3) * XPITCH;
+        bb[0] = frag(bp, XPITCH);
+        bb[1] = frag(bp + XPLANE, XPITCH);
     };
     // A wave's three MFMAs of a tap accumulate into the same registers: they must issue back to back (the accumulator is forwarded;
     // ONE instruction between them costs ~43 cycles, MI355X_MICROARCH.md), while instructions between MFMAs on different accumulators
     // hide behind the running MFMA.  So the fragment reads of the next tap and a slice of the staging work (`fill`) sit BETWEEN the
     // taps, fenced by scheduling barriers.
-    auto kstep = [&](const unsigned char* S, int r, auto&& fill) {
+    auto kstep = [&](const unsigned char* Sb, int r, auto&& fill) {
         f16x8 af[2], bq[2][2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) af[p] = frag(S + a_lane + p * DPLANE + r * 16 * WP_DROW, WP_DROW);
-        bfrag(S, r, 0, bq[0]);
+        for (int p = 0; p < 2; ++p) af[p] = frag(Sb + a_lane + p * DPLANE + r * 16 * WP_DROW, WP_DROW);
+        bfrag(Sb, r, 0, bq[0]);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            if (t + 1 < 9) bfrag(S, r, t + 1, bq[(t + 1) & 1]);
+            if (t + 1 < 9) bfrag(Sb, r, t + 1, bq[(t + 1) & 1]);
             fill(t);
             __builtin_amdgcn_sched_barrier(0);
             // small partial products first (dy1 x2, dy2 x1, then dy1 x1).  The FIRST MFMA takes the fragment that was read LAST
@@ -191,24 +230,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (nst > 0) {
         gload(0);
 #pragma unroll
-        for (int part = 0; part < HR; ++part) lstore(0, part);
+        for (int U = 0; U < 2 * (ND + NX); ++U) lstore_unit(0, U);
         if (nst > 1) gload(1);
     }
     __syncthreads();
     for (int s = 0; s + 1 < nst; ++s) {
-        const unsigned char* S = smem_p + (s & 1) * STAGE;
+        const unsigned char* Sb = smem_p + (s & 1) * STAGE;
 #pragma unroll
         for (int r = 0; r < HR; ++r)
-            kstep(S, r, [&](int t) {
-                if ((t & 1) && t < 8) lstore_unit((s & 1) ^ 1, r, t >> 1);       // units 0..3 behind taps 1, 3, 5, 7
+            kstep(Sb, r, [&](int t) {
+                // the UPK staging units of this k-step, dealt over the nine gaps in order
+#pragma unroll
+                for (int u = 0; u < C::UPK; ++u)
+                    if ((u * 9) / C::UPK == t) lstore_unit((s & 1) ^ 1, r * C::UPK + u);
             });
         if (s + 2 < nst) gload(s + 2);
         __syncthreads();
     }
     if (nst > 0) {                                  // last stage: nothing left to stage
-        const unsigned char* S = smem_p + ((nst - 1) & 1) * STAGE;
+        const unsigned char* Sb = smem_p + ((nst - 1) & 1) * STAGE;
 #pragma unroll
-        for (int r = 0; r < HR; ++r) kstep(S, r, [&](int) {});
+        for (int r = 0; r < HR; ++r) kstep(Sb, r, [&](int) {});
     }
 
     // ---- epilogue: G slab [z][slot][co][ci]
@@ -227,8 +269,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-constexpr int WP_HR = 4;
-
 static bool window9(const ConvGeom& g, int* y0, int* x0, WgPatchSlots* sl) {
     if (g.ntaps != 9) return false;
     int yy = g.dy[0], xx = g.dx[0];
@@ -245,25 +285,42 @@ static bool window9(const ConvGeom& g, int* y0, int* x0, WgPatchSlots* sl) {
     return seen == 0x1ffu;
 }
 
+static int bn_of(const ConvGeom& g) { return g.my == 2 ? 32 : 64; }
+
+template <int S, int BN, int HR, int NW>
+static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hipStream_t st) {
+    using C = WgCfg<S, BN, HR, NW>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_patch_f16_kernel<S, BN, HR, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); attr_done = true; }
+    VIAI_LAUNCH((wgrad_patch_f16_kernel<S, BN, HR, NW>), dim3(a.nblk_co * a.nblk_ci * a.ksplit), dim3(C::NTHR), C::LDS, st, a, y0, x0, sl);
+    return viai_launch_status();
+}
+
 }  // namespace
 
-// stride-1 3 x 3 layers with Cout % 128 == 0, Cin % 64 == 0 (a tile must not straddle the two concatenated sources), output
-// extent a multiple of the 8 x 16 tile and enough tiles to give every block a K loop worth its prologue / epilogue
+// 3 x 3 layers with the full window, stride 1 or 2 (plain conv), Cout % 128 == 0, Cin a multiple of the Cin tile (64 / 32; a tile must
+// not straddle the two concatenated sources), output extent a multiple of the 8 x 16 tile and enough tiles to give every block a K
+// loop worth its prologue / epilogue
 bool viai_wgrad_patch_ok(const ConvGeom& g, int Cout, int C1, int C2) {
-    static int on = -1;
+    static int on = -1, s2 = -1;
     if (on < 0) { const char* e = getenv("VIAI_WGRAD_PATCH"); on = e ? atoi(e) : 1; }
-    if (!on || g.run || g.my != 1 || g.mx != 1 || g.ly != 1 || g.lx != 1) return false;
-    if (Cout % WP_BM != 0 || C1 % WP_BN != 0 || C2 % WP_BN != 0 || C1 < WP_BN) return false;
+    if (s2 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_S2"); s2 = e ? atoi(e) : 1; }
+    if (!on || g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && !(g.my == 2 && s2))) return false;
+    const int bn = bn_of(g);
+    if (Cout % WP_BM != 0 || C1 % bn != 0 || C2 % bn != 0 || C1 < bn) return false;
     if (g.OH % WP_TH != 0 || g.OW % WP_TW != 0) return false;
     if ((long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW) < 64) return false;
     return window9(g, nullptr, nullptr, nullptr);
 }
 
-// K slabs: one round of one block per CU, at least four tiles per block
+// K slabs: one round of resident blocks (1 per CU for the stride-1 instance, 2 for the stride-2 one), at least four tiles per block
 int viai_wgrad_patch_ksplit(const ConvGeom& g, int Cout, int Cin) {
     const long tiles = (long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW);
-    const long per = (long)(Cout / WP_BM) * (Cin / WP_BN);
-    long ks = 256 / per;
+    const long per = (long)(Cout / WP_BM) * (Cin / bn_of(g));
+    static long blk1 = -1, blk2 = -1;
+    if (blk1 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS"); blk1 = e ? atol(e) : 256; }
+    if (blk2 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_S2"); blk2 = e ? atol(e) : 512; }
+    long ks = (g.my == 2 ? blk2 : blk1) / per;
     if (ks > tiles / 4) ks = tiles / 4;
     if (ks < 1) ks = 1;
     const long tps = (tiles + ks - 1) / ks;                  // tiles per slab
@@ -280,10 +337,7 @@ int viai_wgrad_patch_launch(WgradArgs& a, hipStream_t st) {
     a.ksplit = viai_wgrad_patch_ksplit(g, a.Cout, Cin);
     a.chunks_per_split = (int)((tiles + a.ksplit - 1) / a.ksplit);
     a.nblk_co = a.Cout / WP_BM;
-    a.nblk_ci = Cin / WP_BN;
-    constexpr int lds = 2 * (2 * WP_HR * WP_TW * WP_DROW + 2 * (WP_HR + 2) * WP_PC * WP_XPITCH);
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_patch_f16_kernel<WP_HR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
-    VIAI_LAUNCH((wgrad_patch_f16_kernel<WP_HR>), dim3(a.nblk_co * a.nblk_ci * a.ksplit), dim3(512), lds, st, a, y0, x0, sl);
-    return viai_launch_status();
+    a.nblk_ci = Cin / bn_of(g);
+    if (g.my == 2) return launch_patch<2, 32, 2, 4>(a, y0, x0, sl, st);
+    return launch_patch<1, 64, 4, 8>(a, y0, x0, sl, st);
 }
