@@ -253,7 +253,7 @@ class KernelTimer:
             f, n = fam_wgrad(d)
             oh, ow = out_hw(d)
             s1 = (d.sh, d.sw) == (1, 1)
-            s2 = (d.sh, d.sw) == (2, 2) and not d.transposed and os.environ.get("VIAI_WGRAD_PATCH_S2", "1") != "0"
+            s2 = (d.sh, d.sw) == (2, 2) and not d.transposed and os.environ.get("VIAI_WGRAD_PATCH_S2", "0") not in ("0", "")
             bn = 64 if s1 else 32
             if (f == "wgrad_bf3" and os.environ.get("VIAI_WGRAD_PATCH", "1") != "0" and (d.kh, d.kw) == (3, 3) and (s1 or s2)
                     and d.Cout % 128 == 0 and d.C1 % bn == 0 and d.C2 % bn == 0 and oh % 8 == 0 and ow % 16 == 0
@@ -316,12 +316,14 @@ def cpu_baseline(args):
         while sum(times) < budget_s and len(times) < max_steps:
             times.append(one_step(b, args.bins, args.frames, "bench.cpu"))
         return min(times), len(times), sum(times)
-    full_threads = max(1, avail)
-    dt, n, tot = sample(args.batch, full_threads, 15.0, 8)
+    # torch's CPU convolutions stop scaling at ~16 threads and collapse under oversubscription: one 16-clip step measured 5.8 s at 16
+    # threads, 6.4 s at 32, 9.7 s at 64 and 192 s at 256 on the 256-logical-CPU host of an MI355X box -- so 16 is the best case
+    full_threads = max(1, min(avail, 16))
+    dt, n, tot = sample(args.batch, full_threads, 15.0, 4)
     out = {"value": round(args.batch / dt, 4), "unit": "clips/s", "cores": full_threads, "kind": "port",
-           "sample": "oracle/viai_oracle.train_step (torch CPU fp32, %d threads = every core this process may use), %d clips of %dx%d per step "
-                     "(the GPU line's workload), best of %d step(s) (%.1f s of CPU work), %.2f s/step"
-                     % (full_threads, args.batch, args.bins, args.frames, n, tot, dt)}
+           "sample": "oracle/viai_oracle.train_step (torch CPU fp32, %d threads of the %d logical CPUs this process may use: more threads are slower, "
+                     "see bench.py), %d clips of %dx%d per step (the GPU line's workload), best of %d step(s) (%.1f s of CPU work), %.2f s/step"
+                     % (full_threads, avail, args.batch, args.bins, args.frames, n, tot, dt)}
     t2 = max(1, min(avail, 16))
     dt2, n2, tot2 = sample(args.cpu_batch, t2, 6.0, 64)
     out["small_batch"] = {"value": round(args.cpu_batch / dt2, 4), "unit": "clips/s", "cores": t2,

@@ -2,7 +2,11 @@
 
 Restates `melspectrogram` of the reference's utils/audio.py:70-75 in numpy (fp64).
 
-PARITY UNPINNED: utils/audio.py cannot be imported here — its arithmetic lives in two third-party
+PARITY PARTLY PINNED (round 2): the plain-numpy parts of utils/audio.py -- lws_num_frames / lws_pad_lr (:90-108), _amp_to_db
+(:130-132), _normalize (:139-140) and the inverse pair _denormalize / _db_to_amp (:135-144) -- are now exercised through the
+REFERENCE's own functions by tools/make_goldens.py::loader_goldens (utils/audio.py imports with empty stand-ins for `lws` and
+`librosa`, which those functions never touch) and committed as tests/golden/loader.npz.  What remains
+UNPINNED is what lives inside the two absent third-party packages: utils/audio.py cannot be run end to end here — its arithmetic lives in two third-party
 packages that are neither installed, vendored nor version-pinned by the reference (no requirements
 file): `lws` (`lws.lws(fft_size, hop, mode="speech").stft`, call site utils/audio.py:71,86-87) and
 `librosa.filters.mel(sr, n_fft, fmin=, fmax=, n_mels=)` (utils/audio.py:125-127; positional sr/n_fft =>
@@ -97,11 +101,21 @@ def stft_lws(y, fsize, fshift, window=None):
     return np.fft.rfft(frames * win[None, :], axis=1)
 
 
+def amp_to_db(x, min_level_db):
+    """utils/audio.py:130-132 (pinned: tests/golden/loader.npz `amp_to_db_norm`, produced by the reference's own function)"""
+    min_level = np.exp(min_level_db / 20.0 * np.log(10.0))
+    return 20.0 * np.log10(np.maximum(min_level, x))
+
+
+def normalize(S, min_level_db):
+    """utils/audio.py:139-140 (pinned, same fixture)"""
+    return np.clip((S - min_level_db) / -min_level_db, 0.0, 1.0)
+
+
 def melspectrogram(y, cfg=AudioConfig, window=None, basis=None):
     """utils/audio.py:70-75 -> [num_mels][M] in [0, 1]."""
     D = stft_lws(y, cfg.fft_size, cfg.hop_size, window).T                         # :71  (F, M)
     B = mel_basis(cfg.sample_rate, cfg.fft_size, cfg.num_mels, cfg.fmin, cfg.fmax) if basis is None else basis
     mel = B @ np.abs(D)                                                            # :116-120
-    min_level = np.exp(cfg.min_level_db / 20.0 * np.log(10.0))                     # :131
-    S = 20.0 * np.log10(np.maximum(min_level, mel)) - cfg.ref_level_db             # :132, :72
-    return np.clip((S - cfg.min_level_db) / -cfg.min_level_db, 0.0, 1.0)           # :139-140
+    S = amp_to_db(mel, cfg.min_level_db) - cfg.ref_level_db                        # :132, :72
+    return normalize(S, cfg.min_level_db)                                          # :139-140

@@ -1,9 +1,12 @@
 """The callers either side of the train-step path: lr schedules, EMA, retrieval metrics,
 device batch assembly, inverse mel.  CPU tests pin oracle/pipeline_oracle.py and the host-side schedule functions to
 the reference-generated goldens (tests/golden/pipeline.npz, tools/make_goldens.py::pipeline_goldens); GPU tests
-compare the HIP kernels (through libviai_hip.so) with the oracle.  frames_prep / slice_clips / inv_mel are restated
-from Data_loaders/audio_loader.py:185-245,471-523 and utils/audio.py:135-144 (parity unpinned: those modules need
-cv2 / lws / librosa, absent in the build container) and additionally checked by direct index arithmetic here."""
+compare the HIP kernels (through libviai_hip.so) with the oracle.  frames_prep / slice_clips / inv_mel restate
+Data_loaders/audio_loader.py:185-245,471-523 and utils/audio.py:135-144; since round 2 they are PINNED too:
+tests/golden/loader.npz holds what the reference's own sample_data_new / collate_fn / _denormalize / _db_to_amp / _amp_to_db /
+_normalize / lws_num_frames / lws_pad_lr returned on synthetic closed-form frames and mels
+(tools/make_goldens.py::loader_goldens: empty stand-ins for the packages those functions never call, a cv2 harness that
+serves the synthetic frames)."""
 import os
 
 import numpy as np
@@ -258,3 +261,86 @@ def test_checkpoint_file_has_the_reference_structure_and_reference_style_files_l
     b.optimize_parameters(1)
     torch.cuda.synchronize()
     assert torch.equal(a.arena_G.flat, b.arena_G.flat) and torch.equal(a.arena_D.flat, b.arena_D.flat)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# batch assembly and the audio helpers against what the REFERENCE's loader / audio functions returned (loader.npz)
+# ------------------------------------------------------------------------------------------------------------------
+
+def _loader_frame(kind, idx, gray, R=256):
+    """the synthetic frame tools/make_goldens.py's cv2 harness served for `<kind>/<idx>.jpg`"""
+    t = O.cf_uniform("ld.%s.%d" % (kind, idx), (R, R) if gray else (R, R, 3), 0, 256).numpy()
+    return np.clip(np.floor(t), 0, 255).astype(np.uint8)
+
+
+def _loader_clip_frames(lg, ln, i):
+    item = int(lg["starts"][ln]) + i + 1
+    rgb = _loader_frame("image_crop", item, False)[..., ::-1].copy()                    # cv2.cvtColor(BGR -> RGB)
+    fl = np.stack((_loader_frame("flow_x_crop", item, True), _loader_frame("flow_y_crop", item, True)), -1)
+    return rgb, fl
+
+
+def _loader_utterances(lg, use=52, hop=256):
+    mels, wavs = [], []
+    for u in range(2):
+        T_mel = 3 + 4 * (int(lg["starts"].max()) + use) + 5 + 11 * u
+        mels.append(O.cf_uniform("ld.c%d" % u, (T_mel, 80), 0, 1))
+        wavs.append(O.cf_uniform("ld.x%d" % u, (T_mel * hop,), -1, 1))
+    return mels, wavs
+
+
+def test_oracle_batch_assembly_and_audio_helpers_match_reference_loader_golden(golden_dir):
+    from oracle import audio_oracle as AO
+    lg = np.load(os.path.join(golden_dir, "loader.npz"))
+    cx, cy, flip = [int(v) for v in lg["crop_flip"]]
+    assert flip == 1 and (cx, cy) != (0, 0)                       # the fixture exercises flip and a non-trivial crop
+    rgb, _ = _loader_clip_frames(lg, 0, 0)
+    assert np.abs(P.frames_prep(rgb, 224, cx, cy, flip) - lg["video_first"]).max() < 1e-6
+    _, fl = _loader_clip_frames(lg, len(lg["starts"]) - 1, 51)
+    assert np.abs(P.frames_prep(fl, 224, cx, cy, flip) - lg["flow_last"]).max() < 1e-6
+    mels, wavs = _loader_utterances(lg)
+    cs, xs = zip(*[P.slice_clips(m.numpy(), w.numpy(), lg["starts"].tolist(), 52, 256) for m, w in zip(mels, wavs)])
+    c_all, x_all = np.concatenate(cs), np.concatenate(xs)
+    assert np.array_equal(c_all[1], lg["collate.c_clip1"])
+    assert np.allclose(O.digest(torch.from_numpy(c_all), 256), lg["collate.c.dg"], rtol=1e-12)
+    assert np.allclose(O.digest(torch.from_numpy(x_all), 256), lg["collate.x.dg"], rtol=1e-12)
+    S = O.cf_uniform("ld.S", (80, 64), -0.2, 1.2).numpy()
+    assert np.allclose(P.inv_mel_amplitude(S, float(lg["min_level_db"])), lg["inv_mel"], rtol=1e-12)
+    amp = 10.0 ** O.cf_uniform("ld.amp", (80, 64), -7, 1).double().numpy()
+    mn, ref = float(lg["min_level_db"]), float(lg["ref_level_db"])
+    assert np.allclose(AO.normalize(AO.amp_to_db(amp, mn) - ref, mn), lg["amp_to_db_norm"], rtol=1e-12, atol=1e-15)
+    for row in lg["lws_table"].tolist():
+        length = row[0]
+        assert AO.lws_num_frames(length, 1024, 256) == row[1] and tuple(AO.lws_pad_lr(length, 1024, 256)) == tuple(row[2:4])
+        assert AO.lws_num_frames(length, 1024, 320) == row[4] and tuple(AO.lws_pad_lr(length, 1024, 320)) == tuple(row[5:7])
+    from viai_amd import audio as A                               # host mirror in the product package (plain arithmetic, no GPU)
+    for row in lg["lws_table"].tolist():
+        assert A.lws_num_frames(row[0], 1024, 256) == row[1] and tuple(A.lws_pad_lr(row[0], 1024, 256)) == tuple(row[2:4])
+
+
+@pytest.mark.gpu
+def test_batch_assembly_kernels_match_reference_loader_golden(golden_dir):
+    """viai_frames_prep / viai_slice_clips / viai_mel_denorm_amp against the outputs of the reference's sample_data_new / collate_fn /
+    _db_to_amp(_denormalize(.)) on the same synthetic frames, mels and waveforms (tests/golden/loader.npz)."""
+    from viai_amd import audio, batch
+    lg = np.load(os.path.join(golden_dir, "loader.npz"))
+    cx, cy, flip = [int(v) for v in lg["crop_flip"]]
+    starts = lg["starts"].tolist()
+    vids, flows = [], []
+    for ln in range(len(starts)):
+        fr = [_loader_clip_frames(lg, ln, i) for i in range(52)]
+        vids.append(np.stack([f[0] for f in fr])); flows.append(np.stack([f[1] for f in fr]))
+    video = batch.frames_prep(torch.from_numpy(np.stack(vids)).cuda(), 224, cx, cy, bool(flip), nchw=True)
+    flow = batch.frames_prep(torch.from_numpy(np.stack(flows)).cuda(), 224, cx, cy, bool(flip), nchw=True)
+    assert tuple(video.shape) == (2, 52, 3, 224, 224) and tuple(flow.shape) == (2, 52, 2, 224, 224)
+    assert np.array_equal(video[0, 0].cpu().numpy(), lg["video_first"]) and np.array_equal(flow[-1, -1].cpu().numpy(), lg["flow_last"])
+    assert np.allclose(O.digest(video, 256), lg["video.dg"], rtol=1e-12) and np.allclose(O.digest(flow, 256), lg["flow.dg"], rtol=1e-12)
+    mels, wavs = _loader_utterances(lg)
+    cs, xs = zip(*[batch.slice_clips(m.cuda(), w.cuda(), starts, 52, 256) for m, w in zip(mels, wavs)])
+    c_all, x_all = torch.cat(cs), torch.cat(xs)
+    assert tuple(c_all.shape) == (4, 80, 208) and tuple(x_all.shape) == (4, 1, 208 * 256)
+    assert np.array_equal(c_all[1].cpu().numpy(), lg["collate.c_clip1"])
+    assert np.allclose(O.digest(c_all, 256), lg["collate.c.dg"], rtol=1e-12) and np.allclose(O.digest(x_all, 256), lg["collate.x.dg"], rtol=1e-12)
+    S = O.cf_uniform("ld.S", (80, 64), -0.2, 1.2)
+    got = audio.inv_mel_amplitude(S.cuda(), float(lg["min_level_db"])).cpu().numpy().astype(np.float64)
+    assert np.abs(got / lg["inv_mel"] - 1).max() <= 2e-5

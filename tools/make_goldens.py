@@ -677,6 +677,121 @@ def instnorm_goldens():
     print("instnorm -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def loader_goldens():
+    """The callers in front of / behind the path that round 1 left unpinned, now driven through the
+    REFERENCE's own functions:
+
+      * `Data_loaders.audio_loader.sample_data_new` (:156-245: frame normalisation (px - 127) / 128, horizontal flip, random crop,
+        (N, C, H, W) transpose) and `collate_fn` (:432-532: mel / audio window slicing `3 + 4 start`, zero padding, (B, C, T)
+        transposes);
+      * `utils.audio._denormalize` / `_db_to_amp` / `_amp_to_db` / `_normalize` / `lws_num_frames` / `lws_pad_lr` (:90-144).
+
+    Both modules import packages that are absent here (nnmnkwii, keras, cv2, lws, librosa).  None of the functions above calls into
+    nnmnkwii / keras / lws / librosa, so empty stand-in modules make the import succeed; `cv2` is a HARNESS that feeds synthetic
+    closed-form frames: `imread` returns the frame of that file name, `cvtColor` reverses the channel axis (BGR -> RGB), `resize`
+    asserts the frame already has the requested size (so no interpolation is involved).  numpy's RNG is recorded, so the crop / flip /
+    start draws of the reference are part of the fixture."""
+    import tempfile
+    from oracle import pipeline_oracle as P
+    for name in ("nnmnkwii", "nnmnkwii.datasets", "keras", "keras.utils", "keras.utils.np_utils", "lws", "librosa", "librosa.filters"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["nnmnkwii.datasets"].FileSourceDataset = object
+    sys.modules["nnmnkwii.datasets"].FileDataSource = object
+    sys.modules["keras.utils"].np_utils = sys.modules["keras.utils.np_utils"]
+    cv2 = sys.modules["cv2"]
+    R = 256
+
+    def frame(path, gray):
+        idx = int(os.path.basename(path).split(".")[0])
+        kind = os.path.basename(os.path.dirname(path))
+        t = O.cf_uniform("ld.%s.%d" % (kind, idx), (R, R) if gray else (R, R, 3), 0, 256).numpy()
+        return np.clip(np.floor(t), 0, 255).astype(np.uint8)
+    cv2.imread = lambda path, flag=1: frame(path, flag == 0)
+    cv2.COLOR_BGR2RGB = 4
+    cv2.cvtColor = lambda img, code: img[..., ::-1]
+
+    def resize(img, size):
+        assert tuple(img.shape[:2]) == (size[1], size[0]), "harness frames are generated at the requested size"
+        return img
+    cv2.resize = resize
+    from Data_loaders import audio_loader as RL
+    from utils import audio as RA
+    hp = RL.hparams
+    out = OrderedDict()
+    with tempfile.TemporaryDirectory() as td:
+        n_frames = 180
+        for sub in ("flow_x_crop", "flow_y_crop", "image_crop"):
+            os.makedirs(os.path.join(td, sub))
+            for i in range(n_frames):
+                open(os.path.join(td, sub, "%d.jpg" % (i + 1)), "w").close()
+        draws = []
+        orig = np.random.randint
+
+        def rec(*a, **k):
+            v = orig(*a, **k)
+            draws.append(int(v))
+            return v
+        np.random.seed(7)
+        np.random.randint = rec
+        try:
+            video, flow, start = RL.sample_data_new(td, train=True, hparams=hp)
+        finally:
+            np.random.randint = orig
+    use = video.shape[1]
+    assert video.shape == (hp.load_num, use, 3, 224, 224) and flow.shape == (hp.load_num, use, 2, 224, 224) and use == 52
+    crop_x, crop_y, flip = draws[-3], draws[-2], draws[-1]
+    out["starts"] = np.array(start, dtype=np.int64)
+    out["crop_flip"] = np.array([crop_x, crop_y, flip], dtype=np.int64)
+    out["video.dg"] = O.digest(torch.from_numpy(video), 256); out["flow.dg"] = O.digest(torch.from_numpy(flow), 256)
+    out["video_first"] = video[0, 0].astype(np.float32); out["flow_last"] = flow[-1, -1].astype(np.float32)
+    # the oracle's frames_prep on the same frames (read the harness way: RGB = reversed BGR; flow = (x, y) planes)
+    for ln in (0, hp.load_num - 1):
+        for i in (0, use - 1):
+            item = start[ln] + i + 1
+            rgb = frame(os.path.join("image_crop", "%d.jpg" % item), False)[..., ::-1]
+            fl = np.stack((frame(os.path.join("flow_x_crop", "%d.jpg" % item), True), frame(os.path.join("flow_y_crop", "%d.jpg" % item), True)), -1)
+            assert np.abs(P.frames_prep(rgb, 224, crop_x, crop_y, flip) - video[ln, i]).max() < 1e-6
+            assert np.abs(P.frames_prep(fl, 224, crop_x, crop_y, flip) - flow[ln, i]).max() < 1e-6
+    # ---- collate_fn: two utterances, load_num windows each
+    batch, mels, wavs = [], [], []
+    for u in range(2):
+        T_mel = 3 + 4 * (max(start) + use) + 5 + 11 * u
+        c = O.cf_uniform("ld.c%d" % u, (T_mel, 80), 0, 1).numpy()
+        x = O.cf_uniform("ld.x%d" % u, (T_mel * hp.hop_size,), -1, 1).numpy()
+        mels.append(c); wavs.append(x)
+        batch.append((x, c, video, flow, start, None, "utt%d" % u))
+    vb, fb, cb, xb, yb, gb, lens, paths = RL.collate_fn(batch)
+    assert tuple(cb.shape) == (4, 80, 208) and tuple(xb.shape) == (4, 1, 208 * hp.hop_size) and gb is None
+    k = 0
+    for u in range(2):
+        oc, ox = P.slice_clips(mels[u], wavs[u], start, use, hp.hop_size)
+        assert np.array_equal(oc, cb[k:k + 2].numpy()) and np.array_equal(ox, xb[k:k + 2].numpy())
+        k += 2
+    assert torch.equal(yb.squeeze(-1), xb.squeeze(1)) and lens.tolist() == [208 * hp.hop_size] * 4
+    out["collate.c.dg"] = O.digest(cb, 256); out["collate.x.dg"] = O.digest(xb, 256)
+    out["collate.c_clip1"] = cb[1].numpy()
+    # ---- utils/audio.py plain-numpy helpers
+    S = O.cf_uniform("ld.S", (80, 64), -0.2, 1.2).numpy()
+    out["inv_mel"] = RA._db_to_amp(RA._denormalize(S.astype(np.float64)))              # fp64 input: the function's exact arithmetic
+    out["inv_mel_f32"] = RA._db_to_amp(RA._denormalize(S)).astype(np.float64)           # fp32 input, as a network output would arrive
+    assert np.allclose(P.inv_mel_amplitude(S, RA.hparams.min_level_db), out["inv_mel"], rtol=1e-12)
+    assert np.allclose(out["inv_mel_f32"], out["inv_mel"], rtol=2e-5)
+    amp = (10.0 ** O.cf_uniform("ld.amp", (80, 64), -7, 1).double().numpy())
+    out["amp_to_db_norm"] = RA._normalize(RA._amp_to_db(amp) - RA.hparams.ref_level_db)
+    from oracle import audio_oracle as AO
+    assert np.allclose(AO.normalize(AO.amp_to_db(amp, RA.hparams.min_level_db) - RA.hparams.ref_level_db, RA.hparams.min_level_db), out["amp_to_db_norm"], rtol=1e-12, atol=1e-15)
+    tab = []
+    for length in (1, 255, 256, 257, 1024, 65536, 66560, 66561, 100000):
+        x = np.zeros(length)
+        tab.append([length, RA.lws_num_frames(length, 1024, 256)] + list(RA.lws_pad_lr(x, 1024, 256)) + [RA.lws_num_frames(length, 1024, 320)] + list(RA.lws_pad_lr(x, 1024, 320)))
+        assert tab[-1][1] == AO.lws_num_frames(length, 1024, 256) and tuple(tab[-1][2:4]) == tuple(AO.lws_pad_lr(length, 1024, 256))
+    out["lws_table"] = np.array(tab, dtype=np.int64)
+    out["min_level_db"], out["ref_level_db"] = np.float64(RA.hparams.min_level_db), np.float64(RA.hparams.ref_level_db)
+    path = os.path.join(OUT, "loader.npz")
+    np.savez_compressed(path, **out)
+    print("loader -> %s (%.1f KB); starts %s crop/flip %s" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024, start, (crop_x, crop_y, flip)))
+
+
 def adam_goldens():
     """torch.optim.Adam known-answer vectors (what the missing AudioModel's
     optimizer_G/optimizer_D are, utils/util.py:149-150)."""
@@ -795,6 +910,9 @@ if __name__ == "__main__":
         torch.set_num_threads(os.cpu_count())
         wavenet_full_goldens()
         sys.exit(0)
+    if "--loader-only" in sys.argv:
+        loader_goldens()
+        sys.exit(0)
     if "--instnorm-only" in sys.argv:
         instnorm_goldens()
         sys.exit(0)
@@ -821,6 +939,7 @@ if __name__ == "__main__":
     wavenet_onehot_goldens()
     av_step_goldens()
     instnorm_goldens()
+    loader_goldens()
     checkpoint_structure_golden()
     run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
     run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]

@@ -454,10 +454,10 @@ static int wgrad_ksplit(const viai_conv2d* c, long M) {
     return viai_wgrad_pick_ksplit(c->Cout, cin_of(c), c->kh * c->kw, M);
 }
 // the all-taps patch kernel (f16x2 launches of the stride-1 3 x 3 layers with >= 128 x 64 channels)
-static bool wgrad_patch(const viai_conv2d* c) {
+static bool wgrad_patch(const viai_conv2d* c, bool shape_only = false) {
     if (kind_of(c) != K_IGEMM || !f16x2_enabled() || !bf3_enabled() || !viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2)) return false;
     ConvGeom g{}; viai_geom_fwd(c, &g);
-    return viai_wgrad_patch_ok(g, c->Cout, c->C1, c->C2);
+    return shape_only ? viai_wgrad_patch_shape_ok(g, c->Cout, c->C1, c->C2) : viai_wgrad_patch_ok(g, c->Cout, c->C1, c->C2);
 }
 
 extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
@@ -475,7 +475,7 @@ extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
         int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
         long M = (long)c->N * oh * ow;
         int ks = wgrad_ksplit(c, M);
-        if (wgrad_patch(c)) {                                  // workspace covers both forms (with / without the abs-max scale)
+        if (wgrad_patch(c, true)) {                            // workspace covers every form the layer can take, whatever the switches say
             ConvGeom g{}; viai_geom_fwd(c, &g);
             int kp = viai_wgrad_patch_ksplit(g, c->Cout, cin_of(c));
             if (kp > ks) ks = kp;

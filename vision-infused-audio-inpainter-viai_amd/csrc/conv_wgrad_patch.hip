@@ -300,17 +300,27 @@ static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hi
 
 // 3 x 3 layers with the full window, stride 1 or 2 (plain conv), Cout % 128 == 0, Cin a multiple of the Cin tile (64 / 32; a tile must
 // not straddle the two concatenated sources), output extent a multiple of the 8 x 16 tile and enough tiles to give every block a K
-// loop worth its prologue / epilogue
-bool viai_wgrad_patch_ok(const ConvGeom& g, int Cout, int C1, int C2) {
-    static int on = -1, s2 = -1;
-    if (on < 0) { const char* e = getenv("VIAI_WGRAD_PATCH"); on = e ? atoi(e) : 1; }
-    if (s2 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_S2"); s2 = e ? atoi(e) : 1; }
-    if (!on || g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && !(g.my == 2 && s2))) return false;
+// loop worth its prologue / epilogue.  `shape_ok` is the pure shape predicate (workspace sizing); `ok` adds the switches.
+//
+// The stride-2 instance is OFF by default (VIAI_WGRAD_PATCH_S2=1 enables it): alone it is 1.2-1.6x faster than wgrad_bf3_kernel
+// (D.conv2_1 261 -> 159 us, D.conv2_2 163 -> 133 us), but in the three-stream step the weight gradients run beside the main
+// backward chain, and two of its blocks take a CU's whole LDS and register file: same-box A/B of the full step 8.39 ms without it,
+// 8.60 ms with it (8.56 ms with neither patch kernel).  The stride-1 instance (one 8-wave block per CU) does pay: 8.56 -> 8.39 ms.
+bool viai_wgrad_patch_shape_ok(const ConvGeom& g, int Cout, int C1, int C2) {
+    if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2)) return false;
     const int bn = bn_of(g);
     if (Cout % WP_BM != 0 || C1 % bn != 0 || C2 % bn != 0 || C1 < bn) return false;
     if (g.OH % WP_TH != 0 || g.OW % WP_TW != 0) return false;
     if ((long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW) < 64) return false;
     return window9(g, nullptr, nullptr, nullptr);
+}
+
+bool viai_wgrad_patch_ok(const ConvGeom& g, int Cout, int C1, int C2) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_WGRAD_PATCH"); on = e ? atoi(e) : 1; }
+    if (!on) return false;
+    if (g.my == 2) { const char* e = getenv("VIAI_WGRAD_PATCH_S2"); if (!(e && atoi(e))) return false; }     // read per call: tests switch it
+    return viai_wgrad_patch_shape_ok(g, Cout, C1, C2);
 }
 
 // K slabs: one round of resident blocks (1 per CU for the stride-1 instance, 2 for the stride-2 one), at least four tiles per block
