@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 3
+#define VIAI_ABI_VERSION 4
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -276,6 +276,13 @@ int viai_axpy(float a, const float* x, float* y, long n, void* stream);
 int viai_stft_mel(const float* wav, const float* window, const float* basis_t, const float* mask,
                   float* mel, int B, int n_samples, int fft, int hop, int n_mels, int frames,
                   float min_level_db, float ref_level_db, void* stream);
+/* The same stage (utils/audio.py:70-75) on the frame-batched kernel, fft = 1024 (ABI v4): eight frames per block, two real frames per
+ * complex radix-4 FFT, and a BANDED mel basis -- the caller states the support of each band of `basis_t`:
+ * basis_t[k][m] == 0 outside k in [band_lo[m], band_lo[m] + band_cnt[m])  (librosa.filters.mel rows are triangles a few bins wide;
+ * a dense basis is expressed by band_lo = 0, band_cnt = fft/2 + 1).  Same outputs as viai_stft_mel.                                  */
+int viai_stft_mel_banded(const float* wav, const float* window, const float* basis_t, const int* band_lo, const int* band_cnt,
+                         const float* mask, float* mel, int B, int n_samples, int fft, int hop, int n_mels, int frames,
+                         float min_level_db, float ref_level_db, void* stream);
 
 /* -------------------------------------------------- callers either side of the path
  * Batch assembly on the device, Data_loaders/audio_loader.py:185-245: frames uint8 [n][S][S][C] (RGB or

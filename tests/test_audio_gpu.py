@@ -31,6 +31,11 @@ def test_stft_mel_matches_oracle(n_mels, n_samples):
     mask = synth.time_mask(3, frames, "a.mask").reshape(3, frames)
     outm = fe(wav.cuda(), mask.cuda()).cpu().numpy()
     assert np.array_equal(outm[:, 0], out[:, 0] * mask.numpy()[:, None, :])
+    # the frame-batched banded kernel (default for fft 1024) and the one-frame-per-block dense kernel are the same function
+    fe.force_dense = True
+    dense = fe(wav.cuda()).cpu().numpy()
+    assert np.abs(dense - out).max() < 2e-5, np.abs(dense - out).max()
+    assert int(fe.band_cnt.max()) < 64 and int(fe.band_cnt.min()) >= 1            # the Slaney triangles are narrow: banded = sparse
 
 
 def test_front_end_feeds_the_model():

@@ -123,6 +123,7 @@ SIGNATURES = {
     "viai_colsum": (_I, [_P, _L, _I, _P, _P, _I, _P]),
     "viai_axpy": (_I, [_F, _P, _P, _L, _P]),
     "viai_stft_mel": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "viai_stft_mel_banded": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "viai_conv2d_pack_job": (_I, [_CP, _I, _P, _P, C.POINTER(PackJob)]),
     "viai_pack_jobs_run": (_I, [_P, _I, _I, _P]),
     "viai_frames_prep": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
@@ -163,7 +164,7 @@ def load() -> C.CDLL:
             raise ViaiLibraryError("libviai_hip.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.viai_abi_version() != 3:
+    if lib.viai_abi_version() != 4:
         raise ViaiLibraryError("libviai_hip.so ABI version mismatch")
     _lib = lib
     return lib

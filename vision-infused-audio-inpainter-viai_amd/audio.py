@@ -68,6 +68,12 @@ class MelFrontEnd:
         self.window = torch.tensor(sqrt_hann_window(cfg.fft_size, cfg.hop_size), dtype=torch.float32, device=self.device)
         basis = slaney_mel_basis(cfg.sample_rate, cfg.fft_size, cfg.num_mels, cfg.fmin, cfg.fmax)
         self.basis_t = torch.tensor(np.ascontiguousarray(basis.T), dtype=torch.float32, device=self.device)   # [bins][mels]
+        # support of every band (the triangles are a few bins wide): what viai_stft_mel_banded reads instead of all fft/2 + 1 bins
+        nz = basis.astype(np.float32) != 0
+        lo = np.where(nz.any(1), nz.argmax(1), 0)
+        hi = np.where(nz.any(1), nz.shape[1] - nz[:, ::-1].argmax(1), 0)
+        self.band_lo = torch.tensor(lo, dtype=torch.int32, device=self.device)
+        self.band_cnt = torch.tensor(hi - lo, dtype=torch.int32, device=self.device)
 
     def num_frames(self, n_samples):
         return lws_num_frames(n_samples, self.cfg.fft_size, self.cfg.hop_size)
@@ -85,10 +91,16 @@ class MelFrontEnd:
         m = None
         if mask is not None:
             m = mask.reshape(B, frames).contiguous().float()
-        _lib.check(lib.viai_stft_mel(wav.data_ptr(), self.window.data_ptr(), self.basis_t.data_ptr(),
-                                     0 if m is None else m.data_ptr(), out.data_ptr(), B, n, c.fft_size, c.hop_size,
-                                     c.num_mels, frames, float(c.min_level_db), float(c.ref_level_db),
-                                     torch.cuda.current_stream().cuda_stream), "viai_stft_mel")
+        st = torch.cuda.current_stream().cuda_stream
+        if c.fft_size == 1024 and not getattr(self, "force_dense", False):
+            _lib.check(lib.viai_stft_mel_banded(wav.data_ptr(), self.window.data_ptr(), self.basis_t.data_ptr(), self.band_lo.data_ptr(),
+                                                self.band_cnt.data_ptr(), 0 if m is None else m.data_ptr(), out.data_ptr(), B, n, c.fft_size,
+                                                c.hop_size, c.num_mels, frames, float(c.min_level_db), float(c.ref_level_db), st),
+                       "viai_stft_mel_banded")
+        else:
+            _lib.check(lib.viai_stft_mel(wav.data_ptr(), self.window.data_ptr(), self.basis_t.data_ptr(),
+                                         0 if m is None else m.data_ptr(), out.data_ptr(), B, n, c.fft_size, c.hop_size,
+                                         c.num_mels, frames, float(c.min_level_db), float(c.ref_level_db), st), "viai_stft_mel")
         return out
 
 
