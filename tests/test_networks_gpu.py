@@ -9,7 +9,11 @@ pytestmark = pytest.mark.gpu
 from oracle import viai_oracle as O
 
 TOL_FWD = 1e-4      # forward tensors (north star: 1e-3 relative fp32)
-TOL_GRAD = 3e-2     # vs the reference's fp32 gradients, which themselves sit 1.4e-2 from the fp64 truth at cfg1
+# Gradient digests vs the reference's fp32 gradients.  Measured on MI355X (tools/grad_margins.py, round 2): worst norm error 2.0e-4
+# (tiny), 8.1e-4 (cfg 1), 1.35e-3 (cfg 2); worst 64-sample-vector error 3.7e-3.  Two fp32 evaluations of these gradients (oracle vs
+# reference, both torch CPU) differ by 3e-3 .. 5e-3 themselves, so the bounds sit at that level, not an order of magnitude above it.
+TOL_GRAD = 5e-3
+TOL_GRAD_SAMPLES = 1.5e-2
 
 
 def relerr(a, b):
@@ -40,7 +44,8 @@ def to64(sd):
 
 def check_against_oracle(model, ocap, dcap, oE, oG, oD):
     """Parity criterion for gradients: against an fp64 run of the oracle ("truth"), the HIP path must be
-    as accurate as the reference's fp32 CPU arithmetic is (factor 4 + a floor).  Backprop through
+    as accurate as the reference's fp32 CPU arithmetic is (factor 4 + a floor of 1.5e-3 per network / 3e-3 per tensor -- round 1
+    had 5e-3 / 1e-2 there, an order of magnitude above what the kernels deliver; a 1 % systematic gradient error now fails).  Backprop through
     ~45 conv+BN(train) layers and BCE-on-probabilities amplifies fp32 rounding to 1e-3..2e-2 relative in
     ANY fp32 implementation (oracle-vs-reference differ by 3e-3 at cfg1), and the objective's gradient is
     DISCONTINUOUS: one ReLU/LeakyReLU pre-activation or one L1 residual within rounding noise of zero flips
@@ -64,14 +69,14 @@ def check_against_oracle(model, ocap, dcap, oE, oG, oD):
                 assert float(g.abs().max()) < 1e-4
                 continue
             e_hip, e_o32 = relerr(g, truth), relerr(ocap[grp][k], truth)
-            assert e_hip < 4 * e_o32 + 1e-2, (grp, k, e_hip, e_o32)
+            assert e_hip < 4 * e_o32 + 3e-3, (grp, k, e_hip, e_o32)       # measured worst e_hip - 4 e_o32: 7.2e-4 (cfg 1, D.norm_2.bias)
             n_hip += (g.detach().cpu().double() - truth).pow(2).sum().item()
             n_o32 += (ocap[grp][k].double() - truth).pow(2).sum().item()
             den += truth.pow(2).sum().item()
         e_hip, e_o32 = (n_hip / den) ** 0.5, (n_o32 / den) ** 0.5
         report[grp] = (e_hip, e_o32)
-        assert e_hip < 4 * e_o32 + 5e-3, (grp, e_hip, e_o32)
-        assert e_hip < 2e-2, (grp, e_hip)
+        assert e_hip < 4 * e_o32 + 1.5e-3, (grp, e_hip, e_o32)           # measured: 7.8e-4 / 2.3e-3 / 2.2e-3 (D / E / G at cfg 1)
+        assert e_hip < 8e-3, (grp, e_hip)
     for mod, osd in ((model.Mel_Encoder, oE), (model.Mel_Decoder, oG), (model.netD, oD)):
         for k, v in mod.state_dict().items():
             if k.endswith("num_batches_tracked"):
@@ -125,7 +130,7 @@ def test_step_no_update_matches_oracle_and_golden(shape, golden_dir):
             ref = gold[gk]
             # digest = [sum, abs-sum, l2, 64 samples]: compare the norms and the sample vector
             assert abs(dg[2] - ref[2]) < TOL_GRAD * ref[2], (gk, dg[2], ref[2])
-            assert np.linalg.norm(dg[3:] - ref[3:]) < 2 * TOL_GRAD * (np.linalg.norm(ref[3:]) + 1e-12), gk
+            assert np.linalg.norm(dg[3:] - ref[3:]) < TOL_GRAD_SAMPLES * (np.linalg.norm(ref[3:]) + 1e-12), gk
     for mod, nm in ((model.Mel_Encoder, "E"), (model.Mel_Decoder, "G"), (model.netD, "D")):
         for k, v in mod.state_dict().items():
             if "running_" in k:
@@ -186,7 +191,7 @@ def test_step_no_update_matches_reference_golden_at_benchmark_size(golden_dir):
             worst[grp] = max(worst.get(grp, 0.0), en)
             # the reference's own fp32 gradients sit ~5e-3 from a second fp32 evaluation at this size (tools/make_goldens.py)
             assert en < TOL_GRAD, (gk, en)
-            assert es < 2 * TOL_GRAD, (gk, es)
+            assert es < TOL_GRAD_SAMPLES, (gk, es)
     print("cfg2 worst gradient-norm digests vs reference:", worst)
 
 
