@@ -266,6 +266,11 @@ int viai_adam_step(float* p, const float* g, float* m, float* v, long n, double*
 int viai_colsum_blocks(long M, int C);
 int viai_colsum(const float* x, long M, int C, float* part, float* out, int accumulate, void* stream);
 
+/* Debug aid for the f16x2 conv arithmetic (operands are pre-scaled by powers of two and SATURATE beyond the fp16 range:
+ * activations above 65504 / 16 ~ 4094, weights above 65504 / 256 ~ 255): counts[0] += #{|x_i| > limit},
+ * counts[1] = max(counts[1], bit pattern of max |x_i|), counts[2] += #{non-finite x_i}.  counts: 3 zero-initialised uint32. */
+int viai_range_count(const float* x, long n, float limit, unsigned* counts, void* stream);
+
 /* y = a*x + y (flat); used for gradient accumulation on arenas */
 int viai_axpy(float a, const float* x, float* y, long n, void* stream);
 

@@ -544,3 +544,32 @@ def test_f16x2_backward_is_fp32_grade_at_any_gradient_scale(gscale):
     zg.backward(nhwc(gy))
     for nm, h, c32, t in zip(("dx", "dw"), (nchw(xg.grad), wg.grad), cpu32, truth):
         assert relerr(h, t) < 5 * relerr(c32, t) + 1e-6, (gscale, nm, relerr(h, t), relerr(c32, t))
+
+
+def test_f16x2_range_guard_counts_saturating_operands():
+    """debug mode (VIAI_DEBUG_RANGE / ops.DEBUG_RANGE): conv inputs beyond the fp16 range of the pre-scaled f16x2 operands are counted
+    (and refused in strict mode) instead of being clipped silently."""
+    from viai_amd import ops
+    x = O.cf_uniform("rg.x", (1, 16, 16, 32), -1, 1).cuda()
+    x[0, 3, 4, 5] = 5000.0                       # > 65504 / 16
+    x[0, 7, 7, 7] = -4200.0
+    w = O.cf_std("rg.w", (32, 32, 3, 3), 0.05).cuda()
+    w[1, 2, 0, 0] = 300.0                        # > 65504 / 256
+    old, olds = ops.DEBUG_RANGE, ops.DEBUG_RANGE_STRICT
+    try:
+        ops.DEBUG_RANGE, ops.DEBUG_RANGE_STRICT = True, False
+        ops.range_report()
+        y = ops.conv_bn_act(x, w, None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
+        assert torch.isfinite(y).all()                                  # saturates, no NaN
+        rep = ops.range_report()
+        assert rep["activation"][0] == 2 and rep["activation"][1] == 5000.0 and rep["activation"][2] == 0
+        assert rep["weight"][0] == 1 and rep["weight"][1] == 300.0
+        ops.conv_bn_act(x.clamp(-1, 1), w.clamp(-1, 1), None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
+        rep = ops.range_report()
+        assert rep["activation"][0] == 0 and rep["weight"][0] == 0
+        ops.DEBUG_RANGE_STRICT = True
+        with pytest.raises(FloatingPointError):
+            ops.conv_bn_act(x, w.clamp(-1, 1), None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
+    finally:
+        ops.DEBUG_RANGE, ops.DEBUG_RANGE_STRICT = old, olds
+        ops.range_report()

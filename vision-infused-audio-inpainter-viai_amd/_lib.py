@@ -122,6 +122,7 @@ SIGNATURES = {
     "viai_colsum_blocks": (_I, [_L, _I]),
     "viai_colsum": (_I, [_P, _L, _I, _P, _P, _I, _P]),
     "viai_axpy": (_I, [_F, _P, _P, _L, _P]),
+    "viai_range_count": (_I, [_P, _L, _F, _P, _P]),
     "viai_stft_mel": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "viai_stft_mel_banded": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "viai_conv2d_pack_job": (_I, [_CP, _I, _P, _P, C.POINTER(PackJob)]),

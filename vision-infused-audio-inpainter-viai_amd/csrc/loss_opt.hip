@@ -144,6 +144,33 @@ extern "C" int viai_adam_step(float* p, const float* g, float* m, float* v, long
     return viai_launch_status();
 }
 
+// debug aid for the f16x2 conv path: counts[0] += #{ |x_i| > limit }, counts[1] = max(counts[1], bits(max |x_i|)), counts[2] += #{non-finite}
+namespace {
+__global__ __launch_bounds__(256) void range_count_kernel(const float* __restrict__ x, long n, float limit, unsigned* __restrict__ counts) {
+    unsigned over = 0, bad = 0;
+    float mx = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const float a = fabsf(x[i]);
+        if (!(a <= 3.4e38f)) ++bad; else { mx = fmaxf(mx, a); if (a > limit) ++over; }
+    }
+    over = (unsigned)wave_sum((float)over); bad = (unsigned)wave_sum((float)bad);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        if (over) atomicAdd(&counts[0], over);
+        if (mx > 0.f) atomicMax(&counts[1], __float_as_uint(mx));
+        if (bad) atomicAdd(&counts[2], bad);
+    }
+}
+}  // namespace
+
+extern "C" int viai_range_count(const float* x, long n, float limit, unsigned* counts, void* stream) {
+    if (n <= 0) return 0;
+    long b = (n + 255) / 256; if (b > 1024) b = 1024;
+    VIAI_LAUNCH(range_count_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, x, n, limit, counts);
+    return viai_launch_status();
+}
+
 extern "C" int viai_axpy(float a, const float* x, float* y, long n, void* stream) {
     VIAI_LAUNCH(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, x, y, n);
     return viai_launch_status();

@@ -44,6 +44,39 @@ F16_BACKWARD = os.environ.get("VIAI_F16_BACKWARD", "1") != "0"     # f16x2 data 
 GRAD_HOOKS = {}
 
 
+# f16x2 range guard (debug mode, VIAI_DEBUG_RANGE=1 or ops.DEBUG_RANGE = True).  The f16x2 conv kernels pre-scale their operands by
+# powers of two and saturate beyond the fp16 range: activations with |x| > 65504 / 16 and weights with |w| > 65504 / 256 would be
+# clipped silently.  In debug mode every conv input and weight is scanned (one extra streaming pass each) and range_report() tells
+# how many elements were outside; `strict` raises at the offending layer (costs a host sync per layer).
+DEBUG_RANGE = os.environ.get("VIAI_DEBUG_RANGE", "0") not in ("0", "")
+DEBUG_RANGE_STRICT = os.environ.get("VIAI_DEBUG_RANGE", "0") == "strict"
+F16_ACT_LIMIT, F16_WEIGHT_LIMIT = 65504.0 / 16.0, 65504.0 / 256.0
+_range_counts = {}
+
+
+def _range_scan(kind, t, limit):
+    c = _range_counts.get((kind, t.device))
+    if c is None:
+        c = _range_counts[(kind, t.device)] = torch.zeros(3, dtype=torch.int32, device=t.device)
+    _lib.check(_lib.load().viai_range_count(t.data_ptr(), t.numel(), limit, c.data_ptr(), _stream()), "viai_range_count")
+    if DEBUG_RANGE_STRICT and int(c[0]) + int(c[2]) > 0:
+        raise FloatingPointError("f16x2 range guard: %s tensor of shape %s has %d element(s) beyond +-%.0f and %d non-finite; "
+                                 "run with VIAI_F16X2=0 (bf16x3 has the fp32 exponent range)" % (kind, tuple(t.shape), int(c[0]), limit, int(c[2])))
+
+
+def range_report(reset=True):
+    """{'activation': (n_saturating, max_abs, n_nonfinite), 'weight': (...)} accumulated since the last reset (host sync)."""
+    out = {}
+    for (kind, _dev), c in _range_counts.items():
+        v = c.cpu()
+        mx = float(v[1:2].view(torch.float32)[0])
+        a = out.get(kind, (0, 0.0, 0))
+        out[kind] = (a[0] + int(v[0]), max(a[1], mx), a[2] + int(v[2]))
+        if reset:
+            c.zero_()
+    return out
+
+
 def join_wgrad():
     """main stream waits for every deferred weight-gradient launch; call before the gradients are consumed."""
     if WGRAD_STREAM is not None and _deferred:
@@ -289,6 +322,11 @@ class _ConvBnAct(torch.autograd.Function):
         dev = x.device
         OH, OW = d["OH"], d["OW"]
         M = N * OH * OW
+        if DEBUG_RANGE:
+            _range_scan("activation", x, F16_ACT_LIMIT)
+            if x2 is not None:
+                _range_scan("activation", x2, F16_ACT_LIMIT)
+            _range_scan("weight", weight, F16_WEIGHT_LIMIT)
         wp = _packed(weight, d, 0, st)
         has_bn = gamma is not None
         act = cfg["act"]
