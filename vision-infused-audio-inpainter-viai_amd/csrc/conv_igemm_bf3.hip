@@ -839,7 +839,8 @@ __device__ __forceinline__ void pack_planar16_body(const float* __restrict__ w, 
     const long total = (long)n_out * taps * k_in;
     for (long i = blk * (long)blockDim.x + threadIdx.x; i < total; i += (long)nblk * blockDim.x) {
         int ki = (int)(i % k_in); long r = i / k_in; int t = (int)(r % taps); int no = (int)(r / taps);
-        const float x = w[no * s_no + ki * s_ki + t] * F16_WSCALE;
+        // weights beyond the fp16 range of the scaled operand (|w| > 65504 / 256) saturate, like the activations, instead of becoming inf - inf
+        const float x = __builtin_amdgcn_fmed3f(w[no * s_no + ki * s_ki + t] * F16_WSCALE, -65504.f, 65504.f);
         const _Float16 h1 = (_Float16)x;
         const _Float16 h2 = (_Float16)(x - (float)h1);
         wp[i] = __builtin_bit_cast(unsigned short, h1); wp[total + i] = __builtin_bit_cast(unsigned short, h2);
@@ -855,7 +856,7 @@ __device__ __forceinline__ void pack_frag16_body(const float* __restrict__ w, un
         int e = (int)(i & 7); int lane = (int)((i >> 3) & 63); long r = i >> 9;
         int kq = (int)(r % k16); r /= k16; int t = (int)(r % taps); int nt = (int)(r / taps);
         int no = nt * 32 + (lane & 31), ki = kq * 16 + (lane >> 5) * 8 + e;
-        float x = (no < n_out) ? w[no * s_no + ki * s_ki + t] * F16_WSCALE : 0.f;
+        float x = (no < n_out) ? __builtin_amdgcn_fmed3f(w[no * s_no + ki * s_ki + t] * F16_WSCALE, -65504.f, 65504.f) : 0.f;   // saturate (see above)
         _Float16 h1 = (_Float16)x;
         _Float16 h2 = (_Float16)(x - (float)h1);
         wp[i] = __builtin_bit_cast(unsigned short, h1); wp[plane + i] = __builtin_bit_cast(unsigned short, h2);
