@@ -253,7 +253,7 @@ class KernelTimer:
             f, n = fam_wgrad(d)
             oh, ow = out_hw(d)
             s1 = (d.sh, d.sw) == (1, 1)
-            s2 = (d.sh, d.sw) == (2, 2) and not d.transposed and os.environ.get("VIAI_WGRAD_PATCH_S2", "0") not in ("0", "")
+            s2 = (d.sh, d.sw) == (2, 2) and not d.transposed and os.environ.get("VIAI_WGRAD_PATCH_S2", "1") != "0"
             bn = 64 if s1 else 32
             if (f == "wgrad_bf3" and os.environ.get("VIAI_WGRAD_PATCH", "1") != "0" and (d.kh, d.kw) == (3, 3) and (s1 or s2)
                     and d.Cout % 128 == 0 and d.C1 % bn == 0 and d.C2 % bn == 0 and oh % 8 == 0 and ow % 16 == 0

@@ -129,10 +129,10 @@ def _worst_tile(a, b, th=8, tw=16):
 
 
 @pytest.mark.parametrize("case", [c for c in FULL_LAYERS + MORE_LAYERS if c[7] == (2, 2) and c[5] % 128 == 0 and c[4] >= 64],
-                         ids=lambda c: c[0].split(" (")[0] + " [patch wgrad]")
-def test_full_size_stride2_layers_with_the_opt_in_patch_weight_gradient(case, monkeypatch):
-    """the stride-2 instance of conv_wgrad_patch.hip (VIAI_WGRAD_PATCH_S2=1, off by default) at the benchmark shapes"""
-    monkeypatch.setenv("VIAI_WGRAD_PATCH_S2", "1")
+                         ids=lambda c: c[0].split(" (")[0] + " [wgrad_bf3]")
+def test_full_size_stride2_layers_without_the_patch_weight_gradient(case, monkeypatch):
+    """VIAI_WGRAD_PATCH_S2=0: the stride-2 layers fall back to wgrad_bf3_kernel (the round-1 kernel stays covered at the benchmark shapes)"""
+    monkeypatch.setenv("VIAI_WGRAD_PATCH_S2", "0")
     test_full_size_layer_values_against_fp64(case, True)
 
 

@@ -118,28 +118,43 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int xq = tid % C::XQ, xp0 = tid / C::XQ;
 
     u32x4 draw[ND], xraw[NX];
-    auto gload = [&](int s_) {
+    // origin of stage s (uniform): image n, first output row / column, byte offset of the dy rows; a stage past the end is "dead"
+    // (every load of it is pushed out of range and returns zeros that nobody stores)
+    int g_n = 0, g_iy0 = 0, g_ix0 = 0, g_dbase = 0, g_dead = 0;
+    auto gstage = [&](int s_) {
         const int s = __builtin_amdgcn_readfirstlane(s_);
-        const int tile = tile0 + s / SPT, h = s % SPT;
-        const int tx = tile % tiles_x; const int r_ = tile / tiles_x; const int ty = r_ % tiles_y, n = r_ / tiles_y;
+        g_dead = s < nst ? 0 : OOB;
+        const int sc = s < nst ? s : 0;
+        const int tile = tile0 + sc / SPT, h = sc % SPT;
+        const int tx = tile % tiles_x; const int r_ = tile / tiles_x; const int ty = r_ % tiles_y;
+        g_n = r_ / tiles_y;
         const int oy0 = ty * WP_TH + h * HR, ox0 = tx * WP_TW;
-        const int dbase = ((n * g.OH + oy0) * g.OW + ox0) * a.Cout * 4;
+        g_dbase = ((g_n * g.OH + oy0) * g.OW + ox0) * a.Cout * 4;
+        g_iy0 = oy0 * S + y0; g_ix0 = ox0 * S + x0;
+    };
+    // item `it` (dy items first, then x items; compile-time index) of the stage set by gstage()
+    auto gload_item = [&](int it) {
 #pragma unroll
-        for (int j = 0; j < ND; ++j) {
-            constexpr int dummy = 0; (void)dummy;
-            const int row = (PJ * j) >> 4, dcol = (PJ * j) & 15;                 // dp0 < PJ <= 16: pixel dp0 + PJ j = (row, dp0 + dcol)
-            draw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, d_goff + (row * g.OW + dcol) * a.Cout * 4, dbase, 0);
-        }
-        const int iy0 = oy0 * S + y0, ix0 = ox0 * S + x0;
+        for (int j = 0; j < ND; ++j)
+            if (it == j) {
+                const int row = (PJ * j) >> 4, dcol = (PJ * j) & 15;                 // dp0 < PJ <= 16: pixel dp0 + PJ j = (row, dp0 + dcol)
+                draw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (d_goff + (row * g.OW + dcol) * a.Cout * 4) | g_dead, g_dead ? 0 : g_dbase, 0);
+            }
 #pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            const int pp = xp0 + C::XPP * j;
-            const int ppr = S == 1 ? (pp * 3641) >> 16 : (pp * 1986) >> 16;          // pp / PW (PW = 18: pp < 128; PW = 33: pp < 200)
-            const int iy = iy0 + ppr, ix = ix0 + pp - ppr * C::PW;
-            const int dead = (((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | (C::XPIX - 1 - pp)) >> 31) & OOB;
-            const int off = ((((n * g.IH + iy) * g.IW + ix) * xcs + xoff + xq * 4) * 4) | dead;
-            xraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
-        }
+        for (int j = 0; j < NX; ++j)
+            if (it == ND + j) {
+                const int pp = xp0 + C::XPP * j;
+                const int ppr = S == 1 ? (pp * 3641) >> 16 : (pp * 1986) >> 16;      // pp / PW (PW = 18: pp < 128; PW = 33: pp < 200)
+                const int iy = g_iy0 + ppr, ix = g_ix0 + pp - ppr * C::PW;
+                const int dead = ((((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | (C::XPIX - 1 - pp)) >> 31) & OOB) | g_dead;
+                const int off = ((((g_n * g.IH + iy) * g.IW + ix) * xcs + xoff + xq * 4) * 4) | dead;
+                xraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+            }
+    };
+    auto gload = [&](int s_) {
+        gstage(s_);
+#pragma unroll
+        for (int it = 0; it < ND + NX; ++it) gload_item(it);
     };
     // LDS byte offset (within an x plane) of this thread's x item j.  Stride 1: affine in j.  Stride 2: recomputed at the store (a few
     // integer instructions per item and stage) rather than held in NX registers next to 144 accumulators.
@@ -225,26 +240,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
 
-    // Loads run a whole stage ahead of their LDS stores: the registers of stage s + 1 are split / stored during the k-steps of stage s,
-    // and re-filled with stage s + 2 right after the last store, so a load has a barrier and most of a stage to land.
+    // Pipeline.  LDS holds two stages: stage s is multiplied while stage s + 1 is split / stored into the other buffer, one staging unit per
+    // gap between taps.  The registers that carried an item of stage s + 1 are re-loaded with the same item of stage s + 2 THE MOMENT it
+    // has been stored, so every global load has a full stage (and a barrier) to land before its turn comes round again -- issuing all
+    // loads of a stage together at its end left them one barrier of slack and cost a global-memory latency per stage.
     if (nst > 0) {
         gload(0);
 #pragma unroll
         for (int U = 0; U < 2 * (ND + NX); ++U) lstore_unit(0, U);
-        if (nst > 1) gload(1);
+        gload(1);
     }
     __syncthreads();
     for (int s = 0; s + 1 < nst; ++s) {
         const unsigned char* Sb = smem_p + (s & 1) * STAGE;
+        gstage(s + 2);
 #pragma unroll
         for (int r = 0; r < HR; ++r)
             kstep(Sb, r, [&](int t) {
-                // the UPK staging units of this k-step, dealt over the nine gaps in order
+                // the UPK staging units of this k-step, dealt over the nine gaps in order; a finished item is re-loaded at once
 #pragma unroll
                 for (int u = 0; u < C::UPK; ++u)
-                    if ((u * 9) / C::UPK == t) lstore_unit((s & 1) ^ 1, r * C::UPK + u);
+                    if ((u * 9) / C::UPK == t) {
+                        const int U = r * C::UPK + u;
+                        lstore_unit((s & 1) ^ 1, U);
+                        if (U & 1) gload_item(U >> 1);
+                    }
             });
-        if (s + 2 < nst) gload(s + 2);
         __syncthreads();
     }
     if (nst > 0) {                                  // last stage: nothing left to stage
@@ -302,10 +323,10 @@ static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hi
 // not straddle the two concatenated sources), output extent a multiple of the 8 x 16 tile and enough tiles to give every block a K
 // loop worth its prologue / epilogue.  `shape_ok` is the pure shape predicate (workspace sizing); `ok` adds the switches.
 //
-// The stride-2 instance is OFF by default (VIAI_WGRAD_PATCH_S2=1 enables it): alone it is 1.2-1.6x faster than wgrad_bf3_kernel
-// (D.conv2_1 261 -> 159 us, D.conv2_2 163 -> 133 us), but in the three-stream step the weight gradients run beside the main
-// backward chain, and two of its blocks take a CU's whole LDS and register file: same-box A/B of the full step 8.39 ms without it,
-// 8.60 ms with it (8.56 ms with neither patch kernel).  The stride-1 instance (one 8-wave block per CU) does pay: 8.56 -> 8.39 ms.
+// Same-box A/B of the full three-stream step (the weight gradients run beside the main backward chain, so a kernel that is faster alone
+// but takes a CU's whole LDS / register file can still lose): neither patch kernel 8.69 ms, stride-1 instance only 8.54, both with two
+// stride-2 blocks per CU 8.45, both with ONE stride-2 block per CU (256 blocks) 8.37 -- the default.  VIAI_WGRAD_PATCH_S2=0 switches the
+// stride-2 instance off.
 bool viai_wgrad_patch_shape_ok(const ConvGeom& g, int Cout, int C1, int C2) {
     if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2)) return false;
     const int bn = bn_of(g);
@@ -319,7 +340,7 @@ bool viai_wgrad_patch_ok(const ConvGeom& g, int Cout, int C1, int C2) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("VIAI_WGRAD_PATCH"); on = e ? atoi(e) : 1; }
     if (!on) return false;
-    if (g.my == 2) { const char* e = getenv("VIAI_WGRAD_PATCH_S2"); if (!(e && atoi(e))) return false; }     // read per call: tests switch it
+    if (g.my == 2) { const char* e = getenv("VIAI_WGRAD_PATCH_S2"); if (e && !atoi(e)) return false; }       // read per call: tests switch it
     return viai_wgrad_patch_shape_ok(g, Cout, C1, C2);
 }
 
@@ -329,7 +350,7 @@ int viai_wgrad_patch_ksplit(const ConvGeom& g, int Cout, int Cin) {
     const long per = (long)(Cout / WP_BM) * (Cin / bn_of(g));
     static long blk1 = -1, blk2 = -1;
     if (blk1 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS"); blk1 = e ? atol(e) : 256; }
-    if (blk2 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_S2"); blk2 = e ? atol(e) : 512; }
+    if (blk2 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_S2"); blk2 = e ? atol(e) : 256; }
     long ks = (g.my == 2 ? blk2 : blk1) / per;
     if (ks > tiles / 4) ks = tiles / 4;
     if (ks < 1) ks = 1;
