@@ -40,9 +40,10 @@ DOMINANT = ("conv_igemm_bf3_frag_kernel<3,2,2,2,2> (128x128x32 bf16x3 split-MFMA
 
 # kernel behind each launch family of KernelTimer (the mirror predicates above decide the family of a call)
 FAMILY_KERNELS = {
-    "wgrad_patch_f16x2": "wgrad_patch_f16_kernel<1,64,4,8> (csrc/conv_wgrad_patch.hip: weight gradient of the stride-1 3x3 layers with >= 128 x 64 channels; all nine taps per block, "
+    "wgrad_patch_f16x2": "wgrad_patch_f16_kernel<1,128,64,4,1> (csrc/conv_wgrad_patch.hip: weight gradient of the stride-1 3x3 layers with >= 128 x 64 channels; all nine taps per block, "
                          "dy rows + x patch staged once per 64 pixels as [pixel][channel] fp16 planes, MFMA operands through ds_read_b64_tr_b16; f16x2 split)",
-    "wgrad_patch_s2_f16x2": "wgrad_patch_f16_kernel<2,32,2,4> (the stride-2 instance: 128 x 32 channel tile, input patch as four parity sub-patches, 2 blocks / CU)",
+    "wgrad_patch_narrow_f16x2": "wgrad_patch_f16_kernel<1,32,32,4,4> (the narrow instance: 32 x 32 channel tile, four waves split the tile rows of a stage and write one split-K slab each)",
+    "wgrad_patch_s2_f16x2": "wgrad_patch_f16_kernel<2,128,32,2,1> (the stride-2 instance: 128 x 32 channel tile, input patch as four parity sub-patches, 2 blocks / CU)",
     "wgrad_bf3_f16x2": "wgrad_bf3_kernel<2,TM,TN> (csrc/conv_wgrad_bf3.hip: weight gradient, one block per tap x Cout tile x Cin tile, tiles transposed into LDS; f16x2 split)",
     "wgrad_bf3": "wgrad_bf3_kernel<3,TM,TN> (bf16x3 weight gradient)",
     "wgrad_mfma": "wgrad_mfma_kernel<*> (exact fp32 MFMA weight gradient, <= 32-channel layers)",
@@ -60,7 +61,7 @@ FAMILY_KERNELS = {
     "igemm128x128_f16x2": "conv_igemm_bf3_frag_kernel<2,2,2,2,2> (128x128x32 f16x2 gather-GEMM conv)",
     "igemm128x128": "conv_igemm_bf3_frag_kernel<3,2,2,2,2> (128x128x32 bf16x3 gather-GEMM conv)",
 }
-PMC_KERNEL_OF = {"wgrad_patch_f16x2": "wgrad_patch_f16_kernel<1", "wgrad_patch_s2_f16x2": "wgrad_patch_f16_kernel<2", "wgrad_bf3_f16x2": "wgrad_bf3_kernel", "halo_wide256_f16x2": "conv_halo_wide_f16_kernel",
+PMC_KERNEL_OF = {"wgrad_patch_f16x2": "wgrad_patch_f16_kernel<1, 128", "wgrad_patch_s2_f16x2": "wgrad_patch_f16_kernel<2", "wgrad_patch_narrow_f16x2": "wgrad_patch_f16_kernel<1, 32", "wgrad_bf3_f16x2": "wgrad_bf3_kernel", "halo_wide256_f16x2": "conv_halo_wide_f16_kernel",
                  "halo_wide128_f16x2": "conv_halo_wide_f16_kernel", "igemm128x256_f16x2": "frag_kernel<2, 2, 2, 2, 4", "igemm128x128_f16x2": "frag_kernel<2", "igemm128x128": "frag_kernel<3"}
 
 
@@ -252,13 +253,19 @@ class KernelTimer:
         def fam_wgrad_f16(d):
             f, n = fam_wgrad(d)
             oh, ow = out_hw(d)
+            # mirror of pick() in csrc/conv_wgrad_patch.hip
             s1 = (d.sh, d.sw) == (1, 1)
             s2 = (d.sh, d.sw) == (2, 2) and not d.transposed and os.environ.get("VIAI_WGRAD_PATCH_S2", "1") != "0"
-            bn = 64 if s1 else 32
-            if (f == "wgrad_bf3" and os.environ.get("VIAI_WGRAD_PATCH", "1") != "0" and (d.kh, d.kw) == (3, 3) and (s1 or s2)
-                    and d.Cout % 128 == 0 and d.C1 % bn == 0 and d.C2 % bn == 0 and oh % 8 == 0 and ow % 16 == 0
-                    and d.N * (oh // 8) * (ow // 16) >= 64):
-                return ("wgrad_patch_f16x2" if s1 else "wgrad_patch_s2_f16x2"), n        # mirror of viai_wgrad_patch_ok (csrc/conv_wgrad_patch.hip)
+            if (os.environ.get("VIAI_WGRAD_PATCH", "1") != "0" and (d.kh, d.kw) == (3, 3) and (s1 or s2) and oh % 8 == 0 and ow % 16 == 0
+                    and d.N * (oh // 8) * (ow // 16) >= 64 and f not in ("direct",)):
+                def tiles_ok(bm, bn):
+                    return d.Cout % bm == 0 and d.C1 % bn == 0 and d.C2 % bn == 0 and d.C1 >= bn
+                if s2 and tiles_ok(128, 32):
+                    return "wgrad_patch_s2_f16x2", n
+                if s1 and tiles_ok(128, 64):
+                    return "wgrad_patch_f16x2", n
+                if s1 and tiles_ok(32, 32) and os.environ.get("VIAI_WGRAD_PATCH_NARROW", "1") != "0":
+                    return "wgrad_patch_narrow_f16x2", n
             return f + "_f16x2", n
 
         wrap("viai_conv2d_dgrad_f16", fam_dgrad_f16)

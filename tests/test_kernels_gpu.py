@@ -160,12 +160,15 @@ def test_patch_staged_stride2_dgrad_against_fp64():
     assert relerr(wg.grad, wd.grad) < 3e-6
 
 
-@pytest.mark.parametrize("cfg", [(1, 128, 0, 256, False), (1, 64, 64, 128, True), (2, 64, 0, 128, False), (2, 96, 0, 256, False)],
-                         ids=["s1_128to256", "s1_cat64+64to128_T", "s2_64to128", "s2_96to256"])
+@pytest.mark.parametrize("cfg", [(1, 128, 0, 256, False), (1, 64, 64, 128, True), (2, 64, 0, 128, False), (2, 96, 0, 256, False),
+                                 (1, 32, 0, 32, True), (1, 64, 64, 32, True), (1, 64, 0, 64, False), (1, 96, 0, 160, True)],
+                         ids=["s1_128to256", "s1_cat64+64to128_T", "s2_64to128", "s2_96to256",
+                              "narrow_32to32_T", "narrow_cat64+64to32_T", "narrow_64to64", "narrow_96to160_T"])
 def test_patch_staged_weight_gradient_against_fp64(cfg):
     """conv_wgrad_patch.hip (all nine taps per block, fragments through ds_read_b64_tr_b16): weight gradient of 3 x 3 layers with
     Cout % 128 == 0 behind an eval-mode BatchNorm (the abs-max-scaled f16x2 path), stride 1 (plain and transposed, one and two
-    concatenated sources: 128 x 64 tile, eight waves) and stride 2 (128 x 32 tile, parity sub-patches), 2 x (64 x 64 output) = 64 tiles;
+    concatenated sources: 128 x 64 tile, eight waves; narrow layers: 32 x 32 tile whose four waves split the tile rows and write a slab
+    each) and stride 2 (128 x 32 tile, parity sub-patches), 2 x (64 x 64 output) = 64 tiles;
     gradients of constant-free random tensors against an fp64 evaluation."""
     from viai_amd import ops
     S, C1, C2, Co, tr = cfg

@@ -455,7 +455,7 @@ static int wgrad_ksplit(const viai_conv2d* c, long M) {
 }
 // the all-taps patch kernel (f16x2 launches of the stride-1 3 x 3 layers with >= 128 x 64 channels)
 static bool wgrad_patch(const viai_conv2d* c, bool shape_only = false) {
-    if (kind_of(c) != K_IGEMM || !f16x2_enabled() || !bf3_enabled() || !viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2)) return false;
+    if (kind_of(c) != K_IGEMM || !f16x2_enabled() || !bf3_enabled()) return false;
     ConvGeom g{}; viai_geom_fwd(c, &g);
     return shape_only ? viai_wgrad_patch_shape_ok(g, c->Cout, c->C1, c->C2) : viai_wgrad_patch_ok(g, c->Cout, c->C1, c->C2);
 }
@@ -477,7 +477,7 @@ extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
         int ks = wgrad_ksplit(c, M);
         if (wgrad_patch(c, true)) {                            // workspace covers every form the layer can take, whatever the switches say
             ConvGeom g{}; viai_geom_fwd(c, &g);
-            int kp = viai_wgrad_patch_ksplit(g, c->Cout, cin_of(c));
+            int kp = viai_wgrad_patch_ksplit(g, c->Cout, c->C1, c->C2);
             if (kp > ks) ks = kp;
         }
         fl = (size_t)ks * viai_conv2d_packed_floats(c);
@@ -499,7 +499,8 @@ extern "C" int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const flo
 // f16x2 weight gradient (layers on the bf16x3 wgrad kernel): dy scaled on the device from dy_amax = max |dy|, x by the
 // static activation scale; 1 from viai_conv2d_wgrad_f16_ok if the layer has this form
 extern "C" int viai_conv2d_wgrad_f16_ok(const viai_conv2d* c) {
-    return (valid(c) && kind_of(c) == K_IGEMM && f16x2_enabled() && bf3_enabled() && viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2)) ? 1 : 0;
+    // the layers of the f16x2 wgrad_bf3 kernel (> 32 channels on both sides) and every layer an instance of the patch kernel takes
+    return (valid(c) && kind_of(c) == K_IGEMM && f16x2_enabled() && bf3_enabled() && (viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2) || wgrad_patch(c))) ? 1 : 0;
 }
 extern "C" int viai_conv2d_wgrad_f16(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
                                      float* ws, float* dw, float* db, int accumulate, const float* dy_amax, void* stream) {
@@ -539,7 +540,7 @@ static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, con
         viai_geom_fwd(c, &a.g);
         int ks = wgrad_ksplit(c, M);
         const bool patch = amax != nullptr && wgrad_patch(c);
-        if (patch) ks = viai_wgrad_patch_ksplit(a.g, c->Cout, Cin);
+        if (patch) ks = viai_wgrad_patch_ksplit(a.g, c->Cout, c->C1, c->C2);
         used = (size_t)ks * viai_conv2d_packed_floats(c);
         e = patch ? viai_wgrad_patch_launch(a, st)
           : wgrad32(c) ? viai_wgrad32_launch(a, ks, st)

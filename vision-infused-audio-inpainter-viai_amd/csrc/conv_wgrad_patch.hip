@@ -16,9 +16,11 @@
 //   gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels] block, every lane receives
 //   the four pixels of ITS channel) -- two reads per 32 x 16 MFMA operand.
 //
-// Instances <S, BN, HR, NW>:
-//   <1, 64, 4, 8>  stride 1: 128 x 64 channel tile, 4 tile rows per stage, 8 waves (4 along Cout x 2 along Cin), two LDS stages, 1 block / CU
-//   <2, 32, 2, 4>  stride 2: a stride-2 layer reads a (2 HR + 1) x 33 input patch per HR x 16 output pixels (4.4x the pixels of the stride-1
+// Instances <S, BM, BN, HR, WK>  (BM x BN = Cout x Cin tile, HR tile rows per stage, WK = waves that split the k-steps of a stage):
+//   <1, 128, 64, 4, 1>  stride 1: 8 waves (4 along Cout x 2 along Cin), two LDS stages of 74 KB, 1 block / CU
+//   <1,  32, 32, 4, 4>  stride 1, narrow layers (the 32 / 64-channel layers of the generator): 4 waves that share ONE 32 x 32 tile and take
+//                       one tile row each; every wave writes its own split-K slab (the slab reduce adds them), 44 KB of LDS
+//   <2, 128, 32, 2, 1>  stride 2: a stride-2 layer reads a (2 HR + 1) x 33 input patch per HR x 16 output pixels (4.4x the pixels of the stride-1
 //                  case), so the Cin tile is 32 and a stage 2 tile rows; the patch is stored as four parity sub-patches
 //                  P[py][px][r][c] = patch(2 r + py, 2 c + px), so that the 16 pixels of a k-step are again 16 consecutive LDS rows for every
 //                  tap; 4 waves, 75 KB of LDS, 2 blocks / CU.
@@ -31,35 +33,40 @@
 
 namespace {
 
-constexpr int WP_BM = 128;                          // Cout tile of a block (4 waves x 32)
 constexpr int WP_TW = 16, WP_TH = 8;                // output pixel tile
-constexpr int WP_DROW = WP_BM * 2;                  // dy LDS row: 128 fp16 = 256 B, 64-byte groups XOR-swizzled by (pixel & 3)
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct WgPatchSlots { int s[9]; };
 
-template <int S, int BN, int HR, int NW>
+template <int S, int BM, int BN, int HR, int WK>
 struct WgCfg {
+    static constexpr int WMC = BM / 32, WN = BN / 32;               // waves along Cout / Cin
+    static constexpr int NW = WMC * WN * WK;
     static constexpr int NTHR = 64 * NW;
-    static constexpr int WN = BN / 32;                               // waves along Cin
+    static constexpr int KSW = HR / WK;                              // k-steps (tile rows) per wave and stage
     static constexpr int PW = S == 1 ? WP_TW + 2 : 2 * WP_TW + 1;    // x patch columns (input pixels)
     static constexpr int PH = S == 1 ? HR + 2 : 2 * HR + 1;          // x patch rows
     static constexpr int XPIX = PH * PW;
     static constexpr int SUBW = 17;                                  // S = 2: columns of a parity sub-patch
+    static constexpr int ROWSLOTS = S == 1 ? PW : SUBW;              // LDS slots between the windows of consecutive tile rows
     // S = 2 sub-patch bases (tight): (py, px) = (0,0): (HR + 1) rows, (0,1): (HR + 1), (1,0): HR, (1,1): HR
     static constexpr int XSLOTS = S == 1 ? XPIX : (4 * HR + 2) * SUBW;
     static constexpr int XPITCH = BN == 64 ? 192 : 64;               // 64 ch: +64 B pad; 32 ch: four 64-B rows are exactly one 256-B bank row
+    static constexpr int DROW = BM * 2;                              // dy LDS row: 128 ch = 256 B with the 64-byte groups XOR-swizzled by (pixel & 3); 32 ch = 64 B
     static constexpr int DPIX = HR * WP_TW;
-    static constexpr int DPLANE = DPIX * WP_DROW, XPLANE = XSLOTS * XPITCH;
+    static constexpr int DPLANE = DPIX * DROW, XPLANE = XSLOTS * XPITCH;
     static constexpr int STAGE = 2 * DPLANE + 2 * XPLANE;
     static constexpr int LDS = 2 * STAGE;
-    static constexpr int ND = DPIX * (WP_BM / 4) / NTHR;             // dy float4 items per thread and stage
+    static constexpr int DQ = BM / 4;                                // channel quads per dy pixel
+    static constexpr int PJ = NTHR / DQ;                             // dy pixels per staging pass
+    static constexpr int ND = DPIX / PJ;                             // dy float4 items per thread and stage
     static constexpr int XQ = BN / 4;                                // channel quads per x pixel
     static constexpr int XPP = NTHR / XQ;                            // x pixels per staging pass
     static constexpr int NX = (XPIX + XPP - 1) / XPP;                // x float4 items per thread and stage (last one partial)
-    static constexpr int UPK = 2 * (ND + NX) / HR;                   // staging units (half items) per k-step
-    static_assert(DPIX * (WP_BM / 4) % NTHR == 0 && (2 * (ND + NX)) % HR == 0 && NW / WN == 4, "config");
+    static constexpr int UPK = 2 * (ND + NX) / KSW;                  // staging units (half items) per k-step of a wave
+    static_assert((BM == 128 || BM == 32) && (BN == 64 || BN == 32) && HR % WK == 0 && DPIX % PJ == 0 && (PJ == 8 || PJ % 16 == 0)
+                  && (2 * (ND + NX)) % KSW == 0, "config");
     __host__ __device__ static constexpr int sub_base(int py, int px) {
         return S == 1 ? 0 : (py == 0 ? px * (HR + 1) * SUBW : 2 * (HR + 1) * SUBW + px * HR * SUBW);
     }
@@ -73,9 +80,10 @@ struct WgCfg {
     }
 };
 
-template <int S, int BN, int HR, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_patch_f16_kernel(const WgradArgs a, int y0, int x0, WgPatchSlots slots) {
-    using C = WgCfg<S, BN, HR, NW>;
+template <int S, int BM, int BN, int HR, int WK>
+__global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_patch_f16_kernel(const WgradArgs a, int y0, int x0, WgPatchSlots slots) {
+    using C = WgCfg<S, BM, BN, HR, WK>;
+    constexpr int WP_DROW = C::DROW, WP_BM = BM;
     constexpr int DPLANE = C::DPLANE, XPLANE = C::XPLANE, STAGE = C::STAGE, ND = C::ND, NX = C::NX, XPITCH = C::XPITCH;
     constexpr int SPT = WP_TH / HR;                          // stages per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];      // [2 stages]{dy plane 0, dy plane 1, x plane 0, x plane 1}
@@ -85,7 +93,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const float xscale = F16_ASCALE, xlim = 65504.f / F16_ASCALE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / C::WN, wn = wave % C::WN;          // 32 output channels x 32 input channels per wave
+    const int wk = wave / (C::WMC * C::WN), wrem = wave % (C::WMC * C::WN);
+    const int wm = wrem / C::WN, wn = wrem % C::WN;          // 32 output channels x 32 input channels per wave; wk: which k-steps of a stage
 
     int b = xcd_remap(blockIdx.x, gridDim.x);
     const int per_slab = a.nblk_ci * a.nblk_co;
@@ -109,11 +118,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int nst = (tile1 - tile0) * SPT;
 
     // ---- staging maps (thread -> items; everything but the stage origin is fixed per thread)
-    // dy: item j = stage pixel (tid >> 5) + (NTHR / 32) j, channel quad q = tid & 31
-    constexpr int PJ = C::NTHR / 32;
-    const int dq = tid & 31, dp0 = tid >> 5;
-    const int d_goff = (dp0 * a.Cout + co0 + dq * 4) * 4;
-    const int d_lds = dp0 * WP_DROW + (((dq >> 3) ^ (dp0 & 3)) * 64) + (dq & 7) * 8;         // + j * PJ * WP_DROW   (PJ % 4 == 0: same swizzle)
+    // dy: item j = stage pixel tid / DQ + PJ j, channel quad q = tid % DQ
+    constexpr int PJ = C::PJ;
+    const int dq = tid % C::DQ, dp0 = tid / C::DQ;
+    const int d_goff = ((((dp0 >> 4) * g.OW + (dp0 & 15)) * a.Cout) + co0 + dq * 4) * 4;       // pixel dp0 = (row dp0 >> 4, column dp0 & 15) of the stage
+    const int d_lds = BM == 128 ? dp0 * WP_DROW + (((dq >> 3) ^ (dp0 & 3)) * 64) + (dq & 7) * 8       // + j * PJ * WP_DROW   (PJ % 4 == 0: same swizzle)
+                                : dp0 * WP_DROW + dq * 8;
     // x: item j = patch pixel (tid / XQ) + XPP j, channel quad q = tid % XQ
     const int xq = tid % C::XQ, xp0 = tid / C::XQ;
 
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int j = 0; j < ND; ++j)
             if (it == j) {
-                const int row = (PJ * j) >> 4, dcol = (PJ * j) & 15;                 // dp0 < PJ <= 16: pixel dp0 + PJ j = (row, dp0 + dcol)
+                const int row = (PJ * j) >> 4, dcol = (PJ * j) & 15;                 // pixel dp0 + PJ j: PJ = 8 (dp0 < 8) or a multiple of 16, so no carry
                 draw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (d_goff + (row * g.OW + dcol) * a.Cout * 4) | g_dead, g_dead ? 0 : g_dbase, 0);
             }
 #pragma unroll
@@ -202,8 +212,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // ---- fragment addresses (lane parts).  16-lane group grp, lane i in it: channel block m0 = 16 (grp & 1), pixels kb + 4 rd + (i >> 2)
     const int grp = lane >> 4, li = lane & 15;
     const int m0 = 16 * (grp & 1), kb = 8 * (grp >> 1);
-    const int a_lane = (kb + (li >> 2)) * WP_DROW + ((wm ^ (li >> 2)) * 64) + m0 * 2 + (li & 3) * 8;
-    const int b_lane = 2 * DPLANE + (kb + (li >> 2)) * XPITCH + wn * 64 + m0 * 2 + (li & 3) * 8;
+    // (+ the rows of this wave's k-steps when the waves of a block split them)
+    const int a_lane = (kb + (li >> 2) + wk * 16) * WP_DROW + (BM == 128 ? ((wm ^ (li >> 2)) * 64) : 0) + m0 * 2 + (li & 3) * 8;
+    const int b_lane = 2 * DPLANE + (kb + (li >> 2) + wk * C::ROWSLOTS) * XPITCH + wn * 64 + m0 * 2 + (li & 3) * 8;
 
     auto frag = [&](const unsigned char* p, int rowpitch) -> f16x8 {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
@@ -255,8 +266,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const unsigned char* Sb = smem_p + (s & 1) * STAGE;
         gstage(s + 2);
 #pragma unroll
-        for (int r = 0; r < HR; ++r)
-            kstep(Sb, r, [&](int t) {
+        for (int r = 0; r < C::KSW; ++r)
+            kstep(Sb, r * WK, [&](int t) {
                 // the UPK staging units of this k-step, dealt over the nine gaps in order; a finished item is re-loaded at once
 #pragma unroll
                 for (int u = 0; u < C::UPK; ++u)
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (nst > 0) {                                  // last stage: nothing left to stage
         const unsigned char* Sb = smem_p + ((nst - 1) & 1) * STAGE;
 #pragma unroll
-        for (int r = 0; r < HR; ++r) kstep(Sb, r, [&](int) {});
+        for (int r = 0; r < C::KSW; ++r) kstep(Sb, r * WK, [&](int) {});
     }
 
     // ---- epilogue: G slab [z][slot][co][ci]
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int ci = ci0 + wn * 32 + col;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        float* dst = a.ws + ((size_t)z * g.wtaps + slots.s[t]) * a.Cout * Cin;
+        float* dst = a.ws + ((size_t)(z * WK + wk) * g.wtaps + slots.s[t]) * a.Cout * Cin;      // every k-splitting wave owns a slab
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -306,69 +317,87 @@ static bool window9(const ConvGeom& g, int* y0, int* x0, WgPatchSlots* sl) {
     return seen == 0x1ffu;
 }
 
-static int bn_of(const ConvGeom& g) { return g.my == 2 ? 32 : 64; }
+// which instance takes a layer: 0 none, 1 = <1,128,64,4,1>, 2 = <2,128,32,2,1>, 3 = <1,32,32,4,4>
+static int pick(const ConvGeom& g, int Cout, int C1, int C2) {
+    if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2)) return 0;
+    if (g.OH % WP_TH != 0 || g.OW % WP_TW != 0) return 0;
+    if ((long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW) < 64) return 0;
+    if (!window9(g, nullptr, nullptr, nullptr)) return 0;
+    if (g.my == 2) return (Cout % 128 == 0 && C1 % 32 == 0 && C2 % 32 == 0 && C1 >= 32) ? 2 : 0;
+    if (Cout % 128 == 0 && C1 % 64 == 0 && C2 % 64 == 0 && C1 >= 64) return 1;
+    if (Cout % 32 == 0 && C1 % 32 == 0 && C2 % 32 == 0 && C1 >= 32) return 3;
+    return 0;
+}
+static int bm_of(int cfg) { return cfg == 3 ? 32 : 128; }
+static int bn_of(int cfg) { return cfg == 1 ? 64 : 32; }
+static int wk_of(int cfg) { return cfg == 3 ? 4 : 1; }
 
-template <int S, int BN, int HR, int NW>
+template <int S, int BM, int BN, int HR, int WK>
 static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hipStream_t st) {
-    using C = WgCfg<S, BN, HR, NW>;
+    using C = WgCfg<S, BM, BN, HR, WK>;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_patch_f16_kernel<S, BN, HR, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); attr_done = true; }
-    VIAI_LAUNCH((wgrad_patch_f16_kernel<S, BN, HR, NW>), dim3(a.nblk_co * a.nblk_ci * a.ksplit), dim3(C::NTHR), C::LDS, st, a, y0, x0, sl);
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_patch_f16_kernel<S, BM, BN, HR, WK>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); attr_done = true; }
+    VIAI_LAUNCH((wgrad_patch_f16_kernel<S, BM, BN, HR, WK>), dim3(a.nblk_co * a.nblk_ci * a.ksplit), dim3(C::NTHR), C::LDS, st, a, y0, x0, sl);
     return viai_launch_status();
 }
 
-}  // namespace
-
-// 3 x 3 layers with the full window, stride 1 or 2 (plain conv), Cout % 128 == 0, Cin a multiple of the Cin tile (64 / 32; a tile must
-// not straddle the two concatenated sources), output extent a multiple of the 8 x 16 tile and enough tiles to give every block a K
-// loop worth its prologue / epilogue.  `shape_ok` is the pure shape predicate (workspace sizing); `ok` adds the switches.
-//
-// Same-box A/B of the full three-stream step (the weight gradients run beside the main backward chain, so a kernel that is faster alone
-// but takes a CU's whole LDS / register file can still lose): neither patch kernel 8.69 ms, stride-1 instance only 8.54, both with two
-// stride-2 blocks per CU 8.45, both with ONE stride-2 block per CU (256 blocks) 8.37 -- the default.  VIAI_WGRAD_PATCH_S2=0 switches the
-// stride-2 instance off.
-bool viai_wgrad_patch_shape_ok(const ConvGeom& g, int Cout, int C1, int C2) {
-    if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2)) return false;
-    const int bn = bn_of(g);
-    if (Cout % WP_BM != 0 || C1 % bn != 0 || C2 % bn != 0 || C1 < bn) return false;
-    if (g.OH % WP_TH != 0 || g.OW % WP_TW != 0) return false;
-    if ((long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW) < 64) return false;
-    return window9(g, nullptr, nullptr, nullptr);
-}
-
-bool viai_wgrad_patch_ok(const ConvGeom& g, int Cout, int C1, int C2) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VIAI_WGRAD_PATCH"); on = e ? atoi(e) : 1; }
-    if (!on) return false;
-    if (g.my == 2) { const char* e = getenv("VIAI_WGRAD_PATCH_S2"); if (e && !atoi(e)) return false; }       // read per call: tests switch it
-    return viai_wgrad_patch_shape_ok(g, Cout, C1, C2);
-}
-
-// K slabs: one round of resident blocks (1 per CU for the stride-1 instance, 2 for the stride-2 one), at least four tiles per block
-int viai_wgrad_patch_ksplit(const ConvGeom& g, int Cout, int Cin) {
+// number of block-level K slabs
+static int block_ksplit(const ConvGeom& g, int Cout, int Cin, int cfg) {
     const long tiles = (long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW);
-    const long per = (long)(Cout / WP_BM) * (Cin / bn_of(g));
-    static long blk1 = -1, blk2 = -1;
+    const long per = (long)(Cout / bm_of(cfg)) * (Cin / bn_of(cfg));
+    static long blk1 = -1, blk2 = -1, blk3 = -1;
     if (blk1 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS"); blk1 = e ? atol(e) : 256; }
     if (blk2 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_S2"); blk2 = e ? atol(e) : 256; }
-    long ks = (g.my == 2 ? blk2 : blk1) / per;
+    if (blk3 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_NARROW"); blk3 = e ? atol(e) : 256; }
+    long ks = (cfg == 2 ? blk2 : cfg == 3 ? blk3 : blk1) / per;
     if (ks > tiles / 4) ks = tiles / 4;
     if (ks < 1) ks = 1;
     const long tps = (tiles + ks - 1) / ks;                  // tiles per slab
     return (int)((tiles + tps - 1) / tps);                   // no empty slab
 }
 
+}  // namespace
+
+// 3 x 3 layers with the full window, stride 1 or 2 (plain conv), output extent a multiple of the 8 x 16 tile, enough tiles to give every
+// block a K loop worth its prologue / epilogue, and channel counts one of the instances tiles (a Cin tile must not straddle the two
+// concatenated sources).  `shape_ok` is the pure shape predicate (workspace sizing); `ok` adds the switches.
+//
+// Same-box A/B of the full three-stream step (the weight gradients run beside the main backward chain, so a kernel that is faster alone
+// but takes a CU's whole LDS / register file can still lose): neither patch kernel 8.69 ms, stride-1 instance only 8.54, both with two
+// stride-2 blocks per CU 8.45, both with ONE stride-2 block per CU (256 blocks) 8.37 -- the default.  VIAI_WGRAD_PATCH_S2=0 /
+// VIAI_WGRAD_PATCH_NARROW=0 switch the stride-2 / narrow instances off.
+bool viai_wgrad_patch_shape_ok(const ConvGeom& g, int Cout, int C1, int C2) { return pick(g, Cout, C1, C2) != 0; }
+
+bool viai_wgrad_patch_ok(const ConvGeom& g, int Cout, int C1, int C2) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_WGRAD_PATCH"); on = e ? atoi(e) : 1; }
+    if (!on) return false;
+    const int cfg = pick(g, Cout, C1, C2);
+    if (cfg == 2) { const char* e = getenv("VIAI_WGRAD_PATCH_S2"); if (e && !atoi(e)) return false; }         // read per call: tests switch them
+    if (cfg == 3) { const char* e = getenv("VIAI_WGRAD_PATCH_NARROW"); if (e && !atoi(e)) return false; }
+    return cfg != 0;
+}
+
+// total number of K slabs the launch writes (block-level slabs x waves that split the k-steps)
+int viai_wgrad_patch_ksplit(const ConvGeom& g, int Cout, int C1, int C2) {
+    const int cfg = pick(g, Cout, C1, C2);
+    if (cfg == 0) return 1;
+    return block_ksplit(g, Cout, C1 + C2, cfg) * wk_of(cfg);
+}
+
 int viai_wgrad_patch_launch(WgradArgs& a, hipStream_t st) {
     const ConvGeom& g = a.g;
     const int Cin = a.C1 + a.C2;
     if (a.amax == nullptr || !viai_wgrad_patch_ok(g, a.Cout, a.C1, a.C2)) return (int)hipErrorInvalidValue;
+    const int cfg = pick(g, a.Cout, a.C1, a.C2);
     int y0, x0; WgPatchSlots sl;
     window9(g, &y0, &x0, &sl);
     const long tiles = (long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW);
-    a.ksplit = viai_wgrad_patch_ksplit(g, a.Cout, Cin);
+    a.ksplit = block_ksplit(g, a.Cout, Cin, cfg);
     a.chunks_per_split = (int)((tiles + a.ksplit - 1) / a.ksplit);
-    a.nblk_co = a.Cout / WP_BM;
-    a.nblk_ci = Cin / bn_of(g);
-    if (g.my == 2) return launch_patch<2, 32, 2, 4>(a, y0, x0, sl, st);
-    return launch_patch<1, 64, 4, 8>(a, y0, x0, sl, st);
+    a.nblk_co = a.Cout / bm_of(cfg);
+    a.nblk_ci = Cin / bn_of(cfg);
+    if (cfg == 2) return launch_patch<2, 128, 32, 2, 1>(a, y0, x0, sl, st);
+    if (cfg == 3) return launch_patch<1, 32, 32, 4, 4>(a, y0, x0, sl, st);
+    return launch_patch<1, 128, 64, 4, 1>(a, y0, x0, sl, st);
 }

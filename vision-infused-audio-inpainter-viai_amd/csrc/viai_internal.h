@@ -56,7 +56,7 @@ bool viai_wgrad_bf3_ok(int Cout, int C1, int C2);
 int viai_wgrad_pick_ksplit(int Cout, int Cin, int ntaps, long M);
 bool viai_wgrad_patch_ok(const ConvGeom& g, int Cout, int C1, int C2);      // conv_wgrad_patch.hip: all-taps f16x2 kernel (3 x 3, stride 1 / 2)
 bool viai_wgrad_patch_shape_ok(const ConvGeom& g, int Cout, int C1, int C2);
-int viai_wgrad_patch_ksplit(const ConvGeom& g, int Cout, int Cin);
+int viai_wgrad_patch_ksplit(const ConvGeom& g, int Cout, int C1, int C2);
 int viai_wgrad_patch_launch(WgradArgs& a, hipStream_t st);
 
 // geometry builders (conv_api.hip)
