@@ -346,9 +346,9 @@ static int block_ksplit(const ConvGeom& g, int Cout, int Cin, int cfg) {
     const long tiles = (long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW);
     const long per = (long)(Cout / bm_of(cfg)) * (Cin / bn_of(cfg));
     static long blk1 = -1, blk2 = -1, blk3 = -1;
-    if (blk1 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS"); blk1 = e ? atol(e) : 256; }
-    if (blk2 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_S2"); blk2 = e ? atol(e) : 256; }
-    if (blk3 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_NARROW"); blk3 = e ? atol(e) : 256; }
+    if (blk1 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS"); blk1 = e ? atol(e) : 192; }
+    if (blk2 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_S2"); blk2 = e ? atol(e) : 192; }
+    if (blk3 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_NARROW"); blk3 = e ? atol(e) : 128; }
     long ks = (cfg == 2 ? blk2 : cfg == 3 ? blk3 : blk1) / per;
     if (ks > tiles / 4) ks = tiles / 4;
     if (ks < 1) ks = 1;
@@ -364,8 +364,9 @@ static int block_ksplit(const ConvGeom& g, int Cout, int Cin, int cfg) {
 //
 // Same-box A/B of the full three-stream step (the weight gradients run beside the main backward chain, so a kernel that is faster alone
 // but takes a CU's whole LDS / register file can still lose): neither patch kernel 8.69 ms, stride-1 instance only 8.54, both with two
-// stride-2 blocks per CU 8.45, both with ONE stride-2 block per CU (256 blocks) 8.37 -- the default.  VIAI_WGRAD_PATCH_S2=0 /
-// VIAI_WGRAD_PATCH_NARROW=0 switch the stride-2 / narrow instances off.
+// stride-2 blocks per CU 8.45, both with ONE stride-2 block per CU (256 blocks) 8.37; + the narrow instance 8.17; and with the grids
+// cut below one block per CU (192 / 192 / 128 blocks: CUs left to the main chain, fewer slabs to reduce) 8.00 -- the defaults
+// (VIAI_WGRAD_PATCH_BLOCKS[_S2|_NARROW]).  VIAI_WGRAD_PATCH_S2=0 / VIAI_WGRAD_PATCH_NARROW=0 switch the stride-2 / narrow instances off.
 bool viai_wgrad_patch_shape_ok(const ConvGeom& g, int Cout, int C1, int C2) { return pick(g, Cout, C1, C2) != 0; }
 
 bool viai_wgrad_patch_ok(const ConvGeom& g, int Cout, int C1, int C2) {
