@@ -414,6 +414,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 // a two-stage LDS buffer and all nine taps read it at compile-time offsets -- 6x fewer activation loads / splits per MFMA, the
 // weight-fragment stream (fragment-major, straight from global, one (tap, k-step pair) ahead) unchanged.
 struct HaloWideSlots { int s[9]; };
+#ifndef VIAI_HALO_WIDE_NSET3
+#define VIAI_HALO_WIDE_NSET3 1
+#endif
+#ifndef VIAI_HALO_WIDE_FENCED
+#define VIAI_HALO_WIDE_FENCED 1
+#endif
 
 // WM x TM = 4 (the tile's eight rows = WM waves x TM row pairs); BN = 32 * TN * WN output channels per block:
 //   <2,2,2,2> / <2,4,2,2>: 128 / 256 channels (wide layers);  <2,2,2,1>: 64 channels;  <4,1,1,1>: 32 channels
@@ -526,19 +532,25 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 
     // MFMA row r = lane & 31 of M-tile i -> tile pixel (2 (wm TM + i) + (r >> 4), r & 15); the patch origin is the window's top-left tap
     const int aoff = ((wm * TM * 2 + ((lane & 31) >> 4)) * ROW + (lane & 15)) * PITCH + 16 * (lane >> 5);
-    u32x4 B0[2][TN][NP], B1[2][TN][NP];                   // two fragment sets (k-step 0 / 1 each), alternating per tap
+    // fragment sets (k-step 0 / 1 each), rotating per tap.  Stride 1: THREE sets, the fragments of tap t + 2 are fetched while tap t is
+    // multiplied (the weight stream was the largest exposed wait of this kernel: one tap = 12 .. 24 MFMAs does not cover an L2 round trip);
+    // nine taps = 3 x 3, so the set of a tap is the same in every chunk.  Stride 2 (226 registers already): two sets, one tap ahead.
+    constexpr int NSET = (S == 1 && VIAI_HALO_WIDE_NSET3) ? 3 : 2;
+    u32x4 B0[NSET][TN][NP], B1[NSET][TN][NP];
     gloadA(0);
     gloadB(B0[0], B1[0], 0, 0);
+    if constexpr (NSET == 3) gloadB(B0[1], B1[1], 1, 0);
     lstore(0);
     gloadA(1);
     __syncthreads();
 
-    auto mma = [&](const unsigned char* As, const u32x4 (&b)[TN][NP]) {
-        u32x4 af[TM][NP];
+    auto loadA = [&](const unsigned char* As, u32x4 (&af)[TM][NP]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(As + p * PLANE + i * 2 * ROW * PITCH);
+    };
+    auto mfmas = [&](const u32x4 (&af)[TM][NP], const u32x4 (&b)[TN][NP]) {
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};        // smallest partial products first
 #pragma unroll
         for (int pr = 0; pr < 3; ++pr)
@@ -548,21 +560,34 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][PA[pr]]), __builtin_bit_cast(f16x8, b[j][PB[pr]]), acc[i][j], 0, 0, 0);
     };
-    // one chunk: nine taps; P = fragment set of tap 0 (nine is odd, so the parity flips from chunk to chunk)
+    auto tap_off = [&](int t) -> int {
+        return (S == 2 ? (((t / 3) & 1) * 2 + ((t % 3) & 1)) * SUB + ((t / 3) >> 1) * SUBW + ((t % 3) >> 1) : (t / 3) * HT_HW + (t % 3)) * PITCH;
+    };
+    // one chunk: nine taps x two k-steps = 18 groups of 3 TM TN MFMAs.  The operands of a group are requested one group (A fragments,
+    // LDS) or NSET - 1 taps (weight fragments, global) ahead, and a scheduling barrier on either side keeps each group a solid block of
+    // MFMAs: left to itself the compiler threads the reads, loads and a partial s_waitcnt per operand through the MFMA stream, and
+    // every issue slot between two MFMAs costs matrix-pipe time (MI355X_MICROARCH.md: one extra slot between MFMAs = 6 .. 43 cycles).
+    // P = fragment set of tap 0 when there are two sets (nine is odd, so the parity flips from chunk to chunk)
     auto chunk = [&](int cc, auto P) {
         constexpr int p0 = decltype(P)::value;
         const unsigned char* Sb = smem_h + (NSTAGE == 2 ? (cc & 1) * STAGE : 0) + aoff;
+        u32x4 afq[2][TM][NP];
+        loadA(Sb + tap_off(0), afq[0]);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            constexpr int dummy = 0; (void)dummy;
-            const int cur = (p0 + t) & 1, nxt = cur ^ 1;
-            if (t + 1 < 9) gloadB(B0[nxt], B1[nxt], t + 1, cc);
-            else gloadB(B0[nxt], B1[nxt], 0, cc + 1);
-            constexpr int dummy2 = 0; (void)dummy2;
-            const int toff = S == 2 ? (((t / 3) & 1) * 2 + ((t % 3) & 1)) * SUB + ((t / 3) >> 1) * SUBW + ((t % 3) >> 1) : (t / 3) * HT_HW + (t % 3);
-            const unsigned char* As = Sb + toff * PITCH;
-            mma(As, B0[cur]);
-            mma(As + 32, B1[cur]);
+            const int cur = NSET == 3 ? t % 3 : (p0 + t) & 1;
+            constexpr int AHEAD = NSET - 1;
+            const int ta = t + AHEAD, nxt = NSET == 3 ? ta % 3 : cur ^ 1;
+            if (ta < 9) gloadB(B0[nxt], B1[nxt], ta, cc);
+            else gloadB(B0[nxt], B1[nxt], ta - 9, cc + 1);
+            loadA(Sb + tap_off(t) + 32, afq[1]);                               // k-step 1 of this tap
+            if (VIAI_HALO_WIDE_FENCED) __builtin_amdgcn_sched_barrier(0);
+            mfmas(afq[0], B0[cur]);
+            if (VIAI_HALO_WIDE_FENCED) __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < 9) loadA(Sb + tap_off(t + 1), afq[0]);                 // k-step 0 of the next tap
+            if (VIAI_HALO_WIDE_FENCED) __builtin_amdgcn_sched_barrier(0);
+            mfmas(afq[1], B1[cur]);
+            if (VIAI_HALO_WIDE_FENCED) __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (NSTAGE == 1) __syncthreads();            // one stage: every wave is done reading chunk cc
         lstore(NSTAGE == 2 ? (cc & 1) ^ 1 : 0);                // chunk cc + 1 (loaded during this chunk) -> the other stage
