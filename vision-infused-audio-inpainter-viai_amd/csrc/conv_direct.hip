@@ -57,13 +57,22 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
     const int p0 = blockIdx.x * CIN1_PB;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     f32x4 vals[IT];
-    // decode the first pixel once, then walk (PG divides OW in all VIAI shapes; general carry handled)
+    // decode the first pixel once, then walk: the per-pixel 32-bit divisions (p % OW, p / OW, ... = ~100 instructions) cost more than
+    // the 4 .. 9 multiply-adds of the pixel itself and kept this streaming kernel at 2.7 TB/s of writes
+    int ox, oy, n;
+    {
+        const int p = p0 + pg;
+        ox = p % a.OW; const int r_ = p / a.OW; oy = r_ % a.OH; n = r_ / a.OH;
+    }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         int p = p0 + it * PG + pg;
         f32x4 v = bv;
+        if (it > 0) {
+            ox += PG;
+            while (ox >= a.OW) { ox -= a.OW; if (++oy >= a.OH) { oy = 0; ++n; } }
+        }
         if (p < a.M) {
-            int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
             const float* xb = a.x + (size_t)n * a.IH * a.IW;
             const int iy0 = oy * a.sh, ix0 = ox * a.sw;
 #pragma unroll
