@@ -32,20 +32,27 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* pm = part + (size_t)c * nblk;
     const float* p2 = part + (size_t)(C + c) * nblk;
     const long last_n = M - (long)(nblk - 1) * rows;
-    double s = 0.0;
+    // ONE pass over the partials: Chan's merge written around a pivot k = the first block's mean instead of the (not yet known) global
+    // mean:  S = sum n_b (m_b - k),  Q = sum [M2_b + n_b (m_b - k)^2]  =>  mean = k + S / M,  M2 = Q - S^2 / M.
+    // In fp64 with |m_b - k| of the order of the spread of the block means the subtraction Q - S^2/M loses nothing that matters
+    // (tests/test_kernels_gpu.py::test_bn_large_mean_is_stable); the two-pass form cost two more block reductions (four barriers).
+    const double k = (double)pm[0];
+    double s = 0.0, q = 0.0;
     for (int b = threadIdx.x; b < nblk; b += 256) {
-        double nb = (b == nblk - 1) ? (double)last_n : (double)rows;
-        s += nb * (double)pm[b];
+        const double nb = (b == nblk - 1) ? (double)last_n : (double)rows;
+        const double d = (double)pm[b] - k;
+        s += nb * d;
+        q += (double)p2[b] + nb * d * d;
     }
-    s = block_sum_d(s, red);
-    const double mean = s / (double)M;
-    double m2 = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += 256) {
-        double nb = (b == nblk - 1) ? (double)last_n : (double)rows;
-        double d = (double)pm[b] - mean;
-        m2 += (double)p2[b] + nb * d * d;
-    }
-    m2 = block_sum_d(m2, red);
+    // both sums through one pair of barriers
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    __shared__ double red2[4];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red2[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    q = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+    const double mean = k + s / (double)M;
+    const double m2 = fmax(q - s * s / (double)M, 0.0);
     if (threadIdx.x == 0) {
         const double var = m2 / (double)M;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
