@@ -256,8 +256,8 @@ class KernelTimer:
             # mirror of pick() in csrc/conv_wgrad_patch.hip
             s1 = (d.sh, d.sw) == (1, 1)
             s2 = (d.sh, d.sw) == (2, 2) and not d.transposed and os.environ.get("VIAI_WGRAD_PATCH_S2", "1") != "0"
-            if (os.environ.get("VIAI_WGRAD_PATCH", "1") != "0" and (d.kh, d.kw) == (3, 3) and (s1 or s2) and oh % 8 == 0 and ow % 16 == 0
-                    and d.N * (oh // 8) * (ow // 16) >= 64 and f not in ("direct",)):
+            if (os.environ.get("VIAI_WGRAD_PATCH", "1") != "0" and (d.kh, d.kw) == (3, 3) and (s1 or s2)
+                    and d.N * -(-oh // 8) * -(-ow // 16) >= 64 and oh * ow * 3 >= -(-oh // 8) * -(-ow // 16) * 128 and f not in ("direct",)):
                 def tiles_ok(bm, bn):
                     return d.Cout % bm == 0 and d.C1 % bn == 0 and d.C2 % bn == 0 and d.C1 >= bn
                 if s2 and tiles_ok(128, 32):

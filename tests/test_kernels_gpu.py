@@ -205,6 +205,39 @@ def test_patch_staged_weight_gradient_against_fp64(cfg):
             assert relerr(wg.grad[:, :, ky, kx], wd.grad[:, :, ky, kx]) < 5e-6, (ky, kx)
 
 
+@pytest.mark.parametrize("cfg", [(1, 8, 28, 28, 128, 128), (2, 8, 28, 28, 64, 128), (1, 12, 20, 24, 64, 64), (1, 64, 7, 7, 128, 128)],
+                         ids=["s1_28x28_128to128", "s2_to28x28_64to128", "narrow_20x24_64to64", "s1_7x7_128to128"])
+def test_patch_weight_gradient_on_maps_that_are_not_tile_multiples(cfg):
+    """the output maps of the ResNet-18 visual branch (56 / 28 / 14 / 7 pixels) are not multiples of the 8 x 16 tile: the patch weight
+    gradient covers them with partial tiles whose outside pixels are staged as zeros (networks/Image_Embedding.py:13-71 shapes)."""
+    from viai_amd import _lib, ops
+    S, N, OH, OW, Ci, Co = cfg
+    H, W = OH * S, OW * S
+    x = O.cf_uniform("wgq.x", (N, Ci, H, W), -1, 1)
+    w = O.cf_std("wgq.w", (Co, Ci, 3, 3), 0.05)
+    g_, b_ = O.cf_uniform("wgq.g", (Co,), 0.5, 1.5), O.cf_uniform("wgq.b", (Co,), -0.5, 0.5)
+    rm, rv = O.cf_uniform("wgq.rm", (Co,), -0.1, 0.1), O.cf_uniform("wgq.rv", (Co,), 0.5, 1.5)
+    gy = O.cf_uniform("wgq.gy", (N, Co, OH, OW), -1, 1)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y = F.batch_norm(F.conv2d(xd, wd, None, stride=S, padding=1), rm.double(), rv.double(), g_.double(), b_.double(), False, 0.1, 1e-5)
+    y.backward(gy.double())
+    bn = torch.nn.BatchNorm2d(Co).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(g_); bn.bias.copy_(b_); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.eval()
+    a = nhwc(x).requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    ops.begin_step(a.device)
+    yg = ops.conv_bn_act(a, wg, None, bn, kernel=(3, 3), stride=(S, S), padding=(1, 1), act=ops.ACT_NONE, training=False)
+    yg.backward(nhwc(gy))
+    assert relerr(nchw(yg), y) < 3e-6
+    assert relerr(nchw(a.grad), xd.grad) < 3e-6
+    assert relerr(wg.grad, wd.grad) < 3e-6
+    for ky in range(3):
+        for kx in range(3):
+            assert relerr(wg.grad[:, :, ky, kx], wd.grad[:, :, ky, kx]) < 5e-6, (ky, kx)
+
+
 @pytest.mark.parametrize("cfg", [(128, 0, 32), (64, 64, 32), (32, 0, 128), (96, 0, 64), (64, 64, 128)], ids=["128to32", "cat64+64to32", "32to128", "96to64", "cat64+64to128"])
 def test_wide_halo_kernel_fwd_and_f16_backward_against_fp64(cfg):
     """stride-1 3 x 3 transposed conv + BatchNorm(eval) at 3 x 64 x 128 (192 tiles): forward, data gradient (one or two

@@ -110,7 +110,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? a.x : a.x2), 0, (int)(in_pixels * xcs * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((long)a.M * a.Cout * 4), 0x00020000);
 
-    const int tiles_x = g.OW / WP_TW, tiles_y = g.OH / WP_TH;
+    // tiles cover the output map; where the map is not a multiple of 8 x 16 (the 56 / 28 / 14 / 7-pixel maps of the ResNet branch) the
+    // pixels of a tile that fall outside are staged as zeros: dy = 0 contributes nothing to any tap
+    const int tiles_x = (g.OW + WP_TW - 1) / WP_TW, tiles_y = (g.OH + WP_TH - 1) / WP_TH;
     const int ntiles = g.N * tiles_y * tiles_x;
     const int tile0 = z * a.chunks_per_split;                 // chunks_per_split = tiles per K slab here
     int tile1 = tile0 + a.chunks_per_split;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
     u32x4 draw[ND], xraw[NX];
     // origin of stage s (uniform): image n, first output row / column, byte offset of the dy rows; a stage past the end is "dead"
     // (every load of it is pushed out of range and returns zeros that nobody stores)
-    int g_n = 0, g_iy0 = 0, g_ix0 = 0, g_dbase = 0, g_dead = 0;
+    int g_n = 0, g_iy0 = 0, g_ix0 = 0, g_dbase = 0, g_dead = 0, g_oy0 = 0, g_ox0 = 0;
     auto gstage = [&](int s_) {
         const int s = __builtin_amdgcn_readfirstlane(s_);
         g_dead = s < nst ? 0 : OOB;
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
         g_n = r_ / tiles_y;
         const int oy0 = ty * WP_TH + h * HR, ox0 = tx * WP_TW;
         g_dbase = ((g_n * g.OH + oy0) * g.OW + ox0) * a.Cout * 4;
+        g_oy0 = oy0; g_ox0 = ox0;
         g_iy0 = oy0 * S + y0; g_ix0 = ox0 * S + x0;
     };
     // item `it` (dy items first, then x items; compile-time index) of the stage set by gstage()
@@ -148,7 +151,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
         for (int j = 0; j < ND; ++j)
             if (it == j) {
                 const int row = (PJ * j) >> 4, dcol = (PJ * j) & 15;                 // pixel dp0 + PJ j: PJ = 8 (dp0 < 8) or a multiple of 16, so no carry
-                draw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (d_goff + (row * g.OW + dcol) * a.Cout * 4) | g_dead, g_dead ? 0 : g_dbase, 0);
+                const int oy = g_oy0 + row + (dp0 >> 4), ox = g_ox0 + dcol + (dp0 & 15);
+                const int outside = (((g.OH - 1 - oy) | (g.OW - 1 - ox)) >> 31) & OOB;       // partial tile at the bottom / right edge
+                draw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (d_goff + (row * g.OW + dcol) * a.Cout * 4) | g_dead | outside, g_dead ? 0 : g_dbase, 0);
             }
 #pragma unroll
         for (int j = 0; j < NX; ++j)
@@ -320,8 +325,9 @@ static bool window9(const ConvGeom& g, int* y0, int* x0, WgPatchSlots* sl) {
 // which instance takes a layer: 0 none, 1 = <1,128,64,4,1>, 2 = <2,128,32,2,1>, 3 = <1,32,32,4,4>
 static int pick(const ConvGeom& g, int Cout, int C1, int C2) {
     if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2)) return 0;
-    if (g.OH % WP_TH != 0 || g.OW % WP_TW != 0) return 0;
-    if ((long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW) < 64) return 0;
+    if ((long)g.N * ((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW) < 64) return 0;
+    // partial tiles multiply zeros: refuse maps that would waste more than ~2/3 of the MFMAs (7 x 7: 49 of 128 pixels, taken; 4 x 4: not)
+    if ((long)g.OH * g.OW * 3 < (long)((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW) * WP_TH * WP_TW) return 0;
     if (!window9(g, nullptr, nullptr, nullptr)) return 0;
     if (g.my == 2) return (Cout % 128 == 0 && C1 % 32 == 0 && C2 % 32 == 0 && C1 >= 32) ? 2 : 0;
     if (Cout % 128 == 0 && C1 % 64 == 0 && C2 % 64 == 0 && C1 >= 64) return 1;
@@ -343,7 +349,7 @@ static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hi
 
 // number of block-level K slabs
 static int block_ksplit(const ConvGeom& g, int Cout, int Cin, int cfg) {
-    const long tiles = (long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW);
+    const long tiles = (long)g.N * ((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW);
     const long per = (long)(Cout / bm_of(cfg)) * (Cin / bn_of(cfg));
     static long blk1 = -1, blk2 = -1, blk3 = -1;
     if (blk1 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS"); blk1 = e ? atol(e) : 192; }
@@ -393,7 +399,7 @@ int viai_wgrad_patch_launch(WgradArgs& a, hipStream_t st) {
     const int cfg = pick(g, a.Cout, a.C1, a.C2);
     int y0, x0; WgPatchSlots sl;
     window9(g, &y0, &x0, &sl);
-    const long tiles = (long)g.N * (g.OH / WP_TH) * (g.OW / WP_TW);
+    const long tiles = (long)g.N * ((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW);
     a.ksplit = block_ksplit(g, a.Cout, Cin, cfg);
     a.chunks_per_split = (int)((tiles + a.ksplit - 1) / a.ksplit);
     a.nblk_co = a.Cout / bm_of(cfg);
