@@ -469,6 +469,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # instrumented eager pass over the same workload: HIP events around every conv launch
         m2 = AudioModel(hp, device=dev, use_graph=False)
+        m2._skip_exchange = True              # rank 0 only: the other ranks are already at the final barrier, a collective here would hang
         m2.set_inputs(s, mask)
         for i in range(2):
             m2.optimize_parameters(i)

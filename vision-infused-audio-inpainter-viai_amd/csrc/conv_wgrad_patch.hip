@@ -356,6 +356,9 @@ static int block_ksplit(const ConvGeom& g, int Cout, int Cin, int cfg) {
     if (blk2 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_S2"); blk2 = e ? atol(e) : 192; }
     if (blk3 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_NARROW"); blk3 = e ? atol(e) : 128; }
     long ks = (cfg == 2 ? blk2 : cfg == 3 ? blk3 : blk1) / per;
+    // the sub-CU grids above suit the audio step, whose weight gradients are short and share the chip with the main chain; a layer with
+    // hundreds of tiles per block (the ResNet branch on 1024 frames) is worth every CU
+    if (ks >= 1 && tiles / ks > 128) ks = 256 / per;
     if (ks > tiles / 4) ks = tiles / 4;
     if (ks < 1) ks = 1;
     const long tps = (tiles + ks - 1) / ks;                  // tiles per slab
