@@ -74,7 +74,7 @@ def math_string():
         return ("fp32 tensors and fp32 accumulation; conv products on the fp16 matrix cores through the f16x2 operand split (two fp16 terms per fp32 "
                 "operand = 22 significand bits, three partial products, power-of-two pre-scaling: static x16 for activations / x256 for weights, "
                 "per-tensor from max|dy| for gradients) in the forward%s kernels of every layer with > 1 channel on both sides; bf16x3 (three bf16 "
-                "terms, six partial products) where no BatchNorm produces the gradient scale%s; exact fp32 MFMA in the <= 32-channel weight gradients; "
+                "terms, six partial products) where no BatchNorm produces the gradient scale%s; exact fp32 MFMA in the <= 32-channel weight gradients the patch kernel does not tile; "
                 "plain fp32 FMA in the Cin = 1 / Cout = 1 streaming convs; measured 2.7-2.9e-7 relative vs fp64 per layer (CPU fp32: 1.8e-7); "
                 "activations saturate at |x| > 4094 (tests/test_kernels_gpu.py::test_f16x2_saturates_instead_of_nan)"
                 % (", data-gradient and weight-gradient" if f16b else "", "" if f16b else " and in every backward kernel (VIAI_F16_BACKWARD=0)"))

@@ -25,7 +25,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # VIAI_DIST_BACKEND=gloo: CPU-staged collectives (tests, or several ranks sharing one GPU, which RCCL refuses)
+            backend = os.environ.get("VIAI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -35,7 +36,12 @@ def init_from_env(backend=None):
 def broadcast_arena(flat: torch.Tensor, src=0, group=None):
     """identical initial parameters on every rank (DDP semantics)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(flat, src=src, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            h = flat.detach().cpu()
+            dist.broadcast(h, src=src, group=group)
+            flat.copy_(h)
+        else:
+            dist.broadcast(flat, src=src, group=group)
 
 
 def allreduce_mean_(flat_grad: torch.Tensor, group=None, scale_in_optimizer=False):
@@ -70,6 +76,8 @@ def barrier_max_ms(elapsed_ms: float, device=None) -> float:
     """max over ranks of a per-rank time (bench contract)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return elapsed_ms
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([elapsed_ms], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
