@@ -19,7 +19,7 @@
 // Instances <S, BM, BN, HR, WK>  (BM x BN = Cout x Cin tile, HR tile rows per stage, WK = waves that split the k-steps of a stage):
 //   <1, 128, 64, 4, 1>  stride 1: 8 waves (4 along Cout x 2 along Cin), two LDS stages of 74 KB, 1 block / CU
 //   <1,  32, 32, 4, 4>  stride 1, narrow layers (the 32 / 64-channel layers of the generator): 4 waves that share ONE 32 x 32 tile and take
-//                       one tile row each; every wave writes its own split-K slab (the slab reduce adds them), 44 KB of LDS
+//                       one tile row each and add their accumulators through LDS at the end, 44 KB of LDS
 //   <2, 128, 32, 2, 1>  stride 2: a stride-2 layer reads a (2 HR + 1) x 33 input patch per HR x 16 output pixels (4.4x the pixels of the stride-1
 //                  case), so the Cin tile is 32 and a stage 2 tile rows; the patch is stored as four parity sub-patches
 //                  P[py][px][r][c] = patch(2 r + py, 2 c + px), so that the 16 pixels of a k-step are again 16 consecutive LDS rows for every
@@ -290,13 +290,37 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
         for (int r = 0; r < C::KSW; ++r) kstep(Sb, r * WK, [&](int) {});
     }
 
+    // ---- waves that split the k-steps of a stage hold partial sums of the SAME tile: add them up through LDS in a fixed order (wave 1,
+    // 2, ... into wave 0) so the block writes ONE slab (the slab reduce of the narrow instance read 4x the bytes otherwise)
+    if constexpr (WK > 1) {
+        static_assert(C::WMC * C::WN == 1 && 9 * 16 * 64 * 4 <= C::LDS, "one tile per block, accumulators fit the stage buffers");
+        float* red = reinterpret_cast<float*>(smem_p);
+        __syncthreads();                                   // every wave is done with the last stage
+        for (int w = 1; w < WK; ++w) {
+            if (wk == w) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[(t * 16 + e) * 64 + lane] = acc[t][e];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t][e] += red[(t * 16 + e) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wk != 0) return;
+    }
     // ---- epilogue: G slab [z][slot][co][ci]
     const float inv = 1.0f / (dscale * F16_ASCALE);
     const int half = lane >> 5, col = lane & 31;
     const int ci = ci0 + wn * 32 + col;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        float* dst = a.ws + ((size_t)(z * WK + wk) * g.wtaps + slots.s[t]) * a.Cout * Cin;      // every k-splitting wave owns a slab
+        float* dst = a.ws + ((size_t)z * g.wtaps + slots.s[t]) * a.Cout * Cin;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -336,7 +360,7 @@ static int pick(const ConvGeom& g, int Cout, int C1, int C2) {
 }
 static int bm_of(int cfg) { return cfg == 3 ? 32 : 128; }
 static int bn_of(int cfg) { return cfg == 1 ? 64 : 32; }
-static int wk_of(int cfg) { return cfg == 3 ? 4 : 1; }
+static int wk_of(int cfg) { (void)cfg; return 1; }      // slabs per block (the k-splitting waves of the narrow instance reduce in the block)
 
 template <int S, int BM, int BN, int HR, int WK>
 static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hipStream_t st) {
