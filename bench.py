@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--graph", action="store_true", help="replay three captured HIP graphs per step (single stream) instead of "
                     "launching eagerly with the weight gradients on a side stream (the default, measured faster)")
+    ap.add_argument("--plan", action="store_true", help="record the step once (stream capture) and replay it from C as a launch plan: "
+                    "the eager step's kernels, streams and edges without the per-launch host work")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)    # kept for old command lines: eager is the default
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -338,6 +340,42 @@ def cpu_baseline(args):
     return out
 
 
+def launch_modes(hp, dev, s, mask, steps=30):
+    """host time per step.  The loop figure `host_enqueue_ms_per_step` is back-pressure-bound (the host
+    runs ahead until the device queues are full, then waits inside a launch), so the host cost is measured separately: time to
+    enqueue ONE step into an idle queue, for the eager step (Python -> ctypes -> launch) and for the launch plan (csrc/plan.hip:
+    the same launches, streams and edges replayed from C; bitwise the eager step, tests/test_networks_gpu.py::
+    test_launch_plan_replays_the_eager_step_bitwise), plus each mode's steady-state ms/step in this run."""
+    import statistics
+    from viai_amd.model import AudioModel
+    out = {}
+    for name, kw in (("eager", {}), ("plan", {"use_plan": True})):
+        m = AudioModel(hp, device=dev, **kw)
+        m.set_inputs(s, mask)
+        for i in range(8):
+            m.optimize_parameters(i)
+        torch.cuda.synchronize()
+        host = []
+        for i in range(12):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m.optimize_parameters(8 + i)
+            host.append((time.perf_counter() - t0) * 1e3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            m.optimize_parameters(20 + i)
+        torch.cuda.synchronize()
+        out[name] = {"host_ms_per_step_idle_queue": round(statistics.median(host), 3),
+                     "ms_per_step": round((time.perf_counter() - t0) * 1e3 / steps, 3)}
+        if name == "plan":
+            info = m.plan_info()
+            out[name]["launches"] = sum(v[0] for v in info)
+            out[name]["cross_stream_events"] = sum(v[6] for v in info)
+        del m
+    return out
+
+
 def front_end_stages(dev, batch, bins, frames):
     """north_star: achieved HBM GB/s of the STFT / mask stages.  Algorithmic bytes: STFT -> mel reads the
     waveform (4 B x 65 536 samples per clip) and writes the mel (4 B x F x T); the mask multiply reads and writes the mel once."""
@@ -396,7 +434,7 @@ def main():
         hp.use_video, hp.lambda_contrast = True, 0.1
         hp.num_D = 3 if args.config == "av_msd" else 1
         args.no_roofline = args.no_cpu_baseline = True
-    model = AudioModel(hp, device=dev, use_graph=args.graph)
+    model = AudioModel(hp, device=dev, use_graph=args.graph, use_plan=args.plan)
     ddp.broadcast_arena(model.arena_G.flat)
     ddp.broadcast_arena(model.arena_D.flat)
 
@@ -454,7 +492,8 @@ def main():
                     "%dx%d mel, batch %d per GPU" % (2 if args.config == "av" else 3, args.frames // 4,
                                                       "PatchGAN D" if args.config == "av" else "3-scale D", args.bins, args.frames, args.batch)),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                   "launch": "hipGraph replay (3 segments)" if args.graph else "eager, weight gradients on a side stream",
+                   "launch": ("launch plan replayed from C (3 segments; same kernels / streams / edges as the eager step)" if args.plan else
+                              "hipGraph replay (3 segments)" if args.graph else "eager, weight gradients on a side stream"),
                    "math": math_string(),
                    "host_enqueue_ms_per_step": round(enqueue_ms / args.steps, 3), "algorithmic_gflop_per_step": 1208.0, "step_tflops": round(1208.0 * 1e-3 / (ms_per_step * 1e-3), 2),
                    "loss_d": round(losses[0], 5), "loss_g": round(losses[1], 5)},
@@ -556,6 +595,8 @@ def main():
         del m2
     if rank == 0 and args.config == "audio" and not args.no_roofline:
         out["stages"] = front_end_stages(dev, args.batch, args.bins, args.frames)
+    if rank == 0 and world == 1 and args.config == "audio" and not args.no_roofline:
+        out["config"]["launch_modes"] = launch_modes(hp, dev, s, mask)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 4
+#define VIAI_ABI_VERSION 5
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -307,6 +307,22 @@ int viai_mel_denorm_amp(const float* S, float* out, long n, float min_level_db, 
  * |captions[i] - clips[j]|_2 over j, top1[i] = argmin_j; dist (optional) [n_captions][n_clips].             */
 int viai_l2_ranks(const float* clips, const float* captions, int n_clips, int n_captions, int dim,
                   int* ranks, int* top1, float* dist, void* stream);
+
+/* -------------------------------------------------- launch plans: the train step recorded once, replayed from C
+ * Replaces the per-launch host work of `model.optimize_parameters()` (train_whole_sync.py:76).  Protocol:
+ *   viai_plan_log_begin();  <stream-capture the step: every library launch notes (kernel, stream)>;  n = viai_plan_log_end();
+ *   viai_plan_build(captured hipGraph_t, capture origin stream, &plan);   // reads nodes + edges, never instantiates the graph
+ *   viai_plan_replay(plan, stream);                                       // each step: same kernels, arguments, streams, edges
+ * The hipGraph_t (it owns the kernel-argument arrays) and every buffer the capture touched must outlive the plan.
+ * Kernel, 1-D copy, fill and empty nodes are accepted; anything else returns hipErrorNotSupported.
+ * viai_plan_info fills out[0..n) with: nodes, kernels, kernels with a noted stream, copies, fills, streams, events, waits.   */
+typedef struct viai_plan viai_plan;
+int viai_plan_log_begin(void);
+int viai_plan_log_end(void);
+int viai_plan_build(void* hip_graph, void* capture_stream, viai_plan** plan);
+int viai_plan_replay(viai_plan* plan, void* stream);
+int viai_plan_info(const viai_plan* plan, int* out, int n);
+void viai_plan_destroy(viai_plan* plan);
 
 #ifdef __cplusplus
 }

@@ -400,6 +400,44 @@ def test_graph_capture_leaves_training_state_untouched():
         assert relerr(b, a) < 1e-5
 
 
+def test_launch_plan_replays_the_eager_step_bitwise():
+    """csrc/plan.hip: the step recorded once (stream capture used as a recorder) and replayed from C issues the eager step's
+    kernels with the eager step's arguments on the eager step's streams, so after four steps -- with a change of input shape
+    (re-record) in the middle -- parameters, Adam state, BatchNorm buffers and the loss scalars are BIT-identical to the eager
+    model's, and the plan really is multi-stream (side streams noted for the library's own launches)."""
+    from viai_amd.model import AudioModel, StepConfig
+    hp = StepConfig()
+    hp.cin_channels, hp.max_mel_lengths = 80, 32
+    s = O.cf_uniform("pl.s", (2, 1, 80, 32), 0, 1).cuda()
+    mask = O.make_mask(2, 32, "pl.mask").cuda()
+    s2 = O.cf_uniform("pl.s2", (3, 1, 80, 32), 0, 1).cuda()
+    mask2 = O.make_mask(3, 32, "pl.mask2").cuda()
+
+    def run(plan):
+        m = AudioModel(hp, device="cuda", use_plan=plan)
+        m.load_states(O.encoder_state(), O.decoder_state(), O.disc_state())
+        m.set_inputs(s, mask)
+        m.optimize_parameters(0)
+        m.optimize_parameters(1)
+        info = m.plan_info() if plan else None
+        m.set_inputs(s2, mask2)
+        m.optimize_parameters(2)
+        m.optimize_parameters(3)
+        losses = m.get_loss_items()
+        bn = m.netD.norm3
+        return [m.arena_G.flat.clone(), m.arena_D.flat.clone(), m.optimizer_G.exp_avg.clone(), m.optimizer_D.exp_avg_sq.clone(),
+                m.optimizer_G.state.clone(), bn.running_mean.clone(), bn.running_var.clone(), m.fake.clone(),
+                torch.tensor(losses)], info
+    (eager, _), (plan, info) = run(False), run(True)
+    assert len(info) == 3
+    for nodes, kernels, noted, copies, fills, streams, events, waits in info:
+        assert nodes == kernels + copies + fills and nodes > 0
+        assert noted >= 0.8 * kernels                          # the library's launches carry their stream
+    assert info[0][5] >= 3 and info[1][5] >= 2                 # D(real) + weight-gradient side streams are kept
+    for a, b in zip(eager, plan):
+        assert torch.equal(a, b)
+
+
 def test_three_stream_step_is_bitwise_the_single_stream_step(monkeypatch):
     """Weight gradients on a side stream and D(real) on a third stream only reorder launches in time: every
     accumulation keeps its order (event-ordered streams), so losses, gradients and parameters after three steps are

@@ -132,6 +132,12 @@ SIGNATURES = {
     "viai_ema_update": (_I, [_P, _P, _L, _D, _P]),
     "viai_mel_denorm_amp": (_I, [_P, _P, _L, _F, _P]),
     "viai_l2_ranks": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "viai_plan_log_begin": (_I, []),
+    "viai_plan_log_end": (_I, []),
+    "viai_plan_build": (_I, [_P, _P, C.POINTER(C.c_void_p)]),
+    "viai_plan_replay": (_I, [_P, _P]),
+    "viai_plan_info": (_I, [_P, C.POINTER(C.c_int), _I]),
+    "viai_plan_destroy": (None, [_P]),
 }
 
 _lib = None
@@ -165,7 +171,7 @@ def load() -> C.CDLL:
             raise ViaiLibraryError("libviai_hip.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.viai_abi_version() != 4:
+    if lib.viai_abi_version() != 5:
         raise ViaiLibraryError("libviai_hip.so ABI version mismatch")
     _lib = lib
     return lib

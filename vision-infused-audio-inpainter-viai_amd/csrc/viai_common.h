@@ -70,10 +70,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // process (torch's own probing calls) may have left set, so it is cleared before every launch and only
 // errors raised by OUR launches are accumulated (first error wins) and reported by the entry point.
 static thread_local int viai_err_acc = 0;
+// Launch plans (plan.hip): while the log is on, every launch notes (kernel, launch geometry, argument bytes, stream) so that a
+// plan built from the stream capture of the same launches can put each node back on the stream it was issued to (a node is
+// matched to its note by kernel + geometry + argument bytes, whatever order the graph API returns the nodes in).
+extern int viai_plan_log_on;
+void viai_plan_note(const void* func, void* stream, dim3 grid, dim3 block, const unsigned char* blob, const unsigned* sizes, int nargs);
+template <class... P, class... A>
+static inline void viai_plan_note_launch(void (*f)(P...), dim3 grid, dim3 block, size_t, hipStream_t st, A&&... a) {
+    if (!viai_plan_log_on) return;
+    static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+    unsigned char blob[(sizeof(P) + ... + 16)];
+    unsigned sizes[sizeof...(P) + 1];
+    int n = 0;
+    size_t off = 0;
+    auto put = [&](const void* p, size_t bytes) { __builtin_memcpy(blob + off, p, bytes); off += bytes; sizes[n++] = (unsigned)bytes; };
+    ([&] { P v = static_cast<P>(a); put(&v, sizeof(P)); }(), ...);       // the value as the kernel receives it
+    viai_plan_note(reinterpret_cast<const void*>(f), (void*)st, grid, block, blob, sizes, n);
+}
 #define VIAI_LAUNCH(...)                                         \
     do {                                                         \
         (void)hipGetLastError();                                 \
         hipLaunchKernelGGL(__VA_ARGS__);                         \
+        viai_plan_note_launch(__VA_ARGS__);                      \
         int viai_e_ = (int)hipGetLastError();                    \
         if (viai_e_ != 0 && viai_err_acc == 0) viai_err_acc = viai_e_; \
     } while (0)

@@ -19,6 +19,7 @@ graphs (three segments, split at the two all-reduce points).
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 from collections import OrderedDict
@@ -27,6 +28,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._lib import check, load as lib
 from .networks import (ImageEmbedding2, MelDecoder, MelDecoderImage, MelDiscriminator, MelEncoder, MultiScaleDiscriminator,
                        to_nchw_view)
 
@@ -154,7 +156,7 @@ def make_time_mask(batch, frames, blank_length, generator=None, device="cpu"):
 class AudioModel:
     """Interface inferred from train_whole_sync.py:49,50,68,75-85,91-112,145,159-183."""
 
-    def __init__(self, hparams=None, device=None, process_group=None, use_graph=False):
+    def __init__(self, hparams=None, device=None, process_group=None, use_graph=False, use_plan=False):
         self.hparams = hparams if hparams is not None else StepConfig()
         hp = self.hparams
         self.device = torch.device(device) if device is not None else torch.device("cuda")
@@ -188,13 +190,19 @@ class AudioModel:
         self.video_net_norm = None
         self.losses = torch.zeros(6, device=self.device)      # loss_D, loss_G, loss_G_GAN, loss_L1, loss_D_real, EmbeddingL2
         self.mel = self.mask = self.fake = None
-        self.use_graph = bool(use_graph)
+        # use_plan: the step is stream-captured once and replayed from C as a launch plan (csrc/plan.hip): the eager step's
+        # kernels, arguments, streams and cross-stream edges without the per-launch host work.  Shares the segment structure
+        # (and the static-buffer discipline) of graph mode, so it sets use_graph too.
+        self.use_plan = bool(use_plan)
+        self.use_graph = bool(use_graph) or self.use_plan
+        self._plans = None
         # weight gradients trail on a side stream (ops.WGRAD_STREAM) in eager mode: -3.5 % step time on one MI355X.  Inside
         # a captured hipGraph the fork/join edges cost more than the overlap returns (+2 %), so graph mode stays on one
         # stream.  VIAI_WGRAD_STREAM=0/1 overrides.
-        side = os.environ.get("VIAI_WGRAD_STREAM", "0" if self.use_graph else "1") != "0"
+        one_stream = self.use_graph and not self.use_plan
+        side = os.environ.get("VIAI_WGRAD_STREAM", "0" if one_stream else "1") != "0"
         self._wgrad_stream = torch.cuda.Stream(device=self.device) if side else None
-        dreal = os.environ.get("VIAI_DREAL_STREAM", "0" if self.use_graph else "1") != "0"
+        dreal = os.environ.get("VIAI_DREAL_STREAM", "0" if one_stream else "1") != "0"
         self._dreal_stream = torch.cuda.Stream(device=self.device) if dreal else None
         self._graphs = None
         self._comm = None                  # data-parallel exchange stream (created on first use)
@@ -366,6 +374,10 @@ class AudioModel:
         must not be destroyed while in flight, so this is one of the few places that waits for the device."""
         if self._graphs is not None:
             torch.cuda.synchronize(self.device)
+            if self._plans is not None:
+                for p in self._plans:
+                    lib().viai_plan_destroy(p)
+                self._plans = None
             self._graphs = None
             ops.drop_scratch()            # scratch buffers allocated while capturing live in the dead graphs' private memory pool
 
@@ -400,6 +412,11 @@ class AudioModel:
             f_a = feats[-1].mean(dim=1).reshape(B * w, 256)
             lc = ops.l2_contrastive(f_a.contiguous(), fv_nhwc.reshape(B * w, 256).contiguous(), self.cfg.contrast_margin, False)
         return (fake, lc, feats, f_v) if want_feats else (fake, lc)
+
+    def _put(self, i, value):
+        """losses[i] = value through an elementwise kernel: a `copy_` is a device-to-device memcpy, whose node parameters a
+        stream capture does not give back (plan mode reads the captured launches)."""
+        torch.mul(value.detach().reshape(1), 1.0, out=self.losses[i:i + 1])
 
     def _seg_forward_dstep(self):
         s = self.mel
@@ -450,8 +467,8 @@ class AudioModel:
         ops.join_wgrad()
         if self._finish_exchange(self.arena_D, self._late_D):
             main.wait_stream(self._comm)                               # Adam(D) and the G step need the reduced D gradients
-        self.losses[0].copy_(loss_d.detach())
-        self.losses[4].copy_(loss_real.detach())
+        self._put(0, loss_d.detach())
+        self._put(4, loss_real.detach())
 
     def _seg_dupdate_gstep(self, update=True):
         if update:
@@ -466,15 +483,15 @@ class AudioModel:
         if self._lc is not None:
             loss_g = loss_g + self.cfg.lambda_contrast * self._lc
             self.EmbeddingL2 = self._lc.detach()
-            self.losses[5].copy_(self.EmbeddingL2)
+            self._put(5, self.EmbeddingL2)
         self._arm_hooks(self.arena_G, self._early_G, 1)
         loss_g.backward()
         ops.join_wgrad()
         self._g_exchanged = self._finish_exchange(self.arena_G, self._late_G)
         self.netD.requires_grad_(True)
-        self.losses[1].copy_(loss_g.detach())
-        self.losses[2].copy_(loss_gan.detach())
-        self.losses[3].copy_(loss_l1.detach())
+        self._put(1, loss_g.detach())
+        self._put(2, loss_gan.detach())
+        self._put(3, loss_l1.detach())
         self._pred_fake_g = pred
 
     def _seg_gupdate(self):
@@ -513,15 +530,39 @@ class AudioModel:
         for t, v in zip(snap, saved):
             t.copy_(v)
         self.weights_changed()
-        graphs = []
+        graphs, plans = [], []
         pool = None
         for f in segs:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                f()
+            if self.use_plan:
+                # the capture is a recorder: the hipGraph is kept (it owns the kernel-argument arrays) but never instantiated
+                g = torch.cuda.CUDAGraph(keep_graph=True)
+                lib().viai_plan_log_begin()
+                try:
+                    with torch.cuda.graph(g, pool=pool):
+                        origin = torch.cuda.current_stream().cuda_stream
+                        f()
+                finally:
+                    lib().viai_plan_log_end()
+                plan = ctypes.c_void_p()
+                check(lib().viai_plan_build(int(g.raw_cuda_graph()), origin, ctypes.byref(plan)), "viai_plan_build")
+                plans.append(plan)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    f()
             pool = g.pool()
             graphs.append(g)
         self._graphs = graphs
+        self._plans = plans if self.use_plan else None
+
+    def plan_info(self):
+        """per captured segment: nodes, kernels, kernels with a noted stream, copies, fills, streams, events, waits"""
+        out = []
+        for p in self._plans or ():
+            v = (ctypes.c_int * 8)()
+            check(lib().viai_plan_info(p, v, 8), "viai_plan_info")
+            out.append(list(v))
+        return out
 
     def _mutable_state(self):
         """every device tensor a train step writes and the next step reads: parameter arenas, Adam moments and step
@@ -547,12 +588,16 @@ class AudioModel:
         if self.use_graph:
             if self._graphs is None:
                 self._capture()
-            g0, g1, g2 = self._graphs
-            g0.replay()
+            if self.use_plan:
+                run = [lambda p=p: check(lib().viai_plan_replay(p, torch.cuda.current_stream().cuda_stream), "viai_plan_replay")
+                       for p in self._plans]
+            else:
+                run = [g.replay for g in self._graphs]
+            run[0]()
             self._allreduce(self.arena_D)
-            g1.replay()
+            run[1]()
             self._allreduce(self.arena_G)
-            g2.replay()
+            run[2]()
         else:
             self._seg_forward_dstep()          # D exchange: early bucket from inside the backward, the rest at its end
             self._seg_dupdate_gstep()          # G exchange: two early buckets + the encoder range
@@ -590,7 +635,7 @@ class AudioModel:
             with torch.no_grad():
                 fake, _lc, feats, f_v = self._generate(s.view(B, F, T, 1), want_feats=True)
                 self.fake = to_nchw_view(fake)
-                self.losses[3].copy_(ops.l1_mean(fake, s.view(B, F, T, 1)))
+                self._put(3, ops.l1_mean(fake, s.view(B, F, T, 1)))
                 emb = feats[-1].mean(dim=(1, 2))                   # bottleneck (B, h, T/16, 256) -> (B, 256)
                 self.mel_net_norm = torch.nn.functional.normalize(emb, p=2, dim=1)
                 # the retrieval metrics of the reference loop (utils/util.py:99-121) pair the audio embedding with the
