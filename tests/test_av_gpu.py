@@ -41,7 +41,8 @@ def test_av_decoders(variant, golden_dir):
     fake.mean().backward()
     key = "deconv1_1_1.weight" if variant != "old" else "deconv1_1.weight"
     g = dict(G.named_parameters())[key].grad
-    assert abs(O.digest(g)[2] - gold["dec_%s.g.%s.dg" % (variant, key)][2]) < 3e-2 * gold["dec_%s.g.%s.dg" % (variant, key)][2]
+    e_head = abs(O.digest(g)[2] - gold["dec_%s.g.%s.dg" % (variant, key)][2]) / gold["dec_%s.g.%s.dg" % (variant, key)][2]
+    assert e_head < 1e-3            # measured 2e-6 .. 7e-5 (round 1 allowed 3e-2)
     g2 = G.conv6_2.weight.grad
     assert relerr(O.digest(g2), gold["dec_%s.g.conv6_2.weight.dg" % variant]) < 1e-3
     # unused-by-forward parameters stay without gradient, as in the reference
@@ -55,7 +56,8 @@ def test_av_decoders(variant, golden_dir):
     og = torch.autograd.grad(ofake.mean(), [osd[k] for k in keys])
     num = sum((dict(G.named_parameters())[k].grad.cpu().double() - o.double()).pow(2).sum().item() for k, o in zip(keys, og))
     den = sum(o.double().pow(2).sum().item() for o in og)
-    assert (num / den) ** 0.5 < 2e-2
+    print("av decoder %s: head gradient norm vs reference %.2e, all gradients vs oracle %.2e" % (variant, e_head, (num / den) ** 0.5))
+    assert (num / den) ** 0.5 < 8e-3            # measured 4e-4 .. 3e-3 (the `old` decoder's longer BatchNorm chain); round 1 allowed 2e-2
 
 
 def test_init_deconv_1_1_1():
@@ -171,7 +173,7 @@ def test_vision_infused_multiscale_step_matches_reference_composition(golden_dir
             dg, ref = O.digest(p.grad), gold[gk]
             e = abs(dg[2] - ref[2]) / ref[2]
             worst[grp] = max(worst.get(grp, 0.0), e)
-            assert e < 3e-2, (gk, e)          # tiny batch-norm populations (4 .. 64 elements per channel) at this shape
+            assert e < 5e-3, (gk, e)          # measured worst 1.0e-3 (D; tiny batch-norm populations, 4 .. 64 elements per channel, at this shape)
     print("av step: worst gradient-norm digest error vs reference:", worst)
 
 

@@ -108,8 +108,10 @@ def test_image_embedding2_matches_oracle_and_golden(golden_dir):
               "image_single_model.layer4.1.conv2.weight", "image_single_model.fc.weight", "flow_single_model.layer1.0.bn1.weight",
               "conv_1.weight", "conv_2.weight"):
         dg, ref = O.digest(params[k].grad), gold["g.%s.dg" % k]
-        assert abs(dg[2] - ref[2]) < 3e-2 * ref[2], k
-        assert np.linalg.norm(dg[3:] - ref[3:]) < 6e-2 * (np.linalg.norm(ref[3:]) + 1e-12), k
+        # measured on MI355X: norms within 1.7e-4, the 64 strided samples within 1.7e-3 (the 7x7-tap first conv and the first BatchNorm
+        # weight, whose gradients sum 4 x 112 x 112 cancelling terms); round 1 allowed 3e-2 / 6e-2
+        assert abs(dg[2] - ref[2]) < 1e-3 * ref[2], k
+        assert np.linalg.norm(dg[3:] - ref[3:]) < 5e-3 * (np.linalg.norm(ref[3:]) + 1e-12), k
     assert M.bn_1.weight.grad is None
     assert relerr(M.image_single_model.bn1.running_mean, gold["rm.image.bn1"]) < 1e-4
     assert relerr(M.flow_single_model.layer3[0].downsample[1].running_var, gold["rv.flow.layer3.0.downsample.1"]) < 1e-4
