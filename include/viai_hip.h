@@ -246,9 +246,13 @@ typedef struct viai_wn_synth {
     const float *w_first, *b_first, *w_l1, *b_l1, *w_l2, *b_l2;
     const float *cond, *test_inputs, *u1, *u2;
     float *out, *z, *skips, *yhat_dbg;      /* z: (B, G/2), skips: (B, S) scratch; yhat_dbg optional (B,T,out_ch) */
-    int* step;
+    int* step;                              /* device int, 0 before the first call: counts the calls (the step advances it itself) */
 } viai_wn_synth;
 int viai_wavenet_synth_step(const viai_wn_synth* s, void* stream);
+/* The same time steps t0 .. t0 + n_steps - 1 launched from a host loop with the time index passed BY VALUE (ABI v5): no kernel starts
+ * with a load of `*step` in front of its address arithmetic (a full memory round trip at these grid sizes).  `step` is not touched.
+ * wavenet.py:237-364 incremental_forward's loop body, n_steps at a time.                                                         */
+int viai_wavenet_synth_run(const viai_wn_synth* s, int t0, int n_steps, void* stream);
 
 /* ------------------------------------------------------------ mask / optimizer
  * s_in = s * mask, mask (N, T) broadcast over frequency (the missing

@@ -219,3 +219,28 @@ def test_one_hot_input_wavenet_matches_reference_golden(golden_dir):
             assert relerr(params[k[2:]].grad, gold[k]) < 2e-3, k
     sm = net(x.cuda(), c.cuda(), softmax=True)              # the reference's `self.softmax(x, dim=1)` is a latent TypeError; this is its intent
     assert relerr(sm, torch.softmax(torch.from_numpy(gold["yhat"]), 1)) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skip", [256, 320])
+def test_synthesis_paths_agree_with_batch_forward_at_wide_layers(skip):
+    """The two launch forms of a synthesis time step -- `viai_wavenet_synth_run` (host loop, time index by value; the default) and
+    `viai_wavenet_synth_step` under a HIP graph (time index on the device) -- run the same kernels and must give the same logits
+    bit for bit, and both must equal the teacher-forced forward().  Reference-like widths (512 residual / 512 gate channels:
+    the block-per-row gate kernel with two 16-byte chunks per thread); skip = 256 takes the 16-wave head kernel, skip = 320 the
+    generic one (S > 256)."""
+    from viai_amd.wavenet import WaveNet
+    torch.manual_seed(3)
+    net = WaveNet(out_channels=30, layers=4, stacks=2, residual_channels=512, gate_channels=512, skip_out_channels=skip,
+                  kernel_size=3, dropout=0.0, cin_channels=80, gin_channels=-1, upsample_conditional_features=True,
+                  upsample_scales=[4, 4], scalar_input=True).cuda().eval()
+    B, T = 8, 32
+    x = torch.rand(B, 1, T) * 2 - 1
+    c = torch.rand(B, 80, T // 16)
+    xin = torch.cat((torch.zeros(B, 1, 1), x[:, :, :-1]), 2)
+    with torch.no_grad():
+        yh = net(xin.cuda(), c.cuda())
+    out_r, log_r = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=xin.cuda(), log_scale_min=-7.0, use_graph=False, return_logits=True)
+    out_g, log_g = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=xin.cuda(), log_scale_min=-7.0, use_graph=True, return_logits=True)
+    assert torch.equal(log_r, log_g)
+    assert relerr(log_r.transpose(1, 2), yh) < 1e-4

@@ -117,6 +117,7 @@ SIGNATURES = {
     "viai_scale_by_scalar": (_I, [_P, _P, _L, _P]),
     "viai_mol_sample": (_I, [_P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "viai_wavenet_synth_step": (_I, [C.POINTER(WnSynth), _P]),
+    "viai_wavenet_synth_run": (_I, [C.POINTER(WnSynth), _I, _I, _P]),
     "viai_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "viai_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _D, _D, _D, _F, _P]),
     "viai_colsum_blocks": (_I, [_L, _I]),

@@ -2,6 +2,7 @@
 // All activations are NHWC fp32 ([N][H][W][C], C contiguous); see DESIGN.md.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #define VIAI_WAVE 64
@@ -47,6 +48,22 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// The same sum (different association) without the LDS crossbar: `__shfl_xor` compiles to ds_bpermute_b32, ~100+ cycles each and six
+// of them in a dependent chain per value; four DPP adds (quad swaps, half-row and row mirrors: ALU latency) leave every lane with its
+// 16-lane row sum, four v_readlane fetch the row sums.  For latency-bound kernels that reduce several values per wave.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {

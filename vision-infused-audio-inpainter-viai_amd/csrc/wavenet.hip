@@ -469,63 +469,99 @@ namespace {
 constexpr int WN_MAXB = 8;
 
 // x0[b][:] = cur[b] * w_first + b_first -> ring0[slot(t)];  cur = test_inputs[t] | out[t-1] | 0
+// ONE block.  The time index comes either by value (t_arg >= 0: viai_wavenet_synth_run, the host loop knows it) or from device memory
+// (t_arg < 0: viai_wavenet_synth_step, replayable from a hipGraph): there this kernel also advances it once all of its threads have
+// read it -- `*step` counts the first-conv launches, the other kernels of the time step read t = *step - 1 (a separate one-thread
+// tick launch cost 4.3 us per time step).  A load of the index is a full memory round trip (~1.5 us at these tiny grids) in FRONT of
+// every address computation of every kernel, which is why the by-value path exists.
 __global__ __launch_bounds__(256) void wn_first_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ test_inputs,
                                                        int n_test, const float* __restrict__ out, float* __restrict__ ring, int ring_len,
-                                                       const int* __restrict__ step, int B, int C, int T) {
-    const int t = *step;
+                                                       int* __restrict__ step, int t_arg, int B, int C, int T) {
+    const int t = t_arg >= 0 ? t_arg : *step;
     const int slot = t % ring_len;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * C; i += gridDim.x * 256) {
+    for (int i = threadIdx.x; i < B * C; i += 256) {
         int b = i / C, c = i % C;
         float cur = (t < n_test) ? test_inputs[(size_t)b * n_test + t] : (t > 0 ? out[(size_t)b * T + t - 1] : 0.f);
         ring[((size_t)b * ring_len + slot) * C + c] = cur * w[c] + bias[c];
     }
+    if (t_arg < 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) *step = t + 1;
+    }
 }
 
 // gate: z[b][h] = tanh(A) * sigmoid(Bv),  A/Bv = rows h / h+H of (Wlin . [x(t-2d); x(t-d); x(t)] + b + Wc . c_t + bc)
+// One BLOCK per output pair (h, h+H): the 3C + cin reduction is cut into 16-byte chunks over the 256 threads (reference size:
+// 384 + 20 chunks, at most two per thread, all loads of a thread in flight at once), the 2 x NB partial sums meet in LDS.
+// (The first version gave a WAVE the whole row: six dependent trips of 10 loads per lane on 64 blocks, 10.8 us per launch.)
 template <int NB>
 __global__ __launch_bounds__(256) void wn_gate_kernel(const float* __restrict__ ring, int ring_len, int dil, const float* __restrict__ wlin,
                                                       const float* __restrict__ bconv, const float* __restrict__ wc, const float* __restrict__ bc,
                                                       const float* __restrict__ cond, const float* __restrict__ gadd, float* __restrict__ z,
-                                                      const int* __restrict__ step, int C, int H, int cin, int T) {
-    const int t = *step;
-    const int h = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (h >= H) return;
+                                                      const int* __restrict__ step, int t_arg, int C, int H, int cin, int T) {
+    __shared__ float red[2 * NB][260];
+    const int t = t_arg >= 0 ? t_arg : *step - 1;
+    const int h = blockIdx.x, tid = threadIdx.x;
+    // the epilogue's biases are fetched now, not after the reduction (one memory round trip less on the critical path)
+    float ba = 0.f, bg = 0.f;
+    if ((tid & 31) == 0 && tid < 32 * NB) {
+        ba = bconv[h] + (bc ? bc[h] : 0.f); bg = bconv[h + H] + (bc ? bc[h + H] : 0.f);
+        if (gadd != nullptr) { ba += gadd[(size_t)(tid >> 5) * 2 * H + h]; bg += gadd[(size_t)(tid >> 5) * 2 * H + h + H]; }
+    }
     const int K = 3 * C;
+    const int nq = K / 4, nqc = wc != nullptr ? cin / 4 : 0;
     float a[NB], g[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) { a[b] = 0.f; g[b] = 0.f; }
     const float* wa = wlin + (size_t)h * K;
     const float* wg = wlin + (size_t)(h + H) * K;
-    for (int k = lane * 4; k < K; k += 256) {
-        const int j = k / C, ci = k - j * C;
-        int tt = t - (2 - j) * dil;
-        const f32x4 va = *reinterpret_cast<const f32x4*>(wa + k), vg = *reinterpret_cast<const f32x4*>(wg + k);
-        if (tt >= 0) {
-            const int slot = tt % ring_len;
+    for (int q = tid; q < nq + nqc; q += 256) {
+        f32x4 va, vg;
+        const float* xb;
+        size_t xstride;
+        bool live = true;
+        if (q < nq) {
+            const int k = q * 4;
+            const int j = k / C, ci = k - j * C;
+            const int tt = t - (2 - j) * dil;
+            live = tt >= 0;
+            va = *reinterpret_cast<const f32x4*>(wa + k); vg = *reinterpret_cast<const f32x4*>(wg + k);
+            xb = ring + (size_t)(live ? tt % ring_len : 0) * C + ci;
+            xstride = (size_t)ring_len * C;
+        } else {
+            const int k = (q - nq) * 4;
+            va = *reinterpret_cast<const f32x4*>(wc + (size_t)h * cin + k); vg = *reinterpret_cast<const f32x4*>(wc + (size_t)(h + H) * cin + k);
+            xb = cond + (size_t)t * cin + k;
+            xstride = (size_t)T * cin;
+        }
+        if (live) {
+            f32x4 x[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) x[b] = *reinterpret_cast<const f32x4*>(xb + b * xstride);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(ring + ((size_t)b * ring_len + slot) * C + ci);
-                a[b] += x[0] * va[0] + x[1] * va[1] + x[2] * va[2] + x[3] * va[3];
-                g[b] += x[0] * vg[0] + x[1] * vg[1] + x[2] * vg[2] + x[3] * vg[3];
+                a[b] += x[b][0] * va[0] + x[b][1] * va[1] + x[b][2] * va[2] + x[b][3] * va[3];
+                g[b] += x[b][0] * vg[0] + x[b][1] * vg[1] + x[b][2] * vg[2] + x[b][3] * vg[3];
             }
         }
     }
-    if (wc != nullptr)
-        for (int k = lane * 4; k < cin; k += 256) {
-            const f32x4 va = *reinterpret_cast<const f32x4*>(wc + (size_t)h * cin + k), vg = *reinterpret_cast<const f32x4*>(wc + (size_t)(h + H) * cin + k);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(cond + ((size_t)b * T + t) * cin + k);
-                a[b] += x[0] * va[0] + x[1] * va[1] + x[2] * va[2] + x[3] * va[3];
-                g[b] += x[0] * vg[0] + x[1] * vg[1] + x[2] * vg[2] + x[3] * vg[3];
-            }
+    for (int b = 0; b < NB; ++b) { red[2 * b][tid] = a[b]; red[2 * b + 1][tid] = g[b]; }
+    __syncthreads();
+    // 16 lanes per value: lane `part` adds 16 of the 256 partials, four butterfly steps finish the sum (fixed order)
+    if (tid < 32 * NB) {
+        const int v = tid >> 4, part = tid & 15;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += red[v][part * 16 + ((j + part) & 15)];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float other = __shfl_down(sum, 16, 64);          // the gate half (value 2b + 1) sits 16 lanes up
+        if ((tid & 31) == 0) {
+            const int b = tid >> 5;
+            const float sa = sum + ba, sg = other + bg;
+            z[(size_t)b * H + h] = tanhf(sa) * (1.f / (1.f + expf(-sg)));
         }
-    const float ba = bconv[h] + (bc ? bc[h] : 0.f), bg = bconv[h + H] + (bc ? bc[h + H] : 0.f);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        float sa = wave_sum(a[b]) + ba, sg = wave_sum(g[b]) + bg;
-        if (gadd != nullptr) { sa += gadd[(size_t)b * 2 * H + h]; sg += gadd[(size_t)b * 2 * H + h + H]; }
-        if (lane == 0) z[(size_t)b * H + h] = tanhf(sa) * (1.f / (1.f + expf(-sg)));
     }
 }
 
@@ -534,11 +570,16 @@ template <int NB>
 __global__ __launch_bounds__(256) void wn_out_kernel(const float* __restrict__ z, const float* __restrict__ wout, const float* __restrict__ bout,
                                                      const float* __restrict__ wskip, const float* __restrict__ bskip,
                                                      const float* __restrict__ ring, int ring_len, float* __restrict__ next_ring, int next_len,
-                                                     float* __restrict__ skips, int first, const int* __restrict__ step, int C, int H, int S) {
-    const int t = *step;
+                                                     float* __restrict__ skips, int first, const int* __restrict__ step, int t_arg, int C, int H, int S) {
+    const int t = t_arg >= 0 ? t_arg : *step - 1;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (o >= C + S) return;
     const float* w = o < C ? wout + (size_t)o * H : wskip + (size_t)(o - C) * H;
+    // what the epilogue adds (residual x_t / running skip sum, bias) is fetched NOW by lane b for stream b, beside the dot
+    // products, instead of after the reduction
+    float pre = 0.f;
+    if (lane < NB) pre = o < C ? ring[((size_t)lane * ring_len + (t % ring_len)) * C + o] : (first ? 0.f : skips[(size_t)lane * S + (o - C)]);
+    const float bias = o < C ? bout[o] : bskip[o - C];
     float acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
@@ -553,28 +594,96 @@ __global__ __launch_bounds__(256) void wn_out_kernel(const float* __restrict__ z
     const float r5 = 0.70710678118654752f;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        float v = wave_sum(acc[b]);
+        const float v = wave_sum_dpp(acc[b]);
+        const float p = __shfl(pre, b, 64);
         if (lane == 0) {
             if (o < C) {
-                float res = ring[((size_t)b * ring_len + (t % ring_len)) * C + o];
-                if (next_ring) next_ring[((size_t)b * next_len + (t % next_len)) * C + o] = (v + bout[o] + res) * r5;
+                if (next_ring) next_ring[((size_t)b * next_len + (t % next_len)) * C + o] = (v + bias + p) * r5;
             } else {
-                float s = v + bskip[o - C];
-                float* p = skips + (size_t)b * S + (o - C);
-                *p = first ? s : (*p + s) * r5;
+                const float sv = v + bias;
+                skips[(size_t)b * S + (o - C)] = first ? sv : (p + sv) * r5;
             }
         }
     }
 }
 
-// head: relu -> W1 -> relu -> W2 -> MoL sample with injected uniforms -> out[b][t]; one block per stream
-__global__ __launch_bounds__(256) void wn_head_kernel(const float* __restrict__ skips, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                      const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ u1,
-                                                      const float* __restrict__ u2, float* __restrict__ out, float* __restrict__ yhat_dbg,
-                                                      const int* __restrict__ step, int S, int OC, int T, float log_scale_min) {
-    extern __shared__ float sm[];          // [S] relu(skips), [S] hidden, [OC] logits
+// head: relu -> W1 -> relu -> W2 -> MoL sample with injected uniforms -> out[b][t]; one block of 16 waves per stream.
+// At one block per stream the kernel is a chain of load latencies, so everything that does not depend on the previous stage is
+// fetched up front (uniforms, biases) and every stage has all of its rows in flight at once: a wave takes 16 rows, each read
+// coalesced (16 bytes per lane).  (A row per THREAD, 256 strided loads in sequence: 17.7 us; four rows per trip: 49 us.)
+__global__ __launch_bounds__(1024) void wn_head_kernel(const float* __restrict__ skips, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ u1,
+                                                       const float* __restrict__ u2, float* __restrict__ out, float* __restrict__ yhat_dbg,
+                                                       const int* __restrict__ step, int t_arg, int S, int OC, int T, float log_scale_min) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];          // [S] relu(skips), [S] hidden, [OC] logits, [OC/3 + 1] uniforms
+    float* xin = sm; float* hid = sm + S; float* yo = sm + 2 * S; float* us = yo + ((OC + 3) & ~3);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    constexpr int RB = 16;
+    const int K = OC / 3;
+    // Stage order = what can be in flight together: W1's rows depend on nothing, so they (and the biases) are requested before the
+    // time index or the skip sums arrive; W2's rows are requested as soon as W1's registers are free, i.e. before W1's reductions
+    // and the barrier.  A wave holds ONE 16-row batch at a time (16 waves at 128 registers each: holding both layers spilt to scratch,
+    // 38 us per launch).  Needs S <= 256 and out_ch <= 256 (the reference: 256 / 30); wn_head_generic_kernel takes anything else.
+    const int k0 = lane * 4;
+    const int r1 = wave * RB, r2 = wave * RB;
+    const float bv1 = b1[min(r1 + (lane & (RB - 1)), S - 1)], bv2 = b2[min(r2 + (lane & (RB - 1)), OC - 1)];
+    f32x4 p[RB];
+    if (r1 < S && k0 < S) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) p[r] = *reinterpret_cast<const f32x4*>(w1 + (size_t)min(r1 + r, S - 1) * S + k0);
+    }
+    const int t = t_arg >= 0 ? t_arg : *step - 1;
+    for (int k = tid; k < S; k += 1024) { float v = skips[(size_t)b * S + k]; xin[k] = v > 0.f ? v : 0.f; }
+    if (tid < K) us[tid] = u1[((size_t)b * T + t) * K + tid];
+    if (tid == K) us[K] = u2[(size_t)b * T + t];
+    __syncthreads();
+    // one 16-row batch: acc[r] = row (r0 + r) . x with the row slices already in registers (S <= 256: one 16-byte slice per lane)
+    auto batch = [&](const float* __restrict__, const f32x4 (&pre)[RB], const float* x, int, float (&acc)[RB]) {
+        const f32x4 xv = k0 < S ? *reinterpret_cast<const f32x4*>(x + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = k0 < S ? pre[r][0] * xv[0] + pre[r][1] * xv[1] + pre[r][2] * xv[2] + pre[r][3] * xv[3] : 0.f;
+    };
+    auto finish = [&](const float (&acc)[RB], float bv, int h0, int n_out, auto&& emit) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float v = wave_sum_dpp(acc[r]) + __shfl(bv, r, 64);
+            if (lane == 0 && h0 + r < n_out) emit(h0 + r, v);
+        }
+    };
+    auto hid_out = [&](int h, float v) { hid[h] = v > 0.f ? v : 0.f; };
+    auto logit_out = [&](int o, float v) { yo[o] = v; if (yhat_dbg) yhat_dbg[((size_t)b * T + t) * OC + o] = v; };
+    float acc[RB];
+    if (r1 < S) batch(w1, p, xin, S, acc);
+    if (r2 < OC && k0 < S) {                                   // W2's first batch: in flight across W1's reductions and the barrier
+#pragma unroll
+        for (int r = 0; r < RB; ++r) p[r] = *reinterpret_cast<const f32x4*>(w2 + (size_t)min(r2 + r, OC - 1) * S + k0);
+    }
+    if (r1 < S) finish(acc, bv1, r1, S, hid_out);
+    __syncthreads();
+    if (r2 < OC) { batch(w2, p, hid, OC, acc); finish(acc, bv2, r2, OC, logit_out); }
+    __syncthreads();
+    if (tid == 0) {
+        float best = -INFINITY; int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            float v = yo[k] - logf(-logf(us[k]));
+            if (v > best) { best = v; arg = k; }
+        }
+        const float m = yo[K + arg], ls = fmaxf(yo[2 * K + arg], log_scale_min), u = us[K];
+        float x = m + expf(ls) * (logf(u) - logf(1.f - u));
+        out[(size_t)b * T + t] = fminf(fmaxf(x, -1.f), 1.f);
+    }
+}
+
+// any S / out_ch: a row per thread (the first version of the head)
+__global__ __launch_bounds__(256) void wn_head_generic_kernel(const float* __restrict__ skips, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ u1,
+                                                              const float* __restrict__ u2, float* __restrict__ out, float* __restrict__ yhat_dbg,
+                                                              const int* __restrict__ step, int t_arg, int S, int OC, int T, float log_scale_min) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     float* xin = sm; float* hid = sm + S; float* yo = sm + 2 * S;
-    const int b = blockIdx.x, t = *step, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int t = t_arg >= 0 ? t_arg : *step - 1;
     for (int k = tid; k < S; k += 256) { float v = skips[(size_t)b * S + k]; xin[k] = v > 0.f ? v : 0.f; }
     __syncthreads();
     for (int h = tid; h < S; h += 256) {
@@ -603,38 +712,55 @@ __global__ __launch_bounds__(256) void wn_head_kernel(const float* __restrict__ 
     }
 }
 
-__global__ void wn_tick_kernel(int* step) { *step += 1; }
-
 template <int NB>
-int wn_step_impl(const viai_wn_synth* s, hipStream_t st) {
+int wn_step_impl(const viai_wn_synth* s, int t_arg, hipStream_t st) {
     const int C = s->C, H = s->G / 2, S = s->S;
     const viai_wn_layer* L = s->layers;
-    VIAI_LAUNCH(wn_first_kernel, dim3((s->B * C + 255) / 256), dim3(256), 0, st, s->w_first, s->b_first, s->test_inputs, s->n_test, s->out,
-                L[0].ring, L[0].ring_len, s->step, s->B, C, s->T);
+    VIAI_LAUNCH(wn_first_kernel, dim3(1), dim3(256), 0, st, s->w_first, s->b_first, s->test_inputs, s->n_test, s->out,
+                L[0].ring, L[0].ring_len, s->step, t_arg, s->B, C, s->T);
     for (int l = 0; l < s->n_layers; ++l) {
-        VIAI_LAUNCH(wn_gate_kernel<NB>, dim3((H + 3) / 4), dim3(256), 0, st, L[l].ring, L[l].ring_len, L[l].dilation, L[l].w_conv, L[l].b_conv,
-                    L[l].w_c, L[l].b_c, s->cond, L[l].g_add, s->z, s->step, C, H, s->cin, s->T);
+        VIAI_LAUNCH(wn_gate_kernel<NB>, dim3(H), dim3(256), 0, st, L[l].ring, L[l].ring_len, L[l].dilation, L[l].w_conv, L[l].b_conv,
+                    L[l].w_c, L[l].b_c, s->cond, L[l].g_add, s->z, s->step, t_arg, C, H, s->cin, s->T);
         const bool last = (l == s->n_layers - 1);
         VIAI_LAUNCH(wn_out_kernel<NB>, dim3((C + S + 3) / 4), dim3(256), 0, st, s->z, L[l].w_out, L[l].b_out, L[l].w_skip, L[l].b_skip,
                     L[l].ring, L[l].ring_len, last ? (float*)nullptr : L[l + 1].ring, last ? 1 : L[l + 1].ring_len, s->skips, l == 0 ? 1 : 0,
-                    s->step, C, H, S);
+                    s->step, t_arg, C, H, S);
     }
-    VIAI_LAUNCH(wn_head_kernel, dim3(s->B), dim3(256), (2 * S + s->out_ch) * sizeof(float), st, s->skips, s->w_l1, s->b_l1, s->w_l2, s->b_l2,
-                s->u1, s->u2, s->out, s->yhat_dbg, s->step, S, s->out_ch, s->T, s->log_scale_min);
-    VIAI_LAUNCH(wn_tick_kernel, dim3(1), dim3(1), 0, st, s->step);
+    if (S <= 256 && s->out_ch <= 256)
+        VIAI_LAUNCH(wn_head_kernel, dim3(s->B), dim3(1024), (2 * S + ((s->out_ch + 3) & ~3) + s->out_ch / 3 + 1) * sizeof(float), st, s->skips, s->w_l1, s->b_l1, s->w_l2, s->b_l2,
+                    s->u1, s->u2, s->out, s->yhat_dbg, s->step, t_arg, S, s->out_ch, s->T, s->log_scale_min);
+    else
+        VIAI_LAUNCH(wn_head_generic_kernel, dim3(s->B), dim3(256), (2 * S + s->out_ch) * sizeof(float), st, s->skips, s->w_l1, s->b_l1, s->w_l2, s->b_l2,
+                    s->u1, s->u2, s->out, s->yhat_dbg, s->step, t_arg, S, s->out_ch, s->T, s->log_scale_min);
     return viai_launch_status();
+}
+
+bool wn_valid(const viai_wn_synth* s) {
+    return s && s->B >= 1 && s->B <= WN_MAXB && s->C % 4 == 0 && (s->G / 2) % 4 == 0 && s->cin % 4 == 0 && s->S % 4 == 0 && s->out_ch % 3 == 0 && s->n_layers >= 1;
+}
+
+int wn_step(const viai_wn_synth* s, int t_arg, hipStream_t st) {
+    switch (s->B) {
+    case 1: return wn_step_impl<1>(s, t_arg, st);
+    case 2: return wn_step_impl<2>(s, t_arg, st);
+    case 4: return wn_step_impl<4>(s, t_arg, st);
+    case 8: return wn_step_impl<8>(s, t_arg, st);
+    default: return (int)hipErrorInvalidValue;
+    }
 }
 
 }  // namespace
 
 extern "C" int viai_wavenet_synth_step(const viai_wn_synth* s, void* stream) {
-    if (!s || s->B < 1 || s->B > WN_MAXB || s->C % 4 || (s->G / 2) % 4 || s->cin % 4 || s->out_ch % 3 || s->n_layers < 1) return (int)hipErrorInvalidValue;
-    hipStream_t st = (hipStream_t)stream;
-    switch (s->B) {
-    case 1: return wn_step_impl<1>(s, st);
-    case 2: return wn_step_impl<2>(s, st);
-    case 4: return wn_step_impl<4>(s, st);
-    case 8: return wn_step_impl<8>(s, st);
-    default: return (int)hipErrorInvalidValue;
+    if (!wn_valid(s)) return (int)hipErrorInvalidValue;
+    return wn_step(s, -1, (hipStream_t)stream);
+}
+
+extern "C" int viai_wavenet_synth_run(const viai_wn_synth* s, int t0, int n_steps, void* stream) {
+    if (!wn_valid(s) || t0 < 0 || n_steps < 0 || t0 + n_steps > s->T) return (int)hipErrorInvalidValue;
+    for (int t = t0; t < t0 + n_steps; ++t) {
+        const int e = wn_step(s, t, (hipStream_t)stream);
+        if (e != 0) return e;
     }
+    return 0;
 }

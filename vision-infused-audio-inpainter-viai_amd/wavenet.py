@@ -387,11 +387,12 @@ class WaveNet(nn.Module):
 
     @torch.no_grad()
     def incremental_forward(self, initial_input=None, c=None, g=None, T=100, test_inputs=None, tqdm=lambda x: x, softmax=True,
-                            quantize=True, log_scale_min=-7.0, uniforms=None, use_graph=True, return_logits=False):
+                            quantize=True, log_scale_min=-7.0, uniforms=None, use_graph=False, return_logits=False):
         """Sample-by-sample synthesis (wavenet.py:237-364) for the scalar-input / MoL configuration.
 
-        Each time step is ONE call of `viai_wavenet_synth_step` (first conv, 2 GEMV-batch kernels per layer, head +
-        MoL sample); the time index lives on the device, so the step is captured once into a HIP graph and replayed.
+        A time step = first conv, 2 GEMV-batch kernels per layer, head + MoL sample.  Default: `viai_wavenet_synth_run` loops over the
+        steps in C with the time index passed by value; `use_graph=True`: `viai_wavenet_synth_step` (time index on the device, the first
+        conv advances it) captured once into a HIP graph and replayed.
         `uniforms=(u1 (B,T,10), u2 (B,T))` injects the sampler's two uniform draws (parity tests); default torch.rand."""
         import ctypes as Ct
         lib = _lib.load()
@@ -454,7 +455,7 @@ class WaveNet(nn.Module):
         logits = torch.zeros(B, T, self.out_channels, device=dev) if return_logits else None
         z = torch.zeros(B, G // 2, device=dev)
         skips = torch.zeros(B, S, device=dev)
-        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)        # time index, advanced on the device by each step
         st = _lib.WnSynth()
         st.B, st.C, st.G, st.S, st.cin, st.n_layers, st.out_ch, st.T = B, Cc, G, S, (cond.size(2) if cond is not None else 4), len(self.conv_layers), self.out_channels, T
         st.n_test = tin.size(1) if tin is not None else 0
@@ -469,6 +470,7 @@ class WaveNet(nn.Module):
         st.yhat_dbg = logits.data_ptr() if logits is not None else None
         ref = Ct.byref(st)
         if use_graph and T > 2:
+            # device-side time index: one step captured into a HIP graph and replayed (every kernel starts with a load of the index)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -480,8 +482,10 @@ class WaveNet(nn.Module):
             for _ in tqdm(range(T - 1)):
                 graph.replay()
         else:
-            for _ in tqdm(range(T)):
-                _lib.check(lib.viai_wavenet_synth_step(ref, torch.cuda.current_stream().cuda_stream), "viai_wavenet_synth_step")
+            # default: the C side loops over the time steps and hands every kernel its time index by value
+            chunk = 64
+            for t0 in tqdm(range(0, T, chunk)):
+                _lib.check(lib.viai_wavenet_synth_run(ref, t0, min(chunk, T - t0), torch.cuda.current_stream().cuda_stream), "viai_wavenet_synth_run")
         torch.cuda.current_stream().synchronize()
         del keep
         res = out.unsqueeze(1)                                                        # (B, 1, T) like the reference
