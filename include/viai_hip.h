@@ -312,6 +312,26 @@ int viai_mel_denorm_amp(const float* S, float* out, long n, float min_level_db, 
 int viai_l2_ranks(const float* clips, const float* captions, int n_clips, int n_captions, int dim,
                   int* ranks, int* top1, float* dist, void* stream);
 
+/* -------------------------------------------------- fused Cin = 1 conv + BatchNorm2d(train) + activation layer (ABI v5)
+ * MelEncoder.conv1 + bn1 + LeakyReLU (Inpainting_Networks.py:55,71) and MelDiscriminator's first block (Discriminator_Networks.py:17-19,
+ * 38-39): with 4 .. 9 taps and one input channel the convolution is cheaper to RECOMPUTE than its 32 / 64-channel output is to write
+ * and read back, so the pre-BatchNorm tensor y never exists in memory (same arithmetic, same order as viai_conv2d_fwd + viai_bn_*):
+ *   fwd(z = NULL): BatchNorm partials (layout of viai_conv2d_fwd's stat_part, geometry of viai_conv2d_stat_geom) -> viai_bn_finalize
+ *   fwd(stat_part = NULL): z = act(scale * conv(x) + shift)
+ *   bwd: partial sums from (dz, recomputed y) -> sums = {k0, k1}, dgamma, dbeta;  dy only if a data gradient needs it in memory
+ *        (`training` as in viai_bn_act_bwd; part: 2 * Cout * nblk floats, nblk from viai_conv2d_stat_geom)
+ *   wgrad: dw (+)= sum dy * x with dy formed on the fly from dz, y and sums
+ * w: the packed image of viai_conv2d_pack (= the torch layout for this kind).                                                      */
+int viai_conv2d_cin1_bn_ok(const viai_conv2d* c);
+int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, float* stat_part,
+                            const float* scale, const float* shift, float* z, int act, void* stream);
+int viai_conv2d_cin1_bn_bwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, const float* dz,
+                            const float* mean, const float* invstd, const float* scale, const float* shift, float* part,
+                            float* sums, float* dgamma, float* dbeta, float* dy, int act, int training, void* stream);
+int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, const float* w, const float* bias, const float* dz,
+                              const float* mean, const float* scale, const float* shift, const float* sums, float* ws,
+                              float* dw, int accumulate, int act, void* stream);
+
 /* -------------------------------------------------- launch plans: the train step recorded once, replayed from C
  * Replaces the per-launch host work of `model.optimize_parameters()` (train_whole_sync.py:76).  Protocol:
  *   viai_plan_log_begin();  <stream-capture the step: every library launch notes (kernel, stream)>;  n = viai_plan_log_end();

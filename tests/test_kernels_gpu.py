@@ -309,6 +309,44 @@ def test_conv_bn_act_train_matches_torch_cpu(act, shape):
     assert int(bng.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("need_dx", [False, True])
+@pytest.mark.parametrize("geom", [(3, 80, 96, 32, (3, 3), (2, 2), (1, 1)), (2, 64, 72, 64, (1, 4), (1, 2), (0, 1)), (5, 33, 37, 32, (3, 3), (2, 2), (1, 1))])
+def test_cin1_conv_bn_layer_without_the_stored_preactivation(geom, need_dx):
+    """E.conv1 / D.conv1 (Inpainting_Networks.py:55,71; Discriminator_Networks.py:17-19): Cin = 1 conv -> BatchNorm2d(train) ->
+    LeakyReLU on the fused path (viai_conv2d_cin1_bn_*: the conv output is never stored, forward and backward recompute it from x;
+    the weight gradient forms dy on the fly, dy is written only when a data gradient is asked for).  Forward, dw, dgamma, dbeta,
+    dx and the running statistics against fp64 within 5x of torch-CPU-fp32's own rounding error; the third geometry has a ragged last
+    statistics block (pixels not a multiple of 256)."""
+    from viai_amd import ops, _lib
+    N, H, W, Co, k, s_, p_ = geom
+    x = O.cf_uniform("c1.x", (N, 1, H, W), 0, 1)
+    w = O.cf_std("c1.w", (Co, 1) + k, 0.3)
+    g = O.cf_uniform("c1.g", (Co,), 0.8, 1.2)
+    b = O.cf_uniform("c1.b", (Co,), -0.1, 0.1)
+
+    def run(dt):
+        xs, ws, gs, bs = [t.clone().to(dt).requires_grad_(True) for t in (x, w, g, b)]
+        z = F.leaky_relu(F.batch_norm(F.conv2d(xs, ws, None, stride=s_, padding=p_), None, None, gs, bs, True, 0.1, 1e-5), 0.2)
+        gy = O.cf_uniform("c1.gy", tuple(z.shape), -1, 1).to(dt)
+        return (z,) + torch.autograd.grad(z, [xs, ws, gs, bs], grad_outputs=gy), gy
+    (truth, _), (cpu32, gy) = run(torch.float64), run(torch.float32)
+    bn = torch.nn.BatchNorm2d(Co).cuda().train()
+    bn.weight.data.copy_(g); bn.bias.data.copy_(b)
+    xg = nhwc(x).requires_grad_(need_dx)
+    wg = w.cuda().requires_grad_(True)
+    d = ops.conv_desc(N, H, W, 1, 0, Co, k[0], k[1], s_[0], s_[1], p_[0], p_[1], 0, 1, 1, -1, -1)
+    assert _lib.load().viai_conv2d_cin1_bn_ok(d["ref"]) == 1
+    zg = ops.conv_bn_act(xg, wg, None, bn, kernel=k, stride=s_, padding=p_, act=ops.ACT_LRELU)
+    zg.backward(nhwc(gy))
+    hip = (nchw(zg), nchw(xg.grad) if need_dx else None, wg.grad, bn.weight.grad, bn.bias.grad)
+    for nm, h, c32, t in zip(("z", "dx", "dw", "dgamma", "dbeta"), hip, cpu32, truth):
+        if h is not None:
+            assert relerr(h, t) < 5 * relerr(c32, t) + 1e-6, (nm, relerr(h, t), relerr(c32, t))
+    ref = torch.nn.BatchNorm2d(Co).double().train()
+    ref(F.conv2d(x.double(), w.double(), None, stride=s_, padding=p_))
+    assert relerr(bn.running_mean, ref.running_mean) < 1e-5 and relerr(bn.running_var, ref.running_var) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 10, 8, 64), (2, 256, 5, 4, 128), (2, 64, 20, 16, 128), (4, 32, 40, 32, 32)])
 def test_fused_layer_accuracy_against_fp64(shape):
     """one ConvTranspose2d -> BN(train) -> ReLU layer, forward and all gradients, measured against an fp64

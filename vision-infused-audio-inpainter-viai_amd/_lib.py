@@ -133,6 +133,10 @@ SIGNATURES = {
     "viai_ema_update": (_I, [_P, _P, _L, _D, _P]),
     "viai_mel_denorm_amp": (_I, [_P, _P, _L, _F, _P]),
     "viai_l2_ranks": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "viai_conv2d_cin1_bn_ok": (_I, [_CP]),
+    "viai_conv2d_cin1_bn_fwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "viai_conv2d_cin1_bn_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "viai_conv2d_cin1_bn_wgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "viai_plan_log_begin": (_I, []),
     "viai_plan_log_end": (_I, []),
     "viai_plan_build": (_I, [_P, _P, C.POINTER(C.c_void_p)]),

@@ -390,6 +390,13 @@ extern "C" int viai_bn_act_bwd_amax(const float* dz, const float* y, const float
     return viai_launch_status();
 }
 
+// the final pass alone (conv_direct.hip: the fused Cin = 1 layer produces the partials itself)
+int viai_bn_bwd_final_launch(const float* part, int nblk, int C, long M, const float* mean, const float* invstd, const float* scale,
+                             int training, float* sums, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training, sums, dgamma, dbeta, accumulate);
+    return viai_launch_status();
+}
+
 extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mean, const float* invstd,
                                const float* scale, const float* shift, float* part, float* sums,
                                float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,

@@ -19,6 +19,9 @@ struct DirectArgs {
     int M;                            // N*OH*OW
     int nblk;
     int act; float slope;
+    // fused Cin = 1 conv + BatchNorm(train) + activation layer (viai_conv2d_cin1_bn_*): y is never stored, it is recomputed from x
+    const float* scale; const float* shift; const float* mean; const float* invstd; const float* sums; const float* dz;
+    float* part;
 };
 
 __device__ __forceinline__ int tap_dy(const DirectArgs& a, int r) { return a.transposed ? a.ph - r : r - a.ph; }
@@ -39,7 +42,10 @@ __device__ __forceinline__ void fast_divmod(int q, int d, float inv_d, int& quo,
 // y[p][co] = sum_t x[p_t] * w[co][t];  thread = (pixel lane, 4 output channels)
 constexpr int CIN1_PB = 256;   // pixels per block == rows_per_blk of the BN partials
 
-template <int CG, int KH, int KW>   // channel groups of 4 (Cout = 4*CG)
+// MODE 0: y (+ BatchNorm partials when a.stat);  MODE 1: the partials only, y is NOT stored;  MODE 2: z = act(scale * y + shift)
+// (modes 1 + 2 = the fused conv + BatchNorm(train) + activation layer: with K = 4 .. 9 the conv is cheaper to recompute than its
+// 64-channel output is to write and read back -- D.conv1: 134 MB per pass over y)
+template <int CG, int KH, int KW, int MODE = 0>   // channel groups of 4 (Cout = 4*CG)
 __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
     constexpr int PG = 256 / CG;
     constexpr int IT = CIN1_PB / PG;
@@ -54,6 +60,8 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
     }
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + cg * 4);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE == 2) { sc = *reinterpret_cast<const f32x4*>(a.scale + cg * 4); sh = *reinterpret_cast<const f32x4*>(a.shift + cg * 4); }
     const int p0 = blockIdx.x * CIN1_PB;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     f32x4 vals[IT];
@@ -86,18 +94,25 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
                     v += xv * wv[r * KW + q];
                 }
             }
-            if (a.stat == nullptr) {
+            if constexpr (MODE == 2) {
+                f32x4 z;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = viai_act(v[e], a.act, a.slope);
+                for (int e = 0; e < 4; ++e) z[e] = viai_act(v[e] * sc[e] + sh[e], a.act, a.slope);
+                *reinterpret_cast<f32x4*>(a.y + (size_t)p * a.Cout + cg * 4) = z;
+            } else {
+                if (a.stat == nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = viai_act(v[e], a.act, a.slope);
+                }
+                if constexpr (MODE == 0) *reinterpret_cast<f32x4*>(a.y + (size_t)p * a.Cout + cg * 4) = v;
+                sum += v;
             }
-            *reinterpret_cast<f32x4*>(a.y + (size_t)p * a.Cout + cg * 4) = v;
-            sum += v;
         } else {
             v = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         vals[it] = v;
     }
-    if (a.stat == nullptr) return;
+    if (MODE == 2 || a.stat == nullptr) return;
     // block-local (mean, M2) per channel over the valid pixels of this block
     const int cnt = min(CIN1_PB, a.M - p0);
     *reinterpret_cast<f32x4*>(&red[pg][cg * 4]) = sum;
@@ -121,6 +136,91 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
         for (int e = 0; e < 4; ++e) {
             a.stat[(size_t)(cg * 4 + e) * a.nblk + blockIdx.x] = mean[e];
             a.stat[(size_t)(a.Cout + cg * 4 + e) * a.nblk + blockIdx.x] = t[e];
+        }
+    }
+}
+
+__device__ __forceinline__ float dact(float pre, int act, float slope) {
+    if (act == VIAI_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
+    if (act == VIAI_ACT_LRELU) return pre > 0.f ? 1.f : slope;
+    if (act == VIAI_ACT_SIGMOID) { float s_ = 1.f / (1.f + __expf(-pre)); return s_ * (1.f - s_); }
+    return 1.f;
+}
+
+// Backward of the fused Cin = 1 conv + BatchNorm(train) + activation layer with y RECOMPUTED from x (same expression, same order as
+// the forward kernel):  dp = dz * act'(scale * y + shift)
+//   APPLY = false: part[blk][0][c] = sum dp, part[blk][1][c] = sum dp * (y - mean) * invstd over the block's 256 pixels (the layout
+//                  bn_bwd_final_kernel reduces);
+//   APPLY = true:  dy = scale * dp + k1 * (y - mean) + k0  (sums = {k0, k1}) -- only where a data gradient needs dy in memory (the
+//                  frozen-D pass of the G step); the weight gradient applies it on the fly (cin1_wgrad_kernel<.., true>).
+template <int CG, int KH, int KW, bool APPLY>
+__global__ __launch_bounds__(256) void cin1_bn_bwd_kernel(const DirectArgs a) {
+    constexpr int PG = 256 / CG;
+    constexpr int IT = CIN1_PB / PG;
+    constexpr int T = KH * KW;
+    __shared__ float red[2][PG][CG * 4];
+    const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
+    f32x4 wv[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        wv[t][0] = a.w[(cg * 4 + 0) * T + t]; wv[t][1] = a.w[(cg * 4 + 1) * T + t];
+        wv[t][2] = a.w[(cg * 4 + 2) * T + t]; wv[t][3] = a.w[(cg * 4 + 3) * T + t];
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + cg * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + cg * 4), sh = *reinterpret_cast<const f32x4*>(a.shift + cg * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + cg * 4);
+    f32x4 is = {0.f, 0.f, 0.f, 0.f}, k0 = is, k1 = is;
+    if constexpr (APPLY) { k0 = *reinterpret_cast<const f32x4*>(a.sums + cg * 4); k1 = *reinterpret_cast<const f32x4*>(a.sums + a.Cout + cg * 4); }
+    else is = *reinterpret_cast<const f32x4*>(a.invstd + cg * 4);
+    const int p0 = blockIdx.x * CIN1_PB;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    int ox, oy, n;
+    {
+        const int p = p0 + pg;
+        ox = p % a.OW; const int r_ = p / a.OW; oy = r_ % a.OH; n = r_ / a.OH;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int p = p0 + it * PG + pg;
+        if (it > 0) {
+            ox += PG;
+            while (ox >= a.OW) { ox -= a.OW; if (++oy >= a.OH) { oy = 0; ++n; } }
+        }
+        if (p < a.M) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.dz + (size_t)p * a.Cout + cg * 4);
+            f32x4 v = bv;
+            const float* xb = a.x + (size_t)n * a.IH * a.IW;
+            const int iy0 = oy * a.sh, ix0 = ox * a.sw;
+#pragma unroll
+            for (int r = 0; r < KH; ++r) {
+                const int iy = iy0 + tap_dy(a, r);
+                const bool yok = (unsigned)iy < (unsigned)a.IH;
+#pragma unroll
+                for (int q = 0; q < KW; ++q) {
+                    const int ix = ix0 + tap_dx(a, q);
+                    float xv = (yok && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
+                    v += xv * wv[r * KW + q];
+                }
+            }
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dp = g[e] * dact(v[e] * sc[e] + sh[e], a.act, a.slope);
+                if constexpr (APPLY) o[e] = sc[e] * dp + (k1[e] * (v[e] - mu[e]) + k0[e]);
+                else { s1[e] += dp; s2[e] += dp * (v[e] - mu[e]) * is[e]; }
+            }
+            if constexpr (APPLY) *reinterpret_cast<f32x4*>(a.dx + (size_t)p * a.Cout + cg * 4) = o;
+        }
+    }
+    if constexpr (!APPLY) {
+        *reinterpret_cast<f32x4*>(&red[0][pg][cg * 4]) = s1;
+        *reinterpret_cast<f32x4*>(&red[1][pg][cg * 4]) = s2;
+        __syncthreads();
+        if (pg < 2) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < PG; ++k) t += *reinterpret_cast<f32x4*>(&red[pg][k][cg * 4]);
+            *reinterpret_cast<f32x4*>(a.part + ((size_t)blockIdx.x * 2 + pg) * a.Cout + cg * 4) = t;
         }
     }
 }
@@ -176,7 +276,8 @@ __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
 }
 
 // ws[z][t][co] = sum over this block's pixels of dy[p][co] * x[p_t]   (Cin == 1)
-template <int CG, int KH, int KW>
+// FUSED: dy is not read but formed from dz, the recomputed y and the BatchNorm backward coefficients (see cin1_bn_bwd_kernel)
+template <int CG, int KH, int KW, bool FUSED = false>
 __global__ __launch_bounds__(256) void cin1_wgrad_kernel(const DirectArgs a, int pix_per_blk) {
     constexpr int PG = 256 / CG;
     constexpr int T = KH * KW;
@@ -185,13 +286,27 @@ __global__ __launch_bounds__(256) void cin1_wgrad_kernel(const DirectArgs a, int
     f32x4 acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 wv[FUSED ? T : 1];
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sc = bv, sh = bv, mu = bv, k0 = bv, k1 = bv;
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            wv[t][0] = a.w[(cg * 4 + 0) * T + t]; wv[t][1] = a.w[(cg * 4 + 1) * T + t];
+            wv[t][2] = a.w[(cg * 4 + 2) * T + t]; wv[t][3] = a.w[(cg * 4 + 3) * T + t];
+        }
+        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + cg * 4);
+        sc = *reinterpret_cast<const f32x4*>(a.scale + cg * 4); sh = *reinterpret_cast<const f32x4*>(a.shift + cg * 4);
+        mu = *reinterpret_cast<const f32x4*>(a.mean + cg * 4);
+        k0 = *reinterpret_cast<const f32x4*>(a.sums + cg * 4); k1 = *reinterpret_cast<const f32x4*>(a.sums + a.Cout + cg * 4);
+    }
     const int p0 = blockIdx.x * pix_per_blk;
     const int p1 = min(p0 + pix_per_blk, a.M);
     for (int p = p0 + pg; p < p1; p += PG) {
         int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
-        f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.Cout + cg * 4);
+        f32x4 d = *reinterpret_cast<const f32x4*>((FUSED ? a.dz : a.dy) + (size_t)p * a.Cout + cg * 4);
         const float* xb = a.x + (size_t)n * a.IH * a.IW;
         const int iy0 = oy * a.sh, ix0 = ox * a.sw;
+        float xt[T];
 #pragma unroll
         for (int r = 0; r < KH; ++r) {
             const int iy = iy0 + tap_dy(a, r);
@@ -199,10 +314,21 @@ __global__ __launch_bounds__(256) void cin1_wgrad_kernel(const DirectArgs a, int
 #pragma unroll
             for (int q = 0; q < KW; ++q) {
                 const int ix = ix0 + tap_dx(a, q);
-                float xv = (yok && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
-                acc[r * KW + q] += d * xv;
+                xt[r * KW + q] = (yok && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
             }
         }
+        if constexpr (FUSED) {
+            f32x4 v = bv;
+#pragma unroll
+            for (int t = 0; t < T; ++t) v += xt[t] * wv[t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dp = d[e] * dact(v[e] * sc[e] + sh[e], a.act, a.slope);
+                d[e] = sc[e] * dp + (k1[e] * (v[e] - mu[e]) + k0[e]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] += d * xt[t];
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) *reinterpret_cast<f32x4*>(smem + ((size_t)pg * T + t) * a.Cout + cg * 4) = acc[t];
@@ -724,6 +850,100 @@ int viai_cin1_wgrad(const viai_conv2d* c, const float* x, const float* dy, float
     int e = viai_launch_status();
     if (e) return e;
     // torch layout [Cout][1][kh][kw] -> co*T + t
+    return viai_wgrad_reduce(ws, dw, nb, T, c->Cout, 1, T, T, accumulate, st);
+}
+
+// ---- fused Cin = 1 conv + BatchNorm(train) + activation layer (E.conv1, D.conv1): entry points of the public ABI ----------------
+int viai_bn_bwd_final_launch(const float* part, int nblk, int C, long M, const float* mean, const float* invstd, const float* scale,
+                             int training, float* sums, float* dgamma, float* dbeta, int accumulate, hipStream_t st);
+
+extern "C" int viai_conv2d_cin1_bn_ok(const viai_conv2d* c) {
+    if (c == nullptr || c->C1 + c->C2 != 1 || c->transposed) return 0;
+    if (!(c->Cout == 32 || c->Cout == 64 || c->Cout == 128)) return 0;
+    const bool win = (c->kh == 3 && c->kw == 3) || (c->kh == 1 && c->kw == 4) || (c->kh == 1 && c->kw == 1) || (c->kh == 1 && c->kw == 3) ||
+                     (c->kh == 1 && c->kw == 6);
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_CIN1_BN_FUSED"); on = e ? atoi(e) : 1; }
+    return win && on;
+}
+
+// z == NULL: BatchNorm partials only (the conv output is not stored);  z != NULL: z = act(scale * conv(x) + shift)
+extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, float* stat_part,
+                                       const float* scale, const float* shift, float* z, int act, void* stream) {
+    if (!viai_conv2d_cin1_bn_ok(c) || (z == nullptr) == (stat_part == nullptr)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    DirectArgs a = make_args(c);
+    a.x = x; a.w = w; a.bias = bias; a.y = z; a.stat = stat_part; a.scale = scale; a.shift = shift; a.act = act; a.slope = 0.2f;
+    a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
+#define CALL(KH, KW)                                                                                                               \
+    if (z == nullptr) {                                                                                                            \
+        if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                       \
+        else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                 \
+        else VIAI_LAUNCH((cin1_fwd_kernel<32, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                                    \
+    } else {                                                                                                                       \
+        if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 2>), dim3(a.nblk), dim3(256), 0, st, a);                       \
+        else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 2>), dim3(a.nblk), dim3(256), 0, st, a);                 \
+        else VIAI_LAUNCH((cin1_fwd_kernel<32, KH, KW, 2>), dim3(a.nblk), dim3(256), 0, st, a);                                    \
+    }
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
+    return viai_launch_status();
+}
+
+// BatchNorm(train) + activation backward of the fused layer: partial sums from (dz, recomputed y) -> k0 / k1, dgamma, dbeta (the
+// same final kernel as viai_bn_act_bwd); dy (optional) is written only when a data gradient needs it in memory.
+// part: 2 * Cout * ceil(M / 256) floats; sums: 2 * Cout floats (read by viai_conv2d_cin1_bn_wgrad).
+extern "C" int viai_conv2d_cin1_bn_bwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, const float* dz,
+                                       const float* mean, const float* invstd, const float* scale, const float* shift, float* part,
+                                       float* sums, float* dgamma, float* dbeta, float* dy, int act, int training, void* stream) {
+    if (!viai_conv2d_cin1_bn_ok(c)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    DirectArgs a = make_args(c);
+    a.x = x; a.w = w; a.bias = bias; a.dz = dz; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.part = part;
+    a.sums = sums; a.dx = dy; a.act = act; a.slope = 0.2f;
+    a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
+#define CALL(KH, KW)                                                                                                               \
+    if (c->Cout == 32) VIAI_LAUNCH((cin1_bn_bwd_kernel<8, KH, KW, false>), dim3(a.nblk), dim3(256), 0, st, a);                    \
+    else if (c->Cout == 64) VIAI_LAUNCH((cin1_bn_bwd_kernel<16, KH, KW, false>), dim3(a.nblk), dim3(256), 0, st, a);              \
+    else VIAI_LAUNCH((cin1_bn_bwd_kernel<32, KH, KW, false>), dim3(a.nblk), dim3(256), 0, st, a)
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
+    int e = viai_launch_status();
+    if (e) return e;
+    e = viai_bn_bwd_final_launch(part, a.nblk, c->Cout, a.M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, st);
+    if (e || dy == nullptr) return e;
+#define CALL(KH, KW)                                                                                                               \
+    if (c->Cout == 32) VIAI_LAUNCH((cin1_bn_bwd_kernel<8, KH, KW, true>), dim3(a.nblk), dim3(256), 0, st, a);                     \
+    else if (c->Cout == 64) VIAI_LAUNCH((cin1_bn_bwd_kernel<16, KH, KW, true>), dim3(a.nblk), dim3(256), 0, st, a);               \
+    else VIAI_LAUNCH((cin1_bn_bwd_kernel<32, KH, KW, true>), dim3(a.nblk), dim3(256), 0, st, a)
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
+    return viai_launch_status();
+}
+
+// dw (+)= weight gradient of the fused layer from dz: dy = scale * dp + k1 * (y - mean) + k0 is formed per element inside the kernel
+// ws: viai_conv2d_wgrad_ws_bytes(c) bytes
+extern "C" int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, const float* w, const float* bias, const float* dz,
+                                         const float* mean, const float* scale, const float* shift, const float* sums, float* ws,
+                                         float* dw, int accumulate, int act, void* stream) {
+    if (!viai_conv2d_cin1_bn_ok(c)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    DirectArgs a = make_args(c);
+    a.x = x; a.w = w; a.bias = bias; a.dz = dz; a.mean = mean; a.scale = scale; a.shift = shift; a.sums = sums; a.ws = ws;
+    a.act = act; a.slope = 0.2f;
+    const int T = c->kh * c->kw;
+    int nb = direct_wgrad_blocks(a.M);
+    int ppb = (a.M + nb - 1) / nb;
+    int cg = c->Cout / 4;
+    size_t lds = (size_t)(256 / cg) * T * c->Cout * sizeof(float);
+#define CALL(KH, KW)                                                                                                               \
+    if (cg == 8) VIAI_LAUNCH((cin1_wgrad_kernel<8, KH, KW, true>), dim3(nb), dim3(256), lds, st, a, ppb);                         \
+    else if (cg == 16) VIAI_LAUNCH((cin1_wgrad_kernel<16, KH, KW, true>), dim3(nb), dim3(256), lds, st, a, ppb);                  \
+    else VIAI_LAUNCH((cin1_wgrad_kernel<32, KH, KW, true>), dim3(nb), dim3(256), lds, st, a, ppb)
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
+    int e = viai_launch_status();
+    if (e) return e;
     return viai_wgrad_reduce(ws, dw, nb, T, c->Cout, 1, T, T, accumulate, st);
 }
 

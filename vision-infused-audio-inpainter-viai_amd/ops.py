@@ -331,7 +331,27 @@ class _ConvBnAct(torch.autograd.Function):
         has_bn = gamma is not None
         act = cfg["act"]
         training = cfg["training"]
-        if has_bn:
+        fused1 = False
+        if has_bn and training and bias is None and C1 + C2 == 1:
+            fused1 = d.get("cin1_bn")
+            if fused1 is None:
+                fused1 = d["cin1_bn"] = bool(lib.viai_conv2d_cin1_bn_ok(d["ref"]))
+        ctx.fused1 = fused1
+        if fused1:
+            # Cin = 1 conv + BatchNorm(train) + activation: the pre-BatchNorm tensor is never stored (recomputed from x where needed)
+            coef = torch.empty((4, Cout), device=dev, dtype=torch.float32)
+            stat = _scratch("stat", 2 * Cout * d["nblk"], dev)
+            _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), wp.data_ptr(), 0, stat.data_ptr(), 0, 0, 0, act, st),
+                       "viai_conv2d_cin1_bn_fwd")
+            _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, Cout, gamma.data_ptr(),
+                                            beta.data_ptr(), _ptr(rmean), _ptr(rvar), _ptr(nbt),
+                                            cfg["momentum"], cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
+                                            coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_finalize")
+            z = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
+            _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), wp.data_ptr(), 0, 0, coef[2].data_ptr(), coef[3].data_ptr(),
+                                                   z.data_ptr(), act, st), "viai_conv2d_cin1_bn_fwd")
+            ctx.save_for_backward(x, None, weight, None, coef)
+        elif has_bn:
             y = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
             coef = torch.empty((4, Cout), device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
             if training:
@@ -379,6 +399,8 @@ class _ConvBnAct(torch.autograd.Function):
         gt = cfg.get("gt") or (None, None, None, None)       # in-place gradient targets (arena views)
         dgamma = dbeta = None
         amax = None
+        if ctx.fused1:
+            return _ConvBnAct._backward_cin1(ctx, lib, dz, x, weight, coef, st)
         if ctx.has_bn:
             nblk = lib.viai_bn_bwd_blocks(M, Cout)
             part = _scratch("bnpart", 2 * Cout * nblk, dev)
@@ -478,6 +500,65 @@ class _ConvBnAct(torch.autograd.Function):
                 _lib.check(lib.viai_conv2d_dgrad(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), st),
                            "viai_conv2d_dgrad")
         return dx, dx2, dw, db, dgamma, dbeta, None, None, None, None
+
+
+def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
+    """backward of the fused Cin = 1 conv + BatchNorm(train) + activation layer: y is recomputed from x; dy is written to memory only
+    when a data gradient needs it (the frozen-D pass of the G step), the weight gradient forms it on the fly."""
+    d, cfg = ctx.d, ctx.cfg
+    N, IH, IW, C1, C2, Cout, OH, OW = ctx.dims
+    M = N * OH * OW
+    dev = dz.device
+    act = cfg["act"]
+    need_x, _, need_w, _, need_g, need_be = ctx.needs_input_grad[:6]
+    gt = cfg.get("gt") or (None, None, None, None)
+    wp = _packed(weight, d, 0, st)
+    part = _scratch("bnpart1", 2 * Cout * d["nblk"], dev)
+    sums = torch.empty(2 * Cout, device=dev, dtype=torch.float32)     # private: the trailing weight gradient reads it
+    acc_bn = gt[2] is not None and gt[3] is not None and need_g and need_be
+    dgamma = dbeta = None
+    if acc_bn:
+        pg, pb = gt[2], gt[3]
+    else:
+        dgamma = torch.empty(Cout, device=dev, dtype=torch.float32) if need_g else None
+        dbeta = torch.empty(Cout, device=dev, dtype=torch.float32) if need_be else None
+        pg, pb = dgamma, dbeta
+    dy = torch.empty_like(dz) if need_x else None
+    _lib.check(lib.viai_conv2d_cin1_bn_bwd(d["ref"], x.data_ptr(), wp.data_ptr(), 0, dz.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                           coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(), _ptr(pg), _ptr(pb),
+                                           _ptr(dy), act, 1 | (2 if acc_bn else 0), st), "viai_conv2d_cin1_bn_bwd")
+    dw = dx = None
+    if need_w:
+        acc_w = gt[0] is not None
+        dw = gt[0] if acc_w else torch.empty_like(weight)
+
+        def wgrad(stream_obj, handle):
+            ws = _scratch("wgrad", d["ws_floats"], dev, stream_obj) if stream_obj is not None else _scratch("wgrad", d["ws_floats"], dev)
+            _lib.check(lib.viai_conv2d_cin1_bn_wgrad(d["ref"], x.data_ptr(), wp.data_ptr(), 0, dz.data_ptr(), coef[0].data_ptr(),
+                                                     coef[2].data_ptr(), coef[3].data_ptr(), sums.data_ptr(), ws.data_ptr(), dw.data_ptr(),
+                                                     1 if acc_w else 0, act, handle), "viai_conv2d_cin1_bn_wgrad")
+        if WGRAD_STREAM is not None and acc_w:
+            ev = torch.cuda.Event()
+            ev.record()
+            WGRAD_STREAM.wait_event(ev)
+            wgrad(WGRAD_STREAM, WGRAD_STREAM.cuda_stream)
+            _deferred.append((x, dz, weight, wp, coef, sums))
+        else:
+            wgrad(None, st)
+        if acc_w:
+            dw = None
+        if GRAD_HOOKS:
+            hook = GRAD_HOOKS.get(weight.data_ptr())
+            if hook is not None:
+                hook()
+    if need_x:
+        dx = torch.empty((N, IH, IW, C1), device=dev, dtype=torch.float32)
+        wpd = _packed(weight, d, 1, st)
+        _lib.check(lib.viai_conv2d_dgrad(d["ref"], dy.data_ptr(), wpd.data_ptr(), dx.data_ptr(), 0, st), "viai_conv2d_dgrad")
+    return dx, None, dw, None, dgamma, dbeta, None, None, None, None
+
+
+_ConvBnAct._backward_cin1 = staticmethod(_backward_cin1)
 
 
 def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding=(0, 0), transposed=False,
