@@ -125,7 +125,7 @@ class KernelTimer:
         lib = self.lib
         from viai_amd import ops as ops_mod
 
-        def wrap(name, family_of):
+        def wrap(name, family_of, counts=lambda args: True):
             fn = getattr(lib, name)
             self.orig[name] = fn
 
@@ -133,6 +133,8 @@ class KernelTimer:
                 d = desc_ref._obj
                 fam, nl = family_of(d)
                 cin, flops = self._geom(d)
+                if not counts(args):
+                    flops = 0.0                      # a recomputation of the same conv (fused Cin = 1 layer): time yes, algorithmic flops no
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 # the events go on the stream the kernel is launched on (last argument): the weight gradients run on
                 # ops.WGRAD_STREAM next to the main backward chain, and are timed there, overlap included
@@ -273,6 +275,9 @@ class KernelTimer:
         wrap("viai_conv2d_dgrad_f16", fam_dgrad_f16)
         wrap("viai_conv2d_wgrad_f16", fam_wgrad_f16)
         wrap("viai_conv2d_wgrad", fam_wgrad)
+        # fused Cin = 1 conv + BatchNorm layer: statistics pass (z = NULL, args[6]) + apply pass; the weight gradient from dz
+        wrap("viai_conv2d_cin1_bn_fwd", lambda d: ("direct", 1), counts=lambda args: bool(args[6]))
+        wrap("viai_conv2d_cin1_bn_wgrad", lambda d: ("direct", 1))
 
     def per_layer(self):
         torch.cuda.synchronize()

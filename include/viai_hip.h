@@ -331,6 +331,9 @@ int viai_conv2d_cin1_bn_bwd(const viai_conv2d* c, const float* x, const float* w
 int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, const float* w, const float* bias, const float* dz,
                               const float* mean, const float* scale, const float* shift, const float* sums, float* ws,
                               float* dw, int accumulate, int act, void* stream);
+/* dx straight from dz (dy formed per contributing output pixel): no dy tensor at all; needs bias == NULL */
+int viai_conv2d_cin1_bn_dgrad(const viai_conv2d* c, const float* x, const float* w, const float* dz, const float* mean,
+                              const float* scale, const float* shift, const float* sums, float* dx, int act, void* stream);
 
 /* -------------------------------------------------- launch plans: the train step recorded once, replayed from C
  * Replaces the per-launch host work of `model.optimize_parameters()` (train_whole_sync.py:76).  Protocol:

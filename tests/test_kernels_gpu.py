@@ -309,15 +309,17 @@ def test_conv_bn_act_train_matches_torch_cpu(act, shape):
     assert int(bng.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("need_dx", [False, True])
+@pytest.mark.parametrize("need_dx", [False, "fused", "apply"])
 @pytest.mark.parametrize("geom", [(3, 80, 96, 32, (3, 3), (2, 2), (1, 1)), (2, 64, 72, 64, (1, 4), (1, 2), (0, 1)), (5, 33, 37, 32, (3, 3), (2, 2), (1, 1))])
-def test_cin1_conv_bn_layer_without_the_stored_preactivation(geom, need_dx):
+def test_cin1_conv_bn_layer_without_the_stored_preactivation(geom, need_dx, monkeypatch):
     """E.conv1 / D.conv1 (Inpainting_Networks.py:55,71; Discriminator_Networks.py:17-19): Cin = 1 conv -> BatchNorm2d(train) ->
     LeakyReLU on the fused path (viai_conv2d_cin1_bn_*: the conv output is never stored, forward and backward recompute it from x;
-    the weight gradient forms dy on the fly, dy is written only when a data gradient is asked for).  Forward, dw, dgamma, dbeta,
+    the weight gradient forms dy on the fly; the data gradient either reads a dy tensor written by the recomputing apply pass ("apply",
+    the default) or forms dy on the fly too ("fused", VIAI_CIN1_BN_DGRAD=1: slower, opt-in).  Forward, dw, dgamma, dbeta,
     dx and the running statistics against fp64 within 5x of torch-CPU-fp32's own rounding error; the third geometry has a ragged last
     statistics block (pixels not a multiple of 256)."""
     from viai_amd import ops, _lib
+    monkeypatch.setenv("VIAI_CIN1_BN_DGRAD", "0" if need_dx == "apply" else "1")
     N, H, W, Co, k, s_, p_ = geom
     x = O.cf_uniform("c1.x", (N, 1, H, W), 0, 1)
     w = O.cf_std("c1.w", (Co, 1) + k, 0.3)
@@ -332,7 +334,7 @@ def test_cin1_conv_bn_layer_without_the_stored_preactivation(geom, need_dx):
     (truth, _), (cpu32, gy) = run(torch.float64), run(torch.float32)
     bn = torch.nn.BatchNorm2d(Co).cuda().train()
     bn.weight.data.copy_(g); bn.bias.data.copy_(b)
-    xg = nhwc(x).requires_grad_(need_dx)
+    xg = nhwc(x).requires_grad_(bool(need_dx))
     wg = w.cuda().requires_grad_(True)
     d = ops.conv_desc(N, H, W, 1, 0, Co, k[0], k[1], s_[0], s_[1], p_[0], p_[1], 0, 1, 1, -1, -1)
     assert _lib.load().viai_conv2d_cin1_bn_ok(d["ref"]) == 1

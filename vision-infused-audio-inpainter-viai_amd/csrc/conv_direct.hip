@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256) void cin1_bn_bwd_kernel(const DirectArgs a) {
 // dx[q] = sum_t sum_co dy[o_t(q)][co] * w[co][t]   (Cin == 1), LPP = Cout/4 lanes per input pixel
 // SH, SW: the strides as compile-time constants (0 = use a.sh / a.sw): the tap validity test divides by them per tap and
 // pixel, and a runtime integer division is ~30 instructions
-template <int LPP, int KH, int KW, int SH = 0, int SW = 0>
+// FUSED (the fused Cin = 1 conv + BatchNorm layer): a.dy is not read; dy[o] = scale * dz[o] * act'(.) + k1 * (y[o] - mean) + k0 is formed
+// per contributing output pixel with y[o] recomputed from a.x (the frozen-D pass of the G step: no dy tensor at all)
+template <int LPP, int KH, int KW, int SH = 0, int SW = 0, bool FUSED = false>
 __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
     constexpr int T = KH * KW;
     const int sh = SH ? SH : a.sh, sw = SW ? SW : a.sw;
@@ -238,6 +240,12 @@ __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
     for (int t = 0; t < T; ++t) {
         wv[t][0] = a.w[(cl * 4 + 0) * T + t]; wv[t][1] = a.w[(cl * 4 + 1) * T + t];
         wv[t][2] = a.w[(cl * 4 + 2) * T + t]; wv[t][3] = a.w[(cl * 4 + 3) * T + t];
+    }
+    f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, bk0 = bsc, bk1 = bsc;
+    if constexpr (FUSED) {
+        bsc = *reinterpret_cast<const f32x4*>(a.scale + cl * 4); bsh = *reinterpret_cast<const f32x4*>(a.shift + cl * 4);
+        bmu = *reinterpret_cast<const f32x4*>(a.mean + cl * 4);
+        bk0 = *reinterpret_cast<const f32x4*>(a.sums + cl * 4); bk1 = *reinterpret_cast<const f32x4*>(a.sums + a.Cout + cl * 4);
     }
     const int total = a.N * a.IH * a.IW;
     const int qstep = gridDim.x * (256 / LPP);
@@ -262,7 +270,27 @@ __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
                     if (nx < 0 || nx % sw != 0) continue;
                     const int ox = nx / sw;
                     if (ox >= a.OW) continue;
-                    f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.Cout + cl * 4);
+                    f32x4 d = *reinterpret_cast<const f32x4*>((FUSED ? a.dz : a.dy) + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.Cout + cl * 4);
+                    if constexpr (FUSED) {
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        const float* xb = a.x + (size_t)n * a.IH * a.IW;
+#pragma unroll
+                        for (int r2 = 0; r2 < KH; ++r2) {
+                            const int iy2 = oy * sh + tap_dy(a, r2);
+                            const bool yok = (unsigned)iy2 < (unsigned)a.IH;
+#pragma unroll
+                            for (int q2 = 0; q2 < KW; ++q2) {
+                                const int ix2 = ox * sw + tap_dx(a, q2);
+                                const float xv = (yok && (unsigned)ix2 < (unsigned)a.IW) ? xb[iy2 * a.IW + ix2] : 0.f;
+                                v += xv * wv[r2 * KW + q2];
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float dp = d[e] * dact(v[e] * bsc[e] + bsh[e], a.act, a.slope);
+                            d[e] = bsc[e] * dp + (bk1[e] * (v[e] - bmu[e]) + bk0[e]);
+                        }
+                    }
                     const f32x4 w = wv[r * KW + s_];
                     accv += d[0] * w[0] + d[1] * w[1] + d[2] * w[2] + d[3] * w[3];
                 }
@@ -945,6 +973,35 @@ extern "C" int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, c
     int e = viai_launch_status();
     if (e) return e;
     return viai_wgrad_reduce(ws, dw, nb, T, c->Cout, 1, T, T, accumulate, st);
+}
+
+// dx = data gradient of the fused layer straight from dz (no dy tensor): the frozen-D pass of the G step
+extern "C" int viai_conv2d_cin1_bn_dgrad(const viai_conv2d* c, const float* x, const float* w, const float* dz, const float* mean,
+                                         const float* scale, const float* shift, const float* sums, float* dx, int act, void* stream) {
+    if (!viai_conv2d_cin1_bn_ok(c)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    DirectArgs a = make_args(c);
+    a.x = x; a.w = w; a.dz = dz; a.mean = mean; a.scale = scale; a.shift = shift; a.sums = sums; a.dx = dx; a.act = act; a.slope = 0.2f;
+    long tot = (long)a.N * a.IH * a.IW;
+    int lpp = c->Cout / 4;
+    long nb = (tot * lpp + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    int blocks = (int)nb;
+    if (c->kh == 1 && c->kw == 4 && c->sh == 1 && c->sw == 2 && lpp == 16) {          // D.conv1
+        VIAI_LAUNCH((cin1_dgrad_kernel<16, 1, 4, 1, 2, true>), dim3(blocks), dim3(256), 0, st, a);
+        return viai_launch_status();
+    }
+    if (c->kh == 3 && c->kw == 3 && c->sh == 2 && c->sw == 2 && lpp == 8) {           // E.conv1
+        VIAI_LAUNCH((cin1_dgrad_kernel<8, 3, 3, 2, 2, true>), dim3(blocks), dim3(256), 0, st, a);
+        return viai_launch_status();
+    }
+#define CALL(KH, KW)                                                                                                     \
+    if (lpp == 8) VIAI_LAUNCH((cin1_dgrad_kernel<8, KH, KW, 0, 0, true>), dim3(blocks), dim3(256), 0, st, a);            \
+    else if (lpp == 16) VIAI_LAUNCH((cin1_dgrad_kernel<16, KH, KW, 0, 0, true>), dim3(blocks), dim3(256), 0, st, a);     \
+    else VIAI_LAUNCH((cin1_dgrad_kernel<32, KH, KW, 0, 0, true>), dim3(blocks), dim3(256), 0, st, a)
+    VIAI_WINDOW_DISPATCH(c, CALL);
+#undef CALL
+    return viai_launch_status();
 }
 
 int viai_cout1_fwd(const viai_conv2d* c, const float* x, const float* wp, const float* bias, float* y, int act, hipStream_t st) {
