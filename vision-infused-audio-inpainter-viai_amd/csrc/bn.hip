@@ -36,6 +36,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     // mean:  S = sum n_b (m_b - k),  Q = sum [M2_b + n_b (m_b - k)^2]  =>  mean = k + S / M,  M2 = Q - S^2 / M.
     // In fp64 with |m_b - k| of the order of the spread of the block means the subtraction Q - S^2/M loses nothing that matters
     // (tests/test_kernels_gpu.py::test_bn_large_mean_is_stable); the two-pass form cost two more block reductions (four barriers).
+    // what the epilogue needs is fetched now, not after the reduction (these kernels are chains of memory round trips: 6 - 7 us each,
+    // 33 of them on the step's critical path)
+    float g = 1.f, bta = 0.f, rm = 0.f, rv = 0.f;
+    if (threadIdx.x == 0) {
+        if (gamma) g = gamma[c];
+        if (beta) bta = beta[c];
+        if (running_mean) rm = running_mean[c];
+        if (running_var) rv = running_var[c];
+    }
     const double k = (double)pm[0];
     double s = 0.0, q = 0.0;
     for (int b = threadIdx.x; b < nblk; b += 256) {
@@ -45,7 +54,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         q += (double)p2[b] + nb * d * d;
     }
     // both sums through one pair of barriers
-    s = wave_sum_d(s); q = wave_sum_d(q);
+    s = wave_sum_d_dpp(s); q = wave_sum_d_dpp(q);
     __shared__ double red2[4];
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red2[threadIdx.x >> 6] = q; }
     __syncthreads();
@@ -56,15 +65,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     if (threadIdx.x == 0) {
         const double var = m2 / (double)M;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.f, bta = beta ? beta[c] : 0.f;
         mean_o[c] = (float)mean;
         invstd_o[c] = invstd;
         scale_o[c] = g * invstd;
         shift_o[c] = bta - (float)mean * g * invstd;
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        if (running_mean) running_mean[c] = (1.f - momentum) * rm + momentum * (float)mean;
         if (running_var) {
             double unb = (M > 1) ? m2 / (double)(M - 1) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            running_var[c] = (1.f - momentum) * rv + momentum * (float)unb;
         }
         if (nbt && c == 0) *nbt += 1;
     }
@@ -197,6 +205,11 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
     const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
+    float p_sc = 0.f, p_is = 0.f, p_db = 0.f, p_dg = 0.f;        // the epilogue's operands, requested before the reduction
+    if (pl == 0 && c < C) {
+        if (training) { p_sc = scale[c]; p_is = invstd[c]; }
+        if (accumulate) { if (dbeta) p_db = dbeta[c]; if (dgamma) p_dg = dgamma[c]; }
+    }
     if (c < C) {
         int b = pl;
         for (; b + 192 < nblk; b += 256) {               // 8 independent loads in flight per lane
@@ -220,11 +233,11 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
     if (pl == 0 && c < C) {
         s1 = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
         s2 = (r2[0][cl] + r2[1][cl]) + (r2[2][cl] + r2[3][cl]);
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+        if (dbeta) dbeta[c] = accumulate ? p_db + (float)s1 : (float)s1;
+        if (dgamma) dgamma[c] = accumulate ? p_dg + (float)s2 : (float)s2;
         if (training) {
-            double sc = (double)scale[c];
-            sums[C + c] = (float)(-sc * s2 * (double)invstd[c] / (double)M);     // k1
+            double sc = (double)p_sc;
+            sums[C + c] = (float)(-sc * s2 * (double)p_is / (double)M);     // k1
             sums[c] = (float)(-sc * s1 / (double)M);                              // k0
         } else {
             sums[c] = 0.f; sums[C + c] = 0.f;

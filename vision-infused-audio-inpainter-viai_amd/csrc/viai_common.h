@@ -66,6 +66,27 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
 
+// fp64 flavour: the two halves move through DPP separately
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_d_dpp(double v) {
+    v += dpp_mov_d<0xB1>(v);
+    v += dpp_mov_d<0x4E>(v);
+    v += dpp_mov_d<0x141>(v);
+    v += dpp_mov_d<0x140>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
