@@ -1,5 +1,7 @@
 """GPU parity of the module shells and the declared G+D step against the CPU
 oracle and the golden vectors generated from the reference's own modules."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -334,40 +336,63 @@ def test_packed_weight_cache_follows_every_kind_of_weight_update(use_graph):
         assert relerr(a.fake, ref3.fake) < 1e-5
 
 
-def test_gradient_exchange_over_rccl_is_wired_into_the_step():
-    """one-rank RCCL group on the GPU box: the two all-reduce points of the step (ddp.py, model._allreduce) run on the
-    real backend, between the side-stream joins and the Adam kernels, and leave a one-rank result unchanged.  (The
-    world-size-2 semantics are covered on CPU by tests/test_ddp_gloo.py.)"""
+def _rccl_one_rank_child(port, marker):
+    """body of test_gradient_exchange_over_rccl_is_wired_into_the_step, in its own process (see there)"""
     import torch.distributed as dist
     from viai_amd.model import AudioModel, StepConfig
-    if dist.is_initialized():
-        pytest.skip("a process group already exists in this process")
-    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
-    try:
-        hp = StepConfig()
-        hp.cin_channels, hp.max_mel_lengths = 80, 32
-        s = O.cf_uniform("rc.s", (2, 1, 80, 32), 0, 1).cuda()
-        mask = O.make_mask(2, 32, "rc.mask").cuda()
-        outs = []
-        for force, graph in ((False, False), (True, False), (True, True)):
-            m = AudioModel(hp, device="cuda", use_graph=graph)
-            m.load_states(O.encoder_state(), O.decoder_state(), O.disc_state())
-            m._force_allreduce = force
-            m.set_inputs(s, mask)
-            for i in range(3):
-                m.optimize_parameters(i)
-            torch.cuda.synchronize()
-            outs.append((m.fake.detach().clone(), m.arena_D.flat.clone(), m.arena_G.flat.clone()))
-        # eager: the exchange of a one-rank group is the identity and the three-stream step is deterministic -> bitwise equal
-        for a, b in zip(outs[0], outs[1]):
-            assert torch.equal(a, b)
-        # graph mode: the capture warm-up (two real steps) is rolled back (model._capture snapshots and restores parameters, Adam
-        # state and BatchNorm buffers), so three replayed steps land where three eager steps do
-        for a, b in zip(outs[0], outs[2]):
-            assert torch.isfinite(b).all()
-            assert relerr(b, a) < 1e-5
-    finally:
-        dist.destroy_process_group()
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    hp = StepConfig()
+    hp.cin_channels, hp.max_mel_lengths = 80, 32
+    s = O.cf_uniform("rc.s", (2, 1, 80, 32), 0, 1).cuda()
+    mask = O.make_mask(2, 32, "rc.mask").cuda()
+    outs = []
+    for force, graph in ((False, False), (True, False), (True, True)):
+        m = AudioModel(hp, device="cuda", use_graph=graph)
+        m.load_states(O.encoder_state(), O.decoder_state(), O.disc_state())
+        m._force_allreduce = force
+        m.set_inputs(s, mask)
+        for i in range(3):
+            m.optimize_parameters(i)
+        m.sync_pending_update()
+        torch.cuda.synchronize()
+        outs.append((m.fake.detach().clone(), m.arena_D.flat.clone(), m.arena_G.flat.clone()))
+    # eager: the exchange of a one-rank group is the identity and the three-stream step is deterministic -> bitwise equal
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # graph mode: the capture warm-up (two real steps) is rolled back (model._capture snapshots and restores parameters, Adam
+    # state and BatchNorm buffers), so three replayed steps land where three eager steps do
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.isfinite(b).all()
+        assert relerr(b, a) < 1e-5
+    torch.cuda.synchronize()
+    with open(marker, "w") as f:
+        f.write("ok")
+    # no destroy_process_group(): tearing down a one-rank RCCL communicator aborts the process now and then on this stack
+    # ("Fatal Python error: Aborted" inside destroy_process_group, 2 of ~12 runs of the suite) -- which used to take the whole
+    # pytest session with it.  The checks are done; leave without the teardown.
+    os._exit(0)
+
+
+def test_gradient_exchange_over_rccl_is_wired_into_the_step(tmp_path):
+    """one-rank RCCL group on the GPU box: the two all-reduce points of the step (ddp.py, model._allreduce) run on the
+    real backend, between the side-stream joins and the Adam kernels, and leave a one-rank result unchanged.  (The
+    world-size-2 semantics are covered on CPU by tests/test_ddp_gloo.py and on the GPU over gloo by tests/test_ddp_gpu.py.)
+    Runs in a spawned process: the RCCL communicator's teardown is not part of what is tested and is not always clean."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    marker = str(tmp_path / "rccl_ok")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_one_rank_child, args=(port, marker))
+    p.start()
+    p.join(600)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("the RCCL child did not finish")
+    assert os.path.exists(marker), "the RCCL child failed before finishing its checks (exit code %s)" % p.exitcode
 
 
 def test_graph_capture_leaves_training_state_untouched():

@@ -196,6 +196,7 @@ class AudioModel:
         self.use_plan = bool(use_plan)
         self.use_graph = bool(use_graph) or self.use_plan
         self._plans = None
+        self._consts = {}
         # weight gradients trail on a side stream (ops.WGRAD_STREAM) in eager mode: -3.5 % step time on one MI355X.  Inside
         # a captured hipGraph the fork/join edges cost more than the overlap returns (+2 %), so graph mode stays on one
         # stream.  VIAI_WGRAD_STREAM=0/1 overrides.
@@ -413,6 +414,14 @@ class AudioModel:
             lc = ops.l2_contrastive(f_a.contiguous(), fv_nhwc.reshape(B * w, 256).contiguous(), self.cfg.contrast_margin, False)
         return (fake, lc, feats, f_v) if want_feats else (fake, lc)
 
+    def _const(self, v):
+        """device scalar with a fixed value (gradient seeds), made once"""
+        v = float(v)
+        t = self._consts.get(v)
+        if t is None:
+            t = self._consts[v] = torch.full((), v, device=self.device, dtype=torch.float32)
+        return t
+
     def _put(self, i, value):
         """losses[i] = value through an elementwise kernel: a `copy_` is a device-to-device memcpy, whose node parameters a
         stream capture does not give back (plan mode reads the captured launches)."""
@@ -439,7 +448,7 @@ class AudioModel:
                 fwd_done = torch.cuda.Event()
                 fwd_done.record(side)
                 loss_real = self._gan(pred_real, True)
-                (0.5 * loss_real).backward()
+                loss_real.backward(self._const(0.5))                   # d(0.5 L): the factor goes in as the seed, no elementwise launches
         else:
             pred_real = self.netD.forward_nhwc(s_nhwc)
             loss_real = self._gan(pred_real, True)
@@ -458,7 +467,7 @@ class AudioModel:
             main.wait_stream(side)                                     # real-branch gradients are in the arena
             loss_real.record_stream(main)                              # allocated on `side`, read below on main
             self._arm_hooks(self.arena_D, self._early_D, 1)
-            (0.5 * loss_fake).backward()
+            loss_fake.backward(self._const(0.5))
             loss_d = 0.5 * (loss_fake.detach() + loss_real.detach())
         else:
             loss_d = 0.5 * (loss_fake + loss_real)
@@ -479,13 +488,19 @@ class AudioModel:
         pred = self.netD.forward_nhwc(self._fake)
         loss_gan = self._gan(pred, True)
         loss_l1 = ops.l1_mean(self._fake, s.view(B, F, T, 1))
-        loss_g = loss_gan + self.cfg.lambda_l1 * loss_l1
+        # loss_G = gan + lambda_l1 * l1 (+ lambda_c * contrast) is back-propagated from its terms with the weights as seeds: the same
+        # gradients bit for bit, without the scalar mul / add / ones_like launches between D's forward and the backward chain
+        roots, seeds = [loss_gan, loss_l1], [self._const(1.0), self._const(self.cfg.lambda_l1)]
         if self._lc is not None:
-            loss_g = loss_g + self.cfg.lambda_contrast * self._lc
+            roots.append(self._lc)
+            seeds.append(self._const(self.cfg.lambda_contrast))
+        self._arm_hooks(self.arena_G, self._early_G, 1)
+        torch.autograd.backward(roots, seeds)
+        loss_g = loss_gan.detach() + self.cfg.lambda_l1 * loss_l1.detach()
+        if self._lc is not None:
+            loss_g = loss_g + self.cfg.lambda_contrast * self._lc.detach()
             self.EmbeddingL2 = self._lc.detach()
             self._put(5, self.EmbeddingL2)
-        self._arm_hooks(self.arena_G, self._early_G, 1)
-        loss_g.backward()
         ops.join_wgrad()
         self._g_exchanged = self._finish_exchange(self.arena_G, self._late_G)
         self.netD.requires_grad_(True)
