@@ -7,15 +7,18 @@
  * ATen dispatch it replaces (paths relative to the reference root).
  *
  * Conventions
- *   - every pointer is a DEVICE pointer owned by the caller (the library
- *     allocates nothing and keeps no mutable global state);
+ *   - every pointer is a DEVICE pointer owned by the caller.  The library allocates no device memory and keeps no state BETWEEN
+ *     calls that affects results.  What it does keep, per process: the VIAI_* environment switches (read once), the
+ *     max-dynamic-LDS attribute of each kernel (set once), a per-thread first-error slot (cleared by every entry point), and the
+ *     launch-plan log / plans (viai_plan_*: host memory and hipEvents owned by the plan, freed by viai_plan_destroy);
  *   - activations are fp32 NHWC: [N][H][W][C], C contiguous.  A (N,1,H,W) NCHW
  *     tensor is bit-identical to its NHWC form;
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it,
  *     the library never synchronises;
  *   - return value: 0 (hipSuccess) or a hipError_t / hipErrorInvalidValue code.
  *     Nothing throws across this boundary.
- *   - re-entrant; one process per GPU under data parallelism.
+ *   - entry points may be called from several host threads on different streams (the launch-plan log is the exception: one
+ *     recording at a time); one process per GPU under data parallelism.
  */
 #ifndef VIAI_HIP_H
 #define VIAI_HIP_H
