@@ -310,14 +310,16 @@ def test_conv_bn_act_train_matches_torch_cpu(act, shape):
 
 
 @pytest.mark.parametrize("need_dx", [False, "fused", "apply"])
-@pytest.mark.parametrize("geom", [(3, 80, 96, 32, (3, 3), (2, 2), (1, 1)), (2, 64, 72, 64, (1, 4), (1, 2), (0, 1)), (5, 33, 37, 32, (3, 3), (2, 2), (1, 1))])
+@pytest.mark.parametrize("geom", [(3, 80, 96, 32, (3, 3), (2, 2), (1, 1)), (2, 64, 72, 64, (1, 4), (1, 2), (0, 1)), (5, 33, 37, 32, (3, 3), (2, 2), (1, 1)),
+                                  (2, 32, 128, 64, (1, 4), (1, 2), (0, 1)), (2, 64, 64, 32, (3, 3), (2, 2), (1, 1))])
 def test_cin1_conv_bn_layer_without_the_stored_preactivation(geom, need_dx, monkeypatch):
     """E.conv1 / D.conv1 (Inpainting_Networks.py:55,71; Discriminator_Networks.py:17-19): Cin = 1 conv -> BatchNorm2d(train) ->
     LeakyReLU on the fused path (viai_conv2d_cin1_bn_*: the conv output is never stored, forward and backward recompute it from x;
     the weight gradient forms dy on the fly; the data gradient either reads a dy tensor written by the recomputing apply pass ("apply",
     the default) or forms dy on the fly too ("fused", VIAI_CIN1_BN_DGRAD=1: slower, opt-in).  Forward, dw, dgamma, dbeta,
     dx and the running statistics against fp64 within 5x of torch-CPU-fp32's own rounding error; the third geometry has a ragged last
-    statistics block (pixels not a multiple of 256)."""
+    statistics block (pixels not a multiple of 256); the last two have blocks of whole output rows, i.e. the kernels that stage the
+    block's input rows in LDS (the benchmark shapes take that path)."""
     from viai_amd import ops, _lib
     monkeypatch.setenv("VIAI_CIN1_BN_DGRAD", "0" if need_dx == "apply" else "1")
     N, H, W, Co, k, s_, p_ = geom

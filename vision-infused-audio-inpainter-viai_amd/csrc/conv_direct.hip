@@ -22,6 +22,8 @@ struct DirectArgs {
     // fused Cin = 1 conv + BatchNorm(train) + activation layer (viai_conv2d_cin1_bn_*): y is never stored, it is recomputed from x
     const float* scale; const float* shift; const float* mean; const float* invstd; const float* sums; const float* dz;
     float* part;
+    // block = whole output rows of one image (host-checked): the block's input rows are staged in LDS once (xrows x xpitch floats)
+    int xfast, xrows, xpitch, rows_blk;
 };
 
 __device__ __forceinline__ int tap_dy(const DirectArgs& a, int r) { return a.transposed ? a.ph - r : r - a.ph; }
@@ -32,6 +34,50 @@ __device__ __forceinline__ void fast_divmod(int q, int d, float inv_d, int& quo,
     quo = (int)((float)q * inv_d);
     rem = q - quo * d;
     if (rem < 0) { --quo; rem += d; } else if (rem >= d) { ++quo; rem -= d; }
+}
+
+
+// The taps of a Cin = 1 layer are 4-byte loads that 16 .. 64 lanes share (every channel lane of a pixel reads the same x): as global
+// loads each costs a full 64-lane pass through the address unit (16 cycles), 4 .. 9 taps x 16 pixels per thread, and the kernels were
+// bound by THAT, not by HBM (the statistics-only forward read 4 MB in 31 us).  When a block covers whole output rows of one image
+// its input rows are staged in LDS once (coalesced), zero padding included, and the taps become LDS broadcasts.
+constexpr int CIN1_XP = 2560;             // floats of LDS for the staged rows
+__device__ __forceinline__ void cin1_stage_rows(const DirectArgs& a, float* xp, int n, int oy0) {
+    const int iy0 = oy0 * a.sh - a.ph;
+    const float* xb = a.x + (size_t)n * a.IH * a.IW;
+    for (int idx = threadIdx.x; idx < a.xrows * a.xpitch; idx += 256) {
+        const int r = idx / a.xpitch, c = idx - r * a.xpitch;
+        const int iy = iy0 + r, ix = c - a.pw;
+        xp[idx] = ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
+    }
+    __syncthreads();
+}
+// The taps are read from LDS one value per VGPR, pinned by an empty asm: left to itself the compiler fetched them with ds_read2_b32 into
+// register PAIRS and fed v_pk_fma_f32 op_sel broadcasts from the pair, and that sequence produced wrong sums (one tap's term missing
+// for some lanes) whenever waves of the patch weight-gradient kernel shared the CU -- found as a run-to-run difference of D.bn1's
+// gradients in the three-stream step, reproduced with an in-kernel check (LDS values correct, packed-FMA result wrong), gone with
+// single registers.  Bit-identical to the global-load path.
+template <int KH, int KW>
+__device__ __forceinline__ void cin1_lds_taps(const float* xr, int pitch, float (&xt)[KH * KW]) {
+#pragma unroll
+    for (int r = 0; r < KH; ++r)
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+            xt[r * KW + q] = xr[r * pitch + q];
+            asm volatile("" : "+v"(xt[r * KW + q]));
+        }
+}
+static bool cin1_rows_ok(DirectArgs& a, int pix_per_blk, int KH, int KW, int which = 1) {
+    a.xfast = 0;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_CIN1_LDSX"); on = e ? atoi(e) : 7; }
+    if (!(on & which) || a.transposed || pix_per_blk % a.OW != 0 || (a.OH * a.OW) % pix_per_blk != 0) return false;
+    a.rows_blk = pix_per_blk / a.OW;
+    a.xrows = (a.rows_blk - 1) * a.sh + KH;
+    a.xpitch = (a.OW - 1) * a.sw + KW;
+    if (a.xrows * a.xpitch > CIN1_XP) return false;
+    a.xfast = 1;
+    return true;
 }
 
 // All kernels are templated on the (compile-time) kernel window KH x KW so that tap offsets, validity
@@ -63,6 +109,9 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == 2) { sc = *reinterpret_cast<const f32x4*>(a.scale + cg * 4); sh = *reinterpret_cast<const f32x4*>(a.shift + cg * 4); }
     const int p0 = blockIdx.x * CIN1_PB;
+    __shared__ float xp[CIN1_XP];
+    const int oy_blk = (p0 / a.OW) % a.OH;
+    if (a.xfast) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     f32x4 vals[IT];
     // decode the first pixel once, then walk: the per-pixel 32-bit divisions (p % OW, p / OW, ... = ~100 instructions) cost more than
@@ -83,6 +132,12 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
         if (p < a.M) {
             const float* xb = a.x + (size_t)n * a.IH * a.IW;
             const int iy0 = oy * a.sh, ix0 = ox * a.sw;
+            if (a.xfast) {
+                float xt[KH * KW];
+                cin1_lds_taps<KH, KW>(xp + (oy - oy_blk) * a.sh * a.xpitch + ix0, a.xpitch, xt);
+#pragma unroll
+                for (int t = 0; t < KH * KW; ++t) v += xt[t] * wv[t];
+            } else {
 #pragma unroll
             for (int r = 0; r < KH; ++r) {
                 const int iy = iy0 + tap_dy(a, r);
@@ -93,6 +148,7 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
                     float xv = (yok && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
                     v += xv * wv[r * KW + q];
                 }
+            }
             }
             if constexpr (MODE == 2) {
                 f32x4 z;
@@ -174,6 +230,9 @@ __global__ __launch_bounds__(256) void cin1_bn_bwd_kernel(const DirectArgs a) {
     if constexpr (APPLY) { k0 = *reinterpret_cast<const f32x4*>(a.sums + cg * 4); k1 = *reinterpret_cast<const f32x4*>(a.sums + a.Cout + cg * 4); }
     else is = *reinterpret_cast<const f32x4*>(a.invstd + cg * 4);
     const int p0 = blockIdx.x * CIN1_PB;
+    __shared__ float xp[CIN1_XP];
+    const int oy_blk = (p0 / a.OW) % a.OH;
+    if (a.xfast) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     int ox, oy, n;
     {
@@ -192,6 +251,12 @@ __global__ __launch_bounds__(256) void cin1_bn_bwd_kernel(const DirectArgs a) {
             f32x4 v = bv;
             const float* xb = a.x + (size_t)n * a.IH * a.IW;
             const int iy0 = oy * a.sh, ix0 = ox * a.sw;
+            if (a.xfast) {
+                float xt[KH * KW];
+                cin1_lds_taps<KH, KW>(xp + (oy - oy_blk) * a.sh * a.xpitch + ix0, a.xpitch, xt);
+#pragma unroll
+                for (int t = 0; t < KH * KW; ++t) v += xt[t] * wv[t];
+            } else {
 #pragma unroll
             for (int r = 0; r < KH; ++r) {
                 const int iy = iy0 + tap_dy(a, r);
@@ -202,6 +267,7 @@ __global__ __launch_bounds__(256) void cin1_bn_bwd_kernel(const DirectArgs a) {
                     float xv = (yok && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
                     v += xv * wv[r * KW + q];
                 }
+            }
             }
             f32x4 o;
 #pragma unroll
@@ -329,12 +395,18 @@ __global__ __launch_bounds__(256) void cin1_wgrad_kernel(const DirectArgs a, int
     }
     const int p0 = blockIdx.x * pix_per_blk;
     const int p1 = min(p0 + pix_per_blk, a.M);
+    __shared__ float xp[CIN1_XP];
+    const int oy_blk = (p0 / a.OW) % a.OH;
+    if (a.xfast) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk);
     for (int p = p0 + pg; p < p1; p += PG) {
         int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
         f32x4 d = *reinterpret_cast<const f32x4*>((FUSED ? a.dz : a.dy) + (size_t)p * a.Cout + cg * 4);
         const float* xb = a.x + (size_t)n * a.IH * a.IW;
         const int iy0 = oy * a.sh, ix0 = ox * a.sw;
         float xt[T];
+        if (a.xfast) {
+            cin1_lds_taps<KH, KW>(xp + (oy - oy_blk) * a.sh * a.xpitch + ix0, a.xpitch, xt);
+        } else
 #pragma unroll
         for (int r = 0; r < KH; ++r) {
             const int iy = iy0 + tap_dy(a, r);
@@ -793,6 +865,7 @@ int viai_cin1_fwd(const viai_conv2d* c, const float* x, const float* w, const fl
     DirectArgs a = make_args(c);
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.stat = stat; a.act = act; a.slope = 0.2f;
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
+    cin1_rows_ok(a, CIN1_PB, c->kh, c->kw);
 #define CALL(KH, KW)                                                                                             \
     if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW>), dim3(a.nblk), dim3(256), 0, st, a);            \
     else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW>), dim3(a.nblk), dim3(256), 0, st, a);      \
@@ -866,6 +939,7 @@ int viai_cin1_wgrad(const viai_conv2d* c, const float* x, const float* dy, float
     const int T = c->kh * c->kw;
     int nb = direct_wgrad_blocks(a.M);
     int ppb = (a.M + nb - 1) / nb;
+    cin1_rows_ok(a, ppb, c->kh, c->kw, 4);
     int cg = c->Cout / 4;
     size_t lds = (size_t)(256 / cg) * T * c->Cout * sizeof(float);
 #define CALL(KH, KW)                                                                                                  \
@@ -903,6 +977,7 @@ extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, con
     DirectArgs a = make_args(c);
     a.x = x; a.w = w; a.bias = bias; a.y = z; a.stat = stat_part; a.scale = scale; a.shift = shift; a.act = act; a.slope = 0.2f;
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
+    cin1_rows_ok(a, CIN1_PB, c->kh, c->kw);
 #define CALL(KH, KW)                                                                                                               \
     if (z == nullptr) {                                                                                                            \
         if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                       \
@@ -930,6 +1005,7 @@ extern "C" int viai_conv2d_cin1_bn_bwd(const viai_conv2d* c, const float* x, con
     a.x = x; a.w = w; a.bias = bias; a.dz = dz; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.part = part;
     a.sums = sums; a.dx = dy; a.act = act; a.slope = 0.2f;
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
+    cin1_rows_ok(a, CIN1_PB, c->kh, c->kw, 2);
 #define CALL(KH, KW)                                                                                                               \
     if (c->Cout == 32) VIAI_LAUNCH((cin1_bn_bwd_kernel<8, KH, KW, false>), dim3(a.nblk), dim3(256), 0, st, a);                    \
     else if (c->Cout == 64) VIAI_LAUNCH((cin1_bn_bwd_kernel<16, KH, KW, false>), dim3(a.nblk), dim3(256), 0, st, a);              \
@@ -962,6 +1038,7 @@ extern "C" int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, c
     const int T = c->kh * c->kw;
     int nb = direct_wgrad_blocks(a.M);
     int ppb = (a.M + nb - 1) / nb;
+    cin1_rows_ok(a, ppb, c->kh, c->kw, 4);
     int cg = c->Cout / 4;
     size_t lds = (size_t)(256 / cg) * T * c->Cout * sizeof(float);
 #define CALL(KH, KW)                                                                                                               \
