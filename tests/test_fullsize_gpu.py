@@ -216,6 +216,27 @@ def test_three_stream_step_is_bitwise_serial_at_benchmark_size(monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_three_stream_step_is_run_to_run_deterministic_at_benchmark_size(monkeypatch):
+    """Three fresh models, one no-update step each on the same clips with all three streams on: gradient arenas and `fake` must be
+    BIT-identical from run to run.  (tools/step_determinism.py; this is the check that exposed the packed-FMA miscompute of the first
+    LDS-staged Cin = 1 BatchNorm-backward kernel -- correct alone, wrong for a few lanes per launch next to the stride-2 patch weight
+    gradient on the other stream, csrc/conv_direct.hip cin1_lds_taps.)"""
+    from viai_amd import synth
+    s = synth.mel_batch(16, 256, 256, "det.s", 0).cuda()
+    mask = synth.time_mask(16, 256, "det.mask", 0).cuda()
+    outs = []
+    for _ in range(3):
+        m = _full_model(monkeypatch, "1", "1")
+        m.set_inputs(s, mask)
+        m.forward_backward_no_update()
+        torch.cuda.synchronize()
+        outs.append([m.fake.detach().clone(), m.arena_D.grad.clone(), m.arena_G.grad.clone()])
+        del m
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+
+
 def test_eval_discriminator_is_per_clip_at_benchmark_size():
     """running-statistics BatchNorm makes D a per-clip map: the 16-clip forward (128 x 256 tiles, 256+ tiles per layer) must agree
     with two 8-clip forwards (different tile counts, so partly different kernels) to fp32 rounding."""
