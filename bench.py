@@ -602,6 +602,10 @@ def main():
         out["stages"] = front_end_stages(dev, args.batch, args.bins, args.frames)
     if rank == 0 and world == 1 and args.config == "audio" and not args.no_roofline:
         out["config"]["launch_modes"] = launch_modes(hp, dev, s, mask)
+        out["config"]["host_enqueue_note"] = ("host_enqueue_ms_per_step is the LOOP figure: the host runs ahead until the device queues fill and then "
+                                              "waits inside a launch, so it tracks the device time in every launch mode; the host's own cost per step is "
+                                              "launch_modes.*.host_ms_per_step_idle_queue (one step enqueued into an idle queue): eager vs the C launch "
+                                              "plan (bench.py --plan; bitwise the eager step)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
