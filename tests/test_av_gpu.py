@@ -123,12 +123,12 @@ def test_multiscale_discriminator_is_a_composition_of_reference_discriminators()
 # the composed vision-infused step (BASELINE.json configs[2] / configs[3]) against the reference modules' composition
 # ------------------------------------------------------------------------------------------------------------------
 
-def _av_model(num_D=2, lam=0.1, margin=1.0, use_graph=False, F_bins=256, T=32):
+def _av_model(num_D=2, lam=0.1, margin=1.0, use_graph=False, F_bins=256, T=32, use_plan=False):
     from viai_amd.model import AudioModel, StepConfig
     hp = StepConfig()
     hp.cin_channels, hp.max_mel_lengths = F_bins, T
     hp.use_video, hp.num_D, hp.lambda_contrast, hp.contrast_margin = True, num_D, lam, margin
-    m = AudioModel(hp, device="cuda", use_graph=use_graph)
+    m = AudioModel(hp, device="cuda", use_graph=use_graph, use_plan=use_plan)
     m.load_states(O.encoder_state(), O.decoder_variant_state("image"), O.msd_state(num_D) if num_D > 1 else O.disc_state(),
                   O.image_embedding2_state())
     return m
@@ -137,6 +137,29 @@ def _av_model(num_D=2, lam=0.1, margin=1.0, use_graph=False, F_bins=256, T=32):
 def _av_inputs(B, F_bins, T, NF):
     return (O.cf_uniform("avstep.s", (B, 1, F_bins, T)), O.make_mask(B, T, "avstep.mask"),
             O.cf_uniform("avstep.video", (B, NF, 3, 224, 224), -1, 1), O.cf_uniform("avstep.flow", (B, NF, 2, 224, 224), -1, 1))
+
+
+def test_vision_infused_step_replays_bitwise_as_a_launch_plan():
+    """the vision-infused multi-scale step (ResNet branch, contrastive term, two discriminators: PyTorch's own cat / expand / mean
+    kernels and fill nodes inside the capture) recorded once and replayed from C (csrc/plan.hip): three steps, parameters, Adam
+    moments, BatchNorm buffers of the visual branch and the six loss scalars BIT-identical to the eager model's."""
+    B, F_bins, T, NF = 2, 256, 32, 8
+    s, mask, video, flow = _av_inputs(B, F_bins, T, NF)
+
+    def run(plan):
+        m = _av_model(2, 0.1, 1.0, F_bins=F_bins, T=T, use_plan=plan)
+        m.set_inputs(s.cuda(), mask.cuda(), video=video.cuda(), flow=flow.cuda())
+        for i in range(3):
+            m.optimize_parameters(i)
+        losses = torch.tensor(m.get_loss_items())
+        bn = m.VideoEncoder.image_single_model.bn1
+        out = [m.arena_G.flat.clone(), m.arena_D.flat.clone(), m.optimizer_G.exp_avg_sq.clone(), bn.running_var.clone(), m.fake.clone(), losses]
+        info = m.plan_info() if plan else None
+        return out, info
+    (eager, _), (plan, info) = run(False), run(True)
+    assert sum(v[0] for v in info) > 300 and sum(v[4] for v in info) >= 0
+    for a, b in zip(eager, plan):
+        assert torch.equal(a, b)
 
 
 def test_vision_infused_multiscale_step_matches_reference_composition(golden_dir):
