@@ -196,6 +196,7 @@ class AudioModel:
         self.use_plan = bool(use_plan)
         self.use_graph = bool(use_graph) or self.use_plan
         self._plans = None
+        self._graph_scratch = None
         self._consts = {}
         # weight gradients trail on a side stream (ops.WGRAD_STREAM) in eager mode: -3.5 % step time on one MI355X.  Inside
         # a captured hipGraph the fork/join edges cost more than the overlap returns (+2 %), so graph mode stays on one
@@ -380,6 +381,7 @@ class AudioModel:
                     lib().viai_plan_destroy(p)
                 self._plans = None
             self._graphs = None
+            self._graph_scratch = None
             ops.drop_scratch()            # scratch buffers allocated while capturing live in the dead graphs' private memory pool
 
     def _gan(self, pred, real):
@@ -547,6 +549,7 @@ class AudioModel:
         self.weights_changed()
         graphs, plans = [], []
         pool = None
+        before = ops.scratch_snapshot()
         for f in segs:
             if self.use_plan:
                 # the capture is a recorder: the hipGraph is kept (it owns the kernel-argument arrays) but never instantiated
@@ -569,6 +572,8 @@ class AudioModel:
             graphs.append(g)
         self._graphs = graphs
         self._plans = plans if self.use_plan else None
+        # scratch buffers first requested inside the captures came from the graphs' private pool: they belong to this model now
+        self._graph_scratch = ops.scratch_take_new(before)
 
     def plan_info(self):
         """per captured segment: nodes, kernels, kernels with a noted stream, copies, fills, streams, events, waits"""

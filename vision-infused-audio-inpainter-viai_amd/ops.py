@@ -149,6 +149,22 @@ def _amax_slot(dev):
     return torch.zeros(1, device=dev, dtype=torch.float32)
 
 
+def scratch_snapshot():
+    """the pooled scratch buffers as they are now (see scratch_take_new)"""
+    return dict(_scratch_pool)
+
+
+def scratch_take_new(before):
+    """Remove from the pool -- and hand to the caller -- every scratch buffer that was created (or grown) since `before`.  Buffers first
+    requested DURING a stream capture are allocated from that capture's private memory pool: they must live and die with the captured
+    graphs, not stay in this process-wide pool where a later model would pick up memory of a pool that no longer exists (found as an
+    abort two test files after a captured vision-infused model had been deleted)."""
+    new = {k: t for k, t in _scratch_pool.items() if before.get(k) is not t}
+    for k in new:
+        del _scratch_pool[k]
+    return new
+
+
 def drop_scratch():
     """forget every pooled scratch buffer (the next use re-allocates).  Needed when captured hipGraphs are dropped: buffers first
     requested during a capture were allocated from that graph's private pool."""
