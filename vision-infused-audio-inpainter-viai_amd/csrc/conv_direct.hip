@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void cin1_wgrad_kernel(const DirectArgs a, int
     const int p1 = min(p0 + pix_per_blk, a.M);
     __shared__ float xp[CIN1_XP];
     const int oy_blk = (p0 / a.OW) % a.OH;
-    if (a.xfast) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk);
+    if (a.xfast && p0 < a.M) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk);      // (trailing blocks past the last pixel stage nothing)
     for (int p = p0 + pg; p < p1; p += PG) {
         int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
         f32x4 d = *reinterpret_cast<const f32x4*>((FUSED ? a.dz : a.dy) + (size_t)p * a.Cout + cg * 4);
