@@ -126,3 +126,26 @@ def test_synth_matches_oracle_generator():
     from viai_amd import synth
     assert torch.equal(synth.uniform("abc", (5, 7), -1, 2), O.cf_uniform("abc", (5, 7), -1, 2))
     assert torch.equal(synth.time_mask(4, 64, "m"), O.make_mask(4, 64, "m.r0"))
+
+
+def test_capture_scratch_is_handed_to_the_capturing_model():
+    """ops.scratch_snapshot / scratch_take_new (model._capture): buffers created or grown after the snapshot leave the process-wide
+    pool and go to the caller; older ones stay."""
+    import torch
+    from viai_amd import ops
+    saved = dict(ops._scratch_pool)
+    try:
+        ops._scratch_pool.clear()
+        old, grown_old = torch.zeros(4), torch.zeros(4)
+        ops._scratch_pool[("a", 0, 1)] = old
+        ops._scratch_pool[("b", 0, 1)] = grown_old
+        before = ops.scratch_snapshot()
+        grown_new, fresh = torch.zeros(8), torch.zeros(2)
+        ops._scratch_pool[("b", 0, 1)] = grown_new          # re-allocated bigger during the capture
+        ops._scratch_pool[("c", 0, 2)] = fresh              # first requested during the capture
+        taken = ops.scratch_take_new(before)
+        assert set(taken) == {("b", 0, 1), ("c", 0, 2)} and taken[("b", 0, 1)] is grown_new and taken[("c", 0, 2)] is fresh
+        assert set(ops._scratch_pool) == {("a", 0, 1)} and ops._scratch_pool[("a", 0, 1)] is old
+    finally:
+        ops._scratch_pool.clear()
+        ops._scratch_pool.update(saved)
