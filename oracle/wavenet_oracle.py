@@ -50,6 +50,17 @@ class WNConfigFull(WNConfig):
     upsample_scales = (4, 4, 4, 4)
 
 
+class WNConfigDeep(WNConfig):
+    """the reference's DEPTH (24 layers / 4 stacks: dilations 1 .. 32 four times, receptive field 505, wavenet.py:116-131) at reduced
+    width, so the reference's Python `incremental_forward` (wavenet.py:237-364, ring buffers of conv.py:17-46) finishes in seconds on the
+    CPU: the fixture that pins incremental synthesis at every dilation the benchmark's configs[4] runs."""
+    layers = 24
+    stacks = 4
+    residual_channels = 32
+    gate_channels = 32
+    skip_out_channels = 32
+
+
 class WNConfigOneHot(WNConfig):
     """the small configuration with one-hot (mu-law, 256 classes) input and softmax-logit output (`scalar_input=False`)."""
     out_channels = 256

@@ -158,3 +158,39 @@ def test_oracle_reproduces_reference_digests_at_benchmark_size(golden_dir):
         for k, v in sd.items():
             if "running_" in k:
                 assert relerr(v, g["nu.state.%s.%s" % (nm, k)]) < 1e-4, k
+
+
+def test_wavenet_helper_symbols_match_reference_golden(golden_dir):
+    """`receptive_field_size` (wavenet_vocoder/wavenet.py:41-59), `sequence_mask` (loss_functions.py:11-21), `to_one_hot`
+    (wavenet_vocoder/mixture.py:108-114): values produced by the reference's functions (tests/golden/wavenet_deep.npz)."""
+    import torch
+    from viai_amd import losses, wavenet
+    gold = np.load(golden_dir + "/wavenet_deep.npz")
+    assert [wavenet.receptive_field_size(24, 4, 3), wavenet.receptive_field_size(6, 2, 3, lambda x: 1),
+            wavenet.receptive_field_size(4, 2, 2)] == list(gold["rf"]) and int(gold["rf"][0]) == 505
+    with pytest.raises(AssertionError):
+        wavenet.receptive_field_size(5, 2, 3)
+    lens = torch.tensor([3, 5, 1])
+    assert np.array_equal(losses.sequence_mask(lens).numpy(), gold["seqmask"])
+    assert np.array_equal(wavenet.sequence_mask(lens, 6).numpy(), gold["seqmask6"])
+    assert np.array_equal(wavenet.to_one_hot(torch.tensor([[1, 0, 3], [2, 2, 0]]), 4).numpy(), gold["onehot"])
+    assert np.array_equal(wavenet.to_one_hot(torch.tensor([2, 0]), 3, 0.5).numpy(), gold["onehot_fill"])
+
+
+def test_wavenet_oracle_reproduces_reference_incremental_synthesis_at_reference_depth(golden_dir):
+    """24 layers / 4 stacks (dilations 1 .. 32), T = 160: the reference's `incremental_forward` (wavenet.py:237-364), teacher-forced
+    over the whole length, equals the oracle's batch forward + sampler (causality) -- pins the oracle at every dilation."""
+    from oracle import wavenet_oracle as W
+    gold = np.load(golden_dir + "/wavenet_deep.npz")
+    cfg = W.WNConfigDeep
+    B, T = int(gold["meta"][0]), int(gold["meta"][1])
+    assert (cfg.layers, cfg.stacks) == (24, 4) == (int(gold["meta"][2]), int(gold["meta"][3])) and T >= 130
+    sd = W.wavenet_state(cfg, tag="WND.")
+    c = O.cf_uniform("wnd.c", (B, cfg.cin_channels, T // 16), 0, 1)
+    v1 = O.cf_uniform("wnd.v1", (B, T, 10), 1e-5, 1 - 1e-5)
+    v2 = O.cf_uniform("wnd.v2", (B, T), 1e-5, 1 - 1e-5)
+    xin = O.cf_uniform("wnd.xin", (B, 1, T), -1, 1)
+    with torch.no_grad():
+        yh = W.wavenet_forward(sd, xin, c, cfg)
+    assert relerr(O.digest(yh, 256), gold["yhat_tf.dg"]) < 1e-5
+    assert relerr(W.mol_sample(yh, v1, v2, -7.0), gold["gen_tf"][:, 0]) < 1e-4

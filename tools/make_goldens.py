@@ -408,6 +408,71 @@ def wavenet_full_goldens():
     print("wavenet_full -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def wavenet_deep_goldens():
+    """Incremental synthesis at the REFERENCE's depth (24 layers / 4 stacks, dilations 1 .. 32; reduced width), B = 2, T = 160: every
+    ring buffer of conv.py:17-46 (length (k - 1) d + 1 <= 65) wraps at least twice.  Two runs of the reference's
+    `incremental_forward` (wavenet.py:237-364) with the sampler's uniforms injected: teacher-forced over the whole length (each output is a
+    smooth function of that step's logits: no feedback) and free-running after four teacher-forced samples."""
+    import Config  # noqa: F401
+    from oracle import wavenet_oracle as W
+    cfg = W.WNConfigDeep
+    from wavenet_vocoder import wavenet as RW
+    net = RW.WaveNet(out_channels=cfg.out_channels, layers=cfg.layers, stacks=cfg.stacks, residual_channels=cfg.residual_channels,
+                     gate_channels=cfg.gate_channels, skip_out_channels=cfg.skip_out_channels, kernel_size=cfg.kernel_size, dropout=0.0,
+                     cin_channels=cfg.cin_channels, gin_channels=-1, n_speakers=None, weight_normalization=True,
+                     upsample_conditional_features=True, upsample_scales=list(cfg.upsample_scales),
+                     freq_axis_kernel_size=cfg.freq_axis_kernel_size, scalar_input=True)
+    sd = W.wavenet_state(cfg, tag="WND.")
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    load_into(net, sd)
+    net.eval()
+    assert [l.conv.dilation[0] for l in net.conv_layers] == [1, 2, 4, 8, 16, 32] * 4
+    B, T = 2, 160
+    c = O.cf_uniform("wnd.c", (B, cfg.cin_channels, T // 16), 0, 1)
+    v1 = O.cf_uniform("wnd.v1", (B, T, 10), 1e-5, 1 - 1e-5)
+    v2 = O.cf_uniform("wnd.v2", (B, T), 1e-5, 1 - 1e-5)
+    xin = O.cf_uniform("wnd.xin", (B, 1, T), -1, 1)
+    out = OrderedDict()
+    out["meta"] = np.array([B, T, cfg.layers, cfg.stacks], dtype=np.int64)
+    orig = torch.Tensor.uniform_
+
+    def run(test_inputs):
+        seq = []
+        for t in range(T):
+            seq += [v1[:, t:t + 1, :].reshape(B, 1, 10), v2[:, t:t + 1].reshape(B, 1)]
+        torch.Tensor.uniform_ = lambda self, a=0, b=1: self.copy_(seq.pop(0).reshape(self.shape))
+        try:
+            with torch.no_grad():
+                return net.incremental_forward(initial_input=None, c=c, g=None, T=T, test_inputs=test_inputs, tqdm=lambda z: z,
+                                               softmax=False, quantize=False, log_scale_min=-7.0)
+        finally:
+            torch.Tensor.uniform_ = orig
+    gen_tf = run(xin)
+    gen_free = run(xin[:, :, :4].contiguous())
+    assert tuple(gen_tf.shape) == (B, 1, T) and tuple(gen_free.shape) == (B, 1, T)
+    # the oracle's definition-of-causality restatement (batch forward on the teacher-forced input) reproduces the teacher-forced run
+    with torch.no_grad():
+        yh = W.wavenet_forward(sd, xin, c, cfg)                       # logits at t from inputs <= t
+        osmp = W.mol_sample(yh, v1, v2, -7.0)
+        ref_yh = net(xin, c)
+    assert relerr(yh, ref_yh) < 1e-5, relerr(yh, ref_yh)
+    assert relerr(osmp, gen_tf.squeeze(1)) < 1e-4, relerr(osmp, gen_tf.squeeze(1))
+    out["gen_tf"] = gen_tf.numpy()
+    out["gen_free"] = gen_free.numpy()
+    out["yhat_tf.dg"] = O.digest(ref_yh, 256)
+    # the small helpers SURVEY.md section 8 rows a12 / a13 name, through the reference's own functions
+    from wavenet_vocoder import mixture as RM
+    out["rf"] = np.array([RW.receptive_field_size(24, 4, 3), RW.receptive_field_size(6, 2, 3, lambda x: 1), RW.receptive_field_size(4, 2, 2)], dtype=np.int64)
+    lens = torch.tensor([3, 5, 1])
+    out["seqmask"] = RefLoss.sequence_mask(lens).numpy()
+    out["seqmask6"] = RefLoss.sequence_mask(lens, 6).numpy()
+    out["onehot"] = RM.to_one_hot(torch.tensor([[1, 0, 3], [2, 2, 0]]), 4).numpy()
+    out["onehot_fill"] = RM.to_one_hot(torch.tensor([2, 0]), 3, 0.5).numpy()
+    path = os.path.join(OUT, "wavenet_deep.npz")
+    np.savez_compressed(path, **out)
+    print("wavenet_deep -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def wavenet_onehot_goldens():
     """WaveNet with one-hot (mu-law) input, `scalar_input=False` (wavenet.py:116-119,177-235): teacher-forced forward and the
     gradients of a cross-entropy loss, from the reference's module.  (`forward(softmax=True)` raises a TypeError in the
@@ -906,6 +971,9 @@ if __name__ == "__main__":
     if "--wavenet-onehot-only" in sys.argv:
         wavenet_onehot_goldens()
         sys.exit(0)
+    if "--wavenet-deep-only" in sys.argv:
+        wavenet_deep_goldens()
+        sys.exit(0)
     if "--wavenet-full-only" in sys.argv:
         torch.set_num_threads(os.cpu_count())
         wavenet_full_goldens()
@@ -937,6 +1005,7 @@ if __name__ == "__main__":
     wavenet_g_goldens()
     wavenet_full_goldens()
     wavenet_onehot_goldens()
+    wavenet_deep_goldens()
     av_step_goldens()
     instnorm_goldens()
     loader_goldens()

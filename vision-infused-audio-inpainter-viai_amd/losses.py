@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .wavenet import DiscretizedMixturelogisticLoss, sequence_mask   # noqa: F401  (loss_functions.py:11-21,43-62 live in this module in the reference)
 
 
 class GANLoss(nn.Module):

@@ -230,6 +230,29 @@ def mol_sample(yhat_nhwc, u1, u2, log_scale_min=-7.0):
     return out
 
 
+def receptive_field_size(total_layers, num_cycles, kernel_size, dilation=lambda x: 2 ** x):
+    """samples of context one output sees: (k - 1) * sum of the layer dilations + 1 (wavenet_vocoder/wavenet.py:41-59; 505 for the
+    reference's 24 layers / 4 cycles / k = 3).  `dilation(i)` maps the position inside a cycle to the dilation."""
+    if total_layers % num_cycles != 0:
+        raise AssertionError("total_layers must be a multiple of num_cycles")
+    per = total_layers // num_cycles
+    return (kernel_size - 1) * sum(dilation(i % per) for i in range(total_layers)) + 1
+
+
+def sequence_mask(sequence_length, max_len=None):
+    """(B,) lengths -> (B, max_len) float mask, 1 where t < length (loss_functions.py:11-21); stays on the lengths' device."""
+    if max_len is None:
+        max_len = int(sequence_length.max())
+    t = torch.arange(0, max_len, device=sequence_length.device, dtype=torch.long)
+    return (t.unsqueeze(0) < sequence_length.long().unsqueeze(1)).float()
+
+
+def to_one_hot(tensor, n, fill_with=1.):
+    """integer tensor (...) -> float (..., n), one-hot along a new last axis (wavenet_vocoder/mixture.py:108-114)."""
+    out = torch.zeros(tuple(tensor.shape) + (n,), dtype=torch.float32, device=tensor.device)
+    return out.scatter_(tensor.dim(), tensor.long().unsqueeze(-1), fill_with)
+
+
 # ----------------------------------------------------------------------------- modules
 def _wn(m, on):
     return nn.utils.weight_norm(m) if on else m
@@ -511,8 +534,7 @@ class DiscretizedMixturelogisticLoss(nn.Module):
         if lengths is None and mask is None:
             raise RuntimeError("Should provide either lengths or mask")
         if mask is None:
-            ml = int(lengths.max()) if max_len is None else max_len
-            mask = (torch.arange(ml, device=lengths.device)[None, :] < lengths[:, None]).float().unsqueeze(-1)
+            mask = sequence_mask(lengths, max_len).unsqueeze(-1)
         if input.dim() == 3:                                                          # (B, C, T) -> NHWC rows, padded to 32
             B, Cc, T = input.shape
             yh = torch.nn.functional.pad(input.transpose(1, 2), (0, (-Cc) % 4)).reshape(B, 1, T, -1).contiguous()
