@@ -194,6 +194,52 @@ def run_case(name, B, F_bins, T, steps, full):
           % (name, B, F_bins, T, steps, worst, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+CHAIN_STEPS = 3
+SHADOWED_CHAIN = ("G.deconv1_1.bias", "G.deconv1_2.bias", "G.conv6_1.bias")   # bias in front of train-mode BN: exact gradient 0
+
+
+def chain_goldens():
+    """"params after 1 and 3 Adam steps".  The declared step run three times with the REFERENCE's modules +
+    torch.optim.Adam on the tie-free tiny input (oracle.separated_input); after every step 256 strided samples of EVERY parameter
+    tensor of E, G and D (and every BatchNorm running statistic) are stored, plus how far the oracle's own chain (second torch-CPU fp32
+    implementation of the same arithmetic) is from the reference's at that step -- the noise floor any third implementation is
+    judged against.  Adam's update is lr * m / sqrt(v): where a gradient is at the rounding-noise level, or changes sign between
+    steps, two correct fp32 implementations move that weight in different directions; the relative PARAMETER error that follows is
+    ~2e-4 after one step and grows past 1e-3 by the third (printed below)."""
+    B, F_bins, T = 2, 80, 32
+    s = O.cf_uniform("s.tiny", (B, 1, F_bins, T))
+    mask = O.make_mask(B, T, "mask.tiny")
+    s2 = O.separated_input(s, mask)
+    E, G, D, optG, optD, gan = fresh(F_bins)
+    oE, oG, oD = O.encoder_state(), O.decoder_state(), O.disc_state()
+    ooG, ooD = O.new_optimizers(oE, oG, oD)
+    out = OrderedDict()
+    out["meta"] = np.array([B, F_bins, T, CHAIN_STEPS], dtype=np.int64)
+    for it in range(CHAIN_STEPS):
+        cap = ref_step(E, G, D, optG, optD, gan, s2, mask, update=True)
+        ocap = O.train_step(oE, oG, oD, ooG, ooD, s2, mask)
+        for k in ("loss_d", "loss_g", "loss_l1"):
+            out["step%d.%s" % (it + 1, k)] = np.float64(cap[k].item())
+        floor = []
+        for nm, mod, osd in (("E", E, oE), ("G", G, oG), ("D", D, oD)):
+            num = den = 0.0
+            for k, v in mod.state_dict().items():
+                if "num_batches" in k:
+                    continue
+                out["step%d.%s.%s" % (it + 1, nm, k)] = O.strided_samples(v)
+                if not O.is_buffer(k) and (nm + "." + k) not in SHADOWED_CHAIN:
+                    num += (v.double() - osd[k].double()).pow(2).sum().item()
+                    den += v.double().pow(2).sum().item()
+            floor.append((num / den) ** 0.5)
+        out["step%d.oracle_vs_reference" % (it + 1)] = np.array(floor)
+        print("chain step %d: oracle-vs-reference relative parameter error  E %.2e  G %.2e  D %.2e   (loss_d %.5f loss_g %.4f)"
+              % (it + 1, floor[0], floor[1], floor[2], cap["loss_d"].item(), cap["loss_g"].item()))
+        assert max(floor) < (1e-3 if it == 0 else 1e-2), floor
+    path = os.path.join(OUT, "step_chain.npz")
+    np.savez_compressed(path, **out)
+    print("chain -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def av_goldens():
     """AV decoders + sync / domain discriminators at the native MUSICES shape (80 x 208; SURVEY.md §8a:
     MelDecoderImage needs bottleneck h == 1, Inpainting_Dis needs F/8 == 10, DomainDis needs T/16 == 13)."""
@@ -971,6 +1017,9 @@ if __name__ == "__main__":
     if "--wavenet-onehot-only" in sys.argv:
         wavenet_onehot_goldens()
         sys.exit(0)
+    if "--chain-only" in sys.argv:
+        chain_goldens()
+        sys.exit(0)
     if "--wavenet-deep-only" in sys.argv:
         wavenet_deep_goldens()
         sys.exit(0)
@@ -1011,6 +1060,7 @@ if __name__ == "__main__":
     loader_goldens()
     checkpoint_structure_golden()
     run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
+    chain_goldens()
     run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]
     if "--cfg2" in sys.argv:
         run_case("cfg2", 16, 256, 256, 1, full=False)  # configs[1]; ~1 min on 8 cores
