@@ -25,6 +25,7 @@
 #include <cstring>
 #include <map>
 #include <queue>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -41,6 +42,8 @@ struct Note {
     bool used;
 };
 std::vector<Note> g_log;
+std::thread::id g_log_owner;       // the log belongs to the thread that opened it: launches of other threads (another model stepping
+                                   // in the same process) are not part of its capture and are not noted
 
 enum Kind { K_KERNEL, K_COPY, K_SET, K_EMPTY };
 
@@ -67,6 +70,7 @@ struct viai_plan {
 };
 
 void viai_plan_note(const void* func, void* stream, dim3 grid, dim3 block, const unsigned char* blob, const unsigned* sizes, int nargs) {
+    if (std::this_thread::get_id() != g_log_owner) return;
     Note n{func, (hipStream_t)stream, grid, block, {}, {}, false};
     size_t total = 0;
     for (int i = 0; i < nargs; ++i) total += sizes[i];
@@ -76,12 +80,15 @@ void viai_plan_note(const void* func, void* stream, dim3 grid, dim3 block, const
 }
 
 extern "C" int viai_plan_log_begin(void) {
+    if (viai_plan_log_on) return (int)hipErrorInvalidValue;       // one recorder at a time
     g_log.clear();
+    g_log_owner = std::this_thread::get_id();
     viai_plan_log_on = 1;
     return 0;
 }
 
 extern "C" int viai_plan_log_end(void) {
+    if (std::this_thread::get_id() != g_log_owner) return -1;
     viai_plan_log_on = 0;
     return (int)g_log.size();
 }

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <tuple>
+#include <utility>
 #include <stdint.h>
 
 #define VIAI_WAVE 64
@@ -113,23 +115,32 @@ static thread_local int viai_err_acc = 0;
 // matched to its note by kernel + geometry + argument bytes, whatever order the graph API returns the nodes in).
 extern int viai_plan_log_on;
 void viai_plan_note(const void* func, void* stream, dim3 grid, dim3 block, const unsigned char* blob, const unsigned* sizes, int nargs);
-template <class... P, class... A>
-static inline void viai_plan_note_launch(void (*f)(P...), dim3 grid, dim3 block, size_t, hipStream_t st, A&&... a) {
-    if (!viai_plan_log_on) return;
+// One launch: the argument expressions are evaluated ONCE, converted to the kernel's parameter types, and the same packed values go to
+// hipLaunchKernel and (while a plan log is on) into the launch note.
+template <class... P, class... A, size_t... I>
+static inline void viai_launch_impl(void (*f)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t st, std::index_sequence<I...>, A&&... a) {
     static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
-    unsigned char blob[(sizeof(P) + ... + 16)];
-    unsigned sizes[sizeof...(P) + 1];
-    int n = 0;
-    size_t off = 0;
-    auto put = [&](const void* p, size_t bytes) { __builtin_memcpy(blob + off, p, bytes); off += bytes; sizes[n++] = (unsigned)bytes; };
-    ([&] { P v = static_cast<P>(a); put(&v, sizeof(P)); }(), ...);       // the value as the kernel receives it
-    viai_plan_note(reinterpret_cast<const void*>(f), (void*)st, grid, block, blob, sizes, n);
+    std::tuple<std::remove_cv_t<P>...> vals{static_cast<P>(a)...};
+    void* ptrs[sizeof...(P) + 1] = {(void*)&std::get<I>(vals)..., nullptr};
+    (void)hipLaunchKernel(reinterpret_cast<const void*>(f), grid, block, ptrs, lds, st);
+    if (viai_plan_log_on) {
+        unsigned char blob[(sizeof(P) + ... + 16)];
+        unsigned sizes[sizeof...(P) + 1];
+        int n = 0;
+        size_t off = 0;
+        auto put = [&](const void* p, size_t bytes) { __builtin_memcpy(blob + off, p, bytes); off += bytes; sizes[n++] = (unsigned)bytes; };
+        (put(&std::get<I>(vals), sizeof(P)), ...);
+        viai_plan_note(reinterpret_cast<const void*>(f), (void*)st, grid, block, blob, sizes, n);
+    }
+}
+template <class... P, class... A>
+static inline void viai_launch_once(void (*f)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t st, A&&... a) {
+    viai_launch_impl(f, grid, block, lds, st, std::index_sequence_for<P...>{}, static_cast<A&&>(a)...);
 }
 #define VIAI_LAUNCH(...)                                         \
     do {                                                         \
         (void)hipGetLastError();                                 \
-        hipLaunchKernelGGL(__VA_ARGS__);                         \
-        viai_plan_note_launch(__VA_ARGS__);                      \
+        viai_launch_once(__VA_ARGS__);                           \
         int viai_e_ = (int)hipGetLastError();                    \
         if (viai_e_ != 0 && viai_err_acc == 0) viai_err_acc = viai_e_; \
     } while (0)

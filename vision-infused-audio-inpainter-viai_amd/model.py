@@ -104,6 +104,8 @@ class FusedAdam:
         self.arena.zero_grad()
 
     def set_lr(self, lr):
+        """writes the device-side rate on the CURRENT stream: callers that run the optimizer on another stream (AudioModel's deferred
+        G update) order the write themselves -- use AudioModel.set_lr"""
         self.lr = float(lr)
         self.state[1] = self.lr
 
@@ -253,6 +255,15 @@ class AudioModel:
         head = "G.deconv1_1_1.weight" if self.use_video else "G.deconv1_1.weight"
         self._early_G = [("G.convblock3.conv3_0.weight", c3, g_hi), (head, g_lo, c3)]
         self._late_G = [(0, g_lo)] + ([(g_hi, aG.size)] if g_hi < aG.size else [])
+        # An InstanceNorm2d layer runs conv_bn_act once PER SAMPLE with the same weight (networks._instance_norm_layer): the trigger
+        # layer's backward is then invoked B times per pass and a hook armed for one invocation would hand the bucket to RCCL while the
+        # other samples are still accumulating into it.  Such models exchange each arena whole, after its last weight gradient.
+        def has_instance_norm(*mods):
+            return any(isinstance(m, nn.InstanceNorm2d) for mod in mods if mod is not None for m in mod.modules())
+        if has_instance_norm(self.netD):
+            self._early_D, self._late_D = [], [(0, aD.size)]
+        if has_instance_norm(self.Mel_Encoder, self.Mel_Decoder, self.VideoEncoder):
+            self._early_G, self._late_G = [], [(0, aG.size)]
 
     def _exchanging(self):
         return (self.world > 1 or self._force_allreduce) and not self._skip_exchange
@@ -326,6 +337,18 @@ class AudioModel:
         self.sync_pending_update()
         self._weights_changed()
 
+    def set_lr(self, lr, which=("G", "D")):
+        """learning rate of one or both optimizers (viai_amd.lrschedule.apply goes through here when handed the model).  The rate lives
+        in the device-side Adam state; the deferred Adam(E,G) of the previous step may still be reading it on the exchange stream,
+        so the write is ordered behind it."""
+        self.sync_pending_update()
+        if "G" in which:
+            self.optimizer_G.set_lr(lr)
+        if "D" in which:
+            self.optimizer_D.set_lr(lr)
+        self.current_lr = float(lr)
+        return self.current_lr
+
     def _weights_changed(self):
         """Parameters were written outside the optimizers (checkpoint load, manual surgery): re-pack the conv weight
         images now.  Eager steps would notice through the tensor versions; a captured graph contains no per-layer pack
@@ -383,6 +406,16 @@ class AudioModel:
             self._graphs = None
             self._graph_scratch = None
             ops.drop_scratch()            # scratch buffers allocated while capturing live in the dead graphs' private memory pool
+
+    def close(self):
+        """release what the launch plans / captured graphs hold (events, plan nodes, the graphs' memory pool); also runs from __del__"""
+        try:
+            self._drop_graphs()
+        except Exception:
+            pass
+
+    def __del__(self):
+        self.close()
 
     def _gan(self, pred, real):
         t = 1.0 if real else 0.0
@@ -554,7 +587,7 @@ class AudioModel:
             if self.use_plan:
                 # the capture is a recorder: the hipGraph is kept (it owns the kernel-argument arrays) but never instantiated
                 g = torch.cuda.CUDAGraph(keep_graph=True)
-                lib().viai_plan_log_begin()
+                check(lib().viai_plan_log_begin(), "viai_plan_log_begin")
                 try:
                     with torch.cuda.graph(g, pool=pool):
                         origin = torch.cuda.current_stream().cuda_stream
@@ -658,10 +691,13 @@ class AudioModel:
                 self._put(3, ops.l1_mean(fake, s.view(B, F, T, 1)))
                 emb = feats[-1].mean(dim=(1, 2))                   # bottleneck (B, h, T/16, 256) -> (B, 256)
                 self.mel_net_norm = torch.nn.functional.normalize(emb, p=2, dim=1)
-                # the retrieval metrics of the reference loop (utils/util.py:99-121) pair the audio embedding with the
-                # VIDEO embedding; without a visual branch there is nothing to pair it with
+                # the retrieval metrics of the reference loop (utils/util.py:99-121) pair the audio embedding with the VIDEO
+                # embedding, and the loop reads `video_net_norm` unconditionally after test() (train_whole_sync.py:82-83:
+                # util.to_np(model.video_net_norm)), so it is always a tensor.  Without a visual branch there is nothing to pair the
+                # audio embedding with: the attribute is a zero tensor of the same shape and the retrieval numbers computed from it
+                # carry no information (every "video" is equidistant from every clip).
                 self.video_net_norm = (torch.nn.functional.normalize(f_v.mean(dim=(2, 3)), p=2, dim=1)
-                                       if f_v is not None else None)
+                                       if f_v is not None else torch.zeros_like(self.mel_net_norm))
         finally:
             for m, t in zip(mods, was):
                 m.train(t)
@@ -747,6 +783,7 @@ class AudioModel:
         """tolerant partial load of E and G only (utils/util.py:124-144,165-173)."""
         path = path if path is not None else getattr(self.hparams, "resume_path", None)
         ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.sync_pending_update()          # the deferred Adam(E,G) of the last step may still be writing these parameters
         for mod, key in ((self.Mel_Encoder, "Mel_Encoder"), (self.Mel_Decoder, "Mel_Decoder")):
             own = mod.state_dict()
             for k, v in ck[key].items():
