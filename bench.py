@@ -15,6 +15,7 @@ JSON line is generated from the switches in effect).  Rank 0 prints ONE JSON lin
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -26,43 +27,48 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 METRIC = "masked mel-spectrogram clips/sec (G+D train step, 256x256 b16) at 1/2/4/8 GPUs"
+METRIC_WAVENET = "wavenet_vocoder incremental synthesis samples/sec (24 layers / 512 ch, 16 kHz, batch 8 streams)"
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
-# The default conv math is the bf16x3 split (csrc/conv_igemm_bf3.hip): every fp32 MAC costs six bf16 MFMA MACs, so the
-# ceiling for ALGORITHMIC fp32 flops on that kernel is the bf16 peak / 6.  VIAI_MATH=fp32 selects the exact-fp32 MFMA kernel.
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense 16-bit MFMA peak
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured with a float4 copy)
+# conv math: f16x2 split (three fp16 MFMA products per fp32 MAC: ceiling 2500 / 3) by default, bf16x3 (six products: 2500 / 6)
+# under VIAI_F16X2=0, exact fp32 MFMA (157.3) under VIAI_MATH=fp32.  The library names the family every call ran
+# (viai_conv2d_last_kernel); the suffix of the name says which arithmetic, and peak_of() prices it.
 BF3 = os.environ.get("VIAI_MATH", "") != "fp32"
-F16X2 = BF3 and os.environ.get("VIAI_F16X2", "1") != "0"     # wide forward layers: f16x2 split (three partial products)
-PEAK = MFMA_BF16_PEAK_TFLOPS / 6.0 if BF3 else MFMA_F32_PEAK_TFLOPS
-DOMINANT = ("conv_igemm_bf3_frag_kernel<3,2,2,2,2> (128x128x32 bf16x3 split-MFMA implicit-GEMM conv, fp32-grade accuracy; data-gradient launches"
-            + ("" if F16X2 else " and forward launches") + ")"
-            if BF3 else "conv_igemm_kernel<32,2,2,2,2> (128x128x32 fp32-MFMA implicit-GEMM conv, fwd + dgrad)")
+F16X2 = BF3 and os.environ.get("VIAI_F16X2", "1") != "0"
 
-
-# kernel behind each launch family of KernelTimer (the mirror predicates above decide the family of a call)
+# what the families the library reports are (descriptions only: which family a call runs is the library's decision)
 FAMILY_KERNELS = {
     "wgrad_patch_f16x2": "wgrad_patch_f16_kernel<1,128,64,4,1> (csrc/conv_wgrad_patch.hip: weight gradient of the stride-1 3x3 layers with >= 128 x 64 channels; all nine taps per block, "
                          "dy rows + x patch staged once per 64 pixels as [pixel][channel] fp16 planes, MFMA operands through ds_read_b64_tr_b16; f16x2 split)",
     "wgrad_patch_narrow_f16x2": "wgrad_patch_f16_kernel<1,32,32,4,4> (the narrow instance: 32 x 32 channel tile, four waves split the tile rows of a stage and write one split-K slab each)",
-    "wgrad_patch_s2_f16x2": "wgrad_patch_f16_kernel<2,128,32,2,1> (the stride-2 instance: 128 x 32 channel tile, input patch as four parity sub-patches, 2 blocks / CU)",
+    "wgrad_patch_s2_f16x2": "wgrad_patch_f16_kernel<2,128,32,2,1> (the stride-2 instance: 128 x 32 channel tile, input patch as four parity sub-patches)",
     "wgrad_bf3_f16x2": "wgrad_bf3_kernel<2,TM,TN> (csrc/conv_wgrad_bf3.hip: weight gradient, one block per tap x Cout tile x Cin tile, tiles transposed into LDS; f16x2 split)",
-    "wgrad_bf3": "wgrad_bf3_kernel<3,TM,TN> (bf16x3 weight gradient)",
-    "wgrad_mfma": "wgrad_mfma_kernel<*> (exact fp32 MFMA weight gradient, <= 32-channel layers)",
-    "wgrad32_all_taps": "wgrad32_halo_kernel (exact fp32 MFMA, <= 32 x <= 32 channels, stride 1: all taps per block)",
+    "wgrad_bf3_bf16x3": "wgrad_bf3_kernel<3,TM,TN> (bf16x3 weight gradient)",
+    "wgrad_mfma_f32": "wgrad_mfma_kernel<*> (exact fp32 MFMA weight gradient: <= 32-channel layers the patch kernel does not tile, the 7x7 image conv)",
+    "wgrad32_all_taps_f32": "wgrad32_halo_kernel (exact fp32 MFMA, <= 32 x <= 32 channels, stride 1: all taps per block)",
     "halo_wide256_f16x2": "conv_halo_wide_f16_kernel<2,4,2,2> (stride-1 3x3 conv, 8x16-pixel x 256-channel tile, f16x2 split MFMA: the 10x18 input patch of a 32-channel chunk is "
                           "staged once in LDS and read by all nine taps; weight fragments straight from global; forward and data-gradient launches of D.conv3)",
     "halo_wide128_f16x2": "conv_halo_wide_f16_kernel<2,2,2,2> (as above, 128-channel tile)",
     "halo_wide64_f16x2": "conv_halo_wide_f16_kernel<2,2,2,1> (64-channel tile)", "halo_wide32_f16x2": "conv_halo_wide_f16_kernel<4,1,1,1> (32-channel tile)",
     "halo_wide_s2_f16x2": "conv_halo_wide_f16_kernel<2,4,2,{2,1},2> (stride-2 forward, four parity sub-patches)",
-    "halo_f16x2": "conv_halo_f16_c32_kernel / conv_halo_bf3_kernel<CIN,TN,2> (32/64-channel stride-1 layers, f16x2)",
-    "halo": "conv_halo_bf3_kernel<CIN,TN,3> (32/64-channel stride-1 layers, bf16x3)",
-    "dgrad_s2_f16x2": "conv_dgrad_s2_patch_kernel (3x3 stride-2 data gradient, four parity classes fused, dy patch staged once per 32-channel chunk; f16x2)",
-    "dgrad_s2": "conv_dgrad_s2_bf3_kernel<3> (3x3 stride-2 data gradient, bf16x3)",
-    "igemm128x256_f16x2": "conv_igemm_bf3_frag_kernel<2,2,2,2,4> (128x256x32 f16x2 gather-GEMM conv, eight waves)",
+    "halo_c32_f16x2": "conv_halo_f16_c32_kernel (32 -> <= 32 channels, stride-1 3x3, the whole filter in registers; f16x2)",
+    "halo_f16x2": "conv_halo_bf3_kernel<CIN,TN,2> (32/64-channel stride-1 layers, filter streamed; f16x2)",
+    "halo_bf16x3": "conv_halo_bf3_kernel<CIN,TN,3> (32/64-channel stride-1 layers, bf16x3)",
+    "dgrad_s2_patch_f16x2": "conv_dgrad_s2_patch_kernel (3x3 stride-2 data gradient, four parity classes fused, dy patch staged once per 32-channel chunk; f16x2)",
+    "dgrad_s2_f16x2": "conv_dgrad_s2_bf3_kernel<2> (3x3 stride-2 data gradient, four parity classes fused; f16x2)",
+    "dgrad_s2_bf16x3": "conv_dgrad_s2_bf3_kernel<3> (3x3 stride-2 data gradient, bf16x3)",
+    "igemm128x256_f16x2": "conv_igemm_bf3_frag_kernel<2,2,2,2,4> (128x256x32 f16x2 gather-GEMM conv, eight waves, fragment-major weights from global)",
     "igemm128x128_f16x2": "conv_igemm_bf3_frag_kernel<2,2,2,2,2> (128x128x32 f16x2 gather-GEMM conv)",
-    "igemm128x128": "conv_igemm_bf3_frag_kernel<3,2,2,2,2> (128x128x32 bf16x3 gather-GEMM conv)",
+    "igemm128x128_bf16x3": "conv_igemm_bf3_frag_kernel<3,2,2,2,2> (128x128x32 bf16x3 gather-GEMM conv)",
+    "igemm_sk32x32_f16x2": "conv_igemm_bf3_sk_kernel<2> (small-M layers: 32x32 tile, the block's four waves split K; planar fp16 weight planes)",
+    "igemm_sk32x32_bf16x3": "conv_igemm_bf3_sk_kernel<3>",
+    "direct": "cin1_* / cout1_* streaming kernels (Cin = 1 or Cout = 1 layers: HBM-bound, plain fp32 FMA, no MFMA)",
 }
-PMC_KERNEL_OF = {"wgrad_patch_f16x2": "wgrad_patch_f16_kernel<1, 128", "wgrad_patch_s2_f16x2": "wgrad_patch_f16_kernel<2", "wgrad_patch_narrow_f16x2": "wgrad_patch_f16_kernel<1, 32", "wgrad_bf3_f16x2": "wgrad_bf3_kernel", "halo_wide256_f16x2": "conv_halo_wide_f16_kernel",
-                 "halo_wide128_f16x2": "conv_halo_wide_f16_kernel", "igemm128x256_f16x2": "frag_kernel<2, 2, 2, 2, 4", "igemm128x128_f16x2": "frag_kernel<2", "igemm128x128": "frag_kernel<3"}
+# kernel-name fragment of a family in the rocprofv3 counter summaries under profiles/ (traffic of the dominant kernel)
+PMC_KERNEL_OF = {"wgrad_patch_f16x2": "wgrad_patch_f16_kernel<1, 128", "wgrad_patch_s2_f16x2": "wgrad_patch_f16_kernel<2", "wgrad_patch_narrow_f16x2": "wgrad_patch_f16_kernel<1, 32",
+                 "wgrad_bf3_f16x2": "wgrad_bf3_kernel", "halo_wide256_f16x2": "conv_halo_wide_f16_kernel", "halo_wide128_f16x2": "conv_halo_wide_f16_kernel",
+                 "igemm128x256_f16x2": "frag_kernel<2, 2, 2, 2, 4", "igemm128x128_f16x2": "frag_kernel<2", "igemm128x128_bf16x3": "frag_kernel<3"}
 
 
 def math_string():
@@ -84,8 +90,8 @@ def math_string():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 30; --config wavenet: 2048 synthesis time steps)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 5; wavenet: 64)")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--frames", type=int, default=256)
@@ -97,21 +103,50 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-layer conv timing table to stderr")
-    ap.add_argument("--config", choices=["audio", "av", "av_msd"], default="audio",
+    ap.add_argument("--config", choices=["audio", "av", "av_msd", "wavenet"], default="audio",
                     help="audio = BASELINE configs[1] (the metric); av = configs[2] (+ResNet-18 visual branch, N = T/4 frames); "
-                         "av_msd = configs[3] model (+3-scale D).  Non-default configs print the same JSON shape without roofline")
+                         "av_msd = configs[3] model (+3-scale D); wavenet = configs[4] (incremental synthesis, 8 streams, reference-size stack)")
     ap.add_argument("--cpu-batch", type=int, default=2, help="clips per CPU-baseline step (bounded sample)")
-    return ap.parse_args()
+    ap.add_argument("--share-gpu", action="store_true", help="--gpus N on a box with fewer than N devices: the ranks share the visible device(s) and "
+                    "exchange over gloo (RCCL refuses two ranks on one device).  Exercises the launch contract and the bucketed exchange; not a measurement")
+    a = ap.parse_args()
+    wn = a.config == "wavenet"
+    a.steps = a.steps if a.steps is not None else (2048 if wn else 30)
+    a.warmup = a.warmup if a.warmup is not None else (64 if wn else 5)
+    return a
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: run the same command line as N ranks under torch.distributed.run (one
+    process per GPU, RCCL), pass rank 0's JSON line through and exit with the launcher's status."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_dev < args.gpus:
+        if not args.share_gpu:
+            sys.exit("bench.py: --gpus %d but %d device(s) visible (add --share-gpu to run the ranks on the visible device(s) over gloo: "
+                     "a launch-contract check, not a measurement)" % (args.gpus, n_dev))
+        env["VIAI_DIST_BACKEND"] = "gloo"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 class KernelTimer:
-    """HIP-event timing of the conv launches on torch's current stream (the stream the kernels run on).
-    Wraps the ctypes entry points of libviai_hip.so; flops are the ALGORITHMIC 2*MACs of each call."""
+    """HIP-event timing of the conv launches on the stream each one is launched on.  Wraps the ctypes entry points of
+    libviai_hip.so; flops are the ALGORITHMIC 2*MACs of each call; the kernel family of a call is what the LIBRARY reports it
+    launched (`viai_conv2d_last_kernel`, include/viai_hip.h) -- bench.py holds no copy of the dispatch rules."""
 
     def __init__(self, lib):
         self.lib = lib
-        self.records = []          # (family, flops, n_launches, ev0, ev1)
+        self.records = []          # (family, flops, n_launches, ev0, ev1, entry point, layer key)
         self.orig = {}
+        self._buf = ctypes.create_string_buffer(64)
 
     @staticmethod
     def _geom(d):
@@ -125,13 +160,12 @@ class KernelTimer:
         lib = self.lib
         from viai_amd import ops as ops_mod
 
-        def wrap(name, family_of, counts=lambda args: True):
+        def wrap(name, counts=lambda args: True):
             fn = getattr(lib, name)
             self.orig[name] = fn
 
             def timed(desc_ref, *args):
                 d = desc_ref._obj
-                fam, nl = family_of(d)
                 cin, flops = self._geom(d)
                 if not counts(args):
                     flops = 0.0                      # a recomputation of the same conv (fused Cin = 1 layer): time yes, algorithmic flops no
@@ -143,141 +177,15 @@ class KernelTimer:
                 e0.record(strm)
                 r = fn(desc_ref, *args)
                 e1.record(strm)
-                self.records.append((fam, flops, nl, e0, e1, name, (d.N, d.IH, d.IW, d.C1 + d.C2, d.Cout, d.kh, d.kw, d.sh, d.sw, d.transposed)))
+                nl = int(lib.viai_conv2d_last_kernel(self._buf, 64))       # same thread as the call above: the tag is per thread
+                fam = self._buf.value.decode() or "unknown"
+                self.records.append((fam, flops, max(nl, 1), e0, e1, name, (d.N, d.IH, d.IW, d.C1 + d.C2, d.Cout, d.kh, d.kw, d.sh, d.sw, d.transposed)))
                 return r
             setattr(lib, name, timed)
 
-        def tile_m(M, n_out):                     # mirror of viai_igemm_tile_m (csrc/conv_igemm.hip)
-            if n_out <= 32:
-                return 128
-            b = -(-M // 128) * (-(-n_out // 128) if n_out > 64 else -(-n_out // 64))
-            return 128 if b >= 512 else 64
-
-        def igemm_name(M, n_out):
-            if BF3 and n_out > 32 and not (tile_m(M, n_out) == 128 and n_out > 64) and -(-M // 64) * -(-n_out // 64) < 512:
-                return "igemm_sk32x32"               # mirror of viai_bf3_sk_ok (csrc/conv_igemm_bf3.hip)
-            if tile_m(M, n_out) == 64:
-                return "igemm64x64"
-            return "igemm128x128" if n_out > 64 else ("igemm128x64" if n_out > 32 else "igemm128x32")
-
-        def wide_f16(M, n_out):                   # mirror of viai_conv_igemm_bf3_launch: the eight-wave 128 x 256 tile where it fits
-            wn4 = os.environ.get("VIAI_F16_WN4", "1") != "0"
-            return "igemm128x256_f16x2" if (wn4 and n_out % 256 == 0 and -(-M // 128) * (n_out // 256) >= 256) else "igemm128x128_f16x2"
-
-        def out_pixels(d):
-            oh = (d.IH - 1 - 2 * d.ph + d.kh) if d.transposed else (d.IH + 2 * d.ph - d.kh) // d.sh + 1
-            ow = (d.IW - 1 - 2 * d.pw + d.kw) if d.transposed else (d.IW + 2 * d.pw - d.kw) // d.sw + 1
-            return d.N * oh * ow
-
-        def halo_ok(c_in, c2, c_out, d, oh, ow):     # mirror of viai_conv_halo_ok (csrc/conv_halo_bf3.hip)
-            return (BF3 and c2 == 0 and c_in in (32, 64) and c_out <= 64 and d.sh == 1 and d.sw == 1
-                    and d.kh <= 3 and d.kw <= 3 and oh % 8 == 0 and ow % 16 == 0)
-
-        def halo16(c_in, c_out, d):                  # mirror of viai_conv_halo16_ok: filter-in-registers f16x2 variant
-            return F16X2 and os.environ.get("VIAI_HALO16", "1") != "0" and c_in == 32 and c_out <= 32 and d.kh == 3 and d.kw == 3
-
-        def halo_wide(c1, c2, c_out, oc1_split_ok, d, oh, ow):        # mirror of viai_conv_halo_wide_ok (csrc/conv_halo_bf3.hip)
-            if not F16X2 or os.environ.get("VIAI_HALO_WIDE", "1") == "0":
-                return None
-            if c1 % 32 or c2 % 32 or c1 < 32 or not oc1_split_ok or not (c_out in (32, 64) or c_out % 128 == 0):
-                return None
-            if c_out <= 64 and c1 + c2 <= 64 and c2 == 0:
-                return None
-            s2 = (d.sh, d.sw) == (2, 2) and not d.transposed and os.environ.get("VIAI_HALO_WIDE_S2", "1") != "0"
-            if (d.kh, d.kw) != (3, 3) or not ((d.sh, d.sw) == (1, 1) or s2) or oh % 8 or ow % 16:
-                return None
-            if s2 and (c2 != 0 or c_out % 128):
-                return None
-            tiles = d.N * (oh // 8) * (ow // 16)
-            if tiles * (c_out // 128 if c_out >= 128 else 1) < 192:
-                if not (c_out >= 128 and tiles * (c_out // 64) >= int(os.environ.get("VIAI_HALO_WIDE_MIN64", "96"))):
-                    return None
-                return "halo_wide_s2_f16x2" if s2 else "halo_wide64_f16x2"
-            if s2:
-                return "halo_wide_s2_f16x2"
-            if c_out <= 64:
-                return "halo_wide%d_f16x2" % c_out
-            wn4 = os.environ.get("VIAI_HALO_WIDE_WN4", "1") != "0" and c_out % 256 == 0 and tiles * (c_out // 256) >= 256
-            return "halo_wide256_f16x2" if wn4 else "halo_wide128_f16x2"
-
-        def out_hw(d):
-            oh = (d.IH - 1 - 2 * d.ph + d.kh) if d.transposed else (d.IH + 2 * d.ph - d.kh) // d.sh + 1
-            ow = (d.IW - 1 - 2 * d.pw + d.kw) if d.transposed else (d.IW + 2 * d.pw - d.kw) // d.sw + 1
-            return oh, ow
-
-        def fam_fwd(d):
-            cin = d.C1 + d.C2
-            if cin == 1 or d.Cout == 1:
-                return "direct", 1
-            if halo_ok(d.C1, d.C2, d.Cout, d, *out_hw(d)):
-                return ("halo_f16x2" if F16X2 else "halo"), 1
-            hw = halo_wide(d.C1, d.C2, d.Cout, True, d, *out_hw(d))
-            if hw:
-                return hw, 1
-            nm = igemm_name(out_pixels(d), d.Cout)
-            if F16X2 and nm == "igemm128x128":
-                return wide_f16(out_pixels(d), d.Cout), 1                                               # conv_igemm_bf3_frag_kernel<2,...>
-            return (nm + "_f16x2" if (F16X2 and os.environ.get("VIAI_F16_PLANAR", "1") != "0") else nm), 1    # planar f16x2 LDS-weight / split-K kernels
-
-        def fam_dgrad(d):
-            cin = d.C1 + d.C2
-            if cin == 1 or d.Cout == 1:
-                return "direct", 1
-            if halo_ok(d.Cout, 0, cin, d, d.IH, d.IW):
-                return "halo", 1
-            if (BF3 and not d.transposed and (d.kh, d.kw, d.sh, d.sw, d.ph, d.pw) == (3, 3, 2, 2, 1, 1) and d.IH % 2 == 0 and d.IW % 2 == 0
-                    and d.Cout % 32 == 0 and cin % 64 == 0 and -(-(d.N * (d.IH // 2) * (d.IW // 2)) // 128) * (cin // 64) >= (32 if ((d.IH // 2) % 8 == 0 and (d.IW // 2) % 16 == 0) else 256)):
-                return "dgrad_s2", 1                 # mirror of viai_dgrad_s2_ok (csrc/conv_dgrad_s2_bf3.hip); f16x2: the patch-staged kernel where the base lattice tiles in 8 x 16
-            ncls = d.sh * d.sw                        # one launch per output parity class
-            return igemm_name(-(-(d.N * d.IH * d.IW) // ncls), cin), ncls
-
-        def fam_wgrad(d):
-            cin = d.C1 + d.C2
-            if cin == 1 or d.Cout == 1:
-                return "direct", 1
-            if BF3 and cin > 32 and d.Cout > 32 and not (d.C2 > 0 and d.C1 % 64):
-                return "wgrad_bf3", 1                # mirror of viai_wgrad_bf3_ok (csrc/conv_wgrad_bf3.hip)
-            if (os.environ.get("VIAI_WGRAD32", "1") != "0" and d.C2 == 0 and cin <= 32 and d.Cout <= 32 and d.sh == 1 and d.sw == 1
-                    and d.kh <= 3 and d.kw <= 3 and out_hw(d)[1] % 32 == 0):
-                return "wgrad32_all_taps", 1         # mirror of viai_wgrad32_ok (csrc/conv_wgrad.hip)
-            return "wgrad_mfma", 1
-
-        def fam_dgrad_f16(d):                        # viai_conv2d_dgrad_f16: the f16x2 instances of the same kernels
-            f, n = fam_dgrad(d)
-            if f != "halo" and d.sh == 1 and d.sw == 1:
-                hw = halo_wide(d.Cout, 0, d.C1 + d.C2, d.C2 == 0 or d.C1 % 32 == 0, d, d.IH, d.IW)
-                if hw:
-                    return hw, 1
-            if f == "igemm128x128":
-                return wide_f16(-(-(d.N * d.IH * d.IW) // n), d.C1 + d.C2), n
-            return f + "_f16x2", n
-
-        wrap("viai_conv2d_fwd", fam_fwd)
-        wrap("viai_conv2d_dgrad", fam_dgrad)
-        def fam_wgrad_f16(d):
-            f, n = fam_wgrad(d)
-            oh, ow = out_hw(d)
-            # mirror of pick() in csrc/conv_wgrad_patch.hip
-            s1 = (d.sh, d.sw) == (1, 1)
-            s2 = (d.sh, d.sw) == (2, 2) and not d.transposed and os.environ.get("VIAI_WGRAD_PATCH_S2", "1") != "0"
-            if (os.environ.get("VIAI_WGRAD_PATCH", "1") != "0" and (d.kh, d.kw) == (3, 3) and (s1 or s2)
-                    and d.N * -(-oh // 8) * -(-ow // 16) >= 64 and oh * ow * 3 >= -(-oh // 8) * -(-ow // 16) * 128 and f not in ("direct",)):
-                def tiles_ok(bm, bn):
-                    return d.Cout % bm == 0 and d.C1 % bn == 0 and d.C2 % bn == 0 and d.C1 >= bn
-                if s2 and tiles_ok(128, 32):
-                    return "wgrad_patch_s2_f16x2", n
-                if s1 and tiles_ok(128, 64):
-                    return "wgrad_patch_f16x2", n
-                if s1 and tiles_ok(32, 32) and os.environ.get("VIAI_WGRAD_PATCH_NARROW", "1") != "0":
-                    return "wgrad_patch_narrow_f16x2", n
-            return f + "_f16x2", n
-
-        wrap("viai_conv2d_dgrad_f16", fam_dgrad_f16)
-        wrap("viai_conv2d_wgrad_f16", fam_wgrad_f16)
-        wrap("viai_conv2d_wgrad", fam_wgrad)
-        # fused Cin = 1 conv + BatchNorm layer: statistics pass (z = NULL, args[6]) + apply pass; the weight gradient from dz
-        wrap("viai_conv2d_cin1_bn_fwd", lambda d: ("direct", 1), counts=lambda args: bool(args[6]))
-        wrap("viai_conv2d_cin1_bn_wgrad", lambda d: ("direct", 1))
+        for name in FAMILY_CALLS:
+            # fused Cin = 1 conv + BatchNorm layer: statistics pass (z = NULL, args[6]) + apply pass: the flops count once
+            wrap(name, counts=(lambda args: bool(args[6])) if name == "viai_conv2d_cin1_bn_fwd" else (lambda args: True))
 
     def per_layer(self):
         torch.cuda.synchronize()
@@ -286,7 +194,7 @@ class KernelTimer:
             t = agg.setdefault((name, f, key), [0.0, 0.0, 0])
             t[0] += flops; t[1] += e0.elapsed_time(e1) * 1e-3; t[2] += 1
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-        return ["%-18s %-13s %-44s n=%3d avg %8.1f us  %6.1f TF/s" % (k[0][5:], k[1], str(k[2]), v[2], v[1] / v[2] * 1e6, v[0] / v[1] * 1e-12)
+        return ["%-18s %-26s %-44s n=%3d avg %8.1f us  %6.1f TF/s" % (k[0][5:], k[1], str(k[2]), v[2], v[1] / v[2] * 1e6, v[0] / v[1] * 1e-12)
                 for k, v in rows]
 
     def uninstall(self):
@@ -302,6 +210,15 @@ class KernelTimer:
             t[1] += e0.elapsed_time(e1) * 1e-3
             t[2] += nl
         return fam
+
+
+def peak_of(family):
+    """ceiling of a kernel family's arithmetic, from the suffix the library puts on the name"""
+    if family.endswith("_f16x2"):
+        return MFMA_BF16_PEAK_TFLOPS / 3.0
+    if family.endswith("_bf16x3"):
+        return MFMA_BF16_PEAK_TFLOPS / 6.0
+    return MFMA_F32_PEAK_TFLOPS
 
 
 def cpu_baseline(args):
@@ -419,39 +336,143 @@ def front_end_stages(dev, batch, bins, frames):
                     "not a sustained-bandwidth measurement" % (n_samples, bins, fr)}
 
 
+def cpu_baseline_av(args, num_D):
+    """configs[2] / [3] on the host cores: the oracle's vision-infused step (oracle/viai_oracle.av_step_no_update: the reference's
+    modules composed as declared) on ONE clip of the GPU line's shape -- 64 + 64 frames through two ResNet-18s forward and backward
+    is ~1.4 TFLOP, the bounded sample the bench contract asks for; no Adam (the oracle's AV step has none), which favours the CPU."""
+    from oracle import viai_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count()
+    threads = max(1, min(avail, 16))
+    torch.set_num_threads(threads)
+    nf = args.frames // 4
+    s = O.cf_uniform("bench.cpu.av.s", (1, 1, args.bins, args.frames))
+    mask = O.make_mask(1, args.frames, "bench.cpu.av.mask")
+    video = O.cf_uniform("bench.cpu.av.video", (1, nf, 3, 224, 224), -1, 1)
+    flow = O.cf_uniform("bench.cpu.av.flow", (1, nf, 2, 224, 224), -1, 1)
+    E, G = O.encoder_state(), O.decoder_variant_state("image")
+    D = O.msd_state(num_D) if num_D > 1 else O.disc_state()
+    V = O.image_embedding2_state()
+    t0 = time.perf_counter()
+    O.av_step_no_update(E, G, D, V, s, mask, video, flow, num_D=num_D, lambda_contrast=0.1)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "oracle/viai_oracle.av_step_no_update (torch CPU fp32, %d threads of %d logical CPUs), ONE clip of %dx%d with %d video + %d flow "
+                      "frames per step, forward + backward without the Adam updates, one step (%.1f s)" % (threads, avail, args.bins, args.frames, nf, nf, dt)}
+
+
+def main_wavenet(args):
+    """BASELINE configs[4]: wavenet_vocoder incremental synthesis (wavenet.py:237-364) at the reference's size -- 24 layers / 4 stacks,
+    512 residual + gate / 256 skip channels, 24.7 M parameters -- on 8 streams.  A step = one synthesis time step (8 samples).
+    Replicas only (independent streams, sequential in T): N ranks would run N copies, so this configuration is single-GPU."""
+    from viai_amd.wavenet import WaveNet
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(1234)
+    B, hop = 8, 256
+    T = -(-(args.warmup + args.steps) // hop) * hop                 # whole conditioning frames
+    net = WaveNet(dropout=0.0).to(dev).eval()
+    c = torch.rand(B, 80, T // hop, device=dev)
+    timing = {"warmup": T - args.steps}
+    net.incremental_forward(None, c=c, T=T, log_scale_min=-7.0, timing=timing)
+    ms = timing["ms"] / timing["steps"]
+    n_param = sum(p.numel() for p in net.parameters())
+    # weight bytes one time step must stream: every layer's linearised dilated conv (3 x 512 x 512), conditioning (512 x 80), out and
+    # skip 1x1s, first conv, head -- the fp32 weights the step kernels read (the up-sampling net runs once, outside the loop)
+    wbytes = 4 * sum(p.numel() for n, p in net.named_parameters() if n.endswith("weight_v") and not n.startswith("upsample_conv"))
+    ach = wbytes / (ms * 1e-3) * 1e-9
+    out = {
+        "metric": METRIC_WAVENET, "value": round(B * 1e3 / ms, 1), "unit": "samples/s", "n_gpus": 1, "steps": timing["steps"], "warmup": timing["warmup"],
+        "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[4] (NOT the headline metric): wavenet_vocoder incremental synthesis, %d layers / %d stacks / 512 / 512 / 256 channels "
+                               "(%d parameters), local conditioning at hop 256, %d streams, mixture-of-logistics sampling; a step = one time step"
+                               % (len(net.conv_layers), 4, n_param, B),
+                   "global_batch": B, "parallelism": "replicas only (independent streams)", "real_time_factor_16khz": round(1e3 / ms / 16000.0, 3),
+                   "launches_per_step": 2 * len(net.conv_layers) + 2, "launch": "viai_wavenet_synth_run: C loop over the time steps, time index by value"},
+        "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel": "wn_gate_kernel / wn_out_skip_kernel / wn_head_kernel chain (csrc/wavenet.hip): %d dependent launches per time step" % (2 * len(net.conv_layers) + 2),
+                     "algorithmic_bytes_per_step": wbytes,
+                     "note": "weight-streaming bound (SURVEY.md section 8d: incremental lower bound per time step = weight bytes / bandwidth): every time step reads "
+                             "all %.1f MB of fp32 weights once, whatever level of the hierarchy serves them (they fit the 256 MB Infinity Cache, not the 32 MB of L2); "
+                             "the floor at the HBM peak is %.1f us per step, the chain of dependent launches measures %.1f us" % (wbytes * 1e-6, wbytes / HBM_PEAK_GBPS * 1e-3, ms * 1e3)},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import wavenet_oracle as W
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count()
+        threads = max(1, min(avail, 16))
+        torch.set_num_threads(threads)
+        cfg = W.WNConfigFull
+        sd = W.wavenet_state(cfg)
+        Tc = hop
+        cc = torch.rand(B, cfg.cin_channels, 1)
+        u1, u2 = torch.rand(B, Tc, 10).clamp(1e-5, 1 - 1e-5), torch.rand(B, Tc).clamp(1e-5, 1 - 1e-5)
+        t0 = time.perf_counter()
+        W.incremental_forward_ring(sd, cc, Tc, u1, u2, cfg)          # one whole conditioning frame: 256 time steps x 8 streams
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(B * Tc / dt, 1), "unit": "samples/s", "cores": threads, "kind": "port",
+                               "sample": "oracle/wavenet_oracle.incremental_forward_ring (the reference's ring-buffer formulation, conv.py:17-46, torch CPU fp32, %d threads), "
+                                         "%d streams x %d time steps at the reference's size (%.1f s)" % (threads, B, Tc, dt)}
+    print(json.dumps(out), flush=True)
+
+
+def shutdown(world):
+    """leave the process group the clean way: every collective of this process has completed (device sync + barrier) before the
+    communicator is destroyed, and nothing of torch.distributed is left for interpreter exit to tear down in an arbitrary order."""
+    if world <= 1 or not torch.distributed.is_initialized():
+        return
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        spawn_ranks(args)                                    # does not return
+    if args.config == "wavenet":
+        if int(os.environ.get("RANK", "0")) == 0:
+            main_wavenet(args)
+        return
     from viai_amd import _lib, ddp, synth
     from viai_amd.model import AudioModel, StepConfig
 
     rank, local, world = ddp.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    n_dev = torch.cuda.device_count()
+    shared = world > n_dev                                # --share-gpu: several ranks per device (gloo)
+    local = local % n_dev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _lib.load()
+    av = args.config != "audio"
 
     hp = StepConfig()
     hp.cin_channels, hp.max_mel_lengths, hp.batch_size = args.bins, args.frames, args.batch
     torch.manual_seed(1234)                               # identical init on every rank (DDP semantics)
-    if args.config != "audio":
+    if av:
         hp.use_video, hp.lambda_contrast = True, 0.1
         hp.num_D = 3 if args.config == "av_msd" else 1
-        args.no_roofline = args.no_cpu_baseline = True
     model = AudioModel(hp, device=dev, use_graph=args.graph, use_plan=args.plan)
     ddp.broadcast_arena(model.arena_G.flat)
     ddp.broadcast_arena(model.arena_D.flat)
 
     s = synth.mel_batch(args.batch, args.bins, args.frames, "bench.s", rank).to(dev)
     mask = synth.time_mask(args.batch, args.frames, "bench.mask", rank).to(dev)
-    if args.config != "audio":
+    inputs = {}
+    if av:
         nf = args.frames // 4
-        video = synth.uniform("bench.video.r%d" % rank, (args.batch, nf, 3, 224, 224), -1, 1).to(dev)
-        flow = synth.uniform("bench.flow.r%d" % rank, (args.batch, nf, 2, 224, 224), -1, 1).to(dev)
-        model.set_inputs(s, mask, video=video, flow=flow)
-    else:
-        model.set_inputs(s, mask)
+        inputs = {"video": synth.uniform("bench.video.r%d" % rank, (args.batch, nf, 3, 224, 224), -1, 1).to(dev),
+                  "flow": synth.uniform("bench.flow.r%d" % rank, (args.batch, nf, 2, 224, 224), -1, 1).to(dev)}
+    model.set_inputs(s, mask, **inputs)
 
     def barrier():
         if world > 1:
@@ -492,7 +513,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("configs[1]: audio-only MelEncoder+MelDecoder G + MelDiscriminator (PatchGAN) D train step, "
                                 "%dx%d mel, batch %d per GPU, BCE-GAN + 100*L1, Adam(2e-4, 0.5, 0.999)" % (args.bins, args.frames, args.batch))
-                   if args.config == "audio" else
+                   if not av else
                    ("configs[%d] (NOT the metric config): vision-infused G (2x ResNet-18 on %d frames/clip, tiled into the bottleneck) + %s, "
                     "%dx%d mel, batch %d per GPU" % (2 if args.config == "av" else 3, args.frames // 4,
                                                       "PatchGAN D" if args.config == "av" else "3-scale D", args.bins, args.frames, args.batch)),
@@ -500,27 +521,33 @@ def main():
                    "launch": ("launch plan replayed from C (3 segments; same kernels / streams / edges as the eager step)" if args.plan else
                               "hipGraph replay (3 segments)" if args.graph else "eager, weight gradients on a side stream"),
                    "math": math_string(),
-                   "host_enqueue_ms_per_step": round(enqueue_ms / args.steps, 3), "algorithmic_gflop_per_step": 1208.0, "step_tflops": round(1208.0 * 1e-3 / (ms_per_step * 1e-3), 2),
+                   "host_enqueue_ms_per_step": round(enqueue_ms / args.steps, 3),
                    "loss_d": round(losses[0], 5), "loss_g": round(losses[1], 5)},
     }
+    if not av:
+        out["config"]["algorithmic_gflop_per_step"] = 1208.0
+        out["config"]["step_tflops"] = round(1208.0 * 1e-3 / (ms_per_step * 1e-3), 2)
+    if shared:
+        out["config"]["ranks_share_devices"] = ("%d ranks on %d device(s), exchange staged through the host over gloo: a check of the launch contract and the "
+                                                "bucketed exchange, NOT a scaling measurement" % (world, n_dev))
     if comm_exposed is not None:
         out["config"]["comm_ms_exposed"] = comm_exposed
-        out["config"]["exchange"] = ("RCCL all-reduce of the flat gradient arenas in buckets launched from gradient-ready hooks inside the backward "
+        out["config"]["exchange"] = ("%s all-reduce of the flat gradient arenas in buckets launched from gradient-ready hooks inside the backward "
                                      "(D: conv3..conv4 early, rest at the end; G: two decoder buckets early, encoder at the end); the G exchange + "
                                      "Adam(E,G) + weight re-pack overlap the next step's D(real) forward/backward; comm_ms_exposed = ms_per_step - "
-                                     "ms_per_step of the same steps without the collectives")
+                                     "ms_per_step of the same steps without the collectives" % ("gloo (host-staged)" if shared else "RCCL"))
 
     if rank == 0 and not args.no_roofline:
         # instrumented eager pass over the same workload: HIP events around every conv launch
         m2 = AudioModel(hp, device=dev, use_graph=False)
         m2._skip_exchange = True              # rank 0 only: the other ranks are already at the final barrier, a collective here would hang
-        m2.set_inputs(s, mask)
+        m2.set_inputs(s, mask, **inputs)
         for i in range(2):
             m2.optimize_parameters(i)
         torch.cuda.synchronize()
         kt = KernelTimer(lib)
         kt.install()
-        nprof = min(args.steps, 10)
+        nprof = min(args.steps, 3 if av else 10)
         for i in range(nprof):
             m2.optimize_parameters(i)
         fam = kt.summary()
@@ -528,22 +555,19 @@ def main():
             print("\n".join(kt.per_layer()), file=sys.stderr)
         kt.uninstall()
         tot_t = sum(v[1] for v in fam.values())
+        tot_f = sum(v[0] for v in fam.values())
         # dominant kernel = the MFMA kernel family that holds the most time of the step, whichever it is; each family is priced
         # against the ceiling of ITS arithmetic: f16x2 = 2500 / 3 partial products, bf16x3 = 2500 / 6, exact fp32 MFMA = 157.3
-        def peak_of(k):
-            if k in ("wgrad_mfma", "wgrad32_all_taps") or not BF3:
-                return MFMA_F32_PEAK_TFLOPS
-            return MFMA_BF16_PEAK_TFLOPS / 3.0 if k.endswith("f16x2") else MFMA_BF16_PEAK_TFLOPS / 6.0
         cands = [k for k in fam if k != "direct"]                      # "direct" = the Cin = 1 / Cout = 1 streaming convs (HBM-bound, no MFMA)
         dom = max(cands, key=lambda k: fam[k][1])
         f, t, n = fam[dom]
         ach = f / t * 1e-12
         peak = peak_of(dom)
-        dom_name = FAMILY_KERNELS.get(dom, dom)
+        nprod = 3 if dom.endswith("_f16x2") else 6
         # the same kernel with nothing running beside it (weight gradients back on the main stream): what the kernel
         # itself reaches, without the time-sharing the as-run figure above includes
         alone = None
-        if m2._wgrad_stream is not None:
+        if m2._wgrad_stream is not None and not av:
             side, m2._wgrad_stream = m2._wgrad_stream, None
             m2.optimize_parameters(0)
             torch.cuda.synchronize()
@@ -561,24 +585,26 @@ def main():
             "frac": round(ach / peak, 4), "traffic": None,
             "peak_note": ("algorithmic fp32 flops against the dense 16-bit MFMA peak (2500) / %d partial products per MAC; "
                           "the same flops are %.2fx the fp32-MFMA peak (157.3); with random operands the pipes sustain 1810 "
-                          "(profiles/r01_e_mfma_probe.txt), i.e. %.2f of the sustained ceiling"
-                          % (3 if dom.endswith("f16x2") else 6, ach / MFMA_F32_PEAK_TFLOPS, ach / (1810.0 / (3.0 if dom.endswith("f16x2") else 6.0))))
+                          "(profiles/r01_e_mfma_probe.txt), i.e. %.2f of the sustained ceiling" % (nprod, ach / MFMA_F32_PEAK_TFLOPS, ach / (1810.0 / nprod)))
                          if peak != MFMA_F32_PEAK_TFLOPS else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
             "dominant_rule": "the MFMA kernel family with the largest share of the summed conv-launch time of the step (conv_time_share_by_kernel); "
-                             "frac_by_kernel prices every family against its own ceiling",
-            "kernel": dom_name, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
+                             "frac_by_kernel prices every family against its own ceiling; families are the ones the library reports per call "
+                             "(viai_conv2d_last_kernel: the name's suffix is the arithmetic), descriptions in `kernels`",
+            "kernel": FAMILY_KERNELS.get(dom, dom), "family": dom, "launches_per_step": n // nprof, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_step_in_kernel": round(f / nprof * 1e-9, 1),
             "how": "HIP events on the launch stream of each call (main stream, or the weight-gradient side stream), %d instrumented steps of the same eager step after the timed region" % nprof,
-            "launch_family_rule": ("igemm128x128 = conv_igemm_bf3_frag_kernel<3,2,2,2,2> (bf16x3); igemm128x128_f16x2 / igemm128x256_f16x2 = conv_igemm_bf3_frag_kernel<2,2,2,2,2> / <2,2,2,2,4> (f16x2 split: ceiling 2500/3; the 128x256 eight-wave tile where Cout % 256 == 0 and it still yields >= 256 blocks); igemm64x64 = conv_igemm_bf3_lds_kernel<1,1,2,2[,NP]>; igemm_sk32x32 = conv_igemm_bf3_sk_kernel<NP> (small-M layers, waves split K); a _f16x2 suffix on these = the NP = 2 instance (planar fp16 weight planes); "
-                                   "igemm128x64/x32 = conv_igemm_bf3_lds_kernel<2,1,2,2>/<1,1,4,1>; halo_wide{256,128,64,32}_f16x2 = conv_halo_wide_f16_kernel<2,4,2,2> / <2,2,2,2> / <2,2,2,1> / <4,1,1,1> (stride-1 3x3 layers with Cin >= 32: patch staged once per 32-channel chunk), halo_wide_s2_f16x2 = its <2,4,2,{2,1},2> instances (stride-2 forward, four parity sub-patches); halo[_f16x2] = conv_halo_bf3_kernel<CIN,TN,3|2> (32/64-channel stride-1 layers) and, for 32 -> <=32 channels, conv_halo_f16_c32_kernel (filter in registers); dgrad_s2[_f16x2] = conv_dgrad_s2_bf3_kernel<3|2> / conv_dgrad_s2_patch_kernel (3x3 stride-2 data gradient, four parity classes fused; the patch kernel stages the dy patch once per 32-channel chunk); wgrad_bf3 = wgrad_bf3_kernel<*>; "
-                                   "wgrad_mfma = fp32 wgrad_mfma_kernel<*> (<= 32-channel layers); wgrad32_all_taps = wgrad32_halo_kernel (fp32 MFMA, <= 32 x <= 32 channels, stride 1: all taps per block)") if BF3 else
-                                  "igemm64x64 = conv_igemm_kernel<32,1,1,2,2> (small-M layers), igemm128xN = <32,2,2,2,2>/<32,2,1,2,2>/<32,1,1,4,1>",
+            "kernels": {k: FAMILY_KERNELS.get(k, k) for k in sorted(fam)},
             "conv_time_share_by_kernel": {k: round(v[1] / tot_t, 3) for k, v in sorted(fam.items())},
             "conv_tflops_by_kernel": {k: round(v[0] / v[1] * 1e-12, 2) for k, v in sorted(fam.items()) if v[1] > 0},
             "frac_by_kernel": {k: round(v[0] / v[1] * 1e-12 / peak_of(k), 3) for k, v in sorted(fam.items()) if v[1] > 0 and k != "direct"},
-            "conv_frac_whole_step": round(sum(v[0] for v in fam.values()) / tot_t * 1e-12 / (MFMA_BF16_PEAK_TFLOPS / 3.0), 4),
+            "conv_frac_whole_step": round(tot_f / tot_t * 1e-12 / (MFMA_BF16_PEAK_TFLOPS / 3.0), 4),
             "conv_ms_per_step": round(tot_t / nprof * 1e3, 3),
+            "conv_gflop_per_step_timed": round(tot_f / nprof * 1e-9, 1),
         }
+        if av:
+            out["config"]["algorithmic_gflop_per_step"] = round(tot_f / nprof * 1e-9, 1)
+            out["config"]["step_tflops"] = round(tot_f / nprof * 1e-12 / (ms_per_step * 1e-3), 2)
+            out["config"]["algorithmic_gflop_note"] = "2 x MACs of every conv launch of the step (forward, data gradient, weight gradient), summed by the instrumented pass"
         if alone is not None:
             out["roofline"]["standalone"] = alone
         # memory-side traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
@@ -586,7 +612,7 @@ def main():
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dconv3.json")))
         pmc = pmcs[-1] if pmcs else ""
-        if BF3 and pmc:
+        if BF3 and pmc and not av:
             want = PMC_KERNEL_OF.get(dom)
             if want:
                 for k, v in json.load(open(pmc)).items():
@@ -598,26 +624,20 @@ def main():
                             "counters include Infinity-Cache hits, i.e. they are L2-miss traffic, an upper bound on HBM bytes") % os.path.basename(pmc)
                         break
         del m2
-    if rank == 0 and args.config == "audio" and not args.no_roofline:
+    if rank == 0 and not av and not args.no_roofline:
         out["stages"] = front_end_stages(dev, args.batch, args.bins, args.frames)
-    if rank == 0 and world == 1 and args.config == "audio" and not args.no_roofline:
+    if rank == 0 and world == 1 and not av and not args.no_roofline:
         out["config"]["launch_modes"] = launch_modes(hp, dev, s, mask)
         out["config"]["host_enqueue_note"] = ("host_enqueue_ms_per_step is the LOOP figure: the host runs ahead until the device queues fill and then "
                                               "waits inside a launch, so it tracks the device time in every launch mode; the host's own cost per step is "
                                               "launch_modes.*.host_ms_per_step_idle_queue (one step enqueued into an idle queue): eager vs the C launch "
                                               "plan (bench.py --plan; bitwise the eager step)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
+        out["cpu_baseline"] = cpu_baseline_av(args, hp.num_D) if av else cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.cuda.synchronize()
-        # leave without tearing the communicator down: destroy_process_group() on an RCCL group aborts the process now and then on
-        # this stack (seen in the test suite), and a non-zero exit of one rank after the line is printed would read as a failed run
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+    del model
+    shutdown(world)
 
 
 if __name__ == "__main__":

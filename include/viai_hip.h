@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 5
+#define VIAI_ABI_VERSION 6
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -106,6 +106,15 @@ int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const float* x2, con
 int viai_conv2d_wgrad_f16_ok(const viai_conv2d* c);
 int viai_conv2d_wgrad_f16(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
                           float* ws, float* dw, float* db, int accumulate, const float* dy_amax, void* stream);
+
+/* Which kernel ran.  The convolution entry points above (and viai_conv2d_cin1_bn_fwd / _wgrad) choose between kernel families by
+ * shape; this reports the family the LAST such call of the calling thread launched and how many conv-kernel launches it made
+ * (a strided data gradient on the gather kernel is one launch per parity class).  The name ends in the arithmetic of the
+ * kernel -- "_f16x2" (two-term fp16 split, 3 MFMA products per MAC), "_bf16x3" (three-term bf16 split, 6 products), "_f32"
+ * (exact fp32 MFMA) -- or is "direct" for the Cin = 1 / Cout = 1 streaming kernels; bench.py prices each family against the
+ * ceiling of that arithmetic.  buf receives the NUL-terminated name (truncated to cap); returns the launch count, 0 if none.
+ * (measurement aid: no reference counterpart)                                                                             */
+int viai_conv2d_last_kernel(char* buf, int cap);
 
 /* generic weight repack used by the two pack entry points (exposed for tests):
  * wp[no][t][ki] = w[no*s_no + ki*s_ki + t]                                       */

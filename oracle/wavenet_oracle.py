@@ -207,3 +207,75 @@ def incremental_forward(sd, c, T, u1, u2, cfg=WNConfig, test_inputs=None, log_sc
         y = wavenet_forward(sd, x, c, cfg, g)[:, :, t:t + 1]
         out[:, 0, t] = mol_sample(y, u1[:, t:t + 1], u2[:, t:t + 1], log_scale_min)[:, 0]
     return out
+
+
+def incremental_forward_ring(sd, c, T, u1, u2, cfg=WNConfig, test_inputs=None, log_scale_min=-7.0, g=None, return_logits=False):
+    """WaveNet.incremental_forward (wavenet.py:237-364) the way the reference computes it: sample by sample, every dilated conv as a
+    LINEAR layer over a ring buffer of its last (k - 1) d + 1 inputs (conv.py:17-46: shift the buffer, append the new input, gather
+    every d-th entry, one matrix product with the (Cout, k Cin) linearised weight conv.py:53-57) -- O(T) work, unlike
+    `incremental_forward` above (the definition-of-causality form used to pin it).  This is the CPU restatement bench.py times as the
+    `cpu_baseline` of configs[4]."""
+    B = c.shape[0] if c is not None else (test_inputs.shape[0] if test_inputs is not None else 1)
+    k = cfg.kernel_size
+    per = cfg.layers // cfg.stacks
+    sq = math.sqrt(0.5)
+    with torch.no_grad():
+        cu = None
+        if c is not None:                                                    # wavenet.py:291-299: up-sample once
+            cu = c.unsqueeze(1)
+            for j, s in enumerate(cfg.upsample_scales):
+                n = "upsample_conv.%d" % (2 * j)
+                cu = F.relu(F.conv_transpose2d(cu, wn_weight(sd, n), sd[n + ".bias"], stride=(1, s), padding=((cfg.freq_axis_kernel_size - 1) // 2, 0)))
+            cu = cu.squeeze(1).transpose(1, 2).contiguous()                      # (B, T, cin)
+            assert cu.shape[1] == T
+        g_bc = None
+        if g is not None:
+            g_bc = F.embedding(g.view(B, -1), sd["embed_speakers.weight"]).reshape(B, -1)
+        w_first = wn_weight(sd, "first_conv").reshape(cfg.residual_channels, -1)
+        layers = []
+        for i in range(cfg.layers):
+            p = "conv_layers.%d." % i
+            d = 2 ** (i % per)
+            w = wn_weight(sd, p + "conv")                                        # (G, C, k) -> (G, k C): tap-major, as conv.py:53-57
+            layers.append(dict(
+                d=d, ring=torch.zeros(B, (k - 1) * d + 1, cfg.residual_channels),
+                w=w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous(), b=sd[p + "conv.bias"],
+                wc=wn_weight(sd, p + "conv1x1c").reshape(cfg.gate_channels, -1) if cu is not None else None, bc=sd.get(p + "conv1x1c.bias"),
+                wg=wn_weight(sd, p + "conv1x1g").reshape(cfg.gate_channels, -1) if g_bc is not None else None, bg=sd.get(p + "conv1x1g.bias"),
+                wo=wn_weight(sd, p + "conv1x1_out").reshape(cfg.residual_channels, -1), bo=sd[p + "conv1x1_out.bias"],
+                ws=wn_weight(sd, p + "conv1x1_skip").reshape(cfg.skip_out_channels, -1), bs=sd[p + "conv1x1_skip.bias"]))
+        w1 = wn_weight(sd, "last_conv_layers.1").reshape(cfg.skip_out_channels, -1)
+        w2 = wn_weight(sd, "last_conv_layers.3").reshape(cfg.out_channels, -1)
+        out = torch.zeros(B, 1, T)
+        logits = torch.zeros(B, cfg.out_channels, T) if return_logits else None
+        cur = torch.zeros(B, 1)                                                  # initial input: zeros (wavenet.py:305-306)
+        half = cfg.gate_channels // 2
+        for t in range(T):
+            if test_inputs is not None and t < test_inputs.shape[-1]:
+                cur = test_inputs[:, :, t].reshape(B, -1)
+            elif t > 0:
+                cur = out[:, :, t - 1].reshape(B, 1)
+            h = F.linear(cur, w_first, sd["first_conv.bias"])                   # (B, C)
+            skips = None
+            for L in layers:
+                ring = L["ring"]
+                ring[:, :-1] = ring[:, 1:].clone()                               # conv.py:39
+                ring[:, -1] = h
+                x = ring[:, ::L["d"]].reshape(B, -1)                             # conv.py:44: every d-th entry = the k taps
+                y = F.linear(x, L["w"], L["b"])
+                a, b = y[:, :half], y[:, half:]
+                if L["wc"] is not None:
+                    yc = F.linear(cu[:, t], L["wc"], L["bc"])
+                    a, b = a + yc[:, :half], b + yc[:, half:]
+                if L["wg"] is not None:
+                    yg = F.linear(g_bc, L["wg"], L["bg"])
+                    a, b = a + yg[:, :half], b + yg[:, half:]
+                z = torch.tanh(a) * torch.sigmoid(b)
+                s = F.linear(z, L["ws"], L["bs"])
+                h = (F.linear(z, L["wo"], L["bo"]) + h) * sq
+                skips = s if skips is None else (skips + s) * sq
+            y = F.linear(F.relu(F.linear(F.relu(skips), w1, sd["last_conv_layers.1.bias"])), w2, sd["last_conv_layers.3.bias"])
+            if logits is not None:
+                logits[:, :, t] = y
+            out[:, 0, t] = mol_sample(y.unsqueeze(-1), u1[:, t:t + 1], u2[:, t:t + 1], log_scale_min)[:, 0]
+    return (out, logits) if return_logits else out

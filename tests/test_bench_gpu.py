@@ -1,0 +1,75 @@
+"""bench.py's contract, run as the driver runs it (a subprocess, one JSON line on stdout)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_its_own_ranks_and_exits_cleanly():
+    """`python bench.py --gpus 2` with no launcher: bench.py re-runs itself as two ranks under torch.distributed.run; on this
+    one-GPU box the ranks share cuda:0 and exchange over gloo (--share-gpu; RCCL refuses two ranks on one device), the bucketed exchange
+    of the product step runs, rank 0 prints the one JSON line, and every rank leaves through destroy_process_group (exit status 0)."""
+    out = run_bench("--gpus", "2", "--share-gpu", "--steps", "4", "--warmup", "2", "--batch", "2", "--bins", "128", "--frames", "64",
+                    "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 4
+    assert out["steps"] == 4 and out["warmup"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert "comm_ms_exposed" in out["config"] and "ranks_share_devices" in out["config"]
+    assert out["roofline"]["family"].endswith(("_f16x2", "_bf16x3", "_f32")) and 0 < out["roofline"]["frac"] < 1
+
+
+def test_gpus_n_without_devices_or_share_gpu_refuses():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "--share-gpu" in r.stderr
+
+
+def test_kernel_families_come_from_the_library():
+    """the roofline's kernel families are the names the library reports for each launch (viai_conv2d_last_kernel): one family per
+    kernel instance the step runs, every family priced against the ceiling its suffix names; bench.py holds no dispatch mirror."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "viai_conv2d_last_kernel" in src and "mirror of viai_" not in src
+    out = run_bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    fams = out["roofline"]["conv_time_share_by_kernel"]
+    assert "direct" in fams and "halo_wide256_f16x2" in fams and "wgrad_patch_f16x2" in fams and "unknown" not in fams
+    assert abs(sum(fams.values()) - 1.0) < 0.02
+    assert out["roofline"]["family"] in out["roofline"]["frac_by_kernel"]
+    # the timed conv flops of the step are the SURVEY's 1 208 GFLOP (section 8d) to within the first-layer data gradients it leaves out
+    assert abs(out["roofline"]["conv_gflop_per_step_timed"] - 1208.0) < 0.01 * 1208.0
+    assert out["config"]["workload"].startswith("configs[1]") and out["n_gpus"] == 1 and "stages" in out
+
+
+@pytest.mark.parametrize("config", ["av", "av_msd"])
+def test_vision_infused_configs_print_roofline_and_cpu_baseline(config):
+    out = run_bench("--config", config, "--steps", "2", "--warmup", "1", "--batch", "1", "--bins", "256", "--frames", "32")
+    assert out["config"]["workload"].startswith("configs[%d]" % (2 if config == "av" else 3))
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and rf["family"] in rf["frac_by_kernel"]
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["unit"] == "clips/s"
+    assert out["config"]["algorithmic_gflop_per_step"] > 0
+
+
+def test_wavenet_config_prints_the_synthesis_line():
+    out = run_bench("--config", "wavenet", "--steps", "192", "--warmup", "64")
+    assert out["unit"] == "samples/s" and out["steps"] == 192 and out["value"] > 1000
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and 0 < rf["frac"] < 1 and 90e6 < rf["algorithmic_bytes_per_step"] < 110e6
+    assert out["cpu_baseline"]["unit"] == "samples/s" and 0 < out["cpu_baseline"]["value"] < out["value"]

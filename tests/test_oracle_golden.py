@@ -194,3 +194,25 @@ def test_wavenet_oracle_reproduces_reference_incremental_synthesis_at_reference_
         yh = W.wavenet_forward(sd, xin, c, cfg)
     assert relerr(O.digest(yh, 256), gold["yhat_tf.dg"]) < 1e-5
     assert relerr(W.mol_sample(yh, v1, v2, -7.0), gold["gen_tf"][:, 0]) < 1e-4
+
+
+def test_wavenet_ring_buffer_oracle_matches_reference_incremental_synthesis(golden_dir):
+    """the O(T) ring-buffer restatement of conv.py:17-46 / wavenet.py:237-364 (bench.py's configs[4] `cpu_baseline`) against both
+    reference runs of tests/golden/wavenet_deep.npz: teacher-forced and free-running after four forced samples."""
+    from oracle import wavenet_oracle as W
+    gold = np.load(golden_dir + "/wavenet_deep.npz")
+    cfg = W.WNConfigDeep
+    B, T = int(gold["meta"][0]), int(gold["meta"][1])
+    sd = W.wavenet_state(cfg, tag="WND.")
+    c = O.cf_uniform("wnd.c", (B, cfg.cin_channels, T // 16), 0, 1)
+    v1 = O.cf_uniform("wnd.v1", (B, T, 10), 1e-5, 1 - 1e-5)
+    v2 = O.cf_uniform("wnd.v2", (B, T), 1e-5, 1 - 1e-5)
+    xin = O.cf_uniform("wnd.xin", (B, 1, T), -1, 1)
+    assert relerr(W.incremental_forward_ring(sd, c, T, v1, v2, cfg, test_inputs=xin), gold["gen_tf"]) < 1e-4
+    assert relerr(W.incremental_forward_ring(sd, c, T, v1, v2, cfg, test_inputs=xin[:, :, :4]), gold["gen_free"]) < 1e-3
+    # and the small configuration's reference run (tests/golden/wavenet.npz), incl. global conditioning
+    g2 = np.load(golden_dir + "/wavenet.npz")
+    cg = O.cf_uniform("wn.cg", (2, W.WNConfig.cin_channels, 2), 0, 1)
+    gen = W.incremental_forward_ring(W.wavenet_state(W.WNConfig), cg, 32, O.cf_uniform("wn.v1", (2, 32, 10), 1e-5, 1 - 1e-5),
+                                     O.cf_uniform("wn.v2", (2, 32), 1e-5, 1 - 1e-5), W.WNConfig, test_inputs=O.cf_uniform("wn.tin", (2, 1, 4), -1, 1))
+    assert relerr(gen, g2["gen"]) < 1e-4

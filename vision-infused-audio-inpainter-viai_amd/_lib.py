@@ -20,6 +20,16 @@ class ViaiLibraryError(RuntimeError):
     pass
 
 
+def _declared_abi_version():
+    """VIAI_ABI_VERSION of the committed header: the one place the number lives"""
+    import re
+    with open(os.path.join(os.path.dirname(_HERE), "include", "viai_hip.h")) as f:
+        return int(re.search(r"#define\s+VIAI_ABI_VERSION\s+(\d+)", f.read()).group(1))
+
+
+ABI_VERSION = _declared_abi_version()
+
+
 class Conv2dDesc(C.Structure):
     """mirror of `viai_conv2d` (include/viai_hip.h)."""
     _fields_ = [(n, C.c_int) for n in (
@@ -66,6 +76,7 @@ SIGNATURES = {
     "viai_conv2d_dgrad": (_I, [_CP, _P, _P, _P, _P, _P]),
     "viai_conv2d_wgrad_ws_bytes": (C.c_size_t, [_CP]),
     "viai_conv2d_wgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "viai_conv2d_last_kernel": (_I, [C.c_char_p, _I]),
     "viai_pack_weight": (_I, [_P, _P, _I, _I, _I, _L, _L, _P]),
     "viai_bn_finalize": (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "viai_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
@@ -177,8 +188,9 @@ def load() -> C.CDLL:
             raise ViaiLibraryError("libviai_hip.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.viai_abi_version() != 5:
-        raise ViaiLibraryError("libviai_hip.so ABI version mismatch")
+    if lib.viai_abi_version() != ABI_VERSION:
+        raise ViaiLibraryError("libviai_hip.so ABI version %d, include/viai_hip.h declares %d: rebuild (viai_amd._lib.build())"
+                               % (lib.viai_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -158,6 +158,20 @@ static bool use_bf3_dgrad(const viai_conv2d* c) {
 
 extern "C" int viai_abi_version(void) { return VIAI_ABI_VERSION; }
 
+thread_local ViaiKernelTag viai_kernel_tag = {nullptr, 0};
+// name of the kernel family the LAST convolution entry point of this thread (viai_conv2d_fwd / _dgrad[_f16] / _wgrad[_f16] /
+// viai_conv2d_cin1_bn_*) launched, copied into buf (NUL-terminated, truncated to cap); returns the number of conv-kernel launches of
+// that call (a strided data gradient on the gather kernel is one launch per parity class), 0 if none.
+extern "C" int viai_conv2d_last_kernel(char* buf, int cap) {
+    if (buf != nullptr && cap > 0) {
+        const char* s = viai_kernel_tag.family ? viai_kernel_tag.family : "";
+        int i = 0;
+        for (; i < cap - 1 && s[i]; ++i) buf[i] = s[i];
+        buf[i] = 0;
+    }
+    return viai_kernel_tag.launches;
+}
+
 extern "C" int viai_conv2d_out_hw(const viai_conv2d* c, int* OH, int* OW) {
     if (c->transposed) {   // ConvTranspose2d, stride 1: (I-1) - 2p + k
         *OH = c->IH - 1 - 2 * c->ph + c->kh;
@@ -346,10 +360,12 @@ extern "C" int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float
     if (!valid(c) || (c->C2 > 0) != (x2 != nullptr)) return (int)hipErrorInvalidValue;
     if (stat_part != nullptr && act != VIAI_ACT_NONE) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
+    viai_tag_reset();
     switch (kind_of(c)) {
-    case K_CIN1: return viai_cin1_fwd(c, x, wp, bias, y, stat_part, act, st);
+    case K_CIN1: viai_tag_kernel("direct"); return viai_cin1_fwd(c, x, wp, bias, y, stat_part, act, st);
     case K_COUT1:
         if (stat_part) return (int)hipErrorInvalidValue;
+        viai_tag_kernel("direct");
         return viai_cout1_fwd(c, x, wp, bias, y, act, st);
     default: break;
     }
@@ -396,9 +412,10 @@ extern "C" int viai_conv2d_dgrad_f16(const viai_conv2d* c, const float* dy, cons
 static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2, const float* amax, void* stream) {
     if (!valid(c) || (c->C2 > 0) != (dx2 != nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
+    viai_tag_reset();
     switch (kind_of(c)) {
-    case K_CIN1: return viai_cin1_dgrad(c, dy, wp, dx, st);
-    case K_COUT1: return viai_cout1_dgrad(c, dy, wp, dx, st);
+    case K_CIN1: viai_tag_kernel("direct"); return viai_cin1_dgrad(c, dy, wp, dx, st);
+    case K_COUT1: viai_tag_kernel("direct"); return viai_cout1_dgrad(c, dy, wp, dx, st);
     case K_RUN: return (int)hipErrorInvalidValue;
     default: break;
     }
@@ -517,6 +534,8 @@ static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, con
     const int T = c->kh * c->kw, Cin = cin_of(c);
     int e = 0;
     size_t used = 0;
+    viai_tag_reset();
+    if (kind_of(c) == K_CIN1 || kind_of(c) == K_COUT1) viai_tag_kernel("direct");
     switch (kind_of(c)) {
     case K_CIN1: e = viai_cin1_wgrad(c, x, dy, ws, dw, accumulate, st); used = viai_cin1_wgrad_ws_floats(c); break;
     case K_COUT1: e = viai_cout1_wgrad(c, x, dy, ws, dw, accumulate, st); used = viai_cout1_wgrad_ws_floats(c); break;

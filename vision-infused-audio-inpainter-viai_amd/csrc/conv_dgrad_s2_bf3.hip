@@ -408,9 +408,11 @@ int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st) {
         constexpr int lds_p = 2 * 2 * 9 * 17 * 80;
         static bool attr_p = false;
         if (!attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p); attr_p = true; }
+        viai_tag_kernel("dgrad_s2_patch_f16x2");
         VIAI_LAUNCH(conv_dgrad_s2_patch_kernel, dim3(a.nblk_m * a.nblk_n), dim3(256), lds_p, st, a);
         return viai_launch_status();
     }
+    viai_tag_kernel(a.amax != nullptr ? "dgrad_s2_f16x2" : "dgrad_s2_bf16x3");
     if (a.amax != nullptr) VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<2>, dim3(a.nblk_m * a.nblk_n), dim3(256), 2 * 2 * 128 * BF3_PITCH, st, a);   // f16x2
     else VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<3>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
     return viai_launch_status();

@@ -974,6 +974,8 @@ extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, con
                                        const float* scale, const float* shift, float* z, int act, void* stream) {
     if (!viai_conv2d_cin1_bn_ok(c) || (z == nullptr) == (stat_part == nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
+    viai_tag_reset();
+    viai_tag_kernel("direct");
     DirectArgs a = make_args(c);
     a.x = x; a.w = w; a.bias = bias; a.y = z; a.stat = stat_part; a.scale = scale; a.shift = shift; a.act = act; a.slope = 0.2f;
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
@@ -1032,6 +1034,8 @@ extern "C" int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, c
                                          float* dw, int accumulate, int act, void* stream) {
     if (!viai_conv2d_cin1_bn_ok(c)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
+    viai_tag_reset();
+    viai_tag_kernel("direct");
     DirectArgs a = make_args(c);
     a.x = x; a.w = w; a.bias = bias; a.dz = dz; a.mean = mean; a.scale = scale; a.shift = shift; a.sums = sums; a.ws = ws;
     a.act = act; a.slope = 0.2f;

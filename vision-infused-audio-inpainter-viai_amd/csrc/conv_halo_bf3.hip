@@ -10,6 +10,7 @@
 // Inpainting_Networks.py:60-110 (MelEncoder/MelDecoder) and their autograd data gradients.
 #include "viai_common.h"
 #include "viai_internal.h"
+#include <string>
 #include "viai_bf3.h"
 #include <type_traits>
 
@@ -687,6 +688,7 @@ int launch_halo(ConvArgs& a, int hy0, int hx0, hipStream_t st) {
     if (per_cu > 4) per_cu = 4;
     int grid = 256 * per_cu;
     if (grid > a.nblk_m) grid = a.nblk_m;
+    viai_tag_kernel(NP == 2 ? "halo_f16x2" : "halo_bf16x3");
     VIAI_LAUNCH((conv_halo_bf3_kernel<CIN, TN, NP>), dim3(grid), dim3(256), lds, st, a, hy0, hx0, a.nblk_m);
     return viai_launch_status();
 }
@@ -740,6 +742,7 @@ int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st) {
         a.nblk_n = 1;
         int grid = 256 * 2;
         if (grid > a.nblk_m) grid = a.nblk_m;
+        viai_tag_kernel("halo_c32_f16x2");
         VIAI_LAUNCH(conv_halo_f16_c32_kernel, dim3(grid), dim3(256), lds, st, a, y0, x0, a.nblk_m, sl);
         return viai_launch_status();
     }
@@ -794,6 +797,8 @@ static int launch_halo_wide(ConvArgs& a, int y0, int x0, const HaloWideSlots& sl
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_wide_f16_kernel<WM, WN, TM, TN, S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
     a.nblk_n = (a.Cout + 32 * TN * WN - 1) / (32 * TN * WN);
+    static const std::string fam = S == 2 ? std::string("halo_wide_s2_f16x2") : "halo_wide" + std::to_string(32 * TN * WN) + "_f16x2";
+    viai_tag_kernel(fam.c_str());
     VIAI_LAUNCH((conv_halo_wide_f16_kernel<WM, WN, TM, TN, S>), dim3(a.nblk_m * a.nblk_n), dim3(64 * WM * WN), lds, st, a, y0, x0, sl);
     return viai_launch_status();
 }

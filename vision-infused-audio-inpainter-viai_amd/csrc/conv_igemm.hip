@@ -26,6 +26,7 @@
 // (mean, M2) pairs that bn_finalize merges with Chan's formula in fp64.
 #include "viai_common.h"
 #include "viai_internal.h"
+#include <string>
 #include <cstdlib>
 
 namespace {
@@ -295,6 +296,8 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
+    static const std::string fam = "igemm" + std::to_string(BM) + "x" + std::to_string(BN) + "_f32";
+    viai_tag_kernel(fam.c_str());
     VIAI_LAUNCH((conv_igemm_kernel<BK, TM, TN, WM, WN>), dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
     return viai_launch_status();
 }

@@ -14,6 +14,7 @@
 // planes [plane][row][32 + 8 pad] (80-byte rows: conflict-free ds_read_b128 operand fetches).
 #include "viai_common.h"
 #include "viai_internal.h"
+#include <string>
 #include "viai_bf3.h"
 // timing ablation of the wide kernel: bit 0 no weight-fragment loads, bit 1 no activation loads, bit 2 no split / LDS stores
 #ifndef VIAI_ABL
@@ -920,6 +921,8 @@ static int launch_bf3(ConvArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
+    static const std::string fam = "igemm" + std::to_string(BM) + "x" + std::to_string(BN) + (NP == 2 ? "_f16x2" : "_bf16x3");
+    viai_tag_kernel(fam.c_str());
     VIAI_LAUNCH(kern, dim3(a.nblk_m * a.nblk_n), dim3(64 * WM * WN), lds, st, a);
     return viai_launch_status();
 }
@@ -942,6 +945,7 @@ static int launch_bf3_sk(ConvArgs& a, hipStream_t st) {
     a.nblk_m = (a.M + 31) / 32;
     a.nblk_n = (a.Cout + 31) / 32;
     constexpr int lds = 2 * 3 * 32 * (64 * 2 + 16);
+    viai_tag_kernel(a.wfrag == 4 ? "igemm_sk32x32_f16x2" : "igemm_sk32x32_bf16x3");
     if (a.wfrag == 4) VIAI_LAUNCH(conv_igemm_bf3_sk_kernel<2>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);       // planar f16x2 weights
     else VIAI_LAUNCH(conv_igemm_bf3_sk_kernel<3>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
     return viai_launch_status();

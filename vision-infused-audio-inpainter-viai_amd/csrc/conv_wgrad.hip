@@ -335,6 +335,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(a.nblk_co * a.nblk_ci * a.g.ntaps * a.ksplit);
+    viai_tag_kernel("wgrad_mfma_f32");
     VIAI_LAUNCH((wgrad_mfma_kernel<TM, TN, WM, WN>), grid, dim3(256), lds, st, a);
     return viai_launch_status();
 }
@@ -386,6 +387,7 @@ int viai_wgrad32_launch(WgradArgs& a, int ksplit, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad32_halo_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
+    viai_tag_kernel("wgrad32_all_taps_f32");
     if (g.ntaps == 9) VIAI_LAUNCH(wgrad32_halo_kernel<true>, dim3(ksplit), dim3(256), lds, st, a, tp);
     else VIAI_LAUNCH(wgrad32_halo_kernel<false>, dim3(ksplit), dim3(256), lds, st, a, tp);
     return viai_launch_status();

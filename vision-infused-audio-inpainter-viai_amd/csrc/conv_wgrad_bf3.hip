@@ -218,6 +218,7 @@ int launch_wgrad_bf3(WgradArgs& a, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(a.nblk_co * a.nblk_ci * a.g.ntaps * a.ksplit);
+    viai_tag_kernel(a.amax != nullptr ? "wgrad_bf3_f16x2" : "wgrad_bf3_bf16x3");
     if (a.amax != nullptr) VIAI_LAUNCH((wgrad_bf3_kernel<2, TM, TN>), grid, dim3(256), (size_t)2 * (BM + BN) * BF3_PITCH, st, a);   // f16x2
     else VIAI_LAUNCH((wgrad_bf3_kernel<3, TM, TN>), grid, dim3(256), lds, st, a);
     return viai_launch_status();

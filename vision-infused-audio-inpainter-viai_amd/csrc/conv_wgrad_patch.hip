@@ -367,6 +367,7 @@ static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hi
     using C = WgCfg<S, BM, BN, HR, WK>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_patch_f16_kernel<S, BM, BN, HR, WK>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); attr_done = true; }
+    viai_tag_kernel(S == 2 ? "wgrad_patch_s2_f16x2" : BM == 32 ? "wgrad_patch_narrow_f16x2" : "wgrad_patch_f16x2");
     VIAI_LAUNCH((wgrad_patch_f16_kernel<S, BM, BN, HR, WK>), dim3(a.nblk_co * a.nblk_ci * a.ksplit), dim3(C::NTHR), C::LDS, st, a, y0, x0, sl);
     return viai_launch_status();
 }

@@ -59,6 +59,14 @@ bool viai_wgrad_patch_shape_ok(const ConvGeom& g, int Cout, int C1, int C2);
 int viai_wgrad_patch_ksplit(const ConvGeom& g, int Cout, int C1, int C2);
 int viai_wgrad_patch_launch(WgradArgs& a, hipStream_t st);
 
+// Which kernel family ran: every conv launcher tags its launch; the C-ABI entry points reset the tag on entry and
+// viai_conv2d_last_kernel() reports it (bench.py prices each family against the ceiling of its arithmetic -- the name ends in
+// _f16x2 / _bf16x3 / _f32, or is "direct" for the Cin = 1 / Cout = 1 streaming kernels).  Per thread, like the error slot.
+struct ViaiKernelTag { const char* family; int launches; };
+extern thread_local ViaiKernelTag viai_kernel_tag;
+static inline void viai_tag_kernel(const char* family) { viai_kernel_tag.family = family; viai_kernel_tag.launches += 1; }
+static inline void viai_tag_reset() { viai_kernel_tag.family = nullptr; viai_kernel_tag.launches = 0; }
+
 // geometry builders (conv_api.hip)
 void viai_geom_fwd(const viai_conv2d* c, ConvGeom* g);
 int viai_geom_dgrad_class(const viai_conv2d* c, int a, int b, ConvGeom* g);   // returns ntaps

@@ -410,13 +410,15 @@ class WaveNet(nn.Module):
 
     @torch.no_grad()
     def incremental_forward(self, initial_input=None, c=None, g=None, T=100, test_inputs=None, tqdm=lambda x: x, softmax=True,
-                            quantize=True, log_scale_min=-7.0, uniforms=None, use_graph=False, return_logits=False):
+                            quantize=True, log_scale_min=-7.0, uniforms=None, use_graph=False, return_logits=False, timing=None):
         """Sample-by-sample synthesis (wavenet.py:237-364) for the scalar-input / MoL configuration.
 
         A time step = first conv, 2 GEMV-batch kernels per layer, head + MoL sample.  Default: `viai_wavenet_synth_run` loops over the
         steps in C with the time index passed by value; `use_graph=True`: `viai_wavenet_synth_step` (time index on the device, the first
         conv advances it) captured once into a HIP graph and replayed.
-        `uniforms=(u1 (B,T,10), u2 (B,T))` injects the sampler's two uniform draws (parity tests); default torch.rand."""
+        `uniforms=(u1 (B,T,10), u2 (B,T))` injects the sampler's two uniform draws (parity tests); default torch.rand.
+        `timing={"warmup": W}` (bench.py): the first W time steps run untimed, the remaining T - W are bracketed by device
+        synchronisations and reported as timing["ms"] / timing["steps"] (set-up -- weight norm, linearised weights -- excluded)."""
         import ctypes as Ct
         lib = _lib.load()
         if not self.scalar_input:
@@ -507,8 +509,18 @@ class WaveNet(nn.Module):
         else:
             # default: the C side loops over the time steps and hands every kernel its time index by value
             chunk = 64
-            for t0 in tqdm(range(0, T, chunk)):
+            w0 = min(int(timing.get("warmup", 0)), T) if timing is not None else 0
+            if w0 > 0:
+                _lib.check(lib.viai_wavenet_synth_run(ref, 0, w0, torch.cuda.current_stream().cuda_stream), "viai_wavenet_synth_run")
+            if timing is not None:
+                import time
+                torch.cuda.synchronize()
+                t_start = time.perf_counter()
+            for t0 in tqdm(range(w0, T, chunk)):
                 _lib.check(lib.viai_wavenet_synth_run(ref, t0, min(chunk, T - t0), torch.cuda.current_stream().cuda_stream), "viai_wavenet_synth_run")
+            if timing is not None:
+                torch.cuda.synchronize()
+                timing["ms"], timing["steps"] = (time.perf_counter() - t_start) * 1e3, T - w0
         torch.cuda.current_stream().synchronize()
         del keep
         res = out.unsqueeze(1)                                                        # (B, 1, T) like the reference
