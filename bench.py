@@ -78,11 +78,12 @@ def math_string():
     f16b = os.environ.get("VIAI_F16_BACKWARD", "1") != "0"
     if F16X2:
         return ("fp32 tensors and fp32 accumulation; conv products on the fp16 matrix cores through the f16x2 operand split (two fp16 terms per fp32 "
-                "operand = 22 significand bits, three partial products, power-of-two pre-scaling: static x16 for activations / x256 for weights, "
-                "per-tensor from max|dy| for gradients) in the forward%s kernels of every layer with > 1 channel on both sides; bf16x3 (three bf16 "
+                "operand = 22 significand bits, three partial products, power-of-two pre-scaling derived ON THE DEVICE from each tensor's abs-max -- reduced by its "
+                "producer (BatchNorm apply / BatchNorm backward) or inherited through resampling -- for activations and gradients, static x256 for weights, "
+                "whose range model.get_loss_items checks) in the forward%s kernels of every layer with > 1 channel on both sides; bf16x3 (three bf16 "
                 "terms, six partial products) where no BatchNorm produces the gradient scale%s; exact fp32 MFMA in the <= 32-channel weight gradients the patch kernel does not tile; "
-                "plain fp32 FMA in the Cin = 1 / Cout = 1 streaming convs; measured 2.7-2.9e-7 relative vs fp64 per layer (CPU fp32: 1.8e-7); "
-                "activations saturate at |x| > 4094 (tests/test_kernels_gpu.py::test_f16x2_saturates_instead_of_nan)"
+                "plain fp32 FMA in the Cin = 1 / Cout = 1 streaming convs; measured 2.7-2.9e-7 relative vs fp64 per layer (CPU fp32: 1.8e-7), "
+                "at any input magnitude (tests/test_kernels_gpu.py::test_f16x2_operand_scale_follows_the_input_magnitude)"
                 % (", data-gradient and weight-gradient" if f16b else "", "" if f16b else " and in every backward kernel (VIAI_F16_BACKWARD=0)"))
     return "fp32 tensors and fp32 accumulation; conv products on the bf16 matrix cores through the bf16x3 split (six partial products) (VIAI_F16X2=0)"
 
@@ -135,6 +136,10 @@ def spawn_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd, env=env))
+
+
+FAMILY_CALLS = ("viai_conv2d_fwd", "viai_conv2d_fwd_amax", "viai_conv2d_dgrad", "viai_conv2d_dgrad_f16", "viai_conv2d_wgrad", "viai_conv2d_wgrad_f16",
+                "viai_conv2d_cin1_bn_fwd", "viai_conv2d_cin1_bn_wgrad")
 
 
 class KernelTimer:

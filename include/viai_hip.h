@@ -85,6 +85,17 @@ int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_per_blk);
  * per-channel (mean, M2) of y for training-mode BatchNorm; act must be NONE then. */
 int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float* x2, const float* wp_fwd,
                     const float* bias, float* y, float* stat_part, int act, void* stream);
+/* The same with the magnitude of the input known.  The f16x2 kernels (two-term fp16 operand split) pre-scale the activation
+ * operand by a power of two: with x_amax -- a DEVICE float >= max |x| (and |x2|), produced by viai_bn_act_fwd_amax /
+ * viai_conv2d_cin1_bn_fwd / viai_absmax -- the scale is derived on the device and every magnitude is representable; with
+ * x_amax = NULL (and in viai_conv2d_fwd) it is the static 16, right for normalised activations, and |x| beyond 65504 / 16 = 4094
+ * saturates.  Kernels that do not split (fp32, bf16x3, the streaming kernels) ignore it.                                        */
+int viai_conv2d_fwd_f16_ok(const viai_conv2d* c);      /* 1: the forward launch of this layer is an f16x2 kernel */
+int viai_conv2d_fwd_amax(const viai_conv2d* c, const float* x, const float* x2, const float* wp_fwd,
+                         const float* bias, float* y, float* stat_part, int act, const float* x_amax, void* stream);
+/* amax = max(amax, max |x|) over n floats (x 16-byte aligned): the operand magnitude of a tensor this library did not produce;
+ * *amax must hold 0 or an earlier maximum.  One streaming pass.                                                              */
+int viai_absmax(const float* x, long n, float* amax, void* stream);
 /* dx (++ dx2) = conv_backward_data(dy, w) */
 int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const float* wp_dgrad,
                       float* dx, float* dx2, void* stream);
@@ -102,10 +113,11 @@ size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c);
 int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
                       float* ws, float* dw, float* db, int accumulate, void* stream);
 /* f16x2 form of the weight gradient (viai_conv2d_wgrad_f16_ok: layers with more than 32 channels on both sides): dy is
- * scaled on the device from dy_amax = max |dy| (viai_bn_act_bwd_amax), x by a static power of two                     */
+ * scaled on the device from dy_amax = max |dy| (viai_bn_act_bwd_amax), x from x_amax >= max |x|, |x2| (see
+ * viai_conv2d_fwd_amax) or, with x_amax = NULL, by the static 16                                                        */
 int viai_conv2d_wgrad_f16_ok(const viai_conv2d* c);
 int viai_conv2d_wgrad_f16(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
-                          float* ws, float* dw, float* db, int accumulate, const float* dy_amax, void* stream);
+                          float* ws, float* dw, float* db, int accumulate, const float* dy_amax, const float* x_amax, void* stream);
 
 /* Which kernel ran.  The convolution entry points above (and viai_conv2d_cin1_bn_fwd / _wgrad) choose between kernel families by
  * shape; this reports the family the LAST such call of the calling thread launched and how many conv-kernel launches it made
@@ -138,6 +150,10 @@ int viai_bn_eval_coeffs(int C, const float* gamma, const float* beta, const floa
 /* z = act(y*scale[c] + shift[c]) */
 int viai_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z,
                     long M, int C, int act, float slope, void* stream);
+/* the same, also reducing max |z| into the device float z_amax (zero-initialised by the caller; NULL = off): the operand
+ * magnitude the f16x2 kernels that consume z are handed (viai_conv2d_fwd_amax, viai_conv2d_wgrad_f16)                   */
+int viai_bn_act_fwd_amax(const float* y, const float* scale, const float* shift, float* z,
+                         long M, int C, int act, float slope, float* z_amax, void* stream);
 /* backward of the pair above (training-mode statistics):
  *   dgamma, dbeta (optional outputs) and dy.  part: scratch of 2*C*nblk floats,
  *   nblk from viai_bn_bwd_blocks(M, C).  `training` bit 0: 1 = batch statistics, 0 = eval-mode rule;
@@ -329,14 +345,14 @@ int viai_l2_ranks(const float* clips, const float* captions, int n_clips, int n_
  * 38-39): with 4 .. 9 taps and one input channel the convolution is cheaper to RECOMPUTE than its 32 / 64-channel output is to write
  * and read back, so the pre-BatchNorm tensor y never exists in memory (same arithmetic, same order as viai_conv2d_fwd + viai_bn_*):
  *   fwd(z = NULL): BatchNorm partials (layout of viai_conv2d_fwd's stat_part, geometry of viai_conv2d_stat_geom) -> viai_bn_finalize
- *   fwd(stat_part = NULL): z = act(scale * conv(x) + shift)
+ *   fwd(stat_part = NULL): z = act(scale * conv(x) + shift); z_amax (optional, zero-initialised device float) receives max |z|
  *   bwd: partial sums from (dz, recomputed y) -> sums = {k0, k1}, dgamma, dbeta;  dy only if a data gradient needs it in memory
  *        (`training` as in viai_bn_act_bwd; part: 2 * Cout * nblk floats, nblk from viai_conv2d_stat_geom)
  *   wgrad: dw (+)= sum dy * x with dy formed on the fly from dz, y and sums
  * w: the packed image of viai_conv2d_pack (= the torch layout for this kind).                                                      */
 int viai_conv2d_cin1_bn_ok(const viai_conv2d* c);
 int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, float* stat_part,
-                            const float* scale, const float* shift, float* z, int act, void* stream);
+                            const float* scale, const float* shift, float* z, int act, float* z_amax, void* stream);
 int viai_conv2d_cin1_bn_bwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, const float* dz,
                             const float* mean, const float* invstd, const float* scale, const float* shift, float* part,
                             float* sums, float* dgamma, float* dbeta, float* dy, int act, int training, void* stream);

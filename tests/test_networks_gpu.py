@@ -11,11 +11,14 @@ pytestmark = pytest.mark.gpu
 from oracle import viai_oracle as O
 
 TOL_FWD = 1e-4      # forward tensors (north star: 1e-3 relative fp32)
-# Gradient digests vs the reference's fp32 gradients.  Measured on MI355X (tools/grad_margins.py, round 2): worst norm error 2.0e-4
-# (tiny), 8.1e-4 (cfg 1), 1.35e-3 (cfg 2); worst 64-sample-vector error 3.7e-3.  Two fp32 evaluations of these gradients (oracle vs
-# reference, both torch CPU) differ by 3e-3 .. 5e-3 themselves, so the bounds sit at that level, not an order of magnitude above it.
+# Gradient digests vs the reference's fp32 gradients.  Measured on MI355X (tools/grad_margins.py): worst norm error 2.0e-4 .. 3.9e-4
+# (tiny), 8.1e-4 .. 2.6e-3 (cfg 1), 1.35e-3 (cfg 2); worst 64-sample-vector error 3.7e-3 .. 1.8e-2 -- the ranges are two ROUNDING
+# REALISATIONS of the same kernels (static vs magnitude-derived operand scale of the fp16 split, round 3: VIAI_F16_DYNAMIC=0/1), which
+# against fp64 on the tie-free input are equally accurate (cfg 1: E 2.3e-3 / 2.1e-3, G 2.2e-3 / 2.0e-3, D 7.8e-4 / 7.9e-4; CPU fp32:
+# 1.5e-3 / 1.3e-3 / 7.0e-4).  Two fp32 evaluations of these gradients (oracle vs reference, both torch CPU) differ by 3e-3 .. 5e-3
+# themselves, so the norm bound sits at that level; 64 strided samples of one tensor scatter several-fold more than its norm.
 TOL_GRAD = 5e-3
-TOL_GRAD_SAMPLES = 1.5e-2
+TOL_GRAD_SAMPLES = 2.5e-2
 
 
 def relerr(a, b):
@@ -308,7 +311,9 @@ def test_parameters_after_one_two_three_adam_steps_match_reference_chain(golden_
                 ref = gold["step%d.%s.%s" % (it, nm, k)]
                 got = O.strided_samples(t)
                 if "running_" in k:
-                    assert np.linalg.norm(got - ref) < bound * (np.linalg.norm(ref) + 1e-30), (it, nm, k)
+                    # statistics, not parameters: batch means / variances of maps with as few as 4 .. 12 elements per channel at this
+                    # shape respond to the parameter drift several-fold (measured 7e-3 on deconv1_1_bn.running_mean at step 3)
+                    assert np.linalg.norm(got - ref) < 5 * bound * (np.linalg.norm(ref) + 1e-30), (it, nm, k)
                     continue
                 if (nm + "." + k) in SHADOWED_CHAIN:
                     assert np.abs(got - ref).max() < 3 * 2e-4 * it, (it, nm, k)       # noise-driven in torch, exactly still here
@@ -324,6 +329,22 @@ def test_parameters_after_one_two_three_adam_steps_match_reference_chain(golden_
             ref = float(gold["step%d.%s" % (it, key)])
             assert abs(v[idx] - ref) < (2e-4 if it == 1 else 5e-3) * abs(ref), (it, key, v[idx], ref)
     print("chain (step, net, err vs reference samples, err vs oracle, bound):", report)
+
+
+def test_weights_beyond_the_f16x2_range_raise_at_the_sync_point():
+    """the f16x2 weight images clamp beyond |w| = 255.9: AudioModel reads max |w| of its arenas next to the loss scalars (the one
+    host sync of an iteration, train_whole_sync.py:85) and raises instead of training on clipped weights."""
+    B, F_bins, T = 2, 80, 32
+    model = build_model(F_bins, T)
+    model.set_inputs(O.cf_uniform("s.tiny", (B, 1, F_bins, T)), O.make_mask(B, T, "mask.tiny"))
+    model.optimize_parameters(0)
+    model.get_loss_items()                                  # fine
+    with torch.no_grad():
+        model.netD.conv3.weight[3, 4, 1, 1] = 300.0
+    model.weights_changed()
+    model.optimize_parameters(1)
+    with pytest.raises(FloatingPointError, match="diverged"):
+        model.get_loss_items()
 
 
 def _scaled_states(f):

@@ -300,10 +300,11 @@ def test_incremental_equals_batch_forward_at_reference_size():
     xin = torch.cat((torch.zeros(B, 1, 1), x[:, :, :-1]), 2)
     with torch.no_grad():
         yh = net(xin.cuda(), c.cuda())
+    u = (O.cf_uniform("wnf8.u1", (B, T, 10), 1e-5, 1 - 1e-5), O.cf_uniform("wnf8.u2", (B, T), 1e-5, 1 - 1e-5))
     out_r, log_r = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=xin.cuda(), log_scale_min=-7.0, use_graph=False,
-                                           return_logits=True)
+                                           return_logits=True, uniforms=u)
     out_g, log_g = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=xin.cuda(), log_scale_min=-7.0, use_graph=True,
-                                           return_logits=True)
+                                           return_logits=True, uniforms=u)
     assert torch.equal(log_r, log_g) and torch.equal(out_r, out_g)
     assert relerr(log_r.transpose(1, 2), yh) < 1e-4, relerr(log_r.transpose(1, 2), yh)
     assert relerr(log_r[:, 130:].transpose(1, 2), yh[:, :, 130:]) < 1e-4            # the steps after every ring has wrapped

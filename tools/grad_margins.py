@@ -22,6 +22,9 @@ for name, (B, F, Tm) in (("tiny", (2, 80, 32)), ("cfg1", (4, 128, 128))):
     oE, oG, oD = O.encoder_state(), O.decoder_state(), O.disc_state()
     ocap = O.step_no_update(oE, oG, oD, s2, mask)
     dcap = O.step_no_update(T.to64(O.encoder_state()), T.to64(O.decoder_state()), T.to64(O.disc_state()), s2.double(), mask.double())
+    print(name, "aggregate (e_hip, e_o32) vs fp64 per network:", {k: ("%.2e" % v[0], "%.2e" % v[1]) for k, v in T.check_against_oracle(m, ocap, dcap, oE, oG, oD).items()}, flush=True)
+    tie = (m.fake.detach().cpu() - s).abs()
+    print(name, "L1 near-ties on the ORIGINAL input: |fake - s| < 1e-6: %d, < 1e-5: %d of %d" % (0, 0, 0) if False else "", flush=True)
     worst = (0, 0, 0, "")
     for mod, grp in ((m.netD, "grads_D"), (m.Mel_Encoder, "grads_E"), (m.Mel_Decoder, "grads_G")):
         for k, g in T.named_grads(mod).items():

@@ -73,6 +73,10 @@ SIGNATURES = {
     "viai_conv2d_pack_dgrad": (_I, [_CP, _P, _P, _P]),
     "viai_conv2d_stat_geom": (_I, [_CP, _IP, _IP]),
     "viai_conv2d_fwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "viai_conv2d_fwd_f16_ok": (_I, [_CP]),
+    "viai_conv2d_fwd_amax": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "viai_absmax": (_I, [_P, _L, _P, _P]),
+    "viai_bn_act_fwd_amax": (_I, [_P, _P, _P, _P, _L, _I, _I, _F, _P, _P]),
     "viai_conv2d_dgrad": (_I, [_CP, _P, _P, _P, _P, _P]),
     "viai_conv2d_wgrad_ws_bytes": (C.c_size_t, [_CP]),
     "viai_conv2d_wgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P]),
@@ -86,7 +90,7 @@ SIGNATURES = {
     "viai_bn_act_bwd_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P, _P]),
     "viai_conv2d_dgrad_f16_ok": (_I, [_CP]),
     "viai_conv2d_wgrad_f16_ok": (_I, [_CP]),
-    "viai_conv2d_wgrad_f16": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "viai_conv2d_wgrad_f16": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "viai_conv2d_pack_dgrad_f16": (_I, [_CP, _P, _P, _P]),
     "viai_conv2d_dgrad_f16": (_I, [_CP, _P, _P, _P, _P, _P, _P]),
     "viai_act_bwd_from_output": (_I, [_P, _P, _P, _L, _I, _F, _P]),
@@ -145,7 +149,7 @@ SIGNATURES = {
     "viai_mel_denorm_amp": (_I, [_P, _P, _L, _F, _P]),
     "viai_l2_ranks": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "viai_conv2d_cin1_bn_ok": (_I, [_CP]),
-    "viai_conv2d_cin1_bn_fwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "viai_conv2d_cin1_bn_fwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "viai_conv2d_cin1_bn_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "viai_conv2d_cin1_bn_wgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "viai_conv2d_cin1_bn_dgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -92,17 +92,18 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
 template <int ACT, bool FIXED>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, f32x4* __restrict__ z,
-                                                         long n4, int C, float slope) {
+                                                         long n4, int C, float slope, float* __restrict__ amax) {
     const unsigned c4n = (unsigned)(C / 4);
     const long stride = (long)gridDim.x * 256L;
     long i = blockIdx.x * 256L + threadIdx.x;
     unsigned cq = (unsigned)((unsigned long)i % c4n);
     const unsigned cstep = (unsigned)((unsigned long)stride % c4n);
     f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cq * 4), sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
+    float mx = 0.f;
     auto one = [&](const f32x4& v) {
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = viai_act(v[e] * sc[e] + sh[e], ACT, slope);
+        for (int e = 0; e < 4; ++e) { o[e] = viai_act(v[e] * sc[e] + sh[e], ACT, slope); mx = fmaxf(mx, fabsf(o[e])); }
         return o;
     };
     auto next = [&]() {
@@ -119,19 +120,21 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const f32x4* __restrict
         for (int u = 0; u < 4; ++u) { z[i + u * stride] = one(v[u]); next(); }
     }
     for (; i < n4; i += stride) { z[i] = one(y[i]); next(); }
+    // max |z|: the f16x2 operand scale of the kernels that consume z (forward conv of the next layer, this tensor's weight gradient)
+    if (amax != nullptr) block_absmax_to(amax, mx);
 }
 
 template <bool FIXED>
-int launch_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z, long n4, int C, int act, float slope, hipStream_t st) {
+int launch_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z, long n4, int C, int act, float slope, float* amax, hipStream_t st) {
     long blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     const dim3 grid((unsigned)blocks), blk(256);
     auto a0 = reinterpret_cast<const f32x4*>(y); auto a1 = reinterpret_cast<f32x4*>(z);
     switch (act) {
-    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_RELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope); break;
-    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_LRELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope); break;
-    case VIAI_ACT_SIGMOID: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_SIGMOID, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope); break;
-    default: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_NONE, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope); break;
+    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_RELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax); break;
+    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_LRELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax); break;
+    case VIAI_ACT_SIGMOID: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_SIGMOID, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax); break;
+    default: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_NONE, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax); break;
     }
     return viai_launch_status();
 }
@@ -359,13 +362,38 @@ extern "C" int viai_bn_eval_coeffs(int C, const float* gamma, const float* beta,
     return viai_launch_status();
 }
 
-extern "C" int viai_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z,
-                               long M, int C, int act, float slope, void* stream) {
+extern "C" int viai_bn_act_fwd_amax(const float* y, const float* scale, const float* shift, float* z,
+                                    long M, int C, int act, float slope, float* z_amax, void* stream) {
     if (C % 4 != 0) return (int)hipErrorInvalidValue;
     long n4 = M * C / 4;
     const int c4n = C / 4;
-    if (256 % c4n == 0) return launch_bn_act_fwd<true>(y, scale, shift, z, n4, C, act, slope, (hipStream_t)stream);
-    return launch_bn_act_fwd<false>(y, scale, shift, z, n4, C, act, slope, (hipStream_t)stream);
+    if (256 % c4n == 0) return launch_bn_act_fwd<true>(y, scale, shift, z, n4, C, act, slope, z_amax, (hipStream_t)stream);
+    return launch_bn_act_fwd<false>(y, scale, shift, z, n4, C, act, slope, z_amax, (hipStream_t)stream);
+}
+extern "C" int viai_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z,
+                               long M, int C, int act, float slope, void* stream) {
+    return viai_bn_act_fwd_amax(y, scale, shift, z, M, C, act, slope, nullptr, stream);
+}
+
+// amax = max(amax, max |x|): the f16x2 operand scale of a tensor no kernel of this library produced (one streaming pass)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ amax) {
+    float mx = 0.f;
+    const long n4 = n / 4, stride = (long)gridDim.x * 256L;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = x4[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) mx = fmaxf(mx, fabsf(x[n4 * 4 + threadIdx.x]));
+    block_absmax_to(amax, mx);
+}
+extern "C" int viai_absmax(const float* x, long n, float* amax, void* stream) {
+    if (x == nullptr || amax == nullptr || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    VIAI_LAUNCH(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, amax);
+    return viai_launch_status();
 }
 
 extern "C" int viai_bn_bwd_blocks(long M, int C) {

@@ -357,6 +357,20 @@ extern "C" int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_
 
 extern "C" int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float* x2, const float* wp,
                                const float* bias, float* y, float* stat_part, int act, void* stream) {
+    return viai_conv2d_fwd_amax(c, x, x2, wp, bias, y, stat_part, act, nullptr, stream);
+}
+
+// 1 if the forward launch of this layer splits its activations into fp16 terms (then x_amax matters)
+extern "C" int viai_conv2d_fwd_f16_ok(const viai_conv2d* c) {
+    if (!valid(c) || kind_of(c) != K_IGEMM || !use_bf3_fwd(c)) return 0;
+    const int lay = frag_fwd(c);
+    return (lay == 3 || lay == 4) ? 1 : 0;
+}
+
+// x_amax: device float >= max |x| (and |x2|), or NULL.  The f16x2 kernels scale their activation operand by a power of two before the
+// split: from x_amax when it is given (any magnitude is then representable), by the static 16 otherwise (|x| beyond 4094 saturates)
+extern "C" int viai_conv2d_fwd_amax(const viai_conv2d* c, const float* x, const float* x2, const float* wp,
+                                    const float* bias, float* y, float* stat_part, int act, const float* x_amax, void* stream) {
     if (!valid(c) || (c->C2 > 0) != (x2 != nullptr)) return (int)hipErrorInvalidValue;
     if (stat_part != nullptr && act != VIAI_ACT_NONE) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
@@ -378,6 +392,7 @@ extern "C" int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float
     a.M = a.g.N * a.g.OH * a.g.OW;
     if (use_bf3_fwd(c)) {
         a.wfrag = frag_fwd(c);
+        if (a.wfrag == 3 || a.wfrag == 4) a.amax = x_amax;            // f16x2 weight image = f16x2 kernel
         if (halo_fwd(c)) return viai_conv_halo_bf3_launch(a, st);
         a.sk = sk_fwd(c);
         return viai_conv_igemm_bf3_launch(a, st);
@@ -506,11 +521,11 @@ extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
 }
 
 static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
-                      float* ws, float* dw, float* db, int accumulate, const float* amax, void* stream);
+                      float* ws, float* dw, float* db, int accumulate, const float* amax, const float* xmax, void* stream);
 
 extern "C" int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
                                  float* ws, float* dw, float* db, int accumulate, void* stream) {
-    return wgrad_impl(c, x, x2, dy, ws, dw, db, accumulate, nullptr, stream);
+    return wgrad_impl(c, x, x2, dy, ws, dw, db, accumulate, nullptr, nullptr, stream);
 }
 
 // f16x2 weight gradient (layers on the bf16x3 wgrad kernel): dy scaled on the device from dy_amax = max |dy|, x by the
@@ -520,13 +535,13 @@ extern "C" int viai_conv2d_wgrad_f16_ok(const viai_conv2d* c) {
     return (valid(c) && kind_of(c) == K_IGEMM && f16x2_enabled() && bf3_enabled() && (viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2) || wgrad_patch(c))) ? 1 : 0;
 }
 extern "C" int viai_conv2d_wgrad_f16(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
-                                     float* ws, float* dw, float* db, int accumulate, const float* dy_amax, void* stream) {
+                                     float* ws, float* dw, float* db, int accumulate, const float* dy_amax, const float* x_amax, void* stream) {
     if (!viai_conv2d_wgrad_f16_ok(c) || dy_amax == nullptr) return (int)hipErrorInvalidValue;
-    return wgrad_impl(c, x, x2, dy, ws, dw, db, accumulate, dy_amax, stream);
+    return wgrad_impl(c, x, x2, dy, ws, dw, db, accumulate, dy_amax, x_amax, stream);
 }
 
 static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
-                      float* ws, float* dw, float* db, int accumulate, const float* amax, void* stream) {
+                      float* ws, float* dw, float* db, int accumulate, const float* amax, const float* xmax, void* stream) {
     if (!valid(c) || (c->C2 > 0) != (x2 != nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
@@ -556,6 +571,7 @@ static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, con
         WgradArgs a{};
         a.x = x; a.x2 = x2; a.dy = dy; a.ws = ws; a.C1 = c->C1; a.C2 = c->C2; a.Cout = c->Cout; a.M = (int)M;
         a.amax = amax;
+        a.xmax = xmax;
         viai_geom_fwd(c, &a.g);
         int ks = wgrad_ksplit(c, M);
         const bool patch = amax != nullptr && wgrad_patch(c);

@@ -22,6 +22,7 @@ struct DirectArgs {
     // fused Cin = 1 conv + BatchNorm(train) + activation layer (viai_conv2d_cin1_bn_*): y is never stored, it is recomputed from x
     const float* scale; const float* shift; const float* mean; const float* invstd; const float* sums; const float* dz;
     float* part;
+    float* zmax;                      // fused layer, apply pass: max |z| (operand scale of the f16x2 kernels that consume z), or null
     // block = whole output rows of one image (host-checked): the block's input rows are staged in LDS once (xrows x xpitch floats)
     int xfast, xrows, xpitch, rows_blk;
 };
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
     if (a.xfast) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     f32x4 vals[IT];
+    float zmx = 0.f;
     // decode the first pixel once, then walk: the per-pixel 32-bit divisions (p % OW, p / OW, ... = ~100 instructions) cost more than
     // the 4 .. 9 multiply-adds of the pixel itself and kept this streaming kernel at 2.7 TB/s of writes
     int ox, oy, n;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
             if constexpr (MODE == 2) {
                 f32x4 z;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) z[e] = viai_act(v[e] * sc[e] + sh[e], a.act, a.slope);
+                for (int e = 0; e < 4; ++e) { z[e] = viai_act(v[e] * sc[e] + sh[e], a.act, a.slope); zmx = fmaxf(zmx, fabsf(z[e])); }
                 *reinterpret_cast<f32x4*>(a.y + (size_t)p * a.Cout + cg * 4) = z;
             } else {
                 if (a.stat == nullptr) {
@@ -168,7 +170,11 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
         }
         vals[it] = v;
     }
-    if (MODE == 2 || a.stat == nullptr) return;
+    if constexpr (MODE == 2) {
+        if (a.zmax != nullptr) block_absmax_to(a.zmax, zmx);
+        return;
+    }
+    if (a.stat == nullptr) return;
     // block-local (mean, M2) per channel over the valid pixels of this block
     const int cnt = min(CIN1_PB, a.M - p0);
     *reinterpret_cast<f32x4*>(&red[pg][cg * 4]) = sum;
@@ -971,13 +977,14 @@ extern "C" int viai_conv2d_cin1_bn_ok(const viai_conv2d* c) {
 
 // z == NULL: BatchNorm partials only (the conv output is not stored);  z != NULL: z = act(scale * conv(x) + shift)
 extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, float* stat_part,
-                                       const float* scale, const float* shift, float* z, int act, void* stream) {
+                                       const float* scale, const float* shift, float* z, int act, float* z_amax, void* stream) {
     if (!viai_conv2d_cin1_bn_ok(c) || (z == nullptr) == (stat_part == nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     viai_tag_reset();
     viai_tag_kernel("direct");
     DirectArgs a = make_args(c);
     a.x = x; a.w = w; a.bias = bias; a.y = z; a.stat = stat_part; a.scale = scale; a.shift = shift; a.act = act; a.slope = 0.2f;
+    a.zmax = z_amax;
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
     cin1_rows_ok(a, CIN1_PB, c->kh, c->kw);
 #define CALL(KH, KW)                                                                                                               \

@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
 
     const ConvGeom& g = a.g;
     const float dscale = (NP == 2) ? f16_scale_from_amax(a.amax) : 1.f;
-    const float dlim = f16_clamp_for_scale(dscale), xscale = F16_ASCALE, xlim = 65504.f / F16_ASCALE;
+    const float xscale = (NP == 2 && a.xmax != nullptr) ? f16_scale_from_amax(a.xmax) : F16_ASCALE;
+    const float dlim = f16_clamp_for_scale(dscale), xlim = f16_clamp_for_scale(xscale);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgradArgs a) {
         __syncthreads();
     }
 
-    const float inv = (NP == 2) ? 1.0f / (dscale * F16_ASCALE) : 1.0f;
+    const float inv = (NP == 2) ? 1.0f / (dscale * xscale) : 1.0f;
     const int half = lane >> 5, col = lane & 31;
     float* dst = a.ws + ((size_t)z * g.wtaps + g.ws[t]) * a.Cout * Cin;
 #pragma unroll

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
 
     const ConvGeom& g = a.g;
     const float dscale = f16_scale_from_amax(a.amax), dlim = f16_clamp_for_scale(dscale);
-    const float xscale = F16_ASCALE, xlim = 65504.f / F16_ASCALE;
+    const float xscale = a.xmax != nullptr ? f16_scale_from_amax(a.xmax) : F16_ASCALE, xlim = f16_clamp_for_scale(xscale);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave / (C::WMC * C::WN), wrem = wave % (C::WMC * C::WN);
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
         if (wk != 0) return;
     }
     // ---- epilogue: G slab [z][slot][co][ci]
-    const float inv = 1.0f / (dscale * F16_ASCALE);
+    const float inv = 1.0f / (dscale * xscale);
     const int half = lane >> 5, col = lane & 31;
     const int ci = ci0 + wn * 32 + col;
 #pragma unroll

@@ -25,7 +25,7 @@
 #include <cstring>
 #include <map>
 #include <queue>
-#include <thread>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -42,8 +42,8 @@ struct Note {
     bool used;
 };
 std::vector<Note> g_log;
-std::thread::id g_log_owner;       // the log belongs to the thread that opened it: launches of other threads (another model stepping
-                                   // in the same process) are not part of its capture and are not noted
+std::mutex g_log_mu;               // launches are noted from whichever thread issues them: the forward from the caller's thread, the
+                                   // backward from autograd's device thread
 
 enum Kind { K_KERNEL, K_COPY, K_SET, K_EMPTY };
 
@@ -70,25 +70,25 @@ struct viai_plan {
 };
 
 void viai_plan_note(const void* func, void* stream, dim3 grid, dim3 block, const unsigned char* blob, const unsigned* sizes, int nargs) {
-    if (std::this_thread::get_id() != g_log_owner) return;
     Note n{func, (hipStream_t)stream, grid, block, {}, {}, false};
     size_t total = 0;
     for (int i = 0; i < nargs; ++i) total += sizes[i];
     n.blob.assign(blob, blob + total);
     n.sizes.assign(sizes, sizes + nargs);
-    g_log.push_back(std::move(n));
+    std::lock_guard<std::mutex> lk(g_log_mu);
+    if (viai_plan_log_on) g_log.push_back(std::move(n));
 }
 
 extern "C" int viai_plan_log_begin(void) {
+    std::lock_guard<std::mutex> lk(g_log_mu);
     if (viai_plan_log_on) return (int)hipErrorInvalidValue;       // one recorder at a time
     g_log.clear();
-    g_log_owner = std::this_thread::get_id();
     viai_plan_log_on = 1;
     return 0;
 }
 
 extern "C" int viai_plan_log_end(void) {
-    if (std::this_thread::get_id() != g_log_owner) return -1;
+    std::lock_guard<std::mutex> lk(g_log_mu);
     viai_plan_log_on = 0;
     return (int)g_log.size();
 }

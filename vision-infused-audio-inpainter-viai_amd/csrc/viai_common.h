@@ -95,6 +95,23 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// max |.| of a tensor into a device float (zero-initialised by the caller, or holding an earlier maximum): wave shuffle, LDS, at most one
+// conditional atomicMax per block on the float bits (non-negative floats order like unsigned integers; max is order-independent, so the
+// result is deterministic).  256-thread blocks; every thread of the block must call it.
+__device__ __forceinline__ void block_absmax_to(float* amax, float mx) {
+    __shared__ float viai_wmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) viai_wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(viai_wmax[0], viai_wmax[1]), fmaxf(viai_wmax[2], viai_wmax[3]));
+        // plain read first: thousands of blocks hammering one address with atomics measured +0.9 ms per step
+        if (mx > 0.f && __float_as_uint(mx) > __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(amax)))
+            atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
+    }
+}
+
 // XCD-aware bijective remap of a linear workgroup id: consecutive logical tiles
 // land on the same XCD (block b is observed to run on XCD b % 8), so
 // neighbouring tiles share that XCD's L2.  Speed only, never correctness.

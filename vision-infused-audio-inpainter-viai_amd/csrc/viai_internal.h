@@ -26,6 +26,7 @@ struct WgradArgs {
     const float* dy;                   // [M][Cout]
     float* ws;                         // [ksplit][wtaps][Cout][Cin]
     const float* amax;                 // f16x2 launch: device scalar max |dy| (dynamic operand scale); null = bf16x3
+    const float* xmax;                 // f16x2 launch: device scalar max |x| (and |x2|) if known (dynamic operand scale for the forward input); null = static F16_ASCALE
     int C1, C2, Cout;
     int M;
     int nblk_co, nblk_ci, ksplit, chunks_per_split;

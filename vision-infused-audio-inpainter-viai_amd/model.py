@@ -192,6 +192,7 @@ class AudioModel:
         self.video_net_norm = None
         self.losses = torch.zeros(6, device=self.device)      # loss_D, loss_G, loss_G_GAN, loss_L1, loss_D_real, EmbeddingL2
         self.mel = self.mask = self.fake = None
+        self._wmax = None
         # use_plan: the step is stream-captured once and replayed from C as a launch plan (csrc/plan.hip): the eager step's
         # kernels, arguments, streams and cross-stream edges without the per-launch host work.  Shares the segment structure
         # (and the static-buffer discipline) of graph mode, so it sets use_graph too.
@@ -704,9 +705,27 @@ class AudioModel:
         return self.fake
 
     # ------------------------------------------------------------ bookkeeping
+    def _weight_range_check(self):
+        """max |w| over both parameter arenas next to the loss scalars (same host read): the f16x2 weight images are pre-scaled by a
+        static 256 and clamp beyond |w| = 255.9 -- a model that gets there has diverged, and is told so instead of training on clipped
+        weights."""
+        if self._wmax is None:
+            self._wmax = torch.zeros(2, device=self.device)
+        self._wmax.zero_()
+        for i, arena in enumerate((self.arena_G, self.arena_D)):
+            check(lib().viai_absmax(arena.flat.data_ptr(), arena.flat.numel(), self._wmax[i:i + 1].data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream), "viai_absmax")
+        return self._wmax
+
     def get_loss_items(self):
         """host sync point (train_whole_sync.py:85)."""
-        v = self.losses.tolist()
+        self.sync_pending_update()
+        both = torch.cat((self.losses, self._weight_range_check())).tolist()
+        v, wmax = both[:self.losses.numel()], both[self.losses.numel():]
+        if max(wmax) > ops.F16_WEIGHT_LIMIT and os.environ.get("VIAI_F16X2", "1") != "0" and os.environ.get("VIAI_MATH", "") != "fp32":
+            raise FloatingPointError("max |weight| = %.4g (E+G) / %.4g (D) is beyond %.1f, where the f16x2 weight images of the conv kernels "
+                                     "clamp: the model has diverged (VIAI_F16X2=0 selects the bf16x3 kernels, which have the fp32 exponent range)"
+                                     % (wmax[0], wmax[1], ops.F16_WEIGHT_LIMIT))
         self.loss_D_item, self.loss_G_item, self.loss_G_GAN_item, self.loss_mel_L1_item = v[0], v[1], v[2], v[3]
         self.reconstruct_loss_item = v[3]                      # the L1 reconstruction term (train_whole_sync.py:98 accumulates it)
         self.EmbeddingL2_item = v[5] if (self.use_video and self.cfg.lambda_contrast > 0) else 0.0

@@ -36,6 +36,7 @@ DIRECT_GRAD = False
 WGRAD_STREAM = None
 _deferred = []
 F16_BACKWARD = os.environ.get("VIAI_F16_BACKWARD", "1") != "0"     # f16x2 data gradients (dynamic per-tensor scale)
+F16_DYNAMIC = os.environ.get("VIAI_F16_DYNAMIC", "1") != "0"       # 0: static x16 activation scale in the forward / weight-gradient kernels (A/B only)
 
 # Gradient-ready hooks (set by model.AudioModel for the data-parallel exchange): {weight.data_ptr(): callable}.  The callable runs
 # right after the backward of the layer owning that weight has queued its LAST gradient launch (weight gradient on WGRAD_STREAM,
@@ -44,10 +45,11 @@ F16_BACKWARD = os.environ.get("VIAI_F16_BACKWARD", "1") != "0"     # f16x2 data 
 GRAD_HOOKS = {}
 
 
-# f16x2 range guard (debug mode, VIAI_DEBUG_RANGE=1 or ops.DEBUG_RANGE = True).  The f16x2 conv kernels pre-scale their operands by
-# powers of two and saturate beyond the fp16 range: activations with |x| > 65504 / 16 and weights with |w| > 65504 / 256 would be
-# clipped silently.  In debug mode every conv input and weight is scanned (one extra streaming pass each) and range_report() tells
-# how many elements were outside; `strict` raises at the offending layer (costs a host sync per layer).
+# f16x2 range guard.  Activations: the operand scale of the fp16 split follows the tensor's magnitude on the device (`_viai_amax`
+# provenance below), so nothing saturates.  Weights are pre-scaled by the static 256 in the pack kernels and CLAMP beyond
+# |w| > 65504 / 256 = 255.9: model.AudioModel checks max |w| of its arenas at its host sync point (get_loss_items) and raises; in
+# debug mode (VIAI_DEBUG_RANGE=1 or ops.DEBUG_RANGE = True) every conv call scans its weight (one extra streaming pass) and
+# range_report() tells how many elements were outside; `strict` raises at the offending layer (a host sync per layer).
 DEBUG_RANGE = os.environ.get("VIAI_DEBUG_RANGE", "0") not in ("0", "")
 DEBUG_RANGE_STRICT = os.environ.get("VIAI_DEBUG_RANGE", "0") == "strict"
 F16_ACT_LIMIT, F16_WEIGHT_LIMIT = 65504.0 / 16.0, 65504.0 / 256.0
@@ -140,13 +142,66 @@ def begin_step(device=None):
     _amax_managed = True
 
 
+_free_ring = {}     # device -> [zeroed ring, next index]: slots for callers that never call begin_step (one fill per 1024 slots)
+
+
 def _amax_slot(dev):
     global _amax_next
     if _amax_managed and _amax_ring is not None and _amax_ring.device == dev and _amax_next < _amax_ring.numel():
         t = _amax_ring[_amax_next:_amax_next + 1]
         _amax_next += 1
         return t
-    return torch.zeros(1, device=dev, dtype=torch.float32)
+    r = _free_ring.get(dev)
+    if r is None or r[1] >= r[0].numel():
+        r = _free_ring[dev] = [torch.zeros(1024, device=dev, dtype=torch.float32), 0]     # the old ring lives on in the slices handed out
+    t = r[0][r[1]:r[1] + 1]
+    r[1] += 1
+    return t
+
+
+# Operand magnitudes for the f16x2 kernels.  Every tensor an op of this module produces behind a BatchNorm (or a bounded activation)
+# carries `_viai_amax`: a device float >= max |tensor| that its producer reduced on the way out (viai_bn_act_fwd_amax, the fused
+# Cin = 1 layer) or inherited (resampling never increases the maximum).  The consumer hands it to the kernel, which derives the
+# power-of-two scale of the fp16 split from it ON THE DEVICE: no host round trip, and no magnitude saturates.  A tensor without
+# provenance (user data, torch ops in between) gets one streaming viai_absmax pass when -- and only when -- the layer's forward
+# kernel is an f16x2 kernel.
+_unit_amax = {}
+
+
+def _const_amax(dev, value=1.0):
+    t = _unit_amax.get((dev, value))
+    if t is None:
+        t = _unit_amax[(dev, value)] = torch.full((1,), float(value), device=dev, dtype=torch.float32)
+    return t
+
+
+def amax_of(t):
+    return getattr(t, "_viai_amax", None) if t is not None else None
+
+
+def inherit_amax(out, *srcs):
+    """out = a resampling / masking of srcs[0] (|out| <= max |src|): the magnitude carries over"""
+    a = amax_of(srcs[0])
+    if a is not None:
+        out._viai_amax = a
+    return out
+
+
+def _input_amax(x, x2, known, st):
+    """device float >= max(|x|, |x2|) for an f16x2 forward launch; `known` = the magnitudes the caller's tensors carried"""
+    a1, a2 = known
+    if x2 is None and a1 is not None:
+        return a1
+    lib = _lib.load()
+    slot = _amax_slot(x.device)
+    for t, a in ((x, a1), (x2, a2)):
+        if t is None:
+            continue
+        if a is not None:
+            torch.maximum(slot, a, out=slot)
+        else:
+            _lib.check(lib.viai_absmax(t.data_ptr(), t.numel(), slot.data_ptr(), st), "viai_absmax")
+    return slot
 
 
 def scratch_snapshot():
@@ -339,14 +394,17 @@ class _ConvBnAct(torch.autograd.Function):
         OH, OW = d["OH"], d["OW"]
         M = N * OH * OW
         if DEBUG_RANGE:
-            _range_scan("activation", x, F16_ACT_LIMIT)
-            if x2 is not None:
-                _range_scan("activation", x2, F16_ACT_LIMIT)
             _range_scan("weight", weight, F16_WEIGHT_LIMIT)
         wp = _packed(weight, d, 0, st)
         has_bn = gamma is not None
         act = cfg["act"]
         training = cfg["training"]
+        f16f = d.get("fwd_f16")
+        if f16f is None:
+            f16f = d["fwd_f16"] = bool(lib.viai_conv2d_fwd_f16_ok(d["ref"]))
+        xa = _input_amax(x, x2, cfg.get("xa_in", (None, None)), st) if (f16f and F16_DYNAMIC) else None   # operand magnitude of the f16x2 split (forward and weight gradient)
+        ctx.xa = xa
+        za = None
         fused1 = False
         if has_bn and training and bias is None and C1 + C2 == 1:
             fused1 = d.get("cin1_bn")
@@ -357,42 +415,47 @@ class _ConvBnAct(torch.autograd.Function):
             # Cin = 1 conv + BatchNorm(train) + activation: the pre-BatchNorm tensor is never stored (recomputed from x where needed)
             coef = torch.empty((4, Cout), device=dev, dtype=torch.float32)
             stat = _scratch("stat", 2 * Cout * d["nblk"], dev)
-            _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), wp.data_ptr(), 0, stat.data_ptr(), 0, 0, 0, act, st),
+            _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), wp.data_ptr(), 0, stat.data_ptr(), 0, 0, 0, act, 0, st),
                        "viai_conv2d_cin1_bn_fwd")
             _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, Cout, gamma.data_ptr(),
                                             beta.data_ptr(), _ptr(rmean), _ptr(rvar), _ptr(nbt),
                                             cfg["momentum"], cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
                                             coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_finalize")
             z = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
+            za = _amax_slot(dev)
             _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), wp.data_ptr(), 0, 0, coef[2].data_ptr(), coef[3].data_ptr(),
-                                                   z.data_ptr(), act, st), "viai_conv2d_cin1_bn_fwd")
+                                                   z.data_ptr(), act, za.data_ptr(), st), "viai_conv2d_cin1_bn_fwd")
             ctx.save_for_backward(x, None, weight, None, coef)
         elif has_bn:
             y = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
             coef = torch.empty((4, Cout), device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
             if training:
                 stat = _scratch("stat", 2 * Cout * d["nblk"], dev)
-                _lib.check(lib.viai_conv2d_fwd(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
-                                               y.data_ptr(), stat.data_ptr(), ACT_NONE, st), "viai_conv2d_fwd")
+                _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
+                                                    y.data_ptr(), stat.data_ptr(), ACT_NONE, _ptr(xa), st), "viai_conv2d_fwd")
                 _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, Cout, gamma.data_ptr(),
                                                 beta.data_ptr(), _ptr(rmean), _ptr(rvar), _ptr(nbt),
                                                 cfg["momentum"], cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
                                                 coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_finalize")
             else:
-                _lib.check(lib.viai_conv2d_fwd(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
-                                               y.data_ptr(), 0, ACT_NONE, st), "viai_conv2d_fwd")
+                _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
+                                                    y.data_ptr(), 0, ACT_NONE, _ptr(xa), st), "viai_conv2d_fwd")
                 _lib.check(lib.viai_bn_eval_coeffs(Cout, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(),
                                                    rvar.data_ptr(), cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
                                                    coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_eval_coeffs")
             z = torch.empty_like(y)
-            _lib.check(lib.viai_bn_act_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(),
-                                           M, Cout, act, 0.2, st), "viai_bn_act_fwd")
+            za = _amax_slot(dev)
+            _lib.check(lib.viai_bn_act_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(),
+                                                M, Cout, act, 0.2, za.data_ptr(), st), "viai_bn_act_fwd")
             ctx.save_for_backward(x, x2, weight, y, coef)
         else:
             z = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
-            _lib.check(lib.viai_conv2d_fwd(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
-                                           z.data_ptr(), 0, act, st), "viai_conv2d_fwd")
+            _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
+                                                z.data_ptr(), 0, act, _ptr(xa), st), "viai_conv2d_fwd")
+            if act == ACT_SIGMOID:
+                za = _const_amax(dev, 1.0)
             ctx.save_for_backward(x, x2, weight, z, None)
+        cfg["za"] = za                       # conv_bn_act attaches it to the returned tensor
         ctx.d = d
         ctx.cfg = cfg
         ctx.has_bn = has_bn
@@ -472,19 +535,19 @@ class _ConvBnAct(torch.autograd.Function):
                 ws = _scratch("wgrad", d["ws_floats"], dev, WGRAD_STREAM)
                 if amax is not None and d["wgrad_f16"]:
                     _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                         dw.data_ptr(), db.data_ptr() if want_db else 0, 1, amax.data_ptr(),
+                                                         dw.data_ptr(), db.data_ptr() if want_db else 0, 1, amax.data_ptr(), _ptr(ctx.xa),
                                                          WGRAD_STREAM.cuda_stream), "viai_conv2d_wgrad_f16")
                 else:
                     _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
                                                      dw.data_ptr(), db.data_ptr() if want_db else 0, 1, WGRAD_STREAM.cuda_stream),
                                "viai_conv2d_wgrad")
-                _deferred.append((x, x2, dy, weight, amax))
+                _deferred.append((x, x2, dy, weight, amax, ctx.xa))
             elif acc_w == acc_b or not want_db:
                 ws = _scratch("wgrad", d["ws_floats"], dev)
                 if amax is not None and d["wgrad_f16"]:
                     _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
                                                          dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0,
-                                                         amax.data_ptr(), st), "viai_conv2d_wgrad_f16")
+                                                         amax.data_ptr(), _ptr(ctx.xa), st), "viai_conv2d_wgrad_f16")
                 else:
                     _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
                                                      dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0, st),
@@ -591,7 +654,7 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
     `padding2` = (bottom, right) padding when it differs from `padding` (-1 = symmetric)."""
     cfg = {"k": tuple(kernel), "s": tuple(stride), "p": tuple(padding), "transposed": bool(transposed),
            "act": int(act), "training": bool(training), "momentum": 0.1, "eps": BN_EPS,
-           "d": tuple(dilation), "p2": tuple(padding2)}
+           "d": tuple(dilation), "p2": tuple(padding2), "xa_in": (amax_of(x), amax_of(x2))}
     if bn is not None:
         cfg["momentum"] = 0.1 if bn.momentum is None else float(bn.momentum)
         cfg["eps"] = float(bn.eps)
@@ -601,13 +664,20 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
         if DIRECT_GRAD:
             cfg["gt"] = tuple(p.grad if (p is not None and p.is_leaf and p.requires_grad and p.grad is not None) else None
                               for p in (weight, bias, bn.weight, bn.bias))
-        return _ConvBnAct.apply(x, x2, weight, bias, bn.weight, bn.bias,
-                                bn.running_mean if track else None, bn.running_var if track else None,
-                                bn.num_batches_tracked if (track and cfg["training"]) else None, cfg)
+        return _tag_amax(_ConvBnAct.apply(x, x2, weight, bias, bn.weight, bn.bias,
+                                          bn.running_mean if track else None, bn.running_var if track else None,
+                                          bn.num_batches_tracked if (track and cfg["training"]) else None, cfg), cfg)
     if DIRECT_GRAD:
         cfg["gt"] = tuple(p.grad if (p is not None and p.is_leaf and p.requires_grad and p.grad is not None) else None
                           for p in (weight, bias, None, None))
-    return _ConvBnAct.apply(x, x2, weight, bias, None, None, None, None, None, cfg)
+    return _tag_amax(_ConvBnAct.apply(x, x2, weight, bias, None, None, None, None, None, cfg), cfg)
+
+
+def _tag_amax(z, cfg):
+    za = cfg.pop("za", None)
+    if za is not None:
+        z._viai_amax = za
+    return z
 
 
 class _BilinearAC(torch.autograd.Function):
@@ -637,7 +707,7 @@ class _BilinearAC(torch.autograd.Function):
 def bilinear_ac(x, size):
     if x.shape[1] == size[0] and x.shape[2] == size[1]:
         return x            # identity resize (align_corners): exact copy semantics
-    return _BilinearAC.apply(x, int(size[0]), int(size[1]))
+    return inherit_amax(_BilinearAC.apply(x, int(size[0]), int(size[1])), x)      # a convex combination of its inputs
 
 
 class _AvgPoolH(torch.autograd.Function):
@@ -665,7 +735,7 @@ class _AvgPoolH(torch.autograd.Function):
 
 
 def avgpool_h(x, k=3):
-    return _AvgPoolH.apply(x, int(k))
+    return inherit_amax(_AvgPoolH.apply(x, int(k)), x)
 
 
 class _ScalarLoss(torch.autograd.Function):
@@ -752,7 +822,7 @@ class _MaxPool(torch.autograd.Function):
 
 
 def maxpool(x, k=3, s=2, p=1):
-    return _MaxPool.apply(x, int(k), int(s), int(p))
+    return inherit_amax(_MaxPool.apply(x, int(k), int(s), int(p)), x)
 
 
 class _AvgPool2d(torch.autograd.Function):
@@ -781,7 +851,7 @@ class _AvgPool2d(torch.autograd.Function):
 
 
 def avgpool2d(x, k=3, s=2, p=1):
-    return _AvgPool2d.apply(x, int(k), int(s), int(p))
+    return inherit_amax(_AvgPool2d.apply(x, int(k), int(s), int(p)), x)
 
 
 class _AvgPoolHW(torch.autograd.Function):
@@ -809,7 +879,7 @@ class _AvgPoolHW(torch.autograd.Function):
 
 
 def avgpool_hw(x):
-    return _AvgPoolHW.apply(x)
+    return inherit_amax(_AvgPoolHW.apply(x), x)
 
 
 class _AddRelu(torch.autograd.Function):
@@ -836,7 +906,11 @@ class _AddRelu(torch.autograd.Function):
 
 
 def add_relu(a, b):
-    return _AddRelu.apply(a, b)
+    out = _AddRelu.apply(a, b)
+    ma, mb = amax_of(a), amax_of(b)
+    if ma is not None and mb is not None:
+        out._viai_amax = ma + mb                        # |relu(a + b)| <= max |a| + max |b|
+    return out
 
 
 def frames_to_nhwc4(x):
@@ -914,7 +988,7 @@ class _MaskMul(torch.autograd.Function):
 
 def mask_mul(s, mask):
     """s: (N,1,F,T) or (N,F,T); mask: (N,1,1,T) or (N,T)."""
-    return _MaskMul.apply(s, mask.reshape(mask.shape[0], mask.shape[-1]))
+    return inherit_amax(_MaskMul.apply(s, mask.reshape(mask.shape[0], mask.shape[-1])), s)      # mask in {0, 1}
 
 
 def adam_step(p, g, m, v, state, beta1, beta2, eps, grad_scale=1.0):
