@@ -258,3 +258,67 @@ def test_eval_discriminator_is_per_clip_at_benchmark_size():
     assert torch.isfinite(whole).all()
     err = ((whole.double() - halves.double()).norm() / whole.double().norm()).item()
     assert err < 2e-5, err
+
+
+def _full_av_model(monkeypatch, wgrad_stream, dreal_stream, num_D):
+    from viai_amd.model import AudioModel, StepConfig
+    monkeypatch.setenv("VIAI_WGRAD_STREAM", wgrad_stream)
+    monkeypatch.setenv("VIAI_DREAL_STREAM", dreal_stream)
+    hp = StepConfig()
+    hp.cin_channels, hp.max_mel_lengths = 256, 256
+    hp.use_video, hp.num_D, hp.lambda_contrast = True, num_D, 0.1
+    m = AudioModel(hp, device="cuda")
+    m.load_states(O.encoder_state(), O.decoder_variant_state("image"), O.msd_state(num_D) if num_D > 1 else O.disc_state(),
+                  O.image_embedding2_state())
+    return m
+
+
+def test_vision_infused_step_is_bitwise_serial_at_full_size(monkeypatch):
+    """BASELINE.json configs[2] / [3] at their real size -- 16 clips of 256 x 256, 64 video + 64 flow frames of 224 x 224 per clip
+    (1024 + 1024 frames through two ResNet-18s, Image_Embedding.py:187-200), 3-scale D: two full steps (both Adam updates) on three
+    streams are bit-identical to the single-stream steps, and everything is finite.  The ResNet branch at this size takes kernels no
+    other test reaches (partial 8 x 16 tiles on the 56 / 28 / 14 / 7-pixel maps at 1024 frames, full-CU weight-gradient grids)."""
+    from viai_amd import synth
+    B, NF = 16, 64
+    s = synth.mel_batch(B, 256, 256, "fullav.s", 0).cuda()
+    mask = synth.time_mask(B, 256, "fullav.mask", 0).cuda()
+    video = synth.uniform("fullav.video", (B, NF, 3, 224, 224), -1, 1).cuda()
+    flow = synth.uniform("fullav.flow", (B, NF, 2, 224, 224), -1, 1).cuda()
+
+    def run(wgrad, dreal):
+        m = _full_av_model(monkeypatch, wgrad, dreal, 3)
+        m.set_inputs(s, mask, video=video, flow=flow)
+        for i in range(2):
+            m.optimize_parameters(i)
+        v = m.get_loss_items()
+        torch.cuda.synchronize()
+        out = [m.fake.detach().clone(), m.losses.clone(), m.arena_D.grad.clone(), m.arena_G.grad.clone(), m.arena_G.flat.clone()]
+        m.close()
+        del m
+        torch.cuda.empty_cache()
+        return out, v
+    (serial, v0), (streams, v1) = run("0", "0"), run("1", "1")
+    assert all(x == x for x in v0) and v0[5] > 0                 # the contrastive term is live
+    for a, b in zip(serial, streams):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
+
+
+def test_eval_image_embedding_is_per_clip_at_full_size():
+    """eval-mode ImageEmbedding2 (running-statistics BatchNorm) is a per-clip map: 4 clips x 64 frames in one call (256 + 256 frames)
+    agree with two 2-clip calls (different tile counts / grids in every layer) to fp32 rounding."""
+    from viai_amd import synth
+    from viai_amd.networks import ImageEmbedding2
+    V = ImageEmbedding2().cuda()
+    V.load_state_dict(O.image_embedding2_state())
+    V.eval()
+    video = synth.uniform("fullav.ev.video", (4, 64, 3, 224, 224), -1, 1).cuda()
+    flow = synth.uniform("fullav.ev.flow", (4, 64, 2, 224, 224), -1, 1).cuda()
+    with torch.no_grad():
+        whole, fea = V(video, flow)
+        h0, f0 = V(video[:2], flow[:2])
+        h1, f1 = V(video[2:], flow[2:])
+    assert tuple(whole.shape) == (4, 256, 1, 16) and tuple(fea.shape) == (4, 512, 64)
+    for a, b in ((whole, torch.cat((h0, h1), 0)), (fea, torch.cat((f0, f1), 0))):
+        err = ((a.double() - b.double()).norm() / a.double().norm()).item()
+        assert torch.isfinite(a).all() and err < 2e-5, err

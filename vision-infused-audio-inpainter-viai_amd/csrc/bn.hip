@@ -400,8 +400,7 @@ extern "C" int viai_bn_bwd_blocks(long M, int C) {
     // ~512 row blocks for large tensors (two per CU, eight 16-byte loads in flight per lane: enough to cover HBM latency; more
     // blocks only lengthen the partial array the final kernel walks), but never fewer rows per block than one unrolled pass of
     // the reduce kernel covers (256 threads = C/4 channel quads x pixel lanes, 4 rows in flight per lane)
-    static long target = 0;
-    if (target == 0) { const char* e = getenv("VIAI_BN_BWD_BLOCKS"); target = e ? atol(e) : 512; if (target < 1) target = 512; }
+    constexpr long target = 512;
     long rows_min = 4096 / (C > 0 ? C : 1);
     if (rows_min < 4) rows_min = 4;
     long rows = (M + target - 1) / target;

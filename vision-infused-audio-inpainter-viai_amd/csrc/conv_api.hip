@@ -112,8 +112,7 @@ static bool halo_wide_dgrad(const viai_conv2d* c) {
 }
 // f16x2 for the LDS-weight / split-K kernels too (planar fp16 planes); VIAI_F16_PLANAR=0 keeps them on bf16x3
 static bool planar16_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VIAI_F16_PLANAR"); on = e ? atoi(e) : 1; }
+    constexpr int on = 1;
     return on != 0 && f16x2_enabled();
 }
 // forward weight layout: 0 planar bf16x3, 1 fragment-major bf16x3, 3 fragment-major f16x2 (wide-tile / halo kernels), 4 planar f16x2

@@ -386,8 +386,7 @@ bool viai_dgrad_s2_ok(const viai_conv2d* c) {
     // where the base lattice tiles in 8 x 16 (patch-staged kernel) even a fraction of a round beats four class-by-class launches of
     // the split-K kernel (E.conv4 / E.conv5: 4 x ~30 us -> one ~25 us launch)
     const bool tiles = ((c->IH / 2) % 8 == 0) && ((c->IW / 2) % 16 == 0);
-    static long small = -1;
-    if (small < 0) { const char* e = getenv("VIAI_S2_MIN_BLOCKS"); small = e ? atol(e) : 32; }
+    constexpr long small = 32;
     return blocks >= (tiles ? small : 256);
 }
 
@@ -402,8 +401,7 @@ int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_bf3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    static int patch = -1;
-    if (patch < 0) { const char* e = getenv("VIAI_S2_PATCH"); patch = e ? atoi(e) : 1; }
+    constexpr int patch = 1;
     if (a.amax != nullptr && patch && a.g.IH % 8 == 0 && a.g.IW % 16 == 0 && a.g.OH == 2 * a.g.IH && a.g.OW == 2 * a.g.IW && a.C1 % 32 == 0) {
         constexpr int lds_p = 2 * 2 * 9 * 17 * 80;
         static bool attr_p = false;

@@ -70,8 +70,7 @@ __device__ __forceinline__ void cin1_lds_taps(const float* xr, int pitch, float 
 }
 static bool cin1_rows_ok(DirectArgs& a, int pix_per_blk, int KH, int KW, int which = 1) {
     a.xfast = 0;
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VIAI_CIN1_LDSX"); on = e ? atoi(e) : 7; }
+    constexpr int on = 7;
     if (!(on & which) || a.transposed || pix_per_blk % a.OW != 0 || (a.OH * a.OW) % pix_per_blk != 0) return false;
     a.rows_blk = pix_per_blk / a.OW;
     a.xrows = (a.rows_blk - 1) * a.sh + KH;
@@ -895,8 +894,7 @@ int viai_cin1_dgrad(const viai_conv2d* c, const float* dy, const float* w, float
     int lpp = c->Cout / 4;
     long nb = (tot * lpp + 255) / 256;
     // 4096 blocks measured best on D.conv1 (2048 ... 8192 within 4 %; 32768+ slower: every block reloads the filter)
-    static long cap = 0;
-    if (!cap) { const char* e_ = getenv("VIAI_CIN1_DGRAD_BLOCKS"); cap = e_ ? atol(e_) : 4096; }
+    constexpr long cap = 4096;
     if (nb > cap) nb = cap;
     int blocks = (int)nb;
     if (c->kh == 1 && c->kw == 4 && c->sh == 1 && c->sw == 2 && lpp == 16) {          // D.conv1
@@ -1101,8 +1099,7 @@ int viai_cout1_fwd(const viai_conv2d* c, const float* x, const float* wp, const 
     long nb = ((long)a.M * lpp + 255) / 256;
     if (nb > 16384) nb = 16384;
     const int blocks = (int)nb;
-    static int runk = -1;
-    if (runk < 0) { const char* e_ = getenv("VIAI_COUT1_RUN"); runk = e_ ? atoi(e_) : 1; }
+    constexpr int runk = 1;
     if (runk && c->kh == 3 && c->kw == 3 && c->ph == 1 && c->pw == 1 && a.OW % 4 == 0 && a.OW == a.IW && a.OH == a.IH) {
         const int L = cin == 512 ? 2 : 4;                            // (L + 2) x 3 x CPL float4 of window registers
         long nr = (long)a.N * a.OH * (a.OW / L);
@@ -1138,8 +1135,7 @@ int viai_cout1_dgrad(const viai_conv2d* c, const float* dy, const float* wp, flo
     long nb = (total + 255) / 256;
     if (nb > 8192) nb = 8192;
     const int blocks = (int)nb;
-    static int runk = -1;
-    if (runk < 0) { const char* e_ = getenv("VIAI_COUT1_RUN"); runk = e_ ? atoi(e_) : 1; }
+    constexpr int runk = 1;
     constexpr int L = 8;
     if (runk && c->kh == 3 && c->kw == 3 && c->ph == 1 && c->pw == 1 && a.IW % L == 0 && a.OW == a.IW && a.OH == a.IH) {
         long nb2 = ((long)a.N * a.IH * (a.IW / L) * (a.Cin / 4) + 255) / 256;
@@ -1170,8 +1166,7 @@ int viai_cout1_wgrad(const viai_conv2d* c, const float* x, const float* dy, floa
     int ppb = (int)((q + nb - 1) / nb);
     int pg = 256 / (a.Cin / 4);
     size_t lds = (size_t)pg * T * a.Cin * sizeof(float);
-    static int runk = -1;
-    if (runk < 0) { const char* e_ = getenv("VIAI_COUT1_RUN"); runk = e_ ? atoi(e_) : 1; }
+    constexpr int runk = 1;
     constexpr int L = 16;
     if (runk && c->kh == 3 && c->kw == 3 && a.IW % L == 0 && c->ph == 1 && c->pw == 1) {
         const long nruns = (long)a.N * a.IH * (a.IW / L);

@@ -711,8 +711,7 @@ bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout) {
 
 // f16x2 register-resident-filter variant: 32 input channels, <= 32 output channels, all nine positions of a 3 x 3 window
 bool viai_conv_halo16_ok(const ConvGeom& g, int C1, int C2, int Cout) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VIAI_HALO16"); on = e ? atoi(e) : 1; }
+    constexpr int on = 1;
     if (!on || !viai_conv_halo_ok(g, C1, C2, Cout) || C1 != 32 || Cout > 32 || g.ntaps != 9) return false;
     int y0 = g.dy[0], x0 = g.dx[0];
     for (int t = 1; t < 9; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
@@ -770,15 +769,13 @@ bool viai_conv_halo_wide_ok(const ConvArgs& a) {
     if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2) || g.SH != g.OH || g.SW != g.OW || g.ntaps != 9) return false;
     if (g.OH % HT_H != 0 || g.OW % HT_W != 0) return false;
     if (g.my == 2) {                                               // stride-2 forward: eight-wave instances only, one source
-        static int s2 = -1;
-        if (s2 < 0) { const char* e = getenv("VIAI_HALO_WIDE_S2"); s2 = e ? atoi(e) : 1; }
+        constexpr int s2 = 1;
         if (!s2 || a.C2 != 0 || a.Cout % 128 != 0 || a.OC1 != a.Cout) return false;
     }
     const long tiles = (long)g.N * (g.OH / HT_H) * (g.OW / HT_W);
     // small maps: 64-channel blocks double the block count (the 16 x 32 maps of G.convblock2: 64 tiles -> 128 / 256 blocks, each
     // with half the K-loop work of a 128-channel block) -- still better than the split-K kernel those layers ran on
-    static long min64 = -1;
-    if (min64 < 0) { const char* e = getenv("VIAI_HALO_WIDE_MIN64"); min64 = e ? atol(e) : 96; }
+    constexpr long min64 = 96;
     if (tiles * (a.Cout >= 128 ? a.Cout / 128 : 1) < 192 && !(a.Cout >= 128 && tiles * (a.Cout / 64) >= min64)) return false;
     int y0 = g.dy[0], x0 = g.dx[0];
     for (int t = 1; t < 9; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
@@ -814,8 +811,7 @@ int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
     if (g.my == 2) return (a.Cout % 256 == 0) ? launch_halo_wide<2, 4, 2, 2, 2>(a, y0, x0, sl, st) : launch_halo_wide<2, 4, 2, 1, 2>(a, y0, x0, sl, st);
     if (a.Cout == 32) return launch_halo_wide<4, 1, 1, 1>(a, y0, x0, sl, st);
     if (a.Cout == 64 || (long)a.nblk_m * (a.Cout / 128) < 192) return launch_halo_wide<2, 2, 2, 1>(a, y0, x0, sl, st);
-    static int wn4 = -1;
-    if (wn4 < 0) { const char* e = getenv("VIAI_HALO_WIDE_WN4"); wn4 = e ? atoi(e) : 1; }
+    constexpr int wn4 = 1;
     if (wn4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<2, 4, 2, 2>(a, y0, x0, sl, st);
     return launch_halo_wide<2, 2, 2, 2>(a, y0, x0, sl, st);
 }

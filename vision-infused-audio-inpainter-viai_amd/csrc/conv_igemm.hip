@@ -322,8 +322,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 // have only 16..256 such tiles, so they take 64x64 tiles (4x the blocks, 1/4 the per-block latency).
 int viai_igemm_tile_m(long M, int n_out) {
     if (n_out <= 32) return 128;
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("VIAI_FORCE_TILE_M"); force = e ? atoi(e) : 0; }
+    constexpr int force = 0;
     if (force == 64 || force == 128) return force;
     long b128 = ((M + 127) / 128) * ((n_out + 127) / 128);
     if (n_out > 64) return b128 >= 512 ? 128 : 64;

@@ -934,8 +934,7 @@ bool viai_bf3_frag_layout(long M, int n_out) { return viai_igemm_tile_m(M, n_out
 // The split-K kernel takes the layers whose 64 x 64 tiling would leave most CUs idle.
 bool viai_bf3_sk_ok(long M, int n_out, int C1, int C2) {
     if ((C1 + C2) % 16 != 0 || (C2 > 0 && C1 % 64 != 0)) return false;
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("VIAI_BF3_SK"); mode = e ? atoi(e) : 1; }
+    constexpr int mode = 1;
     if (!mode) return false;
     long b64 = ((M + 63) / 64) * ((n_out + 63) / 64);
     return n_out > 32 && b64 < 512;
@@ -961,8 +960,7 @@ int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
         if (viai_conv_halo_wide_ok(a)) return viai_conv_halo_wide_launch(a, st);   // stride-1 3 x 3: patch staged once per chunk, not once per tap
         // 128 x 256 tile (eight waves) where the layer is wide and tall enough: every staged activation row then feeds 256
         // output channels, halving the load / split / LDS-store work per MFMA
-        static int wn4 = -1;
-        if (wn4 < 0) { const char* e = getenv("VIAI_F16_WN4"); wn4 = e ? atoi(e) : 1; }
+        constexpr int wn4 = 1;
         if (wn4 && a.Cout % 256 == 0 && ((a.M + 127) / 128) * (a.Cout / 256) >= 256) {
             return launch_bf3<true, 2, 2, 2, 4, 2>(a, st);
         }

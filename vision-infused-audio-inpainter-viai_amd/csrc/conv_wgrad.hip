@@ -344,8 +344,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
 
 // layers the all-taps 32-channel kernel takes
 bool viai_wgrad32_ok(const ConvGeom& g, int Cout, int C1, int C2) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VIAI_WGRAD32"); on = e ? atoi(e) : 1; }
+    constexpr int on = 1;
     if (!on || C2 != 0 || Cout > 32 || C1 > 32 || Cout % 4 != 0 || C1 % 4 != 0 || g.run) return false;
     if (g.mx != 1 || g.my != 1 || g.ly != 1 || g.lx != 1 || g.SH != g.OH || g.SW != g.OW || g.OW % 32 != 0 || g.ntaps < 1 || g.ntaps > 9) return false;
     int y0 = g.dy[0], y1 = g.dy[0], x0 = g.dx[0], x1 = g.dx[0];
@@ -362,8 +361,7 @@ bool viai_wgrad32_ok(const ConvGeom& g, int Cout, int C1, int C2) {
 int viai_wgrad32_ksplit(long M) {
     long chunks = M / 32;
     long ks = chunks / 4;                  // >= 4 chunks per block
-    static long cap = 0;
-    if (!cap) { const char* e = getenv("VIAI_WGRAD32_BLOCKS"); cap = e ? atol(e) : 256; if (cap < 1) cap = 256; }
+    constexpr long cap = 256;
     if (ks > cap) ks = cap;
     if (ks < 1) ks = 1;
     return (int)ks;
@@ -402,8 +400,7 @@ int viai_wgrad_pick_ksplit(int Cout, int Cin, int ntaps, long M) {
     // blocks per launch: one round of 2 blocks/CU x 256 CUs.  The weight gradients run on a side stream next to the
     // main backward chain, so a second round buys nothing and every extra K slab costs reduce traffic (measured:
     // 512 beats 1024 by 1 %, 256 loses 4 %).
-    static long target = -1;
-    if (target < 0) { const char* e = getenv("VIAI_WGRAD_BLOCKS"); target = e ? atol(e) : 512; if (target < 64) target = 64; }
+    constexpr long target = 512;
     long ks = target / tiles;
     long maxks = chunks / 8; if (maxks < 1) maxks = 1;  // at least 8 chunks (256 pixels) per block
     if (ks > maxks) ks = maxks;

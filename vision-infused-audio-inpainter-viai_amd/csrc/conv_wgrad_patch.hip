@@ -376,10 +376,7 @@ static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hi
 static int block_ksplit(const ConvGeom& g, int Cout, int Cin, int cfg) {
     const long tiles = (long)g.N * ((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW);
     const long per = (long)(Cout / bm_of(cfg)) * (Cin / bn_of(cfg));
-    static long blk1 = -1, blk2 = -1, blk3 = -1;
-    if (blk1 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS"); blk1 = e ? atol(e) : 192; }
-    if (blk2 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_S2"); blk2 = e ? atol(e) : 192; }
-    if (blk3 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_NARROW"); blk3 = e ? atol(e) : 128; }
+    constexpr long blk1 = 192, blk2 = 192, blk3 = 128;       // stride-1 / stride-2 / narrow instance (measured optimum of the three-stream step, see below)
     long ks = (cfg == 2 ? blk2 : cfg == 3 ? blk3 : blk1) / per;
     // the sub-CU grids above suit the audio step, whose weight gradients are short and share the chip with the main chain; a layer with
     // hundreds of tiles per block (the ResNet branch on 1024 frames) is worth every CU

@@ -145,6 +145,9 @@ class FusedAdam:
         self.state.copy_(torch.tensor([step, self.lr, self.betas[0] ** step, self.betas[1] ** step], dtype=torch.float64))
 
 
+_PARKED_PLANS = []      # launch plans of models that were collected while a stream capture was in progress (see AudioModel.close)
+
+
 def make_time_mask(batch, frames, blank_length, generator=None, device="cpu"):
     """One full-height time gap [t0, t0+L) per clip (misc/pipeline2.png); t0 ~ U{T/8 .. 5T/8}."""
     lo, hi = frames // 8, (5 * frames) // 8
@@ -409,11 +412,25 @@ class AudioModel:
             ops.drop_scratch()            # scratch buffers allocated while capturing live in the dead graphs' private memory pool
 
     def close(self):
-        """release what the launch plans / captured graphs hold (events, plan nodes, the graphs' memory pool); also runs from __del__"""
+        """release what the launch plans hold (events, plan nodes).  Also runs from __del__, i.e. whenever the garbage collector gets
+        to a dropped model -- possibly in the middle of ANOTHER model's stream capture, where a device synchronisation would invalidate
+        that capture: plans are then parked and destroyed at the next close() outside a capture.  The process-wide scratch pool is
+        not touched from here (buffers a capture of THIS model allocated live in self._graph_scratch and go with the object)."""
+        plans, self._plans = (self._plans or []), None
+        self._graphs = None
+        self._graph_scratch = None
+        if not plans and not _PARKED_PLANS:
+            return
         try:
-            self._drop_graphs()
+            if torch.cuda.is_current_stream_capturing():
+                _PARKED_PLANS.extend(plans)
+                return
+            torch.cuda.synchronize(self.device)         # a plan's events / kernel nodes must not be destroyed while a replay is in flight
+            for p in plans + _PARKED_PLANS:
+                lib().viai_plan_destroy(p)
+            del _PARKED_PLANS[:]
         except Exception:
-            pass
+            pass                                        # interpreter shutdown: the driver is gone, nothing left to release
 
     def __del__(self):
         self.close()
@@ -584,13 +601,20 @@ class AudioModel:
         graphs, plans = [], []
         pool = None
         before = ops.scratch_snapshot()
+        # torch hands out streams from a pool of 32 per device, round robin, and torch.cuda.graph's default capture stream is one pool
+        # stream made once per process: in a long-lived process it can be the very stream this model got as a side stream, and the
+        # captured branch would collapse into the origin.  Capture on a stream known to differ from both side streams.
+        taken = {st.cuda_stream for st in (self._wgrad_stream, self._dreal_stream) if st is not None}
+        cap = torch.cuda.Stream(device=self.device)
+        while cap.cuda_stream in taken:
+            cap = torch.cuda.Stream(device=self.device)
         for f in segs:
             if self.use_plan:
                 # the capture is a recorder: the hipGraph is kept (it owns the kernel-argument arrays) but never instantiated
                 g = torch.cuda.CUDAGraph(keep_graph=True)
                 check(lib().viai_plan_log_begin(), "viai_plan_log_begin")
                 try:
-                    with torch.cuda.graph(g, pool=pool):
+                    with torch.cuda.graph(g, pool=pool, stream=cap):
                         origin = torch.cuda.current_stream().cuda_stream
                         f()
                 finally:
@@ -600,7 +624,7 @@ class AudioModel:
                 plans.append(plan)
             else:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, stream=cap):
                     f()
             pool = g.pool()
             graphs.append(g)
