@@ -340,6 +340,27 @@ int viai_mel_denorm_amp(const float* S, float* out, long n, float min_level_db, 
 int viai_l2_ranks(const float* clips, const float* captions, int n_clips, int n_captions, int dim,
                   int* ranks, int* top1, float* dist, void* stream);
 
+/* Fused pair: (conv + BatchNorm + activation) -> (3 x 3, stride 1, pad 1 conv or stride-1 transposed conv with ONE output channel).
+ * Reference pairs: G.conv6_1 + conv6_1_bn + ReLU -> conv6_2 (New_Inpainting_Networks.py:85-88, 134 MB per tensor at the benchmark size)
+ * and D.conv3 + norm3 + LeakyReLU -> conv4 (Discriminator_Networks.py:44-49).  Neither the front layer's post-activation tensor z nor the
+ * Cout = 1 layer's data gradient dz is ever stored: the Cout = 1 kernels read the front layer's PRE-BatchNorm output y and apply
+ * z = act_in(scale * y + shift) on load; the BatchNorm backward forms dz = conv_backward_data(du, w) -- nine float4 FMAs per element from
+ * a register window of the one-channel du -- instead of reading it back twice.  `c` describes the Cout = 1 layer (C1 = the front layer's
+ * channels: 32 .. 512, width a multiple of 16); wp = its packed image (viai_conv2d_pack_fwd); du = gradient of its PRE-activation output.
+ *   fwd:    out = act(conv(z, w) + bias)
+ *   wgrad:  dw (+)= conv_backward_weight(z, du);  ws: viai_conv2d_wgrad_ws_bytes(c)
+ *   bn_bwd: the front layer's BatchNorm + activation backward (viai_bn_act_bwd_amax semantics: sums = {k0, k1}, dgamma, dbeta, dy, max |dy|);
+ *           part: 2 * C1 * viai_pair_cout1_bn_bwd_blocks(c) floats                                                                          */
+int viai_pair_cout1_ok(const viai_conv2d* c);
+int viai_pair_cout1_bn_bwd_blocks(const viai_conv2d* c);
+int viai_pair_cout1_fwd(const viai_conv2d* c, const float* y, const float* scale, const float* shift, int act_in,
+                        const float* wp, const float* bias, float* out, int act, void* stream);
+int viai_pair_cout1_wgrad(const viai_conv2d* c, const float* y, const float* scale, const float* shift, int act_in,
+                          const float* du, float* ws, float* dw, int accumulate, void* stream);
+int viai_pair_cout1_bn_bwd(const viai_conv2d* c, const float* du, const float* wp, const float* y, const float* mean,
+                           const float* invstd, const float* scale, const float* shift, int act_in, float* part, float* sums,
+                           float* dgamma, float* dbeta, float* dy, int training, float* dy_amax, void* stream);
+
 /* -------------------------------------------------- fused Cin = 1 conv + BatchNorm2d(train) + activation layer (ABI v5)
  * MelEncoder.conv1 + bn1 + LeakyReLU (Inpainting_Networks.py:55,71) and MelDiscriminator's first block (Discriminator_Networks.py:17-19,
  * 38-39): with 4 .. 9 taps and one input channel the convolution is cheaper to RECOMPUTE than its 32 / 64-channel output is to write

@@ -698,3 +698,70 @@ def test_f16x2_range_guard_counts_saturating_operands():
     finally:
         ops.DEBUG_RANGE, ops.DEBUG_RANGE_STRICT = old, olds
         ops.range_report()
+
+
+@pytest.mark.parametrize("case", ["G.conv6", "D.conv3-4", "D.eval", "wide-frozen"])
+def test_fused_bn_cout1_pair_matches_the_two_layers(case):
+    """(conv + BatchNorm + act) -> (3 x 3 conv to ONE channel) as one op (ops.conv_bn_act_cout1: the tensor between the layers and the
+    second layer's data gradient are never stored; csrc/conv_direct.hip viai_pair_cout1_*) against the same two layers run one after the
+    other AND against torch in fp64: G.conv6_1 + BN + ReLU -> conv6_2 + Sigmoid (transposed convs, 32 channels, biases;
+    New_Inpainting_Networks.py:85-88), D.conv3 + BN + LeakyReLU -> conv4 + Sigmoid (512 channels; Discriminator_Networks.py:44-49),
+    eval-mode BatchNorm, and a frozen pair (data gradient only: the G step's pass through D)."""
+    from viai_amd import networks as N_, ops
+    tr = case == "G.conv6"
+    N, Ci, Cm, H, W = {"G.conv6": (2, 32, 32, 32, 64), "D.conv3-4": (2, 64, 512, 16, 32), "D.eval": (2, 32, 64, 8, 16),
+                       "wide-frozen": (3, 128, 256, 8, 48)}[case]
+    act = ops.ACT_RELU if tr else ops.ACT_LRELU
+    mk = (lambda ci, co: torch.nn.ConvTranspose2d(ci, co, 3, 1, 1, bias=True)) if tr else (lambda ci, co: torch.nn.Conv2d(ci, co, 3, 1, 1, bias=False))
+    conv1, conv2, bn = mk(Ci, Cm).cuda(), mk(Cm, 1).cuda(), torch.nn.BatchNorm2d(Cm).cuda()
+    with torch.no_grad():
+        conv1.weight.copy_(O.cf_std("pair.w1." + case, tuple(conv1.weight.shape), 0.08))
+        conv2.weight.copy_(O.cf_std("pair.w2." + case, tuple(conv2.weight.shape), 0.1))
+        bn.weight.copy_(O.cf_uniform("pair.g." + case, (Cm,), 0.7, 1.3)); bn.bias.copy_(O.cf_uniform("pair.b." + case, (Cm,), -0.2, 0.2))
+        bn.running_mean.copy_(O.cf_uniform("pair.rm." + case, (Cm,), -0.1, 0.1)); bn.running_var.copy_(O.cf_uniform("pair.rv." + case, (Cm,), 0.5, 1.5))
+        if tr:
+            conv1.bias.copy_(O.cf_uniform("pair.b1", (Cm,), -0.1, 0.1)); conv2.bias.copy_(O.cf_uniform("pair.b2", (1,), -0.1, 0.1))
+    if case == "D.eval":
+        bn.eval()
+    if case == "wide-frozen":
+        for m in (conv1, conv2, bn):
+            m.requires_grad_(False)
+    x = O.cf_uniform("pair.x." + case, (N, Ci, H, W), -1, 1)
+    gp = O.cf_uniform("pair.gp." + case, (N, 1, H, W), -1, 1)
+    params = [p for p in list(conv1.parameters()) + list(bn.parameters()) + list(conv2.parameters()) if p.requires_grad]
+
+    def run(fused):
+        bn_state = {k: v.clone() for k, v in bn.state_dict().items()}
+        for p in params:
+            p.grad = None
+        xg = nhwc(x).requires_grad_(True)
+        old, ops.PAIR_FUSED = ops.PAIR_FUSED, fused
+        try:
+            p_ = N_.fused_pair(xg, conv1, bn, act, conv2, ops.ACT_SIGMOID)
+        finally:
+            ops.PAIR_FUSED = old
+        p_.backward(nhwc(gp))
+        out = [p_.detach().clone(), xg.grad.clone()] + [q.grad.clone() for q in params] + [bn.running_mean.clone(), bn.running_var.clone()]
+        bn.load_state_dict(bn_state)
+        return out
+    calls = []
+    lib = ops._lib.load()
+    orig = lib.viai_pair_cout1_bn_bwd
+    try:
+        lib.viai_pair_cout1_bn_bwd = lambda *a: (calls.append(1), orig(*a))[1]
+        fused = run(True)
+    finally:
+        lib.viai_pair_cout1_bn_bwd = orig
+    assert calls == [1]                                   # the pair kernels really ran
+    plain = run(False)
+    assert len(fused) == len(plain)
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        assert relerr(a, b) < 2e-5, (case, i, relerr(a, b))
+    # fp64 truth
+    c1, c2, b64 = [m_.double().cpu() for m_ in (conv1, conv2, bn)]
+    x64 = x.double().requires_grad_(True)
+    z = torch.nn.functional.leaky_relu(b64(c1(x64)), 0.2) if not tr else torch.relu(b64(c1(x64)))
+    p64 = torch.sigmoid(c2(z))
+    p64.backward(gp.double())
+    assert relerr(nchw(fused[0]), p64) < 1e-5 and relerr(nchw(fused[1]), x64.grad) < 5e-5
+    conv1.float().cuda(); conv2.float().cuda(); bn.float().cuda()

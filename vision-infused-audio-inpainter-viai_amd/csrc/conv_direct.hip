@@ -23,6 +23,12 @@ struct DirectArgs {
     const float* scale; const float* shift; const float* mean; const float* invstd; const float* sums; const float* dz;
     float* part;
     float* zmax;                      // fused layer, apply pass: max |z| (operand scale of the f16x2 kernels that consume z), or null
+    // fused (conv + BatchNorm + activation) -> (Cout = 1 conv) pair (viai_pair_cout1_*): the Cout = 1 layer reads the PRE-BatchNorm tensor
+    // y of the layer in front of it and applies z = act_in(scale * y + shift) on load; its data gradient dz is never stored either, the
+    // BatchNorm backward forms it from du (the gradient of the Cout = 1 layer's pre-activation output) with the nine taps in registers
+    int act_in;
+    const float* k_sums;              // {k0, k1} of bn_bwd_final (apply pass)
+    float* amax;                      // apply pass: max |dy|
     // block = whole output rows of one image (host-checked): the block's input rows are staged in LDS once (xrows x xpitch floats)
     int xfast, xrows, xpitch, rows_blk;
 };
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(256) void cout1_fwd_kernel(const DirectArgs a) {
 // Row-run form for 3 x 3 / pad 1 (output width a multiple of L): a lane group computes L consecutive output pixels of one row from
 // the (L + 2) x 3 input vectors it fetches up front (all loads in flight at once), so every input vector is fetched
 // 3 (L + 2) / L times instead of nine, and the pixel index is decoded once per run.  FWD: tap offsets ascend with the tap index (Conv2d).
-template <int LPP, int CPL, int L, bool FWD>
+template <int LPP, int CPL, int L, bool FWD, bool BN = false>
 __global__ __launch_bounds__(256) void cout1_fwd_run_kernel(const DirectArgs a) {
     constexpr int KH = 3, KW = 3;
     const int cl = threadIdx.x % LPP;
@@ -501,6 +507,14 @@ __global__ __launch_bounds__(256) void cout1_fwd_run_kernel(const DirectArgs a) 
     for (int t = 0; t < KH * KW; ++t)
 #pragma unroll
         for (int c = 0; c < CPL; ++c) wv[t][c] = *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.Cin + (c * LPP + cl) * 4);
+    f32x4 bsc[CPL], bsh[CPL];                                       // BN: the input is act_in(scale * x + shift), zero outside the image
+    if constexpr (BN) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            bsc[c] = *reinterpret_cast<const f32x4*>(a.scale + (c * LPP + cl) * 4);
+            bsh[c] = *reinterpret_cast<const f32x4*>(a.shift + (c * LPP + cl) * 4);
+        }
+    }
     const float bias = a.bias ? a.bias[0] : 0.f;
     constexpr int GPB = 256 / LPP;                                  // lane groups (= runs in flight) per block
     const int rpr = a.OW / L, nruns = a.N * a.OH * rpr;
@@ -520,7 +534,11 @@ __global__ __launch_bounds__(256) void cout1_fwd_run_kernel(const DirectArgs a) 
             for (int r = 0; r < KH; ++r)
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(rowp[r] + (size_t)(cok ? ix : 0) * a.Cin + c * LPP * 4);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(rowp[r] + (size_t)(cok ? ix : 0) * a.Cin + c * LPP * 4);
+                    if constexpr (BN) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = viai_act(v[e] * bsc[c][e] + bsh[c][e], a.act_in, a.slope);
+                    }
                     col[r][c] = (cok & rowok[r]) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
         };
@@ -667,13 +685,15 @@ __global__ __launch_bounds__(256) void cout1_wgrad_kernel(const DirectArgs a, in
 // issued 10 vector-memory instructions and ~100 index instructions per KB of x: 322 us on the 16 x 256 x 256 x 32 layer whose
 // 134 MB stream in 27 us).  Thread (cg, pg) takes runs base + pg + PG * i; partial sums as above.
 // FWD: tap offsets ascend with s (Conv2d); otherwise they descend (ConvTranspose2d) -- keeps every window index a constant
-template <int KH, int KW, int L, bool FWD>
+template <int KH, int KW, int L, bool FWD, bool BN = false>
 __global__ __launch_bounds__(256) void cout1_wgrad_run_kernel(const DirectArgs a, int runs_per_lane) {
     constexpr int T = KH * KW, WN_ = L + KW - 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [PG][T][Cin]
     const int CG = a.Cin / 4;
     const int PG = 256 / CG;
     const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
+    f32x4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BN) { bsc = *reinterpret_cast<const f32x4*>(a.scale + cg * 4); bsh = *reinterpret_cast<const f32x4*>(a.shift + cg * 4); }
     f32x4 acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -708,6 +728,12 @@ __global__ __launch_bounds__(256) void cout1_wgrad_run_kernel(const DirectArgs a
             f32x4 xv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) xv[u] = xp[(size_t)(p0 + u) * CG];
+            if constexpr (BN) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[u][e] = viai_act(xv[u][e] * bsc[e] + bsh[e], a.act_in, a.slope);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -728,6 +754,103 @@ __global__ __launch_bounds__(256) void cout1_wgrad_run_kernel(const DirectArgs a
         float s = 0.f;
         for (int k = 0; k < PG; ++k) s += smem[(size_t)k * T * a.Cin + i];
         a.ws[(size_t)blockIdx.x * T * a.Cin + i] = s;
+    }
+}
+
+__device__ __forceinline__ float pair_act_grad(float pre, int act, float slope) {
+    if (act == VIAI_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
+    if (act == VIAI_ACT_LRELU) return pre > 0.f ? 1.f : slope;
+    if (act == VIAI_ACT_SIGMOID) { float s = 1.f / (1.f + __expf(-pre)); return s * (1.f - s); }
+    return 1.f;
+}
+
+// BatchNorm + activation backward of the layer in FRONT of a Cout = 1 3 x 3 conv, with that conv's data gradient formed on the fly:
+// dz[q][c] = sum_t du[o_t(q)] * w[t][c] is nine float4 FMAs from an (L + 2) x 3 register window of the one-channel du -- cheaper than
+// the 4 bytes per element it costs to write dz and the 8 to read it back twice (G.conv6_1 -> conv6_2: 3 x 134 MB per step; D.conv3 ->
+// conv4: 3 x 67 MB per D pass).  Thread = (run lane, channel quad), runs of L consecutive pixels of one row as in the kernels above.
+//   APPLY = false: partial sums part[blk][0][c] = sum dp, part[blk][1][c] = sum dp * xhat  (-> bn_bwd_final_kernel, bn.hip)
+//   APPLY = true : dy = scale * dp + k1 * (y - mean) + k0, and max |dy|
+// a.x = y (pre-BatchNorm tensor of the front layer), a.dy = du, a.w = the Cout = 1 layer's [tap][channel] weight image.
+template <int L, bool FWD, bool APPLY>
+__global__ __launch_bounds__(256) void cout1_bn_bwd_rows_kernel(const DirectArgs a, int R) {
+    constexpr int KH = 3, KW = 3, WN_ = L + KW - 1;
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // du rows r0 - 1 .. r0 + R, columns -1 .. IW (zeros outside the image)
+    __shared__ f32x4 r1[256], r2[256];
+    const int CG = a.Cin / 4;               // divides 256
+    const int PG = 256 / CG;
+    const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
+    const int bpi = a.IH / R;
+    const int n = blockIdx.x / bpi, r0 = (blockIdx.x - n * bpi) * R;
+    const int pitch = a.IW + 2;
+    for (int idx = tid; idx < (R + 2) * pitch; idx += 256) {
+        const int rr = idx / pitch, cc = idx - rr * pitch;
+        const int oy = r0 - 1 + rr, ox = cc - 1;
+        tile[idx] = ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW) ? a.dy[(size_t)(n * a.OH + oy) * a.OW + ox] : 0.f;
+    }
+    f32x4 wv[KH * KW];
+#pragma unroll
+    for (int t = 0; t < KH * KW; ++t) wv[t] = *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.Cin + cg * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + cg * 4), sh = *reinterpret_cast<const f32x4*>(a.shift + cg * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + cg * 4);
+    f32x4 is = {0.f, 0.f, 0.f, 0.f}, k0 = is, k1 = is;
+    if constexpr (APPLY) { k0 = *reinterpret_cast<const f32x4*>(a.k_sums + cg * 4); k1 = *reinterpret_cast<const f32x4*>(a.k_sums + a.Cin + cg * 4); }
+    else is = *reinterpret_cast<const f32x4*>(a.invstd + cg * 4);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    float mx = 0.f;
+    __syncthreads();
+    const int rpr = a.IW / L;
+    for (int run = pg; run < R * rpr; run += PG) {
+        const int rrow = run / rpr, ix0 = (run - rrow * rpr) * L;
+        float win[KH][WN_];                                         // win[r][j] = du(iy - tap_dy(r), ix0 - 1 + j); one value per VGPR (see cin1_lds_taps)
+#pragma unroll
+        for (int r = 0; r < KH; ++r)
+#pragma unroll
+            for (int j = 0; j < WN_; ++j) {
+                win[r][j] = tile[(rrow + 1 - tap_dy(a, r)) * pitch + ix0 + j];
+                asm volatile("" : "+v"(win[r][j]));
+            }
+        const size_t base = ((size_t)(n * a.IH + r0 + rrow) * a.IW + ix0) * CG + cg;
+        const f32x4* yp = reinterpret_cast<const f32x4*>(a.x) + base;
+        f32x4* dst = reinterpret_cast<f32x4*>(a.dx) + base;
+#pragma unroll
+        for (int p0 = 0; p0 < L; p0 += 4) {
+            f32x4 yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) yv[u] = yp[(size_t)(p0 + u) * CG];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < KH; ++r)
+#pragma unroll
+                    for (int s_ = 0; s_ < KW; ++s_) dz += wv[r * KW + s_] * win[r][(p0 + u) + (FWD ? (KW - 1 - s_) : s_)];
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dp = dz[e] * pair_act_grad(yv[u][e] * sc[e] + sh[e], a.act_in, a.slope);
+                    if constexpr (APPLY) {
+                        o[e] = sc[e] * dp + (k1[e] * (yv[u][e] - mu[e]) + k0[e]);
+                        mx = fmaxf(mx, fabsf(o[e]));
+                    } else {
+                        s1[e] += dp;
+                        s2[e] += dp * (yv[u][e] - mu[e]) * is[e];
+                    }
+                }
+                if constexpr (APPLY) dst[(size_t)(p0 + u) * CG] = o;
+            }
+        }
+    }
+    if constexpr (APPLY) {
+        if (a.amax != nullptr) block_absmax_to(a.amax, mx);
+    } else {
+        r1[tid] = s1; r2[tid] = s2;
+        __syncthreads();
+        if (tid < CG) {
+            f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < PG; ++k) { t1 += r1[k * CG + tid]; t2 += r2[k * CG + tid]; }
+            *reinterpret_cast<f32x4*>(a.part + ((size_t)blockIdx.x * 2 + 0) * a.Cin + tid * 4) = t1;
+            *reinterpret_cast<f32x4*>(a.part + ((size_t)blockIdx.x * 2 + 1) * a.Cin + tid * 4) = t2;
+        }
     }
 }
 
@@ -1182,6 +1305,98 @@ int viai_cout1_wgrad(const viai_conv2d* c, const float* x, const float* dy, floa
     if (e) return e;
     // conv [1][Cin][kh][kw] and convT [Cin][1][kh][kw] both flatten to ci*T + t
     return viai_wgrad_reduce(ws, dw, nb, T, 1, a.Cin, (long)a.Cin * T, T, accumulate, st);
+}
+
+// ---- fused (conv + BatchNorm + activation) -> (3 x 3 stride-1 pad-1 conv with ONE output channel) pair ----------------------------
+// c2 describes the Cout = 1 layer (C1 = the front layer's channel count).  The front layer's post-activation tensor z is never stored:
+// these entry points read its pre-BatchNorm output y with (scale, shift, act_in) applied on load, and the BatchNorm backward forms the
+// Cout = 1 layer's data gradient in registers (kernels above).  Reference layer pairs: G.conv6_1 + conv6_1_bn + ReLU -> conv6_2
+// (New_Inpainting_Networks.py:85-88), D.conv3 + norm3 + LeakyReLU -> conv4 (Discriminator_Networks.py:44-49).
+static int pair_rows(const DirectArgs& a) {       // rows of du staged per block of the BatchNorm-backward kernels
+    int R = 4;
+    while (R > 1 && (a.IH % R != 0 || (long)a.N * (a.IH / R) < 512)) R >>= 1;
+    return a.IH % R == 0 ? R : 1;
+}
+extern "C" int viai_pair_cout1_ok(const viai_conv2d* c) {
+    if (!c || c->Cout != 1 || c->C2 != 0 || c->kh != 3 || c->kw != 3 || c->sh != 1 || c->sw != 1 || c->ph != 1 || c->pw != 1) return 0;
+    if (c->dh > 1 || c->dw > 1 || c->ph2 >= 0 || c->pw2 >= 0) return 0;
+    if (!(c->C1 == 32 || c->C1 == 64 || c->C1 == 128 || c->C1 == 256 || c->C1 == 512)) return 0;
+    if (c->IW % 16 != 0 || c->IW + 2 > 4096) return 0;
+    return 1;
+}
+extern "C" int viai_pair_cout1_bn_bwd_blocks(const viai_conv2d* c) {
+    if (!viai_pair_cout1_ok(c)) return 0;
+    DirectArgs a = make_args(c);
+    return a.N * (a.IH / pair_rows(a));
+}
+extern "C" int viai_pair_cout1_fwd(const viai_conv2d* c, const float* y, const float* scale, const float* shift, int act_in,
+                                   const float* wp, const float* bias, float* out, int act, void* stream) {
+    if (!viai_pair_cout1_ok(c)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    DirectArgs a = make_args(c);
+    a.x = y; a.w = wp; a.bias = bias; a.y = out; a.act = act; a.slope = 0.2f; a.scale = scale; a.shift = shift; a.act_in = act_in;
+    const int cin = a.Cin;
+    const int lpp = cin >= 256 ? 64 : cin / 4;
+    const int L = cin == 512 ? 2 : 4;
+    long nb2 = ((long)a.N * a.OH * (a.OW / L) * lpp + 255) / 256;
+    if (nb2 > 8192) nb2 = 8192;
+    const dim3 g2((unsigned)nb2), b2(256);
+    viai_tag_reset();
+    viai_tag_kernel("direct");
+#define RUN(LPP_, CPL_, L_)                                                                                                    \
+    do { if (a.transposed) VIAI_LAUNCH((cout1_fwd_run_kernel<LPP_, CPL_, L_, false, true>), g2, b2, 0, st, a);                 \
+         else VIAI_LAUNCH((cout1_fwd_run_kernel<LPP_, CPL_, L_, true, true>), g2, b2, 0, st, a); } while (0)
+    if (cin == 32) RUN(8, 1, 4); else if (cin == 64) RUN(16, 1, 4); else if (cin == 128) RUN(32, 1, 4);
+    else if (cin == 256) RUN(64, 1, 4); else RUN(64, 2, 2);
+#undef RUN
+    return viai_launch_status();
+}
+// dw (+)= weight gradient of the Cout = 1 layer from du and z = act_in(scale * y + shift) formed on load; ws: viai_conv2d_wgrad_ws_bytes(c)
+extern "C" int viai_pair_cout1_wgrad(const viai_conv2d* c, const float* y, const float* scale, const float* shift, int act_in,
+                                     const float* du, float* ws, float* dw, int accumulate, void* stream) {
+    if (!viai_pair_cout1_ok(c)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    DirectArgs a = make_args(c);
+    a.x = y; a.dy = du; a.ws = ws; a.scale = scale; a.shift = shift; a.act_in = act_in; a.slope = 0.2f;
+    constexpr int T = 9, L = 16;
+    const long q = (long)a.N * a.IH * a.IW;
+    const int nb = direct_wgrad_blocks(q);
+    const int pg = 256 / (a.Cin / 4);
+    const size_t lds = (size_t)pg * T * a.Cin * sizeof(float);
+    const long nruns = (long)a.N * a.IH * (a.IW / L);
+    const int rpl = (int)((nruns + (long)nb * pg - 1) / ((long)nb * pg));
+    viai_tag_reset();
+    viai_tag_kernel("direct");
+    if (a.transposed) VIAI_LAUNCH((cout1_wgrad_run_kernel<3, 3, L, false, true>), dim3(nb), dim3(256), lds, st, a, rpl);
+    else VIAI_LAUNCH((cout1_wgrad_run_kernel<3, 3, L, true, true>), dim3(nb), dim3(256), lds, st, a, rpl);
+    int e = viai_launch_status();
+    if (e) return e;
+    return viai_wgrad_reduce(ws, dw, nb, T, 1, a.Cin, (long)a.Cin * T, T, accumulate, st);
+}
+// BatchNorm + activation backward of the front layer from du (N, H, W, 1) -- the gradient of the Cout = 1 layer's PRE-activation output:
+// part: 2 * C * viai_pair_cout1_bn_bwd_blocks(c) floats; sums / dgamma / dbeta / training / dy_amax as in viai_bn_act_bwd_amax;
+// dy (optional) = the gradient of the front layer's conv output.
+extern "C" int viai_pair_cout1_bn_bwd(const viai_conv2d* c, const float* du, const float* wp, const float* y, const float* mean,
+                                      const float* invstd, const float* scale, const float* shift, int act_in, float* part, float* sums,
+                                      float* dgamma, float* dbeta, float* dy, int training, float* dy_amax, void* stream) {
+    if (!viai_pair_cout1_ok(c)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    DirectArgs a = make_args(c);
+    a.x = y; a.dy = du; a.w = wp; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.act_in = act_in; a.slope = 0.2f;
+    a.part = part; a.k_sums = sums; a.dx = dy; a.amax = dy_amax;
+    const int R = pair_rows(a);
+    const int nb = a.N * (a.IH / R);
+    const size_t lds = (size_t)(R + 2) * (a.IW + 2) * sizeof(float);
+    constexpr int L = 8;
+    if (a.transposed) VIAI_LAUNCH((cout1_bn_bwd_rows_kernel<L, false, false>), dim3(nb), dim3(256), lds, st, a, R);
+    else VIAI_LAUNCH((cout1_bn_bwd_rows_kernel<L, true, false>), dim3(nb), dim3(256), lds, st, a, R);
+    int e = viai_launch_status();
+    if (e) return e;
+    e = viai_bn_bwd_final_launch(part, nb, a.Cin, (long)a.N * a.IH * a.IW, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, st);
+    if (e || dy == nullptr) return e;
+    if (a.transposed) VIAI_LAUNCH((cout1_bn_bwd_rows_kernel<L, false, true>), dim3(nb), dim3(256), lds, st, a, R);
+    else VIAI_LAUNCH((cout1_bn_bwd_rows_kernel<L, true, true>), dim3(nb), dim3(256), lds, st, a, R);
+    return viai_launch_status();
 }
 
 extern "C" int viai_colsum_blocks(long M, int C) {

@@ -103,6 +103,22 @@ def fused_layer(x, conv, bn, act, x2=None, training=True):
                            training=(bn.training if bn is not None else training))
 
 
+def fused_pair(x, conv, bn, act, conv2, act2, x2=None):
+    """conv -> bn -> act -> conv2 (one output channel) -> act2.  Where the pair kernels apply (BatchNorm, conv2 3 x 3 / stride 1 / pad 1,
+    width a multiple of 16: G.conv6_1 -> conv6_2 and D.conv3 -> conv4 at every shape the step runs) neither the tensor between the two
+    layers nor conv2's data gradient is ever stored (ops.conv_bn_act_cout1); otherwise two fused layers."""
+    tr, tr2 = isinstance(conv, nn.ConvTranspose2d), isinstance(conv2, nn.ConvTranspose2d)
+    if (isinstance(bn, nn.modules.batchnorm._BatchNorm) and conv2.out_channels == 1 and (not tr or _pair(conv.stride) == (1, 1))
+            and _pair(conv2.dilation) == (1, 1) and _pair(conv.dilation) == (1, 1) and getattr(conv2, "groups", 1) == 1
+            and ops.conv_bn_act_cout1_ok(x, conv.weight, bn, conv2.weight, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
+                                         padding=_pair(conv.padding), transposed=tr, kernel2=_pair(conv2.kernel_size),
+                                         stride2=_pair(conv2.stride), padding2=_pair(conv2.padding), x2=x2)):
+        return ops.conv_bn_act_cout1(x, conv.weight, conv.bias, bn, conv2.weight, conv2.bias, kernel=_pair(conv.kernel_size),
+                                     stride=_pair(conv.stride), padding=_pair(conv.padding), transposed=tr, act=act, transposed2=tr2,
+                                     act2=act2, x2=x2, training=bn.training)
+    return fused_layer(fused_layer(x, conv, bn, act, x2=x2), conv2, None, act2)
+
+
 class TransConvBlock(nn.Module):
     """`nums` x [ConvTranspose2d 3x3 s1 p1 (no bias) -> BN -> ReLU]; sub-module names
     conv{name}_{i}, conv{name}_{i}_bn (New_Inpainting_Networks.py:12-45)."""
@@ -223,8 +239,7 @@ class MelDecoder(nn.Module):
             skip = net[-(i + 1)] if i == self.skip_at else None     # virtual concat: two source pointers
             out = self._modules["convblock%d" % (i + 1)].forward_nhwc(out, skip)
         out = ops.bilinear_ac(out, out_hw)
-        out = fused_layer(out, self.conv6_1, self.conv6_1_bn, ACT_RELU)
-        return fused_layer(out, self.conv6_2, None, ACT_SIGMOID)
+        return fused_pair(out, self.conv6_1, self.conv6_1_bn, ACT_RELU, self.conv6_2, ACT_SIGMOID)
 
     def forward(self, net, x_size):
         net = [to_nhwc(t) for t in net]
@@ -322,8 +337,7 @@ class MelDiscriminator(nn.Module):
         net = fused_layer(x, self.conv1, self.bn1, ACT_LRELU)
         for n in range(1, self.n_layers):
             net = fused_layer(net, self._modules["conv2_%d" % n], self._modules["norm_%d" % n], ACT_LRELU)
-        net = fused_layer(net, self.conv3, self.norm3, ACT_LRELU)
-        return fused_layer(net, self.conv4, None, ACT_SIGMOID if self.use_sigmoid else ACT_NONE)
+        return fused_pair(net, self.conv3, self.norm3, ACT_LRELU, self.conv4, ACT_SIGMOID if self.use_sigmoid else ACT_NONE)
 
     def forward(self, input):
         return to_nchw_view(self.forward_nhwc(to_nhwc(input)))

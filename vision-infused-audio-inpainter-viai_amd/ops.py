@@ -364,6 +364,85 @@ def conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed, dh=1,
     return d
 
 
+def _conv_grads(lib, d, cfg, dims, has_bn, has_bias, needs, xa, x, x2, weight, dy, amax, st):
+    """weight / bias / data gradients of one conv layer from dy (the gradient of its output): the tail every fused layer's backward
+    shares.  needs = (need_x, need_x2, need_w, need_b); returns (dx, dx2, dw, db) with None where the gradient went into the arena."""
+    N, IH, IW, C1, C2, Cout, OH, OW = dims
+    M = N * OH * OW
+    dev = dy.device
+    need_x, need_x2, need_w, need_b = needs
+    gt = cfg.get("gt") or (None, None, None, None)
+    dw = db = dx = dx2 = None
+    if need_w or (need_b and has_bias):
+        ws = None
+        shadowed = has_bn and cfg["training"]     # bias in front of train-mode BN: gradient is exactly 0
+        acc_w = gt[0] is not None and need_w
+        dw = gt[0] if acc_w else torch.empty_like(weight)
+        acc_b = False
+        if has_bias and need_b:
+            if gt[1] is not None:
+                acc_b, db = True, gt[1]              # (+= 0 when shadowed: nothing to do)
+            elif shadowed:
+                db = torch.zeros(Cout, device=dev, dtype=torch.float32)
+            else:
+                db = torch.empty(Cout, device=dev, dtype=torch.float32)
+        want_db = db is not None and not shadowed
+        if WGRAD_STREAM is not None and acc_w and (acc_b or not want_db):
+            # in-place accumulation into the arenas: nothing flows back through autograd, so the launch can trail
+            ev = torch.cuda.Event()
+            ev.record()
+            WGRAD_STREAM.wait_event(ev)
+            # (no `with torch.cuda.stream(...)` here: the launch takes the stream handle explicitly, and entering / leaving the
+            # context costs ~25 us of host time per layer)
+            ws = _scratch("wgrad", d["ws_floats"], dev, WGRAD_STREAM)
+            if amax is not None and d["wgrad_f16"]:
+                _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                     dw.data_ptr(), db.data_ptr() if want_db else 0, 1, amax.data_ptr(), _ptr(xa),
+                                                     WGRAD_STREAM.cuda_stream), "viai_conv2d_wgrad_f16")
+            else:
+                _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                 dw.data_ptr(), db.data_ptr() if want_db else 0, 1, WGRAD_STREAM.cuda_stream),
+                           "viai_conv2d_wgrad")
+            _deferred.append((x, x2, dy, weight, amax, xa))
+        elif acc_w == acc_b or not want_db:
+            ws = _scratch("wgrad", d["ws_floats"], dev)
+            if amax is not None and d["wgrad_f16"]:
+                _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                     dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0,
+                                                     amax.data_ptr(), _ptr(xa), st), "viai_conv2d_wgrad_f16")
+            else:
+                _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                                 dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0, st),
+                           "viai_conv2d_wgrad")
+        else:   # mixed modes (only outside AudioModel): two calls keep the accumulate flag consistent
+            ws = _scratch("wgrad", d["ws_floats"], dev)
+            _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
+                                             dw.data_ptr(), 0, 1 if acc_w else 0, st), "viai_conv2d_wgrad")
+            part_b = torch.empty(lib.viai_colsum_blocks(M, Cout) * Cout, device=dev, dtype=torch.float32)
+            _lib.check(lib.viai_colsum(dy.data_ptr(), M, Cout, part_b.data_ptr(), db.data_ptr(), 1 if acc_b else 0, st),
+                       "viai_colsum")
+        if acc_w or not need_w:
+            dw = None
+        if acc_b:
+            db = None
+        if GRAD_HOOKS:
+            hook = GRAD_HOOKS.get(weight.data_ptr())
+            if hook is not None:
+                hook()
+    if need_x or need_x2:
+        dx = torch.empty((N, IH, IW, C1), device=dev, dtype=torch.float32)
+        dx2 = torch.empty((N, IH, IW, C2), device=dev, dtype=torch.float32) if C2 > 0 else None
+        if amax is not None and d["dgrad_f16"]:
+            wp = _packed(weight, d, 2, st)
+            _lib.check(lib.viai_conv2d_dgrad_f16(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), amax.data_ptr(), st),
+                       "viai_conv2d_dgrad_f16")
+        else:
+            wp = _packed(weight, d, 1, st)
+            _lib.check(lib.viai_conv2d_dgrad(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), st),
+                       "viai_conv2d_dgrad")
+    return dx, dx2, dw, db
+
+
 class _ConvBnAct(torch.autograd.Function):
     """y = conv(x ++ x2, w) + b ; [BatchNorm2d] ; activation  — one fused layer.
 
@@ -510,74 +589,8 @@ class _ConvBnAct(torch.autograd.Function):
             dy = torch.empty_like(dz)
             _lib.check(lib.viai_act_bwd_from_output(dz.data_ptr(), y_or_z.data_ptr(), dy.data_ptr(), dz.numel(), act,
                                                     0.2, st), "viai_act_bwd_from_output")
-        dw = db = dx = dx2 = None
-        if need_w or (need_b and ctx.has_bias):
-            ws = None
-            shadowed = ctx.has_bn and cfg["training"]     # bias in front of train-mode BN: gradient is exactly 0
-            acc_w = gt[0] is not None and need_w
-            dw = gt[0] if acc_w else torch.empty_like(weight)
-            acc_b = False
-            if ctx.has_bias and need_b:
-                if gt[1] is not None:
-                    acc_b, db = True, gt[1]              # (+= 0 when shadowed: nothing to do)
-                elif shadowed:
-                    db = torch.zeros(Cout, device=dev, dtype=torch.float32)
-                else:
-                    db = torch.empty(Cout, device=dev, dtype=torch.float32)
-            want_db = db is not None and not shadowed
-            if WGRAD_STREAM is not None and acc_w and (acc_b or not want_db):
-                # in-place accumulation into the arenas: nothing flows back through autograd, so the launch can trail
-                ev = torch.cuda.Event()
-                ev.record()
-                WGRAD_STREAM.wait_event(ev)
-                # (no `with torch.cuda.stream(...)` here: the launch takes the stream handle explicitly, and entering / leaving the
-                # context costs ~25 us of host time per layer)
-                ws = _scratch("wgrad", d["ws_floats"], dev, WGRAD_STREAM)
-                if amax is not None and d["wgrad_f16"]:
-                    _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                         dw.data_ptr(), db.data_ptr() if want_db else 0, 1, amax.data_ptr(), _ptr(ctx.xa),
-                                                         WGRAD_STREAM.cuda_stream), "viai_conv2d_wgrad_f16")
-                else:
-                    _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                     dw.data_ptr(), db.data_ptr() if want_db else 0, 1, WGRAD_STREAM.cuda_stream),
-                               "viai_conv2d_wgrad")
-                _deferred.append((x, x2, dy, weight, amax, ctx.xa))
-            elif acc_w == acc_b or not want_db:
-                ws = _scratch("wgrad", d["ws_floats"], dev)
-                if amax is not None and d["wgrad_f16"]:
-                    _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                         dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0,
-                                                         amax.data_ptr(), _ptr(ctx.xa), st), "viai_conv2d_wgrad_f16")
-                else:
-                    _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                     dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0, st),
-                               "viai_conv2d_wgrad")
-            else:   # mixed modes (only outside AudioModel): two calls keep the accumulate flag consistent
-                ws = _scratch("wgrad", d["ws_floats"], dev)
-                _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                 dw.data_ptr(), 0, 1 if acc_w else 0, st), "viai_conv2d_wgrad")
-                part_b = torch.empty(lib.viai_colsum_blocks(M, Cout) * Cout, device=dev, dtype=torch.float32)
-                _lib.check(lib.viai_colsum(dy.data_ptr(), M, Cout, part_b.data_ptr(), db.data_ptr(), 1 if acc_b else 0, st),
-                           "viai_colsum")
-            if acc_w or not need_w:
-                dw = None
-            if acc_b:
-                db = None
-            if GRAD_HOOKS:
-                hook = GRAD_HOOKS.get(weight.data_ptr())
-                if hook is not None:
-                    hook()
-        if need_x or need_x2:
-            dx = torch.empty((N, IH, IW, C1), device=dev, dtype=torch.float32)
-            dx2 = torch.empty((N, IH, IW, C2), device=dev, dtype=torch.float32) if C2 > 0 else None
-            if amax is not None and d["dgrad_f16"]:
-                wp = _packed(weight, d, 2, st)
-                _lib.check(lib.viai_conv2d_dgrad_f16(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), amax.data_ptr(), st),
-                           "viai_conv2d_dgrad_f16")
-            else:
-                wp = _packed(weight, d, 1, st)
-                _lib.check(lib.viai_conv2d_dgrad(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), st),
-                           "viai_conv2d_dgrad")
+        dx, dx2, dw, db = _conv_grads(lib, d, cfg, ctx.dims, ctx.has_bn, ctx.has_bias, (need_x, need_x2, need_w, need_b), ctx.xa,
+                                      x, x2, weight, dy, amax, st)
         return dx, dx2, dw, db, dgamma, dbeta, None, None, None, None
 
 
@@ -678,6 +691,200 @@ def _tag_amax(z, cfg):
     if za is not None:
         z._viai_amax = za
     return z
+
+
+PAIR_FUSED = os.environ.get("VIAI_PAIR_FUSED", "1") != "0"     # (conv + BN + act) -> (Cout = 1 conv) pairs as one op (A/B switch)
+
+
+class _ConvBnActCout1(torch.autograd.Function):
+    """p = act2(conv2(act1(BN(conv1(x ++ x2, w1) + b1)), w2) + b2) with conv2 a 3 x 3 / stride 1 / pad 1 (transposed) conv to ONE channel:
+    G.conv6_1 + conv6_1_bn + ReLU -> conv6_2 + Sigmoid (New_Inpainting_Networks.py:85-88) and D.conv3 + norm3 + LeakyReLU -> conv4 +
+    Sigmoid (Discriminator_Networks.py:44-49).  Same arithmetic as two _ConvBnAct layers, minus three tensors: the front layer's
+    post-activation z (the Cout = 1 kernels apply BatchNorm + activation to y on load) and the Cout = 1 layer's data gradient dz
+    (the BatchNorm backward forms it from du in registers) -- csrc/conv_direct.hip `viai_pair_cout1_*`."""
+
+    @staticmethod
+    def forward(ctx, x, x2, w1, b1, gamma, beta, rmean, rvar, nbt, w2, b2, cfg):
+        lib = _lib.load()
+        _require(x, x2, w1, b1, gamma, beta, w2, b2)
+        x = _c(x)
+        x2 = _c(x2) if x2 is not None else None
+        N, IH, IW, C1 = x.shape
+        C2 = x2.shape[3] if x2 is not None else 0
+        kh, kw = cfg["k"]
+        tr1 = cfg["transposed"]
+        Cmid = w1.shape[1] if tr1 else w1.shape[0]
+        d = conv_desc(N, IH, IW, C1, C2, Cmid, kh, kw, cfg["s"][0], cfg["s"][1], cfg["p"][0], cfg["p"][1], 1 if tr1 else 0)
+        OH, OW = d["OH"], d["OW"]
+        d2 = conv_desc(N, OH, OW, Cmid, 0, 1, 3, 3, 1, 1, 1, 1, 1 if cfg["transposed2"] else 0)
+        st = _stream()
+        dev = x.device
+        M = N * OH * OW
+        if DEBUG_RANGE:
+            _range_scan("weight", w1, F16_WEIGHT_LIMIT)
+        wp1 = _packed(w1, d, 0, st)
+        wp2 = _packed(w2, d2, 0, st)
+        f16f = d.get("fwd_f16")
+        if f16f is None:
+            f16f = d["fwd_f16"] = bool(lib.viai_conv2d_fwd_f16_ok(d["ref"]))
+        xa = _input_amax(x, x2, cfg.get("xa_in", (None, None)), st) if (f16f and F16_DYNAMIC) else None
+        y = torch.empty((N, OH, OW, Cmid), device=dev, dtype=torch.float32)
+        coef = torch.empty((4, Cmid), device=dev, dtype=torch.float32)       # mean, invstd, scale, shift
+        if cfg["training"]:
+            stat = _scratch("stat", 2 * Cmid * d["nblk"], dev)
+            _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp1.data_ptr(), _ptr(b1), y.data_ptr(), stat.data_ptr(),
+                                                ACT_NONE, _ptr(xa), st), "viai_conv2d_fwd")
+            _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, Cmid, gamma.data_ptr(), beta.data_ptr(), _ptr(rmean),
+                                            _ptr(rvar), _ptr(nbt), cfg["momentum"], cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
+                                            coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_finalize")
+        else:
+            _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp1.data_ptr(), _ptr(b1), y.data_ptr(), 0, ACT_NONE,
+                                                _ptr(xa), st), "viai_conv2d_fwd")
+            _lib.check(lib.viai_bn_eval_coeffs(Cmid, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), cfg["eps"],
+                                               coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st),
+                       "viai_bn_eval_coeffs")
+        p = torch.empty((N, OH, OW, 1), device=dev, dtype=torch.float32)
+        if cfg.get("fwd_on_load"):
+            # BatchNorm + activation applied while the Cout = 1 kernel loads y: no z at all.  Measured SLOWER (D.conv4 36 -> 106 us,
+            # G.conv6_2 57 -> 129 us): the row-run kernel fetches every input element 3 (L + 2) / L = 4.5 .. 6 times from L1 / L2 and
+            # now normalises it as often, which turns a streaming kernel into a VALU-bound one.  Kept for the record, off.
+            _lib.check(lib.viai_pair_cout1_fwd(d2["ref"], y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), cfg["act"], wp2.data_ptr(),
+                                               _ptr(b2), p.data_ptr(), cfg["act2"], st), "viai_pair_cout1_fwd")
+        else:
+            # z exists only between these two launches: the backward works from y (z is re-formed on load where it is needed once per
+            # element: the Cout = 1 layer's weight gradient), so it is not kept
+            z = torch.empty_like(y)
+            _lib.check(lib.viai_bn_act_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(), M, Cmid, cfg["act"], 0.2, st),
+                       "viai_bn_act_fwd")
+            _lib.check(lib.viai_conv2d_fwd(d2["ref"], z.data_ptr(), 0, wp2.data_ptr(), _ptr(b2), p.data_ptr(), 0, cfg["act2"], st),
+                       "viai_conv2d_fwd")
+            del z
+        ctx.save_for_backward(x, x2, w1, y, coef, w2, p)
+        ctx.d, ctx.d2, ctx.cfg, ctx.xa = d, d2, cfg, xa
+        ctx.has_bias, ctx.has_bias2 = b1 is not None, b2 is not None
+        ctx.dims = (N, IH, IW, C1, C2, Cmid, OH, OW)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        lib = _lib.load()
+        x, x2, w1, y, coef, w2, p = ctx.saved_tensors
+        d, d2, cfg = ctx.d, ctx.d2, ctx.cfg
+        N, IH, IW, C1, C2, Cmid, OH, OW = ctx.dims
+        M = N * OH * OW
+        st = _stream()
+        dev = dp.device
+        dp = _c(dp)
+        need_x, need_x2, need_w1, need_b1, need_g, need_be = ctx.needs_input_grad[:6]
+        need_w2, need_b2 = ctx.needs_input_grad[9], ctx.needs_input_grad[10]
+        gt = cfg.get("gt") or (None, None, None, None)
+        gt2 = cfg.get("gt2") or (None, None)
+        # du = gradient of the Cout = 1 layer's pre-activation output (N, OH, OW, 1): 4 bytes per pixel
+        if cfg["act2"] == ACT_NONE:
+            du = dp
+        else:
+            du = torch.empty_like(dp)
+            _lib.check(lib.viai_act_bwd_from_output(dp.data_ptr(), p.data_ptr(), du.data_ptr(), dp.numel(), cfg["act2"], 0.2, st),
+                       "viai_act_bwd_from_output")
+        wp2 = _packed(w2, d2, 0, st)
+        # ---- the Cout = 1 layer's own parameter gradients
+        dw2 = db2 = None
+        if need_w2 or (need_b2 and ctx.has_bias2):
+            acc_w2 = gt2[0] is not None and need_w2
+            dw2 = gt2[0] if acc_w2 else torch.empty_like(w2)
+            acc_b2 = False
+            if ctx.has_bias2 and need_b2:
+                acc_b2 = gt2[1] is not None
+                db2 = gt2[1] if acc_b2 else torch.empty(1, device=dev, dtype=torch.float32)
+            side = WGRAD_STREAM if (WGRAD_STREAM is not None and acc_w2 and (acc_b2 or db2 is None)) else None
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                side.wait_event(ev)
+            handle = side.cuda_stream if side is not None else st
+            ws = _scratch("wgrad", d2["ws_floats"] + lib.viai_colsum_blocks(M, 1) + 8, dev, side) if side is not None else \
+                _scratch("wgrad", d2["ws_floats"] + lib.viai_colsum_blocks(M, 1) + 8, dev)
+            if need_w2:
+                _lib.check(lib.viai_pair_cout1_wgrad(d2["ref"], y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), cfg["act"], du.data_ptr(),
+                                                     ws.data_ptr(), dw2.data_ptr(), 1 if acc_w2 else 0, handle), "viai_pair_cout1_wgrad")
+            if db2 is not None:
+                _lib.check(lib.viai_colsum(du.data_ptr(), M, 1, ws[d2["ws_floats"]:].data_ptr(), db2.data_ptr(), 1 if acc_b2 else 0, handle),
+                           "viai_colsum")
+            if side is not None:
+                _deferred.append((y, coef, du, w2, ws))
+            if acc_w2 or not need_w2:
+                dw2 = None
+            if acc_b2:
+                db2 = None
+        # ---- BatchNorm + activation backward of the front layer, dz formed on the fly from du
+        nblk = d2.get("pair_blk")
+        if nblk is None:
+            nblk = d2["pair_blk"] = int(lib.viai_pair_cout1_bn_bwd_blocks(d2["ref"]))
+        part = _scratch("bnpart", 2 * Cmid * nblk, dev)
+        sums = _scratch("bnsums", 2 * Cmid, dev)
+        acc_bn = gt[2] is not None and gt[3] is not None and need_g and need_be
+        dgamma = dbeta = None
+        if acc_bn:
+            pg, pb = gt[2], gt[3]
+        else:
+            dgamma = torch.empty(Cmid, device=dev, dtype=torch.float32) if need_g else None
+            dbeta = torch.empty(Cmid, device=dev, dtype=torch.float32) if need_be else None
+            pg, pb = dgamma, dbeta
+        f16d = d.get("dgrad_f16")
+        if f16d is None:
+            f16d = d["dgrad_f16"] = bool(lib.viai_conv2d_dgrad_f16_ok(d["ref"]))
+        f16w = d.get("wgrad_f16")
+        if f16w is None:
+            f16w = d["wgrad_f16"] = bool(lib.viai_conv2d_wgrad_f16_ok(d["ref"]))
+        amax = _amax_slot(dev) if (F16_BACKWARD and ((f16d and (need_x or need_x2)) or (f16w and need_w1))) else None
+        want_dy = need_x or need_x2 or need_w1 or (need_b1 and ctx.has_bias)
+        dy = torch.empty_like(y) if want_dy else None
+        _lib.check(lib.viai_pair_cout1_bn_bwd(d2["ref"], du.data_ptr(), wp2.data_ptr(), y.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                              coef[2].data_ptr(), coef[3].data_ptr(), cfg["act"], part.data_ptr(), sums.data_ptr(), _ptr(pg), _ptr(pb),
+                                              _ptr(dy), (1 if cfg["training"] else 0) | (2 if acc_bn else 0), _ptr(amax), st), "viai_pair_cout1_bn_bwd")
+        dx = dx2 = dw1 = db1 = None
+        if want_dy:
+            dx, dx2, dw1, db1 = _conv_grads(lib, d, cfg, ctx.dims, True, ctx.has_bias, (need_x, need_x2, need_w1, need_b1), ctx.xa,
+                                            x, x2, w1, dy, amax, st)
+        return dx, dx2, dw1, db1, dgamma, dbeta, None, None, None, dw2, db2, None
+
+
+def conv_bn_act_cout1_ok(x, weight, bn, conv2_weight, *, kernel, stride, padding, transposed, kernel2, stride2, padding2, x2=None):
+    """can (conv + bn + act) -> conv2 run as the fused pair?  conv2: 3 x 3, stride 1, pad 1, one output channel; bn a BatchNorm."""
+    if not PAIR_FUSED or bn is None or not isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) or not x.is_cuda:
+        return False
+    if tuple(kernel2) != (3, 3) or tuple(stride2) != (1, 1) or tuple(padding2) != (1, 1):
+        return False
+    N, IH, IW, C1 = x.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    Cmid = weight.shape[1] if transposed else weight.shape[0]
+    d = conv_desc(N, IH, IW, C1, C2, Cmid, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], 1 if transposed else 0)
+    d2 = conv_desc(N, d["OH"], d["OW"], Cmid, 0, 1, 3, 3, 1, 1, 1, 1, 0)
+    ok = d2.get("pair_ok")
+    if ok is None:
+        ok = d2["pair_ok"] = bool(_lib.load().viai_pair_cout1_ok(d2["ref"]))
+    return ok
+
+
+def conv_bn_act_cout1(x, weight, bias, bn, weight2, bias2, *, kernel, stride=(1, 1), padding=(0, 0), transposed=False, act=ACT_NONE,
+                      transposed2=False, act2=ACT_NONE, x2=None, training=True):
+    """the fused pair on NHWC tensors (check conv_bn_act_cout1_ok first)"""
+    cfg = {"k": tuple(kernel), "s": tuple(stride), "p": tuple(padding), "transposed": bool(transposed), "act": int(act), "training": bool(training),
+           "momentum": 0.1 if bn.momentum is None else float(bn.momentum), "eps": float(bn.eps), "transposed2": bool(transposed2),
+           "act2": int(act2), "xa_in": (amax_of(x), amax_of(x2))}
+    track = bn.track_running_stats and bn.running_mean is not None
+    if not training and not track:
+        cfg["training"] = True
+    if DIRECT_GRAD:
+        def tgt(p):
+            return p.grad if (p is not None and p.is_leaf and p.requires_grad and p.grad is not None) else None
+        cfg["gt"] = tuple(tgt(p) for p in (weight, bias, bn.weight, bn.bias))
+        cfg["gt2"] = (tgt(weight2), tgt(bias2))
+    out = _ConvBnActCout1.apply(x, x2, weight, bias, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
+                                bn.num_batches_tracked if (track and cfg["training"]) else None, weight2, bias2, cfg)
+    if act2 == ACT_SIGMOID:
+        out._viai_amax = _const_amax(x.device, 1.0)
+    return out
 
 
 class _BilinearAC(torch.autograd.Function):
