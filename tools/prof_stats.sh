@@ -8,7 +8,7 @@ rm -rf "$out"; mkdir -p "$out" "$root/gpurun_out"
 f=$(find "$out" -name "*kernel_stats.csv" | head -1)
 if [ -z "$f" ]; then tail -30 "$out/log.txt"; exit 1; fi
 cp "$f" "$root/gpurun_out/${tag}_kernel_stats.csv"
-grep '^{"metric"' "$out/log.txt" > "$root/gpurun_out/${tag}_bench_line.json"
+grep '^{"metric"' "$out/log.txt" > "$root/gpurun_out/${tag}_profiled_bench_line.json"
 python - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
