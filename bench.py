@@ -384,6 +384,11 @@ def main_wavenet(args):
     net.incremental_forward(None, c=c, T=T, log_scale_min=-7.0, timing=timing)
     ms = timing["ms"] / timing["steps"]
     n_param = sum(p.numel() for p in net.parameters())
+    fused = os.environ.get("VIAI_WN_FUSED", "1") != "0"
+    n_launch = len(net.conv_layers) + 1 if fused else 2 * len(net.conv_layers) + 2
+    kernel_chain = "wn_stage_kernel x %d / wn_head_fused_kernel" % len(net.conv_layers) if fused else "wn_gate_kernel / wn_out_kernel / wn_head_kernel"
+    launch_form = ("fused stages: gate_l computed from z_(l-1) and x_(l-1)(t) through host-folded rows [Wc0 | Wc1 | r Wc2 | r Wc2 Wo_prev], "
+                   "one dependent launch per layer") if fused else "two dependent launches per layer (VIAI_WN_FUSED=0)"
     # weight bytes one time step must stream: every layer's linearised dilated conv (3 x 512 x 512), conditioning (512 x 80), out and
     # skip 1x1s, first conv, head -- the fp32 weights the step kernels read (the up-sampling net runs once, outside the loop)
     wbytes = 4 * sum(p.numel() for n, p in net.named_parameters() if n.endswith("weight_v") and not n.startswith("upsample_conv"))
@@ -395,9 +400,9 @@ def main_wavenet(args):
                                "(%d parameters), local conditioning at hop 256, %d streams, mixture-of-logistics sampling; a step = one time step"
                                % (len(net.conv_layers), 4, n_param, B),
                    "global_batch": B, "parallelism": "replicas only (independent streams)", "real_time_factor_16khz": round(1e3 / ms / 16000.0, 3),
-                   "launches_per_step": 2 * len(net.conv_layers) + 2, "launch": "viai_wavenet_synth_run: C loop over the time steps, time index by value"},
+                   "launches_per_step": n_launch, "launch": "viai_wavenet_synth_run: C loop over the time steps, time index by value; " + launch_form},
         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "wn_gate_kernel / wn_out_skip_kernel / wn_head_kernel chain (csrc/wavenet.hip): %d dependent launches per time step" % (2 * len(net.conv_layers) + 2),
+                     "kernel": "%s chain (csrc/wavenet.hip): %d dependent launches per time step" % (kernel_chain, n_launch),
                      "algorithmic_bytes_per_step": wbytes,
                      "note": "weight-streaming bound (SURVEY.md section 8d: incremental lower bound per time step = weight bytes / bandwidth): every time step reads "
                              "all %.1f MB of fp32 weights once, whatever level of the hierarchy serves them (they fit the 256 MB Infinity Cache, not the 32 MB of L2); "

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 6
+#define VIAI_ABI_VERSION 7
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -266,6 +266,11 @@ typedef struct viai_wn_layer {
     int dilation, ring_len;
     const float* g_add;     /* optional [B][G]: the time-invariant gate contribution of global conditioning,
                                conv1x1g(embed_speakers(g)) + bias (modules.py:195-199); NULL without it (ABI v3) */
+    /* fused stages (ABI v7, viai_wn_synth.fused): extended gate rows [G][K] = [Wc^0 | Wc^1 | Wc^2] for layer 0 (K = 3 C) and
+     * [Wc^0 | Wc^1 | r Wc^2 | r Wc^2 Wo_prev] for layer l > 0 (K = 3 C + G/2, r = sqrt(.5), Wo_prev = the previous layer's w_out), and
+     * the folded bias [G] = b_conv + b_c (+ r Wc^2 bo_prev): gate_l then needs only z_{l-1} and x_{l-1}(t), i.e. ONE dependent launch
+     * per layer instead of two                                                                                                      */
+    const float *w_stage, *b_stage;
 } viai_wn_layer;
 typedef struct viai_wn_synth {
     int B, C, G, S, cin, n_layers, out_ch, T, n_test;
@@ -275,6 +280,8 @@ typedef struct viai_wn_synth {
     const float *cond, *test_inputs, *u1, *u2;
     float *out, *z, *skips, *yhat_dbg;      /* z: (B, G/2), skips: (B, S) scratch; yhat_dbg optional (B,T,out_ch) */
     int* step;                              /* device int, 0 before the first call: counts the calls (the step advances it itself) */
+    float* z2;                              /* fused stages: second (B, G/2) buffer (z is double-buffered) */
+    int fused;                              /* 1: run the fused-stage form (needs layers[].w_stage / b_stage, z2; S, out_ch, G/2 <= 256) */
 } viai_wn_synth;
 int viai_wavenet_synth_step(const viai_wn_synth* s, void* stream);
 /* The same time steps t0 .. t0 + n_steps - 1 launched from a host loop with the time index passed BY VALUE (ABI v5): no kernel starts

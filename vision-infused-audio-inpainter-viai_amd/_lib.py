@@ -45,7 +45,7 @@ class PackJob(C.Structure):
 class WnLayer(C.Structure):
     """mirror of `viai_wn_layer`."""
     _fields_ = [(n, C.c_void_p) for n in ("w_conv", "b_conv", "w_c", "b_c", "w_out", "b_out", "w_skip", "b_skip", "ring")] + \
-               [("dilation", C.c_int), ("ring_len", C.c_int), ("g_add", C.c_void_p)]
+               [("dilation", C.c_int), ("ring_len", C.c_int), ("g_add", C.c_void_p), ("w_stage", C.c_void_p), ("b_stage", C.c_void_p)]
 
 
 class WnSynth(C.Structure):
@@ -53,7 +53,7 @@ class WnSynth(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "C", "G", "S", "cin", "n_layers", "out_ch", "T", "n_test")] + [("log_scale_min", C.c_float)] + \
                [("layers", C.POINTER(WnLayer))] + \
                [(n, C.c_void_p) for n in ("w_first", "b_first", "w_l1", "b_l1", "w_l2", "b_l2", "cond", "test_inputs", "u1", "u2",
-                                          "out", "z", "skips", "yhat_dbg", "step")]
+                                          "out", "z", "skips", "yhat_dbg", "step", "z2")] + [("fused", C.c_int)]
 
 
 _P = C.c_void_p

@@ -712,6 +712,280 @@ __global__ __launch_bounds__(256) void wn_head_generic_kernel(const float* __res
     }
 }
 
+// ---- fused stages (ABI 7): ONE dependent launch per layer instead of two -----------------------------------------------------------
+// A time step of the plain form is a chain of 2 L + 2 dependent launches: gate_l needs all of x_l(t), which out_{l-1} produces from all
+// of z_{l-1}.  But x_l(t) = (Wo_{l-1} z_{l-1} + bo_{l-1} + x_{l-1}(t)) sqrt(.5) is LINEAR in z_{l-1}, and gate_l uses it only through
+// the current tap Wc_l^2 x_l(t), so
+//     Wc_l^2 x_l(t) = [sqrt(.5) Wc_l^2 Wo_{l-1}] z_{l-1} + [sqrt(.5) Wc_l^2] x_{l-1}(t) + sqrt(.5) Wc_l^2 bo_{l-1}
+// and gate_l can start from what stage l - 1 left behind: z_{l-1} and x_{l-1}(t).  The host builds the extended rows
+// [Wc^0 | Wc^1 | sqrt(.5) Wc^2 | sqrt(.5) Wc^2 Wo_{l-1}] (K = 3 C + H) and the folded bias once; stage l then runs, side by side in
+// one launch, (A) gate_l -> z_l from the two past taps (ring_l), x_{l-1}(t) (ring_{l-1}) and z_{l-1}, and (B) the out / skip rows of
+// layer l - 1 (x_l(t) -> ring_l for the FUTURE time steps' past taps, the running skip sum).  Stage 0 forms x_0(t) = first conv inline.
+// The last layer's skip row product moves into the head.  L + 1 dependent launches per time step; z is double-buffered (stage l
+// writes z_l while its B blocks still read z_{l-1}).  Reassociation only: sums agree with the plain form to fp32 rounding.
+struct WnStage {
+    const float* ring; int ring_len, dil;          // x_l at the past time steps
+    const float* ring_prev; int prev_len;          // x_{l-1}, current slot written by stage l - 1 (l > 0)
+    const float* w; const float* bias;             // [G][K] extended rows, [G] folded bias
+    const float* wc; const float* cond; const float* gadd;
+    const float* z_in; float* z_out;
+    const float* w_first; const float* b_first; const float* test_inputs; int n_test; const float* out;   // stage 0
+    const float* w_out; const float* b_out; const float* w_skip; const float* b_skip;                      // layer l - 1 (B blocks)
+    float* ring_w; float* skips; int first_skip;
+    const int* step; int t_arg, l, C, H, S, cin, T, B;
+};
+
+__global__ void wn_tick_kernel(int* step) { *step += 1; }
+
+template <int NB>
+__global__ __launch_bounds__(256) void wn_stage_kernel(const WnStage a) {
+    __shared__ float red[2 * NB][260];
+    const int t = a.t_arg >= 0 ? a.t_arg : *a.step - 1;
+    const int tid = threadIdx.x, C = a.C, H = a.H;
+    if ((int)blockIdx.x >= H) {
+        // ---------------------------------------------------------------- B: what layer l - 1 still owes (or the first conv)
+        const int bid = blockIdx.x - H;
+        if (a.l == 0) {
+            for (int i = tid; i < NB * C; i += 256) {
+                const int b = i / C, c = i - b * C;
+                const float cur = (t < a.n_test) ? a.test_inputs[(size_t)b * a.n_test + t] : (t > 0 ? a.out[(size_t)b * a.T + t - 1] : 0.f);
+                a.ring_w[((size_t)b * a.ring_len + (t % a.ring_len)) * C + c] = cur * a.w_first[c] + a.b_first[c];
+            }
+            return;
+        }
+        const int o = bid * 4 + (tid >> 6), lane = tid & 63, S = a.S;
+        if (o >= C + S) return;
+        const float* w = o < C ? a.w_out + (size_t)o * H : a.w_skip + (size_t)(o - C) * H;
+        float pre = 0.f;
+        if (lane < NB) pre = o < C ? a.ring_prev[((size_t)lane * a.prev_len + (t % a.prev_len)) * C + o] : (a.first_skip ? 0.f : a.skips[(size_t)lane * S + (o - C)]);
+        const float bias = o < C ? a.b_out[o] : a.b_skip[o - C];
+        float acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+        for (int k = lane * 4; k < H; k += 256) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(a.z_in + (size_t)b * H + k);
+                acc[b] += x[0] * wv[0] + x[1] * wv[1] + x[2] * wv[2] + x[3] * wv[3];
+            }
+        }
+        const float r5 = 0.70710678118654752f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float v = wave_sum_dpp(acc[b]);
+            const float p = __shfl(pre, b, 64);
+            if (lane == 0) {
+                if (o < C) a.ring_w[((size_t)b * a.ring_len + (t % a.ring_len)) * C + o] = (v + bias + p) * r5;
+                else { const float sv = v + bias; a.skips[(size_t)b * S + (o - C)] = a.first_skip ? sv : (p + sv) * r5; }
+            }
+        }
+        return;
+    }
+    // -------------------------------------------------------------------- A: gate pair (h, h + H) of layer l
+    const int h = blockIdx.x;
+    float ba = 0.f, bg = 0.f;
+    if ((tid & 31) == 0 && tid < 32 * NB) {
+        ba = a.bias[h]; bg = a.bias[h + H];
+        if (a.gadd != nullptr) { ba += a.gadd[(size_t)(tid >> 5) * 2 * H + h]; bg += a.gadd[(size_t)(tid >> 5) * 2 * H + h + H]; }
+    }
+    const int K = 3 * C + (a.l > 0 ? H : 0);
+    const int nq = K / 4, nqc = a.wc != nullptr ? a.cin / 4 : 0;
+    float sa[NB], sg[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { sa[b] = 0.f; sg[b] = 0.f; }
+    const float* wa = a.w + (size_t)h * K;
+    const float* wg = a.w + (size_t)(h + H) * K;
+    for (int q = tid; q < nq + nqc; q += 256) {
+        f32x4 va, vg, x[NB];
+        bool live = true;
+        if (q < nq) {
+            const int k = q * 4;
+            va = *reinterpret_cast<const f32x4*>(wa + k); vg = *reinterpret_cast<const f32x4*>(wg + k);
+            if (k < 2 * C) {                                        // past taps: x_l(t - 2 d), x_l(t - d)
+                const int j = k / C, ci = k - j * C;
+                const int tt = t - (2 - j) * a.dil;
+                live = tt >= 0;
+                if (live) {
+                    const float* xb = a.ring + (size_t)(tt % a.ring_len) * C + ci;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) x[b] = *reinterpret_cast<const f32x4*>(xb + (size_t)b * a.ring_len * C);
+                }
+            } else if (k < 3 * C) {                                 // current tap
+                const int ci = k - 2 * C;
+                if (a.l == 0) {                                     // x_0(t): the first conv, formed here
+                    const f32x4 wf = *reinterpret_cast<const f32x4*>(a.w_first + ci), bf = *reinterpret_cast<const f32x4*>(a.b_first + ci);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const float cur = (t < a.n_test) ? a.test_inputs[(size_t)b * a.n_test + t] : (t > 0 ? a.out[(size_t)b * a.T + t - 1] : 0.f);
+                        x[b] = cur * wf + bf;
+                    }
+                } else {                                            // x_{l-1}(t), against sqrt(.5) Wc^2
+                    const float* xb = a.ring_prev + (size_t)(t % a.prev_len) * C + ci;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) x[b] = *reinterpret_cast<const f32x4*>(xb + (size_t)b * a.prev_len * C);
+                }
+            } else {                                                // z_{l-1}, against sqrt(.5) Wc^2 Wo_{l-1}
+                const int kz = k - 3 * C;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) x[b] = *reinterpret_cast<const f32x4*>(a.z_in + (size_t)b * H + kz);
+            }
+        } else {
+            const int k = (q - nq) * 4;
+            va = *reinterpret_cast<const f32x4*>(a.wc + (size_t)h * a.cin + k); vg = *reinterpret_cast<const f32x4*>(a.wc + (size_t)(h + H) * a.cin + k);
+            const float* xb = a.cond + (size_t)t * a.cin + k;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) x[b] = *reinterpret_cast<const f32x4*>(xb + (size_t)b * a.T * a.cin);
+        }
+        if (live) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                sa[b] += x[b][0] * va[0] + x[b][1] * va[1] + x[b][2] * va[2] + x[b][3] * va[3];
+                sg[b] += x[b][0] * vg[0] + x[b][1] * vg[1] + x[b][2] * vg[2] + x[b][3] * vg[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { red[2 * b][tid] = sa[b]; red[2 * b + 1][tid] = sg[b]; }
+    __syncthreads();
+    if (tid < 32 * NB) {
+        const int v = tid >> 4, part = tid & 15;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += red[v][part * 16 + ((j + part) & 15)];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float other = __shfl_down(sum, 16, 64);
+        if ((tid & 31) == 0) {
+            const int b = tid >> 5;
+            const float va_ = sum + ba, vg_ = other + bg;
+            a.z_out[(size_t)b * H + h] = tanhf(va_) * (1.f / (1.f + expf(-vg_)));
+        }
+    }
+}
+
+// head of the fused form: first the LAST layer's skip rows (skips <- (skips + Ws z + bs) sqrt(.5), relu'd into LDS), then wn_head_kernel's
+// two layers and the sampler.  16 waves x 16 rows, S <= 256, H <= 256, out_ch <= 256.
+__global__ __launch_bounds__(1024) void wn_head_fused_kernel(const float* __restrict__ skips, const float* __restrict__ z, const float* __restrict__ wsk,
+                                                             const float* __restrict__ bsk, int first_skip, int H,
+                                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ u1,
+                                                             const float* __restrict__ u2, float* __restrict__ out, float* __restrict__ yhat_dbg,
+                                                             const int* __restrict__ step, int t_arg, int S, int OC, int T, float log_scale_min) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];          // [S] relu(skips), [S] hidden, [OC] logits, [OC/3 + 1] uniforms
+    float* xin = sm; float* hid = sm + S; float* yo = sm + 2 * S; float* us = yo + ((OC + 3) & ~3);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    constexpr int RB = 16;
+    const int K = OC / 3;
+    const int k0 = lane * 4;
+    const int r0 = wave * RB;
+    f32x4 p[RB];
+    if (r0 < S && k0 < H) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) p[r] = *reinterpret_cast<const f32x4*>(wsk + (size_t)min(r0 + r, S - 1) * H + k0);
+    }
+    const float bvs = bsk[min(r0 + (lane & (RB - 1)), S - 1)];
+    const float bv1 = b1[min(r0 + (lane & (RB - 1)), S - 1)], bv2 = b2[min(r0 + (lane & (RB - 1)), OC - 1)];
+    const float prev = (!first_skip && r0 < S) ? skips[(size_t)b * S + min(r0 + (lane & (RB - 1)), S - 1)] : 0.f;
+    const int t = t_arg >= 0 ? t_arg : *step - 1;
+    if (tid < K) us[tid] = u1[((size_t)b * T + t) * K + tid];
+    if (tid == K) us[K] = u2[(size_t)b * T + t];
+    float acc[RB];
+    const float r5 = 0.70710678118654752f;
+    if (r0 < S) {
+        const f32x4 zv = k0 < H ? *reinterpret_cast<const f32x4*>(z + (size_t)b * H + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = k0 < H ? p[r][0] * zv[0] + p[r][1] * zv[1] + p[r][2] * zv[2] + p[r][3] * zv[3] : 0.f;
+    }
+    if (r0 < S && k0 < S) {                                    // W1's rows: in flight across the skip reductions
+#pragma unroll
+        for (int r = 0; r < RB; ++r) p[r] = *reinterpret_cast<const f32x4*>(w1 + (size_t)min(r0 + r, S - 1) * S + k0);
+    }
+    if (r0 < S) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float sv = wave_sum_dpp(acc[r]) + __shfl(bvs, r, 64);
+            const float pv = __shfl(prev, r, 64);
+            if (lane == 0 && r0 + r < S) { const float v = first_skip ? sv : (pv + sv) * r5; xin[r0 + r] = v > 0.f ? v : 0.f; }
+        }
+    }
+    __syncthreads();
+    if (r0 < S) {
+        const f32x4 xv = k0 < S ? *reinterpret_cast<const f32x4*>(xin + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = k0 < S ? p[r][0] * xv[0] + p[r][1] * xv[1] + p[r][2] * xv[2] + p[r][3] * xv[3] : 0.f;
+    }
+    if (r0 < OC && k0 < S) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) p[r] = *reinterpret_cast<const f32x4*>(w2 + (size_t)min(r0 + r, OC - 1) * S + k0);
+    }
+    if (r0 < S) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float v = wave_sum_dpp(acc[r]) + __shfl(bv1, r, 64);
+            if (lane == 0 && r0 + r < S) hid[r0 + r] = v > 0.f ? v : 0.f;
+        }
+    }
+    __syncthreads();
+    if (r0 < OC) {
+        const f32x4 xv = k0 < S ? *reinterpret_cast<const f32x4*>(hid + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = k0 < S ? p[r][0] * xv[0] + p[r][1] * xv[1] + p[r][2] * xv[2] + p[r][3] * xv[3] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float v = wave_sum_dpp(acc[r]) + __shfl(bv2, r, 64);
+            if (lane == 0 && r0 + r < OC) { yo[r0 + r] = v; if (yhat_dbg) yhat_dbg[((size_t)b * T + t) * OC + r0 + r] = v; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float best = -INFINITY; int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            float v = yo[k] - logf(-logf(us[k]));
+            if (v > best) { best = v; arg = k; }
+        }
+        const float m = yo[K + arg], ls = fmaxf(yo[2 * K + arg], log_scale_min), u = us[K];
+        float x = m + expf(ls) * (logf(u) - logf(1.f - u));
+        out[(size_t)b * T + t] = fminf(fmaxf(x, -1.f), 1.f);
+    }
+}
+
+bool wn_fused_ok(const viai_wn_synth* s) {
+    if (!s->fused || s->z2 == nullptr) return false;
+    if (s->S > 256 || s->out_ch > 256 || s->G / 2 > 256) return false;
+    for (int l = 0; l < s->n_layers; ++l) if (s->layers[l].w_stage == nullptr || s->layers[l].b_stage == nullptr) return false;
+    return true;
+}
+
+template <int NB>
+int wn_step_fused_impl(const viai_wn_synth* s, int t_arg, hipStream_t st) {
+    const int C = s->C, H = s->G / 2, S = s->S, n = s->n_layers;
+    const viai_wn_layer* L = s->layers;
+    if (t_arg < 0) VIAI_LAUNCH(wn_tick_kernel, dim3(1), dim3(1), 0, st, s->step);
+    float* zb[2] = {s->z, s->z2};
+    for (int l = 0; l < n; ++l) {
+        WnStage a{};
+        a.ring = L[l].ring; a.ring_len = L[l].ring_len; a.dil = L[l].dilation;
+        a.w = L[l].w_stage; a.bias = L[l].b_stage; a.wc = L[l].w_c; a.cond = s->cond; a.gadd = L[l].g_add;
+        a.z_out = zb[l & 1]; a.z_in = zb[(l & 1) ^ 1];
+        a.w_first = s->w_first; a.b_first = s->b_first; a.test_inputs = s->test_inputs; a.n_test = s->n_test; a.out = s->out;
+        a.ring_w = L[l].ring; a.skips = s->skips;
+        if (l > 0) {
+            a.ring_prev = L[l - 1].ring; a.prev_len = L[l - 1].ring_len;
+            a.w_out = L[l - 1].w_out; a.b_out = L[l - 1].b_out; a.w_skip = L[l - 1].w_skip; a.b_skip = L[l - 1].b_skip;
+            a.first_skip = (l == 1) ? 1 : 0;
+        }
+        a.step = s->step; a.t_arg = t_arg; a.l = l; a.C = C; a.H = H; a.S = S; a.cin = s->cin; a.T = s->T; a.B = s->B;
+        const int nb = H + (l == 0 ? 1 : (C + S + 3) / 4);
+        VIAI_LAUNCH(wn_stage_kernel<NB>, dim3(nb), dim3(256), 0, st, a);
+    }
+    VIAI_LAUNCH(wn_head_fused_kernel, dim3(s->B), dim3(1024), (2 * S + ((s->out_ch + 3) & ~3) + s->out_ch / 3 + 1) * sizeof(float), st,
+                s->skips, zb[(n - 1) & 1], L[n - 1].w_skip, L[n - 1].b_skip, n == 1 ? 1 : 0, H, s->w_l1, s->b_l1, s->w_l2, s->b_l2, s->u1, s->u2,
+                s->out, s->yhat_dbg, s->step, t_arg, S, s->out_ch, s->T, s->log_scale_min);
+    return viai_launch_status();
+}
+
 template <int NB>
 int wn_step_impl(const viai_wn_synth* s, int t_arg, hipStream_t st) {
     const int C = s->C, H = s->G / 2, S = s->S;
@@ -740,6 +1014,15 @@ bool wn_valid(const viai_wn_synth* s) {
 }
 
 int wn_step(const viai_wn_synth* s, int t_arg, hipStream_t st) {
+    if (wn_fused_ok(s)) {
+        switch (s->B) {
+        case 1: return wn_step_fused_impl<1>(s, t_arg, st);
+        case 2: return wn_step_fused_impl<2>(s, t_arg, st);
+        case 4: return wn_step_fused_impl<4>(s, t_arg, st);
+        case 8: return wn_step_fused_impl<8>(s, t_arg, st);
+        default: return (int)hipErrorInvalidValue;
+        }
+    }
     switch (s->B) {
     case 1: return wn_step_impl<1>(s, t_arg, st);
     case 2: return wn_step_impl<2>(s, t_arg, st);

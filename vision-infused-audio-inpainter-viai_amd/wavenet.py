@@ -460,6 +460,12 @@ class WaveNet(nn.Module):
             keep.append(x)
             return x.data_ptr()
         layers = (_lib.WnLayer * len(self.conv_layers))()
+        # fused stages (csrc/wavenet.hip, ABI 7): gate_l from z_{l-1} and x_{l-1}(t) through the extended rows built below -- one
+        # dependent launch per layer instead of two
+        import os
+        fuse = os.environ.get("VIAI_WN_FUSED", "1") != "0" and S <= 256 and self.out_channels <= 256 and G // 2 <= 256
+        r5 = math.sqrt(0.5)
+        prev = None
         for i, f in enumerate(self.conv_layers):
             d = f.conv.dilation[0]
             ring = torch.zeros(B, 2 * d + 1, Cc, device=dev)
@@ -472,6 +478,18 @@ class WaveNet(nn.Module):
             L.w_out, L.b_out = t(normed_weight(f.conv1x1_out).reshape(Cc, -1)), t(f.conv1x1_out.bias)
             L.w_skip, L.b_skip = t(normed_weight(f.conv1x1_skip).reshape(S, -1)), t(f.conv1x1_skip.bias)
             L.ring, L.dilation, L.ring_len = ring.data_ptr(), d, 2 * d + 1
+            if fuse:
+                wlin = normed_weight(f.conv).permute(0, 2, 1).reshape(G, -1).double()           # [Wc^0 | Wc^1 | Wc^2]
+                bias = f.conv.bias.double()
+                if f.conv1x1c is not None and cond is not None:
+                    bias = bias + f.conv1x1c.bias.double()
+                if prev is not None:
+                    wc2 = wlin[:, 2 * Cc:]
+                    wo, bo = normed_weight(prev.conv1x1_out).reshape(Cc, -1).double(), prev.conv1x1_out.bias.double()
+                    wlin = torch.cat((wlin[:, :2 * Cc], r5 * wc2, r5 * (wc2 @ wo)), 1)
+                    bias = bias + r5 * (wc2 @ bo)
+                L.w_stage, L.b_stage = t(wlin.float()), t(bias.float())
+                prev = f
             # global conditioning adds conv1x1g(g) + bias to the gate pre-activation at every step (modules.py:195-199):
             # computed once per layer by the HIP 1x1 conv and handed to the step kernel as a per-stream constant
             L.g_add = (t(conv1d_apply(g_vec.transpose(1, 2).reshape(B, 1, 1, -1).contiguous(), f.conv1x1g).reshape(B, G))
@@ -479,6 +497,7 @@ class WaveNet(nn.Module):
         out = torch.zeros(B, T, device=dev)
         logits = torch.zeros(B, T, self.out_channels, device=dev) if return_logits else None
         z = torch.zeros(B, G // 2, device=dev)
+        z2 = torch.zeros(B, G // 2, device=dev)
         skips = torch.zeros(B, S, device=dev)
         step = torch.zeros(1, dtype=torch.int32, device=dev)        # time index, advanced on the device by each step
         st = _lib.WnSynth()
@@ -493,6 +512,7 @@ class WaveNet(nn.Module):
         st.test_inputs = tin.data_ptr() if tin is not None else None
         st.u1, st.u2, st.out, st.z, st.skips, st.step = u1.data_ptr(), u2.data_ptr(), out.data_ptr(), z.data_ptr(), skips.data_ptr(), step.data_ptr()
         st.yhat_dbg = logits.data_ptr() if logits is not None else None
+        st.z2, st.fused = z2.data_ptr(), 1 if fuse else 0
         ref = Ct.byref(st)
         if use_graph and T > 2:
             # device-side time index: one step captured into a HIP graph and replayed (every kernel starts with a load of the index)
