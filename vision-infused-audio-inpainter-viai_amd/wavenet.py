@@ -479,16 +479,17 @@ class WaveNet(nn.Module):
             L.w_skip, L.b_skip = t(normed_weight(f.conv1x1_skip).reshape(S, -1)), t(f.conv1x1_skip.bias)
             L.ring, L.dilation, L.ring_len = ring.data_ptr(), d, 2 * d + 1
             if fuse:
-                wlin = normed_weight(f.conv).permute(0, 2, 1).reshape(G, -1).double()           # [Wc^0 | Wc^1 | Wc^2]
-                bias = f.conv.bias.double()
+                # (set-up arithmetic, once per synthesis call, in fp64 on the host: no library GEMM on the device path)
+                wlin = normed_weight(f.conv).permute(0, 2, 1).reshape(G, -1).double().cpu()     # [Wc^0 | Wc^1 | Wc^2]
+                bias = f.conv.bias.double().cpu()
                 if f.conv1x1c is not None and cond is not None:
-                    bias = bias + f.conv1x1c.bias.double()
+                    bias = bias + f.conv1x1c.bias.double().cpu()
                 if prev is not None:
                     wc2 = wlin[:, 2 * Cc:]
-                    wo, bo = normed_weight(prev.conv1x1_out).reshape(Cc, -1).double(), prev.conv1x1_out.bias.double()
+                    wo, bo = normed_weight(prev.conv1x1_out).reshape(Cc, -1).double().cpu(), prev.conv1x1_out.bias.double().cpu()
                     wlin = torch.cat((wlin[:, :2 * Cc], r5 * wc2, r5 * (wc2 @ wo)), 1)
                     bias = bias + r5 * (wc2 @ bo)
-                L.w_stage, L.b_stage = t(wlin.float()), t(bias.float())
+                L.w_stage, L.b_stage = t(wlin.float().to(dev)), t(bias.float().to(dev))
                 prev = f
             # global conditioning adds conv1x1g(g) + bias to the gate pre-activation at every step (modules.py:195-199):
             # computed once per layer by the HIP 1x1 conv and handed to the step kernel as a per-stream constant
