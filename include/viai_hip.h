@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 7
+#define VIAI_ABI_VERSION 8
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -377,18 +377,20 @@ int viai_pair_cout1_bn_bwd(const viai_conv2d* c, const float* du, const float* w
  *   bwd: partial sums from (dz, recomputed y) -> sums = {k0, k1}, dgamma, dbeta;  dy only if a data gradient needs it in memory
  *        (`training` as in viai_bn_act_bwd; part: 2 * Cout * nblk floats, nblk from viai_conv2d_stat_geom)
  *   wgrad: dw (+)= sum dy * x with dy formed on the fly from dz, y and sums
- * w: the packed image of viai_conv2d_pack (= the torch layout for this kind).                                                      */
+ * w: the packed image of viai_conv2d_pack (= the torch layout for this kind).
+ * x_mask (optional, (N, IW) floats): x is read as x[n][iy][ix] * x_mask[n][ix] -- the time mask of the inpainting step (s_in = s * mask,
+ * the missing AudioModel.set_inputs; misc/pipeline2.png) applied where E.conv1 loads s, not in a pass of its own (ABI 8).           */
 int viai_conv2d_cin1_bn_ok(const viai_conv2d* c);
-int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, float* stat_part,
+int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias, float* stat_part,
                             const float* scale, const float* shift, float* z, int act, float* z_amax, void* stream);
-int viai_conv2d_cin1_bn_bwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, const float* dz,
+int viai_conv2d_cin1_bn_bwd(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias, const float* dz,
                             const float* mean, const float* invstd, const float* scale, const float* shift, float* part,
                             float* sums, float* dgamma, float* dbeta, float* dy, int act, int training, void* stream);
-int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, const float* w, const float* bias, const float* dz,
+int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias, const float* dz,
                               const float* mean, const float* scale, const float* shift, const float* sums, float* ws,
                               float* dw, int accumulate, int act, void* stream);
 /* dx straight from dz (dy formed per contributing output pixel): no dy tensor at all; needs bias == NULL */
-int viai_conv2d_cin1_bn_dgrad(const viai_conv2d* c, const float* x, const float* w, const float* dz, const float* mean,
+int viai_conv2d_cin1_bn_dgrad(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* dz, const float* mean,
                               const float* scale, const float* shift, const float* sums, float* dx, int act, void* stream);
 
 /* -------------------------------------------------- launch plans: the train step recorded once, replayed from C

@@ -765,3 +765,48 @@ def test_fused_bn_cout1_pair_matches_the_two_layers(case):
     p64.backward(gp.double())
     assert relerr(nchw(fused[0]), p64) < 1e-5 and relerr(nchw(fused[1]), x64.grad) < 5e-5
     conv1.float().cuda(); conv2.float().cuda(); bn.float().cuda()
+
+
+@pytest.mark.parametrize("geom", [(3, 80, 96, 32, (3, 3), (2, 2), (1, 1)), (2, 64, 64, 32, (3, 3), (2, 2), (1, 1)), (5, 33, 37, 32, (3, 3), (2, 2), (1, 1))])
+@pytest.mark.parametrize("need_dx", [False, True])
+def test_time_mask_applied_where_the_first_conv_loads_its_input(geom, need_dx):
+    """s_in = s * mask (the inpainting step's full-height time gap, misc/pipeline2.png) is not a pass of its own any more: the fused
+    Cin = 1 layer (E.conv1 + bn1 + LeakyReLU, Inpainting_Networks.py:55,71) multiplies while it loads s, in its forward, its BatchNorm
+    backward and its weight gradient (`x_mask` of viai_conv2d_cin1_bn_*, LDS-staged and global-load paths).  Against the same layer
+    on an explicitly masked input -- bit for bit, the arithmetic is the same -- and the gradient w.r.t. the UNMASKED s."""
+    from viai_amd import ops
+    N, H, W, Co, k, s_, p_ = geom
+    x = O.cf_uniform("mk.x", (N, 1, H, W), 0, 1)
+    mask = (O.cf_uniform("mk.m", (N, 1, 1, W), 0, 1) > 0.3).float()
+    w = O.cf_std("mk.w", (Co, 1) + k, 0.3)
+    gy = None
+
+    def run(fused_mask):
+        nonlocal gy
+        bn = torch.nn.BatchNorm2d(Co).cuda().train()
+        xg = nhwc(x).requires_grad_(need_dx)
+        wg = w.cuda().requires_grad_(True)
+        calls = []
+        lib = ops._lib.load()
+        orig = lib.viai_mask_mul
+        lib.viai_mask_mul = lambda *a: (calls.append(1), orig(*a))[1]
+        try:
+            if fused_mask:
+                z = ops.conv_bn_act(xg, wg, None, bn, kernel=k, stride=s_, padding=p_, act=ops.ACT_LRELU, xmask=mask.cuda())
+            else:
+                z = ops.conv_bn_act(ops.mask_mul(xg, mask.cuda()), wg, None, bn, kernel=k, stride=s_, padding=p_, act=ops.ACT_LRELU)
+            if gy is None:
+                gy = O.cf_uniform("mk.gy", tuple(z.shape), -1, 1).cuda()
+            z.backward(gy)
+        finally:
+            lib.viai_mask_mul = orig
+        return [z.detach(), wg.grad, bn.weight.grad, bn.bias.grad, bn.running_var.clone()] + ([xg.grad] if need_dx else []), len(calls)
+    (plain, n_plain), (fused, n_fused) = run(False), run(True)
+    assert n_plain >= 1 and n_fused == (1 if need_dx else 0)          # no mask pass in the step's configuration (s needs no gradient)
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        assert torch.equal(a, b), (i, relerr(a, b))
+    # and a layer the fused path does not take (eval-mode BatchNorm) still sees the masked input
+    bn = torch.nn.BatchNorm2d(Co).cuda().eval()
+    a = ops.conv_bn_act(nhwc(x), w.cuda(), None, bn, kernel=k, stride=s_, padding=p_, act=ops.ACT_LRELU, xmask=mask.cuda(), training=False)
+    b = ops.conv_bn_act(ops.mask_mul(nhwc(x), mask.cuda()), w.cuda(), None, bn, kernel=k, stride=s_, padding=p_, act=ops.ACT_LRELU, training=False)
+    assert torch.equal(a, b)

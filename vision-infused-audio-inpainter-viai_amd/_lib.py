@@ -154,10 +154,10 @@ SIGNATURES = {
     "viai_pair_cout1_fwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     "viai_pair_cout1_wgrad": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     "viai_pair_cout1_bn_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
-    "viai_conv2d_cin1_bn_fwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
-    "viai_conv2d_cin1_bn_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    "viai_conv2d_cin1_bn_wgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    "viai_conv2d_cin1_bn_dgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "viai_conv2d_cin1_bn_fwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "viai_conv2d_cin1_bn_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "viai_conv2d_cin1_bn_wgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "viai_conv2d_cin1_bn_dgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "viai_plan_log_begin": (_I, []),
     "viai_plan_log_end": (_I, []),
     "viai_plan_build": (_I, [_P, _P, C.POINTER(C.c_void_p)]),

@@ -27,6 +27,8 @@ struct DirectArgs {
     // y of the layer in front of it and applies z = act_in(scale * y + shift) on load; its data gradient dz is never stored either, the
     // BatchNorm backward forms it from du (the gradient of the Cout = 1 layer's pre-activation output) with the nine taps in registers
     int act_in;
+    const float* xmask;               // Cin = 1 kernels: optional (N, IW) factor per input column -- x is read as x[n][iy][ix] * xmask[n][ix] (the time
+                                      // mask of the inpainting step, s_in = s * mask, applied where E.conv1 loads s instead of in a pass of its own)
     const float* k_sums;              // {k0, k1} of bn_bwd_final (apply pass)
     float* amax;                      // apply pass: max |dy|
     // block = whole output rows of one image (host-checked): the block's input rows are staged in LDS once (xrows x xpitch floats)
@@ -48,6 +50,10 @@ __device__ __forceinline__ void fast_divmod(int q, int d, float inv_d, int& quo,
 // loads each costs a full 64-lane pass through the address unit (16 cycles), 4 .. 9 taps x 16 pixels per thread, and the kernels were
 // bound by THAT, not by HBM (the statistics-only forward read 4 MB in 31 us).  When a block covers whole output rows of one image
 // its input rows are staged in LDS once (coalesced), zero padding included, and the taps become LDS broadcasts.
+__device__ __forceinline__ float cin1_x(const DirectArgs& a, const float* xb, int n, int iy, int ix) {
+    const float v = xb[iy * a.IW + ix];
+    return a.xmask != nullptr ? v * a.xmask[(size_t)n * a.IW + ix] : v;
+}
 constexpr int CIN1_XP = 2560;             // floats of LDS for the staged rows
 __device__ __forceinline__ void cin1_stage_rows(const DirectArgs& a, float* xp, int n, int oy0) {
     const int iy0 = oy0 * a.sh - a.ph;
@@ -55,7 +61,7 @@ __device__ __forceinline__ void cin1_stage_rows(const DirectArgs& a, float* xp, 
     for (int idx = threadIdx.x; idx < a.xrows * a.xpitch; idx += 256) {
         const int r = idx / a.xpitch, c = idx - r * a.xpitch;
         const int iy = iy0 + r, ix = c - a.pw;
-        xp[idx] = ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
+        xp[idx] = ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) ? cin1_x(a, xb, n, iy, ix) : 0.f;
     }
     __syncthreads();
 }
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
 #pragma unroll
                 for (int q = 0; q < KW; ++q) {
                     const int ix = ix0 + tap_dx(a, q);
-                    float xv = (yok && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
+                    float xv = (yok && (unsigned)ix < (unsigned)a.IW) ? cin1_x(a, xb, n, iy, ix) : 0.f;
                     v += xv * wv[r * KW + q];
                 }
             }
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256) void cin1_bn_bwd_kernel(const DirectArgs a) {
 #pragma unroll
                 for (int q = 0; q < KW; ++q) {
                     const int ix = ix0 + tap_dx(a, q);
-                    float xv = (yok && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
+                    float xv = (yok && (unsigned)ix < (unsigned)a.IW) ? cin1_x(a, xb, n, iy, ix) : 0.f;
                     v += xv * wv[r * KW + q];
                 }
             }
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
 #pragma unroll
                             for (int q2 = 0; q2 < KW; ++q2) {
                                 const int ix2 = ox * sw + tap_dx(a, q2);
-                                const float xv = (yok && (unsigned)ix2 < (unsigned)a.IW) ? xb[iy2 * a.IW + ix2] : 0.f;
+                                const float xv = (yok && (unsigned)ix2 < (unsigned)a.IW) ? cin1_x(a, xb, n, iy2, ix2) : 0.f;
                                 v += xv * wv[r2 * KW + q2];
                             }
                         }
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(256) void cin1_wgrad_kernel(const DirectArgs a, int
 #pragma unroll
             for (int q = 0; q < KW; ++q) {
                 const int ix = ix0 + tap_dx(a, q);
-                xt[r * KW + q] = (yok && (unsigned)ix < (unsigned)a.IW) ? xb[iy * a.IW + ix] : 0.f;
+                xt[r * KW + q] = (yok && (unsigned)ix < (unsigned)a.IW) ? cin1_x(a, xb, n, iy, ix) : 0.f;
             }
         }
         if constexpr (FUSED) {
@@ -1097,7 +1103,7 @@ extern "C" int viai_conv2d_cin1_bn_ok(const viai_conv2d* c) {
 }
 
 // z == NULL: BatchNorm partials only (the conv output is not stored);  z != NULL: z = act(scale * conv(x) + shift)
-extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, float* stat_part,
+extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias, float* stat_part,
                                        const float* scale, const float* shift, float* z, int act, float* z_amax, void* stream) {
     if (!viai_conv2d_cin1_bn_ok(c) || (z == nullptr) == (stat_part == nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
@@ -1105,7 +1111,7 @@ extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, con
     viai_tag_kernel("direct");
     DirectArgs a = make_args(c);
     a.x = x; a.w = w; a.bias = bias; a.y = z; a.stat = stat_part; a.scale = scale; a.shift = shift; a.act = act; a.slope = 0.2f;
-    a.zmax = z_amax;
+    a.zmax = z_amax; a.xmask = x_mask;
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
     cin1_rows_ok(a, CIN1_PB, c->kh, c->kw);
 #define CALL(KH, KW)                                                                                                               \
@@ -1126,12 +1132,13 @@ extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, con
 // BatchNorm(train) + activation backward of the fused layer: partial sums from (dz, recomputed y) -> k0 / k1, dgamma, dbeta (the
 // same final kernel as viai_bn_act_bwd); dy (optional) is written only when a data gradient needs it in memory.
 // part: 2 * Cout * ceil(M / 256) floats; sums: 2 * Cout floats (read by viai_conv2d_cin1_bn_wgrad).
-extern "C" int viai_conv2d_cin1_bn_bwd(const viai_conv2d* c, const float* x, const float* w, const float* bias, const float* dz,
+extern "C" int viai_conv2d_cin1_bn_bwd(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias, const float* dz,
                                        const float* mean, const float* invstd, const float* scale, const float* shift, float* part,
                                        float* sums, float* dgamma, float* dbeta, float* dy, int act, int training, void* stream) {
     if (!viai_conv2d_cin1_bn_ok(c)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     DirectArgs a = make_args(c);
+    a.xmask = x_mask;
     a.x = x; a.w = w; a.bias = bias; a.dz = dz; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.part = part;
     a.sums = sums; a.dx = dy; a.act = act; a.slope = 0.2f;
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
@@ -1157,7 +1164,7 @@ extern "C" int viai_conv2d_cin1_bn_bwd(const viai_conv2d* c, const float* x, con
 
 // dw (+)= weight gradient of the fused layer from dz: dy = scale * dp + k1 * (y - mean) + k0 is formed per element inside the kernel
 // ws: viai_conv2d_wgrad_ws_bytes(c) bytes
-extern "C" int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, const float* w, const float* bias, const float* dz,
+extern "C" int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias, const float* dz,
                                          const float* mean, const float* scale, const float* shift, const float* sums, float* ws,
                                          float* dw, int accumulate, int act, void* stream) {
     if (!viai_conv2d_cin1_bn_ok(c)) return (int)hipErrorInvalidValue;
@@ -1165,6 +1172,7 @@ extern "C" int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, c
     viai_tag_reset();
     viai_tag_kernel("direct");
     DirectArgs a = make_args(c);
+    a.xmask = x_mask;
     a.x = x; a.w = w; a.bias = bias; a.dz = dz; a.mean = mean; a.scale = scale; a.shift = shift; a.sums = sums; a.ws = ws;
     a.act = act; a.slope = 0.2f;
     const int T = c->kh * c->kw;
@@ -1185,11 +1193,12 @@ extern "C" int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, c
 }
 
 // dx = data gradient of the fused layer straight from dz (no dy tensor): the frozen-D pass of the G step
-extern "C" int viai_conv2d_cin1_bn_dgrad(const viai_conv2d* c, const float* x, const float* w, const float* dz, const float* mean,
+extern "C" int viai_conv2d_cin1_bn_dgrad(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* dz, const float* mean,
                                          const float* scale, const float* shift, const float* sums, float* dx, int act, void* stream) {
     if (!viai_conv2d_cin1_bn_ok(c)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     DirectArgs a = make_args(c);
+    a.xmask = x_mask;
     a.x = x; a.w = w; a.dz = dz; a.mean = mean; a.scale = scale; a.shift = shift; a.sums = sums; a.dx = dx; a.act = act; a.slope = 0.2f;
     long tot = (long)a.N * a.IH * a.IW;
     int lpp = c->Cout / 4;

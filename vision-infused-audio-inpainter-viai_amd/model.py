@@ -449,8 +449,7 @@ class AudioModel:
         """E (+ E_v) + G forward on NHWC; returns fake (B,F,T,1) and the contrastive term (or None)
         [+ the encoder maps and the video feature (B,256,1,T/16) when `want_feats`]."""
         B, F, T, _ = s_nhwc.shape
-        s_in = ops.mask_mul(s_nhwc, self.mask)
-        feats = self.Mel_Encoder.forward_nhwc(s_in.view(B, F, T))
+        feats = self.Mel_Encoder.forward_nhwc(s_nhwc.view(B, F, T), mask=self.mask)       # s_in = s * mask, where E.conv1 loads s
         if not self.use_video:
             fake = self.Mel_Decoder.forward_nhwc(feats, (F, T))
             return (fake, None, feats, None) if want_feats else (fake, None)

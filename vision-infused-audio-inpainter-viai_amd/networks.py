@@ -91,16 +91,19 @@ def _instance_norm_layer(x, conv, inorm, act, x2, transposed):
     return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
-def fused_layer(x, conv, bn, act, x2=None, training=True):
-    """conv (nn.Conv2d | nn.ConvTranspose2d holder) -> bn (nn.BatchNorm2d | nn.InstanceNorm2d holder | None) -> act, on NHWC."""
+def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None):
+    """conv (nn.Conv2d | nn.ConvTranspose2d holder) -> bn (nn.BatchNorm2d | nn.InstanceNorm2d holder | None) -> act, on NHWC.
+    `xmask`: the layer convolves x * xmask (ops.conv_bn_act)."""
     transposed = isinstance(conv, nn.ConvTranspose2d)
     if transposed and _pair(conv.stride) != (1, 1):
         raise NotImplementedError("ConvTranspose2d stride != 1")
     if isinstance(bn, nn.InstanceNorm2d):
+        if xmask is not None:
+            x = ops.mask_mul(x, xmask)
         return _instance_norm_layer(x, conv, bn, act, x2, transposed)
     return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
                            padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2,
-                           training=(bn.training if bn is not None else training))
+                           training=(bn.training if bn is not None else training), xmask=xmask)
 
 
 def fused_pair(x, conv, bn, act, conv2, act2, x2=None):
@@ -183,14 +186,15 @@ class MelEncoder(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    def forward_nhwc(self, c):
-        """c: (B, F, T) or (B,1,F,T) -> list of 5 NHWC maps."""
+    def forward_nhwc(self, c, mask=None):
+        """c: (B, F, T) or (B,1,F,T) -> list of 5 NHWC maps.  `mask` (B, T) / (B,1,1,T): the encoder sees c * mask (the inpainting
+        step's time gap), multiplied where conv1 loads c."""
         b = c.size(0)
         f = c.size(-2) if c.dim() >= 3 else self.hparams.cin_channels
         x = c.reshape(b, f, -1, 1)                      # (B,1,F,T) NCHW == (B,F,T,1) NHWC
         net = []
         for i in range(5):
-            x = fused_layer(x, self._modules["conv%d" % (i + 1)], self._modules["bn%d" % (i + 1)], ACT_LRELU)
+            x = fused_layer(x, self._modules["conv%d" % (i + 1)], self._modules["bn%d" % (i + 1)], ACT_LRELU, xmask=mask if i == 0 else None)
             net.append(x)
         net[-1] = ops.avgpool_h(net[-1], 3)
         return net

@@ -490,11 +490,15 @@ class _ConvBnAct(torch.autograd.Function):
             if fused1 is None:
                 fused1 = d["cin1_bn"] = bool(lib.viai_conv2d_cin1_bn_ok(d["ref"]))
         ctx.fused1 = fused1
+        xmask = cfg.get("xmask")
+        if xmask is not None and not fused1:
+            raise RuntimeError("conv_bn_act: xmask reached a layer that is not the fused Cin = 1 layer (conv_bn_act applies it up front otherwise)")
+        ctx.xmask = xmask
         if fused1:
             # Cin = 1 conv + BatchNorm(train) + activation: the pre-BatchNorm tensor is never stored (recomputed from x where needed)
             coef = torch.empty((4, Cout), device=dev, dtype=torch.float32)
             stat = _scratch("stat", 2 * Cout * d["nblk"], dev)
-            _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), wp.data_ptr(), 0, stat.data_ptr(), 0, 0, 0, act, 0, st),
+            _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, stat.data_ptr(), 0, 0, 0, act, 0, st),
                        "viai_conv2d_cin1_bn_fwd")
             _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, Cout, gamma.data_ptr(),
                                             beta.data_ptr(), _ptr(rmean), _ptr(rvar), _ptr(nbt),
@@ -502,7 +506,7 @@ class _ConvBnAct(torch.autograd.Function):
                                             coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_finalize")
             z = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
             za = _amax_slot(dev)
-            _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), wp.data_ptr(), 0, 0, coef[2].data_ptr(), coef[3].data_ptr(),
+            _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, 0, coef[2].data_ptr(), coef[3].data_ptr(),
                                                    z.data_ptr(), act, za.data_ptr(), st), "viai_conv2d_cin1_bn_fwd")
             ctx.save_for_backward(x, None, weight, None, coef)
         elif has_bn:
@@ -619,7 +623,8 @@ def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
     # writing dy once with the recomputing apply pass (7.48 - 7.50 vs 7.38 - 7.40 ms per step), so it is opt-in
     fused_dx = need_x and os.environ.get("VIAI_CIN1_BN_DGRAD", "0") != "0"
     dy = torch.empty_like(dz) if (need_x and not fused_dx) else None
-    _lib.check(lib.viai_conv2d_cin1_bn_bwd(d["ref"], x.data_ptr(), wp.data_ptr(), 0, dz.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+    xmask = ctx.xmask
+    _lib.check(lib.viai_conv2d_cin1_bn_bwd(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, dz.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
                                            coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(), _ptr(pg), _ptr(pb),
                                            _ptr(dy), act, 1 | (2 if acc_bn else 0), st), "viai_conv2d_cin1_bn_bwd")
     dw = dx = None
@@ -629,7 +634,7 @@ def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
 
         def wgrad(stream_obj, handle):
             ws = _scratch("wgrad", d["ws_floats"], dev, stream_obj) if stream_obj is not None else _scratch("wgrad", d["ws_floats"], dev)
-            _lib.check(lib.viai_conv2d_cin1_bn_wgrad(d["ref"], x.data_ptr(), wp.data_ptr(), 0, dz.data_ptr(), coef[0].data_ptr(),
+            _lib.check(lib.viai_conv2d_cin1_bn_wgrad(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, dz.data_ptr(), coef[0].data_ptr(),
                                                      coef[2].data_ptr(), coef[3].data_ptr(), sums.data_ptr(), ws.data_ptr(), dw.data_ptr(),
                                                      1 if acc_w else 0, act, handle), "viai_conv2d_cin1_bn_wgrad")
         if WGRAD_STREAM is not None and acc_w:
@@ -637,7 +642,7 @@ def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
             ev.record()
             WGRAD_STREAM.wait_event(ev)
             wgrad(WGRAD_STREAM, WGRAD_STREAM.cuda_stream)
-            _deferred.append((x, dz, weight, wp, coef, sums))
+            _deferred.append((x, dz, weight, wp, coef, sums, xmask))
         else:
             wgrad(None, st)
         if acc_w:
@@ -650,24 +655,48 @@ def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
         dx = torch.empty((N, IH, IW, C1), device=dev, dtype=torch.float32)
         wpd = _packed(weight, d, 1, st)
         if fused_dx:
-            _lib.check(lib.viai_conv2d_cin1_bn_dgrad(d["ref"], x.data_ptr(), wpd.data_ptr(), dz.data_ptr(), coef[0].data_ptr(),
+            _lib.check(lib.viai_conv2d_cin1_bn_dgrad(d["ref"], x.data_ptr(), _ptr(xmask), wpd.data_ptr(), dz.data_ptr(), coef[0].data_ptr(),
                                                      coef[2].data_ptr(), coef[3].data_ptr(), sums.data_ptr(), dx.data_ptr(), act, st),
                        "viai_conv2d_cin1_bn_dgrad")
         else:
             _lib.check(lib.viai_conv2d_dgrad(d["ref"], dy.data_ptr(), wpd.data_ptr(), dx.data_ptr(), 0, st), "viai_conv2d_dgrad")
+        if xmask is not None:                                   # d/ds of conv(s * mask)
+            N_, T_ = xmask.shape[0], xmask.shape[-1]
+            _lib.check(lib.viai_mask_mul(dx.data_ptr(), xmask.data_ptr(), dx.data_ptr(), N_, dx.numel() // (N_ * T_), T_, st), "viai_mask_mul")
     return dx, None, dw, None, dgamma, dbeta, None, None, None, None
 
 
 _ConvBnAct._backward_cin1 = staticmethod(_backward_cin1)
 
 
+def _cin1_fused_applies(x, weight, bias, bn, kernel, stride, padding, transposed, training):
+    """will this call take the fused Cin = 1 conv + BatchNorm(train) layer?  (the predicate of _ConvBnAct.forward)"""
+    if bn is None or not training or bias is not None or x.shape[3] != 1 or not isinstance(bn, torch.nn.modules.batchnorm._BatchNorm):
+        return False
+    Cout = weight.shape[1] if transposed else weight.shape[0]
+    d = conv_desc(x.shape[0], x.shape[1], x.shape[2], 1, 0, Cout, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], 1 if transposed else 0)
+    f = d.get("cin1_bn")
+    if f is None:
+        f = d["cin1_bn"] = bool(_lib.load().viai_conv2d_cin1_bn_ok(d["ref"]))
+    return f
+
+
 def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding=(0, 0), transposed=False,
-                act=ACT_NONE, x2=None, training=True, dilation=(1, 1), padding2=(-1, -1)):
+                act=ACT_NONE, x2=None, training=True, dilation=(1, 1), padding2=(-1, -1), xmask=None):
     """Fused layer on NHWC tensors.  `bn` is an nn.BatchNorm2d (parameter/buffer holder) or None.
-    `padding2` = (bottom, right) padding when it differs from `padding` (-1 = symmetric)."""
+    `padding2` = (bottom, right) padding when it differs from `padding` (-1 = symmetric).
+    `xmask` (N, W) or (N,1,1,W): the layer convolves x * xmask (the inpainting step's time mask).  The fused Cin = 1 layer multiplies
+    while it loads x; every other kernel gets a masked copy first."""
+    if xmask is not None:
+        xmask = _c(xmask.reshape(xmask.shape[0], xmask.shape[-1]))
+        trainmode = training if (bn is None or (bn.track_running_stats and bn.running_mean is not None)) else True
+        if not (x2 is None and tuple(dilation) == (1, 1) and tuple(padding2) == (-1, -1)
+                and _cin1_fused_applies(x, weight, bias, bn, tuple(kernel), tuple(stride), tuple(padding), transposed, trainmode)):
+            x = mask_mul(x, xmask)
+            xmask = None
     cfg = {"k": tuple(kernel), "s": tuple(stride), "p": tuple(padding), "transposed": bool(transposed),
            "act": int(act), "training": bool(training), "momentum": 0.1, "eps": BN_EPS,
-           "d": tuple(dilation), "p2": tuple(padding2), "xa_in": (amax_of(x), amax_of(x2))}
+           "d": tuple(dilation), "p2": tuple(padding2), "xa_in": (amax_of(x), amax_of(x2)), "xmask": xmask}
     if bn is not None:
         cfg["momentum"] = 0.1 if bn.momentum is None else float(bn.momentum)
         cfg["eps"] = float(bn.eps)
