@@ -53,7 +53,9 @@ struct WgCfg {
     // S = 2 sub-patch bases (tight): (py, px) = (0,0): (HR + 1) rows, (0,1): (HR + 1), (1,0): HR, (1,1): HR
     static constexpr int XSLOTS = S == 1 ? XPIX : (4 * HR + 2) * SUBW;
     static constexpr int XPITCH = BN == 64 ? 192 : 64;               // 64 ch: +64 B pad; 32 ch: four 64-B rows are exactly one 256-B bank row
-    static constexpr int DROW = BM * 2;                              // dy LDS row: 128 ch = 256 B with the 64-byte groups XOR-swizzled by (pixel & 3); 32 ch = 64 B
+    static constexpr int DROW = BM * 2;                              // dy LDS row: 128 ch = 256 B with the 64-byte groups XOR-swizzled by (pixel & 3); 64 ch = 128 B, the two
+                                                                     // groups swapped by bit 1 of the pixel (rows p, p+1 are the two halves of a 256-B bank row, p+2, p+3
+                                                                     // take the other group: four distinct 64-B segments per four rows); 32 ch = 64 B
     static constexpr int DPIX = HR * WP_TW;
     static constexpr int DPLANE = DPIX * DROW, XPLANE = XSLOTS * XPITCH;
     static constexpr int STAGE = 2 * DPLANE + 2 * XPLANE;
@@ -65,7 +67,7 @@ struct WgCfg {
     static constexpr int XPP = NTHR / XQ;                            // x pixels per staging pass
     static constexpr int NX = (XPIX + XPP - 1) / XPP;                // x float4 items per thread and stage (last one partial)
     static constexpr int UPK = 2 * (ND + NX) / KSW;                  // staging units (half items) per k-step of a wave
-    static_assert((BM == 128 || BM == 32) && (BN == 64 || BN == 32) && HR % WK == 0 && DPIX % PJ == 0 && (PJ == 8 || PJ % 16 == 0)
+    static_assert((BM == 128 || BM == 64 || BM == 32) && (BN == 64 || BN == 32) && HR % WK == 0 && DPIX % PJ == 0 && (PJ == 8 || PJ % 16 == 0)
                   && (2 * (ND + NX)) % KSW == 0, "config");
     __host__ __device__ static constexpr int sub_base(int py, int px) {
         return S == 1 ? 0 : (py == 0 ? px * (HR + 1) * SUBW : 2 * (HR + 1) * SUBW + px * HR * SUBW);
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
     const int dq = tid % C::DQ, dp0 = tid / C::DQ;
     const int d_goff = ((((dp0 >> 4) * g.OW + (dp0 & 15)) * a.Cout) + co0 + dq * 4) * 4;       // pixel dp0 = (row dp0 >> 4, column dp0 & 15) of the stage
     const int d_lds = BM == 128 ? dp0 * WP_DROW + (((dq >> 3) ^ (dp0 & 3)) * 64) + (dq & 7) * 8       // + j * PJ * WP_DROW   (PJ % 4 == 0: same swizzle)
+                    : BM == 64  ? dp0 * WP_DROW + (((dq >> 3) ^ ((dp0 >> 1) & 1)) * 64) + (dq & 7) * 8
                                 : dp0 * WP_DROW + dq * 8;
     // x: item j = patch pixel (tid / XQ) + XPP j, channel quad q = tid % XQ
     const int xq = tid % C::XQ, xp0 = tid / C::XQ;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
     const int grp = lane >> 4, li = lane & 15;
     const int m0 = 16 * (grp & 1), kb = 8 * (grp >> 1);
     // (+ the rows of this wave's k-steps when the waves of a block split them)
-    const int a_lane = (kb + (li >> 2) + wk * 16) * WP_DROW + (BM == 128 ? ((wm ^ (li >> 2)) * 64) : 0) + m0 * 2 + (li & 3) * 8;
+    const int a_lane = (kb + (li >> 2) + wk * 16) * WP_DROW + (BM == 128 ? ((wm ^ (li >> 2)) * 64) : BM == 64 ? ((wm ^ ((li >> 3) & 1)) * 64) : 0) + m0 * 2 + (li & 3) * 8;
     const int b_lane = 2 * DPLANE + (kb + (li >> 2) + wk * C::ROWSLOTS) * XPITCH + wn * 64 + m0 * 2 + (li & 3) * 8;
 
     auto frag = [&](const unsigned char* p, int rowpitch) -> f16x8 {
@@ -346,7 +349,9 @@ static bool window9(const ConvGeom& g, int* y0, int* x0, WgPatchSlots* sl) {
     return seen == 0x1ffu;
 }
 
-// which instance takes a layer: 0 none, 1 = <1,128,64,4,1>, 2 = <2,128,32,2,1>, 3 = <1,32,32,4,4>
+// which instance takes a layer: 0 none, 1 = <1,128,64,4,1>, 2 = <2,128,32,2,1>, 3 = <1,32,32,4,4>, 4 = <1,64,64,2,1> (round 3: the 64-channel stride-1
+// layers -- ResNet-18 layer1 on 56 x 56 maps, G.convblock3 -- ran on the narrow instance, whose four waves stage a 32-channel dy row and a
+// 32-channel x patch for ONE 32 x 32 tile; four tiles per block halve the staging per MFMA)
 static int pick(const ConvGeom& g, int Cout, int C1, int C2) {
     if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2)) return 0;
     if ((long)g.N * ((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW) < 64) return 0;
@@ -355,11 +360,12 @@ static int pick(const ConvGeom& g, int Cout, int C1, int C2) {
     if (!window9(g, nullptr, nullptr, nullptr)) return 0;
     if (g.my == 2) return (Cout % 128 == 0 && C1 % 32 == 0 && C2 % 32 == 0 && C1 >= 32) ? 2 : 0;
     if (Cout % 128 == 0 && C1 % 64 == 0 && C2 % 64 == 0 && C1 >= 64) return 1;
+    if (Cout % 64 == 0 && C1 % 64 == 0 && C2 % 64 == 0 && C1 >= 64) { const char* e = getenv("VIAI_WGRAD_PATCH_64"); if (!e || atoi(e)) return 4; }
     if (Cout % 32 == 0 && C1 % 32 == 0 && C2 % 32 == 0 && C1 >= 32) return 3;
     return 0;
 }
-static int bm_of(int cfg) { return cfg == 3 ? 32 : 128; }
-static int bn_of(int cfg) { return cfg == 1 ? 64 : 32; }
+static int bm_of(int cfg) { return cfg == 3 ? 32 : cfg == 4 ? 64 : 128; }
+static int bn_of(int cfg) { return (cfg == 1 || cfg == 4) ? 64 : 32; }
 static int wk_of(int cfg) { (void)cfg; return 1; }      // slabs per block (the k-splitting waves of the narrow instance reduce in the block)
 
 template <int S, int BM, int BN, int HR, int WK>
@@ -367,7 +373,7 @@ static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hi
     using C = WgCfg<S, BM, BN, HR, WK>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_patch_f16_kernel<S, BM, BN, HR, WK>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); attr_done = true; }
-    viai_tag_kernel(S == 2 ? "wgrad_patch_s2_f16x2" : BM == 32 ? "wgrad_patch_narrow_f16x2" : "wgrad_patch_f16x2");
+    viai_tag_kernel(S == 2 ? "wgrad_patch_s2_f16x2" : BM == 32 ? "wgrad_patch_narrow_f16x2" : BM == 64 ? "wgrad_patch64_f16x2" : "wgrad_patch_f16x2");
     VIAI_LAUNCH((wgrad_patch_f16_kernel<S, BM, BN, HR, WK>), dim3(a.nblk_co * a.nblk_ci * a.ksplit), dim3(C::NTHR), C::LDS, st, a, y0, x0, sl);
     return viai_launch_status();
 }
@@ -376,8 +382,10 @@ static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hi
 static int block_ksplit(const ConvGeom& g, int Cout, int Cin, int cfg) {
     const long tiles = (long)g.N * ((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW);
     const long per = (long)(Cout / bm_of(cfg)) * (Cin / bn_of(cfg));
+    static long blk4 = -1;
+    if (blk4 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_64"); blk4 = e ? atol(e) : 192; }
     constexpr long blk1 = 192, blk2 = 192, blk3 = 128;       // stride-1 / stride-2 / narrow instance (measured optimum of the three-stream step, see below)
-    long ks = (cfg == 2 ? blk2 : cfg == 3 ? blk3 : blk1) / per;
+    long ks = (cfg == 2 ? blk2 : cfg == 3 ? blk3 : cfg == 4 ? blk4 : blk1) / per;
     // the sub-CU grids above suit the audio step, whose weight gradients are short and share the chip with the main chain; a layer with
     // hundreds of tiles per block (the ResNet branch on 1024 frames) is worth every CU
     if (ks >= 1 && tiles / ks > 128) ks = 256 / per;
@@ -431,5 +439,6 @@ int viai_wgrad_patch_launch(WgradArgs& a, hipStream_t st) {
     a.nblk_ci = Cin / bn_of(cfg);
     if (cfg == 2) return launch_patch<2, 128, 32, 2, 1>(a, y0, x0, sl, st);
     if (cfg == 3) return launch_patch<1, 32, 32, 4, 4>(a, y0, x0, sl, st);
+    if (cfg == 4) return launch_patch<1, 64, 64, 2, 1>(a, y0, x0, sl, st);
     return launch_patch<1, 128, 64, 4, 1>(a, y0, x0, sl, st);
 }
