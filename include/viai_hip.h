@@ -293,6 +293,11 @@ int viai_wavenet_synth_run(const viai_wn_synth* s, int t0, int n_steps, void* st
  * s_in = s * mask, mask (N, T) broadcast over frequency (the missing
  * AudioModel.set_inputs; figure misc/pipeline2.png)                             */
 int viai_mask_mul(const float* s, const float* mask, float* out, int N, int F, int T, void* stream);
+/* the loss scalars an iteration reports (train_whole_sync.py:85-112 reads them through get_loss_items / get_current_errors), from the
+ * device scalars the loss kernels left: out[0] = 0.5 (d_fake + d_real), out[1] = g_gan + lambda_l1 l1 (+ lambda_c contrast), out[2] = g_gan,
+ * out[3] = l1, out[4] = d_real, out[5] = contrast (only when contrast != NULL).  One launch instead of ten one-element kernels.     */
+int viai_step_scalars(const float* d_real, const float* d_fake, const float* g_gan, const float* l1, const float* contrast,
+                      float lambda_l1, float lambda_c, float* out, void* stream);
 /* torch.optim.Adam step on a flat fp32 arena (optimizer_G / optimizer_D,
  * utils/util.py:149-150).  `state` is 4 device doubles {step, lr, beta1^t, beta2^t}
  * (initialise to {0, lr, 1, 1}) advanced ON DEVICE so that the launch is

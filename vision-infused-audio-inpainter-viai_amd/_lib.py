@@ -81,6 +81,7 @@ SIGNATURES = {
     "viai_conv2d_wgrad_ws_bytes": (C.c_size_t, [_CP]),
     "viai_conv2d_wgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P]),
     "viai_conv2d_last_kernel": (_I, [C.c_char_p, _I]),
+    "viai_step_scalars": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P]),
     "viai_pack_weight": (_I, [_P, _P, _I, _I, _I, _L, _L, _P]),
     "viai_bn_finalize": (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "viai_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),

@@ -130,6 +130,23 @@ extern "C" int viai_mse_bwd(const float* p, float t, long n, const float* gs, fl
 extern "C" int viai_l1_fwd(const float* a, const float* b, long n, float* part, float* loss, void* s) { return loss_fwd<L_L1>(a, b, 0.f, n, part, loss, s); }
 extern "C" int viai_l1_bwd(const float* a, const float* b, long n, const float* gs, float* da, void* s) { return loss_bwd<L_L1>(a, b, 0.f, n, gs, da, s); }
 
+// the six loss scalars of a G+D step in ONE launch (they were ~10 one-element torch kernels at the two ends of the step's critical path):
+//   out[0] = 0.5 (d_fake + d_real)   out[1] = g_gan + lambda_l1 l1 (+ lambda_c contrast)   out[2] = g_gan   out[3] = l1   out[4] = d_real
+//   out[5] = contrast (untouched when contrast == NULL)
+__global__ void step_scalars_kernel(const float* d_real, const float* d_fake, const float* g_gan, const float* l1, const float* contrast,
+                                    float lambda_l1, float lambda_c, float* out) {
+    const float dr = *d_real, df = *d_fake, gg = *g_gan, l = *l1;
+    float lg = gg + lambda_l1 * l;
+    if (contrast != nullptr) { const float c = *contrast; lg = lg + lambda_c * c; out[5] = c; }
+    out[0] = 0.5f * (df + dr); out[1] = lg; out[2] = gg; out[3] = l; out[4] = dr;
+}
+extern "C" int viai_step_scalars(const float* d_real, const float* d_fake, const float* g_gan, const float* l1, const float* contrast,
+                                 float lambda_l1, float lambda_c, float* out, void* stream) {
+    if (!d_real || !d_fake || !g_gan || !l1 || !out) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(step_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_real, d_fake, g_gan, l1, contrast, lambda_l1, lambda_c, out);
+    return viai_launch_status();
+}
+
 extern "C" int viai_mask_mul(const float* s, const float* mask, float* out, int N, int F, int T, void* stream) {
     long total = (long)N * F * T;
     VIAI_LAUNCH(mask_mul_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, mask, out, N, F, T);

@@ -520,16 +520,13 @@ class AudioModel:
             loss_real.record_stream(main)                              # allocated on `side`, read below on main
             self._arm_hooks(self.arena_D, self._early_D, 1)
             loss_fake.backward(self._const(0.5))
-            loss_d = 0.5 * (loss_fake.detach() + loss_real.detach())
         else:
-            loss_d = 0.5 * (loss_fake + loss_real)
             self._arm_hooks(self.arena_D, self._early_D, 2)
-            loss_d.backward()
+            torch.autograd.backward([loss_fake, loss_real], [self._const(0.5), self._const(0.5)])      # d(0.5 (fake + real)): the factor as seeds
         ops.join_wgrad()
         if self._finish_exchange(self.arena_D, self._late_D):
             main.wait_stream(self._comm)                               # Adam(D) and the G step need the reduced D gradients
-        self._put(0, loss_d.detach())
-        self._put(4, loss_real.detach())
+        self._loss_real, self._loss_fake = loss_real.detach(), loss_fake.detach()      # -> losses[0], losses[4] at the end of the step (one launch)
 
     def _seg_dupdate_gstep(self, update=True):
         if update:
@@ -548,17 +545,16 @@ class AudioModel:
             seeds.append(self._const(self.cfg.lambda_contrast))
         self._arm_hooks(self.arena_G, self._early_G, 1)
         torch.autograd.backward(roots, seeds)
-        loss_g = loss_gan.detach() + self.cfg.lambda_l1 * loss_l1.detach()
         if self._lc is not None:
-            loss_g = loss_g + self.cfg.lambda_contrast * self._lc.detach()
             self.EmbeddingL2 = self._lc.detach()
-            self._put(5, self.EmbeddingL2)
         ops.join_wgrad()
         self._g_exchanged = self._finish_exchange(self.arena_G, self._late_G)
         self.netD.requires_grad_(True)
-        self._put(1, loss_g.detach())
-        self._put(2, loss_gan.detach())
-        self._put(3, loss_l1.detach())
+        # the six scalars get_loss_items reports, in one launch
+        check(lib().viai_step_scalars(self._loss_real.data_ptr(), self._loss_fake.data_ptr(), loss_gan.data_ptr(), loss_l1.data_ptr(),
+                                      self._lc.data_ptr() if self._lc is not None else 0, float(self.cfg.lambda_l1), float(self.cfg.lambda_contrast),
+                                      self.losses.data_ptr(), torch.cuda.current_stream().cuda_stream), "viai_step_scalars")
+        self._scalars_src = (self._loss_real, self._loss_fake, loss_gan, loss_l1, self._lc)       # alive until the launch has run
         self._pred_fake_g = pred
 
     def _seg_gupdate(self):
