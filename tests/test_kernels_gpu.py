@@ -524,6 +524,22 @@ def test_ganloss_module_matches_reference_semantics():
             assert abs(out.item() - O.gan_loss(p, real, lsgan).item()) < 1e-5
 
 
+def test_ganloss_soft_labels_match_reference_golden(golden_dir):
+    """GANLoss(..., softlabel=True) (loss_functions.py:90-99): label = real - U(0, 0.1) / fake + U(0, 0.1) drawn from Python's `random`,
+    one draw per call: with the generator seeded like the fixture's, the reference's five values per loss kind
+    (tests/golden/ganloss_soft.npz, tools/make_goldens.py --ganloss-soft-only), call for call."""
+    import random
+    from viai_amd import losses
+    gold = np.load(golden_dir + "/ganloss_soft.npz")
+    p = O.cf_uniform("gl.p", (4, 1, 8, 4), 0.01, 0.99).cuda()
+    for lsgan in (False, True):
+        crit = losses.GANLoss(use_lsgan=lsgan)
+        random.seed(20260929)
+        vals = [crit(p, real, softlabel=True).item() for real in (True, False, True, True, False)]
+        assert np.allclose(vals, gold["lsgan%d" % int(lsgan)], rtol=2e-6, atol=0), (vals, gold["lsgan%d" % int(lsgan)])
+        assert len(set(np.round(vals, 6))) == 5                 # five different labels: the draws really happen
+
+
 def test_bf16x3_path_is_fp32_grade():
     """Large layers run on the split-bf16 ("bf16x3") MFMA kernel (csrc/conv_igemm_bf3.hip).  Its error against an
     fp64 evaluation must stay at the fp32 level: within 4x of the CPU fp32 convolution's own rounding error

@@ -194,6 +194,22 @@ def run_case(name, B, F_bins, T, steps, full):
           % (name, B, F_bins, T, steps, worst, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def ganloss_soft_goldens():
+    """GANLoss(softlabel=True) (loss_functions.py:90-99): the label is real - U(0, 0.1) / fake + U(0, 0.1) from Python's `random`; with
+    the generator seeded the reference's values are reproducible -- and so is the ORDER of its draws (one per call)."""
+    import random
+    p = O.cf_uniform("gl.p", (4, 1, 8, 4), 0.01, 0.99)
+    out = OrderedDict()
+    for lsgan in (False, True):
+        crit = RefLoss.GANLoss(use_lsgan=lsgan, device=torch.device("cpu"))
+        random.seed(20260929)
+        vals = [crit(p, real, softlabel=True).item() for real in (True, False, True, True, False)]
+        out["lsgan%d" % int(lsgan)] = np.array(vals, dtype=np.float64)
+    path = os.path.join(OUT, "ganloss_soft.npz")
+    np.savez_compressed(path, **out)
+    print("ganloss_soft -> %s (%.1f KB)" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 CHAIN_STEPS = 3
 SHADOWED_CHAIN = ("G.deconv1_1.bias", "G.deconv1_2.bias", "G.conv6_1.bias")   # bias in front of train-mode BN: exact gradient 0
 
@@ -1017,6 +1033,9 @@ if __name__ == "__main__":
     if "--wavenet-onehot-only" in sys.argv:
         wavenet_onehot_goldens()
         sys.exit(0)
+    if "--ganloss-soft-only" in sys.argv:
+        ganloss_soft_goldens()
+        sys.exit(0)
     if "--chain-only" in sys.argv:
         chain_goldens()
         sys.exit(0)
@@ -1061,6 +1080,7 @@ if __name__ == "__main__":
     checkpoint_structure_golden()
     run_case("tiny", 2, 80, 32, 3, full=True)        # smallest valid shape
     chain_goldens()
+    ganloss_soft_goldens()
     run_case("cfg1", 4, 128, 128, 1, full=False)      # BASELINE.json configs[0]
     if "--cfg2" in sys.argv:
         run_case("cfg2", 16, 256, 256, 1, full=False)  # configs[1]; ~1 min on 8 cores

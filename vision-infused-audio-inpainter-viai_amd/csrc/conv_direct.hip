@@ -763,6 +763,100 @@ __global__ __launch_bounds__(256) void cout1_wgrad_run_kernel(const DirectArgs a
     }
 }
 
+// sum over the LPP consecutive lanes of a lane group (LPP = 8 .. 64, a power of two); every lane of the group gets the sum
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // xor 1
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // xor 2
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // mirror within 8 lanes
+    if constexpr (LPP >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});     // mirror within 16 lanes
+    if constexpr (LPP >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (LPP >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// Forward of the Cout = 1 layer of a fused pair, every input element read ONCE: z = act_in(scale * y + shift) is formed when a lane
+// group loads its input pixel, the pixel's nine partial dot products d[t] = <z, w[t]> are reduced across the group and stored into nine
+// LDS planes at the output pixel each belongs to; after a barrier an output is bias + the sum of its nine planes in tap order
+// (deterministic: every (tap, output) cell has exactly one writer, cells whose input pixel lies outside the image stay zero).
+// Block = R output rows x the full width of one image; it walks the R + 2 input rows those outputs touch.  (The row-run kernel above
+// fetches every input element 3 (L + 2) / L times and, with BatchNorm on load, normalised it as often: 36 -> 106 us on D.conv4.)
+template <int LPP, int CPL, bool FWD>
+__global__ __launch_bounds__(256) void cout1_pair_fwd_kernel(const DirectArgs a, int R) {
+    constexpr int KH = 3, KW = 3, PPB = 256 / LPP;
+    extern __shared__ __attribute__((aligned(16))) float part[];      // [9][R][W]
+    const int tid = threadIdx.x, cl = tid % LPP, grp = tid / LPP;
+    const int W = a.IW, bpi = (a.IH + R - 1) / R;
+    const int n = blockIdx.x / bpi, r0 = (blockIdx.x - n * bpi) * R;
+    const int rows = min(R, a.OH - r0);
+    const int plane = R * W;
+    for (int i = tid; i < 9 * plane; i += 256) part[i] = 0.f;
+    f32x4 wv[KH * KW][CPL], sc[CPL], sh[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        sc[c] = *reinterpret_cast<const f32x4*>(a.scale + (c * LPP + cl) * 4);
+        sh[c] = *reinterpret_cast<const f32x4*>(a.shift + (c * LPP + cl) * 4);
+#pragma unroll
+        for (int t = 0; t < KH * KW; ++t) wv[t][c] = *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.Cin + (c * LPP + cl) * 4);
+    }
+    __syncthreads();
+    // input rows r0 - 1 .. r0 + rows (inside the image), all columns: pixel index q over (rows + 2) x W
+    const int iy_lo = max(r0 - 1, 0), iy_hi = min(r0 + rows, a.IH - 1);
+    const int npix = (iy_hi - iy_lo + 1) * W;
+    constexpr int U = CPL >= 2 ? 4 : 8;                     // input pixels in flight per lane group (a block is 4 .. 32 groups: latency, not issue, bounds it)
+    for (int q0 = 0; q0 < npix; q0 += U * PPB) {
+        f32x4 v[U][CPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = min(q0 + u * PPB + grp, npix - 1);
+            const float* src = a.x + ((size_t)(n * a.IH + iy_lo) * W + q) * a.Cin + cl * 4;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) v[u][c] = *reinterpret_cast<const f32x4*>(src + c * LPP * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u * PPB + grp;
+            const int iy = iy_lo + q / W, ix = q % W;
+            float d[KH * KW];
+#pragma unroll
+            for (int t = 0; t < KH * KW; ++t) d[t] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                f32x4 z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = viai_act(v[u][c][e] * sc[c][e] + sh[c][e], a.act_in, a.slope);
+#pragma unroll
+                for (int t = 0; t < KH * KW; ++t) d[t] += z[0] * wv[t][c][0] + z[1] * wv[t][c][1] + z[2] * wv[t][c][2] + z[3] * wv[t][c][3];
+            }
+#pragma unroll
+            for (int t = 0; t < KH * KW; ++t) d[t] = group_sum<LPP>(d[t]);
+            if (cl == 0 && q < npix) {
+#pragma unroll
+                for (int r = 0; r < KH; ++r) {
+                    const int oy = iy - tap_dy(a, r) - r0;              // output row (within the block) this input row feeds through tap row r
+                    if ((unsigned)oy >= (unsigned)rows) continue;
+#pragma unroll
+                    for (int s_ = 0; s_ < KW; ++s_) {
+                        const int ox = ix - tap_dx(a, s_);
+                        if ((unsigned)ox < (unsigned)W) part[(r * KW + s_) * plane + oy * W + ox] = d[r * KW + s_];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float bias = a.bias ? a.bias[0] : 0.f;
+    for (int i = tid; i < rows * W; i += 256) {
+        float s = bias;
+#pragma unroll
+        for (int t = 0; t < KH * KW; ++t) s += part[t * plane + i];
+        a.y[(size_t)(n * a.OH + r0) * W + i] = viai_act(s, a.act, a.slope);
+    }
+}
+
 __device__ __forceinline__ float pair_act_grad(float pre, int act, float slope) {
     if (act == VIAI_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
     if (act == VIAI_ACT_LRELU) return pre > 0.f ? 1.f : slope;
@@ -1345,18 +1439,18 @@ extern "C" int viai_pair_cout1_fwd(const viai_conv2d* c, const float* y, const f
     DirectArgs a = make_args(c);
     a.x = y; a.w = wp; a.bias = bias; a.y = out; a.act = act; a.slope = 0.2f; a.scale = scale; a.shift = shift; a.act_in = act_in;
     const int cin = a.Cin;
-    const int lpp = cin >= 256 ? 64 : cin / 4;
-    const int L = cin == 512 ? 2 : 4;
-    long nb2 = ((long)a.N * a.OH * (a.OW / L) * lpp + 255) / 256;
-    if (nb2 > 8192) nb2 = 8192;
-    const dim3 g2((unsigned)nb2), b2(256);
+    // rows per block: as many as keep >= 512 blocks in flight and the nine planes within 64 KB of LDS
+    int R = 8;
+    while (R > 1 && ((long)a.N * ((a.IH + R - 1) / R) < 256 || (size_t)9 * R * a.IW * sizeof(float) > 65536)) R >>= 1;
+    const dim3 g2((unsigned)(a.N * ((a.IH + R - 1) / R))), b2(256);
+    const size_t lds = (size_t)9 * R * a.IW * sizeof(float);
     viai_tag_reset();
     viai_tag_kernel("direct");
-#define RUN(LPP_, CPL_, L_)                                                                                                    \
-    do { if (a.transposed) VIAI_LAUNCH((cout1_fwd_run_kernel<LPP_, CPL_, L_, false, true>), g2, b2, 0, st, a);                 \
-         else VIAI_LAUNCH((cout1_fwd_run_kernel<LPP_, CPL_, L_, true, true>), g2, b2, 0, st, a); } while (0)
-    if (cin == 32) RUN(8, 1, 4); else if (cin == 64) RUN(16, 1, 4); else if (cin == 128) RUN(32, 1, 4);
-    else if (cin == 256) RUN(64, 1, 4); else RUN(64, 2, 2);
+#define RUN(LPP_, CPL_)                                                                                                          \
+    do { if (a.transposed) VIAI_LAUNCH((cout1_pair_fwd_kernel<LPP_, CPL_, false>), g2, b2, lds, st, a, R);                       \
+         else VIAI_LAUNCH((cout1_pair_fwd_kernel<LPP_, CPL_, true>), g2, b2, lds, st, a, R); } while (0)
+    if (cin == 32) RUN(8, 1); else if (cin == 64) RUN(16, 1); else if (cin == 128) RUN(32, 1);
+    else if (cin == 256) RUN(64, 1); else RUN(64, 2);
 #undef RUN
     return viai_launch_status();
 }

@@ -723,6 +723,7 @@ def _tag_amax(z, cfg):
 
 
 PAIR_FUSED = os.environ.get("VIAI_PAIR_FUSED", "1") != "0"     # (conv + BN + act) -> (Cout = 1 conv) pairs as one op (A/B switch)
+PAIR_FWD_FUSED = os.environ.get("VIAI_PAIR_FWD_FUSED", "1") != "0"     # ... and their forward without the tensor in between (A/B switch)
 
 
 class _ConvBnActCout1(torch.autograd.Function):
@@ -773,15 +774,17 @@ class _ConvBnActCout1(torch.autograd.Function):
                                                coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st),
                        "viai_bn_eval_coeffs")
         p = torch.empty((N, OH, OW, 1), device=dev, dtype=torch.float32)
-        if cfg.get("fwd_on_load"):
-            # BatchNorm + activation applied while the Cout = 1 kernel loads y: no z at all.  Measured SLOWER (D.conv4 36 -> 106 us,
-            # G.conv6_2 57 -> 129 us): the row-run kernel fetches every input element 3 (L + 2) / L = 4.5 .. 6 times from L1 / L2 and
-            # now normalises it as often, which turns a streaming kernel into a VALU-bound one.  Kept for the record, off.
+        if PAIR_FWD_FUSED and Cmid <= 64:
+            # BatchNorm + activation applied where the one-channel conv loads y: no z at all.  `cout1_pair_fwd_kernel` reads every input
+            # element once (a lane group owns an INPUT pixel and deposits its nine partial dot products in LDS planes); the first
+            # attempt -- BatchNorm on load inside the row-run forward kernel, which fetches every element 4.5 - 6 times -- was 3x slower.
+            # Standalone (tools/profile_pair.py): G.conv6_1 -> conv6_2 (32 channels, 256 x 256) 62 us against 46 + 57 for the two
+            # launches; D.conv3 -> conv4 (512 channels on 64 x 32 maps) 67 us against 24 + 38 -- a whole wave per pixel leaves four
+            # lane groups per block and 12 dependent load rounds each, so wide layers keep the two launches
             _lib.check(lib.viai_pair_cout1_fwd(d2["ref"], y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), cfg["act"], wp2.data_ptr(),
                                                _ptr(b2), p.data_ptr(), cfg["act2"], st), "viai_pair_cout1_fwd")
         else:
-            # z exists only between these two launches: the backward works from y (z is re-formed on load where it is needed once per
-            # element: the Cout = 1 layer's weight gradient), so it is not kept
+            # z exists only between these two launches: the backward works from y
             z = torch.empty_like(y)
             _lib.check(lib.viai_bn_act_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(), M, Cmid, cfg["act"], 0.2, st),
                        "viai_bn_act_fwd")
