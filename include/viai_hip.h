@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 8
+#define VIAI_ABI_VERSION 9
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -81,6 +81,10 @@ int viai_pack_jobs_run(const viai_pack_job* jobs_dev, int njobs, int total_block
 /* BatchNorm partial-statistics geometry of the forward kernel: number of row
  * blocks and rows per block; stat_part holds 2*Cout*nblk floats.                */
 int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_per_blk);
+/* (ABI 9) Where the forward kernel works on 2-D output tiles and the map is not a whole number of them, the partial blocks are
+ * tiles clipped at the map's edge (block = (n, tile row, tile column), row-major), not runs of rows_per_blk rows: tile_h x tile_w
+ * is returned here (0, 0 otherwise) and the partials go to viai_bn_finalize_tiles instead of viai_bn_finalize.                    */
+int viai_conv2d_stat_tiles(const viai_conv2d* c, int* tile_h, int* tile_w);
 /* y = conv(x ++ x2, w) + bias [; act].  stat_part (optional) receives per-block
  * per-channel (mean, M2) of y for training-mode BatchNorm; act must be NONE then. */
 int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float* x2, const float* wp_fwd,
@@ -143,6 +147,12 @@ int viai_bn_finalize(const float* stat_part, int nblk, int rows_per_blk, long M,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, float momentum, float eps,
                      float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* (ABI 9) the same merge where block b = tile (n, ty, tx) of tile_h x tile_w output pixels clipped at the edge of the OH x OW map
+ * (viai_conv2d_stat_tiles): N * ceil(OH / tile_h) * ceil(OW / tile_w) blocks of min(tile_h, OH - ty tile_h) * min(tile_w, OW - tx tile_w) rows */
+int viai_bn_finalize_tiles(const float* stat_part, int N, int OH, int OW, int tile_h, int tile_w, int C,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, float momentum, float eps,
+                           float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* eval mode: (scale, shift) from the running statistics */
 int viai_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* mean, float* invstd,

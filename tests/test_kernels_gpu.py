@@ -826,3 +826,73 @@ def test_time_mask_applied_where_the_first_conv_loads_its_input(geom, need_dx):
     a = ops.conv_bn_act(nhwc(x), w.cuda(), None, bn, kernel=k, stride=s_, padding=p_, act=ops.ACT_LRELU, xmask=mask.cuda(), training=False)
     b = ops.conv_bn_act(ops.mask_mul(nhwc(x), mask.cuda()), w.cuda(), None, bn, kernel=k, stride=s_, padding=p_, act=ops.ACT_LRELU, training=False)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cfg", [(8, 56, 56, 64, 64), (8, 28, 28, 128, 128), (16, 14, 14, 256, 256), (4, 80, 104, 64, 128), (24, 22, 44, 128, 32)],
+                         ids=["56x56_64to64", "28x28_128to128", "14x14_256to256", "80x104_64to128", "22x44_128to32"])
+def test_wide_halo_kernel_on_maps_with_partial_tiles(cfg):
+    """the 8 x 16 tiles of the wide halo kernel clipped at the map's edge (the 56 / 28 / 14-pixel maps of networks/Image_Embedding.py:13-71,
+    the 80 x 104 maps of the reference's native 80 x 208 clips): conv -> BatchNorm(train) -> ReLU with the batch statistics merged from
+    tile-shaped partial blocks of unequal size, forward + running statistics + every gradient against an fp64 evaluation."""
+    from viai_amd import _lib, ops
+    import ctypes as C
+    N, H, W, Ci, Co = cfg
+    d = ops.conv_desc(N, H, W, Ci, 0, Co, 3, 3, 1, 1, 1, 1, 0)
+    assert d["tiles"] == (8, 16) and d["nblk"] == N * ((H + 7) // 8) * ((W + 15) // 16)
+    x = O.cf_uniform("pt.x", (N, Ci, H, W), -1, 1)
+    w = O.cf_std("pt.w", (Co, Ci, 3, 3), 0.05)
+    gy = O.cf_uniform("pt.gy", (N, Co, H, W), -1, 1)
+    g = O.cf_uniform("pt.g", (Co,), 0.8, 1.2)
+    b = O.cf_uniform("pt.b", (Co,), -0.1, 0.1)
+
+    def run(dt):
+        xs, ws, gs, bs = [t.clone().to(dt).requires_grad_(True) for t in (x, w, g, b)]
+        rm, rv = torch.zeros(Co, dtype=dt), torch.ones(Co, dtype=dt)
+        z = F.relu(F.batch_norm(F.conv2d(xs, ws, None, stride=1, padding=1), rm, rv, gs, bs, True, 0.1, 1e-5))
+        return (z,) + torch.autograd.grad(z, [xs, ws, gs, bs], grad_outputs=gy.to(dt)) + (rm, rv)
+    truth, cpu32 = run(torch.float64), run(torch.float32)
+    bn = torch.nn.BatchNorm2d(Co).cuda().train()
+    bn.weight.data.copy_(g); bn.bias.data.copy_(b)
+    xg = nhwc(x).requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    ops.begin_step(xg.device)
+    zg = ops.conv_bn_act(xg, wg, None, bn, kernel=(3, 3), stride=(1, 1), padding=(1, 1), act=ops.ACT_RELU)
+    buf = C.create_string_buffer(64)
+    zg.backward(nhwc(gy))
+    hip = (nchw(zg), nchw(xg.grad), wg.grad, bn.weight.grad, bn.bias.grad, None, bn.running_var)
+    for nm, h, c32, t in zip(("z", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var"), hip, cpu32, truth):
+        if h is not None:
+            assert relerr(h, t) < 5 * relerr(c32, t) + 1e-6, (nm, relerr(h, t), relerr(c32, t))
+    # the batch mean is ~1e-3 of the batch deviation here: its error is measured against the deviation, not against itself
+    sd = ((truth[6] - 0.9) / 0.1).sqrt()
+    assert float(((bn.running_mean.cpu().double() - truth[5]).abs() / (0.1 * sd)).max()) < 1e-6
+    # the forward ran on the wide halo kernel (not on the gather kernel these shapes used before)
+    ops.begin_step(xg.device)
+    with torch.no_grad():
+        ops.conv_bn_act(xg, wg, None, bn, kernel=(3, 3), stride=(1, 1), padding=(1, 1), act=ops.ACT_RELU, training=False)
+    _lib.load().viai_conv2d_last_kernel(buf, 64)
+    assert buf.value.decode().startswith("halo_wide"), buf.value
+
+
+def test_tiled_batchnorm_merge_matches_the_uniform_merge():
+    """viai_bn_finalize_tiles on a map that IS a whole number of tiles equals viai_bn_finalize on the same partials bit for bit"""
+    from viai_amd import _lib
+    lib = _lib.load()
+    N, OH, OW, Cc = 3, 16, 32, 8
+    nblk = N * 2 * 2
+    part = torch.randn(2 * Cc * nblk, device="cuda").abs_()
+    gam, bet = torch.rand(Cc, device="cuda") + 0.5, torch.randn(Cc, device="cuda")
+    outs = []
+    for tiled in (False, True):
+        rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+        coef = torch.empty(4, Cc, device="cuda")
+        tail = (Cc, gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0, 0.1, 1e-5, coef[0].data_ptr(), coef[1].data_ptr(),
+                coef[2].data_ptr(), coef[3].data_ptr(), 0)
+        if tiled:
+            _lib.check(lib.viai_bn_finalize_tiles(part.data_ptr(), N, OH, OW, 8, 16, *tail), "tiles")
+        else:
+            _lib.check(lib.viai_bn_finalize(part.data_ptr(), nblk, 128, N * OH * OW, *tail), "uniform")
+        torch.cuda.synchronize()
+        outs.append((coef.clone(), rm.clone(), rv.clone()))
+    for u, t in zip(*outs):
+        assert torch.equal(u, t)

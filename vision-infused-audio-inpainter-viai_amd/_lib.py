@@ -84,6 +84,8 @@ SIGNATURES = {
     "viai_step_scalars": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P]),
     "viai_pack_weight": (_I, [_P, _P, _I, _I, _I, _L, _L, _P]),
     "viai_bn_finalize": (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "viai_bn_finalize_tiles": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "viai_conv2d_stat_tiles": (_I, [_CP, _IP, _IP]),
     "viai_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
     "viai_bn_act_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "viai_bn_bwd_blocks": (_I, [_L, _I]),

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ part, int nblk, int rows, long M, int C,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
-    float* mean_o, float* invstd_o, float* scale_o, float* shift_o) {
+    float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int th, int tw, int OH, int OW) {
     __shared__ double red[4];
     const int c = blockIdx.x;
     const float* pm = part + (size_t)c * nblk;
@@ -47,8 +47,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     }
     const double k = (double)pm[0];
     double s = 0.0, q = 0.0;
+    // th > 0: block b is the th x tw output tile (n, ty, tx) of an OH x OW map, clipped at the map's edge (viai_bn_finalize_tiles)
+    const int tiles_x = th > 0 ? (OW + tw - 1) / tw : 1, tiles_y = th > 0 ? (OH + th - 1) / th : 1;
     for (int b = threadIdx.x; b < nblk; b += 256) {
-        const double nb = (b == nblk - 1) ? (double)last_n : (double)rows;
+        double nb = (b == nblk - 1) ? (double)last_n : (double)rows;
+        if (th > 0) {
+            const int tx = b % tiles_x, ty = (b / tiles_x) % tiles_y;
+            nb = (double)(min(th, OH - ty * th) * min(tw, OW - tx * tw));
+        }
         const double d = (double)pm[b] - k;
         s += nb * d;
         q += (double)p2[b] + nb * d * d;
@@ -351,7 +357,18 @@ extern "C" int viai_bn_finalize(const float* stat_part, int nblk, int rows_per_b
                                 float* mean, float* invstd, float* scale, float* shift, void* stream) {
     if (nblk <= 0 || C <= 0 || M <= 0) return (int)hipErrorInvalidValue;
     VIAI_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, nblk, rows_per_blk, M, C,
-                       gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift);
+                       gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, 0, 0, 0, 0);
+    return viai_launch_status();
+}
+
+extern "C" int viai_bn_finalize_tiles(const float* stat_part, int N, int OH, int OW, int tile_h, int tile_w, int C,
+                                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                      int64_t* nbt, float momentum, float eps,
+                                      float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    if (N <= 0 || OH <= 0 || OW <= 0 || tile_h <= 0 || tile_w <= 0 || C <= 0) return (int)hipErrorInvalidValue;
+    const int nblk = N * ((OH + tile_h - 1) / tile_h) * ((OW + tile_w - 1) / tile_w);
+    VIAI_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, nblk, tile_h * tile_w, (long)N * OH * OW, C,
+                       gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, tile_h, tile_w, OH, OW);
     return viai_launch_status();
 }
 

@@ -351,6 +351,18 @@ extern "C" int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_
     const int bm = (kind_of(c) == K_COUT1 || halo_fwd(c) || halo_wide_fwd(c)) ? 128 : sk_fwd(c) ? 32 : viai_igemm_tile_m(M, c->Cout);
     *rows_per_blk = bm;
     *nblk = (int)((M + bm - 1) / bm);
+    int th, tw;
+    if (viai_conv2d_stat_tiles(c, &th, &tw) == 0 && th > 0) *nblk = c->N * ((oh + th - 1) / th) * ((ow + tw - 1) / tw);
+    return 0;
+}
+
+extern "C" int viai_conv2d_stat_tiles(const viai_conv2d* c, int* tile_h, int* tile_w) {
+    if (!valid(c)) return (int)hipErrorInvalidValue;
+    *tile_h = *tile_w = 0;
+    if (kind_of(c) == K_CIN1 || kind_of(c) == K_COUT1 || !halo_wide_fwd(c)) return 0;
+    int oh, ow;
+    viai_conv2d_out_hw(c, &oh, &ow);
+    if (oh % 8 != 0 || ow % 16 != 0) { *tile_h = 8; *tile_w = 16; }       // the wide halo kernel's 8 x 16 tiles, clipped at the map's edge
     return 0;
 }
 

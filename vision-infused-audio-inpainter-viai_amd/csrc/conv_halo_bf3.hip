@@ -448,7 +448,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     const int wm = wave / WN, wn = wave % WN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bn = bid % a.nblk_n, tile = bid / a.nblk_n;
-    const int tiles_x = g.OW / HT_W, tiles_y = g.OH / HT_H;
+    // tiles cover the output map; where it is not a multiple of 8 x 16 (stride 1 only: the 56 / 28 / 14-pixel maps of the ResNet branch, the
+    // 80 x 104 maps of the reference's native 80 x 208 clips) the tile pixels outside are computed on zero-padded input and never stored
+    const int tiles_x = (g.OW + HT_W - 1) / HT_W, tiles_y = (g.OH + HT_H - 1) / HT_H;
     const int tx = tile % tiles_x; const int r_ = tile / tiles_x; const int ty = r_ % tiles_y, n = r_ / tiles_y;
     const int py = ty * HT_H * S + hy0, px = tx * HT_W * S + hx0;
     const int Cin = a.C1 + a.C2, k16 = Cin / 16, nch = Cin / 32, nch1 = a.C1 / 32;        // chunks [0, nch1) read a.in, the rest a.in2 (virtual concat)
@@ -618,35 +620,44 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
             const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
             const int oy = oy0 + 2 * (wm * TM + i) + (row >> 4), ox = ox0 + (row & 15);
             const size_t opix = ((size_t)n * g.OH + oy) * g.OW + ox;
+            const bool inside = oy < g.OH && ox < g.OW;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float v = acc[i][j][e] * inv + bv[j];
                 if (a.stat == nullptr) v = viai_act(v, a.act, a.slope);
-                acc[i][j][e] = v;
-                if (co[j] < a.Cout) {
+                acc[i][j][e] = inside ? v : 0.f;                  // (zeros outside: the statistics below skip them by count)
+                if (co[j] < a.Cout && inside) {
                     if (co[j] < a.OC1) a.out[opix * a.OC1 + co[j]] = v;
                     else a.out2[opix * (a.Cout - a.OC1) + (co[j] - a.OC1)] = v;
                 }
             }
         }
-    if (a.stat != nullptr) {          // (mean, M2) of the tile's 128 pixels per channel: per-wave two-pass over its rows, Chan merge of the WM waves
+    if (a.stat != nullptr) {          // (mean, M2) of the tile's VALID pixels per channel: per-wave two-pass over its rows, Chan merge of the WM waves
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem_h);          // [WM][2][BN]
-        constexpr float RW = (float)(32 * TM);                  // rows per wave
+        // valid pixels of this wave's rows: (tile rows 2 wm TM .. 2 (wm + 1) TM - 1 that lie inside the map) x (tile columns inside)
+        const int vc = min(HT_W, g.OW - ox0), vr_all = min(HT_H, g.OH - oy0);
+        auto rows_of = [&](int w) { const int lo = 2 * w * TM; return max(0, min(vr_all - lo, 2 * TM)); };
+        const float nw = (float)(rows_of(wm) * vc);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float t = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];           // pixels outside were set to zero above
             t += __shfl_xor(t, 32, 64);
-            const float mw = t * (1.f / RW);
+            const float mw = nw > 0.f ? t / nw : 0.f;
             float m2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { const float d = acc[i][j][e] - mw; m2 += d * d; }
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    const bool inside = oy0 + 2 * (wm * TM + i) + (row >> 4) < g.OH && ox0 + (row & 15) < g.OW;
+                    const float d = acc[i][j][e] - mw;
+                    m2 += inside ? d * d : 0.f;
+                }
             m2 += __shfl_xor(m2, 32, 64);
             if (half == 0) {
                 red[(wm * 2 + 0) * BN + (wn * TN + j) * 32 + col] = mw;
@@ -659,12 +670,13 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
             for (int j = 0; j < TN; ++j)
                 if (co[j] < a.Cout) {
                     const int c = (wn * TN + j) * 32 + col;
+                    const float ntot = (float)(vr_all * vc);
                     float mean = 0.f, M2 = 0.f;
 #pragma unroll
-                    for (int w = 0; w < WM; ++w) { mean += red[(w * 2) * BN + c]; M2 += red[(w * 2 + 1) * BN + c]; }
-                    mean *= 1.f / (float)WM;
+                    for (int w = 0; w < WM; ++w) { mean += (float)(rows_of(w) * vc) * red[(w * 2) * BN + c]; M2 += red[(w * 2 + 1) * BN + c]; }
+                    mean /= ntot;
 #pragma unroll
-                    for (int w = 0; w < WM; ++w) { const float d = red[(w * 2) * BN + c] - mean; M2 += RW * d * d; }
+                    for (int w = 0; w < WM; ++w) { const float d = red[(w * 2) * BN + c] - mean; M2 += (float)(rows_of(w) * vc) * d * d; }
                     a.stat[(size_t)co[j] * a.nblk_m + tile] = mean;
                     a.stat[(size_t)(a.Cout + co[j]) * a.nblk_m + tile] = M2;
                 }
@@ -759,20 +771,27 @@ int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st) {
 // channels, the full window, output extent a multiple of the 8 x 16 tile, and enough tiles to occupy the chip (smaller layers stay
 // on the split-K / 64 x 64 kernels).  The fragment-major f16x2 weight image is a consequence of this predicate: conv_api.hip asks it
 // when it packs, viai_conv_igemm_bf3_launch when it launches.
+int viai_halo_tiles_y(const ConvGeom& g) { return (g.OH + HT_H - 1) / HT_H; }
+int viai_halo_tiles_x(const ConvGeom& g) { return (g.OW + HT_W - 1) / HT_W; }
+
 bool viai_conv_halo_wide_ok(const ConvArgs& a) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("VIAI_HALO_WIDE"); on = e ? atoi(e) : 1; }
     const ConvGeom& g = a.g;
     if (!on || a.C1 % 32 != 0 || a.C2 % 32 != 0 || a.C1 < 32 || (a.OC1 != a.Cout && a.OC1 % 32 != 0)) return false;
     if (!(a.Cout == 32 || a.Cout == 64 || a.Cout % 128 == 0)) return false;
-    if (a.Cout <= 64 && a.C1 + a.C2 <= 64 && a.C2 == 0) return false;              // the small-channel halo kernels take these
+    const bool whole = g.OH % HT_H == 0 && g.OW % HT_W == 0;
+    if (whole && a.Cout <= 64 && a.C1 + a.C2 <= 64 && a.C2 == 0) return false;     // the small-channel halo kernels take these (whole tiles only)
     if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2) || g.SH != g.OH || g.SW != g.OW || g.ntaps != 9) return false;
-    if (g.OH % HT_H != 0 || g.OW % HT_W != 0) return false;
+    if (!whole) {
+        // partial tiles (stride 1): worth it while the tiles are >= 70 % full -- 56 x 56: 87 %, 28 x 28: 77 %, 14 x 14: 77 %, 7 x 7: 38 % (stays on the gather kernel)
+        if (g.my != 1 || (long)g.OH * g.OW * 10 < (long)viai_halo_tiles_y(g) * viai_halo_tiles_x(g) * HT_H * HT_W * 7) return false;
+    }
     if (g.my == 2) {                                               // stride-2 forward: eight-wave instances only, one source
         constexpr int s2 = 1;
         if (!s2 || a.C2 != 0 || a.Cout % 128 != 0 || a.OC1 != a.Cout) return false;
     }
-    const long tiles = (long)g.N * (g.OH / HT_H) * (g.OW / HT_W);
+    const long tiles = (long)g.N * viai_halo_tiles_y(g) * viai_halo_tiles_x(g);
     // small maps: 64-channel blocks double the block count (the 16 x 32 maps of G.convblock2: 64 tiles -> 128 / 256 blocks, each
     // with half the K-loop work of a 128-channel block) -- still better than the split-K kernel those layers ran on
     constexpr long min64 = 96;
@@ -807,7 +826,7 @@ int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
     for (int t = 1; t < 9; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
     HaloWideSlots sl;
     for (int t = 0; t < 9; ++t) sl.s[(g.dy[t] - y0) * 3 + (g.dx[t] - x0)] = g.ws[t];
-    a.nblk_m = a.M / 128;
+    a.nblk_m = g.N * viai_halo_tiles_y(g) * viai_halo_tiles_x(g);
     if (g.my == 2) return (a.Cout % 256 == 0) ? launch_halo_wide<2, 4, 2, 2, 2>(a, y0, x0, sl, st) : launch_halo_wide<2, 4, 2, 1, 2>(a, y0, x0, sl, st);
     if (a.Cout == 32) return launch_halo_wide<4, 1, 1, 1>(a, y0, x0, sl, st);
     if (a.Cout == 64 || (long)a.nblk_m * (a.Cout / 128) < 192) return launch_halo_wide<2, 2, 2, 1>(a, y0, x0, sl, st);

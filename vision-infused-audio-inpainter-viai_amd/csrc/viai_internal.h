@@ -45,6 +45,8 @@ bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout);
 bool viai_conv_halo16_ok(const ConvGeom& g, int C1, int C2, int Cout);
 int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st);
 bool viai_conv_halo_wide_ok(const ConvArgs& a);
+int viai_halo_tiles_y(const ConvGeom& g);      // 8 x 16 output tiles of the wide halo kernel (the last row / column of tiles may be partial)
+int viai_halo_tiles_x(const ConvGeom& g);
 int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st);
 bool viai_dgrad_s2_ok(const viai_conv2d* c);
 int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st);

@@ -344,6 +344,18 @@ def weights_changed(params=None, owner=None):
     repack(params, owner)
 
 
+def _bn_finalize(lib, d, stat, M, Cc, gamma, beta, rmean, rvar, nbt, cfg, coef, st):
+    """partials of the conv forward -> (mean, invstd, scale, shift) + running statistics; tile-shaped partial blocks where the forward
+    kernel's tiles are clipped at the map's edge (viai_conv2d_stat_tiles)"""
+    th, tw = d["tiles"]
+    tail = (Cc, gamma.data_ptr(), beta.data_ptr(), _ptr(rmean), _ptr(rvar), _ptr(nbt), cfg["momentum"], cfg["eps"],
+            coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st)
+    if th > 0:
+        _lib.check(lib.viai_bn_finalize_tiles(stat.data_ptr(), d["N"], d["OH"], d["OW"], th, tw, *tail), "viai_bn_finalize_tiles")
+    else:
+        _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, *tail), "viai_bn_finalize")
+
+
 def conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed, dh=1, dw=1, ph2=-1, pw2=-1):
     key = (N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed, dh, dw, ph2, pw2)
     d = _desc_cache.get(key)
@@ -354,9 +366,11 @@ def conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed, dh=1,
         lib.viai_conv2d_out_hw(C.byref(desc), C.byref(oh), C.byref(ow))
         nblk, rows = C.c_int(), C.c_int()
         _lib.check(lib.viai_conv2d_stat_geom(C.byref(desc), C.byref(nblk), C.byref(rows)), "viai_conv2d_stat_geom")
+        th, tw = C.c_int(), C.c_int()
+        _lib.check(lib.viai_conv2d_stat_tiles(C.byref(desc), C.byref(th), C.byref(tw)), "viai_conv2d_stat_tiles")
         d = {
-            "desc": desc, "ref": C.byref(desc), "OH": oh.value, "OW": ow.value,
-            "nblk": nblk.value, "rows": rows.value,
+            "desc": desc, "ref": C.byref(desc), "OH": oh.value, "OW": ow.value, "N": N,
+            "nblk": nblk.value, "rows": rows.value, "tiles": (th.value, tw.value),
             "packed": int(lib.viai_conv2d_packed_floats(C.byref(desc))),
             "ws_floats": int(lib.viai_conv2d_wgrad_ws_bytes(C.byref(desc))) // 4,
         }
@@ -500,10 +514,7 @@ class _ConvBnAct(torch.autograd.Function):
             stat = _scratch("stat", 2 * Cout * d["nblk"], dev)
             _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, stat.data_ptr(), 0, 0, 0, act, 0, st),
                        "viai_conv2d_cin1_bn_fwd")
-            _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, Cout, gamma.data_ptr(),
-                                            beta.data_ptr(), _ptr(rmean), _ptr(rvar), _ptr(nbt),
-                                            cfg["momentum"], cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
-                                            coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_finalize")
+            _bn_finalize(lib, d, stat, M, Cout, gamma, beta, rmean, rvar, nbt, cfg, coef, st)
             z = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
             za = _amax_slot(dev)
             _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, 0, coef[2].data_ptr(), coef[3].data_ptr(),
@@ -516,10 +527,7 @@ class _ConvBnAct(torch.autograd.Function):
                 stat = _scratch("stat", 2 * Cout * d["nblk"], dev)
                 _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
                                                     y.data_ptr(), stat.data_ptr(), ACT_NONE, _ptr(xa), st), "viai_conv2d_fwd")
-                _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, Cout, gamma.data_ptr(),
-                                                beta.data_ptr(), _ptr(rmean), _ptr(rvar), _ptr(nbt),
-                                                cfg["momentum"], cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
-                                                coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_finalize")
+                _bn_finalize(lib, d, stat, M, Cout, gamma, beta, rmean, rvar, nbt, cfg, coef, st)
             else:
                 _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
                                                     y.data_ptr(), 0, ACT_NONE, _ptr(xa), st), "viai_conv2d_fwd")
@@ -764,9 +772,7 @@ class _ConvBnActCout1(torch.autograd.Function):
             stat = _scratch("stat", 2 * Cmid * d["nblk"], dev)
             _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp1.data_ptr(), _ptr(b1), y.data_ptr(), stat.data_ptr(),
                                                 ACT_NONE, _ptr(xa), st), "viai_conv2d_fwd")
-            _lib.check(lib.viai_bn_finalize(stat.data_ptr(), d["nblk"], d["rows"], M, Cmid, gamma.data_ptr(), beta.data_ptr(), _ptr(rmean),
-                                            _ptr(rvar), _ptr(nbt), cfg["momentum"], cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
-                                            coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_finalize")
+            _bn_finalize(lib, d, stat, M, Cmid, gamma, beta, rmean, rvar, nbt, cfg, coef, st)
         else:
             _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp1.data_ptr(), _ptr(b1), y.data_ptr(), 0, ACT_NONE,
                                                 _ptr(xa), st), "viai_conv2d_fwd")
