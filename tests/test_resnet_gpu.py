@@ -162,3 +162,40 @@ def test_audiomodel_av_multiscale_step_runs_and_trains():
     assert float((m.arena_G.flat - g0).abs().max()) > 0 and float((m.arena_D.flat - d0).abs().max()) > 0
     vp = dict(m.VideoEncoder.named_parameters())["image_single_model.conv1.weight"]
     assert float(vp.grad.abs().sum()) > 0                          # gradients reach the visual branch through the arena
+
+
+@pytest.mark.parametrize("cin,N,hw", [(3, 3, (224, 224)), (2, 5, (224, 224)), (3, 2, (64, 96))], ids=["rgb224", "flow224", "rgb64x96"])
+def test_stem_conv_on_the_f16x2_kernels_against_fp64(cin, N, hw):
+    """networks/Image_Embedding.py:20-22 conv1 -> bn1 -> relu on the patch-staged f16x2 kernels of csrc/conv_stem.hip: forward, batch
+    statistics and every gradient within 5x of torch-CPU-fp32's own rounding error against an fp64 evaluation."""
+    import ctypes as C
+    from viai_amd import _lib, ops
+    x = O.cf_uniform("stem.x", (N, cin) + hw, -1, 1)
+    w = O.cf_std("stem.w", (64, cin, 7, 7), 0.05)
+    g_, b_ = O.cf_uniform("stem.g", (64,), 0.8, 1.2), O.cf_uniform("stem.b", (64,), -0.1, 0.1)
+    gy = O.cf_uniform("stem.gy", (N, 64, hw[0] // 2, hw[1] // 2), -1, 1)
+
+    def run(dt):
+        ws, gs, bs = [t.clone().to(dt).requires_grad_(True) for t in (w, g_, b_)]
+        rm, rv = torch.zeros(64, dtype=dt), torch.ones(64, dtype=dt)
+        z = F.relu(F.batch_norm(F.conv2d(x.to(dt), ws, None, stride=2, padding=3), rm, rv, gs, bs, True, 0.1, 1e-5))
+        return (z,) + torch.autograd.grad(z, [ws, gs, bs], grad_outputs=gy.to(dt)) + (rv,)
+    truth, cpu32 = run(torch.float64), run(torch.float32)
+    bn = torch.nn.BatchNorm2d(64).cuda().train()
+    bn.weight.data.copy_(g_); bn.bias.data.copy_(b_)
+    xg = ops.frames_to_nhwc4(x.cuda())
+    wg = w.cuda().requires_grad_(True)
+    ops.begin_step(xg.device)
+    zg = ops.conv_bn_act(xg, wg, None, bn, kernel=(7, 7), stride=(2, 2), padding=(3, 3), act=ops.ACT_RELU)
+    buf = C.create_string_buffer(64)
+    _lib.load().viai_conv2d_last_kernel(buf, 64)
+    assert buf.value.decode() == "stem_f16x2", buf.value
+    zg.backward(nhwc(gy))
+    torch.cuda.synchronize()
+    hip = (nchw(zg), wg.grad, bn.weight.grad, bn.bias.grad, bn.running_var)
+    for nm, h, c32, t in zip(("z", "dw", "dgamma", "dbeta", "running_var"), hip, cpu32, truth):
+        assert relerr(h, t) < 5 * relerr(c32, t) + 1e-6, (nm, relerr(h, t), relerr(c32, t))
+    # every filter position and channel separately (a row / column / channel mix-up hides in a global norm)
+    for r in range(7):
+        for s in range(7):
+            assert relerr(wg.grad[:, :, r, s], truth[1][:, :, r, s]) < 2e-5, (r, s)

@@ -221,6 +221,12 @@ static void geom_run(const viai_conv2d* c, ConvGeom* g) {
     g->ntaps = g->wtaps = c->kh;
     for (int r = 0; r < c->kh; ++r) { g->dy[r] = r - c->ph; g->dx[r] = -c->pw; g->ws[r] = r; }
 }
+// the ResNet stem (7 x 7, stride 2, 64 channels) on the f16x2 kernels of conv_stem.hip
+static bool stem_f16(const viai_conv2d* c) {
+    if (kind_of(c) != K_RUN || !f16x2_enabled() || !bf3_enabled() || c->transposed) return false;
+    ConvGeom g{}; geom_run(c, &g);
+    return viai_conv_stem_ok(g, cin_of(c), c->Cout, c->kh, c->kw, c->sh, c->sw, c->ph, c->pw);
+}
 
 // wp[co][r][s*4+ch] = w[co][ch][r][s], zero for s >= kw or ch >= Cin
 __global__ void pack_run_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int kh, int kw) {
@@ -286,6 +292,7 @@ extern "C" int viai_conv2d_pack_fwd(const viai_conv2d* c, const float* w, float*
     case K_COUT1:   // wp[t][ci] == pack with n_out = 1 ... expressed as [1][T][Cin]
         return viai_pack_weight(w, wp, 1, Cin, T, 0, T, stream);
     case K_RUN: {
+        if (stem_f16(c)) return viai_conv_stem_pack(w, wp, Cin, (hipStream_t)stream);
         int total = c->Cout * c->kh * 32;
         VIAI_LAUNCH(pack_run_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, wp, c->Cout, Cin, c->kh, c->kw);
         return viai_launch_status();
@@ -348,7 +355,7 @@ extern "C" int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_
     int oh, ow;
     viai_conv2d_out_hw(c, &oh, &ow);
     long M = (long)c->N * oh * ow;
-    const int bm = (kind_of(c) == K_COUT1 || halo_fwd(c) || halo_wide_fwd(c)) ? 128 : sk_fwd(c) ? 32 : viai_igemm_tile_m(M, c->Cout);
+    const int bm = (kind_of(c) == K_COUT1 || stem_f16(c) || halo_fwd(c) || halo_wide_fwd(c)) ? 128 : sk_fwd(c) ? 32 : viai_igemm_tile_m(M, c->Cout);
     *rows_per_blk = bm;
     *nblk = (int)((M + bm - 1) / bm);
     int th, tw;
@@ -373,6 +380,7 @@ extern "C" int viai_conv2d_fwd(const viai_conv2d* c, const float* x, const float
 
 // 1 if the forward launch of this layer splits its activations into fp16 terms (then x_amax matters)
 extern "C" int viai_conv2d_fwd_f16_ok(const viai_conv2d* c) {
+    if (valid(c) && stem_f16(c)) return 1;
     if (!valid(c) || kind_of(c) != K_IGEMM || !use_bf3_fwd(c)) return 0;
     const int lay = frag_fwd(c);
     return (lay == 3 || lay == 4) ? 1 : 0;
@@ -401,6 +409,7 @@ extern "C" int viai_conv2d_fwd_amax(const viai_conv2d* c, const float* x, const 
     if (kind_of(c) == K_RUN) { geom_run(c, &a.g); a.C1 = 32; a.C2 = 0; }
     else viai_geom_fwd(c, &a.g);
     a.M = a.g.N * a.g.OH * a.g.OW;
+    if (stem_f16(c)) { a.amax = x_amax; return viai_conv_stem_fwd_launch(a, st); }
     if (use_bf3_fwd(c)) {
         a.wfrag = frag_fwd(c);
         if (a.wfrag == 3 || a.wfrag == 4) a.amax = x_amax;            // f16x2 weight image = f16x2 kernel
@@ -512,6 +521,7 @@ extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
     case K_RUN: {
         int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
         int ks = viai_wgrad_pick_ksplit(c->Cout, 32, c->kh, (long)c->N * oh * ow);
+        if (stem_f16(c)) { ConvGeom g{}; geom_run(c, &g); const int kz = viai_conv_stem_wgrad_slabs(g); if (kz > ks) ks = kz; }
         fl = (size_t)ks * viai_conv2d_packed_floats(c); break;
     }
     default: {
@@ -543,6 +553,7 @@ extern "C" int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const flo
 // static activation scale; 1 from viai_conv2d_wgrad_f16_ok if the layer has this form
 extern "C" int viai_conv2d_wgrad_f16_ok(const viai_conv2d* c) {
     // the layers of the f16x2 wgrad_bf3 kernel (> 32 channels on both sides) and every layer an instance of the patch kernel takes
+    if (valid(c) && stem_f16(c)) return 1;
     return (valid(c) && kind_of(c) == K_IGEMM && f16x2_enabled() && bf3_enabled() && (viai_wgrad_bf3_ok(c->Cout, c->C1, c->C2) || wgrad_patch(c))) ? 1 : 0;
 }
 extern "C" int viai_conv2d_wgrad_f16(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
@@ -569,6 +580,12 @@ static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, con
         WgradArgs a{};
         a.x = x; a.x2 = nullptr; a.dy = dy; a.ws = ws; a.C1 = 32; a.C2 = 0; a.Cout = c->Cout; a.M = (int)M;
         geom_run(c, &a.g);
+        if (amax != nullptr && stem_f16(c)) {                 // f16x2 launch (viai_conv2d_wgrad_f16): conv_stem.hip, slabs + reduce in one call
+            a.amax = amax; a.xmax = xmax;
+            used = (size_t)viai_conv_stem_wgrad_slabs(a.g) * viai_conv2d_packed_floats(c);
+            e = viai_conv_stem_wgrad_launch(a, Cin, dw, accumulate, st);
+            break;
+        }
         int ks = viai_wgrad_pick_ksplit(c->Cout, 32, c->kh, M);
         used = (size_t)ks * viai_conv2d_packed_floats(c);
         e = viai_wgrad_mfma_launch(a, ks, st);

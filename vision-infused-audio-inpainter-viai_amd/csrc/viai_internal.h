@@ -44,6 +44,12 @@ bool viai_bf3_sk_ok(long M, int n_out, int C1, int C2);
 bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout);
 bool viai_conv_halo16_ok(const ConvGeom& g, int C1, int C2, int Cout);
 int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st);
+// conv_stem.hip: the 7 x 7 stride-2 image conv of the ResNet branch on the f16x2 matrix-core path (forward + weight gradient)
+bool viai_conv_stem_ok(const ConvGeom& g, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
+int viai_conv_stem_fwd_launch(ConvArgs& a, hipStream_t st);
+int viai_conv_stem_wgrad_slabs(const ConvGeom& g);
+int viai_conv_stem_wgrad_launch(WgradArgs& a, int Cin, float* dw, int accumulate, hipStream_t st);
+int viai_conv_stem_pack(const float* w, float* wp, int Cin, hipStream_t st);
 bool viai_conv_halo_wide_ok(const ConvArgs& a);
 int viai_halo_tiles_y(const ConvGeom& g);      // 8 x 16 output tiles of the wide halo kernel (the last row / column of tiles may be partial)
 int viai_halo_tiles_x(const ConvGeom& g);
