@@ -205,8 +205,9 @@ def test_patch_staged_weight_gradient_against_fp64(cfg):
             assert relerr(wg.grad[:, :, ky, kx], wd.grad[:, :, ky, kx]) < 5e-6, (ky, kx)
 
 
-@pytest.mark.parametrize("cfg", [(1, 8, 28, 28, 128, 128), (2, 8, 28, 28, 64, 128), (1, 12, 20, 24, 64, 64), (1, 64, 7, 7, 128, 128)],
-                         ids=["s1_28x28_128to128", "s2_to28x28_64to128", "narrow_20x24_64to64", "s1_7x7_128to128"])
+@pytest.mark.parametrize("cfg", [(1, 8, 28, 28, 128, 128), (2, 8, 28, 28, 64, 128), (1, 12, 20, 24, 64, 64), (1, 128, 7, 7, 128, 128), (1, 129, 7, 7, 64, 64),
+                                 (1, 160, 5, 6, 128, 64)],
+                         ids=["s1_28x28_128to128", "s2_to28x28_64to128", "narrow_20x24_64to64", "s1_7x7_128to128_pairs", "s1_7x7_64to64_odd_batch", "s1_5x6_64to128_pairs"])
 def test_patch_weight_gradient_on_maps_that_are_not_tile_multiples(cfg):
     """the output maps of the ResNet-18 visual branch (56 / 28 / 14 / 7 pixels) are not multiples of the 8 x 16 tile: the patch weight
     gradient covers them with partial tiles whose outside pixels are staged as zeros (networks/Image_Embedding.py:13-71 shapes)."""

@@ -39,6 +39,18 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct WgPatchSlots { int s[9]; };
 
+// two images per tile (stride 1, maps of at most 8 x 7 pixels, same extent in and out)
+__host__ __device__ inline bool wgrad_patch_pairs(const ConvGeom& g) {
+    if (!(g.my == 1 && g.mx == 1 && g.OH <= WP_TH && g.OW <= 7 && g.IH == g.OH && g.IW == g.OW && g.N >= 2 && g.ntaps == 9)) return false;
+    int lo = g.dx[0], hi = g.dx[0];                      // the window must reach exactly one column to either side (pad 1)
+    for (int t = 1; t < 9; ++t) { lo = g.dx[t] < lo ? g.dx[t] : lo; hi = g.dx[t] > hi ? g.dx[t] : hi; }
+    return lo == -1 && hi == 1;
+}
+__host__ inline long wgrad_patch_tiles(const ConvGeom& g) {
+    if (wgrad_patch_pairs(g)) return (g.N + 1) / 2;
+    return (long)g.N * ((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW);
+}
+
 template <int S, int BM, int BN, int HR, int WK>
 struct WgCfg {
     static constexpr int WMC = BM / 32, WN = BN / 32;               // waves along Cout / Cin
@@ -114,8 +126,13 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
 
     // tiles cover the output map; where the map is not a multiple of 8 x 16 (the 56 / 28 / 14 / 7-pixel maps of the ResNet branch) the
     // pixels of a tile that fall outside are staged as zeros: dy = 0 contributes nothing to any tap
-    const int tiles_x = (g.OW + WP_TW - 1) / WP_TW, tiles_y = (g.OH + WP_TH - 1) / WP_TH;
-    const int ntiles = g.N * tiles_y * tiles_x;
+    // Maps of at most 8 x 7 pixels (the 7 x 7 maps of ResNet layer4) would fill 38 % of a tile: TWO images share one, side by side --
+    // image n0 in tile columns 0 .. 7, image n0 + 1 in columns 8 .. 15.  Patch column 8 is the right padding of the first image and the
+    // left padding of the second (both zero), tile column 7 is outside the first image (dy staged as zero), so every tap window of a
+    // pixel still lies in its own image and the MFMA side of the kernel does not know the difference.
+    const bool pair = S == 1 && wgrad_patch_pairs(g);
+    const int tiles_x = pair ? 1 : (g.OW + WP_TW - 1) / WP_TW, tiles_y = (g.OH + WP_TH - 1) / WP_TH;
+    const int ntiles = pair ? (g.N + 1) / 2 : g.N * tiles_y * tiles_x;
     const int tile0 = z * a.chunks_per_split;                 // chunks_per_split = tiles per K slab here
     int tile1 = tile0 + a.chunks_per_split;
     if (tile1 > ntiles) tile1 = ntiles;
@@ -142,7 +159,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
         const int sc = s < nst ? s : 0;
         const int tile = tile0 + sc / SPT, h = sc % SPT;
         const int tx = tile % tiles_x; const int r_ = tile / tiles_x; const int ty = r_ % tiles_y;
-        g_n = r_ / tiles_y;
+        g_n = pair ? 2 * (r_ / tiles_y) : r_ / tiles_y;
         const int oy0 = ty * WP_TH + h * HR, ox0 = tx * WP_TW;
         g_dbase = ((g_n * g.OH + oy0) * g.OW + ox0) * a.Cout * 4;
         g_oy0 = oy0; g_ox0 = ox0;
@@ -155,6 +172,13 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
             if (it == j) {
                 const int row = (PJ * j) >> 4, dcol = (PJ * j) & 15;                 // pixel dp0 + PJ j: PJ = 8 (dp0 < 8) or a multiple of 16, so no carry
                 const int oy = g_oy0 + row + (dp0 >> 4), ox = g_ox0 + dcol + (dp0 & 15);
+                if (pair) {
+                    const int second = ox >> 3, oxi = ox & 7;                                // which image of the pair, column in it
+                    const int outside = (((g.OH - 1 - oy) | (g.OW - 1 - oxi) | (g.N - 1 - g_n - second)) >> 31) & OOB;
+                    const int off = (((second * g.OH + row + (dp0 >> 4)) * g.OW + oxi) * a.Cout + co0 + dq * 4) * 4;
+                    draw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off | g_dead | outside, g_dead ? 0 : g_dbase, 0);
+                    continue;
+                }
                 const int outside = (((g.OH - 1 - oy) | (g.OW - 1 - ox)) >> 31) & OOB;       // partial tile at the bottom / right edge
                 draw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (d_goff + (row * g.OW + dcol) * a.Cout * 4) | g_dead | outside, g_dead ? 0 : g_dbase, 0);
             }
@@ -163,9 +187,11 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
             if (it == ND + j) {
                 const int pp = xp0 + C::XPP * j;
                 const int ppr = S == 1 ? (pp * 3641) >> 16 : (pp * 1986) >> 16;      // pp / PW (PW = 18: pp < 128; PW = 33: pp < 200)
-                const int iy = g_iy0 + ppr, ix = g_ix0 + pp - ppr * C::PW;
-                const int dead = ((((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | (C::XPIX - 1 - pp)) >> 31) & OOB) | g_dead;
-                const int off = ((((g_n * g.IH + iy) * g.IW + ix) * xcs + xoff + xq * 4) * 4) | dead;
+                const int pc = pp - ppr * C::PW;
+                const int second = (pair && pc >= 8) ? 1 : 0;                                 // patch columns 8 .. 17: the second image of a pair
+                const int iy = g_iy0 + ppr, ix = g_ix0 + pc - 8 * second;
+                const int dead = ((((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | (C::XPIX - 1 - pp) | (g.N - 1 - g_n - second)) >> 31) & OOB) | g_dead;
+                const int off = (((((g_n + second) * g.IH + iy) * g.IW + ix) * xcs + xoff + xq * 4) * 4) | dead;
                 xraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
             }
     };
@@ -354,9 +380,9 @@ static bool window9(const ConvGeom& g, int* y0, int* x0, WgPatchSlots* sl) {
 // 32-channel x patch for ONE 32 x 32 tile; four tiles per block halve the staging per MFMA)
 static int pick(const ConvGeom& g, int Cout, int C1, int C2) {
     if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2)) return 0;
-    if ((long)g.N * ((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW) < 64) return 0;
-    // partial tiles multiply zeros: refuse maps that would waste more than ~2/3 of the MFMAs (7 x 7: 49 of 128 pixels, taken; 4 x 4: not)
-    if ((long)g.OH * g.OW * 3 < (long)((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW) * WP_TH * WP_TW) return 0;
+    if (wgrad_patch_tiles(g) < 64) return 0;
+    // partial tiles multiply zeros: refuse maps that would waste more than ~2/3 of the MFMAs (7 x 7: two images per tile, 98 of 128 pixels; 4 x 4: not taken)
+    if ((long)g.N * g.OH * g.OW * 3 < wgrad_patch_tiles(g) * WP_TH * WP_TW) return 0;
     if (!window9(g, nullptr, nullptr, nullptr)) return 0;
     if (g.my == 2) return (Cout % 128 == 0 && C1 % 32 == 0 && C2 % 32 == 0 && C1 >= 32) ? 2 : 0;
     if (Cout % 128 == 0 && C1 % 64 == 0 && C2 % 64 == 0 && C1 >= 64) return 1;
@@ -380,7 +406,7 @@ static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hi
 
 // number of block-level K slabs
 static int block_ksplit(const ConvGeom& g, int Cout, int Cin, int cfg) {
-    const long tiles = (long)g.N * ((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW);
+    const long tiles = wgrad_patch_tiles(g);
     const long per = (long)(Cout / bm_of(cfg)) * (Cin / bn_of(cfg));
     static long blk4 = -1;
     if (blk4 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_64"); blk4 = e ? atol(e) : 192; }
@@ -432,7 +458,7 @@ int viai_wgrad_patch_launch(WgradArgs& a, hipStream_t st) {
     const int cfg = pick(g, a.Cout, a.C1, a.C2);
     int y0, x0; WgPatchSlots sl;
     window9(g, &y0, &x0, &sl);
-    const long tiles = (long)g.N * ((g.OH + WP_TH - 1) / WP_TH) * ((g.OW + WP_TW - 1) / WP_TW);
+    const long tiles = wgrad_patch_tiles(g);
     a.ksplit = block_ksplit(g, a.Cout, Cin, cfg);
     a.chunks_per_split = (int)((tiles + a.ksplit - 1) / a.ksplit);
     a.nblk_co = a.Cout / bm_of(cfg);
