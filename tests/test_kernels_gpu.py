@@ -829,8 +829,8 @@ def test_time_mask_applied_where_the_first_conv_loads_its_input(geom, need_dx):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("cfg", [(8, 56, 56, 64, 64), (8, 28, 28, 128, 128), (16, 14, 14, 256, 256), (4, 80, 104, 64, 128), (24, 22, 44, 128, 32)],
-                         ids=["56x56_64to64", "28x28_128to128", "14x14_256to256", "80x104_64to128", "22x44_128to32"])
+@pytest.mark.parametrize("cfg", [(8, 56, 56, 64, 64), (8, 28, 28, 128, 128), (16, 14, 14, 256, 256), (4, 80, 104, 64, 128), (24, 22, 44, 128, 32), (16, 20, 26, 256, 512)],
+                         ids=["56x56_64to64", "28x28_128to128", "14x14_256to256", "80x104_64to128", "22x44_128to32", "20x26_256to512"])
 def test_wide_halo_kernel_on_maps_with_partial_tiles(cfg):
     """the 8 x 16 tiles of the wide halo kernel clipped at the map's edge (the 56 / 28 / 14-pixel maps of networks/Image_Embedding.py:13-71,
     the 80 x 104 maps of the reference's native 80 x 208 clips): conv -> BatchNorm(train) -> ReLU with the batch statistics merged from

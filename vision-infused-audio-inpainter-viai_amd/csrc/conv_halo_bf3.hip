@@ -784,8 +784,9 @@ bool viai_conv_halo_wide_ok(const ConvArgs& a) {
     if (whole && a.Cout <= 64 && a.C1 + a.C2 <= 64 && a.C2 == 0) return false;     // the small-channel halo kernels take these (whole tiles only)
     if (g.run || g.ly != 1 || g.lx != 1 || g.my != g.mx || (g.my != 1 && g.my != 2) || g.SH != g.OH || g.SW != g.OW || g.ntaps != 9) return false;
     if (!whole) {
-        // partial tiles (stride 1): worth it while the tiles are >= 70 % full -- 56 x 56: 87 %, 28 x 28: 77 %, 14 x 14: 77 %, 7 x 7: 38 % (stays on the gather kernel)
-        if (g.my != 1 || (long)g.OH * g.OW * 10 < (long)viai_halo_tiles_y(g) * viai_halo_tiles_x(g) * HT_H * HT_W * 7) return false;
+        // partial tiles (stride 1): worth it while the tiles are >= 2/3 full -- 56 x 56: 87 %, 28 x 28: 77 %, 14 x 14: 77 %, 20 x 26 (D.conv3 on the
+        // reference's native 80 x 208 clips): 68 %, 7 x 7: 38 % (stays on the gather kernel)
+        if (g.my != 1 || (long)g.OH * g.OW * 3 < (long)viai_halo_tiles_y(g) * viai_halo_tiles_x(g) * HT_H * HT_W * 2) return false;
     }
     if (g.my == 2) {                                               // stride-2 forward: eight-wave instances only, one source
         constexpr int s2 = 1;
