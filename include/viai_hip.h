@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 9
+#define VIAI_ABI_VERSION 10
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -206,6 +206,19 @@ int viai_avgpool2d_fwd(const float* x, float* y, int N, int IH, int IW, int C, i
 int viai_avgpool2d_bwd(const float* dy, float* dx, int N, int IH, int IW, int C, int k, int s, int p, void* stream);
 /* BasicBlock join: out = relu(a + b); backward d = g * (out > 0) (same for both addends) */
 int viai_add_relu_fwd(const float* a, const float* b, float* out, long n, void* stream);
+/* (ABI 10) the BatchNorm-apply pass fused with what follows it in the ResNet branch (networks/ResNet.py:43-55, Image_Embedding.py:20-23):
+ *   viai_bn_add_act_fwd_amax : z = act(scale*y + shift + res)            bn2 -> += identity -> ReLU of a BasicBlock in one pass
+ *   viai_bn_act_maxpool_fwd  : out = maxpool_{k,s,p}(act(scale*y + shift)) + argmax bytes; the stem's post-activation map is never stored
+ *   viai_bn_act_pool_bwd_amax: viai_bn_act_bwd_amax with the gradient of that map gathered from (dpool, idx) where it is loaded
+ * act = VIAI_ACT_RELU or VIAI_ACT_NONE.                                                                                            */
+int viai_bn_add_act_fwd_amax(const float* y, const float* scale, const float* shift, const float* res, float* z,
+                             long M, int C, int act, float slope, float* z_amax, void* stream);
+int viai_bn_act_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, unsigned char* idx,
+                            int N, int IH, int IW, int C, int k, int s, int p, int act, float slope, float* out_amax, void* stream);
+int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char* idx, int N, int IH, int IW, int k, int s, int p,
+                              const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
+                              float* part, float* sums, float* dgamma, float* dbeta, float* dy, int C, int act, float slope,
+                              int training, float* amax, void* stream);
 int viai_relu_bwd(const float* g, const float* out, float* d, long n, void* stream);
 
 /* ----------------------------------------------------------------------- losses

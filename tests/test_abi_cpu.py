@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_typed(lib):
         assert n in _lib.SIGNATURES, "no ctypes signature for %s" % n
     for n in _lib.SIGNATURES:
         assert n in names, "%s is bound but not declared in include/viai_hip.h" % n
-    assert lib.viai_abi_version() == _lib.ABI_VERSION >= 9
+    assert lib.viai_abi_version() == _lib.ABI_VERSION >= 10
 
 
 def test_conv_geometry_queries_match_torch(lib):

@@ -199,3 +199,46 @@ def test_stem_conv_on_the_f16x2_kernels_against_fp64(cin, N, hw):
     for r in range(7):
         for s in range(7):
             assert relerr(wg.grad[:, :, r, s], truth[1][:, :, r, s]) < 2e-5, (r, s)
+
+
+@pytest.mark.parametrize("what", ["residual", "residual_downsample_shape", "pool"])
+def test_batchnorm_tail_fusions_equal_the_separate_passes(what, monkeypatch):
+    """BatchNorm apply + (residual add + ReLU) of a BasicBlock (networks/ResNet.py:46-53) and BatchNorm apply + ReLU + MaxPool2d(3, 2, 1) of
+    the stem (Image_Embedding.py:20-23) as one pass each, and the pool's backward gathered inside the BatchNorm backward: every output,
+    statistic and gradient bit-identical to the separate kernels (same arithmetic, fewer passes over memory)."""
+    from viai_amd import networks as N_, ops
+    import torch.nn as nn
+    if what == "pool":
+        Nb, Ci, Co, H, W, k, s_, p = 3, 4, 64, 64, 96, 7, 2, 3
+    elif what == "residual":
+        Nb, Ci, Co, H, W, k, s_, p = 4, 64, 64, 28, 28, 3, 1, 1
+    else:
+        Nb, Ci, Co, H, W, k, s_, p = 2, 96, 96, 14, 10, 3, 1, 1           # 256 % (C / 4) != 0: the non-fixed channel walk
+    conv = nn.Conv2d(3 if what == "pool" else Ci, Co, k, s_, p, bias=False).cuda()
+    x0 = O.cf_uniform("tail.x", (Nb, 3 if what == "pool" else Ci, H, W), -1, 1)
+    r0 = O.cf_uniform("tail.r", (Nb, Co, H, W), -1, 1)
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(N_, "FUSE_BN_TAIL", fused)
+        bn = nn.BatchNorm2d(Co).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(O.cf_uniform("tail.g", (Co,), 0.8, 1.2)); bn.bias.copy_(O.cf_uniform("tail.b", (Co,), -0.1, 0.1))
+        conv.weight.grad = None
+        ops.begin_step(torch.device("cuda"))
+        if what == "pool":
+            x = ops.frames_to_nhwc4(x0.cuda())
+            z = N_.fused_layer(x, conv, bn, ops.ACT_RELU, pool=(3, 2, 1))
+            assert tuple(z.shape) == (Nb, H // 4, W // 4, Co)
+            r = None
+        else:
+            x = nhwc(x0).requires_grad_(True)
+            r = nhwc(r0).requires_grad_(True)
+            z = N_.fused_layer(x, conv, bn, ops.ACT_RELU, residual=r)
+        gz = nhwc(O.cf_uniform("tail.gz", (Nb, Co) + tuple(z.shape[1:3]), -1, 1))
+        z.backward(gz)
+        torch.cuda.synchronize()
+        outs.append([z.detach().clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()]
+                    + ([x.grad.clone(), r.grad.clone()] if r is not None else []))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(outs[0][0].abs().max()) > 0

@@ -95,10 +95,11 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
 
 // z = act(scale*y + shift).  FIXED: 256 % (C/4) == 0 -> one channel quad per thread, coefficients loaded once (see
 // bn_bwd_apply_kernel); four independent 16-byte loads in flight per thread.
-template <int ACT, bool FIXED>
+// RES: z = act(scale*y + shift + res) -- the residual join of a ResNet block (networks/ResNet.py:49-53) in the same pass.
+template <int ACT, bool FIXED, bool RES = false>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, f32x4* __restrict__ z,
-                                                         long n4, int C, float slope, float* __restrict__ amax) {
+                                                         long n4, int C, float slope, float* __restrict__ amax, const f32x4* __restrict__ res = nullptr) {
     const unsigned c4n = (unsigned)(C / 4);
     const long stride = (long)gridDim.x * 256L;
     long i = blockIdx.x * 256L + threadIdx.x;
@@ -106,10 +107,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const f32x4* __restrict
     const unsigned cstep = (unsigned)((unsigned long)stride % c4n);
     f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cq * 4), sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
     float mx = 0.f;
-    auto one = [&](const f32x4& v) {
+    auto one = [&](const f32x4& v, const f32x4& r = f32x4{0.f, 0.f, 0.f, 0.f}) {
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = viai_act(v[e] * sc[e] + sh[e], ACT, slope); mx = fmaxf(mx, fabsf(o[e])); }
+        for (int e = 0; e < 4; ++e) { o[e] = viai_act(RES ? (v[e] * sc[e] + sh[e]) + r[e] : v[e] * sc[e] + sh[e], ACT, slope); mx = fmaxf(mx, fabsf(o[e])); }
         return o;
     };
     auto next = [&]() {
@@ -119,13 +120,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const f32x4* __restrict
         }
     };
     for (; i + 3 * stride < n4; i += 4 * stride) {
-        f32x4 v[4];
+        f32x4 v[4], r[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = y[i + u * stride];
+        for (int u = 0; u < 4; ++u) { v[u] = y[i + u * stride]; if constexpr (RES) r[u] = res[i + u * stride]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { z[i + u * stride] = one(v[u]); next(); }
+        for (int u = 0; u < 4; ++u) { z[i + u * stride] = RES ? one(v[u], r[u]) : one(v[u]); next(); }
     }
-    for (; i < n4; i += stride) { z[i] = one(y[i]); next(); }
+    for (; i < n4; i += stride) { z[i] = RES ? one(y[i], res[i]) : one(y[i]); next(); }
     // max |z|: the f16x2 operand scale of the kernels that consume z (forward conv of the next layer, this tensor's weight gradient)
     if (amax != nullptr) block_absmax_to(amax, mx);
 }
@@ -137,10 +138,10 @@ int launch_bn_act_fwd(const float* y, const float* scale, const float* shift, fl
     const dim3 grid((unsigned)blocks), blk(256);
     auto a0 = reinterpret_cast<const f32x4*>(y); auto a1 = reinterpret_cast<f32x4*>(z);
     switch (act) {
-    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_RELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax); break;
-    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_LRELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax); break;
-    case VIAI_ACT_SIGMOID: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_SIGMOID, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax); break;
-    default: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_NONE, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax); break;
+    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_RELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax, (const f32x4*)nullptr); break;
+    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_LRELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax, (const f32x4*)nullptr); break;
+    case VIAI_ACT_SIGMOID: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_SIGMOID, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax, (const f32x4*)nullptr); break;
+    default: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_NONE, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax, (const f32x4*)nullptr); break;
     }
     return viai_launch_status();
 }
@@ -152,11 +153,38 @@ __device__ __forceinline__ float act_grad(float pre, int act, float slope) {
     return 1.f;
 }
 
+// BatchNorm + activation followed by nn.MaxPool2d (ResNet stem, networks/Image_Embedding.py:20-23): the gradient of the post-activation
+// tensor is a gather from the pooled gradient and the window argmax bytes (exactly maxpool_bwd_kernel's sum), formed where the BatchNorm
+// backward loads it -- the 3.3 GB tensor per 1024 frames is neither written nor read back twice.
+struct PoolGather {
+    const float* dpool; const unsigned char* idx;
+    int IH, IW, OH, OW, k, st, pd;
+};
+__device__ __forceinline__ f32x4 pool_dz(const PoolGather& p, long row, int c, int C) {
+    const int ix = (int)(row % p.IW); const long r = row / p.IW;
+    const int iy = (int)(r % p.IH); const long n = r / p.IH;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int oy_lo = iy + p.pd - p.k + 1 < 0 ? 0 : (iy + p.pd - p.k + 1 + p.st - 1) / p.st;
+    const int ox_lo = ix + p.pd - p.k + 1 < 0 ? 0 : (ix + p.pd - p.k + 1 + p.st - 1) / p.st;
+    const int oy_hi = min((iy + p.pd) / p.st, p.OH - 1), ox_hi = min((ix + p.pd) / p.st, p.OW - 1);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const unsigned want = (unsigned)((iy - (oy * p.st - p.pd)) * p.k + (ix - (ox * p.st - p.pd)));
+            const size_t o = (((size_t)n * p.OH + oy) * p.OW + ox) * C + c;
+            const unsigned pk = *reinterpret_cast<const unsigned*>(p.idx + o);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.dpool + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (((pk >> (8 * e)) & 0xffu) == want) acc[e] += g[e];
+        }
+    return acc;
+}
+
 // partial sums over a row range: part[blk][0][c] = sum dpre, part[blk][1][c] = sum dpre * xhat
+template <bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dz, const float* __restrict__ y, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
-    float* __restrict__ part, long M, int C, long rows_per_blk, int act, float slope) {
+    float* __restrict__ part, long M, int C, long rows_per_blk, int act, float slope, const PoolGather pg_ = PoolGather{}) {
     __shared__ f32x4 r1[256], r2[256];
     const int tid = threadIdx.x;
     const int CG = C / 4;
@@ -177,7 +205,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                 for (int u = 0; u < 4; ++u) {           // 8 independent 16-byte loads in flight per lane
                     long rr = r + (long)u * pg;
                     bool ok = rr < row1;
-                    g[u] = ok ? *reinterpret_cast<const f32x4*>(dz + rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (POOL) g[u] = ok ? pool_dz(pg_, rr, c, C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    else g[u] = ok ? *reinterpret_cast<const f32x4*>(dz + rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
                     v[u] = ok ? *reinterpret_cast<const f32x4*>(y + rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
@@ -258,11 +287,11 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
 // channel quad for its whole grid-stride walk and the five coefficient vectors are loaded once; otherwise the quad index
 // advances by (stride mod C/4) with one conditional subtract.  Four independent element pairs are in flight per thread (the
 // first version recomputed a 64-bit modulo and reloaded 80 bytes of coefficients per 32 bytes of data: 2.0 TB/s).
-template <int ACT, bool FIXED>
+template <int ACT, bool FIXED, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const f32x4* __restrict__ dz, const f32x4* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ sums, f32x4* __restrict__ dy,
-    long n4, int C, float slope, float* __restrict__ amax) {
+    long n4, int C, float slope, float* __restrict__ amax, const PoolGather pg_ = PoolGather{}) {
     const unsigned c4n = (unsigned)(C / 4);
     const long stride = (long)gridDim.x * 256L;
     long i = blockIdx.x * 256L + threadIdx.x;
@@ -291,14 +320,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     auto next = [&]() {
         if constexpr (!FIXED) { cq += cstep; if (cq >= c4n) cq -= c4n; coeffs(cq); }
     };
+    auto grad = [&](long q) -> f32x4 {                 // gradient of the post-activation tensor at float4 index q
+        if constexpr (POOL) return pool_dz(pg_, q / c4n, (int)(q % c4n) * 4, C);
+        else return dz[q];
+    };
     for (; i + 3 * stride < n4; i += 4 * stride) {
         f32x4 g[4], v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { g[u] = dz[i + u * stride]; v[u] = y[i + u * stride]; }
+        for (int u = 0; u < 4; ++u) { g[u] = grad(i + u * stride); v[u] = y[i + u * stride]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { dy[i + u * stride] = one(g[u], v[u]); next(); }
     }
-    for (; i < n4; i += stride) { dy[i] = one(dz[i], y[i]); next(); }
+    for (; i < n4; i += stride) { dy[i] = one(grad(i), y[i]); next(); }
     if (amax != nullptr) {           // max |dy| of the tensor: the consumers' f16x2 operand scale (order-independent, deterministic)
         __shared__ float wmax[4];
 #pragma unroll
@@ -323,10 +356,10 @@ int launch_bn_bwd_apply(const float* dz, const float* y, const float* mean, cons
     const dim3 grid((unsigned)blocks), blk(256);
     auto a0 = reinterpret_cast<const f32x4*>(dz); auto a1 = reinterpret_cast<const f32x4*>(y); auto a2 = reinterpret_cast<f32x4*>(dy);
     switch (act) {
-    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_RELU, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax); break;
-    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_LRELU, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax); break;
-    case VIAI_ACT_SIGMOID: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_SIGMOID, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax); break;
-    default: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_NONE, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax); break;
+    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_RELU, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, PoolGather{}); break;
+    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_LRELU, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, PoolGather{}); break;
+    case VIAI_ACT_SIGMOID: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_SIGMOID, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, PoolGather{}); break;
+    default: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_NONE, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, PoolGather{}); break;
     }
     return viai_launch_status();
 }
@@ -387,6 +420,27 @@ extern "C" int viai_bn_act_fwd_amax(const float* y, const float* scale, const fl
     if (256 % c4n == 0) return launch_bn_act_fwd<true>(y, scale, shift, z, n4, C, act, slope, z_amax, (hipStream_t)stream);
     return launch_bn_act_fwd<false>(y, scale, shift, z, n4, C, act, slope, z_amax, (hipStream_t)stream);
 }
+// z = act(scale*y + shift + res): BatchNorm apply + residual add + ReLU of a ResNet block in one pass (ReLU or no activation)
+extern "C" int viai_bn_add_act_fwd_amax(const float* y, const float* scale, const float* shift, const float* res, float* z,
+                                        long M, int C, int act, float slope, float* z_amax, void* stream) {
+    if (C % 4 != 0 || res == nullptr || (act != VIAI_ACT_RELU && act != VIAI_ACT_NONE)) return (int)hipErrorInvalidValue;
+    const long n4 = M * C / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), blk(256);
+    auto a0 = reinterpret_cast<const f32x4*>(y); auto a1 = reinterpret_cast<f32x4*>(z); auto a2 = reinterpret_cast<const f32x4*>(res);
+    hipStream_t st = (hipStream_t)stream;
+    const bool fixed = 256 % (C / 4) == 0;
+    if (act == VIAI_ACT_RELU) {
+        if (fixed) VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_RELU, true, true>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, z_amax, a2);
+        else VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_RELU, false, true>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, z_amax, a2);
+    } else {
+        if (fixed) VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_NONE, true, true>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, z_amax, a2);
+        else VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_NONE, false, true>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, z_amax, a2);
+    }
+    return viai_launch_status();
+}
+
 extern "C" int viai_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z,
                                long M, int C, int act, float slope, void* stream) {
     return viai_bn_act_fwd_amax(y, scale, shift, z, M, C, act, slope, nullptr, stream);
@@ -436,13 +490,43 @@ extern "C" int viai_bn_act_bwd_amax(const float* dz, const float* y, const float
     hipStream_t st = (hipStream_t)stream;
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
-    VIAI_LAUNCH(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope);
+    VIAI_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, PoolGather{});
     VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1);
     if (dy != nullptr) {
         long n4 = M * C / 4;
         const int c4n = C / 4;
         if (c4n > 0 && 256 % c4n == 0) return launch_bn_bwd_apply<true>(dz, y, mean, scale, shift, sums, dy, n4, C, act, slope, amax, st);
         return launch_bn_bwd_apply<false>(dz, y, mean, scale, shift, sums, dy, n4, C, act, slope, amax, st);
+    }
+    return viai_launch_status();
+}
+
+// The same backward where nn.MaxPool2d(k, s, p) follows the activation (ReLU or none): dpool (N, OH, OW, C) and the argmax bytes of
+// viai_bn_act_maxpool_fwd stand in for dz, which is gathered on load in both passes.  y, dy: (N, IH, IW, C).
+extern "C" int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char* idx, int N, int IH, int IW, int k, int s, int p,
+                                         const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                         float* part, float* sums, float* dgamma, float* dbeta, float* dy, int C, int act, float slope,
+                                         int training, float* amax, void* stream) {
+    if (C % 4 != 0 || dy == nullptr || k * k > 255 || (act != VIAI_ACT_RELU && act != VIAI_ACT_NONE)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const long M = (long)N * IH * IW;
+    PoolGather pg{dpool, idx, IH, IW, (IH + 2 * p - k) / s + 1, (IW + 2 * p - k) / s + 1, k, s, p};
+    const int nblk = viai_bn_bwd_blocks(M, C);
+    const long rpb = (M + nblk - 1) / nblk;
+    VIAI_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, (const float*)nullptr, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, pg);
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1);
+    const long n4 = M * C / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), blk(256);
+    auto a1 = reinterpret_cast<const f32x4*>(y); auto a2 = reinterpret_cast<f32x4*>(dy);
+    const bool fixed = 256 % (C / 4) == 0;
+    if (act == VIAI_ACT_RELU) {
+        if (fixed) VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_RELU, true, true>), grid, blk, 0, st, (const f32x4*)nullptr, a1, mean, scale, shift, (const float*)sums, a2, n4, C, slope, amax, pg);
+        else VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_RELU, false, true>), grid, blk, 0, st, (const f32x4*)nullptr, a1, mean, scale, shift, (const float*)sums, a2, n4, C, slope, amax, pg);
+    } else {
+        if (fixed) VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_NONE, true, true>), grid, blk, 0, st, (const f32x4*)nullptr, a1, mean, scale, shift, (const float*)sums, a2, n4, C, slope, amax, pg);
+        else VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_NONE, false, true>), grid, blk, 0, st, (const f32x4*)nullptr, a1, mean, scale, shift, (const float*)sums, a2, n4, C, slope, amax, pg);
     }
     return viai_launch_status();
 }

@@ -119,12 +119,20 @@ __global__ __launch_bounds__(256) void avgpool_h_bwd_kernel(const float* __restr
 
 // nn.MaxPool2d(k, s, p) on NHWC with the window argmax kept as one byte per output element (first maximum in
 // row-major window order, like torch) so that the backward is an exact gather.  (networks/Image_Embedding.py:21)
+// BN: the pooled tensor is act(scale * x + shift) (BatchNorm apply + ReLU of the ResNet stem, networks/Image_Embedding.py:20-23) formed
+// while the window is read -- the post-activation tensor is never written; amax receives max |pooled| (= max of the un-pooled tensor for
+// ReLU outputs: every pixel lies in a window)
+template <bool BN>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
-                                                          int N, int IH, int IW, int OH, int OW, int C, int k, int st, int pd) {
+                                                          int N, int IH, int IW, int OH, int OW, int C, int k, int st, int pd,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope, float* __restrict__ amax) {
     const int c4n = C / 4;
     const long total = (long)N * OH * OW * c4n;
+    float mx = 0.f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
         int c4 = (int)(i % c4n); long r = i / c4n;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BN) { sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4); sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4); }
         int ox = (int)(r % OW); r /= OW;
         int oy = (int)(r % OH); int n = (int)(r / OH);
         f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -136,13 +144,19 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
                 int ix = ox * st - pd + b;
                 if ((unsigned)ix >= (unsigned)IW) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * IH + iy) * IW + ix) * C + c4 * 4);
+                if constexpr (BN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = viai_act(v[e] * sc[e] + sh[e], act, slope);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (v[e] > best[e]) { best[e] = v[e]; bi[e] = a * k + b; }
             }
         }
         *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = best;
         *reinterpret_cast<unsigned*>(idx + (size_t)i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        if constexpr (BN) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(best[0]), fabsf(best[1]))), fmaxf(fabsf(best[2]), fabsf(best[3])));
     }
+    if constexpr (BN) { if (amax != nullptr) block_absmax_to(amax, mx); }
 }
 
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx,
@@ -304,7 +318,19 @@ extern "C" int viai_maxpool_fwd(const float* x, float* y, unsigned char* idx, in
     if (C % 4 != 0 || k * k > 255) return (int)hipErrorInvalidValue;
     int OH = (IH + 2 * p - k) / s + 1, OW = (IW + 2 * p - k) / s + 1;
     long total = (long)N * OH * OW * (C / 4);
-    VIAI_LAUNCH(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, IH, IW, OH, OW, C, k, s, p);
+    VIAI_LAUNCH(maxpool_fwd_kernel<false>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, IH, IW, OH, OW, C, k, s, p,
+                (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr);
+    return viai_launch_status();
+}
+
+// out = maxpool(act(scale * y + shift)) with the argmax bytes; act = ReLU or none (max |out| -> out_amax, optional)
+extern "C" int viai_bn_act_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, unsigned char* idx,
+                                       int N, int IH, int IW, int C, int k, int s, int p, int act, float slope, float* out_amax, void* stream) {
+    if (C % 4 != 0 || k * k > 255 || (act != VIAI_ACT_RELU && act != VIAI_ACT_NONE)) return (int)hipErrorInvalidValue;
+    int OH = (IH + 2 * p - k) / s + 1, OW = (IW + 2 * p - k) / s + 1;
+    long total = (long)N * OH * OW * (C / 4);
+    VIAI_LAUNCH(maxpool_fwd_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, out, idx, N, IH, IW, OH, OW, C, k, s, p,
+                scale, shift, act, slope, out_amax);
     return viai_launch_status();
 }
 

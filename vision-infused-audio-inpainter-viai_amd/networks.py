@@ -16,6 +16,8 @@ data is NHWC.  Tensors returned to the caller are NCHW *views* of NHWC storage
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -91,7 +93,10 @@ def _instance_norm_layer(x, conv, inorm, act, x2, transposed):
     return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
-def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None):
+FUSE_BN_TAIL = os.environ.get("VIAI_FUSE_BN_TAIL", "1") != "0"      # BatchNorm apply + (residual add + ReLU | ReLU + max-pool) in one pass (A/B switch)
+
+
+def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=None, pool=None):
     """conv (nn.Conv2d | nn.ConvTranspose2d holder) -> bn (nn.BatchNorm2d | nn.InstanceNorm2d holder | None) -> act, on NHWC.
     `xmask`: the layer convolves x * xmask (ops.conv_bn_act)."""
     transposed = isinstance(conv, nn.ConvTranspose2d)
@@ -100,10 +105,20 @@ def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None):
     if isinstance(bn, nn.InstanceNorm2d):
         if xmask is not None:
             x = ops.mask_mul(x, xmask)
-        return _instance_norm_layer(x, conv, bn, act, x2, transposed)
-    return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
-                           padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2,
-                           training=(bn.training if bn is not None else training), xmask=xmask)
+        out = _instance_norm_layer(x, conv, bn, ACT_NONE if residual is not None else act, x2, transposed)
+        if residual is not None:
+            out = ops.add_relu(out, residual) if act == ACT_RELU else out + residual
+        return ops.maxpool(out, *pool) if pool is not None else out
+    if FUSE_BN_TAIL and isinstance(bn, nn.modules.batchnorm._BatchNorm) and act in (ACT_RELU, ACT_NONE) and (residual is not None or pool is not None):
+        return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
+                               padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2, training=bn.training, xmask=xmask,
+                               residual=residual, pool=pool)
+    out = ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
+                          padding=_pair(conv.padding), transposed=transposed, act=(ACT_NONE if residual is not None else act), x2=x2,
+                          training=(bn.training if bn is not None else training), xmask=xmask)
+    if residual is not None:
+        out = ops.add_relu(out, residual) if act == ACT_RELU else out + residual
+    return ops.maxpool(out, *pool) if pool is not None else out
 
 
 def fused_pair(x, conv, bn, act, conv2, act2, x2=None):
@@ -451,9 +466,8 @@ class BasicBlock(nn.Module):
 
     def forward_nhwc(self, x):
         out = fused_layer(x, self.conv1, self.bn1, ACT_RELU)
-        out = fused_layer(out, self.conv2, self.bn2, ACT_NONE)
         res = x if self.downsample is None else fused_layer(x, self.downsample[0], self.downsample[1], ACT_NONE)
-        return ops.add_relu(out, res)
+        return fused_layer(out, self.conv2, self.bn2, ACT_RELU, residual=res)        # relu(bn2(conv2(out)) + res), networks/ResNet.py:46-53
 
     def forward(self, x):
         return to_nchw_view(self.forward_nhwc(to_nhwc(x)))
@@ -496,8 +510,7 @@ class ResNet(nn.Module):
     def forward(self, x):
         """x: (N, C, 224, 224) NCHW frames -> (N, length_feature)."""
         h = ops.frames_to_nhwc4(x)
-        h = fused_layer(h, self.conv1, self.bn1, ACT_RELU)
-        h = ops.maxpool(h, 3, 2, 1)
+        h = fused_layer(h, self.conv1, self.bn1, ACT_RELU, pool=(3, 2, 1))           # conv1 -> bn1 -> relu -> maxpool, Image_Embedding.py:20-23
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 h = blk.forward_nhwc(h)

@@ -465,9 +465,9 @@ class _ConvBnAct(torch.autograd.Function):
     New_Inpainting_Networks.py:31-37,71-75,85-88, Discriminator_Networks.py:38-49)."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, gamma, beta, rmean, rvar, nbt, cfg):
+    def forward(ctx, x, x2, weight, bias, gamma, beta, rmean, rvar, nbt, res, cfg):
         lib = _lib.load()
-        _require(x, x2, weight, bias, gamma, beta)
+        _require(x, x2, weight, bias, gamma, beta, res)
         x = _c(x)
         x2 = _c(x2) if x2 is not None else None
         weight = _c(weight)
@@ -534,11 +534,31 @@ class _ConvBnAct(torch.autograd.Function):
                 _lib.check(lib.viai_bn_eval_coeffs(Cout, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(),
                                                    rvar.data_ptr(), cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
                                                    coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_eval_coeffs")
-            z = torch.empty_like(y)
             za = _amax_slot(dev)
-            _lib.check(lib.viai_bn_act_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(),
-                                                M, Cout, act, 0.2, za.data_ptr(), st), "viai_bn_act_fwd")
-            ctx.save_for_backward(x, x2, weight, y, coef)
+            pool = cfg.get("pool")
+            if pool is not None:
+                # BatchNorm + activation + max-pool in one pass over y: the post-activation map is never stored (the backward gathers its
+                # gradient from the pooled gradient and the argmax bytes inside the BatchNorm-backward passes)
+                k_, s_, p_ = pool
+                PH, PW = (OH + 2 * p_ - k_) // s_ + 1, (OW + 2 * p_ - k_) // s_ + 1
+                z = torch.empty((N, PH, PW, Cout), device=dev, dtype=torch.float32)
+                pidx = torch.empty((N, PH, PW, Cout), device=dev, dtype=torch.uint8)
+                _lib.check(lib.viai_bn_act_maxpool_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(), pidx.data_ptr(),
+                                                       N, OH, OW, Cout, k_, s_, p_, act, 0.2, za.data_ptr(), st), "viai_bn_act_maxpool_fwd")
+                ctx.save_for_backward(x, x2, weight, y, coef, pidx)
+            elif res is not None:
+                # BatchNorm + residual add + activation in one pass (ResNet BasicBlock); z is kept: the activation's mask needs the sum
+                res = _c(res)
+                z = torch.empty_like(y)
+                _lib.check(lib.viai_bn_add_act_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), res.data_ptr(), z.data_ptr(),
+                                                        M, Cout, act, 0.2, za.data_ptr(), st), "viai_bn_add_act_fwd")
+                ctx.save_for_backward(x, x2, weight, y, coef, z)
+            else:
+                z = torch.empty_like(y)
+                _lib.check(lib.viai_bn_act_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(),
+                                                    M, Cout, act, 0.2, za.data_ptr(), st), "viai_bn_act_fwd")
+                ctx.save_for_backward(x, x2, weight, y, coef)
+            ctx.tail = "pool" if pool is not None else ("res" if res is not None else None)
         else:
             z = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
             _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
@@ -546,6 +566,10 @@ class _ConvBnAct(torch.autograd.Function):
             if act == ACT_SIGMOID:
                 za = _const_amax(dev, 1.0)
             ctx.save_for_backward(x, x2, weight, z, None)
+        if not has_bn or fused1:
+            if res is not None or cfg.get("pool") is not None:
+                raise RuntimeError("conv_bn_act: residual / pool need a BatchNorm layer on the MFMA path")
+            ctx.tail = None
         cfg["za"] = za                       # conv_bn_act attaches it to the returned tensor
         ctx.d = d
         ctx.cfg = cfg
@@ -557,7 +581,7 @@ class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         lib = _lib.load()
-        x, x2, weight, y_or_z, coef = ctx.saved_tensors
+        x, x2, weight, y_or_z, coef = ctx.saved_tensors[:5]
         d, cfg = ctx.d, ctx.cfg
         N, IH, IW, C1, C2, Cout, OH, OW = ctx.dims
         M = N * OH * OW
@@ -571,6 +595,17 @@ class _ConvBnAct(torch.autograd.Function):
         amax = None
         if ctx.fused1:
             return _ConvBnAct._backward_cin1(ctx, lib, dz, x, weight, coef, st)
+        dres = None
+        if ctx.tail == "res":
+            # d/d(sum) through the activation (mask from the saved output); the same tensor is the residual branch's gradient
+            if act != ACT_NONE:
+                dres = torch.empty_like(dz)
+                _lib.check(lib.viai_act_bwd_from_output(dz.data_ptr(), ctx.saved_tensors[5].data_ptr(), dres.data_ptr(), dz.numel(), act, 0.2, st),
+                           "viai_act_bwd_from_output")
+                dz = dres
+            else:
+                dres = dz
+            act = ACT_NONE
         if ctx.has_bn:
             nblk = lib.viai_bn_bwd_blocks(M, Cout)
             part = _scratch("bnpart", 2 * Cout * nblk, dev)
@@ -591,10 +626,18 @@ class _ConvBnAct(torch.autograd.Function):
                 f16w = d["wgrad_f16"] = bool(lib.viai_conv2d_wgrad_f16_ok(d["ref"]))
             # max |dy|: operand scale of the f16x2 data- and weight-gradient kernels
             amax = _amax_slot(dev) if (F16_BACKWARD and ((f16d and need_x) or (f16w and need_w))) else None
-            _lib.check(lib.viai_bn_act_bwd_amax(dz.data_ptr(), y_or_z.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
-                                                coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
-                                                _ptr(pg), _ptr(pb), dy.data_ptr(), M, Cout, act, 0.2,
-                                                (1 if cfg["training"] else 0) | (2 if acc_bn else 0), _ptr(amax), st), "viai_bn_act_bwd")
+            if ctx.tail == "pool":
+                k_, s_, p_ = cfg["pool"]
+                dy = torch.empty_like(y_or_z)
+                _lib.check(lib.viai_bn_act_pool_bwd_amax(dz.data_ptr(), ctx.saved_tensors[5].data_ptr(), N, OH, OW, k_, s_, p_, y_or_z.data_ptr(),
+                                                         coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
+                                                         part.data_ptr(), sums.data_ptr(), _ptr(pg), _ptr(pb), dy.data_ptr(), Cout, act, 0.2,
+                                                         (1 if cfg["training"] else 0) | (2 if acc_bn else 0), _ptr(amax), st), "viai_bn_act_pool_bwd")
+            else:
+                _lib.check(lib.viai_bn_act_bwd_amax(dz.data_ptr(), y_or_z.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                                    coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
+                                                    _ptr(pg), _ptr(pb), dy.data_ptr(), M, Cout, act, 0.2,
+                                                    (1 if cfg["training"] else 0) | (2 if acc_bn else 0), _ptr(amax), st), "viai_bn_act_bwd")
         elif act == ACT_NONE:
             dy = dz
         else:
@@ -603,7 +646,7 @@ class _ConvBnAct(torch.autograd.Function):
                                                     0.2, st), "viai_act_bwd_from_output")
         dx, dx2, dw, db = _conv_grads(lib, d, cfg, ctx.dims, ctx.has_bn, ctx.has_bias, (need_x, need_x2, need_w, need_b), ctx.xa,
                                       x, x2, weight, dy, amax, st)
-        return dx, dx2, dw, db, dgamma, dbeta, None, None, None, None
+        return dx, dx2, dw, db, dgamma, dbeta, None, None, None, dres, None
 
 
 def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
@@ -671,7 +714,7 @@ def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
         if xmask is not None:                                   # d/ds of conv(s * mask)
             N_, T_ = xmask.shape[0], xmask.shape[-1]
             _lib.check(lib.viai_mask_mul(dx.data_ptr(), xmask.data_ptr(), dx.data_ptr(), N_, dx.numel() // (N_ * T_), T_, st), "viai_mask_mul")
-    return dx, None, dw, None, dgamma, dbeta, None, None, None, None
+    return dx, None, dw, None, dgamma, dbeta, None, None, None, None, None
 
 
 _ConvBnAct._backward_cin1 = staticmethod(_backward_cin1)
@@ -690,11 +733,16 @@ def _cin1_fused_applies(x, weight, bias, bn, kernel, stride, padding, transposed
 
 
 def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding=(0, 0), transposed=False,
-                act=ACT_NONE, x2=None, training=True, dilation=(1, 1), padding2=(-1, -1), xmask=None):
+                act=ACT_NONE, x2=None, training=True, dilation=(1, 1), padding2=(-1, -1), xmask=None, residual=None, pool=None):
     """Fused layer on NHWC tensors.  `bn` is an nn.BatchNorm2d (parameter/buffer holder) or None.
     `padding2` = (bottom, right) padding when it differs from `padding` (-1 = symmetric).
     `xmask` (N, W) or (N,1,1,W): the layer convolves x * xmask (the inpainting step's time mask).  The fused Cin = 1 layer multiplies
-    while it loads x; every other kernel gets a masked copy first."""
+    while it loads x; every other kernel gets a masked copy first.
+    `residual` (BatchNorm layers): act(BN(conv(x)) + residual) in the BatchNorm-apply pass -- the join of networks/ResNet.py:49-53.
+    `pool` = (k, s, p) (BatchNorm layers, act ReLU / none): max_pool2d(act(BN(conv(x))), k, s, p) without storing the un-pooled map --
+    the stem of networks/Image_Embedding.py:20-23."""
+    if (residual is not None or pool is not None) and (bn is None or (residual is not None and pool is not None) or act not in (ACT_RELU, ACT_NONE)):
+        raise ValueError("conv_bn_act: residual / pool take a BatchNorm layer, ReLU or no activation, and exclude each other")
     if xmask is not None:
         xmask = _c(xmask.reshape(xmask.shape[0], xmask.shape[-1]))
         trainmode = training if (bn is None or (bn.track_running_stats and bn.running_mean is not None)) else True
@@ -704,7 +752,8 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
             xmask = None
     cfg = {"k": tuple(kernel), "s": tuple(stride), "p": tuple(padding), "transposed": bool(transposed),
            "act": int(act), "training": bool(training), "momentum": 0.1, "eps": BN_EPS,
-           "d": tuple(dilation), "p2": tuple(padding2), "xa_in": (amax_of(x), amax_of(x2)), "xmask": xmask}
+           "d": tuple(dilation), "p2": tuple(padding2), "xa_in": (amax_of(x), amax_of(x2)), "xmask": xmask,
+           "pool": tuple(int(v) for v in pool) if pool is not None else None}
     if bn is not None:
         cfg["momentum"] = 0.1 if bn.momentum is None else float(bn.momentum)
         cfg["eps"] = float(bn.eps)
@@ -716,11 +765,11 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
                               for p in (weight, bias, bn.weight, bn.bias))
         return _tag_amax(_ConvBnAct.apply(x, x2, weight, bias, bn.weight, bn.bias,
                                           bn.running_mean if track else None, bn.running_var if track else None,
-                                          bn.num_batches_tracked if (track and cfg["training"]) else None, cfg), cfg)
+                                          bn.num_batches_tracked if (track and cfg["training"]) else None, residual, cfg), cfg)
     if DIRECT_GRAD:
         cfg["gt"] = tuple(p.grad if (p is not None and p.is_leaf and p.requires_grad and p.grad is not None) else None
                           for p in (weight, bias, None, None))
-    return _tag_amax(_ConvBnAct.apply(x, x2, weight, bias, None, None, None, None, None, cfg), cfg)
+    return _tag_amax(_ConvBnAct.apply(x, x2, weight, bias, None, None, None, None, None, None, cfg), cfg)
 
 
 def _tag_amax(z, cfg):
