@@ -404,8 +404,11 @@ def main_wavenet(args):
     ms = timing["ms"] / timing["steps"]
     n_param = sum(p.numel() for p in net.parameters())
     fused = os.environ.get("VIAI_WN_FUSED", "1") != "0"
-    n_launch = len(net.conv_layers) + 1 if fused else 2 * len(net.conv_layers) + 2
-    kernel_chain = "wn_stage_kernel x %d / wn_head_fused_kernel" % len(net.conv_layers) if fused else "wn_gate_kernel / wn_out_kernel / wn_head_kernel"
+    head_rows = os.environ.get("VIAI_WN_HEAD_ROWS", "1") != "0"
+    n_launch = len(net.conv_layers) + (3 if head_rows else 1) if fused else 2 * len(net.conv_layers) + 2
+    kernel_chain = ("wn_stage_kernel x %d / %s" % (len(net.conv_layers), "wn_head_rows_kernel x 2 / wn_head_sample_kernel (head rows spread over the blocks, every row read once for all streams)"
+                                                   if head_rows else "wn_head_fused_kernel")
+                    if fused else "wn_gate_kernel / wn_out_kernel / wn_head_kernel")
     launch_form = ("fused stages: gate_l computed from z_(l-1) and x_(l-1)(t) through host-folded rows [Wc0 | Wc1 | r Wc2 | r Wc2 Wo_prev], "
                    "one dependent launch per layer") if fused else "two dependent launches per layer (VIAI_WN_FUSED=0)"
     # weight bytes one time step must stream: every layer's linearised dilated conv (3 x 512 x 512), conditioning (512 x 80), out and

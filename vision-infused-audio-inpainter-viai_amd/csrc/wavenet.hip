@@ -951,6 +951,74 @@ __global__ __launch_bounds__(1024) void wn_head_fused_kernel(const float* __rest
     }
 }
 
+// ---- the head as three row-parallel launches -------------------------------------------------------------------------------------
+// wn_head_fused_kernel runs one block per stream: each of the 8 blocks pulls the 0.5 MB of head weights through ONE compute unit (25 us per
+// time step, rocprofv3).  Spread over the rows instead -- a wave per row, every weight row read once for all streams, as the stages do:
+//   rows kernel, mode 0: skips <- relu((skips + Ws z + bs) sqrt(.5))   (the last layer's skip rows; in place)
+//   rows kernel, mode 1: hid   <- relu(W1 skips + b1)                   (hid lives in the z buffer the last stage did not write)
+//   wn_head_sample_kernel: logits of stream b = W2 hid_b + b2 and the mixture-of-logistics sample (mixture.py:125-153, injected uniforms)
+template <int NB>
+__global__ __launch_bounds__(256) void wn_head_rows_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ x, int K,
+                                                           float* __restrict__ out, int nrows, int mode, int first_skip) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= nrows) return;
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    float pre = 0.f;
+    if (mode == 0 && !first_skip && lane < NB) pre = out[(size_t)lane * nrows + o];
+    const float bv = bias[o];
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)o * K + k);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + k);
+            acc[b] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+        }
+    }
+    const float r5 = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float v = wave_sum_dpp(acc[b]) + bv;
+        const float p = __shfl(pre, b, 64);
+        if (lane == 0) {
+            const float y = mode == 0 ? (first_skip ? v : (p + v) * r5) : v;
+            out[(size_t)b * nrows + o] = y > 0.f ? y : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wn_head_sample_kernel(const float* __restrict__ hid, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             const float* __restrict__ u1, const float* __restrict__ u2, float* __restrict__ out,
+                                                             float* __restrict__ yhat_dbg, const int* __restrict__ step, int t_arg, int S, int OC, int T,
+                                                             float log_scale_min) {
+    __shared__ float yo[256];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = t_arg >= 0 ? t_arg : *step - 1;
+    const int K3 = OC / 3;
+    for (int o = wave; o < OC; o += 4) {
+        float acc = 0.f;
+        for (int k = lane * 4; k < S; k += 256) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w2 + (size_t)o * S + k);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(hid + (size_t)b * S + k);
+            acc += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+        }
+        const float v = wave_sum_dpp(acc) + b2[o];
+        if (lane == 0) { yo[o] = v; if (yhat_dbg) yhat_dbg[((size_t)b * T + t) * OC + o] = v; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float best = -INFINITY; int arg = 0;
+        for (int k = 0; k < K3; ++k) {
+            const float v = yo[k] - logf(-logf(u1[((size_t)b * T + t) * K3 + k]));
+            if (v > best) { best = v; arg = k; }
+        }
+        const float m = yo[K3 + arg], ls = fmaxf(yo[2 * K3 + arg], log_scale_min), u = u2[(size_t)b * T + t];
+        const float x = m + expf(ls) * (logf(u) - logf(1.f - u));
+        out[(size_t)b * T + t] = fminf(fmaxf(x, -1.f), 1.f);
+    }
+}
+
 bool wn_fused_ok(const viai_wn_synth* s) {
     if (!s->fused || s->z2 == nullptr) return false;
     if (s->S > 256 || s->out_ch > 256 || s->G / 2 > 256) return false;
@@ -979,6 +1047,16 @@ int wn_step_fused_impl(const viai_wn_synth* s, int t_arg, hipStream_t st) {
         a.step = s->step; a.t_arg = t_arg; a.l = l; a.C = C; a.H = H; a.S = S; a.cin = s->cin; a.T = s->T; a.B = s->B;
         const int nb = H + (l == 0 ? 1 : (C + S + 3) / 4);
         VIAI_LAUNCH(wn_stage_kernel<NB>, dim3(nb), dim3(256), 0, st, a);
+    }
+    static const bool split_head = !(getenv("VIAI_WN_HEAD_ROWS") != nullptr && atoi(getenv("VIAI_WN_HEAD_ROWS")) == 0);
+    if (split_head && S <= H && s->out_ch <= 256) {
+        float* zlast = zb[(n - 1) & 1];
+        float* hid = zb[n & 1];                    // (B, S) fits the (B, H) buffer; the next time step's stage 0 overwrites it
+        VIAI_LAUNCH(wn_head_rows_kernel<NB>, dim3((S + 3) / 4), dim3(256), 0, st, L[n - 1].w_skip, L[n - 1].b_skip, (const float*)zlast, H, s->skips, S, 0, n == 1 ? 1 : 0);
+        VIAI_LAUNCH(wn_head_rows_kernel<NB>, dim3((S + 3) / 4), dim3(256), 0, st, s->w_l1, s->b_l1, (const float*)s->skips, S, hid, S, 1, 0);
+        VIAI_LAUNCH(wn_head_sample_kernel, dim3(s->B), dim3(256), 0, st, (const float*)hid, s->w_l2, s->b_l2, s->u1, s->u2, s->out, s->yhat_dbg, s->step, t_arg, S,
+                    s->out_ch, s->T, s->log_scale_min);
+        return viai_launch_status();
     }
     VIAI_LAUNCH(wn_head_fused_kernel, dim3(s->B), dim3(1024), (2 * S + ((s->out_ch + 3) & ~3) + s->out_ch / 3 + 1) * sizeof(float), st,
                 s->skips, zb[(n - 1) & 1], L[n - 1].w_skip, L[n - 1].b_skip, n == 1 ? 1 : 0, H, s->w_l1, s->b_l1, s->w_l2, s->b_l2, s->u1, s->u2,
