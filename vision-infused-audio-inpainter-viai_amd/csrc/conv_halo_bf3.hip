@@ -832,6 +832,11 @@ int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
     if (a.Cout == 32) return launch_halo_wide<4, 1, 1, 1>(a, y0, x0, sl, st);
     if (a.Cout == 64 || (long)a.nblk_m * (a.Cout / 128) < 192) return launch_halo_wide<2, 2, 2, 1>(a, y0, x0, sl, st);
     constexpr int wn4 = 1;
+    // 256-channel blocks: eight waves, each ALL 128 pixels x 32 channels (<1,8,4,1>) rather than 64 x 64 (<2,4,2,2>): a weight fragment
+    // then feeds four M tiles, so the fragment stream through L1 halves (2 KB per 12 MFMAs) while the patch reads from LDS double (8 KB) --
+    // LDS has twice L1's bandwidth, and the registers drop 231 -> 215.  D.conv3 203.5 -> 198 us, step 7.455 -> 7.423 ms (same box A/B).
+    constexpr int tm4 = 1;
+    if (tm4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<1, 8, 4, 1>(a, y0, x0, sl, st);
     if (wn4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<2, 4, 2, 2>(a, y0, x0, sl, st);
     return launch_halo_wide<2, 2, 2, 2>(a, y0, x0, sl, st);
 }
