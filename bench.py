@@ -49,7 +49,7 @@ FAMILY_KERNELS = {
     "wgrad32_all_taps_f32": "wgrad32_halo_kernel (exact fp32 MFMA, <= 32 x <= 32 channels, stride 1: all taps per block)",
     "halo_wide256_f16x2": "conv_halo_wide_f16_kernel<1,8,4,1> (stride-1 3x3 conv, 8x16-pixel x 256-channel tile, eight waves of 128 pixels x 32 channels, f16x2 split MFMA: the 10x18 input patch of a 32-channel chunk is "
                           "staged once in LDS and read by all nine taps; weight fragments straight from global; forward and data-gradient launches of D.conv3)",
-    "halo_wide128_f16x2": "conv_halo_wide_f16_kernel<2,2,2,2> (as above, 128-channel tile, four waves of 64 x 64)",
+    "halo_wide128_f16x2": "conv_halo_wide_f16_kernel<1,4,4,1> (as above, 128-channel tile, four waves of 128 pixels x 32 channels)",
     "halo_wide64_f16x2": "conv_halo_wide_f16_kernel<2,2,2,1> (64-channel tile)", "halo_wide32_f16x2": "conv_halo_wide_f16_kernel<4,1,1,1> (32-channel tile)",
     "halo_wide_s2_f16x2": "conv_halo_wide_f16_kernel<2,4,2,{2,1},2> (stride-2 forward, four parity sub-patches)",
     "halo_c32_f16x2": "conv_halo_f16_c32_kernel (32 -> <= 32 channels, stride-1 3x3, the whole filter in registers; f16x2)",

@@ -828,6 +828,7 @@ int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
     HaloWideSlots sl;
     for (int t = 0; t < 9; ++t) sl.s[(g.dy[t] - y0) * 3 + (g.dx[t] - x0)] = g.ws[t];
     a.nblk_m = g.N * viai_halo_tiles_y(g) * viai_halo_tiles_x(g);
+    // (stride 2 keeps the 64-pixel wave tiles: <1,8,4,1,2> 70.7 vs 72.1 us on D.conv2_2 but with spills, <1,4,4,1,2> 269 vs 101 us on D.conv2_1)
     if (g.my == 2) return (a.Cout % 256 == 0) ? launch_halo_wide<2, 4, 2, 2, 2>(a, y0, x0, sl, st) : launch_halo_wide<2, 4, 2, 1, 2>(a, y0, x0, sl, st);
     if (a.Cout == 32) return launch_halo_wide<4, 1, 1, 1>(a, y0, x0, sl, st);
     if (a.Cout == 64 || (long)a.nblk_m * (a.Cout / 128) < 192) return launch_halo_wide<2, 2, 2, 1>(a, y0, x0, sl, st);
@@ -838,5 +839,5 @@ int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
     constexpr int tm4 = 1;
     if (tm4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<1, 8, 4, 1>(a, y0, x0, sl, st);
     if (wn4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<2, 4, 2, 2>(a, y0, x0, sl, st);
-    return launch_halo_wide<2, 2, 2, 2>(a, y0, x0, sl, st);
+    return launch_halo_wide<1, 4, 4, 1>(a, y0, x0, sl, st);           // (128-channel blocks, same reasoning: 899 -> 855 us on 1024 x 28 x 28 x 128, 122.5 -> 117 us on 16 x 64 x 128 x 128)
 }
