@@ -93,6 +93,7 @@ def _instance_norm_layer(x, conv, inorm, act, x2, transposed):
     return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
+FLOW_STREAM = os.environ.get("VIAI_FLOW_STREAM", "1") != "0"           # ImageEmbedding: the flow ResNet on its own stream (A/B switch)
 FUSE_BN_TAIL = os.environ.get("VIAI_FUSE_BN_TAIL", "1") != "0"      # BatchNorm apply + (residual add + ReLU | ReLU + max-pool) in one pass (A/B switch)
 
 
@@ -562,9 +563,31 @@ class ImageEmbedding2(_ImageEmbeddingBase):
         sz = getattr(self.hparams, "image_size", 224)
         lf = getattr(self.hparams, "length_feature", 256)
         b = video_block.size(0)
-        img = self.image_single_model(video_block.reshape(-1, 3, sz, sz)).reshape(b, -1, lf)
-        flw = self.flow_single_model(flow_block.reshape(-1, 2, sz, sz)).reshape(b, -1, lf)
+        side = self._flow_stream(flow_block)
+        if side is None:
+            img = self.image_single_model(video_block.reshape(-1, 3, sz, sz)).reshape(b, -1, lf)
+            flw = self.flow_single_model(flow_block.reshape(-1, 2, sz, sz)).reshape(b, -1, lf)
+        else:
+            # the two ResNets share nothing: the flow network runs on its own stream next to the RGB network (autograd replays each
+            # backward node on its forward stream, so the two backward chains overlap the same way).  What either chain leaves idle --
+            # kernel tails, the BatchNorm passes' memory latency -- the other fills.
+            cur = torch.cuda.current_stream(flow_block.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                flw = self.flow_single_model(flow_block.reshape(-1, 2, sz, sz)).reshape(b, -1, lf)
+            flow_block.record_stream(side)
+            img = self.image_single_model(video_block.reshape(-1, 3, sz, sz)).reshape(b, -1, lf)
+            cur.wait_stream(side)
+            flw.record_stream(cur)
         return torch.cat((img, flw), 2).transpose(2, 1)                # (B, 512, N)
+
+    def _flow_stream(self, t):
+        if not (FLOW_STREAM and t.is_cuda) or torch.cuda.is_current_stream_capturing():
+            return None
+        st = getattr(self, "_flow_side", None)
+        if st is None or st.device != t.device:
+            st = self._flow_side = torch.cuda.Stream(device=t.device)
+        return st
 
     def forward(self, video_block, flow_block):
         fea_cat = self._features(video_block, flow_block)
