@@ -551,7 +551,9 @@ def main():
                                                       "PatchGAN D" if args.config == "av" else "3-scale D", args.bins, args.frames, args.batch)),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                    "launch": ("launch plan replayed from C (3 segments; same kernels / streams / edges as the eager step)" if args.plan else
-                              "hipGraph replay (3 segments)" if args.graph else "eager, weight gradients on a side stream"),
+                              "hipGraph replay (3 segments)" if args.graph else
+                              ("eager; the RGB and the flow ResNet as two chains on two streams, each with its own weight gradients" if (av and model._wgrad_stream is None)
+                               else "eager, weight gradients on a side stream")),
                    "math": math_string(),
                    "host_enqueue_ms_per_step": round(enqueue_ms / args.steps, 3),
                    "loss_d": round(losses[0], 5), "loss_g": round(losses[1], 5)},

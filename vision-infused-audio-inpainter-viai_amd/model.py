@@ -207,8 +207,12 @@ class AudioModel:
         # weight gradients trail on a side stream (ops.WGRAD_STREAM) in eager mode: -3.5 % step time on one MI355X.  Inside
         # a captured hipGraph the fork/join edges cost more than the overlap returns (+2 %), so graph mode stays on one
         # stream.  VIAI_WGRAD_STREAM=0/1 overrides.
+        # With the visual branch the two ResNets already run as two chains on two streams (networks.ImageEmbedding2), each carrying its
+        # own weight gradients; funnelling all of them through one trailing stream costs more than it overlaps (120.8 vs 124.1 ms).
         one_stream = self.use_graph and not self.use_plan
-        side = os.environ.get("VIAI_WGRAD_STREAM", "0" if one_stream else "1") != "0"
+        from . import networks as _nets
+        two_chains = self.use_video and _nets.FLOW_STREAM
+        side = os.environ.get("VIAI_WGRAD_STREAM", "0" if (one_stream or two_chains) else "1") != "0"
         self._wgrad_stream = torch.cuda.Stream(device=self.device) if side else None
         dreal = os.environ.get("VIAI_DREAL_STREAM", "0" if one_stream else "1") != "0"
         self._dreal_stream = torch.cuda.Stream(device=self.device) if dreal else None
@@ -545,6 +549,7 @@ class AudioModel:
             seeds.append(self._const(self.cfg.lambda_contrast))
         self._arm_hooks(self.arena_G, self._early_G, 1)
         torch.autograd.backward(roots, seeds)
+        ops.join_side_streams()                   # (the visual branch's flow network back-propagates on its own stream)
         if self._lc is not None:
             self.EmbeddingL2 = self._lc.detach()
         ops.join_wgrad()

@@ -587,6 +587,7 @@ class ImageEmbedding2(_ImageEmbeddingBase):
         st = getattr(self, "_flow_side", None)
         if st is None or st.device != t.device:
             st = self._flow_side = torch.cuda.Stream(device=t.device)
+            ops.SIDE_STREAMS.append(st)
         return st
 
     def forward(self, video_block, flow_block):

@@ -226,6 +226,20 @@ def drop_scratch():
     _scratch_pool.clear()
 
 
+# Streams a module forks work onto inside the forward pass (networks.ImageEmbedding2: the flow ResNet).  Autograd replays their backward
+# nodes on the same streams, and a branch that ends in a parameter (no data gradient flows back to the caller's stream) is joined by
+# nothing: whoever reads the gradients after backward() calls join_side_streams() first.
+SIDE_STREAMS = []
+
+
+def join_side_streams():
+    if SIDE_STREAMS:
+        cur = torch.cuda.current_stream()
+        for s in SIDE_STREAMS:
+            if s.device == cur.device:
+                cur.wait_stream(s)
+
+
 def _scratch(tag, n, dev, stream=None):
     key = (tag, dev.index, stream.cuda_stream if stream is not None else _stream())
     t = _scratch_pool.get(key)
