@@ -160,13 +160,36 @@ struct PoolGather {
     const float* dpool; const unsigned char* idx;
     int IH, IW, OH, OW, k, st, pd;
 };
-__device__ __forceinline__ f32x4 pool_dz(const PoolGather& p, long row, int c, int C) {
-    const int ix = (int)(row % p.IW); const long r = row / p.IW;
-    const int iy = (int)(r % p.IH); const long n = r / p.IH;
+// pixel (n, iy, ix) of the un-pooled map, channels c .. c + 3.  The kernels below walk the pixels with a constant stride and keep the
+// three coordinates incrementally (PoolPos): the two 64-bit divisions per element of the first version made the pass instruction-bound
+// (4.8 ms on 3.3 GB where the memory time is ~1 ms).
+__device__ __forceinline__ f32x4 pool_dz(const PoolGather& p, int n, int iy, int ix, int c, int C) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int oy_lo = iy + p.pd - p.k + 1 < 0 ? 0 : (iy + p.pd - p.k + 1 + p.st - 1) / p.st;
     const int ox_lo = ix + p.pd - p.k + 1 < 0 ? 0 : (ix + p.pd - p.k + 1 + p.st - 1) / p.st;
     const int oy_hi = min((iy + p.pd) / p.st, p.OH - 1), ox_hi = min((ix + p.pd) / p.st, p.OW - 1);
+    if (p.k <= 2 * p.st) {
+        // at most 2 x 2 windows hold a pixel (k <= 2 s: the 3 x 3 / stride 2 pool of the stem): all four candidates are fetched up front
+        // (clamped addresses, a validity bit each) so that eight loads are in flight per element instead of a chain of dependent pairs
+        unsigned pk[4]; f32x4 g[4]; unsigned want[4]; bool ok[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int oy = oy_lo + a, ox = ox_lo + b;
+                ok[a * 2 + b] = oy <= oy_hi && ox <= ox_hi;
+                const int oyc = min(oy, oy_hi), oxc = min(ox, ox_hi);
+                want[a * 2 + b] = (unsigned)((iy - (oy * p.st - p.pd)) * p.k + (ix - (ox * p.st - p.pd)));
+                const size_t o = (((size_t)n * p.OH + oyc) * p.OW + oxc) * C + c;
+                pk[a * 2 + b] = *reinterpret_cast<const unsigned*>(p.idx + o);
+                g[a * 2 + b] = *reinterpret_cast<const f32x4*>(p.dpool + o);
+            }
+#pragma unroll
+        for (int w = 0; w < 4; ++w)                 // (same order as the loop below: oy outer, ox inner)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (ok[w] && ((pk[w] >> (8 * e)) & 0xffu) == want[w]) acc[e] += g[w][e];
+        return acc;
+    }
     for (int oy = oy_lo; oy <= oy_hi; ++oy)
         for (int ox = ox_lo; ox <= ox_hi; ++ox) {
             const unsigned want = (unsigned)((iy - (oy * p.st - p.pd)) * p.k + (ix - (ox * p.st - p.pd)));
@@ -178,6 +201,19 @@ __device__ __forceinline__ f32x4 pool_dz(const PoolGather& p, long row, int c, i
         }
     return acc;
 }
+struct PoolPos {
+    int n, iy, ix;
+    __device__ __forceinline__ void set(const PoolGather& p, long row) {
+        ix = (int)(row % p.IW); const long r = row / p.IW;
+        iy = (int)(r % p.IH); n = (int)(r / p.IH);
+    }
+    // advance by (dn images, dy rows, dx pixels), dx < IW, dy < IH
+    __device__ __forceinline__ void step(const PoolGather& p, int dn, int dy, int dx) {
+        ix += dx; if (ix >= p.IW) { ix -= p.IW; ++iy; }
+        iy += dy; if (iy >= p.IH) { iy -= p.IH; ++n; }
+        n += dn;
+    }
+};
 
 // partial sums over a row range: part[blk][0][c] = sum dpre, part[blk][1][c] = sum dpre * xhat
 template <bool POOL = false>
@@ -199,13 +235,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             const int c = (g0 + cg) * 4;
             f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
             f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+            PoolPos pp{0, 0, 0};
+            int sy = 0, sx = 0;                          // the row stride pg as (rows, pixels) of the un-pooled map
+            if constexpr (POOL) { pp.set(pg_, row0 + pl); sy = (pg / pg_.IW) % pg_.IH; sx = pg % pg_.IW; }
+            const int sn = POOL ? pg / (pg_.IW * pg_.IH) : 0;
             for (long r = row0 + pl; r < row1; r += 4L * pg) {
                 f32x4 g[4], v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {           // 8 independent 16-byte loads in flight per lane
                     long rr = r + (long)u * pg;
                     bool ok = rr < row1;
-                    if constexpr (POOL) g[u] = ok ? pool_dz(pg_, rr, c, C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (POOL) { g[u] = ok ? pool_dz(pg_, pp.n, pp.iy, pp.ix, c, C) : f32x4{0.f, 0.f, 0.f, 0.f}; pp.step(pg_, sn, sy, sx); }
                     else g[u] = ok ? *reinterpret_cast<const f32x4*>(dz + rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
                     v[u] = ok ? *reinterpret_cast<const f32x4*>(y + rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -320,9 +360,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     auto next = [&]() {
         if constexpr (!FIXED) { cq += cstep; if (cq >= c4n) cq -= c4n; coeffs(cq); }
     };
-    auto grad = [&](long q) -> f32x4 {                 // gradient of the post-activation tensor at float4 index q
-        if constexpr (POOL) return pool_dz(pg_, q / c4n, (int)(q % c4n) * 4, C);
-        else return dz[q];
+    // POOL: the pixel of float4 index i, kept incrementally; the walk advances by `stride` float4s = (stride / c4n) pixels + (stride % c4n) quads
+    PoolPos pp{0, 0, 0};
+    int pq = 0, sn = 0, sy = 0, sx = 0, sq = 0;
+    if constexpr (POOL) {
+        pp.set(pg_, i / c4n); pq = (int)(i % c4n);
+        const long srow = stride / c4n; sq = (int)(stride % c4n);
+        sx = (int)(srow % pg_.IW); sy = (int)((srow / pg_.IW) % pg_.IH); sn = (int)(srow / ((long)pg_.IW * pg_.IH));
+    }
+    auto grad = [&](long q) -> f32x4 {                 // gradient of the post-activation tensor at float4 index q (POOL: q is the walk's current index)
+        if constexpr (POOL) {
+            const f32x4 gq = pool_dz(pg_, pp.n, pp.iy, pp.ix, pq * 4, C);
+            pq += sq;
+            int carry = 0;
+            if (pq >= (int)c4n) { pq -= c4n; carry = 1; }
+            pp.step(pg_, sn, sy, sx);
+            if (carry) pp.step(pg_, 0, 0, 1);
+            return gq;
+        } else return dz[q];
     };
     for (; i + 3 * stride < n4; i += 4 * stride) {
         f32x4 g[4], v[4];
