@@ -93,6 +93,7 @@ def _instance_norm_layer(x, conv, inorm, act, x2, transposed):
     return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
+_FLOW_STREAMS = {}
 FLOW_STREAM = os.environ.get("VIAI_FLOW_STREAM", "1") != "0"           # ImageEmbedding: the flow ResNet on its own stream (A/B switch)
 FUSE_BN_TAIL = os.environ.get("VIAI_FUSE_BN_TAIL", "1") != "0"      # BatchNorm apply + (residual add + ReLU | ReLU + max-pool) in one pass (A/B switch)
 
@@ -584,9 +585,9 @@ class ImageEmbedding2(_ImageEmbeddingBase):
     def _flow_stream(self, t):
         if not (FLOW_STREAM and t.is_cuda) or torch.cuda.is_current_stream_capturing():
             return None
-        st = getattr(self, "_flow_side", None)
-        if st is None or st.device != t.device:
-            st = self._flow_side = torch.cuda.Stream(device=t.device)
+        st = _FLOW_STREAMS.get(t.device.index)          # one per device for the process (ops.SIDE_STREAMS must not grow with every model)
+        if st is None:
+            st = _FLOW_STREAMS[t.device.index] = torch.cuda.Stream(device=t.device)
             ops.SIDE_STREAMS.append(st)
         return st
 
