@@ -96,13 +96,15 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
 // z = act(scale*y + shift).  FIXED: 256 % (C/4) == 0 -> one channel quad per thread, coefficients loaded once (see
 // bn_bwd_apply_kernel); four independent 16-byte loads in flight per thread.
 // RES: z = act(scale*y + shift + res) -- the residual join of a ResNet block (networks/ResNet.py:49-53) in the same pass.
-template <int ACT, bool FIXED, bool RES = false>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale,
+// NT threads per block: 256, or 1024 when the pass ends in the abs-max atomics (one fat block per CU: 8x fewer same-address atomics
+// queued behind the kernel's last store, viai_common.h block_absmax_to)
+template <int ACT, bool FIXED, bool RES = false, int NT = 256>
+__global__ __launch_bounds__(NT) void bn_act_fwd_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, f32x4* __restrict__ z,
                                                          long n4, int C, float slope, float* __restrict__ amax, const f32x4* __restrict__ res = nullptr) {
     const unsigned c4n = (unsigned)(C / 4);
-    const long stride = (long)gridDim.x * 256L;
-    long i = blockIdx.x * 256L + threadIdx.x;
+    const long stride = (long)gridDim.x * NT;
+    long i = blockIdx.x * (long)NT + threadIdx.x;
     unsigned cq = (unsigned)((unsigned long)i % c4n);
     const unsigned cstep = (unsigned)((unsigned long)stride % c4n);
     f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cq * 4), sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
@@ -131,19 +133,36 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const f32x4* __restrict
     if (amax != nullptr) block_absmax_to(amax, mx);
 }
 
+// grid of a streaming pass over n4 float4 items: 256-thread blocks, at most 2048 of them -- or, when the pass ends in the abs-max
+// atomics, 1024-thread blocks, at most one per CU
+inline bool amax_fat_blocks() {              // VIAI_AMAX_FAT=0: the 2048 x 256-thread grid also for the passes that end in the abs-max atomics (A/B)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_AMAX_FAT"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+inline unsigned stream_grid(long n4, int nt) {
+    long blocks = (n4 + nt - 1) / nt;
+    const long cap = nt == 1024 ? 256 : 2048;
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+template <int ACT, bool FIXED, bool RES>
+int launch_bn_act_fwd_t(const float* y, const float* scale, const float* shift, const float* res, float* z, long n4, int C, float slope, float* amax, hipStream_t st) {
+    auto a0 = reinterpret_cast<const f32x4*>(y); auto a1 = reinterpret_cast<f32x4*>(z); auto a2 = reinterpret_cast<const f32x4*>(res);
+    if (amax != nullptr && amax_fat_blocks()) VIAI_LAUNCH((bn_act_fwd_kernel<ACT, FIXED, RES, 1024>), dim3(stream_grid(n4, 1024)), dim3(1024), 0, st, a0, scale, shift, a1, n4, C, slope, amax, a2);
+    else VIAI_LAUNCH((bn_act_fwd_kernel<ACT, FIXED, RES, 256>), dim3(stream_grid(n4, 256)), dim3(256), 0, st, a0, scale, shift, a1, n4, C, slope, amax, a2);
+    return viai_launch_status();
+}
+
 template <bool FIXED>
 int launch_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z, long n4, int C, int act, float slope, float* amax, hipStream_t st) {
-    long blocks = (n4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    const dim3 grid((unsigned)blocks), blk(256);
-    auto a0 = reinterpret_cast<const f32x4*>(y); auto a1 = reinterpret_cast<f32x4*>(z);
     switch (act) {
-    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_RELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax, (const f32x4*)nullptr); break;
-    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_LRELU, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax, (const f32x4*)nullptr); break;
-    case VIAI_ACT_SIGMOID: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_SIGMOID, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax, (const f32x4*)nullptr); break;
-    default: VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_NONE, FIXED>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, amax, (const f32x4*)nullptr); break;
+    case VIAI_ACT_RELU: return launch_bn_act_fwd_t<VIAI_ACT_RELU, FIXED, false>(y, scale, shift, nullptr, z, n4, C, slope, amax, st);
+    case VIAI_ACT_LRELU: return launch_bn_act_fwd_t<VIAI_ACT_LRELU, FIXED, false>(y, scale, shift, nullptr, z, n4, C, slope, amax, st);
+    case VIAI_ACT_SIGMOID: return launch_bn_act_fwd_t<VIAI_ACT_SIGMOID, FIXED, false>(y, scale, shift, nullptr, z, n4, C, slope, amax, st);
+    default: return launch_bn_act_fwd_t<VIAI_ACT_NONE, FIXED, false>(y, scale, shift, nullptr, z, n4, C, slope, amax, st);
     }
-    return viai_launch_status();
 }
 
 __device__ __forceinline__ float act_grad(float pre, int act, float slope) {
@@ -327,14 +346,14 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
 // channel quad for its whole grid-stride walk and the five coefficient vectors are loaded once; otherwise the quad index
 // advances by (stride mod C/4) with one conditional subtract.  Four independent element pairs are in flight per thread (the
 // first version recomputed a 64-bit modulo and reloaded 80 bytes of coefficients per 32 bytes of data: 2.0 TB/s).
-template <int ACT, bool FIXED, bool POOL = false>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+template <int ACT, bool FIXED, bool POOL = false, int NT = 256>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     const f32x4* __restrict__ dz, const f32x4* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ sums, f32x4* __restrict__ dy,
     long n4, int C, float slope, float* __restrict__ amax, const PoolGather pg_ = PoolGather{}) {
     const unsigned c4n = (unsigned)(C / 4);
-    const long stride = (long)gridDim.x * 256L;
-    long i = blockIdx.x * 256L + threadIdx.x;
+    const long stride = (long)gridDim.x * NT;
+    long i = blockIdx.x * (long)NT + threadIdx.x;
     unsigned cq = (unsigned)((unsigned long)i % c4n);
     const unsigned cstep = (unsigned)((unsigned long)stride % c4n);
     f32x4 sc, sh, k0, k1, mu;
@@ -387,36 +406,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         for (int u = 0; u < 4; ++u) { dy[i + u * stride] = one(g[u], v[u]); next(); }
     }
     for (; i < n4; i += stride) { dy[i] = one(grad(i), y[i]); next(); }
-    if (amax != nullptr) {           // max |dy| of the tensor: the consumers' f16x2 operand scale (order-independent, deterministic)
-        __shared__ float wmax[4];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            // one atomic per block at most, and none once a larger value is already there (plain read first: 8192 blocks
-            // hammering one address with atomics measured +0.9 ms per step)
-            if (mx > 0.f && __float_as_uint(mx) > __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(amax)))
-                atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
-        }
-    }
+    // max |dy| of the tensor: the consumers' f16x2 operand scale (order-independent, deterministic)
+    if (amax != nullptr) block_absmax_to(amax, mx);
+}
+
+template <int ACT, bool FIXED, bool POOL>
+int launch_bn_bwd_apply_t(const float* dz, const float* y, const float* mean, const float* scale, const float* shift, const float* sums,
+                          float* dy, long n4, int C, float slope, float* amax, hipStream_t st, const PoolGather& pg) {
+    auto a0 = reinterpret_cast<const f32x4*>(dz); auto a1 = reinterpret_cast<const f32x4*>(y); auto a2 = reinterpret_cast<f32x4*>(dy);
+    if (amax != nullptr && amax_fat_blocks()) VIAI_LAUNCH((bn_bwd_apply_kernel<ACT, FIXED, POOL, 1024>), dim3(stream_grid(n4, 1024)), dim3(1024), 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, pg);
+    else VIAI_LAUNCH((bn_bwd_apply_kernel<ACT, FIXED, POOL, 256>), dim3(stream_grid(n4, 256)), dim3(256), 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, pg);
+    return viai_launch_status();
 }
 
 template <bool FIXED>
 int launch_bn_bwd_apply(const float* dz, const float* y, const float* mean, const float* scale, const float* shift, const float* sums,
                         float* dy, long n4, int C, int act, float slope, float* amax, hipStream_t st) {
-    long blocks = (n4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    const dim3 grid((unsigned)blocks), blk(256);
-    auto a0 = reinterpret_cast<const f32x4*>(dz); auto a1 = reinterpret_cast<const f32x4*>(y); auto a2 = reinterpret_cast<f32x4*>(dy);
+    const PoolGather pg{};
     switch (act) {
-    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_RELU, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, PoolGather{}); break;
-    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_LRELU, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, PoolGather{}); break;
-    case VIAI_ACT_SIGMOID: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_SIGMOID, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, PoolGather{}); break;
-    default: VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_NONE, FIXED>), grid, blk, 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, PoolGather{}); break;
+    case VIAI_ACT_RELU: return launch_bn_bwd_apply_t<VIAI_ACT_RELU, FIXED, false>(dz, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
+    case VIAI_ACT_LRELU: return launch_bn_bwd_apply_t<VIAI_ACT_LRELU, FIXED, false>(dz, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
+    case VIAI_ACT_SIGMOID: return launch_bn_bwd_apply_t<VIAI_ACT_SIGMOID, FIXED, false>(dz, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
+    default: return launch_bn_bwd_apply_t<VIAI_ACT_NONE, FIXED, false>(dz, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
     }
-    return viai_launch_status();
 }
 
 __global__ void act_bwd_out_kernel(const float* __restrict__ dz, const float* __restrict__ z, float* __restrict__ dx,
@@ -480,20 +492,14 @@ extern "C" int viai_bn_add_act_fwd_amax(const float* y, const float* scale, cons
                                         long M, int C, int act, float slope, float* z_amax, void* stream) {
     if (C % 4 != 0 || res == nullptr || (act != VIAI_ACT_RELU && act != VIAI_ACT_NONE)) return (int)hipErrorInvalidValue;
     const long n4 = M * C / 4;
-    long blocks = (n4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    const dim3 grid((unsigned)blocks), blk(256);
-    auto a0 = reinterpret_cast<const f32x4*>(y); auto a1 = reinterpret_cast<f32x4*>(z); auto a2 = reinterpret_cast<const f32x4*>(res);
     hipStream_t st = (hipStream_t)stream;
     const bool fixed = 256 % (C / 4) == 0;
     if (act == VIAI_ACT_RELU) {
-        if (fixed) VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_RELU, true, true>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, z_amax, a2);
-        else VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_RELU, false, true>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, z_amax, a2);
-    } else {
-        if (fixed) VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_NONE, true, true>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, z_amax, a2);
-        else VIAI_LAUNCH((bn_act_fwd_kernel<VIAI_ACT_NONE, false, true>), grid, blk, 0, st, a0, scale, shift, a1, n4, C, slope, z_amax, a2);
+        if (fixed) return launch_bn_act_fwd_t<VIAI_ACT_RELU, true, true>(y, scale, shift, res, z, n4, C, slope, z_amax, st);
+        return launch_bn_act_fwd_t<VIAI_ACT_RELU, false, true>(y, scale, shift, res, z, n4, C, slope, z_amax, st);
     }
-    return viai_launch_status();
+    if (fixed) return launch_bn_act_fwd_t<VIAI_ACT_NONE, true, true>(y, scale, shift, res, z, n4, C, slope, z_amax, st);
+    return launch_bn_act_fwd_t<VIAI_ACT_NONE, false, true>(y, scale, shift, res, z, n4, C, slope, z_amax, st);
 }
 
 extern "C" int viai_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z,
@@ -571,19 +577,13 @@ extern "C" int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char
     VIAI_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, (const float*)nullptr, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, pg);
     VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1);
     const long n4 = M * C / 4;
-    long blocks = (n4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    const dim3 grid((unsigned)blocks), blk(256);
-    auto a1 = reinterpret_cast<const f32x4*>(y); auto a2 = reinterpret_cast<f32x4*>(dy);
     const bool fixed = 256 % (C / 4) == 0;
     if (act == VIAI_ACT_RELU) {
-        if (fixed) VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_RELU, true, true>), grid, blk, 0, st, (const f32x4*)nullptr, a1, mean, scale, shift, (const float*)sums, a2, n4, C, slope, amax, pg);
-        else VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_RELU, false, true>), grid, blk, 0, st, (const f32x4*)nullptr, a1, mean, scale, shift, (const float*)sums, a2, n4, C, slope, amax, pg);
-    } else {
-        if (fixed) VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_NONE, true, true>), grid, blk, 0, st, (const f32x4*)nullptr, a1, mean, scale, shift, (const float*)sums, a2, n4, C, slope, amax, pg);
-        else VIAI_LAUNCH((bn_bwd_apply_kernel<VIAI_ACT_NONE, false, true>), grid, blk, 0, st, (const f32x4*)nullptr, a1, mean, scale, shift, (const float*)sums, a2, n4, C, slope, amax, pg);
+        if (fixed) return launch_bn_bwd_apply_t<VIAI_ACT_RELU, true, true>(nullptr, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
+        return launch_bn_bwd_apply_t<VIAI_ACT_RELU, false, true>(nullptr, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
     }
-    return viai_launch_status();
+    if (fixed) return launch_bn_bwd_apply_t<VIAI_ACT_NONE, true, true>(nullptr, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
+    return launch_bn_bwd_apply_t<VIAI_ACT_NONE, false, true>(nullptr, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
 }
 
 // the final pass alone (conv_direct.hip: the fused Cin = 1 layer produces the partials itself)

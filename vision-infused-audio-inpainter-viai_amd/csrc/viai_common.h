@@ -97,15 +97,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // max |.| of a tensor into a device float (zero-initialised by the caller, or holding an earlier maximum): wave shuffle, LDS, at most one
 // conditional atomicMax per block on the float bits (non-negative floats order like unsigned integers; max is order-independent, so the
-// result is deterministic).  256-thread blocks; every thread of the block must call it.
+// result is deterministic).  Blocks of 64 .. 1024 threads; every thread of the block must call it.
+// The atomics of one launch all hit ONE address and are executed at the memory side one after the other (~10 ns each): a launch of 2048
+// blocks that all finish together -- and therefore all read the slot while it still holds 0 -- spends 10 - 20 us in them after its last
+// store (tools/probes/bn_fresh.py: the 16.8 MB BatchNorm apply pass 10 -> 30 us).  Kernels that end in this call run as FEW, FAT blocks
+// (one 1024-thread block per CU) for that reason.
 __device__ __forceinline__ void block_absmax_to(float* amax, float mx) {
-    __shared__ float viai_wmax[4];
+    __shared__ float viai_wmax[16];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if ((threadIdx.x & 63) == 0) viai_wmax[threadIdx.x >> 6] = mx;
     __syncthreads();
     if (threadIdx.x == 0) {
-        mx = fmaxf(fmaxf(viai_wmax[0], viai_wmax[1]), fmaxf(viai_wmax[2], viai_wmax[3]));
+        const int nw = (int)(blockDim.x >> 6);
+        for (int w = 1; w < nw; ++w) mx = fmaxf(mx, viai_wmax[w]);
         // plain read first: thousands of blocks hammering one address with atomics measured +0.9 ms per step
         if (mx > 0.f && __float_as_uint(mx) > __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(amax)))
             atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
