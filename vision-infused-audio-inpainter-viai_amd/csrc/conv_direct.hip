@@ -55,10 +55,11 @@ __device__ __forceinline__ float cin1_x(const DirectArgs& a, const float* xb, in
     return a.xmask != nullptr ? v * a.xmask[(size_t)n * a.IW + ix] : v;
 }
 constexpr int CIN1_XP = 2560;             // floats of LDS for the staged rows
-__device__ __forceinline__ void cin1_stage_rows(const DirectArgs& a, float* xp, int n, int oy0) {
+// (tid = index among the 256 threads that work the chunk; live = false: a chunk past the last pixel stages nothing but joins the barrier)
+__device__ __forceinline__ void cin1_stage_rows(const DirectArgs& a, float* xp, int n, int oy0, int tid, bool live = true) {
     const int iy0 = oy0 * a.sh - a.ph;
     const float* xb = a.x + (size_t)n * a.IH * a.IW;
-    for (int idx = threadIdx.x; idx < a.xrows * a.xpitch; idx += 256) {
+    for (int idx = tid; live && idx < a.xrows * a.xpitch; idx += 256) {
         const int r = idx / a.xpitch, c = idx - r * a.xpitch;
         const int iy = iy0 + r, ix = c - a.pw;
         xp[idx] = ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) ? cin1_x(a, xb, n, iy, ix) : 0.f;
@@ -103,13 +104,19 @@ constexpr int CIN1_PB = 256;   // pixels per block == rows_per_blk of the BN par
 // MODE 0: y (+ BatchNorm partials when a.stat);  MODE 1: the partials only, y is NOT stored;  MODE 2: z = act(scale * y + shift)
 // (modes 1 + 2 = the fused conv + BatchNorm(train) + activation layer: with K = 4 .. 9 the conv is cheaper to recompute than its
 // 64-channel output is to write and read back -- D.conv1: 134 MB per pass over y)
-template <int CG, int KH, int KW, int MODE = 0>   // channel groups of 4 (Cout = 4*CG)
-__global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
+// NT = 1024 (MODE 2 only): four 256-pixel chunks per block, each worked by its own four waves exactly as a 256-thread block would -- the
+// pass ends in the abs-max atomics, and a quarter of the blocks is a quarter of the same-address atomics queued behind the last store
+// (viai_common.h block_absmax_to)
+template <int CG, int KH, int KW, int MODE = 0, int NT = 256>   // channel groups of 4 (Cout = 4*CG)
+__global__ __launch_bounds__(NT) void cin1_fwd_kernel(const DirectArgs a) {
     constexpr int PG = 256 / CG;
     constexpr int IT = CIN1_PB / PG;
     constexpr int T = KH * KW;
-    __shared__ float red[PG][CG * 4];
-    const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
+    static_assert(NT == 256 || (NT == 1024 && MODE == 2), "fat blocks: apply pass only");
+    __shared__ float red[MODE == 2 ? 1 : PG][CG * 4];
+    const int sub = NT == 256 ? 0 : (int)(threadIdx.x >> 8);
+    const int chunk = (int)blockIdx.x * (NT / 256) + sub;
+    const int tid = threadIdx.x & 255, cg = tid % CG, pg = tid / CG;
     f32x4 wv[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -120,10 +127,11 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
     if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + cg * 4);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == 2) { sc = *reinterpret_cast<const f32x4*>(a.scale + cg * 4); sh = *reinterpret_cast<const f32x4*>(a.shift + cg * 4); }
-    const int p0 = blockIdx.x * CIN1_PB;
-    __shared__ float xp[CIN1_XP];
+    const int p0 = chunk * CIN1_PB;
+    __shared__ float xp_all[NT / 256][CIN1_XP];
+    float* xp = xp_all[sub];
     const int oy_blk = (p0 / a.OW) % a.OH;
-    if (a.xfast) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk);
+    if (a.xfast) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk, tid, p0 < a.M);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     f32x4 vals[IT];
     float zmx = 0.f;
@@ -183,8 +191,7 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
     }
     if constexpr (MODE == 2) {
         if (a.zmax != nullptr) block_absmax_to(a.zmax, zmx);
-        return;
-    }
+    } else {
     if (a.stat == nullptr) return;
     // block-local (mean, M2) per channel over the valid pixels of this block
     const int cnt = min(CIN1_PB, a.M - p0);
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(256) void cin1_fwd_kernel(const DirectArgs a) {
             a.stat[(size_t)(cg * 4 + e) * a.nblk + blockIdx.x] = mean[e];
             a.stat[(size_t)(a.Cout + cg * 4 + e) * a.nblk + blockIdx.x] = t[e];
         }
+    }
     }
 }
 
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(256) void cin1_bn_bwd_kernel(const DirectArgs a) {
     const int p0 = blockIdx.x * CIN1_PB;
     __shared__ float xp[CIN1_XP];
     const int oy_blk = (p0 / a.OW) % a.OH;
-    if (a.xfast) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk);
+    if (a.xfast) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk, threadIdx.x);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     int ox, oy, n;
     {
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(256) void cin1_wgrad_kernel(const DirectArgs a, int
     const int p1 = min(p0 + pix_per_blk, a.M);
     __shared__ float xp[CIN1_XP];
     const int oy_blk = (p0 / a.OW) % a.OH;
-    if (a.xfast && p0 < a.M) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk);      // (trailing blocks past the last pixel stage nothing)
+    if (a.xfast && p0 < a.M) cin1_stage_rows(a, xp, p0 / (a.OH * a.OW), oy_blk, threadIdx.x);      // (trailing blocks past the last pixel stage nothing)
     for (int p = p0 + pg; p < p1; p += PG) {
         int ox = p % a.OW; int r_ = p / a.OW; int oy = r_ % a.OH; int n = r_ / a.OH;
         f32x4 d = *reinterpret_cast<const f32x4*>((FUSED ? a.dz : a.dy) + (size_t)p * a.Cout + cg * 4);
@@ -1213,6 +1221,10 @@ extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, con
         if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                       \
         else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                 \
         else VIAI_LAUNCH((cin1_fwd_kernel<32, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                                    \
+    } else if (z_amax != nullptr && a.nblk >= 512 && viai_amax_fat_blocks()) {                                                                            \
+        if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);      \
+        else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);\
+        else VIAI_LAUNCH((cin1_fwd_kernel<32, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);                   \
     } else {                                                                                                                       \
         if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 2>), dim3(a.nblk), dim3(256), 0, st, a);                       \
         else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 2>), dim3(a.nblk), dim3(256), 0, st, a);                 \
