@@ -394,6 +394,71 @@ __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
     }
 }
 
+// Data gradient of the fused Cin = 1 conv + BatchNorm + activation layer in ONE pass over dz, for windows of one row (KH == 1, sh == 1,
+// ph == 0: D.conv1, the frozen-D pass of the G step).  cin1_dgrad_kernel maps threads to INPUT pixels: every dz vector is fetched (and,
+// FUSED, its y recomputed) once per tap, and the unfused route writes dy (134 MB) only to read it back: 55 + 80 us.  Here a thread owns
+// an OUTPUT pixel's channel quad: dz is loaded once, y recomputed once from the LDS-staged input rows, dy formed in registers, and the
+// KW products <dy[o][:], w[:][t]> are reduced over the pixel's channel lanes into c[o][t] in LDS; an output row touches one input row
+// only, so the block then gathers dx[iy][ix] = sum over (ox, t) with ox sw + t - pw == ix of c[ox][t] for its own rows.  Fixed order.
+template <int CG, int KW>
+__global__ __launch_bounds__(256) void cin1_bn_dgrad_rows_kernel(const DirectArgs a) {
+    constexpr int PG = 256 / CG;
+    constexpr int IT = CIN1_PB / PG;
+    __shared__ float cs[CIN1_PB * KW];
+    __shared__ float xp[CIN1_XP];
+    const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
+    f32x4 wv[KW];
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+        wv[t][0] = a.w[(cg * 4 + 0) * KW + t]; wv[t][1] = a.w[(cg * 4 + 1) * KW + t];
+        wv[t][2] = a.w[(cg * 4 + 2) * KW + t]; wv[t][3] = a.w[(cg * 4 + 3) * KW + t];
+    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + cg * 4), sh = *reinterpret_cast<const f32x4*>(a.shift + cg * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + cg * 4);
+    const f32x4 k0 = *reinterpret_cast<const f32x4*>(a.sums + cg * 4), k1 = *reinterpret_cast<const f32x4*>(a.sums + a.Cout + cg * 4);
+    const int p0 = blockIdx.x * CIN1_PB;
+    const int n = p0 / (a.OH * a.OW), oy_blk = (p0 / a.OW) % a.OH;
+    cin1_stage_rows(a, xp, n, oy_blk, tid);
+    f32x4 g[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) g[it] = *reinterpret_cast<const f32x4*>(a.dz + (size_t)(p0 + it * PG + pg) * a.Cout + cg * 4);
+    int ox = pg % a.OW, row = pg / a.OW;                  // pixel p0 + pg of the block's rows
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        if (it > 0) { ox += PG; while (ox >= a.OW) { ox -= a.OW; ++row; } }
+        float xt[KW];
+        cin1_lds_taps<1, KW>(xp + row * a.xpitch + ox * a.sw, a.xpitch, xt);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KW; ++t) v += xt[t] * wv[t];
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dp = g[it][e] * dact(v[e] * sc[e] + sh[e], a.act, a.slope);
+            d[e] = sc[e] * dp + (k1[e] * (v[e] - mu[e]) + k0[e]);
+        }
+#pragma unroll
+        for (int t = 0; t < KW; ++t) {
+            float c = (d[0] * wv[t][0] + d[1] * wv[t][1]) + (d[2] * wv[t][2] + d[3] * wv[t][3]);
+#pragma unroll
+            for (int o = CG / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (cg == 0) cs[(it * PG + pg) * KW + t] = c;
+        }
+    }
+    __syncthreads();
+    float* dxb = a.dx + ((size_t)n * a.IH + oy_blk) * a.IW;        // ph == 0, sh == 1: input row == output row
+    for (int idx = tid; idx < a.rows_blk * a.IW; idx += 256) {
+        const int r = idx / a.IW, ix = idx - r * a.IW;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < KW; ++t) {
+            const int nx = ix + a.pw - t;                            // ix = ox sw + t - pw
+            if (nx >= 0 && nx % a.sw == 0 && nx / a.sw < a.OW) acc += cs[(r * a.OW + nx / a.sw) * KW + t];
+        }
+        dxb[idx] = acc;
+    }
+}
+
 // ws[z][t][co] = sum over this block's pixels of dy[p][co] * x[p_t]   (Cin == 1)
 // FUSED: dy is not read but formed from dz, the recomputed y and the BatchNorm backward coefficients (see cin1_bn_bwd_kernel)
 template <int CG, int KH, int KW, bool FUSED = false>
@@ -1308,6 +1373,18 @@ extern "C" int viai_conv2d_cin1_bn_dgrad(const viai_conv2d* c, const float* x, c
     a.x = x; a.w = w; a.dz = dz; a.mean = mean; a.scale = scale; a.shift = shift; a.sums = sums; a.dx = dx; a.act = act; a.slope = 0.2f;
     long tot = (long)a.N * a.IH * a.IW;
     int lpp = c->Cout / 4;
+    // one-row windows (D.conv1): the single-pass kernel, thread = output pixel x channel quad
+    if (c->kh == 1 && c->kw == 4 && c->sh == 1 && c->ph == 0 && !c->transposed && (lpp == 8 || lpp == 16 || lpp == 32) && a.IH == a.OH) {
+        static int rows_on = -1;
+        if (rows_on < 0) { const char* e = getenv("VIAI_CIN1_DGRAD_ROWS"); rows_on = e ? atoi(e) : 1; }
+        if (rows_on && cin1_rows_ok(a, CIN1_PB, 1, 4)) {
+            const int nblk = a.M / CIN1_PB;
+            if (lpp == 8) VIAI_LAUNCH((cin1_bn_dgrad_rows_kernel<8, 4>), dim3(nblk), dim3(256), 0, st, a);
+            else if (lpp == 16) VIAI_LAUNCH((cin1_bn_dgrad_rows_kernel<16, 4>), dim3(nblk), dim3(256), 0, st, a);
+            else VIAI_LAUNCH((cin1_bn_dgrad_rows_kernel<32, 4>), dim3(nblk), dim3(256), 0, st, a);
+            return viai_launch_status();
+        }
+    }
     long nb = (tot * lpp + 255) / 256;
     if (nb > 4096) nb = 4096;
     int blocks = (int)nb;

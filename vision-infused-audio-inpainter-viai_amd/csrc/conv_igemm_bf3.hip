@@ -988,7 +988,9 @@ int viai_pack_job_bf3(const float* w, void* wp, int n_out, int k_in, int taps, l
     if (frag != 2 && k_in % 16 != 0) return (int)hipErrorInvalidValue;
     long total = (long)((frag == 1 || frag == 3) ? (n_out + 31) / 32 * 32 : n_out) * taps * k_in;
     long blocks = (total + 1023) / 1024;                   // four elements per thread
-    if (blocks > 64) blocks = 64;
+    // (a cap of 64 blocks per image left D.conv3's two 1.2 M-element images to 16 k threads walking 72 elements each, a chain of gather
+    // latencies: the batched pack of D's arena -- on the critical path between Adam(D) and the G step's D forward -- took 36 us)
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     job->w = w; job->wp = wp; job->n_out = n_out; job->k_in = k_in; job->taps = taps; job->frag = frag;
     job->s_no = s_no; job->s_ki = s_ki; job->blk0 = 0; job->nblk = (int)blocks;

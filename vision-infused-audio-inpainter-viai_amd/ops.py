@@ -684,9 +684,12 @@ def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
         dgamma = torch.empty(Cout, device=dev, dtype=torch.float32) if need_g else None
         dbeta = torch.empty(Cout, device=dev, dtype=torch.float32) if need_be else None
         pg, pb = dgamma, dbeta
-    # the data gradient straight from dz (viai_conv2d_cin1_bn_dgrad) recomputes y per contributing output pixel: measured SLOWER than
-    # writing dy once with the recomputing apply pass (7.48 - 7.50 vs 7.38 - 7.40 ms per step), so it is opt-in
-    fused_dx = need_x and os.environ.get("VIAI_CIN1_BN_DGRAD", "0") != "0"
+    # the data gradient straight from dz (viai_conv2d_cin1_bn_dgrad).  Windows of one row (D.conv1: 1 x 4, the frozen-D pass of the G step)
+    # take the single-pass kernel -- thread = output pixel, dz read once, no dy tensor: 55 + 80 us -> one pass over dz.  Other windows map
+    # threads to INPUT pixels and recompute y per contributing output pixel: measured SLOWER than writing dy once with the recomputing
+    # apply pass (7.48 - 7.50 vs 7.38 - 7.40 ms per step), so there it stays opt-in (VIAI_CIN1_BN_DGRAD=1; =0 switches both off)
+    one_row = (cfg["k"][0] == 1 and cfg["s"][0] == 1 and cfg["p"][0] == 0 and not cfg["transposed"])
+    fused_dx = need_x and os.environ.get("VIAI_CIN1_BN_DGRAD", "1" if one_row else "0") != "0"
     dy = torch.empty_like(dz) if (need_x and not fused_dx) else None
     xmask = ctx.xmask
     _lib.check(lib.viai_conv2d_cin1_bn_bwd(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, dz.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
