@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 10
+#define VIAI_ABI_VERSION 11
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -390,6 +390,10 @@ int viai_pair_cout1_ok(const viai_conv2d* c);
 int viai_pair_cout1_bn_bwd_blocks(const viai_conv2d* c);
 int viai_pair_cout1_fwd(const viai_conv2d* c, const float* y, const float* scale, const float* shift, int act_in,
                         const float* wp, const float* bias, float* out, int act, void* stream);
+/* fwd through a per-pixel tensor of the nine tap products (ws: 9 * N * IH * IW floats): one grid-stride pass over y + a gather -- the form
+ * wide front layers take (D.conv3 -> conv4, 512 channels), where a block of whole rows leaves too few pixels in flight (ABI 11)            */
+int viai_pair_cout1_fwd_dots(const viai_conv2d* c, const float* y, const float* scale, const float* shift, int act_in,
+                             const float* wp, const float* bias, float* ws, float* out, int act, void* stream);
 int viai_pair_cout1_wgrad(const viai_conv2d* c, const float* y, const float* scale, const float* shift, int act_in,
                           const float* du, float* ws, float* dw, int accumulate, void* stream);
 int viai_pair_cout1_bn_bwd(const viai_conv2d* c, const float* du, const float* wp, const float* y, const float* mean,

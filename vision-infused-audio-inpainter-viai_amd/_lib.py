@@ -158,6 +158,7 @@ SIGNATURES = {
     "viai_pair_cout1_ok": (_I, [_CP]),
     "viai_pair_cout1_bn_bwd_blocks": (_I, [_CP]),
     "viai_pair_cout1_fwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
+    "viai_pair_cout1_fwd_dots": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
     "viai_pair_cout1_wgrad": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     "viai_pair_cout1_bn_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "viai_conv2d_cin1_bn_fwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),

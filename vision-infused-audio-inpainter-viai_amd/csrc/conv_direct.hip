@@ -851,6 +851,74 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// The same forward for WIDE front layers (D.conv3 -> conv4: 512 channels on 64 x 32 maps) as two launches with a small tensor in between:
+//   dots:   a lane group owns an input pixel: z = act_in(scale * y + shift) on load, the nine products c[q][t] = <z[q], w[t]> reduced over the
+//           group, nine floats per pixel stored.  A plain grid-stride stream over y -- no row blocks, no halo rows read twice, U pixels in
+//           flight per group -- where the LDS-plane kernel below had four lane groups per block walking twelve dependent load rounds.
+//   gather: out[p] = act(bias + sum_t c[p + d_t][t]) in tap order (zero outside the image).
+// Replaces bn_act_fwd (y -> z, 67 + 67 MB) + the row-run forward (z fetched 3 (L + 2) / L times through L1 / L2) of the two-launch route.
+template <int LPP, int CPL>
+__global__ __launch_bounds__(256) void cout1_pair_dots_kernel(const DirectArgs a, float* __restrict__ cbuf, int npix) {
+    constexpr int T = 9, PPB = 256 / LPP, U = CPL >= 2 ? 4 : 8;
+    const int tid = threadIdx.x, cl = tid % LPP, grp = tid / LPP;
+    f32x4 wv[T][CPL], sc[CPL], sh[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        sc[c] = *reinterpret_cast<const f32x4*>(a.scale + (c * LPP + cl) * 4);
+        sh[c] = *reinterpret_cast<const f32x4*>(a.shift + (c * LPP + cl) * 4);
+#pragma unroll
+        for (int t = 0; t < T; ++t) wv[t][c] = *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.Cin + (c * LPP + cl) * 4);
+    }
+    for (int q0 = (blockIdx.x * PPB + grp) * U; q0 < npix; q0 += gridDim.x * PPB * U) {
+        f32x4 v[U][CPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* src = a.x + (size_t)min(q0 + u, npix - 1) * a.Cin + cl * 4;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) v[u][c] = *reinterpret_cast<const f32x4*>(src + c * LPP * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float d[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) d[t] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                f32x4 z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = viai_act(v[u][c][e] * sc[c][e] + sh[c][e], a.act_in, a.slope);
+#pragma unroll
+                for (int t = 0; t < T; ++t) d[t] += z[0] * wv[t][c][0] + z[1] * wv[t][c][1] + z[2] * wv[t][c][2] + z[3] * wv[t][c][3];
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) d[t] = group_sum<LPP>(d[t]);
+            if (cl == 0 && q0 + u < npix) {
+                float* dst = cbuf + (size_t)(q0 + u) * T;
+#pragma unroll
+                for (int t = 0; t < T; ++t) dst[t] = d[t];
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void cout1_pair_gather_kernel(const DirectArgs a, const float* __restrict__ cbuf) {
+    constexpr int KH = 3, KW = 3;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.M) return;
+    const int ox = p % a.OW; const int r_ = p / a.OW; const int oy = r_ % a.OH, n = r_ / a.OH;
+    float s = a.bias ? a.bias[0] : 0.f;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) {
+        const int iy = oy + tap_dy(a, r);
+        if ((unsigned)iy >= (unsigned)a.IH) continue;
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+            const int ix = ox + tap_dx(a, q);
+            if ((unsigned)ix < (unsigned)a.IW) s += cbuf[((size_t)(n * a.IH + iy) * a.IW + ix) * (KH * KW) + r * KW + q];
+        }
+    }
+    a.y[p] = viai_act(s, a.act, a.slope);
+}
+
 // Forward of the Cout = 1 layer of a fused pair, every input element read ONCE: z = act_in(scale * y + shift) is formed when a lane
 // group loads its input pixel, the pixel's nine partial dot products d[t] = <z, w[t]> are reduced across the group and stored into nine
 // LDS planes at the output pixel each belongs to; after a barrier an output is bias + the sum of its nine planes in tap order
@@ -1541,6 +1609,29 @@ extern "C" int viai_pair_cout1_fwd(const viai_conv2d* c, const float* y, const f
     if (cin == 32) RUN(8, 1); else if (cin == 64) RUN(16, 1); else if (cin == 128) RUN(32, 1);
     else if (cin == 256) RUN(64, 1); else RUN(64, 2);
 #undef RUN
+    return viai_launch_status();
+}
+// the same result through the dots / gather pair (wide front layers); ws: 9 * N * IH * IW floats
+extern "C" int viai_pair_cout1_fwd_dots(const viai_conv2d* c, const float* y, const float* scale, const float* shift, int act_in,
+                                        const float* wp, const float* bias, float* ws, float* out, int act, void* stream) {
+    if (!viai_pair_cout1_ok(c) || ws == nullptr) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    DirectArgs a = make_args(c);
+    a.x = y; a.w = wp; a.bias = bias; a.y = out; a.act = act; a.slope = 0.2f; a.scale = scale; a.shift = shift; a.act_in = act_in;
+    const int cin = a.Cin;
+    const int npix = a.N * a.IH * a.IW;
+    const int lpp = cin >= 256 ? 64 : cin / 4, cpl = cin == 512 ? 2 : 1, u = cpl >= 2 ? 4 : 8;
+    long nb = ((long)npix + (256 / lpp) * u - 1) / ((256 / lpp) * u);
+    if (nb > 2048) nb = 2048;
+    const dim3 g2((unsigned)nb), b2(256);
+    viai_tag_reset();
+    viai_tag_kernel("direct");
+    if (cin == 32) VIAI_LAUNCH((cout1_pair_dots_kernel<8, 1>), g2, b2, 0, st, a, ws, npix);
+    else if (cin == 64) VIAI_LAUNCH((cout1_pair_dots_kernel<16, 1>), g2, b2, 0, st, a, ws, npix);
+    else if (cin == 128) VIAI_LAUNCH((cout1_pair_dots_kernel<32, 1>), g2, b2, 0, st, a, ws, npix);
+    else if (cin == 256) VIAI_LAUNCH((cout1_pair_dots_kernel<64, 1>), g2, b2, 0, st, a, ws, npix);
+    else VIAI_LAUNCH((cout1_pair_dots_kernel<64, 2>), g2, b2, 0, st, a, ws, npix);
+    VIAI_LAUNCH(cout1_pair_gather_kernel, dim3((a.M + 255) / 256), dim3(256), 0, st, a, (const float*)ws);
     return viai_launch_status();
 }
 // dw (+)= weight gradient of the Cout = 1 layer from du and z = act_in(scale * y + shift) formed on load; ws: viai_conv2d_wgrad_ws_bytes(c)

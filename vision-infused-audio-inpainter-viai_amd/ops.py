@@ -797,6 +797,7 @@ def _tag_amax(z, cfg):
 
 
 PAIR_FUSED = os.environ.get("VIAI_PAIR_FUSED", "1") != "0"     # (conv + BN + act) -> (Cout = 1 conv) pairs as one op (A/B switch)
+PAIR_FWD_DOTS = os.environ.get("VIAI_PAIR_FWD_DOTS", "1") != "0"       # wide pairs: tap products per pixel + gather instead of bn_act + row-run forward (A/B switch)
 PAIR_FWD_FUSED = os.environ.get("VIAI_PAIR_FWD_FUSED", "1") != "0"     # ... and their forward without the tensor in between (A/B switch)
 
 
@@ -855,6 +856,12 @@ class _ConvBnActCout1(torch.autograd.Function):
             # lane groups per block and 12 dependent load rounds each, so wide layers keep the two launches
             _lib.check(lib.viai_pair_cout1_fwd(d2["ref"], y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), cfg["act"], wp2.data_ptr(),
                                                _ptr(b2), p.data_ptr(), cfg["act2"], st), "viai_pair_cout1_fwd")
+        elif PAIR_FWD_DOTS:
+            # wide front layers (D.conv3 -> conv4): one grid-stride pass over y leaves the nine tap products of every pixel, a gather sums
+            # them: no z, y read once (was: bn_act_fwd 22 us + the row-run forward 36 us on the 67 MB tensor)
+            ws = _scratch("pairdots", 9 * M, dev)
+            _lib.check(lib.viai_pair_cout1_fwd_dots(d2["ref"], y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), cfg["act"], wp2.data_ptr(),
+                                                    _ptr(b2), ws.data_ptr(), p.data_ptr(), cfg["act2"], st), "viai_pair_cout1_fwd_dots")
         else:
             # z exists only between these two launches: the backward works from y
             z = torch.empty_like(y)
