@@ -897,3 +897,59 @@ def test_tiled_batchnorm_merge_matches_the_uniform_merge():
         outs.append((coef.clone(), rm.clone(), rv.clone()))
     for u, t in zip(*outs):
         assert torch.equal(u, t)
+
+
+@pytest.mark.parametrize("cin,transposed", [(32, 1), (128, 0), (256, 0), (512, 0), (512, 1)])
+def test_pair_forward_through_the_tap_products_equals_the_lds_plane_kernel(cin, transposed):
+    """viai_pair_cout1_fwd_dots (one grid-stride pass over y leaving nine tap products per pixel + a gather: the form D.conv3 -> conv4 takes,
+    Discriminator_Networks.py:44-50) against viai_pair_cout1_fwd (nine LDS planes per row block) on the same y, BatchNorm coefficients and
+    packed weights, through the C ABI: the same nine products summed in the same tap order, so the outputs agree to the last bits of an fp32
+    sigmoid; maps with an odd number of pixel groups per block exercise the clamped tail."""
+    from viai_amd import ops, _lib
+    lib = _lib.load()
+    N, H, W = 3, 12, 48
+    y = O.cf_uniform("pd.y.%d" % cin, (N, H, W, cin), -2, 2).cuda()
+    w = O.cf_std("pd.w.%d" % cin, (cin, 1, 3, 3) if transposed else (1, cin, 3, 3), 0.05).cuda()
+    sc = O.cf_uniform("pd.sc.%d" % cin, (cin,), 0.5, 1.5).cuda(); sh = O.cf_uniform("pd.sh.%d" % cin, (cin,), -0.3, 0.3).cuda()
+    bias = torch.tensor([0.1], device="cuda")
+    d = ops.conv_desc(N, H, W, cin, 0, 1, 3, 3, 1, 1, 1, 1, transposed)
+    assert lib.viai_pair_cout1_ok(d["ref"]) == 1
+    wp = torch.empty(d["packed"], device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.viai_conv2d_pack_fwd(d["ref"], w.data_ptr(), wp.data_ptr(), st), "pack")
+    a, b = torch.empty(N, H, W, 1, device="cuda"), torch.empty(N, H, W, 1, device="cuda")
+    ws = torch.empty(9 * N * H * W, device="cuda")
+    _lib.check(lib.viai_pair_cout1_fwd(d["ref"], y.data_ptr(), sc.data_ptr(), sh.data_ptr(), ops.ACT_LRELU, wp.data_ptr(), bias.data_ptr(),
+                                       a.data_ptr(), ops.ACT_SIGMOID, st), "fwd")
+    _lib.check(lib.viai_pair_cout1_fwd_dots(d["ref"], y.data_ptr(), sc.data_ptr(), sh.data_ptr(), ops.ACT_LRELU, wp.data_ptr(), bias.data_ptr(),
+                                            ws.data_ptr(), b.data_ptr(), ops.ACT_SIGMOID, st), "fwd_dots")
+    torch.cuda.synchronize()
+    assert (a - b).abs().max().item() < 2e-6
+    # and against torch in fp64
+    z = F.leaky_relu(y.double().cpu() * sc.double().cpu() + sh.double().cpu(), 0.2).permute(0, 3, 1, 2)
+    ref = torch.sigmoid((F.conv_transpose2d if transposed else F.conv2d)(z, w.double().cpu(), bias.double().cpu(), 1, 1))
+    assert relerr(nchw(b), ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,C", [(131072, 32), (32768, 64), (5000, 128), (4096, 96)])
+def test_operand_magnitude_of_the_fat_block_batchnorm_passes_is_the_exact_maximum(M, C):
+    """The BatchNorm apply passes that end in the abs-max atomics run as one 1024-thread block per CU (viai_common.h block_absmax_to): the
+    slot -- zeroed, as at the start of a step -- must receive exactly max |z| / max |dy| whatever the grid, including tensors smaller than
+    one block per CU, a channel count whose quads do not divide the block (C = 96) and a ragged tail."""
+    from viai_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    y = O.cf_uniform("fat.y", (M, C), -3, 3).cuda(); dz = O.cf_uniform("fat.dz", (M, C), -1, 1).cuda()
+    sc = O.cf_uniform("fat.sc", (C,), 0.5, 1.5).cuda(); sh = O.cf_uniform("fat.sh", (C,), -0.5, 0.5).cuda()
+    mean = O.cf_uniform("fat.mu", (C,), -0.2, 0.2).cuda(); inv = O.cf_uniform("fat.is", (C,), 0.5, 2.0).cuda()
+    z, dy = torch.empty_like(y), torch.empty_like(y)
+    am = torch.zeros(2, device="cuda")
+    _lib.check(lib.viai_bn_act_fwd_amax(y.data_ptr(), sc.data_ptr(), sh.data_ptr(), z.data_ptr(), M, C, 2, 0.2, am[0:1].data_ptr(), st), "fwd")
+    nblk = lib.viai_bn_bwd_blocks(M, C)
+    part = torch.empty(2 * C * nblk, device="cuda"); sums = torch.empty(2 * C, device="cuda"); dg = torch.empty(C, device="cuda"); db = torch.empty(C, device="cuda")
+    _lib.check(lib.viai_bn_act_bwd_amax(dz.data_ptr(), y.data_ptr(), mean.data_ptr(), inv.data_ptr(), sc.data_ptr(), sh.data_ptr(), part.data_ptr(),
+                                        sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dy.data_ptr(), M, C, 2, 0.2, 1, am[1:2].data_ptr(), st), "bwd")
+    torch.cuda.synchronize()
+    assert am[0].item() == z.abs().max().item() and am[1].item() == dy.abs().max().item()
+    zr = F.leaky_relu(y * sc + sh, 0.2)
+    assert relerr(z.cpu(), zr.cpu()) < 1e-6
