@@ -22,12 +22,15 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
     return t;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+// NT threads per channel: 256, or 1024 where a channel has thousands of partial blocks (the ResNet branch on 1024 frames: 25 088 tiles per
+// channel of layer1 -- one 256-thread block walked them in 98 dependent rounds, 46 us per layer and 73 such launches per step)
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_finalize_kernel(
     const float* __restrict__ part, int nblk, int rows, long M, int C,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
     float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int th, int tw, int OH, int OW) {
-    __shared__ double red[4];
+    __shared__ double red[NT / 64];
     const int c = blockIdx.x;
     const float* pm = part + (size_t)c * nblk;
     const float* p2 = part + (size_t)(C + c) * nblk;
@@ -49,23 +52,43 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     double s = 0.0, q = 0.0;
     // th > 0: block b is the th x tw output tile (n, ty, tx) of an OH x OW map, clipped at the map's edge (viai_bn_finalize_tiles)
     const int tiles_x = th > 0 ? (OW + tw - 1) / tw : 1, tiles_y = th > 0 ? (OH + th - 1) / th : 1;
-    for (int b = threadIdx.x; b < nblk; b += 256) {
-        double nb = (b == nblk - 1) ? (double)last_n : (double)rows;
+    auto count = [&](int b) -> double {
         if (th > 0) {
             const int tx = b % tiles_x, ty = (b / tiles_x) % tiles_y;
-            nb = (double)(min(th, OH - ty * th) * min(tw, OW - tx * tw));
+            return (double)(min(th, OH - ty * th) * min(tw, OW - tx * tw));
         }
-        const double d = (double)pm[b] - k;
+        return (b == nblk - 1) ? (double)last_n : (double)rows;
+    };
+    int b = threadIdx.x;
+    for (; b + 3 * NT < nblk; b += 4 * NT) {                // eight independent loads in flight per lane; the sums keep the order of the plain walk
+        float m[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { m[u] = pm[b + u * NT]; v[u] = p2[b + u * NT]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double nb = count(b + u * NT), d = (double)m[u] - k;
+            s += nb * d;
+            q += (double)v[u] + nb * d * d;
+        }
+    }
+    for (; b < nblk; b += NT) {
+        const double nb = count(b), d = (double)pm[b] - k;
         s += nb * d;
         q += (double)p2[b] + nb * d * d;
     }
     // both sums through one pair of barriers
     s = wave_sum_d_dpp(s); q = wave_sum_d_dpp(q);
-    __shared__ double red2[4];
+    __shared__ double red2[NT / 64];
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red2[threadIdx.x >> 6] = q; }
     __syncthreads();
-    s = (red[0] + red[1]) + (red[2] + red[3]);
-    q = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+    if constexpr (NT == 256) {
+        s = (red[0] + red[1]) + (red[2] + red[3]);
+        q = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+    } else {
+        s = 0.0; q = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { s += red[w]; q += red2[w]; }
+    }
     const double mean = k + s / (double)M;
     const double m2 = fmax(q - s * s / (double)M, 0.0);
     if (threadIdx.x == 0) {
@@ -451,8 +474,10 @@ extern "C" int viai_bn_finalize(const float* stat_part, int nblk, int rows_per_b
                                 int64_t* nbt, float momentum, float eps,
                                 float* mean, float* invstd, float* scale, float* shift, void* stream) {
     if (nblk <= 0 || C <= 0 || M <= 0) return (int)hipErrorInvalidValue;
-    VIAI_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, nblk, rows_per_blk, M, C,
-                       gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, 0, 0, 0, 0);
+    if (nblk > 4096) VIAI_LAUNCH(bn_finalize_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, stat_part, nblk, rows_per_blk, M, C,
+                                 gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, 0, 0, 0, 0);
+    else VIAI_LAUNCH(bn_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, nblk, rows_per_blk, M, C,
+                     gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, 0, 0, 0, 0);
     return viai_launch_status();
 }
 
@@ -462,8 +487,10 @@ extern "C" int viai_bn_finalize_tiles(const float* stat_part, int N, int OH, int
                                       float* mean, float* invstd, float* scale, float* shift, void* stream) {
     if (N <= 0 || OH <= 0 || OW <= 0 || tile_h <= 0 || tile_w <= 0 || C <= 0) return (int)hipErrorInvalidValue;
     const int nblk = N * ((OH + tile_h - 1) / tile_h) * ((OW + tile_w - 1) / tile_w);
-    VIAI_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, nblk, tile_h * tile_w, (long)N * OH * OW, C,
-                       gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, tile_h, tile_w, OH, OW);
+    if (nblk > 4096) VIAI_LAUNCH(bn_finalize_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, stat_part, nblk, tile_h * tile_w, (long)N * OH * OW, C,
+                                 gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, tile_h, tile_w, OH, OW);
+    else VIAI_LAUNCH(bn_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, nblk, tile_h * tile_w, (long)N * OH * OW, C,
+                     gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, tile_h, tile_w, OH, OW);
     return viai_launch_status();
 }
 
