@@ -316,8 +316,10 @@ def test_conv_bn_act_train_matches_torch_cpu(act, shape):
 def test_cin1_conv_bn_layer_without_the_stored_preactivation(geom, need_dx, monkeypatch):
     """E.conv1 / D.conv1 (Inpainting_Networks.py:55,71; Discriminator_Networks.py:17-19): Cin = 1 conv -> BatchNorm2d(train) ->
     LeakyReLU on the fused path (viai_conv2d_cin1_bn_*: the conv output is never stored, forward and backward recompute it from x;
-    the weight gradient forms dy on the fly; the data gradient either reads a dy tensor written by the recomputing apply pass ("apply",
-    the default) or forms dy on the fly too ("fused", VIAI_CIN1_BN_DGRAD=1: slower, opt-in).  Forward, dw, dgamma, dbeta,
+    the weight gradient forms dy on the fly; the data gradient either reads a dy tensor written by the recomputing apply pass ("apply":
+    the default for 3 x 3 windows) or forms dy on the fly too ("fused", VIAI_CIN1_BN_DGRAD=1: the default for one-row windows -- D.conv1's
+    1 x 4 -- whose block-of-whole-rows shapes take the single-pass cin1_bn_dgrad_rows_kernel, here the fourth geometry; the other
+    geometries take the input-pixel-mapped kernel, slower than "apply" and opt-in).  Forward, dw, dgamma, dbeta,
     dx and the running statistics against fp64 within 5x of torch-CPU-fp32's own rounding error; the third geometry has a ragged last
     statistics block (pixels not a multiple of 256); the last two have blocks of whole output rows, i.e. the kernels that stage the
     block's input rows in LDS (the benchmark shapes take that path)."""

@@ -168,7 +168,7 @@ inline unsigned stream_grid(long n4, int nt) {
 template <int ACT, bool FIXED, bool RES>
 int launch_bn_act_fwd_t(const float* y, const float* scale, const float* shift, const float* res, float* z, long n4, int C, float slope, float* amax, hipStream_t st) {
     auto a0 = reinterpret_cast<const f32x4*>(y); auto a1 = reinterpret_cast<f32x4*>(z); auto a2 = reinterpret_cast<const f32x4*>(res);
-    if (amax != nullptr && viai_amax_fat_blocks()) VIAI_LAUNCH((bn_act_fwd_kernel<ACT, FIXED, RES, 1024>), dim3(stream_grid(n4, 1024)), dim3(1024), 0, st, a0, scale, shift, a1, n4, C, slope, amax, a2);
+    if (amax != nullptr) VIAI_LAUNCH((bn_act_fwd_kernel<ACT, FIXED, RES, 1024>), dim3(stream_grid(n4, 1024)), dim3(1024), 0, st, a0, scale, shift, a1, n4, C, slope, amax, a2);
     else VIAI_LAUNCH((bn_act_fwd_kernel<ACT, FIXED, RES, 256>), dim3(stream_grid(n4, 256)), dim3(256), 0, st, a0, scale, shift, a1, n4, C, slope, amax, a2);
     return viai_launch_status();
 }
@@ -432,7 +432,7 @@ template <int ACT, bool FIXED, bool POOL>
 int launch_bn_bwd_apply_t(const float* dz, const float* y, const float* mean, const float* scale, const float* shift, const float* sums,
                           float* dy, long n4, int C, float slope, float* amax, hipStream_t st, const PoolGather& pg) {
     auto a0 = reinterpret_cast<const f32x4*>(dz); auto a1 = reinterpret_cast<const f32x4*>(y); auto a2 = reinterpret_cast<f32x4*>(dy);
-    if (amax != nullptr && viai_amax_fat_blocks()) VIAI_LAUNCH((bn_bwd_apply_kernel<ACT, FIXED, POOL, 1024>), dim3(stream_grid(n4, 1024)), dim3(1024), 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, pg);
+    if (amax != nullptr) VIAI_LAUNCH((bn_bwd_apply_kernel<ACT, FIXED, POOL, 1024>), dim3(stream_grid(n4, 1024)), dim3(1024), 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, pg);
     else VIAI_LAUNCH((bn_bwd_apply_kernel<ACT, FIXED, POOL, 256>), dim3(stream_grid(n4, 256)), dim3(256), 0, st, a0, a1, mean, scale, shift, sums, a2, n4, C, slope, amax, pg);
     return viai_launch_status();
 }

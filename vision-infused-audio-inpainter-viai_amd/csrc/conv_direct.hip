@@ -1354,7 +1354,7 @@ extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, con
         if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                       \
         else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                 \
         else VIAI_LAUNCH((cin1_fwd_kernel<32, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                                    \
-    } else if (z_amax != nullptr && a.nblk >= 512 && viai_amax_fat_blocks()) {                                                                            \
+    } else if (z_amax != nullptr && a.nblk >= 512) {                                                                                                          \
         if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);      \
         else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);\
         else VIAI_LAUNCH((cin1_fwd_kernel<32, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);                   \
@@ -1443,9 +1443,7 @@ extern "C" int viai_conv2d_cin1_bn_dgrad(const viai_conv2d* c, const float* x, c
     int lpp = c->Cout / 4;
     // one-row windows (D.conv1): the single-pass kernel, thread = output pixel x channel quad
     if (c->kh == 1 && c->kw == 4 && c->sh == 1 && c->ph == 0 && !c->transposed && (lpp == 8 || lpp == 16 || lpp == 32) && a.IH == a.OH) {
-        static int rows_on = -1;
-        if (rows_on < 0) { const char* e = getenv("VIAI_CIN1_DGRAD_ROWS"); rows_on = e ? atoi(e) : 1; }
-        if (rows_on && cin1_rows_ok(a, CIN1_PB, 1, 4)) {
+        if (cin1_rows_ok(a, CIN1_PB, 1, 4)) {
             const int nblk = a.M / CIN1_PB;
             if (lpp == 8) VIAI_LAUNCH((cin1_bn_dgrad_rows_kernel<8, 4>), dim3(nblk), dim3(256), 0, st, a);
             else if (lpp == 16) VIAI_LAUNCH((cin1_bn_dgrad_rows_kernel<16, 4>), dim3(nblk), dim3(256), 0, st, a);

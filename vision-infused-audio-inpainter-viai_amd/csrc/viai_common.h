@@ -117,13 +117,6 @@ __device__ __forceinline__ void block_absmax_to(float* amax, float mx) {
     }
 }
 
-// VIAI_AMAX_FAT=0: the thin-block grids also for the passes that end in block_absmax_to (same-box A/B of the fat-block launches)
-static inline bool viai_amax_fat_blocks() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VIAI_AMAX_FAT"); on = e ? atoi(e) : 1; }
-    return on != 0;
-}
-
 // XCD-aware bijective remap of a linear workgroup id: consecutive logical tiles
 // land on the same XCD (block b is observed to run on XCD b % 8), so
 // neighbouring tiles share that XCD's L2.  Speed only, never correctness.

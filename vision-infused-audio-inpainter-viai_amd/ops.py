@@ -194,6 +194,9 @@ def _input_amax(x, x2, known, st):
         return a1
     lib = _lib.load()
     slot = _amax_slot(x.device)
+    if a1 is not None and a2 is not None:
+        torch.maximum(a1, a2, out=slot)                 # both magnitudes travelled with their tensors (the virtual concat of G.convblock4): one launch
+        return slot
     for t, a in ((x, a1), (x2, a2)):
         if t is None:
             continue
@@ -797,7 +800,7 @@ def _tag_amax(z, cfg):
 
 
 PAIR_FUSED = os.environ.get("VIAI_PAIR_FUSED", "1") != "0"     # (conv + BN + act) -> (Cout = 1 conv) pairs as one op (A/B switch)
-PAIR_FWD_DOTS = os.environ.get("VIAI_PAIR_FWD_DOTS", "1") != "0"       # wide pairs: tap products per pixel + gather instead of bn_act + row-run forward (A/B switch)
+PAIR_FWD_DOTS = True        # wide pairs: tap products per pixel + gather instead of bn_act + the row-run forward (7.00 -> 6.94 ms; module switch for A/B)
 PAIR_FWD_FUSED = os.environ.get("VIAI_PAIR_FWD_FUSED", "1") != "0"     # ... and their forward without the tensor in between (A/B switch)
 
 
