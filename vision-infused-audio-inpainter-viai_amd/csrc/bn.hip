@@ -184,10 +184,8 @@ int launch_bn_act_fwd(const float* y, const float* scale, const float* shift, fl
 }
 
 __device__ __forceinline__ float act_grad(float pre, int act, float slope) {
-    if (act == VIAI_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
-    if (act == VIAI_ACT_LRELU) return pre > 0.f ? 1.f : slope;
     if (act == VIAI_ACT_SIGMOID) { float s = 1.f / (1.f + __expf(-pre)); return s * (1.f - s); }
-    return 1.f;
+    return viai_act_grad_pl(pre, act, slope);
 }
 
 // BatchNorm + activation followed by nn.MaxPool2d (ResNet stem, networks/Image_Embedding.py:20-23): the gradient of the post-activation

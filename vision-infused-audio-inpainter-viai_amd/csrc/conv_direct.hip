@@ -222,10 +222,8 @@ __global__ __launch_bounds__(NT) void cin1_fwd_kernel(const DirectArgs a) {
 }
 
 __device__ __forceinline__ float dact(float pre, int act, float slope) {
-    if (act == VIAI_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
-    if (act == VIAI_ACT_LRELU) return pre > 0.f ? 1.f : slope;
     if (act == VIAI_ACT_SIGMOID) { float s_ = 1.f / (1.f + __expf(-pre)); return s_ * (1.f - s_); }
-    return 1.f;
+    return viai_act_grad_pl(pre, act, slope);
 }
 
 // Backward of the fused Cin = 1 conv + BatchNorm(train) + activation layer with y RECOMPUTED from x (same expression, same order as
@@ -999,10 +997,8 @@ __global__ __launch_bounds__(256) void cout1_pair_fwd_kernel(const DirectArgs a,
 }
 
 __device__ __forceinline__ float pair_act_grad(float pre, int act, float slope) {
-    if (act == VIAI_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
-    if (act == VIAI_ACT_LRELU) return pre > 0.f ? 1.f : slope;
     if (act == VIAI_ACT_SIGMOID) { float s = 1.f / (1.f + __expf(-pre)); return s * (1.f - s); }
-    return 1.f;
+    return viai_act_grad_pl(pre, act, slope);
 }
 
 // BatchNorm + activation backward of the layer in FRONT of a Cout = 1 3 x 3 conv, with that conv's data gradient formed on the fly:

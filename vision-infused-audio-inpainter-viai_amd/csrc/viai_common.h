@@ -39,12 +39,16 @@ struct ConvGeom {
     int dy[VIAI_MAX_TAPS], dx[VIAI_MAX_TAPS], ws[VIAI_MAX_TAPS];
 };
 
+// none / ReLU / LeakyReLU are ONE expression, max(v, 0) + ns min(v, 0) with ns = 1 / 0 / slope (the same values bit for bit: the fma rounds
+// slope * v once, and 0 + (-0) = +0): with `act` a kernel argument the three-way branch used to sit in front of every element of the
+// streaming kernels' unrolled loops; now the compiler hoists one scalar select and keeps a single uniform branch for the sigmoid
+__device__ __forceinline__ float viai_act_ns(int act, float slope) { return act == VIAI_ACT_RELU ? 0.f : (act == VIAI_ACT_LRELU ? slope : 1.f); }
 __device__ __forceinline__ float viai_act(float v, int act, float slope) {
-    if (act == VIAI_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == VIAI_ACT_LRELU) return v > 0.f ? v : v * slope;
     if (act == VIAI_ACT_SIGMOID) return 1.f / (1.f + expf(-v));   // accurate exp: BCE divides by p(1-p)
-    return v;
+    return fmaf(viai_act_ns(act, slope), fminf(v, 0.f), fmaxf(v, 0.f));
 }
+// d act / d pre for the piecewise-linear activations (sigmoid: see the callers)
+__device__ __forceinline__ float viai_act_grad_pl(float pre, int act, float slope) { return pre > 0.f ? 1.f : viai_act_ns(act, slope); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
