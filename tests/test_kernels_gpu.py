@@ -399,11 +399,16 @@ def test_bn_large_mean_is_stable():
     assert relerr(bng.running_var, bn.running_var) < 1e-4
 
 
-@pytest.mark.parametrize("sizes", [((4, 16), (16, 32)), ((3, 8), (7, 20)), ((64, 128), (128, 128)), ((5, 7), (5, 7)), ((9, 9), (4, 5))])
-def test_bilinear_ac_matches_torch_cpu(sizes):
+@pytest.mark.parametrize("C", [32, 24])
+@pytest.mark.parametrize("sizes", [((4, 16), (16, 32)), ((3, 8), (7, 20)), ((64, 128), (128, 128)), ((5, 7), (5, 7)), ((9, 9), (4, 5)), ((4, 4), (32, 30)),
+                                   ((40, 6), (5, 6))])
+def test_bilinear_ac_matches_torch_cpu(sizes, C):
+    """F.interpolate(mode="bilinear", align_corners=True) forward and backward (New_Inpainting_Networks.py:78,83).  C = 32 takes the per-pixel
+    kernels (a channel quad per thread, exact candidate ranges, <= 6 column weights held in registers; (4, 4) -> (32, 30) has more columns per
+    input pixel than that and takes their generic inner loop), C = 24 (six quads: not a power of two) the index-decoding kernels."""
     from viai_amd import ops
     (ih, iw), (oh, ow) = sizes
-    x = O.cf_uniform("bl.x", (2, 32, ih, iw), -1, 1).requires_grad_(True)
+    x = O.cf_uniform("bl.x", (2, C, ih, iw), -1, 1).requires_grad_(True)
     y = F.interpolate(x, size=[oh, ow], mode="bilinear", align_corners=True)
     gy = O.cf_uniform("bl.gy", tuple(y.shape), -1, 1)
     y.backward(gy)
