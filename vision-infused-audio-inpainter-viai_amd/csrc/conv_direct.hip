@@ -392,6 +392,21 @@ __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
     }
 }
 
+// sum over the LPP consecutive lanes of a lane group (LPP = 8 .. 64, a power of two); every lane of the group gets the sum
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // xor 1
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // xor 2
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // mirror within 8 lanes
+    if constexpr (LPP >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});     // mirror within 16 lanes
+    if constexpr (LPP >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (LPP >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // Data gradient of the fused Cin = 1 conv + BatchNorm + activation layer in ONE pass over dz, for windows of one row (KH == 1, sh == 1,
 // ph == 0: D.conv1, the frozen-D pass of the G step).  cin1_dgrad_kernel maps threads to INPUT pixels: every dz vector is fetched (and,
 // FUSED, its y recomputed) once per tap, and the unfused route writes dy (134 MB) only to read it back: 55 + 80 us.  Here a thread owns
@@ -417,31 +432,45 @@ __global__ __launch_bounds__(256) void cin1_bn_dgrad_rows_kernel(const DirectArg
     const int p0 = blockIdx.x * CIN1_PB;
     const int n = p0 / (a.OH * a.OW), oy_blk = (p0 / a.OW) % a.OH;
     cin1_stage_rows(a, xp, n, oy_blk, tid);
-    f32x4 g[IT];
+    // dz in chunks of four items, one chunk ahead of the arithmetic.  All 2048 blocks of this launch are resident at once and start together:
+    // with the sixteen loads of a thread issued up front the whole chip first waited for memory and then computed (27 + 22 us in a row);
+    // staged, a wave's next loads fly while it (and the seven other waves of its SIMD) work on the previous chunk.
+    constexpr int CH = 4, NCH = IT / CH;
+    static_assert(IT % CH == 0, "chunks");
+    f32x4 g[2][CH];
+    auto gload = [&](int c, f32x4 (&dst)[CH]) {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) g[it] = *reinterpret_cast<const f32x4*>(a.dz + (size_t)(p0 + it * PG + pg) * a.Cout + cg * 4);
+        for (int u = 0; u < CH; ++u) dst[u] = *reinterpret_cast<const f32x4*>(a.dz + (size_t)(p0 + (c * CH + u) * PG + pg) * a.Cout + cg * 4);
+    };
+    gload(0, g[0]);
     int ox = pg % a.OW, row = pg / a.OW;                  // pixel p0 + pg of the block's rows
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        if (it > 0) { ox += PG; while (ox >= a.OW) { ox -= a.OW; ++row; } }
-        float xt[KW];
-        cin1_lds_taps<1, KW>(xp + row * a.xpitch + ox * a.sw, a.xpitch, xt);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) gload(c + 1, g[(c + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < KW; ++t) v += xt[t] * wv[t];
-        f32x4 d;
+        for (int u = 0; u < CH; ++u) {
+            const int it = c * CH + u;
+            if (it > 0) { ox += PG; while (ox >= a.OW) { ox -= a.OW; ++row; } }
+            float xt[KW];
+            cin1_lds_taps<1, KW>(xp + row * a.xpitch + ox * a.sw, a.xpitch, xt);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float dp = g[it][e] * dact(v[e] * sc[e] + sh[e], a.act, a.slope);
-            d[e] = sc[e] * dp + (k1[e] * (v[e] - mu[e]) + k0[e]);
+            for (int t = 0; t < KW; ++t) v += xt[t] * wv[t];
+            f32x4 d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dp = g[c & 1][u][e] * dact(v[e] * sc[e] + sh[e], a.act, a.slope);
+                d[e] = sc[e] * dp + (k1[e] * (v[e] - mu[e]) + k0[e]);
+            }
+#pragma unroll
+            for (int t = 0; t < KW; ++t) {
+                float cc = (d[0] * wv[t][0] + d[1] * wv[t][1]) + (d[2] * wv[t][2] + d[3] * wv[t][3]);
+                cc = group_sum<CG>(cc);                   // DPP row operations: __shfl_xor is a ds_bpermute, and sixteen of them per item made the LDS crossbar the bound
+                if (cg == 0) cs[(it * PG + pg) * KW + t] = cc;
+            }
         }
-#pragma unroll
-        for (int t = 0; t < KW; ++t) {
-            float c = (d[0] * wv[t][0] + d[1] * wv[t][1]) + (d[2] * wv[t][2] + d[3] * wv[t][3]);
-#pragma unroll
-            for (int o = CG / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-            if (cg == 0) cs[(it * PG + pg) * KW + t] = c;
-        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     float* dxb = a.dx + ((size_t)n * a.IH + oy_blk) * a.IW;        // ph == 0, sh == 1: input row == output row
@@ -832,21 +861,6 @@ __global__ __launch_bounds__(256) void cout1_wgrad_run_kernel(const DirectArgs a
         for (int k = 0; k < PG; ++k) s += smem[(size_t)k * T * a.Cin + i];
         a.ws[(size_t)blockIdx.x * T * a.Cin + i] = s;
     }
-}
-
-// sum over the LPP consecutive lanes of a lane group (LPP = 8 .. 64, a power of two); every lane of the group gets the sum
-template <int LPP>
-__device__ __forceinline__ float group_sum(float v) {
-    auto dpp = [](float x, auto ctrl) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
-    };
-    v += dpp(v, std::integral_constant<int, 0xB1>{});      // xor 1
-    v += dpp(v, std::integral_constant<int, 0x4E>{});      // xor 2
-    v += dpp(v, std::integral_constant<int, 0x141>{});     // mirror within 8 lanes
-    if constexpr (LPP >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});     // mirror within 16 lanes
-    if constexpr (LPP >= 32) v += __shfl_xor(v, 16, 64);
-    if constexpr (LPP >= 64) v += __shfl_xor(v, 32, 64);
-    return v;
 }
 
 // The same forward for WIDE front layers (D.conv3 -> conv4: 512 channels on 64 x 32 maps) as two launches with a small tensor in between:
