@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void cin1_dgrad_kernel(const DirectArgs a) {
 // sum over the LPP consecutive lanes of a lane group (LPP = 8 .. 64, a power of two); every lane of the group gets the sum
 template <int LPP>
 __device__ __forceinline__ float group_sum(float v) {
+    if constexpr (LPP == 64) return wave_sum_dpp(v);      // whole wave: row sums by DPP + four readlanes, no ds_bpermute
     auto dpp = [](float x, auto ctrl) {
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
     };
