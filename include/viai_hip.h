@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 11
+#define VIAI_ABI_VERSION 12
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -187,6 +187,12 @@ int viai_act_bwd_from_output(const float* dz, const float* z, float* dx, long n,
  * F.interpolate(mode='bilinear', align_corners=True)  New_Inpainting_Networks.py:78,83 */
 int viai_bilinear_ac_fwd(const float* x, float* y, int N, int IH, int IW, int OH, int OW, int C, void* stream);
 int viai_bilinear_ac_bwd(const float* dy, float* dx, int N, int IH, int IW, int OH, int OW, int C, void* stream);
+/* BatchNorm apply + activation + the resize in one pass: out = interpolate(act(scale * y + shift), size=(OH, OW), mode="bilinear",
+ * align_corners=True) -- the last layer of each decoder block and the F.interpolate behind it (New_Inpainting_Networks.py:76-83); the
+ * post-activation map is not stored.  act: none / ReLU / LeakyReLU; C / 4 a power of two <= 256; N * OH * OW < 2^24.  *z_amax (optional,
+ * zero-initialised): max |act(..)| over the taps read, the whole map's when the resize does not shrink it (ABI 12)                      */
+int viai_bn_act_bilinear_fwd_amax(const float* y, const float* scale, const float* shift, float* out, int N, int IH, int IW,
+                                  int OH, int OW, int C, int act, float slope, float* z_amax, void* stream);
 /* nn.AvgPool2d((3,1)) on the bottleneck  Inpainting_Networks.py:65,77 (floor mode) */
 int viai_avgpool_h_fwd(const float* x, float* y, int N, int IH, int W, int C, int k, void* stream);
 int viai_avgpool_h_bwd(const float* dy, float* dx, int N, int IH, int W, int C, int k, void* stream);

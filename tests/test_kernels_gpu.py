@@ -960,3 +960,49 @@ def test_operand_magnitude_of_the_fat_block_batchnorm_passes_is_the_exact_maximu
     assert am[0].item() == z.abs().max().item() and am[1].item() == dy.abs().max().item()
     zr = F.leaky_relu(y * sc + sh, 0.2)
     assert relerr(z.cpu(), zr.cpu()) < 1e-6
+
+
+def test_resize_inside_the_batchnorm_apply_pass_is_bitwise_the_two_passes():
+    """MelDecoder (New_Inpainting_Networks.py:70-89): every F.interpolate follows the last layer of a block; ops.conv_bn_act(..., upsample=)
+    applies BatchNorm + ReLU to the four taps while the resize loads them (viai_bn_act_bilinear_fwd_amax) and never stores the map in
+    between.  Output, operand magnitudes and every gradient must equal the two-pass route bit for bit (same expressions, same kernels in
+    the backward); a 24-channel layer (six quads: the per-pixel kernels do not take it) must fall back to the separate resize."""
+    from viai_amd import networks as N_, ops
+    torch.manual_seed(3)
+    dec = N_.MelDecoder().cuda().train()
+    B, F_, T = 2, 64, 32
+    shapes = [(B, F_ // 2, T // 2, 32), (B, F_ // 4, T // 2, 64), (B, F_ // 8, T // 4, 128), (B, F_ // 16, T // 8, 256), (B, 2, T // 16, 256)]
+    net0 = [O.cf_uniform("up.n%d" % i, sh_, -1, 1).cuda() for i, sh_ in enumerate(shapes)]
+    gout = O.cf_uniform("up.g", (B, F_, T, 1), -1, 1).cuda()
+
+    def run(on):
+        old, ops.FUSE_BN_UP = ops.FUSE_BN_UP, on
+        calls = []
+        lib = ops._lib.load()
+        orig = lib.viai_bn_act_bilinear_fwd_amax
+        lib.viai_bn_act_bilinear_fwd_amax = lambda *a: (calls.append(1), orig(*a))[1]
+        try:
+            state = {k: v.clone() for k, v in dec.state_dict().items()}
+            for p_ in dec.parameters():
+                p_.grad = None
+            net = [t.clone().requires_grad_(True) for t in net0]
+            out = dec.forward_nhwc(net, (F_, T))
+            out.backward(gout)
+            res = [out.detach().clone()] + [t.grad.clone() for t in net if t.grad is not None] + [p_.grad.clone() for p_ in dec.parameters() if p_.grad is not None]
+            dec.load_state_dict(state)
+            return res, len(calls)
+        finally:
+            ops.FUSE_BN_UP = old
+            lib.viai_bn_act_bilinear_fwd_amax = orig
+    fused, nf = run(True)
+    plain, npl = run(False)
+    assert nf == 5 and npl == 0                    # head + four blocks resized inside their BatchNorm apply pass
+    assert len(fused) == len(plain)
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        assert torch.equal(a, b), i
+    # a channel count the fused pass does not take
+    conv = torch.nn.ConvTranspose2d(16, 24, 3, 1, 1, bias=False).cuda(); bn = torch.nn.BatchNorm2d(24).cuda()
+    x = O.cf_uniform("up.x24", (2, 8, 8, 16), -1, 1).cuda()
+    assert not ops.upsample_fusable(x, conv.weight, None, bn, True, ops.ACT_RELU)
+    y = N_.fused_layer(x, conv, bn, ops.ACT_RELU, upsample=(16, 12))
+    assert tuple(y.shape) == (2, 16, 12, 24)

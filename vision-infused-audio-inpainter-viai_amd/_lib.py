@@ -99,6 +99,7 @@ SIGNATURES = {
     "viai_act_bwd_from_output": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "viai_bilinear_ac_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "viai_bilinear_ac_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "viai_bn_act_bilinear_fwd_amax": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "viai_avgpool_h_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "viai_avgpool_h_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "viai_nchw_to_nhwc4": (_I, [_P, _P, _L, _I, _L, _P]),

@@ -19,6 +19,19 @@ __device__ __forceinline__ void ac_src(float scale, int dst, int in, int& i0, in
     l0 = 1.f - l1;
 }
 
+// the interpolation with its roundings spelled out (three fused multiply-adds over three products), so that every kernel that resizes
+// -- alone or inside the BatchNorm apply pass -- produces the same bits whatever the compiler would contract
+__device__ __forceinline__ f32x4 ac_lerp(const f32x4& v00, const f32x4& v01, const f32x4& v10, const f32x4& v11, float lx0, float lx1, float ly0, float ly1) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t0 = __builtin_fmaf(lx1, v01[e], lx0 * v00[e]);
+        const float t1 = __builtin_fmaf(lx1, v11[e], lx0 * v10[e]);
+        o[e] = __builtin_fmaf(ly1, t1, ly0 * t0);
+    }
+    return o;
+}
+
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                            int N, int IH, int IW, int OH, int OW, int C) {
     const int c4n = C / 4;
@@ -36,7 +49,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
         f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * IW + x1) * C);
         f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * IW + x0) * C);
         f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * IW + x1) * C);
-        f32x4 o = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        f32x4 o = ac_lerp(v00, v01, v10, v11, lx0, lx1, ly0, ly1);
         *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = o;
     }
 }
@@ -116,9 +129,50 @@ __global__ __launch_bounds__(256) void bilinear_fwd_px_kernel(const float* __res
         f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * IW + x1) * C);
         f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * IW + x0) * C);
         f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * IW + x1) * C);
-        f32x4 o = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        f32x4 o = ac_lerp(v00, v01, v10, v11, lx0, lx1, ly0, ly1);
         *reinterpret_cast<f32x4*>(y + ((size_t)p * c4n + c4) * 4) = o;
     }
+}
+
+// BatchNorm apply + activation + bilinear resize in ONE pass: out = interpolate(act(scale * y + shift)) without the tensor in between --
+// the last layer of every decoder block is followed by F.interpolate (New_Inpainting_Networks.py:76-83), and the post-activation map z
+// was written by the apply pass only to be read back by the resize.  The four taps are normalised on load (an output pixel's taps are
+// shared with its neighbours through L1); max |z| over the taps is max |z| of the whole map when the resize does not shrink it (every
+// input pixel is then some output pixel's tap), which is all the consumers' operand scale needs, and the resize never exceeds it.
+// One 1024-thread block per CU: the pass ends in the abs-max atomics (viai_common.h block_absmax_to).
+template <int ACT>
+__global__ __launch_bounds__(1024) void bn_act_bilinear_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   float* __restrict__ out, int N, int IH, int IW, int OH, int OW, int C, int c4sh,
+                                                                   float slope, float* __restrict__ amax) {
+    const int c4n = 1 << c4sh, c4 = threadIdx.x & (c4n - 1), pl = threadIdx.x >> c4sh, ppb = 1024 >> c4sh;
+    const int npix = N * OH * OW;
+    const float sh_ = ac_scale(IH, OH), sw_ = ac_scale(IW, OW);
+    const float inv_ow = 1.0f / (float)OW, inv_oh = 1.0f / (float)OH;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4), sf = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+    float mx = 0.f;
+    auto z = [&](const f32x4& v) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = viai_act(v[e] * sc[e] + sf[e], ACT, slope); mx = fmaxf(mx, fabsf(o[e])); }
+        return o;
+    };
+    for (int p = blockIdx.x * ppb + pl; p < npix; p += gridDim.x * ppb) {
+        int r_, ox, n, oy;
+        rs_divmod(p, OW, inv_ow, r_, ox);
+        rs_divmod(r_, OH, inv_oh, n, oy);
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        ac_src(sh_, oy, IH, y0, y1, ly0, ly1);
+        ac_src(sw_, ox, IW, x0, x1, lx0, lx1);
+        const float* b = y + (size_t)n * IH * IW * C + c4 * 4;
+        const f32x4 r00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * IW + x0) * C);
+        const f32x4 r01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * IW + x1) * C);
+        const f32x4 r10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * IW + x0) * C);
+        const f32x4 r11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * IW + x1) * C);
+        const f32x4 v00 = z(r00), v01 = z(r01), v10 = z(r10), v11 = z(r11);
+        const f32x4 o = ac_lerp(v00, v01, v10, v11, lx0, lx1, ly0, ly1);       // the expression of bilinear_fwd_kernel
+        *reinterpret_cast<f32x4*>(out + ((size_t)p * c4n + c4) * 4) = o;
+    }
+    if (amax != nullptr) block_absmax_to(amax, mx);
 }
 
 // weight with which output index o reads input index i along one axis (0 and false when it does not)
@@ -403,6 +457,27 @@ extern "C" int viai_bilinear_ac_fwd(const float* x, float* y, int N, int IH, int
     const int c4sh = px_shift(C, (long)N * OH * OW);
     if (c4sh >= 0) VIAI_LAUNCH(bilinear_fwd_px_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, IH, IW, OH, OW, C, c4sh);
     else VIAI_LAUNCH(bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, IH, IW, OH, OW, C);
+    return viai_launch_status();
+}
+
+// out (N, OH, OW, C) = bilinear(act(scale * y + shift)), y (N, IH, IW, C); *z_amax (optional, zero-initialised) receives max |act(..)| over
+// the taps read (= over the whole map when OH >= IH and OW >= IW).  C / 4 a power of two <= 256, N * OH * OW < 2^24 (else invalid value)
+extern "C" int viai_bn_act_bilinear_fwd_amax(const float* y, const float* scale, const float* shift, float* out, int N, int IH, int IW,
+                                             int OH, int OW, int C, int act, float slope, float* z_amax, void* stream) {
+    if (C % 4 != 0 || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return (int)hipErrorInvalidValue;
+    const int c4sh = px_shift(C, (long)N * OH * OW);
+    if (c4sh < 0) return (int)hipErrorInvalidValue;
+    const long ppb = 1024 >> c4sh;
+    long blocks = ((long)N * OH * OW + ppb - 1) / ppb;
+    if (blocks > 256) blocks = 256;
+    const dim3 g((unsigned)blocks), b(1024);
+    hipStream_t st = (hipStream_t)stream;
+    switch (act) {
+    case VIAI_ACT_RELU: VIAI_LAUNCH(bn_act_bilinear_fwd_kernel<VIAI_ACT_RELU>, g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax); break;
+    case VIAI_ACT_LRELU: VIAI_LAUNCH(bn_act_bilinear_fwd_kernel<VIAI_ACT_LRELU>, g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax); break;
+    case VIAI_ACT_NONE: VIAI_LAUNCH(bn_act_bilinear_fwd_kernel<VIAI_ACT_NONE>, g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax); break;
+    default: return (int)hipErrorInvalidValue;
+    }
     return viai_launch_status();
 }
 

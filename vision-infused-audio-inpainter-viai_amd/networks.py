@@ -98,12 +98,19 @@ FLOW_STREAM = os.environ.get("VIAI_FLOW_STREAM", "1") != "0"           # ImageEm
 FUSE_BN_TAIL = os.environ.get("VIAI_FUSE_BN_TAIL", "1") != "0"      # BatchNorm apply + (residual add + ReLU | ReLU + max-pool) in one pass (A/B switch)
 
 
-def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=None, pool=None):
+def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=None, pool=None, upsample=None):
     """conv (nn.Conv2d | nn.ConvTranspose2d holder) -> bn (nn.BatchNorm2d | nn.InstanceNorm2d holder | None) -> act, on NHWC.
-    `xmask`: the layer convolves x * xmask (ops.conv_bn_act)."""
+    `xmask`: the layer convolves x * xmask (ops.conv_bn_act).  `upsample` = (H, W): F.interpolate(.., align_corners=True) behind the
+    layer -- inside the BatchNorm apply pass where ops.upsample_fusable allows, as a pass of its own otherwise."""
     transposed = isinstance(conv, nn.ConvTranspose2d)
     if transposed and _pair(conv.stride) != (1, 1):
         raise NotImplementedError("ConvTranspose2d stride != 1")
+    if upsample is not None:
+        up = (int(upsample[0]), int(upsample[1]))
+        if residual is None and pool is None and xmask is None and ops.upsample_fusable(x, conv.weight, conv.bias, bn, transposed, act):
+            return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
+                                   padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2, training=bn.training, upsample=up)
+        return ops.bilinear_ac(fused_layer(x, conv, bn, act, x2=x2, training=training, xmask=xmask, residual=residual, pool=pool), up)
     if isinstance(bn, nn.InstanceNorm2d):
         if xmask is not None:
             x = ops.mask_mul(x, xmask)
@@ -167,11 +174,12 @@ class TransConvBlock(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    def forward_nhwc(self, x, x2=None):
+    def forward_nhwc(self, x, x2=None, upsample=None):
+        """`upsample` = (H, W): the F.interpolate the decoder applies to the block's output (New_Inpainting_Networks.py:78,83)"""
         for i in range(self.nums):
             conv = self._modules["conv%s_%d" % (self.name, i)]
             bn = self._modules["conv%s_%d_bn" % (self.name, i)]
-            x = fused_layer(x, conv, bn, ACT_RELU, x2=x2 if i == 0 else None)
+            x = fused_layer(x, conv, bn, ACT_RELU, x2=x2 if i == 0 else None, upsample=upsample if i == self.nums - 1 else None)
         return x
 
     def forward(self, x):
@@ -248,18 +256,18 @@ class MelDecoder(nn.Module):
         self.upsample_mode = "bilinear"
         self.skip_at = 3            # i == 3: concat with net[-4]
 
-    def _head(self, net):
+    def _head(self, net, upsample=None):
         out = fused_layer(net[-1], self.deconv1_1, self.deconv1_1_bn, ACT_RELU)
-        return fused_layer(out, self.deconv1_2, self.deconv1_2_bn, ACT_RELU)
+        return fused_layer(out, self.deconv1_2, self.deconv1_2_bn, ACT_RELU, upsample=upsample)
 
     def forward_nhwc(self, net, out_hw, head=None):
-        out = self._head(net) if head is None else head
+        # every F.interpolate of the reference's loop (New_Inpainting_Networks.py:76-83) follows the last layer of the block in front of it:
+        # it is handed to that layer (resize inside its BatchNorm apply pass) instead of being a pass of its own
+        sizes = [(net[-1 - i].shape[1], net[-1 - i].shape[2]) for i in range(1, len(net))] + [(int(out_hw[0]), int(out_hw[1]))]
+        out = self._head(net, upsample=sizes[0]) if head is None else ops.bilinear_ac(head, sizes[0])
         for i in range(1, len(net)):
-            tgt = net[-1 - i]
-            out = ops.bilinear_ac(out, (tgt.shape[1], tgt.shape[2]))
             skip = net[-(i + 1)] if i == self.skip_at else None     # virtual concat: two source pointers
-            out = self._modules["convblock%d" % (i + 1)].forward_nhwc(out, skip)
-        out = ops.bilinear_ac(out, out_hw)
+            out = self._modules["convblock%d" % (i + 1)].forward_nhwc(out, skip, upsample=sizes[i])
         return fused_pair(out, self.conv6_1, self.conv6_1_bn, ACT_RELU, self.conv6_2, ACT_SIGMOID)
 
     def forward(self, net, x_size):

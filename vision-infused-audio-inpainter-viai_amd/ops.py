@@ -570,12 +570,20 @@ class _ConvBnAct(torch.autograd.Function):
                 _lib.check(lib.viai_bn_add_act_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), res.data_ptr(), z.data_ptr(),
                                                         M, Cout, act, 0.2, za.data_ptr(), st), "viai_bn_add_act_fwd")
                 ctx.save_for_backward(x, x2, weight, y, coef, z)
+            elif cfg.get("up") is not None:
+                # BatchNorm + activation + the F.interpolate behind the layer in one pass over y: the post-activation map is not stored
+                # (the backward gathers its gradient with the resize's backward and goes on from y)
+                UH, UW = cfg["up"]
+                z = torch.empty((N, UH, UW, Cout), device=dev, dtype=torch.float32)
+                _lib.check(lib.viai_bn_act_bilinear_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(), N, OH, OW, UH, UW,
+                                                             Cout, act, 0.2, za.data_ptr(), st), "viai_bn_act_bilinear_fwd")
+                ctx.save_for_backward(x, x2, weight, y, coef)
             else:
                 z = torch.empty_like(y)
                 _lib.check(lib.viai_bn_act_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(),
                                                     M, Cout, act, 0.2, za.data_ptr(), st), "viai_bn_act_fwd")
                 ctx.save_for_backward(x, x2, weight, y, coef)
-            ctx.tail = "pool" if pool is not None else ("res" if res is not None else None)
+            ctx.tail = "pool" if pool is not None else ("res" if res is not None else ("up" if cfg.get("up") is not None else None))
         else:
             z = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
             _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
@@ -584,8 +592,8 @@ class _ConvBnAct(torch.autograd.Function):
                 za = _const_amax(dev, 1.0)
             ctx.save_for_backward(x, x2, weight, z, None)
         if not has_bn or fused1:
-            if res is not None or cfg.get("pool") is not None:
-                raise RuntimeError("conv_bn_act: residual / pool need a BatchNorm layer on the MFMA path")
+            if res is not None or cfg.get("pool") is not None or cfg.get("up") is not None:
+                raise RuntimeError("conv_bn_act: residual / pool / upsample need a BatchNorm layer on the MFMA path")
             ctx.tail = None
         cfg["za"] = za                       # conv_bn_act attaches it to the returned tensor
         ctx.d = d
@@ -613,6 +621,11 @@ class _ConvBnAct(torch.autograd.Function):
         if ctx.fused1:
             return _ConvBnAct._backward_cin1(ctx, lib, dz, x, weight, coef, st)
         dres = None
+        if ctx.tail == "up":
+            UH, UW = cfg["up"]
+            dlo = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
+            _lib.check(lib.viai_bilinear_ac_bwd(dz.data_ptr(), dlo.data_ptr(), N, OH, OW, UH, UW, Cout, st), "viai_bilinear_ac_bwd")
+            dz = dlo
         if ctx.tail == "res":
             # d/d(sum) through the activation (mask from the saved output); the same tensor is the residual branch's gradient
             if act != ACT_NONE:
@@ -753,16 +766,20 @@ def _cin1_fused_applies(x, weight, bias, bn, kernel, stride, padding, transposed
 
 
 def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding=(0, 0), transposed=False,
-                act=ACT_NONE, x2=None, training=True, dilation=(1, 1), padding2=(-1, -1), xmask=None, residual=None, pool=None):
+                act=ACT_NONE, x2=None, training=True, dilation=(1, 1), padding2=(-1, -1), xmask=None, residual=None, pool=None, upsample=None):
     """Fused layer on NHWC tensors.  `bn` is an nn.BatchNorm2d (parameter/buffer holder) or None.
     `padding2` = (bottom, right) padding when it differs from `padding` (-1 = symmetric).
     `xmask` (N, W) or (N,1,1,W): the layer convolves x * xmask (the inpainting step's time mask).  The fused Cin = 1 layer multiplies
     while it loads x; every other kernel gets a masked copy first.
     `residual` (BatchNorm layers): act(BN(conv(x)) + residual) in the BatchNorm-apply pass -- the join of networks/ResNet.py:49-53.
     `pool` = (k, s, p) (BatchNorm layers, act ReLU / none): max_pool2d(act(BN(conv(x))), k, s, p) without storing the un-pooled map --
-    the stem of networks/Image_Embedding.py:20-23."""
+    the stem of networks/Image_Embedding.py:20-23.
+    `upsample` = (H, W) (BatchNorm layers where upsample_fusable() says so): F.interpolate(act(BN(conv(x))), (H, W), mode="bilinear",
+    align_corners=True) without storing the map in between -- the decoder blocks of New_Inpainting_Networks.py:76-83."""
     if (residual is not None or pool is not None) and (bn is None or (residual is not None and pool is not None) or act not in (ACT_RELU, ACT_NONE)):
         raise ValueError("conv_bn_act: residual / pool take a BatchNorm layer, ReLU or no activation, and exclude each other")
+    if upsample is not None and (residual is not None or pool is not None or not upsample_fusable(x, weight, bias, bn, transposed, act)):
+        raise ValueError("conv_bn_act: upsample takes a BatchNorm layer on the MFMA path (see upsample_fusable) and excludes residual / pool")
     if xmask is not None:
         xmask = _c(xmask.reshape(xmask.shape[0], xmask.shape[-1]))
         trainmode = training if (bn is None or (bn.track_running_stats and bn.running_mean is not None)) else True
@@ -773,7 +790,8 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
     cfg = {"k": tuple(kernel), "s": tuple(stride), "p": tuple(padding), "transposed": bool(transposed),
            "act": int(act), "training": bool(training), "momentum": 0.1, "eps": BN_EPS,
            "d": tuple(dilation), "p2": tuple(padding2), "xa_in": (amax_of(x), amax_of(x2)), "xmask": xmask,
-           "pool": tuple(int(v) for v in pool) if pool is not None else None}
+           "pool": tuple(int(v) for v in pool) if pool is not None else None,
+           "up": (int(upsample[0]), int(upsample[1])) if upsample is not None else None}
     if bn is not None:
         cfg["momentum"] = 0.1 if bn.momentum is None else float(bn.momentum)
         cfg["eps"] = float(bn.eps)
@@ -790,6 +808,21 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
         cfg["gt"] = tuple(p.grad if (p is not None and p.is_leaf and p.requires_grad and p.grad is not None) else None
                           for p in (weight, bias, None, None))
     return _tag_amax(_ConvBnAct.apply(x, x2, weight, bias, None, None, None, None, None, None, cfg), cfg)
+
+
+FUSE_BN_UP = os.environ.get("VIAI_FUSE_BN_UP", "1") != "0"      # BatchNorm apply + the resize behind a decoder block in one pass (A/B switch)
+
+
+def upsample_fusable(x, weight, bias, bn, transposed, act):
+    """can conv_bn_act(..., upsample=...) take this layer?  A BatchNorm2d layer that is not the fused Cin = 1 layer, a piecewise-linear
+    activation, a channel count the per-pixel resize kernels take (C / 4 a power of two <= 256)."""
+    if not FUSE_BN_UP or bn is None or not isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) or act not in (ACT_NONE, ACT_RELU, ACT_LRELU):
+        return False
+    if x.shape[3] == 1:
+        return False
+    cout = weight.shape[1] if transposed else weight.shape[0]
+    c4 = cout // 4
+    return cout % 4 == 0 and 1 <= c4 <= 256 and (c4 & (c4 - 1)) == 0
 
 
 def _tag_amax(z, cfg):
