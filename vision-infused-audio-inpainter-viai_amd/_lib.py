@@ -20,14 +20,22 @@ class ViaiLibraryError(RuntimeError):
     pass
 
 
-def _declared_abi_version():
-    """VIAI_ABI_VERSION of the committed header: the one place the number lives"""
+# ABI version THIS file's SIGNATURES / struct mirrors were written against: bumped together with them.  load() compares it with the
+# library, and with the committed header where that is present (a source checkout), so a stale _lib.py cannot call a rebuilt .so.
+ABI_VERSION = 12
+
+
+def _header_abi_version():
+    """VIAI_ABI_VERSION of include/viai_hip.h, or None when the package was installed without the header"""
     import re
-    with open(os.path.join(os.path.dirname(_HERE), "include", "viai_hip.h")) as f:
-        return int(re.search(r"#define\s+VIAI_ABI_VERSION\s+(\d+)", f.read()).group(1))
-
-
-ABI_VERSION = _declared_abi_version()
+    try:
+        with open(os.path.join(os.path.dirname(_HERE), "include", "viai_hip.h")) as f:
+            m = re.search(r"#define\s+VIAI_ABI_VERSION\s+(\d+)", f.read())
+    except OSError:
+        return None
+    if m is None:
+        raise ViaiLibraryError("include/viai_hip.h does not define VIAI_ABI_VERSION")
+    return int(m.group(1))
 
 
 class Conv2dDesc(C.Structure):
@@ -205,9 +213,10 @@ def load() -> C.CDLL:
             raise ViaiLibraryError("libviai_hip.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.viai_abi_version() != ABI_VERSION:
-        raise ViaiLibraryError("libviai_hip.so ABI version %d, include/viai_hip.h declares %d: rebuild (viai_amd._lib.build())"
-                               % (lib.viai_abi_version(), ABI_VERSION))
+    hdr = _header_abi_version()
+    if lib.viai_abi_version() != ABI_VERSION or (hdr is not None and hdr != ABI_VERSION):
+        raise ViaiLibraryError("ABI mismatch: libviai_hip.so is version %d, viai_amd/_lib.py binds version %d, include/viai_hip.h declares %s: "
+                               "rebuild (viai_amd._lib.build()) / update the bindings" % (lib.viai_abi_version(), ABI_VERSION, hdr))
     _lib = lib
     return lib
 

@@ -45,7 +45,10 @@ struct ConvGeom {
 __device__ __forceinline__ float viai_act_ns(int act, float slope) { return act == VIAI_ACT_RELU ? 0.f : (act == VIAI_ACT_LRELU ? slope : 1.f); }
 __device__ __forceinline__ float viai_act(float v, int act, float slope) {
     if (act == VIAI_ACT_SIGMOID) return 1.f / (1.f + expf(-v));   // accurate exp: BCE divides by p(1-p)
-    return fmaf(viai_act_ns(act, slope), fminf(v, 0.f), fmaxf(v, 0.f));
+    // fminf / fmaxf return the non-NaN operand, so the sum alone would turn a NaN into 0 and a diverged network would report finite
+    // losses; torch (and the reference) propagate it: one compare + select per element, the finite values are unchanged bit for bit
+    const float r = fmaf(viai_act_ns(act, slope), fminf(v, 0.f), fmaxf(v, 0.f));
+    return v != v ? v : r;
 }
 // d act / d pre for the piecewise-linear activations (sigmoid: see the callers)
 __device__ __forceinline__ float viai_act_grad_pl(float pre, int act, float slope) { return pre > 0.f ? 1.f : viai_act_ns(act, slope); }

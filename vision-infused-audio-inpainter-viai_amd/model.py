@@ -211,7 +211,8 @@ class AudioModel:
         # own weight gradients; funnelling all of them through one trailing stream costs more than it overlaps (120.8 vs 124.1 ms).
         one_stream = self.use_graph and not self.use_plan
         from . import networks as _nets
-        two_chains = self.use_video and _nets.FLOW_STREAM
+        # (eager mode only: inside a capture ImageEmbedding2 does not fork its flow stream, so plan / graph mode keeps the trailing stream)
+        two_chains = self.use_video and _nets.FLOW_STREAM and not self.use_graph
         side = os.environ.get("VIAI_WGRAD_STREAM", "0" if (one_stream or two_chains) else "1") != "0"
         self._wgrad_stream = torch.cuda.Stream(device=self.device) if side else None
         dreal = os.environ.get("VIAI_DREAL_STREAM", "0" if one_stream else "1") != "0"
@@ -420,7 +421,7 @@ class AudioModel:
         to a dropped model -- possibly in the middle of ANOTHER model's stream capture, where a device synchronisation would invalidate
         that capture: plans are then parked and destroyed at the next close() outside a capture.  The process-wide scratch pool is
         not touched from here (buffers a capture of THIS model allocated live in self._graph_scratch and go with the object)."""
-        plans, self._plans = (self._plans or []), None
+        plans, self._plans = (getattr(self, "_plans", None) or []), None      # __del__ of a half-built object: __init__ may have raised early
         self._graphs = None
         self._graph_scratch = None
         if not plans and not _PARKED_PLANS:

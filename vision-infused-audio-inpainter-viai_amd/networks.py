@@ -107,7 +107,7 @@ def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=N
         raise NotImplementedError("ConvTranspose2d stride != 1")
     if upsample is not None:
         up = (int(upsample[0]), int(upsample[1]))
-        if residual is None and pool is None and xmask is None and ops.upsample_fusable(x, conv.weight, conv.bias, bn, transposed, act):
+        if residual is None and pool is None and xmask is None and ops.upsample_fusable(x, conv.weight, conv.bias, bn, transposed, act, up):
             return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
                                    padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2, training=bn.training, upsample=up)
         return ops.bilinear_ac(fused_layer(x, conv, bn, act, x2=x2, training=training, xmask=xmask, residual=residual, pool=pool), up)

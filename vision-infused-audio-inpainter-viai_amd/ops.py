@@ -778,7 +778,7 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
     align_corners=True) without storing the map in between -- the decoder blocks of New_Inpainting_Networks.py:76-83."""
     if (residual is not None or pool is not None) and (bn is None or (residual is not None and pool is not None) or act not in (ACT_RELU, ACT_NONE)):
         raise ValueError("conv_bn_act: residual / pool take a BatchNorm layer, ReLU or no activation, and exclude each other")
-    if upsample is not None and (residual is not None or pool is not None or not upsample_fusable(x, weight, bias, bn, transposed, act)):
+    if upsample is not None and (residual is not None or pool is not None or not upsample_fusable(x, weight, bias, bn, transposed, act, upsample)):
         raise ValueError("conv_bn_act: upsample takes a BatchNorm layer on the MFMA path (see upsample_fusable) and excludes residual / pool")
     if xmask is not None:
         xmask = _c(xmask.reshape(xmask.shape[0], xmask.shape[-1]))
@@ -813,9 +813,12 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
 FUSE_BN_UP = os.environ.get("VIAI_FUSE_BN_UP", "1") != "0"      # BatchNorm apply + the resize behind a decoder block in one pass (A/B switch)
 
 
-def upsample_fusable(x, weight, bias, bn, transposed, act):
-    """can conv_bn_act(..., upsample=...) take this layer?  A BatchNorm2d layer that is not the fused Cin = 1 layer, a piecewise-linear
-    activation, a channel count the per-pixel resize kernels take (C / 4 a power of two <= 256)."""
+def upsample_fusable(x, weight, bias, bn, transposed, act, size=None):
+    """can conv_bn_act(..., upsample=size) take this layer?  A BatchNorm2d layer that is not the fused Cin = 1 layer, a piecewise-linear
+    activation, a channel count the per-pixel resize kernels take (C / 4 a power of two <= 256), and a target of fewer than 2^24
+    pixels (the fused kernel's pixel index; the two-pass path has a generic-index kernel for more)."""
+    if size is not None and x.shape[0] * int(size[0]) * int(size[1]) >= (1 << 24):
+        return False
     if not FUSE_BN_UP or bn is None or not isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) or act not in (ACT_NONE, ACT_RELU, ACT_LRELU):
         return False
     if x.shape[3] == 1:
