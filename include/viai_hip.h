@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 12
+#define VIAI_ABI_VERSION 13
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -430,6 +430,48 @@ int viai_conv2d_cin1_bn_wgrad(const viai_conv2d* c, const float* x, const float*
 /* dx straight from dz (dy formed per contributing output pixel): no dy tensor at all; needs bias == NULL */
 int viai_conv2d_cin1_bn_dgrad(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* dz, const float* mean,
                               const float* scale, const float* shift, const float* sums, float* dx, int act, void* stream);
+
+/* -------------------------------------------------- (ABI 13) pre-split activations and gradients: the P16 layout
+ * Between a BatchNorm pass and the f16x2 conv kernels that consume its output nothing needs fp32: every consumer (the next layer's forward,
+ * this layer's data gradient, the weight gradients on either side) splits each value into two fp16 terms, value * S = lead + rem, S a power
+ * of two, while it stages the tile -- up to four times per tensor and step, 6 VALU per element pair each time, in kernels that rocprofv3
+ * shows issue-bound (6 - 7 non-MFMA VALU per MFMA in the stride-2 and 32-channel families, profiles/r04_a_pmc_*.json).  A P16 tensor holds
+ * the two terms instead of the fp32 value, in the SAME bytes: shape (N, H, W, C) "fp32", C % 32 == 0; per pixel and 32-channel group g the
+ * 128 bytes at g * 128 are [32 x fp16 lead (64 B)][32 x fp16 rem (64 B)].  A consumer stages 16-byte PIECES (8 channels of one plane) where
+ * it staged 16-byte channel quads: same addresses, no conversion, one 16-byte LDS store.
+ * The scale S = 2^(14 - e), magnitude < 2^e, must be known BEFORE the pass that writes the planes, so it is derived from an a-priori BOUND
+ * of the tensor (written to *amax for the consumers), not from its measured maximum:
+ *   forward (training-mode statistics over m_stat samples):  |act(gamma xhat + beta)| <= |gamma| sqrt(m_stat - 1) + |beta|   (Samuelson)
+ *   backward: |dy| <= |scale| max|dpre| + |k1| sqrt(M - 1) / invstd + |k0| per channel, max|dpre| reduced with the sums
+ * fp16 keeps 11 bits at every magnitude down to 2^-14 S^-1, so values 2^10 below the bound still carry 22 bits (tests/test_p16_gpu.py).
+ * The arithmetic is that of the fp32-input kernels handed the same *amax, bit for bit.
+ * Reference semantics: the tensors between nn.BatchNorm2d / LeakyReLU and the next nn.Conv2d (Discriminator_Networks.py:38-46,
+ * New_Inpainting_Networks.py:31-37) -- an internal format; the module API keeps returning fp32.                                       */
+#define VIAI_P16_DY 1              /* viai_conv2d_wgrad_f16_p16 flags: dy is P16 (scale from *dy_amax) */
+#define VIAI_P16_X 2               /*                                  x is P16 (scale from *x_amax; no x2) */
+#define VIAI_P16_OK_FWD_X 1        /* viai_conv2d_p16_ok mask: the forward kernel takes a P16 x */
+#define VIAI_P16_OK_DGRAD_DY 2     /*                          the data-gradient kernel takes a P16 dy */
+#define VIAI_P16_OK_WGRAD_DY 4     /*                          the weight-gradient kernel takes a P16 dy */
+#define VIAI_P16_OK_WGRAD_X 8      /*                          ... and a P16 x */
+int viai_conv2d_p16_ok(const viai_conv2d* c);
+/* z (P16) = act(scale * y + shift); gamma / beta (NULL = 1 / 0) and m_stat give the bound; *z_amax receives it.  act: none / ReLU / LeakyReLU */
+int viai_bn_act_fwd_p16(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
+                        float* z, long M, int C, int act, float slope, float* z_amax, void* stream);
+/* viai_bn_act_bwd_amax with dy written as P16; part: 3 * C * viai_bn_bwd_blocks(M, C) floats, sums: 3 * C floats; *amax receives the bound */
+int viai_bn_act_bwd_p16(const float* dz, const float* y, const float* mean, const float* invstd,
+                        const float* scale, const float* shift, float* part, float* sums,
+                        float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
+                        int training, float* amax, void* stream);
+/* x (fp32) = the values a P16 tensor holds, (lead + rem) / S(*amax) */
+int viai_p16_decode(const float* p16, float* x, long M, int C, const float* amax, void* stream);
+/* viai_conv2d_fwd_amax / viai_conv2d_dgrad_f16 with the gathered tensor pre-split (one source; scale from *x_amax / *dy_amax) */
+int viai_conv2d_fwd_p16(const viai_conv2d* c, const float* x, const float* wp_fwd, const float* bias, float* y, float* stat_part,
+                        int act, const float* x_amax, void* stream);
+int viai_conv2d_dgrad_f16_p16(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2,
+                              const float* dy_amax, void* stream);
+/* viai_conv2d_wgrad_f16 with pre-split operands (flags: VIAI_P16_DY | VIAI_P16_X); db must be NULL when dy is P16 */
+int viai_conv2d_wgrad_f16_p16(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
+                              float* ws, float* dw, float* db, int accumulate, const float* dy_amax, const float* x_amax, int flags, void* stream);
 
 /* -------------------------------------------------- launch plans: the train step recorded once, replayed from C
  * Replaces the per-launch host work of `model.optimize_parameters()` (train_whole_sync.py:76).  Protocol:

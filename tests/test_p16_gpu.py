@@ -1,0 +1,200 @@
+"""Pre-split (P16) activations and gradients (include/viai_hip.h, ABI 13): the BatchNorm passes write their output as the two fp16 planes the
+f16x2 conv kernels would otherwise make of it while staging, with a scale derived from an a-priori bound.
+
+  * the producers: decode(P16) equals the fp32 pass to 2^-21 of the value (22 significand bits) wherever the value is within 2^10 of the
+    bound, the statistics / parameter gradients of the backward are bit-identical, the bound holds;
+  * the consumers: a kernel fed P16 operands returns bit for bit what the same kernel returns on the fp32 tensors with the same scale.
+Reference semantics: nn.BatchNorm2d + LeakyReLU between two nn.Conv2d (networks/Discriminator_Networks.py:38-46) and its autograd backward."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bn_coeffs(Cc, gen):
+    gamma = torch.rand(Cc, device="cuda", generator=gen) + 0.5
+    beta = torch.rand(Cc, device="cuda", generator=gen) - 0.5
+    mean = torch.rand(Cc, device="cuda", generator=gen) * 0.2 - 0.1
+    invstd = 1.0 / torch.sqrt(torch.rand(Cc, device="cuda", generator=gen) + 0.5)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    return gamma, beta, mean, invstd, scale, shift
+
+
+def to_p16(t, amax_value=None):
+    """fp32 NHWC tensor -> (P16 tensor, amax slot) through the forward producer with identity coefficients (gamma = 1: bound = sqrt(M - 1))"""
+    from viai_amd import _lib
+    lib = _lib.load()
+    Cc = t.shape[-1]
+    M = t.numel() // Cc
+    one, zero = torch.ones(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    out = torch.empty_like(t)
+    am = torch.zeros(1, device="cuda")
+    m_stat = M if amax_value is None else int(amax_value) ** 2 + 1
+    _lib.check(lib.viai_bn_act_fwd_p16(t.data_ptr(), one.data_ptr(), zero.data_ptr(), one.data_ptr(), zero.data_ptr(), m_stat, out.data_ptr(), M, Cc, 0, 0.2,
+                                       am.data_ptr(), _st()), "viai_bn_act_fwd_p16")
+    return out, am
+
+
+def decode(p, am):
+    from viai_amd import _lib
+    Cc = p.shape[-1]
+    out = torch.empty_like(p)
+    _lib.check(_lib.load().viai_p16_decode(p.data_ptr(), out.data_ptr(), p.numel() // Cc, Cc, am.data_ptr(), _st()), "viai_p16_decode")
+    return out
+
+
+@pytest.mark.parametrize("Cc", [32, 64, 96, 256])
+@pytest.mark.parametrize("act", [0, 1, 2], ids=["none", "relu", "lrelu"])
+def test_forward_producer_writes_the_split_of_the_fp32_pass(Cc, act):
+    from viai_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(Cc + act)
+    M = 5000
+    y = torch.randn(M, Cc, device="cuda", generator=gen) * 3
+    gamma, beta, mean, invstd, scale, shift = _bn_coeffs(Cc, gen)
+    z = torch.empty_like(y)
+    _lib.check(lib.viai_bn_act_fwd(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), z.data_ptr(), M, Cc, act, 0.2, _st()), "viai_bn_act_fwd")
+    zp, am = torch.empty_like(y), torch.zeros(1, device="cuda")
+    _lib.check(lib.viai_bn_act_fwd_p16(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, zp.data_ptr(), M, Cc, act, 0.2,
+                                       am.data_ptr(), _st()), "viai_bn_act_fwd_p16")
+    bound = float(am)
+    want = float((gamma.abs() * (M - 1) ** 0.5 + beta.abs()).max())
+    assert want <= bound <= want * 1.01
+    d = decode(zp, am)
+    # two fp16 terms: 22 bits for values down to 2^-10 of the bound's binade; below that the remainder term runs out of exponent (absolute 2^-24 / S)
+    S = 2.0 ** (14 - (torch.tensor(bound).log2().floor().item() + 1))
+    err = (d - z).abs()
+    tol = z.abs() * 2.0 ** -21 + 2.0 ** -24 / S
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert float(z.abs().max()) <= bound
+
+
+def test_backward_producer_matches_the_fp32_pass_and_bounds_dy():
+    from viai_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    for Cc, M, act, training in ((64, 6000, 2, 1), (128, 3000, 1, 1), (32, 4096, 0, 1), (96, 2000, 2, 0)):
+        y = torch.randn(M, Cc, device="cuda", generator=gen)
+        dz = torch.randn(M, Cc, device="cuda", generator=gen) * 1e-3
+        dz[17, 5] = 0.7                                                   # a heavy tail: the bound must follow it
+        gamma, beta, mean, invstd, scale, shift = _bn_coeffs(Cc, gen)
+        nblk = lib.viai_bn_bwd_blocks(M, Cc)
+        outs = []
+        for p16 in (False, True):
+            part = torch.empty((3 if p16 else 2) * Cc * nblk, device="cuda")
+            sums = torch.empty((3 if p16 else 2) * Cc, device="cuda")
+            dg, db = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+            dy, am = torch.empty_like(y), torch.zeros(1, device="cuda")
+            fn = lib.viai_bn_act_bwd_p16 if p16 else lib.viai_bn_act_bwd_amax
+            _lib.check(fn(dz.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), part.data_ptr(), sums.data_ptr(),
+                          dg.data_ptr(), db.data_ptr(), dy.data_ptr(), M, Cc, act, 0.2, training, am.data_ptr(), _st()), "bn_act_bwd")
+            outs.append((dy, am, dg, db, sums[:2 * Cc].clone()))
+        (dy, am, dg, db, sums), (dyp, amp, dgp, dbp, sumsp) = outs
+        assert torch.equal(dg, dgp) and torch.equal(db, dbp) and torch.equal(sums, sumsp)
+        assert float(am) <= float(amp) <= float(am) * 8, (float(am), float(amp))        # the bound holds and is not wildly loose
+        d = decode(dyp, amp)
+        S = 2.0 ** (14 - (amp.log2().floor().item() + 1))
+        err = (d - dy).abs()
+        # (+ an ulp of the LARGEST term of the sum: the two kernels may contract the fp32 expression scale * dpre + (k1 (y - mean) + k0)
+        # differently, and where the terms cancel that ulp is large against the result)
+        tol = dy.abs() * 2.0 ** -20 + 2.0 ** -23 / S + (scale.abs() * dz.abs() + sums[Cc:].abs() * (y - mean).abs() + sums[:Cc].abs()) * 2.0 ** -22
+        assert bool((err <= tol).all()), (Cc, float((err - tol).max()))
+
+
+WG_CASES = {"s1_128to128": (1, 128, 128, False), "s1_64to128_T": (1, 64, 128, True), "s2_64to128": (2, 64, 128, False), "s2_32to256": (2, 32, 256, False),
+            "narrow_32to32_T": (1, 32, 32, True), "narrow_64to32": (1, 64, 32, False), "p64_64to64": (1, 64, 64, False)}
+
+
+@pytest.mark.parametrize("case", list(WG_CASES), ids=list(WG_CASES))
+@pytest.mark.parametrize("which", [1, 2, 3], ids=["dy", "x", "both"])
+def test_weight_gradient_on_presplit_operands_is_bitwise_the_fp32_input_kernel(case, which):
+    from viai_amd import _lib, ops
+    lib = _lib.load()
+    S, Ci, Co, tr = WG_CASES[case]
+    N, OHW = 2, 64
+    H = W = OHW * S
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(N, H, W, Ci, device="cuda", generator=gen)
+    dy = torch.randn(N, OHW, OHW, Co, device="cuda", generator=gen) * 1e-2
+    d = ops.conv_desc(N, H, W, Ci, 0, Co, 3, 3, S, S, 1, 1, 1 if tr else 0)
+    ok = lib.viai_conv2d_p16_ok(d["ref"])
+    assert ok & 4 and ok & 8, ok
+    xp, xa = to_p16(x)
+    dyp, da = to_p16(dy)
+    wshape = (Ci, Co, 3, 3) if tr else (Co, Ci, 3, 3)
+    ws = torch.empty(d["ws_floats"], device="cuda")
+    ref = torch.empty(wshape, device="cuda")
+    _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), 0, dy.data_ptr(), ws.data_ptr(), ref.data_ptr(), 0, 0, da.data_ptr(), xa.data_ptr(), _st()), "wgrad_f16")
+    out = torch.empty(wshape, device="cuda")
+    _lib.check(lib.viai_conv2d_wgrad_f16_p16(d["ref"], (xp if which & 2 else x).data_ptr(), 0, (dyp if which & 1 else dy).data_ptr(), ws.data_ptr(), out.data_ptr(), 0, 0,
+                                             da.data_ptr(), xa.data_ptr(), which, _st()), "wgrad_f16_p16")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+    # and it is the weight gradient: against torch in fp64
+    xd, dyd = x.double().permute(0, 3, 1, 2).cpu(), dy.double().permute(0, 3, 1, 2).cpu()
+    wd = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+    o = torch.nn.functional.conv_transpose2d(xd, wd, None, 1, 1) if tr else torch.nn.functional.conv2d(xd, wd, None, S, 1)
+    (o * dyd).sum().backward()
+    rel = ((out.double().cpu() - wd.grad).norm() / wd.grad.norm()).item()
+    assert rel < 2e-6, rel
+
+
+CONV_CASES = {"wide_s1_128to256": (1, 128, 256, False, 64), "wide_s1_256to128_T": (1, 256, 128, True, 64), "wide_s1_128to32_T": (1, 128, 32, True, 96),
+              "halo64_64to64_T": (1, 64, 64, True, 64), "c32_32to32_T": (1, 32, 32, True, 64), "halo32_32to64": (1, 32, 64, False, 64),
+              "wide_s2_64to128": (2, 64, 128, False, 64), "wide_s2_128to256": (2, 128, 256, False, 32)}
+
+
+@pytest.mark.parametrize("case", list(CONV_CASES), ids=list(CONV_CASES))
+def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_input_kernels(case):
+    """every patch-staged f16x2 kernel family: wide halo (stride 1 and 2), streamed-filter halo, register-filter halo, stride-2 data gradient"""
+    from viai_amd import _lib, ops
+    lib = _lib.load()
+    S, Ci, Co, tr, OHW = CONV_CASES[case]
+    N = 4
+    H = W = OHW * S
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(N, H, W, Ci, device="cuda", generator=gen)
+    dy = torch.randn(N, OHW, OHW, Co, device="cuda", generator=gen) * 1e-2
+    w = torch.randn((Ci, Co, 3, 3) if tr else (Co, Ci, 3, 3), device="cuda", generator=gen) * 0.05
+    d = ops.conv_desc(N, H, W, Ci, 0, Co, 3, 3, S, S, 1, 1, 1 if tr else 0)
+    ok = lib.viai_conv2d_p16_ok(d["ref"])
+    assert ok & 1 and ok & 2, (case, ok)                  # (the shapes are chosen so that both directions run on a patch-staged kernel)
+    xp, xa = to_p16(x)
+    dyp, da = to_p16(dy)
+    fam = C.create_string_buffer(64)
+    # forward
+    wp = torch.empty(d["packed"], device="cuda")
+    _lib.check(lib.viai_conv2d_pack_fwd(d["ref"], w.data_ptr(), wp.data_ptr(), _st()), "pack_fwd")
+    y0, y1 = torch.empty(N, OHW, OHW, Co, device="cuda"), torch.empty(N, OHW, OHW, Co, device="cuda")
+    st0 = torch.empty(2 * Co * d["nblk"], device="cuda"); st1 = torch.empty_like(st0)
+    _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), 0, wp.data_ptr(), 0, y0.data_ptr(), st0.data_ptr(), 0, xa.data_ptr(), _st()), "fwd_amax")
+    lib.viai_conv2d_last_kernel(fam, 64); f0 = fam.value
+    _lib.check(lib.viai_conv2d_fwd_p16(d["ref"], xp.data_ptr(), wp.data_ptr(), 0, y1.data_ptr(), st1.data_ptr(), 0, xa.data_ptr(), _st()), "fwd_p16")
+    lib.viai_conv2d_last_kernel(fam, 64)
+    assert fam.value == f0 and f0.endswith(b"_f16x2"), (f0, fam.value)
+    assert torch.equal(y0, y1) and torch.equal(st0, st1)
+    ref = torch.nn.functional.conv_transpose2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, 1, 1) if tr else \
+        torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, S, 1)
+    assert ((y1.double().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm()).item() < 2e-6
+    # data gradient
+    wpd = torch.empty(d["packed"], device="cuda")
+    _lib.check(lib.viai_conv2d_pack_dgrad_f16(d["ref"], w.data_ptr(), wpd.data_ptr(), _st()), "pack_dgrad_f16")
+    g0, g1 = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(lib.viai_conv2d_dgrad_f16(d["ref"], dy.data_ptr(), wpd.data_ptr(), g0.data_ptr(), 0, da.data_ptr(), _st()), "dgrad_f16")
+    lib.viai_conv2d_last_kernel(fam, 64); f0 = fam.value
+    _lib.check(lib.viai_conv2d_dgrad_f16_p16(d["ref"], dyp.data_ptr(), wpd.data_ptr(), g1.data_ptr(), 0, da.data_ptr(), _st()), "dgrad_f16_p16")
+    lib.viai_conv2d_last_kernel(fam, 64)
+    assert fam.value == f0, (f0, fam.value)
+    torch.cuda.synchronize()
+    assert torch.equal(g0, g1)
+    xr = x.double().permute(0, 3, 1, 2).cpu().requires_grad_(True)
+    o = torch.nn.functional.conv_transpose2d(xr, w.double().cpu(), None, 1, 1) if tr else torch.nn.functional.conv2d(xr, w.double().cpu(), None, S, 1)
+    (o * dy.double().permute(0, 3, 1, 2).cpu()).sum().backward()
+    assert ((g1.double().cpu().permute(0, 3, 1, 2) - xr.grad).norm() / xr.grad.norm()).item() < 2e-6

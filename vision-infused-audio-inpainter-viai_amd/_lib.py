@@ -22,7 +22,7 @@ class ViaiLibraryError(RuntimeError):
 
 # ABI version THIS file's SIGNATURES / struct mirrors were written against: bumped together with them.  load() compares it with the
 # library, and with the committed header where that is present (a source checkout), so a stale _lib.py cannot call a rebuilt .so.
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 def _header_abi_version():
@@ -174,6 +174,13 @@ SIGNATURES = {
     "viai_conv2d_cin1_bn_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "viai_conv2d_cin1_bn_wgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "viai_conv2d_cin1_bn_dgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "viai_conv2d_p16_ok": (_I, [_CP]),
+    "viai_bn_act_fwd_p16": (_I, [_P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _F, _P, _P]),
+    "viai_bn_act_bwd_p16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P, _P]),
+    "viai_p16_decode": (_I, [_P, _P, _L, _I, _P, _P]),
+    "viai_conv2d_fwd_p16": (_I, [_CP, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "viai_conv2d_dgrad_f16_p16": (_I, [_CP, _P, _P, _P, _P, _P, _P]),
+    "viai_conv2d_wgrad_f16_p16": (_I, [_CP, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
     "viai_plan_log_begin": (_I, []),
     "viai_plan_log_end": (_I, []),
     "viai_plan_build": (_I, [_P, _P, C.POINTER(C.c_void_p)]),

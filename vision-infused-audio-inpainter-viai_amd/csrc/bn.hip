@@ -8,6 +8,7 @@
 // 1M-element channel never sees the E[x^2] - E[x]^2 cancellation.
 #include "viai_common.h"
 #include "viai_internal.h"
+#include "viai_bf3.h"
 
 namespace {
 
@@ -251,12 +252,15 @@ struct PoolPos {
 };
 
 // partial sums over a row range: part[blk][0][c] = sum dpre, part[blk][1][c] = sum dpre * xhat
-template <bool POOL = false>
+// MAXDP: a third partial per channel, max |dpre| over the block's rows (part[blk][2][c]): what the pre-split (P16) apply pass bounds |dy| with
+template <bool POOL = false, bool MAXDP = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dz, const float* __restrict__ y, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
     float* __restrict__ part, long M, int C, long rows_per_blk, int act, float slope, const PoolGather pg_ = PoolGather{}) {
     __shared__ f32x4 r1[256], r2[256];
+    __shared__ f32x4 r3[MAXDP ? 256 : 1];
+    constexpr int PS = MAXDP ? 3 : 2;
     const int tid = threadIdx.x;
     const int CG = C / 4;
     const long row0 = blockIdx.x * rows_per_blk;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         const int cgw = min(256, CG - g0);
         const int pg = 256 / cgw;
         const int cg = tid % cgw, pl = tid / cgw;
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
         if (pl < pg) {
             const int c = (g0 + cg) * 4;
             f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
@@ -291,17 +295,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                         float dp = g[u][e] * act_grad(v[u][e] * sc[e] + sh[e], act, slope);
                         s1[e] += dp;
                         s2[e] += dp * (v[u][e] - mu[e]) * is[e];
+                        if constexpr (MAXDP) s3[e] = fmaxf(s3[e], fabsf(dp));
                     }
             }
         }
         r1[tid] = s1; r2[tid] = s2;
+        if constexpr (MAXDP) r3[tid] = s3;
         __syncthreads();
         if (tid < cgw) {
-            f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < pg; ++k) { t1 += r1[k * cgw + tid]; t2 += r2[k * cgw + tid]; }
+            f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f}, t3 = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < pg; ++k) {
+                t1 += r1[k * cgw + tid]; t2 += r2[k * cgw + tid];
+                if constexpr (MAXDP) { const f32x4 m = r3[k * cgw + tid]; for (int e = 0; e < 4; ++e) t3[e] = fmaxf(t3[e], m[e]); }
+            }
             const int c = (g0 + tid) * 4;
-            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + c) = t1;
-            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + c) = t2;
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * PS + 0) * C + c) = t1;
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * PS + 1) * C + c) = t2;
+            if constexpr (MAXDP) *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * PS + 2) * C + c) = t3;
         }
         __syncthreads();
     }
@@ -313,39 +323,53 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, long M,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ scale, int training,
-                                                           float* sums, float* dgamma, float* dbeta, int accumulate) {
+                                                           float* sums, float* dgamma, float* dbeta, int accumulate, int ps) {
     __shared__ double r1[4][4], r2[4][4];
     const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
+    float mxdp = 0.f;
     float p_sc = 0.f, p_is = 0.f, p_db = 0.f, p_dg = 0.f;        // the epilogue's operands, requested before the reduction
     if (pl == 0 && c < C) {
-        if (training) { p_sc = scale[c]; p_is = invstd[c]; }
+        if (training || ps == 3) { p_sc = scale[c]; p_is = invstd[c]; }
         if (accumulate) { if (dbeta) p_db = dbeta[c]; if (dgamma) p_dg = dgamma[c]; }
     }
     if (c < C) {
         int b = pl;
         for (; b + 192 < nblk; b += 256) {               // 8 independent loads in flight per lane
-            float a0 = part[((size_t)b * 2 + 0) * C + c], b0 = part[((size_t)b * 2 + 1) * C + c];
-            float a1 = part[((size_t)(b + 64) * 2 + 0) * C + c], b1 = part[((size_t)(b + 64) * 2 + 1) * C + c];
-            float a2 = part[((size_t)(b + 128) * 2 + 0) * C + c], b2 = part[((size_t)(b + 128) * 2 + 1) * C + c];
-            float a3 = part[((size_t)(b + 192) * 2 + 0) * C + c], b3 = part[((size_t)(b + 192) * 2 + 1) * C + c];
+            float a0 = part[((size_t)b * ps + 0) * C + c], b0 = part[((size_t)b * ps + 1) * C + c];
+            float a1 = part[((size_t)(b + 64) * ps + 0) * C + c], b1 = part[((size_t)(b + 64) * ps + 1) * C + c];
+            float a2 = part[((size_t)(b + 128) * ps + 0) * C + c], b2 = part[((size_t)(b + 128) * ps + 1) * C + c];
+            float a3 = part[((size_t)(b + 192) * ps + 0) * C + c], b3 = part[((size_t)(b + 192) * ps + 1) * C + c];
             s1 += (double)a0; s1 += (double)a1; s1 += (double)a2; s1 += (double)a3;
             s2 += (double)b0; s2 += (double)b1; s2 += (double)b2; s2 += (double)b3;
+            if (ps == 3) for (int u = 0; u < 4; ++u) mxdp = fmaxf(mxdp, part[((size_t)(b + 64 * u) * 3 + 2) * C + c]);
         }
         for (; b < nblk; b += 64) {
-            s1 += (double)part[((size_t)b * 2 + 0) * C + c];
-            s2 += (double)part[((size_t)b * 2 + 1) * C + c];
+            s1 += (double)part[((size_t)b * ps + 0) * C + c];
+            s2 += (double)part[((size_t)b * ps + 1) * C + c];
+            if (ps == 3) mxdp = fmaxf(mxdp, part[((size_t)b * 3 + 2) * C + c]);
         }
     }
     // fixed-order tree: across the 16 partial lanes of a wave by shuffles, then across the four waves through LDS
 #pragma unroll
     for (int o = 4; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    if ((threadIdx.x & 63) < 4) { r1[threadIdx.x >> 6][cl] = s1; r2[threadIdx.x >> 6][cl] = s2; }
+    __shared__ float r3[4][4];
+    if (ps == 3) { for (int o = 4; o < 64; o <<= 1) mxdp = fmaxf(mxdp, __shfl_xor(mxdp, o, 64)); }
+    if ((threadIdx.x & 63) < 4) { r1[threadIdx.x >> 6][cl] = s1; r2[threadIdx.x >> 6][cl] = s2; r3[threadIdx.x >> 6][cl] = mxdp; }
     __syncthreads();
     if (pl == 0 && c < C) {
         s1 = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
         s2 = (r2[0][cl] + r2[1][cl]) + (r2[2][cl] + r2[3][cl]);
+        if (ps == 3) {
+            // |dy| <= |scale| max|dpre| + |k1| max|y - mean| + |k0| with max |y - mean| <= sqrt(M - 1) / invstd (Samuelson: no sample lies more than
+            // sqrt(M - 1) standard deviations from the mean; invstd^-2 = var + eps >= var): the magnitude the P16 apply pass scales dy by
+            mxdp = fmaxf(fmaxf(r3[0][cl], r3[1][cl]), fmaxf(r3[2][cl], r3[3][cl]));
+            const double sc_ = fabs((double)p_sc);
+            double bnd = sc_ * (double)mxdp;
+            if (training) bnd += sc_ * fabs(s2) * sqrt((double)(M > 1 ? M - 1 : 1)) / (double)M + sc_ * fabs(s1) / (double)M;
+            sums[2 * C + c] = (float)(bnd * 1.001);
+        }
         if (dbeta) dbeta[c] = accumulate ? p_db + (float)s1 : (float)s1;
         if (dgamma) dgamma[c] = accumulate ? p_dg + (float)s2 : (float)s2;
         if (training) {
@@ -445,6 +469,115 @@ int launch_bn_bwd_apply(const float* dz, const float* y, const float* mean, cons
     case VIAI_ACT_SIGMOID: return launch_bn_bwd_apply_t<VIAI_ACT_SIGMOID, FIXED, false>(dz, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
     default: return launch_bn_bwd_apply_t<VIAI_ACT_NONE, FIXED, false>(dz, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
     }
+}
+
+// ---- pre-split (P16) producers: the same two passes writing their output as fp16 planes (viai_bf3.h) -- what the f16x2 consumers would
+// otherwise make of the fp32 values, once per consumer and per staging.  A thread owns a channel OCTET (two 16-byte loads, one 16-byte store
+// per plane).  The scale must be known before the pass, so it comes from a bound instead of the measured maximum:
+//   forward  |z| = |act(gamma xhat + beta)| <= |gamma| sqrt(M - 1) + |beta|   (training-mode statistics over M samples: Samuelson)
+//   backward |dy| <= sums[2C + c]  (bn_bwd_final_kernel, ps = 3)
+// every block reduces the per-channel bounds to the tensor's (max is exact: all blocks agree), block 0 stores it for the consumers.
+__device__ __forceinline__ float block_max_all(float v) {
+    __shared__ float viai_bmx[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) viai_bmx[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = viai_bmx[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, viai_bmx[w]);
+    return m;
+}
+
+// z (P16) = act(scale y + shift); `rad` = sqrt(M - 1) of the statistics' population.  FIXED: C / 8 is a power of two <= 256, so a thread keeps
+// ONE octet for its whole grid-stride walk (coefficients loaded once, no division per item -- see bn_bwd_apply_kernel).
+template <bool FIXED>
+__global__ __launch_bounds__(256) void bn_act_fwd_p16_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float rad,
+                                                             u32x4* __restrict__ z, long n8, int C, int act, float slope, float* __restrict__ amax) {
+    float b = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) b = fmaxf(b, fabsf(gamma ? gamma[c] : 1.f) * rad + fabsf(beta ? beta[c] : 0.f));
+    const float bound = block_max_all(b) * 1.001f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *amax = bound;
+    const float S = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f16_scale_from_amax_value(bound)))), L = f16_clamp_for_scale(S);
+    const unsigned c8n = (unsigned)(C / 8);
+    const int lg = 31 - __builtin_clz(c8n);
+    const long stride = (long)gridDim.x * 256;
+    unsigned o = FIXED ? (threadIdx.x & (c8n - 1)) : 0u;
+    f32x4 sc0, sc1, sh0, sh1;
+    auto coeffs = [&]() {
+        sc0 = *reinterpret_cast<const f32x4*>(scale + o * 8); sc1 = *reinterpret_cast<const f32x4*>(scale + o * 8 + 4);
+        sh0 = *reinterpret_cast<const f32x4*>(shift + o * 8); sh1 = *reinterpret_cast<const f32x4*>(shift + o * 8 + 4);
+    };
+    if constexpr (FIXED) coeffs();
+    auto item = [&](long i, const f32x4& v0, const f32x4& v1) {
+        long pix;
+        if constexpr (FIXED) pix = i >> lg;
+        else { o = (unsigned)((unsigned long)i % c8n); pix = i / c8n; coeffs(); }
+        f32x4 a0, a1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] = viai_act(v0[e] * sc0[e] + sh0[e], act, slope); a1[e] = viai_act(v1[e] * sc1[e] + sh1[e], act, slope); }
+        u32x4 hi, lo;
+        p16_split8(a0, a1, S, L, hi, lo);
+        u32x4* dst = z + pix * (C / 4) + (o >> 2) * 8 + (o & 3);          // 16-byte units: group (o >> 2) starts at 8, piece o & 3
+        dst[0] = hi; dst[4] = lo;
+    };
+    long i = blockIdx.x * 256L + threadIdx.x;
+    for (; i + stride < n8; i += 2 * stride) {                            // four independent 16-byte loads in flight per thread
+        const f32x4 v0 = y[2 * i], v1 = y[2 * i + 1], w0 = y[2 * (i + stride)], w1 = y[2 * (i + stride) + 1];
+        item(i, v0, v1); item(i + stride, w0, w1);
+    }
+    for (; i < n8; i += stride) item(i, y[2 * i], y[2 * i + 1]);
+}
+
+// dy (P16) = scale dpre + k1 (y - mean) + k0
+template <bool FIXED>
+__global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ y, const float* __restrict__ mean,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ sums,
+                                                               u32x4* __restrict__ dy, long n8, int C, int act, float slope, float* __restrict__ amax) {
+    float b = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) b = fmaxf(b, sums[2 * C + c]);
+    const float bound = block_max_all(b);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *amax = bound;
+    const float S = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f16_scale_from_amax_value(bound)))), L = f16_clamp_for_scale(S);
+    const unsigned c8n = (unsigned)(C / 8);
+    const int lg = 31 - __builtin_clz(c8n);
+    const long stride = (long)gridDim.x * 256;
+    unsigned o = FIXED ? (threadIdx.x & (c8n - 1)) : 0u;
+    f32x4 sc[2], sh[2], k0[2], k1[2], mu[2];
+    auto coeffs = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = (int)o * 8 + 4 * h;
+            sc[h] = *reinterpret_cast<const f32x4*>(scale + c); sh[h] = *reinterpret_cast<const f32x4*>(shift + c);
+            k0[h] = *reinterpret_cast<const f32x4*>(sums + c); k1[h] = *reinterpret_cast<const f32x4*>(sums + C + c);
+            mu[h] = *reinterpret_cast<const f32x4*>(mean + c);
+        }
+    };
+    if constexpr (FIXED) coeffs();
+    auto item = [&](long i, const f32x4 (&g)[2], const f32x4 (&v)[2]) {
+        long pix;
+        if constexpr (FIXED) pix = i >> lg;
+        else { o = (unsigned)((unsigned long)i % c8n); pix = i / c8n; coeffs(); }
+        f32x4 r[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dp = g[h][e] * act_grad(v[h][e] * sc[h][e] + sh[h][e], act, slope);
+                r[h][e] = sc[h][e] * dp + (k1[h][e] * (v[h][e] - mu[h][e]) + k0[h][e]);          // the expression of bn_bwd_apply_kernel, bit for bit
+            }
+        u32x4 hi, lo;
+        p16_split8(r[0], r[1], S, L, hi, lo);
+        u32x4* dst = dy + pix * (C / 4) + (o >> 2) * 8 + (o & 3);
+        dst[0] = hi; dst[4] = lo;
+    };
+    long i = blockIdx.x * 256L + threadIdx.x;
+    for (; i + stride < n8; i += 2 * stride) {                            // eight independent 16-byte loads in flight per thread
+        const f32x4 g0[2] = {dz[2 * i], dz[2 * i + 1]}, v0[2] = {y[2 * i], y[2 * i + 1]};
+        const f32x4 g1[2] = {dz[2 * (i + stride)], dz[2 * (i + stride) + 1]}, v1[2] = {y[2 * (i + stride)], y[2 * (i + stride) + 1]};
+        item(i, g0, v0); item(i + stride, g1, v1);
+    }
+    for (; i < n8; i += stride) { const f32x4 g0[2] = {dz[2 * i], dz[2 * i + 1]}, v0[2] = {y[2 * i], y[2 * i + 1]}; item(i, g0, v0); }
 }
 
 __global__ void act_bwd_out_kernel(const float* __restrict__ dz, const float* __restrict__ z, float* __restrict__ dx,
@@ -572,7 +705,7 @@ extern "C" int viai_bn_act_bwd_amax(const float* dz, const float* y, const float
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
     VIAI_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, PoolGather{});
-    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1);
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 2);
     if (dy != nullptr) {
         long n4 = M * C / 4;
         const int c4n = C / 4;
@@ -595,7 +728,7 @@ extern "C" int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
     VIAI_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, (const float*)nullptr, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, pg);
-    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1);
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 2);
     const long n4 = M * C / 4;
     const bool fixed = 256 % (C / 4) == 0;
     if (act == VIAI_ACT_RELU) {
@@ -609,7 +742,7 @@ extern "C" int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char
 // the final pass alone (conv_direct.hip: the fused Cin = 1 layer produces the partials itself)
 int viai_bn_bwd_final_launch(const float* part, int nblk, int C, long M, const float* mean, const float* invstd, const float* scale,
                              int training, float* sums, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
-    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training, sums, dgamma, dbeta, accumulate);
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training, sums, dgamma, dbeta, accumulate, 2);
     return viai_launch_status();
 }
 
@@ -622,5 +755,70 @@ extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mea
 
 extern "C" int viai_act_bwd_from_output(const float* dz, const float* z, float* dx, long n, int act, float slope, void* stream) {
     VIAI_LAUNCH(act_bwd_out_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dz, z, dx, n, act, slope);
+    return viai_launch_status();
+}
+
+// ---- (ABI 13) pre-split outputs.  z / dy are written as P16 planes (csrc/viai_bf3.h: per pixel and 32-channel group, 32 leading fp16 terms then
+// 32 remainder terms of value * scale), the layout the f16x2 conv kernels stage without converting; *amax receives the magnitude BOUND the
+// scale was derived from (consumers derive the same scale from it).  C % 32 == 0.
+extern "C" int viai_bn_act_fwd_p16(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
+                                   float* z, long M, int C, int act, float slope, float* z_amax, void* stream) {
+    if (C % 32 != 0 || z_amax == nullptr || m_stat < 1 || act == VIAI_ACT_SIGMOID) return (int)hipErrorInvalidValue;
+    const long n8 = M * C / 8;
+    const float rad = sqrtf((float)(m_stat > 1 ? m_stat - 1 : 1));
+    const int c8n = C / 8;
+    if ((c8n & (c8n - 1)) == 0 && c8n <= 256)
+        VIAI_LAUNCH(bn_act_fwd_p16_kernel<true>, dim3(stream_grid(n8, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(y), scale, shift, gamma, beta, rad,
+                    reinterpret_cast<u32x4*>(z), n8, C, act, slope, z_amax);
+    else
+        VIAI_LAUNCH(bn_act_fwd_p16_kernel<false>, dim3(stream_grid(n8, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(y), scale, shift, gamma, beta, rad,
+                    reinterpret_cast<u32x4*>(z), n8, C, act, slope, z_amax);
+    return viai_launch_status();
+}
+
+// viai_bn_act_bwd_amax with dy pre-split; part: 3 * C * viai_bn_bwd_blocks(M, C) floats, sums: 3 * C floats
+extern "C" int viai_bn_act_bwd_p16(const float* dz, const float* y, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, float* part, float* sums,
+                                   float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
+                                   int training, float* amax, void* stream) {
+    if (C % 32 != 0 || amax == nullptr || dy == nullptr || act == VIAI_ACT_SIGMOID) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = viai_bn_bwd_blocks(M, C);
+    const long rpb = (M + nblk - 1) / nblk;
+    VIAI_LAUNCH((bn_bwd_reduce_kernel<false, true>), dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, PoolGather{});
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 3);
+    const long n8 = M * C / 8;
+    const int c8n = C / 8;
+    if ((c8n & (c8n - 1)) == 0 && c8n <= 256)
+        VIAI_LAUNCH(bn_bwd_apply_p16_kernel<true>, dim3(stream_grid(n8, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz), reinterpret_cast<const f32x4*>(y), mean, scale, shift, sums,
+                    reinterpret_cast<u32x4*>(dy), n8, C, act, slope, amax);
+    else
+        VIAI_LAUNCH(bn_bwd_apply_p16_kernel<false>, dim3(stream_grid(n8, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz), reinterpret_cast<const f32x4*>(y), mean, scale, shift, sums,
+                    reinterpret_cast<u32x4*>(dy), n8, C, act, slope, amax);
+    return viai_launch_status();
+}
+
+// fp32 view of a pre-split tensor: x[i] = (leading + remainder) / scale(*amax).  For tests and for consumers without a P16 loader.
+__global__ __launch_bounds__(256) void p16_decode_kernel(const u32x4* __restrict__ p, f32x4* __restrict__ x, long n8, int C, const float* __restrict__ amax) {
+    const float inv = 1.f / f16_scale_from_amax(amax);
+    const unsigned c8n = (unsigned)(C / 8);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const unsigned o = (unsigned)((unsigned long)i % c8n);
+        const long pix = i / c8n;
+        const u32x4* src = p + pix * (C / 4) + (o >> 2) * 8 + (o & 3);
+        const u32x4 hi = src[0], lo = src[4];
+        f32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            a[2 * e] = (f16_lo(hi[e]) + f16_lo(lo[e])) * inv; a[2 * e + 1] = (f16_hi(hi[e]) + f16_hi(lo[e])) * inv;
+            b[2 * e] = (f16_lo(hi[2 + e]) + f16_lo(lo[2 + e])) * inv; b[2 * e + 1] = (f16_hi(hi[2 + e]) + f16_hi(lo[2 + e])) * inv;
+        }
+        x[2 * i] = a; x[2 * i + 1] = b;
+    }
+}
+extern "C" int viai_p16_decode(const float* p16, float* x, long M, int C, const float* amax, void* stream) {
+    if (C % 32 != 0 || amax == nullptr) return (int)hipErrorInvalidValue;
+    const long n8 = M * C / 8;
+    VIAI_LAUNCH(p16_decode_kernel, dim3(stream_grid(n8, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const u32x4*>(p16), reinterpret_cast<f32x4*>(x), n8, C, amax);
     return viai_launch_status();
 }

@@ -388,8 +388,23 @@ extern "C" int viai_conv2d_fwd_f16_ok(const viai_conv2d* c) {
 
 // x_amax: device float >= max |x| (and |x2|), or NULL.  The f16x2 kernels scale their activation operand by a power of two before the
 // split: from x_amax when it is given (any magnitude is then representable), by the static 16 otherwise (|x| beyond 4094 saturates)
+static int fwd_impl(const viai_conv2d* c, const float* x, const float* x2, const float* wp,
+                    const float* bias, float* y, float* stat_part, int act, const float* x_amax, void* stream, int p16);
 extern "C" int viai_conv2d_fwd_amax(const viai_conv2d* c, const float* x, const float* x2, const float* wp,
                                     const float* bias, float* y, float* stat_part, int act, const float* x_amax, void* stream) {
+    return fwd_impl(c, x, x2, wp, bias, y, stat_part, act, x_amax, stream, 0);
+}
+static bool p16_fwd_ok(const viai_conv2d* c) {
+    return valid(c) && kind_of(c) == K_IGEMM && f16x2_enabled() && c->C2 == 0 && (halo_fwd(c) || halo_wide_fwd(c));
+}
+// (ABI 13) the forward with x pre-split (P16 planes, scale from *x_amax): layers with VIAI_P16_OK_FWD_X in viai_conv2d_p16_ok
+extern "C" int viai_conv2d_fwd_p16(const viai_conv2d* c, const float* x, const float* wp, const float* bias, float* y, float* stat_part,
+                                   int act, const float* x_amax, void* stream) {
+    if (!p16_fwd_ok(c) || x_amax == nullptr) return (int)hipErrorInvalidValue;
+    return fwd_impl(c, x, nullptr, wp, bias, y, stat_part, act, x_amax, stream, 1);
+}
+static int fwd_impl(const viai_conv2d* c, const float* x, const float* x2, const float* wp,
+                    const float* bias, float* y, float* stat_part, int act, const float* x_amax, void* stream, int p16) {
     if (!valid(c) || (c->C2 > 0) != (x2 != nullptr)) return (int)hipErrorInvalidValue;
     if (stat_part != nullptr && act != VIAI_ACT_NONE) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
@@ -406,6 +421,7 @@ extern "C" int viai_conv2d_fwd_amax(const viai_conv2d* c, const float* x, const 
     a.in = x; a.in2 = x2; a.wp = wp; a.bias = bias; a.out = y; a.out2 = nullptr; a.stat = stat_part;
     a.C1 = c->C1; a.C2 = c->C2; a.Cout = c->Cout; a.OC1 = c->Cout;
     a.act = act; a.slope = 0.2f;
+    a.in_p16 = p16;
     if (kind_of(c) == K_RUN) { geom_run(c, &a.g); a.C1 = 32; a.C2 = 0; }
     else viai_geom_fwd(c, &a.g);
     a.M = a.g.N * a.g.OH * a.g.OW;
@@ -420,7 +436,7 @@ extern "C" int viai_conv2d_fwd_amax(const viai_conv2d* c, const float* x, const 
     return viai_conv_igemm_launch(a, st);
 }
 
-static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2, const float* amax, void* stream);
+static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2, const float* amax, void* stream, int p16 = 0);
 
 extern "C" int viai_conv2d_dgrad(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2, void* stream) {
     return dgrad_impl(c, dy, wp, dx, dx2, nullptr, stream);
@@ -444,7 +460,25 @@ extern "C" int viai_conv2d_dgrad_f16(const viai_conv2d* c, const float* dy, cons
     return dgrad_impl(c, dy, wp, dx, dx2, dy_amax, stream);
 }
 
-static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2, const float* amax, void* stream) {
+// the patch-staged stride-2 data gradient (conv_dgrad_s2_bf3.hip) takes this layer: base lattice a multiple of 8 x 16
+static bool s2_patch_dgrad(const viai_conv2d* c) {
+    if (!s2_dgrad(c)) return false;
+    int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
+    return oh % 8 == 0 && ow % 16 == 0 && c->IH == 2 * oh && c->IW == 2 * ow && c->Cout % 32 == 0;
+}
+static bool p16_dgrad_ok(const viai_conv2d* c) {
+    if (!valid(c) || kind_of(c) != K_IGEMM || !dgrad_f16(c)) return false;
+    if (s2_dgrad(c)) return s2_patch_dgrad(c);
+    return c->sh == 1 && c->sw == 1 && (halo_dgrad(c) || halo_wide_dgrad(c));
+}
+// (ABI 13) viai_conv2d_dgrad_f16 with dy pre-split (P16 planes, scale from *dy_amax): layers with VIAI_P16_OK_DGRAD_DY
+extern "C" int viai_conv2d_dgrad_f16_p16(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2,
+                                         const float* dy_amax, void* stream) {
+    if (!p16_dgrad_ok(c) || dy_amax == nullptr) return (int)hipErrorInvalidValue;
+    return dgrad_impl(c, dy, wp, dx, dx2, dy_amax, stream, 1);
+}
+
+static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2, const float* amax, void* stream, int p16) {
     if (!valid(c) || (c->C2 > 0) != (dx2 != nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     viai_tag_reset();
@@ -474,6 +508,7 @@ static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, fl
         a.M = c->N * (c->IH / 2) * (c->IW / 2);
         a.wfrag = amax != nullptr ? 3 : 1;
         a.amax = amax;
+        a.in_p16 = p16;
         return viai_conv_dgrad_s2_bf3_launch(a, st);
     }
     for (int a_ = 0; a_ < c->sh; ++a_)
@@ -482,6 +517,7 @@ static int dgrad_impl(const viai_conv2d* c, const float* dy, const float* wp, fl
             a.in = dy; a.in2 = nullptr; a.wp = wp; a.bias = nullptr; a.out = dx; a.out2 = dx2; a.stat = nullptr;
             a.C1 = c->Cout; a.C2 = 0; a.Cout = cin_of(c); a.OC1 = c->C1;
             a.act = VIAI_ACT_NONE; a.slope = 0.f;
+            a.in_p16 = p16;
             int nt = viai_geom_dgrad_class(c, a_, b_, &a.g);
             if (a.g.SH <= 0 || a.g.SW <= 0) continue;
             if (nt == 0) continue;                            // zero-filled above
@@ -542,7 +578,7 @@ extern "C" size_t viai_conv2d_wgrad_ws_bytes(const viai_conv2d* c) {
 }
 
 static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
-                      float* ws, float* dw, float* db, int accumulate, const float* amax, const float* xmax, void* stream);
+                      float* ws, float* dw, float* db, int accumulate, const float* amax, const float* xmax, void* stream, int p16 = 0);
 
 extern "C" int viai_conv2d_wgrad(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
                                  float* ws, float* dw, float* db, int accumulate, void* stream) {
@@ -562,9 +598,26 @@ extern "C" int viai_conv2d_wgrad_f16(const viai_conv2d* c, const float* x, const
     return wgrad_impl(c, x, x2, dy, ws, dw, db, accumulate, dy_amax, x_amax, stream);
 }
 
+// (ABI 13) which operands of this layer's f16x2 kernels may arrive pre-split (P16 planes, csrc/viai_bf3.h): a mask of VIAI_P16_OK_*
+extern "C" int viai_conv2d_p16_ok(const viai_conv2d* c) {
+    if (!valid(c) || kind_of(c) != K_IGEMM || !f16x2_enabled() || !bf3_enabled()) return 0;
+    int m = 0;
+    if (wgrad_patch(c)) { m |= VIAI_P16_OK_WGRAD_DY; if (c->C2 == 0) m |= VIAI_P16_OK_WGRAD_X; }
+    if (p16_fwd_ok(c)) m |= VIAI_P16_OK_FWD_X;
+    if (p16_dgrad_ok(c)) m |= VIAI_P16_OK_DGRAD_DY;
+    return m;
+}
+extern "C" int viai_conv2d_wgrad_f16_p16(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
+                                         float* ws, float* dw, float* db, int accumulate, const float* dy_amax, const float* x_amax, int flags, void* stream) {
+    if (!viai_conv2d_wgrad_f16_ok(c) || dy_amax == nullptr) return (int)hipErrorInvalidValue;
+    return wgrad_impl(c, x, x2, dy, ws, dw, db, accumulate, dy_amax, x_amax, stream, flags);
+}
+
 static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, const float* dy,
-                      float* ws, float* dw, float* db, int accumulate, const float* amax, const float* xmax, void* stream) {
+                      float* ws, float* dw, float* db, int accumulate, const float* amax, const float* xmax, void* stream, int p16) {
     if (!valid(c) || (c->C2 > 0) != (x2 != nullptr)) return (int)hipErrorInvalidValue;
+    if (p16 != 0 && (kind_of(c) != K_IGEMM || amax == nullptr || !wgrad_patch(c) || ((p16 & VIAI_P16_DY) && db != nullptr)
+                     || ((p16 & VIAI_P16_X) && (x2 != nullptr || xmax == nullptr)))) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     int oh, ow; viai_conv2d_out_hw(c, &oh, &ow);
     const long M = (long)c->N * oh * ow;
@@ -600,6 +653,7 @@ static int wgrad_impl(const viai_conv2d* c, const float* x, const float* x2, con
         a.x = x; a.x2 = x2; a.dy = dy; a.ws = ws; a.C1 = c->C1; a.C2 = c->C2; a.Cout = c->Cout; a.M = (int)M;
         a.amax = amax;
         a.xmax = xmax;
+        a.dy_p16 = (p16 & VIAI_P16_DY) ? 1 : 0; a.x_p16 = (p16 & VIAI_P16_X) ? 1 : 0;
         viai_geom_fwd(c, &a.g);
         int ks = wgrad_ksplit(c, M);
         const bool patch = amax != nullptr && wgrad_patch(c);

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 // times per 32-channel chunk, one barrier each, a wave-uniform branch per class).  Here a block owns an 8 x 16 tile of the base
 // lattice: per chunk the (8+1) x (16+1) dy patch is staged ONCE, the four shifts are four compile-time window offsets, and the nine
 // (shift, class, tap) units of a chunk are a static list -- one barrier per chunk, no branches in the K loop.
+template <bool P16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_dgrad_s2_patch_kernel(const ConvArgs a) {
     constexpr int NP = 2, TM = 2, PITCH = 80, PH = 9, PW = 17, HP = PH * PW, PLANE = HP * PITCH, STAGE = NP * PLANE;
     constexpr int NL = (HP * 8 + 255) / 256;         // float4 per thread per chunk
@@ -263,16 +264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             const int h = h0 + 32 * j;
-            if (h < HP) {
-                const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
-                unsigned a1, a2, b1, b2;
-                split2_pair(v[0], v[1], ascale, alim, a1, a2);
-                split2_pair(v[2], v[3], ascale, alim, b1, b2);
-                const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
-                unsigned char* d = smem_b + buf * STAGE + h * PITCH + q * 8;
-                *reinterpret_cast<u32x2*>(d) = p1;
-                *reinterpret_cast<u32x2*>(d + PLANE) = p2;
-            }
+            if (h < HP) stage_put32<P16>(smem_b + buf * STAGE + h * PITCH, PLANE, q, raw[j], ascale, alim);
         }
     };
     // the nine units of a chunk: (shift sy, sx) -> window offset; class (a, b) -> accumulator a * 2 + b; tap r * 3 + s
@@ -405,11 +397,17 @@ int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st) {
     if (a.amax != nullptr && patch && a.g.IH % 8 == 0 && a.g.IW % 16 == 0 && a.g.OH == 2 * a.g.IH && a.g.OW == 2 * a.g.IW && a.C1 % 32 == 0) {
         constexpr int lds_p = 2 * 2 * 9 * 17 * 80;
         static bool attr_p = false;
-        if (!attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p); attr_p = true; }
+        if (!attr_p) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_patch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_patch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p);
+            attr_p = true;
+        }
         viai_tag_kernel("dgrad_s2_patch_f16x2");
-        VIAI_LAUNCH(conv_dgrad_s2_patch_kernel, dim3(a.nblk_m * a.nblk_n), dim3(256), lds_p, st, a);
+        if (a.in_p16) VIAI_LAUNCH(conv_dgrad_s2_patch_kernel<true>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds_p, st, a);
+        else VIAI_LAUNCH(conv_dgrad_s2_patch_kernel<false>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds_p, st, a);
         return viai_launch_status();
     }
+    if (a.in_p16) return (int)hipErrorInvalidValue;
     viai_tag_kernel(a.amax != nullptr ? "dgrad_s2_f16x2" : "dgrad_s2_bf16x3");
     if (a.amax != nullptr) VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<2>, dim3(a.nblk_m * a.nblk_n), dim3(256), 2 * 2 * 128 * BF3_PITCH, st, a);   // f16x2
     else VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<3>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);

@@ -22,8 +22,10 @@ constexpr int HT_HH = HT_H + 2, HT_HW = HT_W + 2, HT_HP = HT_HH * HT_HW;   // st
 constexpr int HALO_WIDE_ROW_BYTES = 1536;       // conv_halo_wide_f16_kernel, stride 1: LDS bytes per patch row (18 pixels x 80 bytes, padded to a multiple of 256)
 
 // NP = 3: bf16x3; NP = 2: f16x2 (two fp16 planes, three partial products; operand scale static or from a.amax)
-template <int CIN, int TN, int NP = 3>
+// P16 (NP = 2 only): the gathered tensor arrives pre-split (viai_bf3.h): pieces are copied into their plane instead of quads being split
+template <int CIN, int TN, int NP = 3, bool P16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 && TN == 1) ? 3 : 2))) void conv_halo_bf3_kernel(const ConvArgs a, int hy0, int hx0, int ntiles) {
+    static_assert(!P16 || NP == 2, "P16 is an f16x2 format");
     constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int PITCH = CIN * 2 + 16;             // bytes per LDS pixel row (80 / 144: conflict-free ds_read_b128)
     constexpr int Q = CIN / 4;                      // float4 per pixel
@@ -87,12 +89,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
                     *reinterpret_cast<u32x2*>(d + PLANE) = p2;
                     *reinterpret_cast<u32x2*>(d + 2 * PLANE) = p3;
                 } else {
-                    unsigned a1, a2, b1, b2;
-                    split2_pair(v[0], v[1], ascale, alim, a1, a2);
-                    split2_pair(v[2], v[3], ascale, alim, b1, b2);
-                    const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
-                    *reinterpret_cast<u32x2*>(d) = p1;
-                    *reinterpret_cast<u32x2*>(d + PLANE) = p2;
+                    stage_put32<P16>(smem_h + (h0 + (256 / Q) * j) * PITCH + (q >> 3) * 64, PLANE, q & 7, reg[j], ascale, alim);
                 }
             }
         }
@@ -264,6 +261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
 // planes in LDS -> 54 MFMAs per wave whose A operands are ds_read_b128 at compile-time offsets -> epilogue.
 struct HaloSlots { int s[9]; };                    // weight slot of window position (row * 3 + col)
 
+template <bool P16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_f16_c32_kernel(const ConvArgs a, int hy0, int hx0, int ntiles, HaloSlots slots) {
     constexpr int CIN = 32, PITCH = 80, Q = 8, KS = 2;
     constexpr int NL = (HT_HP * Q + 255) / 256;     // 6 float4 per thread
@@ -318,16 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     auto store_patch = [&]() {
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            if (prc[j] >= 0) {
-                const f32x4 v = __builtin_bit_cast(f32x4, reg[j]);
-                unsigned a1, a2, b1, b2;
-                split2_pair(v[0], v[1], ascale, alim, a1, a2);
-                split2_pair(v[2], v[3], ascale, alim, b1, b2);
-                const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
-                unsigned char* d = smem_h + (h0 + (256 / Q) * j) * PITCH + q * 8;
-                *reinterpret_cast<u32x2*>(d) = p1;
-                *reinterpret_cast<u32x2*>(d + PLANE) = p2;
-            }
+            if (prc[j] >= 0) stage_put32<P16>(smem_h + (h0 + (256 / Q) * j) * PITCH, PLANE, q, reg[j], ascale, alim);
         }
     };
 
@@ -428,7 +417,7 @@ struct HaloWideSlots { int s[9]; };
 // S = 2: 3 x 3 STRIDE-2 forward conv.  The (17 x 33) input patch of the tile is stored as four parity sub-patches
 //   P[py][px][r][c] = patch(2 r + py, 2 c + px), so that window position (ty, tx) of output pixel (r, c) is sub-patch (ty & 1, tx & 1) at
 //   (r + (ty >> 1), c + (tx >> 1)): consecutive output pixels read consecutive 80-byte rows, as in the stride-1 case.  One LDS stage (98 KB).
-template <int WM, int WN, int TM, int TN, int S = 1>
+template <int WM, int WN, int TM, int TN, int S = 1, bool P16 = false>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_wide_f16_kernel(const ConvArgs a, int hy0, int hx0, HaloWideSlots slots) {
     static_assert(WM * TM == 4, "config");
     constexpr int NP = 2, BN = 32 * TN * WN, NTHR = 64 * WM * WN;
@@ -499,14 +488,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
             if (h < NPIX) {
                 const int hr = h / PW, hc = h - hr * PW;
                 const int soff = S == 2 ? (((hr & 1) * 2 + (hc & 1)) * SUB + (hr >> 1) * SUBW + (hc >> 1)) * PITCH : hr * RPB + hc * PITCH;
-                const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
-                unsigned a1, a2, b1, b2;
-                split2_pair(v[0], v[1], ascale, alim, a1, a2);
-                split2_pair(v[2], v[3], ascale, alim, b1, b2);
-                const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
-                unsigned char* d = smem_h + buf * STAGE + soff + q * 8;
-                *reinterpret_cast<u32x2*>(d) = p1;
-                *reinterpret_cast<u32x2*>(d + PLANE) = p2;
+                stage_put32<P16>(smem_h + buf * STAGE + soff, PLANE, q, raw[j], ascale, alim);
             }
         }
     };
@@ -708,6 +690,15 @@ int launch_halo(ConvArgs& a, int hy0, int hx0, hipStream_t st) {
     int grid = 256 * per_cu;
     if (grid > a.nblk_m) grid = a.nblk_m;
     viai_tag_kernel(NP == 2 ? "halo_f16x2" : "halo_bf16x3");
+    if constexpr (NP == 2) {
+        if (a.in_p16) {
+            static bool attr_p = false;
+            if (!attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bf3_kernel<CIN, TN, NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_p = true; }
+            VIAI_LAUNCH((conv_halo_bf3_kernel<CIN, TN, NP, true>), dim3(grid), dim3(256), lds, st, a, hy0, hx0, a.nblk_m);
+            return viai_launch_status();
+        }
+    }
+    if (a.in_p16) return (int)hipErrorInvalidValue;
     VIAI_LAUNCH((conv_halo_bf3_kernel<CIN, TN, NP>), dim3(grid), dim3(256), lds, st, a, hy0, hx0, a.nblk_m);
     return viai_launch_status();
 }
@@ -761,7 +752,8 @@ int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st) {
         int grid = 256 * 2;
         if (grid > a.nblk_m) grid = a.nblk_m;
         viai_tag_kernel("halo_c32_f16x2");
-        VIAI_LAUNCH(conv_halo_f16_c32_kernel, dim3(grid), dim3(256), lds, st, a, y0, x0, a.nblk_m, sl);
+        if (a.in_p16) VIAI_LAUNCH(conv_halo_f16_c32_kernel<true>, dim3(grid), dim3(256), lds, st, a, y0, x0, a.nblk_m, sl);
+        else VIAI_LAUNCH(conv_halo_f16_c32_kernel<false>, dim3(grid), dim3(256), lds, st, a, y0, x0, a.nblk_m, sl);
         return viai_launch_status();
     }
     int y0 = g.dy[0], y1 = g.dy[0], x0 = g.dx[0], x1 = g.dx[0];
@@ -819,11 +811,17 @@ template <int WM, int WN, int TM, int TN, int S = 1>
 static int launch_halo_wide(ConvArgs& a, int y0, int x0, const HaloWideSlots& sl, hipStream_t st) {
     constexpr int lds = S == 2 ? 2 * 4 * 9 * 17 * 80 : 2 * 2 * HT_HH * HALO_WIDE_ROW_BYTES;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_wide_f16_kernel<WM, WN, TM, TN, S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_wide_f16_kernel<WM, WN, TM, TN, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_wide_f16_kernel<WM, WN, TM, TN, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
     a.nblk_n = (a.Cout + 32 * TN * WN - 1) / (32 * TN * WN);
     static const std::string fam = S == 2 ? std::string("halo_wide_s2_f16x2") : "halo_wide" + std::to_string(32 * TN * WN) + "_f16x2";
     viai_tag_kernel(fam.c_str());
-    VIAI_LAUNCH((conv_halo_wide_f16_kernel<WM, WN, TM, TN, S>), dim3(a.nblk_m * a.nblk_n), dim3(64 * WM * WN), lds, st, a, y0, x0, sl);
+    if (a.in_p16 && (a.C2 != 0 || a.amax == nullptr)) return (int)hipErrorInvalidValue;          // one pre-split source, with its scale
+    if (a.in_p16) VIAI_LAUNCH((conv_halo_wide_f16_kernel<WM, WN, TM, TN, S, true>), dim3(a.nblk_m * a.nblk_n), dim3(64 * WM * WN), lds, st, a, y0, x0, sl);
+    else VIAI_LAUNCH((conv_halo_wide_f16_kernel<WM, WN, TM, TN, S, false>), dim3(a.nblk_m * a.nblk_n), dim3(64 * WM * WN), lds, st, a, y0, x0, sl);
     return viai_launch_status();
 }
 

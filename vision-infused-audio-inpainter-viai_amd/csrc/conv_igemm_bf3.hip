@@ -954,6 +954,7 @@ int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
     const int Cin = a.C1 + a.C2;
     if (Cin % 16 != 0 || (a.C2 > 0 && a.C1 % 32 != 0)) return (int)hipErrorInvalidValue;
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
+    if (a.in_p16 && !(a.wfrag == 3 && !a.sk && viai_conv_halo_wide_ok(a))) return (int)hipErrorInvalidValue;     // only the patch-staged kernels stage P16 pieces
     if (a.sk) return launch_bf3_sk(a, st);
     const int bm = viai_igemm_tile_m(a.M, a.Cout);           // same tile rule as the fp32 kernels (BN partial geometry)
     if (a.wfrag == 3) {                                                        // f16x2 weights

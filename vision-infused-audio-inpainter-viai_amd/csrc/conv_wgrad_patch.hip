@@ -94,7 +94,9 @@ struct WgCfg {
     }
 };
 
-template <int S, int BM, int BN, int HR, int WK>
+// PD / PX: dy / x arrive pre-split (P16 planes, viai_bf3.h): the staged 16-byte item is a PIECE (8 channels of one plane) instead of a
+// channel quad -- same global address, no split, one 16-byte LDS store into the piece's plane
+template <int S, int BM, int BN, int HR, int WK, bool PD = false, bool PX = false>
 __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_patch_f16_kernel(const WgradArgs a, int y0, int x0, WgPatchSlots slots) {
     using C = WgCfg<S, BM, BN, HR, WK>;
     constexpr int WP_DROW = C::DROW, WP_BM = BM;
@@ -143,9 +145,11 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
     constexpr int PJ = C::PJ;
     const int dq = tid % C::DQ, dp0 = tid / C::DQ;
     const int d_goff = ((((dp0 >> 4) * g.OW + (dp0 & 15)) * a.Cout) + co0 + dq * 4) * 4;       // pixel dp0 = (row dp0 >> 4, column dp0 & 15) of the stage
-    const int d_lds = BM == 128 ? dp0 * WP_DROW + (((dq >> 3) ^ (dp0 & 3)) * 64) + (dq & 7) * 8       // + j * PJ * WP_DROW   (PJ % 4 == 0: same swizzle)
-                    : BM == 64  ? dp0 * WP_DROW + (((dq >> 3) ^ ((dp0 >> 1) & 1)) * 64) + (dq & 7) * 8
-                                : dp0 * WP_DROW + dq * 8;
+    // (P16: item dq is piece dq & 7 of 32-channel group dq >> 3: plane (dq >> 2) & 1, bytes 16 (dq & 3) .. of the group's 64-byte row)
+    const int d_in = PD ? ((dq >> 2) & 1) * DPLANE + (dq & 3) * 16 : (dq & 7) * 8;
+    const int d_lds = BM == 128 ? dp0 * WP_DROW + (((dq >> 3) ^ (dp0 & 3)) * 64) + d_in       // + j * PJ * WP_DROW   (PJ % 4 == 0: same swizzle)
+                    : BM == 64  ? dp0 * WP_DROW + (((dq >> 3) ^ ((dp0 >> 1) & 1)) * 64) + d_in
+                                : dp0 * WP_DROW + d_in;
     // x: item j = patch pixel (tid / XQ) + XPP j, channel quad q = tid % XQ
     const int xq = tid % C::XQ, xp0 = tid / C::XQ;
 
@@ -202,18 +206,23 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
     };
     // LDS byte offset (within an x plane) of this thread's x item j.  Stride 1: affine in j.  Stride 2: recomputed at the store (a few
     // integer instructions per item and stage) rather than held in NX registers next to 144 accumulators.
-    const int x_lds0 = xp0 * XPITCH + xq * 8;
+    const int x_in = PX ? (xq >> 3) * 64 + ((xq >> 2) & 1) * XPLANE + (xq & 3) * 16 : xq * 8;
+    const int x_lds0 = xp0 * XPITCH + x_in;
     auto x_lds = [&](int j) -> int {
         if constexpr (S == 1) return x_lds0 + j * C::XPP * XPITCH;
         const int pp = xp0 + C::XPP * j;
         const int ppr = (pp * 1986) >> 16, ppc = pp - ppr * C::PW;
         const int sl = ((ppr & 1) ? 2 * (HR + 1) * C::SUBW + (ppc & 1) * HR * C::SUBW : (ppc & 1) * (HR + 1) * C::SUBW) + (ppr >> 1) * C::SUBW + (ppc >> 1);
-        return sl * XPITCH + xq * 8;
+        return sl * XPITCH + x_in;
     };
     // split + store of one staged float4 in two halves (unit 0: channels 0, 1; unit 1: channels 2, 3 + the two 8-byte LDS stores), so the
     // work can be dealt out between the taps of a k-step, a few instructions at a time
     unsigned hp1, hp2;
-    auto put_unit = [&](unsigned char* d, int plane, const u32x4& raw, float Sc, float L, int unit) {
+    auto put_unit = [&](unsigned char* d, int plane, const u32x4& raw, float Sc, float L, int unit, auto P16) {
+        if constexpr (decltype(P16)::value) {                 // a piece: copied as it is (d already points into its plane)
+            if (unit == 1) *reinterpret_cast<u32x4*>(d) = raw;
+            return;
+        }
         const f32x4 v = __builtin_bit_cast(f32x4, raw);
         if (unit == 0) {
             split2_pair(v[0], v[1], Sc, L, hp1, hp2);
@@ -231,10 +240,10 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
         const int it = U >> 1, half = U & 1;
 #pragma unroll
         for (int j = 0; j < ND; ++j)
-            if (it == j) put_unit(base + d_lds + j * PJ * WP_DROW, DPLANE, draw[j], dscale, dlim, half);
+            if (it == j) put_unit(base + d_lds + j * PJ * WP_DROW, DPLANE, draw[j], dscale, dlim, half, std::integral_constant<bool, PD>{});
 #pragma unroll
         for (int j = 0; j < NX; ++j)
-            if (it == ND + j && (C::XPP * (j + 1) <= C::XPIX || xp0 + C::XPP * j < C::XPIX)) put_unit(base + 2 * DPLANE + (half ? x_lds(j) : 0), XPLANE, xraw[j], xscale, xlim, half);
+            if (it == ND + j && (C::XPP * (j + 1) <= C::XPIX || xp0 + C::XPP * j < C::XPIX)) put_unit(base + 2 * DPLANE + (half ? x_lds(j) : 0), XPLANE, xraw[j], xscale, xlim, half, std::integral_constant<bool, PX>{});
     };
 
     f32x16 acc[9];
@@ -394,14 +403,22 @@ static int bm_of(int cfg) { return cfg == 3 ? 32 : cfg == 4 ? 64 : 128; }
 static int bn_of(int cfg) { return (cfg == 1 || cfg == 4) ? 64 : 32; }
 static int wk_of(int cfg) { (void)cfg; return 1; }      // slabs per block (the k-splitting waves of the narrow instance reduce in the block)
 
-template <int S, int BM, int BN, int HR, int WK>
-static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hipStream_t st) {
+template <int S, int BM, int BN, int HR, int WK, bool PD, bool PX>
+static int launch_patch_p(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hipStream_t st) {
     using C = WgCfg<S, BM, BN, HR, WK>;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_patch_f16_kernel<S, BM, BN, HR, WK>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); attr_done = true; }
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_patch_f16_kernel<S, BM, BN, HR, WK, PD, PX>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); attr_done = true; }
     viai_tag_kernel(S == 2 ? "wgrad_patch_s2_f16x2" : BM == 32 ? "wgrad_patch_narrow_f16x2" : BM == 64 ? "wgrad_patch64_f16x2" : "wgrad_patch_f16x2");
-    VIAI_LAUNCH((wgrad_patch_f16_kernel<S, BM, BN, HR, WK>), dim3(a.nblk_co * a.nblk_ci * a.ksplit), dim3(C::NTHR), C::LDS, st, a, y0, x0, sl);
+    VIAI_LAUNCH((wgrad_patch_f16_kernel<S, BM, BN, HR, WK, PD, PX>), dim3(a.nblk_co * a.nblk_ci * a.ksplit), dim3(C::NTHR), C::LDS, st, a, y0, x0, sl);
     return viai_launch_status();
+}
+template <int S, int BM, int BN, int HR, int WK>
+static int launch_patch(WgradArgs& a, int y0, int x0, const WgPatchSlots& sl, hipStream_t st) {
+    if (a.x_p16 && (a.C2 != 0 || a.xmax == nullptr)) return (int)hipErrorInvalidValue;       // one pre-split source, with its scale
+    if (a.dy_p16 && a.x_p16) return launch_patch_p<S, BM, BN, HR, WK, true, true>(a, y0, x0, sl, st);
+    if (a.dy_p16) return launch_patch_p<S, BM, BN, HR, WK, true, false>(a, y0, x0, sl, st);
+    if (a.x_p16) return launch_patch_p<S, BM, BN, HR, WK, false, true>(a, y0, x0, sl, st);
+    return launch_patch_p<S, BM, BN, HR, WK, false, false>(a, y0, x0, sl, st);
 }
 
 // number of block-level K slabs

@@ -63,3 +63,43 @@ __device__ __forceinline__ float f16_scale_from_amax(const float* amax) {
     field = field < 1 ? 1 : (field > 254 ? 254 : field);
     return __uint_as_float((unsigned)field << 23);
 }
+
+// ---- P16: activation / gradient tensors stored PRE-SPLIT (round 4).  Same bytes as the fp32 NHWC tensor, C % 32 == 0: per pixel, per
+// 32-channel group g, [32 leading fp16 terms (64 B)][32 remainder terms (64 B)] at byte offset g * 128 of the pixel's C * 4 bytes -- i.e.
+// exactly what split2_pair would make of the group's fp32 values with the tensor's scale.  A 16-byte piece q (0 .. 7) of a group holds
+// plane q >> 2, channels 8 (q & 3) .. + 7; a consumer that staged fp32 channel quads (16 B per lane, split, two 8-byte LDS stores) stages
+// pieces instead (16 B per lane, one 16-byte LDS store into the piece's plane): same addresses, same byte counts, no conversion.  The
+// scale is the power of two f16_scale_from_amax derives from the tensor's magnitude slot, which the PRODUCER fills with an a-priori bound
+// (BatchNorm: |gamma| sqrt(M - 1) + |beta| by Samuelson's inequality; its backward: from per-channel max |d pre|), so it is known before
+// the pass that writes the planes.
+__device__ __forceinline__ float f16_scale_from_amax_value(float amax) {
+    const unsigned bits = __float_as_uint(amax);
+    if (bits == 0u) return 1.f;
+    int field = 127 + 14 - ((int)((bits >> 23) & 255u) - 126);
+    field = field < 1 ? 1 : (field > 254 ? 254 : field);
+    return __uint_as_float((unsigned)field << 23);
+}
+// eight consecutive channels (two fp32 quads) -> their leading / remainder pieces
+__device__ __forceinline__ void p16_split8(const f32x4& a, const f32x4& b, float S, float L, u32x4& hi, u32x4& lo) {
+    unsigned h, l;
+    split2_pair(a[0], a[1], S, L, h, l); hi[0] = h; lo[0] = l;
+    split2_pair(a[2], a[3], S, L, h, l); hi[1] = h; lo[1] = l;
+    split2_pair(b[0], b[1], S, L, h, l); hi[2] = h; lo[2] = l;
+    split2_pair(b[2], b[3], S, L, h, l); hi[3] = h; lo[3] = l;
+}
+// One staged 16-byte item of a 32-channel chunk row going to LDS.  fp32 source: channel quad q (0 .. 7), split into both planes (8 bytes
+// each at q * 8); P16 source: piece q, copied into its plane.  `row` = the row's address in plane 0, `plane` = bytes between the planes.
+template <bool P16>
+__device__ __forceinline__ void stage_put32(unsigned char* row, int plane, int q, const u32x4& raw, float S, float L) {
+    if constexpr (P16) {
+        *reinterpret_cast<u32x4*>(row + (q >> 2) * plane + (q & 3) * 16) = raw;
+    } else {
+        const f32x4 v = __builtin_bit_cast(f32x4, raw);
+        unsigned a1, a2, b1, b2;
+        split2_pair(v[0], v[1], S, L, a1, a2);
+        split2_pair(v[2], v[3], S, L, b1, b2);
+        const u32x2 p1 = {a1, b1}, p2 = {a2, b2};
+        *reinterpret_cast<u32x2*>(row + q * 8) = p1;
+        *reinterpret_cast<u32x2*>(row + plane + q * 8) = p2;
+    }
+}

@@ -18,6 +18,7 @@ struct ConvArgs {
     int wfrag;            // bf16x3 only: 1 = weights packed fragment-major (viai_bf3_frag_layout)
     int sk;               // bf16x3 only: 1 = 32x32-tile kernel whose four waves split K (viai_bf3_sk_ok)
     const float* amax;    // f16x2 launches: device scalar max |gathered tensor| (dynamic operand scale, data gradients); null = static F16_ASCALE
+    int in_p16;           // 1: the gathered tensor (in; no in2) is stored pre-split (P16 planes, viai_bf3.h) with the scale of *amax
     ConvGeom g;
 };
 
@@ -30,6 +31,7 @@ struct WgradArgs {
     int C1, C2, Cout;
     int M;
     int nblk_co, nblk_ci, ksplit, chunks_per_split;
+    int dy_p16, x_p16;                 // 1: dy / x (no x2) stored pre-split (P16 planes, viai_bf3.h) with the scales of *amax / *xmax
     ConvGeom g;                        // forward geometry (ly = lx = 1)
 };
 
