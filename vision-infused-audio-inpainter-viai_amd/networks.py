@@ -98,8 +98,29 @@ FLOW_STREAM = os.environ.get("VIAI_FLOW_STREAM", "1") != "0"           # ImageEm
 FUSE_BN_TAIL = os.environ.get("VIAI_FUSE_BN_TAIL", "1") != "0"      # BatchNorm apply + (residual add + ReLU | ReLU + max-pool) in one pass (A/B switch)
 
 
-def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=None, pool=None, upsample=None):
-    """conv (nn.Conv2d | nn.ConvTranspose2d holder) -> bn (nn.BatchNorm2d | nn.InstanceNorm2d holder | None) -> act, on NHWC.
+def takes_p16(x_shape, conv):
+    """will `conv` (the layer behind a BatchNorm pass) stage a pre-split (P16) input of this NHWC shape?  (ops.conv_takes_p16)"""
+    tr = isinstance(conv, nn.ConvTranspose2d)
+    if not isinstance(conv, (nn.Conv2d, nn.ConvTranspose2d)) or getattr(conv, "groups", 1) != 1 or _pair(conv.dilation) != (1, 1):
+        return False
+    if tr and _pair(conv.stride) != (1, 1):
+        return False
+    return ops.conv_takes_p16(tuple(x_shape), conv.weight, _pair(conv.kernel_size), _pair(conv.stride), _pair(conv.padding), tr)
+
+
+def out_shape(x_shape, conv):
+    """NHWC shape of conv(x)"""
+    N, H, W, _ = x_shape
+    k, s, p = _pair(conv.kernel_size), _pair(conv.stride), _pair(conv.padding)
+    if isinstance(conv, nn.ConvTranspose2d):
+        return (N, (H - 1) * s[0] - 2 * p[0] + k[0], (W - 1) * s[1] - 2 * p[1] + k[1], conv.out_channels)
+    return (N, (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1, conv.out_channels)
+
+
+def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=None, pool=None, upsample=None, next_conv=None):
+    """`next_conv`: the conv layer that consumes this layer's output (and nothing else does): where its kernels stage pre-split pieces, the
+    BatchNorm apply pass writes them (ops.conv_bn_act(out_p16=True)).
+    conv (nn.Conv2d | nn.ConvTranspose2d holder) -> bn (nn.BatchNorm2d | nn.InstanceNorm2d holder | None) -> act, on NHWC.
     `xmask`: the layer convolves x * xmask (ops.conv_bn_act).  `upsample` = (H, W): F.interpolate(.., align_corners=True) behind the
     layer -- inside the BatchNorm apply pass where ops.upsample_fusable allows, as a pass of its own otherwise."""
     transposed = isinstance(conv, nn.ConvTranspose2d)
@@ -122,9 +143,11 @@ def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=N
         return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
                                padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2, training=bn.training, xmask=xmask,
                                residual=residual, pool=pool)
+    p16 = (next_conv is not None and residual is None and pool is None and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training
+           and takes_p16(out_shape(x.shape, conv), next_conv))
     out = ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
                           padding=_pair(conv.padding), transposed=transposed, act=(ACT_NONE if residual is not None else act), x2=x2,
-                          training=(bn.training if bn is not None else training), xmask=xmask)
+                          training=(bn.training if bn is not None else training), xmask=xmask, out_p16=p16)
     if residual is not None:
         out = ops.add_relu(out, residual) if act == ACT_RELU else out + residual
     return ops.maxpool(out, *pool) if pool is not None else out
@@ -179,7 +202,8 @@ class TransConvBlock(nn.Module):
         for i in range(self.nums):
             conv = self._modules["conv%s_%d" % (self.name, i)]
             bn = self._modules["conv%s_%d_bn" % (self.name, i)]
-            x = fused_layer(x, conv, bn, ACT_RELU, x2=x2 if i == 0 else None, upsample=upsample if i == self.nums - 1 else None)
+            nxt = self._modules["conv%s_%d" % (self.name, i + 1)] if i + 1 < self.nums else None
+            x = fused_layer(x, conv, bn, ACT_RELU, x2=x2 if i == 0 else None, upsample=upsample if i == self.nums - 1 else None, next_conv=nxt)
         return x
 
     def forward(self, x):
@@ -365,7 +389,8 @@ class MelDiscriminator(nn.Module):
     def forward_nhwc(self, x):
         net = fused_layer(x, self.conv1, self.bn1, ACT_LRELU)
         for n in range(1, self.n_layers):
-            net = fused_layer(net, self._modules["conv2_%d" % n], self._modules["norm_%d" % n], ACT_LRELU)
+            nxt = self._modules["conv2_%d" % (n + 1)] if n + 1 < self.n_layers else self.conv3
+            net = fused_layer(net, self._modules["conv2_%d" % n], self._modules["norm_%d" % n], ACT_LRELU, next_conv=nxt)
         return fused_pair(net, self.conv3, self.norm3, ACT_LRELU, self.conv4, ACT_SIGMOID if self.use_sigmoid else ACT_NONE)
 
     def forward(self, input):

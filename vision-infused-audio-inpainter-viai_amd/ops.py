@@ -38,6 +38,52 @@ _deferred = []
 F16_BACKWARD = os.environ.get("VIAI_F16_BACKWARD", "1") != "0"     # f16x2 data gradients (dynamic per-tensor scale)
 F16_DYNAMIC = os.environ.get("VIAI_F16_DYNAMIC", "1") != "0"       # 0: static x16 activation scale in the forward / weight-gradient kernels (A/B only)
 
+# Pre-split tensors (P16, include/viai_hip.h ABI 13).  A tensor tagged `_viai_p16` holds, in the bytes of an fp32 NHWC tensor of the same
+# shape, the two fp16 planes the f16x2 kernels would make of its values (scale from its `_viai_amax` slot, filled by the producer with an
+# a-priori bound).  Producers: the BatchNorm apply passes (forward: where the caller asks with out_p16 -- networks.py knows the consumer;
+# backward: where this layer's own data- / weight-gradient kernels take it).  Consumers: conv_bn_act / conv_bn_act_cout1 (anything else
+# refuses a P16 tensor; p16_decode() gives the fp32 values).  VIAI_P16=0 switches the format off (A/B; results are bit-identical).
+P16 = os.environ.get("VIAI_P16", "1") != "0"
+P16_OK_FWD_X, P16_OK_DGRAD_DY, P16_OK_WGRAD_DY, P16_OK_WGRAD_X = 1, 2, 4, 8
+
+
+def is_p16(t):
+    return t is not None and getattr(t, "_viai_p16", False)
+
+
+def p16_mask(d):
+    m = d.get("p16")
+    if m is None:
+        m = d["p16"] = int(_lib.load().viai_conv2d_p16_ok(d["ref"])) if P16 else 0
+    return m
+
+
+def _p16_decode(t, amax):
+    out = torch.empty_like(t)
+    Cc = t.shape[-1]
+    _lib.check(_lib.load().viai_p16_decode(t.data_ptr(), out.data_ptr(), t.numel() // Cc, Cc, amax.data_ptr(), _stream()), "viai_p16_decode")
+    out._viai_amax = amax
+    return out
+
+
+def p16_decode(t):
+    """fp32 values of a pre-split tensor (one streaming pass): for consumers without a P16 loader, and for tests"""
+    return _p16_decode(t, t._viai_amax) if is_p16(t) else t
+
+
+def conv_takes_p16(x_shape, weight, kernel, stride, padding, transposed):
+    """will conv_bn_act on an input of this NHWC shape stage a pre-split x in both its forward and its weight-gradient kernel?
+    (what a producer asks before it writes its output as P16: networks.py)"""
+    if not P16:
+        return False
+    N, IH, IW, C1 = x_shape
+    Cout = weight.shape[1] if transposed else weight.shape[0]
+    if C1 % 32 != 0:
+        return False
+    d = conv_desc(N, IH, IW, C1, 0, Cout, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], 1 if transposed else 0)
+    return (p16_mask(d) & (P16_OK_FWD_X | P16_OK_WGRAD_X)) == (P16_OK_FWD_X | P16_OK_WGRAD_X)
+
+
 # Gradient-ready hooks (set by model.AudioModel for the data-parallel exchange): {weight.data_ptr(): callable}.  The callable runs
 # right after the backward of the layer owning that weight has queued its LAST gradient launch (weight gradient on WGRAD_STREAM,
 # BatchNorm gamma / beta gradients on the current stream), i.e. every parameter gradient of that layer and of all layers behind it
@@ -105,6 +151,8 @@ def _require(*tensors):
     for t in tensors:
         if t is None:
             continue
+        if getattr(t, "_viai_p16", False):
+            raise TypeError("this op does not take a pre-split (P16) tensor; ops.p16_decode() gives its fp32 values")
         if not t.is_cuda:
             raise _lib.ViaiLibraryError("viai ops run on the GPU only (got a %s tensor); no CPU fallback" % t.device)
         if t.dtype != torch.float32:
@@ -395,7 +443,19 @@ def conv_desc(N, IH, IW, C1, C2, Cout, kh, kw, sh, sw, ph, pw, transposed, dh=1,
     return d
 
 
-def _conv_grads(lib, d, cfg, dims, has_bn, has_bias, needs, xa, x, x2, weight, dy, amax, st):
+def _wgrad_call(lib, d, x, x2, dy, ws, dw, db, acc, amax, xa, flags, handle):
+    if flags:
+        _lib.check(lib.viai_conv2d_wgrad_f16_p16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(), dw.data_ptr(), db, acc,
+                                                 amax.data_ptr(), _ptr(xa), flags, handle), "viai_conv2d_wgrad_f16_p16")
+    elif amax is not None and d["wgrad_f16"]:
+        _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(), dw.data_ptr(), db, acc,
+                                             amax.data_ptr(), _ptr(xa), handle), "viai_conv2d_wgrad_f16")
+    else:
+        _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(), dw.data_ptr(), db, acc, handle),
+                   "viai_conv2d_wgrad")
+
+
+def _conv_grads(lib, d, cfg, dims, has_bn, has_bias, needs, xa, x, x2, weight, dy, amax, st, dy_p16=False, x_p16=False):
     """weight / bias / data gradients of one conv layer from dy (the gradient of its output): the tail every fused layer's backward
     shares.  needs = (need_x, need_x2, need_w, need_b); returns (dx, dx2, dw, db) with None where the gradient went into the arena."""
     N, IH, IW, C1, C2, Cout, OH, OW = dims
@@ -404,6 +464,10 @@ def _conv_grads(lib, d, cfg, dims, has_bn, has_bias, needs, xa, x, x2, weight, d
     need_x, need_x2, need_w, need_b = needs
     gt = cfg.get("gt") or (None, None, None, None)
     dw = db = dx = dx2 = None
+    if need_w and x_p16 and not (p16_mask(d) & P16_OK_WGRAD_X and (amax is not None and d.get("wgrad_f16"))):
+        x = _p16_decode(x, xa)                 # (a layer whose weight gradient cannot stage pieces: not reached by the networks of this package)
+        x_p16 = False
+    flags = (1 if dy_p16 else 0) | (2 if x_p16 else 0)
     if need_w or (need_b and has_bias):
         ws = None
         shadowed = has_bn and cfg["training"]     # bias in front of train-mode BN: gradient is exactly 0
@@ -426,26 +490,14 @@ def _conv_grads(lib, d, cfg, dims, has_bn, has_bias, needs, xa, x, x2, weight, d
             # (no `with torch.cuda.stream(...)` here: the launch takes the stream handle explicitly, and entering / leaving the
             # context costs ~25 us of host time per layer)
             ws = _scratch("wgrad", d["ws_floats"], dev, WGRAD_STREAM)
-            if amax is not None and d["wgrad_f16"]:
-                _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                     dw.data_ptr(), db.data_ptr() if want_db else 0, 1, amax.data_ptr(), _ptr(xa),
-                                                     WGRAD_STREAM.cuda_stream), "viai_conv2d_wgrad_f16")
-            else:
-                _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                 dw.data_ptr(), db.data_ptr() if want_db else 0, 1, WGRAD_STREAM.cuda_stream),
-                           "viai_conv2d_wgrad")
+            _wgrad_call(lib, d, x, x2, dy, ws, dw, db.data_ptr() if want_db else 0, 1, amax, xa, flags, WGRAD_STREAM.cuda_stream)
             _deferred.append((x, x2, dy, weight, amax, xa))
         elif acc_w == acc_b or not want_db:
             ws = _scratch("wgrad", d["ws_floats"], dev)
-            if amax is not None and d["wgrad_f16"]:
-                _lib.check(lib.viai_conv2d_wgrad_f16(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                     dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0,
-                                                     amax.data_ptr(), _ptr(xa), st), "viai_conv2d_wgrad_f16")
-            else:
-                _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
-                                                 dw.data_ptr(), db.data_ptr() if want_db else 0, 1 if acc_w else 0, st),
-                           "viai_conv2d_wgrad")
+            _wgrad_call(lib, d, x, x2, dy, ws, dw, db.data_ptr() if want_db else 0, 1 if acc_w else 0, amax, xa, flags, st)
         else:   # mixed modes (only outside AudioModel): two calls keep the accumulate flag consistent
+            if flags:
+                raise RuntimeError("pre-split operands with a mixed accumulate / overwrite bias gradient")
             ws = _scratch("wgrad", d["ws_floats"], dev)
             _lib.check(lib.viai_conv2d_wgrad(d["ref"], x.data_ptr(), _ptr(x2), dy.data_ptr(), ws.data_ptr(),
                                              dw.data_ptr(), 0, 1 if acc_w else 0, st), "viai_conv2d_wgrad")
@@ -463,7 +515,11 @@ def _conv_grads(lib, d, cfg, dims, has_bn, has_bias, needs, xa, x, x2, weight, d
     if need_x or need_x2:
         dx = torch.empty((N, IH, IW, C1), device=dev, dtype=torch.float32)
         dx2 = torch.empty((N, IH, IW, C2), device=dev, dtype=torch.float32) if C2 > 0 else None
-        if amax is not None and d["dgrad_f16"]:
+        if dy_p16:
+            wp = _packed(weight, d, 2, st)
+            _lib.check(lib.viai_conv2d_dgrad_f16_p16(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), amax.data_ptr(), st),
+                       "viai_conv2d_dgrad_f16_p16")
+        elif amax is not None and d["dgrad_f16"]:
             wp = _packed(weight, d, 2, st)
             _lib.check(lib.viai_conv2d_dgrad_f16(d["ref"], dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), _ptr(dx2), amax.data_ptr(), st),
                        "viai_conv2d_dgrad_f16")
@@ -484,7 +540,8 @@ class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, weight, bias, gamma, beta, rmean, rvar, nbt, res, cfg):
         lib = _lib.load()
-        _require(x, x2, weight, bias, gamma, beta, res)
+        xp = is_p16(x)
+        _require(None if xp else x, x2, weight, bias, gamma, beta, res)
         x = _c(x)
         x2 = _c(x2) if x2 is not None else None
         weight = _c(weight)
@@ -512,8 +569,22 @@ class _ConvBnAct(torch.autograd.Function):
         f16f = d.get("fwd_f16")
         if f16f is None:
             f16f = d["fwd_f16"] = bool(lib.viai_conv2d_fwd_f16_ok(d["ref"]))
-        xa = _input_amax(x, x2, cfg.get("xa_in", (None, None)), st) if (f16f and F16_DYNAMIC) else None   # operand magnitude of the f16x2 split (forward and weight gradient)
+        if xp and (x2 is not None or (p16_mask(d) & P16_OK_FWD_X) == 0):
+            x = p16_decode(x)                   # (a layer without a P16 loader: the networks of this package ask conv_takes_p16 first)
+            xp = False
+        if xp:
+            xa = amax_of(x)                     # the scale the planes were written with
+        else:
+            xa = _input_amax(x, x2, cfg.get("xa_in", (None, None)), st) if (f16f and F16_DYNAMIC) else None   # operand magnitude of the f16x2 split (forward and weight gradient)
         ctx.xa = xa
+        ctx.x_p16 = xp
+
+        def conv_fwd(out, stat, act_):
+            if xp:
+                _lib.check(lib.viai_conv2d_fwd_p16(d["ref"], x.data_ptr(), wp.data_ptr(), _ptr(bias), out.data_ptr(), stat, act_, xa.data_ptr(), st), "viai_conv2d_fwd_p16")
+            else:
+                _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias), out.data_ptr(), stat, act_, _ptr(xa), st),
+                           "viai_conv2d_fwd")
         za = None
         fused1 = False
         if has_bn and training and bias is None and C1 + C2 == 1:
@@ -542,12 +613,10 @@ class _ConvBnAct(torch.autograd.Function):
             coef = torch.empty((4, Cout), device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
             if training:
                 stat = _scratch("stat", 2 * Cout * d["nblk"], dev)
-                _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
-                                                    y.data_ptr(), stat.data_ptr(), ACT_NONE, _ptr(xa), st), "viai_conv2d_fwd")
+                conv_fwd(y, stat.data_ptr(), ACT_NONE)
                 _bn_finalize(lib, d, stat, M, Cout, gamma, beta, rmean, rvar, nbt, cfg, coef, st)
             else:
-                _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
-                                                    y.data_ptr(), 0, ACT_NONE, _ptr(xa), st), "viai_conv2d_fwd")
+                conv_fwd(y, 0, ACT_NONE)
                 _lib.check(lib.viai_bn_eval_coeffs(Cout, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(),
                                                    rvar.data_ptr(), cfg["eps"], coef[0].data_ptr(), coef[1].data_ptr(),
                                                    coef[2].data_ptr(), coef[3].data_ptr(), st), "viai_bn_eval_coeffs")
@@ -578,6 +647,13 @@ class _ConvBnAct(torch.autograd.Function):
                 _lib.check(lib.viai_bn_act_bilinear_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(), N, OH, OW, UH, UW,
                                                              Cout, act, 0.2, za.data_ptr(), st), "viai_bn_act_bilinear_fwd")
                 ctx.save_for_backward(x, x2, weight, y, coef)
+            elif cfg.get("p16_out") and P16 and training and Cout % 32 == 0 and act in (ACT_NONE, ACT_RELU, ACT_LRELU):
+                # the consumer stages pre-split pieces (networks.py asked conv_takes_p16): z is written as the two fp16 planes, scale from the bound
+                z = torch.empty_like(y)
+                _lib.check(lib.viai_bn_act_fwd_p16(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, z.data_ptr(),
+                                                   M, Cout, act, 0.2, za.data_ptr(), st), "viai_bn_act_fwd_p16")
+                cfg["z_p16"] = True
+                ctx.save_for_backward(x, x2, weight, y, coef)
             else:
                 z = torch.empty_like(y)
                 _lib.check(lib.viai_bn_act_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(),
@@ -586,8 +662,7 @@ class _ConvBnAct(torch.autograd.Function):
             ctx.tail = "pool" if pool is not None else ("res" if res is not None else ("up" if cfg.get("up") is not None else None))
         else:
             z = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
-            _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp.data_ptr(), _ptr(bias),
-                                                z.data_ptr(), 0, act, _ptr(xa), st), "viai_conv2d_fwd")
+            conv_fwd(z, 0, act)
             if act == ACT_SIGMOID:
                 za = _const_amax(dev, 1.0)
             ctx.save_for_backward(x, x2, weight, z, None)
@@ -618,6 +693,7 @@ class _ConvBnAct(torch.autograd.Function):
         gt = cfg.get("gt") or (None, None, None, None)       # in-place gradient targets (arena views)
         dgamma = dbeta = None
         amax = None
+        dy_p16 = False
         if ctx.fused1:
             return _ConvBnAct._backward_cin1(ctx, lib, dz, x, weight, coef, st)
         dres = None
@@ -656,7 +732,20 @@ class _ConvBnAct(torch.autograd.Function):
                 f16w = d["wgrad_f16"] = bool(lib.viai_conv2d_wgrad_f16_ok(d["ref"]))
             # max |dy|: operand scale of the f16x2 data- and weight-gradient kernels
             amax = _amax_slot(dev) if (F16_BACKWARD and ((f16d and need_x) or (f16w and need_w))) else None
-            if ctx.tail == "pool":
+            # dy pre-split (P16) when every kernel that reads it stages pieces: this layer's data gradient (if needed) and weight gradient
+            # (if needed); a bias gradient (column sums of dy) needs the fp32 tensor
+            pm = p16_mask(d)
+            dy_p16 = (P16 and amax is not None and Cout % 32 == 0 and act != ACT_SIGMOID and ctx.tail in (None, "up")
+                      and (need_x or need_w) and (not need_x or (f16d and pm & P16_OK_DGRAD_DY)) and (not need_w or (f16w and pm & P16_OK_WGRAD_DY))
+                      and not (need_b and ctx.has_bias and not cfg["training"]))
+            if dy_p16:
+                part = _scratch("bnpart", 3 * Cout * nblk, dev)
+                sums = _scratch("bnsums", 3 * Cout, dev)
+                _lib.check(lib.viai_bn_act_bwd_p16(dz.data_ptr(), y_or_z.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                                   coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
+                                                   _ptr(pg), _ptr(pb), dy.data_ptr(), M, Cout, act, 0.2,
+                                                   (1 if cfg["training"] else 0) | (2 if acc_bn else 0), amax.data_ptr(), st), "viai_bn_act_bwd_p16")
+            elif ctx.tail == "pool":
                 k_, s_, p_ = cfg["pool"]
                 dy = torch.empty_like(y_or_z)
                 _lib.check(lib.viai_bn_act_pool_bwd_amax(dz.data_ptr(), ctx.saved_tensors[5].data_ptr(), N, OH, OW, k_, s_, p_, y_or_z.data_ptr(),
@@ -675,7 +764,7 @@ class _ConvBnAct(torch.autograd.Function):
             _lib.check(lib.viai_act_bwd_from_output(dz.data_ptr(), y_or_z.data_ptr(), dy.data_ptr(), dz.numel(), act,
                                                     0.2, st), "viai_act_bwd_from_output")
         dx, dx2, dw, db = _conv_grads(lib, d, cfg, ctx.dims, ctx.has_bn, ctx.has_bias, (need_x, need_x2, need_w, need_b), ctx.xa,
-                                      x, x2, weight, dy, amax, st)
+                                      x, x2, weight, dy, amax, st, dy_p16=dy_p16, x_p16=ctx.x_p16)
         return dx, dx2, dw, db, dgamma, dbeta, None, None, None, dres, None
 
 
@@ -766,7 +855,8 @@ def _cin1_fused_applies(x, weight, bias, bn, kernel, stride, padding, transposed
 
 
 def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding=(0, 0), transposed=False,
-                act=ACT_NONE, x2=None, training=True, dilation=(1, 1), padding2=(-1, -1), xmask=None, residual=None, pool=None, upsample=None):
+                act=ACT_NONE, x2=None, training=True, dilation=(1, 1), padding2=(-1, -1), xmask=None, residual=None, pool=None, upsample=None,
+                out_p16=False):
     """Fused layer on NHWC tensors.  `bn` is an nn.BatchNorm2d (parameter/buffer holder) or None.
     `padding2` = (bottom, right) padding when it differs from `padding` (-1 = symmetric).
     `xmask` (N, W) or (N,1,1,W): the layer convolves x * xmask (the inpainting step's time mask).  The fused Cin = 1 layer multiplies
@@ -791,7 +881,8 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
            "act": int(act), "training": bool(training), "momentum": 0.1, "eps": BN_EPS,
            "d": tuple(dilation), "p2": tuple(padding2), "xa_in": (amax_of(x), amax_of(x2)), "xmask": xmask,
            "pool": tuple(int(v) for v in pool) if pool is not None else None,
-           "up": (int(upsample[0]), int(upsample[1])) if upsample is not None else None}
+           "up": (int(upsample[0]), int(upsample[1])) if upsample is not None else None,
+           "p16_out": bool(out_p16) and bn is not None and isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) and bn.weight is not None}
     if bn is not None:
         cfg["momentum"] = 0.1 if bn.momentum is None else float(bn.momentum)
         cfg["eps"] = float(bn.eps)
@@ -832,6 +923,8 @@ def _tag_amax(z, cfg):
     za = cfg.pop("za", None)
     if za is not None:
         z._viai_amax = za
+    if cfg.pop("z_p16", False):
+        z._viai_p16 = True
     return z
 
 
@@ -850,7 +943,8 @@ class _ConvBnActCout1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, w1, b1, gamma, beta, rmean, rvar, nbt, w2, b2, cfg):
         lib = _lib.load()
-        _require(x, x2, w1, b1, gamma, beta, w2, b2)
+        xp = is_p16(x)
+        _require(None if xp else x, x2, w1, b1, gamma, beta, w2, b2)
         x = _c(x)
         x2 = _c(x2) if x2 is not None else None
         N, IH, IW, C1 = x.shape
@@ -871,17 +965,27 @@ class _ConvBnActCout1(torch.autograd.Function):
         f16f = d.get("fwd_f16")
         if f16f is None:
             f16f = d["fwd_f16"] = bool(lib.viai_conv2d_fwd_f16_ok(d["ref"]))
-        xa = _input_amax(x, x2, cfg.get("xa_in", (None, None)), st) if (f16f and F16_DYNAMIC) else None
+        if xp and (x2 is not None or (p16_mask(d) & P16_OK_FWD_X) == 0):
+            x = p16_decode(x)
+            xp = False
+        if xp:
+            xa = amax_of(x)
+        else:
+            xa = _input_amax(x, x2, cfg.get("xa_in", (None, None)), st) if (f16f and F16_DYNAMIC) else None
         y = torch.empty((N, OH, OW, Cmid), device=dev, dtype=torch.float32)
         coef = torch.empty((4, Cmid), device=dev, dtype=torch.float32)       # mean, invstd, scale, shift
+
+        def conv_fwd(stat):
+            if xp:
+                _lib.check(lib.viai_conv2d_fwd_p16(d["ref"], x.data_ptr(), wp1.data_ptr(), _ptr(b1), y.data_ptr(), stat, ACT_NONE, xa.data_ptr(), st), "viai_conv2d_fwd_p16")
+            else:
+                _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp1.data_ptr(), _ptr(b1), y.data_ptr(), stat, ACT_NONE, _ptr(xa), st), "viai_conv2d_fwd")
         if cfg["training"]:
             stat = _scratch("stat", 2 * Cmid * d["nblk"], dev)
-            _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp1.data_ptr(), _ptr(b1), y.data_ptr(), stat.data_ptr(),
-                                                ACT_NONE, _ptr(xa), st), "viai_conv2d_fwd")
+            conv_fwd(stat.data_ptr())
             _bn_finalize(lib, d, stat, M, Cmid, gamma, beta, rmean, rvar, nbt, cfg, coef, st)
         else:
-            _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), _ptr(x2), wp1.data_ptr(), _ptr(b1), y.data_ptr(), 0, ACT_NONE,
-                                                _ptr(xa), st), "viai_conv2d_fwd")
+            conv_fwd(0)
             _lib.check(lib.viai_bn_eval_coeffs(Cmid, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), cfg["eps"],
                                                coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st),
                        "viai_bn_eval_coeffs")
@@ -911,6 +1015,7 @@ class _ConvBnActCout1(torch.autograd.Function):
             del z
         ctx.save_for_backward(x, x2, w1, y, coef, w2, p)
         ctx.d, ctx.d2, ctx.cfg, ctx.xa = d, d2, cfg, xa
+        ctx.x_p16 = xp
         ctx.has_bias, ctx.has_bias2 = b1 is not None, b2 is not None
         ctx.dims = (N, IH, IW, C1, C2, Cmid, OH, OW)
         return p
@@ -995,7 +1100,7 @@ class _ConvBnActCout1(torch.autograd.Function):
         dx = dx2 = dw1 = db1 = None
         if want_dy:
             dx, dx2, dw1, db1 = _conv_grads(lib, d, cfg, ctx.dims, True, ctx.has_bias, (need_x, need_x2, need_w1, need_b1), ctx.xa,
-                                            x, x2, w1, dy, amax, st)
+                                            x, x2, w1, dy, amax, st, x_p16=ctx.x_p16)
         return dx, dx2, dw1, db1, dgamma, dbeta, None, None, None, dw2, db2, None
 
 
