@@ -457,6 +457,17 @@ int viai_conv2d_p16_ok(const viai_conv2d* c);
 /* z (P16) = act(scale * y + shift); gamma / beta (NULL = 1 / 0) and m_stat give the bound; *z_amax receives it.  act: none / ReLU / LeakyReLU */
 int viai_bn_act_fwd_p16(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
                         float* z, long M, int C, int act, float slope, float* z_amax, void* stream);
+/* viai_bn_act_bilinear_fwd_amax with the resized tensor written as P16 */
+int viai_bn_act_bilinear_fwd_p16(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
+                                 float* out, int N, int IH, int IW, int OH, int OW, int C, int act, float slope, float* z_amax, void* stream);
+/* the apply pass of the fused Cin = 1 layer (viai_conv2d_cin1_bn_fwd with z != NULL) writing z as P16 */
+int viai_conv2d_cin1_bn_fwd_p16(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias,
+                                const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
+                                float* z, int act, float* z_amax, void* stream);
+/* viai_pair_cout1_bn_bwd with dy written as P16 (part: 3 * C * blocks floats, sums: 3 * C floats) */
+int viai_pair_cout1_bn_bwd_p16(const viai_conv2d* c, const float* du, const float* wp, const float* y, const float* mean,
+                               const float* invstd, const float* scale, const float* shift, int act_in, float* part, float* sums,
+                               float* dgamma, float* dbeta, float* dy, int training, float* dy_amax, void* stream);
 /* viai_bn_act_bwd_amax with dy written as P16; part: 3 * C * viai_bn_bwd_blocks(M, C) floats, sums: 3 * C floats; *amax receives the bound */
 int viai_bn_act_bwd_p16(const float* dz, const float* y, const float* mean, const float* invstd,
                         const float* scale, const float* shift, float* part, float* sums,

@@ -198,3 +198,79 @@ def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_inp
     o = torch.nn.functional.conv_transpose2d(xr, w.double().cpu(), None, 1, 1) if tr else torch.nn.functional.conv2d(xr, w.double().cpu(), None, S, 1)
     (o * dy.double().permute(0, 3, 1, 2).cpu()).sum().backward()
     assert ((g1.double().cpu().permute(0, 3, 1, 2) - xr.grad).norm() / xr.grad.norm()).item() < 2e-6
+
+
+def _close_to_split(d, ref, am, extra=0.0):
+    S = 2.0 ** (14 - (am.log2().floor().item() + 1))
+    err = (d - ref).abs()
+    tol = ref.abs() * 2.0 ** -20 + 2.0 ** -23 / S + extra
+    assert float(ref.abs().max()) <= float(am), (float(ref.abs().max()), float(am))
+    assert bool((err <= tol).all()), float((err - tol).max())
+
+
+def test_resize_producer_and_fused_cin1_producer_write_the_split_of_their_fp32_pass():
+    from viai_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    # BatchNorm apply + bilinear resize (the last layer of a decoder block, New_Inpainting_Networks.py:76-83)
+    N, IH, IW, OH, OW, Cc = 2, 16, 32, 32, 64, 64
+    y = torch.randn(N, IH, IW, Cc, device="cuda", generator=gen) * 2
+    gamma, beta, mean, invstd, scale, shift = _bn_coeffs(Cc, gen)
+    z, am0 = torch.empty(N, OH, OW, Cc, device="cuda"), torch.zeros(1, device="cuda")
+    _lib.check(lib.viai_bn_act_bilinear_fwd_amax(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), z.data_ptr(), N, IH, IW, OH, OW, Cc, 1, 0.2, am0.data_ptr(), _st()), "fwd")
+    zp, am = torch.empty_like(z), torch.zeros(1, device="cuda")
+    _lib.check(lib.viai_bn_act_bilinear_fwd_p16(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N * IH * IW, zp.data_ptr(),
+                                                N, IH, IW, OH, OW, Cc, 1, 0.2, am.data_ptr(), _st()), "fwd_p16")
+    _close_to_split(decode(zp, am), z, am)
+    # fused Cin = 1 conv + BatchNorm + LeakyReLU (D.conv1: 1 x 4 window, stride (1, 2); Discriminator_Networks.py:20-22)
+    N, H, W, Co = 2, 32, 64, 64
+    x = torch.rand(N, H, W, 1, device="cuda", generator=gen)
+    w = torch.randn(Co, 1, 1, 4, device="cuda", generator=gen)
+    d = ops.conv_desc(N, H, W, 1, 0, Co, 1, 4, 1, 2, 0, 1, 0)
+    assert lib.viai_conv2d_cin1_bn_ok(d["ref"])
+    wp = torch.empty(d["packed"], device="cuda")
+    _lib.check(lib.viai_conv2d_pack_fwd(d["ref"], w.data_ptr(), wp.data_ptr(), _st()), "pack")
+    gamma, beta, mean, invstd, scale, shift = _bn_coeffs(Co, gen)
+    M = N * d["OH"] * d["OW"]
+    z, am0 = torch.empty(N, d["OH"], d["OW"], Co, device="cuda"), torch.zeros(1, device="cuda")
+    _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), 0, wp.data_ptr(), 0, 0, scale.data_ptr(), shift.data_ptr(), z.data_ptr(), 2, am0.data_ptr(), _st()), "cin1")
+    zp, am = torch.empty_like(z), torch.zeros(1, device="cuda")
+    _lib.check(lib.viai_conv2d_cin1_bn_fwd_p16(d["ref"], x.data_ptr(), 0, wp.data_ptr(), 0, scale.data_ptr(), shift.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M,
+                                               zp.data_ptr(), 2, am.data_ptr(), _st()), "cin1_p16")
+    # the statistics here are not the batch's, so the Samuelson bound need not hold for these random coefficients: compare where it does
+    torch.cuda.synchronize()
+    if float(z.abs().max()) <= float(am):
+        _close_to_split(decode(zp, am), z, am)
+    else:
+        pytest.fail("bound below the data: the test's coefficients must stay inside it")
+
+
+@pytest.mark.parametrize("Cc,tr", [(32, True), (512, False)], ids=["g_conv6", "d_conv3"])
+def test_pair_backward_producer_matches_the_fp32_pass(Cc, tr):
+    """(conv + BatchNorm + act) -> (one-channel conv) pairs: dy of the front layer pre-split (viai_pair_cout1_bn_bwd_p16)"""
+    from viai_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    N, H, W = 2, 32, 32
+    d2 = ops.conv_desc(N, H, W, Cc, 0, 1, 3, 3, 1, 1, 1, 1, 1 if tr else 0)
+    assert lib.viai_pair_cout1_ok(d2["ref"])
+    w2 = torch.randn((Cc, 1, 3, 3) if tr else (1, Cc, 3, 3), device="cuda", generator=gen) * 0.1
+    wp2 = torch.empty(d2["packed"], device="cuda")
+    _lib.check(lib.viai_conv2d_pack_fwd(d2["ref"], w2.data_ptr(), wp2.data_ptr(), _st()), "pack")
+    y = torch.randn(N, H, W, Cc, device="cuda", generator=gen)
+    du = torch.randn(N, H, W, 1, device="cuda", generator=gen) * 1e-3
+    gamma, beta, mean, invstd, scale, shift = _bn_coeffs(Cc, gen)
+    nblk = int(lib.viai_pair_cout1_bn_bwd_blocks(d2["ref"]))
+    outs = []
+    for p16 in (False, True):
+        part = torch.empty(3 * Cc * nblk, device="cuda"); sums = torch.empty(3 * Cc, device="cuda")
+        dg, db = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+        dy, am = torch.empty_like(y), torch.zeros(1, device="cuda")
+        fn = lib.viai_pair_cout1_bn_bwd_p16 if p16 else lib.viai_pair_cout1_bn_bwd
+        _lib.check(fn(d2["ref"], du.data_ptr(), wp2.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), 2,
+                      part.data_ptr(), sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dy.data_ptr(), 1, am.data_ptr(), _st()), "pair_bn_bwd")
+        outs.append((dy, am, dg, db, sums[:2 * Cc].clone()))
+    (dy, am, dg, db, sums), (dyp, amp, dgp, dbp, sumsp) = outs
+    assert torch.equal(dg, dgp) and torch.equal(db, dbp) and torch.equal(sums, sumsp)
+    assert float(am) <= float(amp) <= float(am) * 16, (float(am), float(amp))
+    _close_to_split(decode(dyp, amp), dy, amp, extra=float(dy.abs().max()) * 2.0 ** -20)

@@ -477,28 +477,13 @@ int launch_bn_bwd_apply(const float* dz, const float* y, const float* mean, cons
 //   forward  |z| = |act(gamma xhat + beta)| <= |gamma| sqrt(M - 1) + |beta|   (training-mode statistics over M samples: Samuelson)
 //   backward |dy| <= sums[2C + c]  (bn_bwd_final_kernel, ps = 3)
 // every block reduces the per-channel bounds to the tensor's (max is exact: all blocks agree), block 0 stores it for the consumers.
-__device__ __forceinline__ float block_max_all(float v) {
-    __shared__ float viai_bmx[16];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    if ((threadIdx.x & 63) == 0) viai_bmx[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float m = viai_bmx[0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, viai_bmx[w]);
-    return m;
-}
-
 // z (P16) = act(scale y + shift); `rad` = sqrt(M - 1) of the statistics' population.  FIXED: C / 8 is a power of two <= 256, so a thread keeps
 // ONE octet for its whole grid-stride walk (coefficients loaded once, no division per item -- see bn_bwd_apply_kernel).
 template <bool FIXED>
 __global__ __launch_bounds__(256) void bn_act_fwd_p16_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float rad,
                                                              u32x4* __restrict__ z, long n8, int C, int act, float slope, float* __restrict__ amax) {
-    float b = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) b = fmaxf(b, fabsf(gamma ? gamma[c] : 1.f) * rad + fabsf(beta ? beta[c] : 0.f));
-    const float bound = block_max_all(b) * 1.001f;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *amax = bound;
-    const float S = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f16_scale_from_amax_value(bound)))), L = f16_clamp_for_scale(S);
+    const float S = p16_fwd_scale(gamma, beta, C, rad, amax), L = f16_clamp_for_scale(S);
     const unsigned c8n = (unsigned)(C / 8);
     const int lg = 31 - __builtin_clz(c8n);
     const long stride = (long)gridDim.x * 256;
@@ -741,8 +726,8 @@ extern "C" int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char
 
 // the final pass alone (conv_direct.hip: the fused Cin = 1 layer produces the partials itself)
 int viai_bn_bwd_final_launch(const float* part, int nblk, int C, long M, const float* mean, const float* invstd, const float* scale,
-                             int training, float* sums, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
-    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training, sums, dgamma, dbeta, accumulate, 2);
+                             int training, float* sums, float* dgamma, float* dbeta, int accumulate, hipStream_t st, int ps) {
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training, sums, dgamma, dbeta, accumulate, ps);
     return viai_launch_status();
 }
 

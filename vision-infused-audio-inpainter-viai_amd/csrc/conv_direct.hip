@@ -7,6 +7,7 @@
 //   networks/New_Inpainting_Networks.py:63.
 #include "viai_common.h"
 #include "viai_internal.h"
+#include "viai_bf3.h"
 
 namespace {
 
@@ -23,6 +24,10 @@ struct DirectArgs {
     const float* scale; const float* shift; const float* mean; const float* invstd; const float* sums; const float* dz;
     float* part;
     float* zmax;                      // fused layer, apply pass: max |z| (operand scale of the f16x2 kernels that consume z), or null
+    int dy_p16;                       // pair kernels: dy is written pre-split (P16): the reduce pass adds max |dpre| partials (part stride 3), the apply pass scales by the
+                                      // bound k_sums[2 C + c] (bn_bwd_final_kernel, ps = 3) and stores it in *amax
+    int z_p16;                        // apply pass: z is written pre-split (P16, viai_bf3.h) with the scale of the bound |gamma| p16_rad + |beta|, stored in *zmax
+    const float* gamma; const float* beta; float p16_rad;
     // fused (conv + BatchNorm + activation) -> (Cout = 1 conv) pair (viai_pair_cout1_*): the Cout = 1 layer reads the PRE-BatchNorm tensor
     // y of the layer in front of it and applies z = act_in(scale * y + shift) on load; its data gradient dz is never stored either, the
     // BatchNorm backward forms it from du (the gradient of the Cout = 1 layer's pre-activation output) with the nine taps in registers
@@ -126,7 +131,11 @@ __global__ __launch_bounds__(NT) void cin1_fwd_kernel(const DirectArgs a) {
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + cg * 4);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (MODE == 2) { sc = *reinterpret_cast<const f32x4*>(a.scale + cg * 4); sh = *reinterpret_cast<const f32x4*>(a.shift + cg * 4); }
+    float pS = 1.f, pL = 0.f;
+    if constexpr (MODE == 2) {
+        sc = *reinterpret_cast<const f32x4*>(a.scale + cg * 4); sh = *reinterpret_cast<const f32x4*>(a.shift + cg * 4);
+        if (a.z_p16) { pS = p16_fwd_scale(a.gamma, a.beta, a.Cout, a.p16_rad, a.zmax); pL = f16_clamp_for_scale(pS); }
+    }
     const int p0 = chunk * CIN1_PB;
     __shared__ float xp_all[NT / 256][CIN1_XP];
     float* xp = xp_all[sub];
@@ -175,7 +184,8 @@ __global__ __launch_bounds__(NT) void cin1_fwd_kernel(const DirectArgs a) {
                 f32x4 z;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { z[e] = viai_act(v[e] * sc[e] + sh[e], a.act, a.slope); zmx = fmaxf(zmx, fabsf(z[e])); }
-                *reinterpret_cast<f32x4*>(a.y + (size_t)p * a.Cout + cg * 4) = z;
+                if (a.z_p16) p16_store_quad(a.y + (size_t)p * a.Cout, cg, z, pS, pL);
+                else *reinterpret_cast<f32x4*>(a.y + (size_t)p * a.Cout + cg * 4) = z;
             } else {
                 if (a.stat == nullptr) {
 #pragma unroll
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(NT) void cin1_fwd_kernel(const DirectArgs a) {
         vals[it] = v;
     }
     if constexpr (MODE == 2) {
-        if (a.zmax != nullptr) block_absmax_to(a.zmax, zmx);
+        if (a.zmax != nullptr && !a.z_p16) block_absmax_to(a.zmax, zmx);
     } else {
     if (a.stat == nullptr) return;
     // block-local (mean, M2) per channel over the valid pixels of this block
@@ -1028,9 +1038,20 @@ __global__ __launch_bounds__(256) void cout1_bn_bwd_rows_kernel(const DirectArgs
     constexpr int KH = 3, KW = 3, WN_ = L + KW - 1;
     extern __shared__ __attribute__((aligned(16))) float tile[];     // du rows r0 - 1 .. r0 + R, columns -1 .. IW (zeros outside the image)
     __shared__ f32x4 r1[256], r2[256];
+    __shared__ f32x4 r3[APPLY ? 1 : 256];
     const int CG = a.Cin / 4;               // divides 256
     const int PG = 256 / CG;
     const int tid = threadIdx.x, cg = tid % CG, pg = tid / CG;
+    float pS = 1.f, pL = 0.f;
+    if constexpr (APPLY) {
+        if (a.dy_p16) {
+            float b = 0.f;
+            for (int c = tid; c < a.Cin; c += 256) b = fmaxf(b, a.k_sums[2 * a.Cin + c]);
+            const float bound = block_max_all(b);
+            if (blockIdx.x == 0 && tid == 0) *a.amax = bound;
+            pS = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f16_scale_from_amax_value(bound)))); pL = f16_clamp_for_scale(pS);
+        }
+    }
     const int bpi = a.IH / R;
     const int n = blockIdx.x / bpi, r0 = (blockIdx.x - n * bpi) * R;
     const int pitch = a.IW + 2;
@@ -1047,7 +1068,7 @@ __global__ __launch_bounds__(256) void cout1_bn_bwd_rows_kernel(const DirectArgs
     f32x4 is = {0.f, 0.f, 0.f, 0.f}, k0 = is, k1 = is;
     if constexpr (APPLY) { k0 = *reinterpret_cast<const f32x4*>(a.k_sums + cg * 4); k1 = *reinterpret_cast<const f32x4*>(a.k_sums + a.Cin + cg * 4); }
     else is = *reinterpret_cast<const f32x4*>(a.invstd + cg * 4);
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
     float mx = 0.f;
     __syncthreads();
     const int rpr = a.IW / L;
@@ -1086,22 +1107,32 @@ __global__ __launch_bounds__(256) void cout1_bn_bwd_rows_kernel(const DirectArgs
                     } else {
                         s1[e] += dp;
                         s2[e] += dp * (yv[u][e] - mu[e]) * is[e];
+                        s3[e] = fmaxf(s3[e], fabsf(dp));
                     }
                 }
-                if constexpr (APPLY) dst[(size_t)(p0 + u) * CG] = o;
+                if constexpr (APPLY) {
+                    if (a.dy_p16) p16_store_quad(reinterpret_cast<float*>(dst - cg) + (size_t)(p0 + u) * a.Cin, cg, o, pS, pL);
+                    else dst[(size_t)(p0 + u) * CG] = o;
+                }
             }
         }
     }
     if constexpr (APPLY) {
-        if (a.amax != nullptr) block_absmax_to(a.amax, mx);
+        if (a.amax != nullptr && !a.dy_p16) block_absmax_to(a.amax, mx);
     } else {
-        r1[tid] = s1; r2[tid] = s2;
+        r1[tid] = s1; r2[tid] = s2; r3[tid] = s3;
         __syncthreads();
         if (tid < CG) {
-            f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < PG; ++k) { t1 += r1[k * CG + tid]; t2 += r2[k * CG + tid]; }
-            *reinterpret_cast<f32x4*>(a.part + ((size_t)blockIdx.x * 2 + 0) * a.Cin + tid * 4) = t1;
-            *reinterpret_cast<f32x4*>(a.part + ((size_t)blockIdx.x * 2 + 1) * a.Cin + tid * 4) = t2;
+            const int ps = a.dy_p16 ? 3 : 2;
+            f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f}, t3 = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < PG; ++k) {
+                t1 += r1[k * CG + tid]; t2 += r2[k * CG + tid];
+                const f32x4 m = r3[k * CG + tid];
+                for (int e = 0; e < 4; ++e) t3[e] = fmaxf(t3[e], m[e]);
+            }
+            *reinterpret_cast<f32x4*>(a.part + ((size_t)blockIdx.x * ps + 0) * a.Cin + tid * 4) = t1;
+            *reinterpret_cast<f32x4*>(a.part + ((size_t)blockIdx.x * ps + 1) * a.Cin + tid * 4) = t2;
+            if (a.dy_p16) *reinterpret_cast<f32x4*>(a.part + ((size_t)blockIdx.x * 3 + 2) * a.Cin + tid * 4) = t3;
         }
     }
 }
@@ -1336,7 +1367,7 @@ int viai_cin1_wgrad(const viai_conv2d* c, const float* x, const float* dy, float
 
 // ---- fused Cin = 1 conv + BatchNorm(train) + activation layer (E.conv1, D.conv1): entry points of the public ABI ----------------
 int viai_bn_bwd_final_launch(const float* part, int nblk, int C, long M, const float* mean, const float* invstd, const float* scale,
-                             int training, float* sums, float* dgamma, float* dbeta, int accumulate, hipStream_t st);
+                             int training, float* sums, float* dgamma, float* dbeta, int accumulate, hipStream_t st, int ps = 2);
 
 extern "C" int viai_conv2d_cin1_bn_ok(const viai_conv2d* c) {
     if (c == nullptr || c->C1 + c->C2 != 1 || c->transposed) return 0;
@@ -1349,8 +1380,23 @@ extern "C" int viai_conv2d_cin1_bn_ok(const viai_conv2d* c) {
 }
 
 // z == NULL: BatchNorm partials only (the conv output is not stored);  z != NULL: z = act(scale * conv(x) + shift)
+static int cin1_bn_fwd_impl(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias, float* stat_part,
+                            const float* scale, const float* shift, float* z, int act, float* z_amax, void* stream,
+                            int p16, const float* gamma, const float* beta, long m_stat);
 extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias, float* stat_part,
                                        const float* scale, const float* shift, float* z, int act, float* z_amax, void* stream) {
+    return cin1_bn_fwd_impl(c, x, x_mask, w, bias, stat_part, scale, shift, z, act, z_amax, stream, 0, nullptr, nullptr, 0);
+}
+// (ABI 13) the apply pass writing z pre-split (P16); gamma / beta / m_stat give the bound stored in *z_amax.  Cout = 32 / 64 / 128
+extern "C" int viai_conv2d_cin1_bn_fwd_p16(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias,
+                                           const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
+                                           float* z, int act, float* z_amax, void* stream) {
+    if (z == nullptr || z_amax == nullptr || m_stat < 1 || act == VIAI_ACT_SIGMOID) return (int)hipErrorInvalidValue;
+    return cin1_bn_fwd_impl(c, x, x_mask, w, bias, nullptr, scale, shift, z, act, z_amax, stream, 1, gamma, beta, m_stat);
+}
+static int cin1_bn_fwd_impl(const viai_conv2d* c, const float* x, const float* x_mask, const float* w, const float* bias, float* stat_part,
+                            const float* scale, const float* shift, float* z, int act, float* z_amax, void* stream,
+                            int p16, const float* gamma, const float* beta, long m_stat) {
     if (!viai_conv2d_cin1_bn_ok(c) || (z == nullptr) == (stat_part == nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     viai_tag_reset();
@@ -1358,6 +1404,7 @@ extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, con
     DirectArgs a = make_args(c);
     a.x = x; a.w = w; a.bias = bias; a.y = z; a.stat = stat_part; a.scale = scale; a.shift = shift; a.act = act; a.slope = 0.2f;
     a.zmax = z_amax; a.xmask = x_mask;
+    a.z_p16 = p16; a.gamma = gamma; a.beta = beta; a.p16_rad = p16 ? sqrtf((float)(m_stat > 1 ? m_stat - 1 : 1)) : 0.f;
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
     cin1_rows_ok(a, CIN1_PB, c->kh, c->kw);
 #define CALL(KH, KW)                                                                                                               \
@@ -1365,7 +1412,7 @@ extern "C" int viai_conv2d_cin1_bn_fwd(const viai_conv2d* c, const float* x, con
         if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                       \
         else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                 \
         else VIAI_LAUNCH((cin1_fwd_kernel<32, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                                    \
-    } else if (z_amax != nullptr && a.nblk >= 512) {                                                                                                          \
+    } else if (z_amax != nullptr && a.nblk >= 512 && !p16) {                                                                                                       \
         if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);      \
         else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);\
         else VIAI_LAUNCH((cin1_fwd_kernel<32, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);                   \
@@ -1668,12 +1715,28 @@ extern "C" int viai_pair_cout1_wgrad(const viai_conv2d* c, const float* y, const
 // BatchNorm + activation backward of the front layer from du (N, H, W, 1) -- the gradient of the Cout = 1 layer's PRE-activation output:
 // part: 2 * C * viai_pair_cout1_bn_bwd_blocks(c) floats; sums / dgamma / dbeta / training / dy_amax as in viai_bn_act_bwd_amax;
 // dy (optional) = the gradient of the front layer's conv output.
+static int pair_bn_bwd_impl(const viai_conv2d* c, const float* du, const float* wp, const float* y, const float* mean,
+                            const float* invstd, const float* scale, const float* shift, int act_in, float* part, float* sums,
+                            float* dgamma, float* dbeta, float* dy, int training, float* dy_amax, void* stream, int p16);
 extern "C" int viai_pair_cout1_bn_bwd(const viai_conv2d* c, const float* du, const float* wp, const float* y, const float* mean,
                                       const float* invstd, const float* scale, const float* shift, int act_in, float* part, float* sums,
                                       float* dgamma, float* dbeta, float* dy, int training, float* dy_amax, void* stream) {
+    return pair_bn_bwd_impl(c, du, wp, y, mean, invstd, scale, shift, act_in, part, sums, dgamma, dbeta, dy, training, dy_amax, stream, 0);
+}
+// (ABI 13) the same with dy written pre-split (P16): part 3 * C * blocks floats, sums 3 * C floats, *dy_amax receives the bound; C % 32 == 0
+extern "C" int viai_pair_cout1_bn_bwd_p16(const viai_conv2d* c, const float* du, const float* wp, const float* y, const float* mean,
+                                          const float* invstd, const float* scale, const float* shift, int act_in, float* part, float* sums,
+                                          float* dgamma, float* dbeta, float* dy, int training, float* dy_amax, void* stream) {
+    if (c == nullptr || (c->C1 + c->C2) % 32 != 0 || dy == nullptr || dy_amax == nullptr || act_in == VIAI_ACT_SIGMOID) return (int)hipErrorInvalidValue;
+    return pair_bn_bwd_impl(c, du, wp, y, mean, invstd, scale, shift, act_in, part, sums, dgamma, dbeta, dy, training, dy_amax, stream, 1);
+}
+static int pair_bn_bwd_impl(const viai_conv2d* c, const float* du, const float* wp, const float* y, const float* mean,
+                            const float* invstd, const float* scale, const float* shift, int act_in, float* part, float* sums,
+                            float* dgamma, float* dbeta, float* dy, int training, float* dy_amax, void* stream, int p16) {
     if (!viai_pair_cout1_ok(c)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     DirectArgs a = make_args(c);
+    a.dy_p16 = p16;
     a.x = y; a.dy = du; a.w = wp; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.act_in = act_in; a.slope = 0.2f;
     a.part = part; a.k_sums = sums; a.dx = dy; a.amax = dy_amax;
     const int R = pair_rows(a);
@@ -1684,7 +1747,7 @@ extern "C" int viai_pair_cout1_bn_bwd(const viai_conv2d* c, const float* du, con
     else VIAI_LAUNCH((cout1_bn_bwd_rows_kernel<L, true, false>), dim3(nb), dim3(256), lds, st, a, R);
     int e = viai_launch_status();
     if (e) return e;
-    e = viai_bn_bwd_final_launch(part, nb, a.Cin, (long)a.N * a.IH * a.IW, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, st);
+    e = viai_bn_bwd_final_launch(part, nb, a.Cin, (long)a.N * a.IH * a.IW, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, st, p16 ? 3 : 2);
     if (e || dy == nullptr) return e;
     if (a.transposed) VIAI_LAUNCH((cout1_bn_bwd_rows_kernel<L, false, true>), dim3(nb), dim3(256), lds, st, a, R);
     else VIAI_LAUNCH((cout1_bn_bwd_rows_kernel<L, true, true>), dim3(nb), dim3(256), lds, st, a, R);

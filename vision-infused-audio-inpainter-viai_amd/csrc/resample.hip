@@ -4,6 +4,7 @@
 // Inpainting_Networks.py:65,77 (nn.AvgPool2d((3,1)), floor mode).
 #include "viai_common.h"
 #include "viai_internal.h"
+#include "viai_bf3.h"
 
 namespace {
 
@@ -140,10 +141,15 @@ __global__ __launch_bounds__(256) void bilinear_fwd_px_kernel(const float* __res
 // shared with its neighbours through L1); max |z| over the taps is max |z| of the whole map when the resize does not shrink it (every
 // input pixel is then some output pixel's tap), which is all the consumers' operand scale needs, and the resize never exceeds it.
 // One 1024-thread block per CU: the pass ends in the abs-max atomics (viai_common.h block_absmax_to).
-template <int ACT>
+// P16: the resized tensor is written pre-split (viai_bf3.h; C % 32 == 0) with the scale of the bound |gamma| rad + |beta| -- an interpolation never
+// exceeds its taps -- which block 0 stores in *amax (no abs-max reduction, no atomics)
+template <int ACT, bool P16 = false>
 __global__ __launch_bounds__(1024) void bn_act_bilinear_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    float* __restrict__ out, int N, int IH, int IW, int OH, int OW, int C, int c4sh,
-                                                                   float slope, float* __restrict__ amax) {
+                                                                   float slope, float* __restrict__ amax, const float* __restrict__ gamma = nullptr,
+                                                                   const float* __restrict__ beta = nullptr, float rad = 0.f) {
+    float pS = 1.f, pL = 0.f;
+    if constexpr (P16) { pS = p16_fwd_scale(gamma, beta, C, rad, amax); pL = f16_clamp_for_scale(pS); }
     const int c4n = 1 << c4sh, c4 = threadIdx.x & (c4n - 1), pl = threadIdx.x >> c4sh, ppb = 1024 >> c4sh;
     const int npix = N * OH * OW;
     const float sh_ = ac_scale(IH, OH), sw_ = ac_scale(IW, OW);
@@ -170,9 +176,10 @@ __global__ __launch_bounds__(1024) void bn_act_bilinear_fwd_kernel(const float* 
         const f32x4 r11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * IW + x1) * C);
         const f32x4 v00 = z(r00), v01 = z(r01), v10 = z(r10), v11 = z(r11);
         const f32x4 o = ac_lerp(v00, v01, v10, v11, lx0, lx1, ly0, ly1);       // the expression of bilinear_fwd_kernel
-        *reinterpret_cast<f32x4*>(out + ((size_t)p * c4n + c4) * 4) = o;
+        if constexpr (P16) p16_store_quad(out + (size_t)p * c4n * 4, c4, o, pS, pL);
+        else *reinterpret_cast<f32x4*>(out + ((size_t)p * c4n + c4) * 4) = o;
     }
-    if (amax != nullptr) block_absmax_to(amax, mx);
+    if constexpr (!P16) { if (amax != nullptr) block_absmax_to(amax, mx); }
 }
 
 // weight with which output index o reads input index i along one axis (0 and false when it does not)
@@ -473,9 +480,30 @@ extern "C" int viai_bn_act_bilinear_fwd_amax(const float* y, const float* scale,
     const dim3 g((unsigned)blocks), b(1024);
     hipStream_t st = (hipStream_t)stream;
     switch (act) {
-    case VIAI_ACT_RELU: VIAI_LAUNCH(bn_act_bilinear_fwd_kernel<VIAI_ACT_RELU>, g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax); break;
-    case VIAI_ACT_LRELU: VIAI_LAUNCH(bn_act_bilinear_fwd_kernel<VIAI_ACT_LRELU>, g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax); break;
-    case VIAI_ACT_NONE: VIAI_LAUNCH(bn_act_bilinear_fwd_kernel<VIAI_ACT_NONE>, g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax); break;
+    case VIAI_ACT_RELU: VIAI_LAUNCH(bn_act_bilinear_fwd_kernel<VIAI_ACT_RELU>, g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax, (const float*)nullptr, (const float*)nullptr, 0.f); break;
+    case VIAI_ACT_LRELU: VIAI_LAUNCH(bn_act_bilinear_fwd_kernel<VIAI_ACT_LRELU>, g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax, (const float*)nullptr, (const float*)nullptr, 0.f); break;
+    case VIAI_ACT_NONE: VIAI_LAUNCH(bn_act_bilinear_fwd_kernel<VIAI_ACT_NONE>, g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax, (const float*)nullptr, (const float*)nullptr, 0.f); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    return viai_launch_status();
+}
+
+// (ABI 13) the same pass writing the resized tensor pre-split (P16); gamma / beta / m_stat give the bound stored in *z_amax.  C % 32 == 0
+extern "C" int viai_bn_act_bilinear_fwd_p16(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
+                                            float* out, int N, int IH, int IW, int OH, int OW, int C, int act, float slope, float* z_amax, void* stream) {
+    if (C % 32 != 0 || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || z_amax == nullptr || m_stat < 1) return (int)hipErrorInvalidValue;
+    const int c4sh = px_shift(C, (long)N * OH * OW);
+    if (c4sh < 0) return (int)hipErrorInvalidValue;
+    const long ppb = 1024 >> c4sh;
+    long blocks = ((long)N * OH * OW + ppb - 1) / ppb;
+    if (blocks > 512) blocks = 512;
+    const dim3 g((unsigned)blocks), b(1024);
+    hipStream_t st = (hipStream_t)stream;
+    const float rad = sqrtf((float)(m_stat > 1 ? m_stat - 1 : 1));
+    switch (act) {
+    case VIAI_ACT_RELU: VIAI_LAUNCH((bn_act_bilinear_fwd_kernel<VIAI_ACT_RELU, true>), g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax, gamma, beta, rad); break;
+    case VIAI_ACT_LRELU: VIAI_LAUNCH((bn_act_bilinear_fwd_kernel<VIAI_ACT_LRELU, true>), g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax, gamma, beta, rad); break;
+    case VIAI_ACT_NONE: VIAI_LAUNCH((bn_act_bilinear_fwd_kernel<VIAI_ACT_NONE, true>), g, b, 0, st, y, scale, shift, out, N, IH, IW, OH, OW, C, c4sh, slope, z_amax, gamma, beta, rad); break;
     default: return (int)hipErrorInvalidValue;
     }
     return viai_launch_status();

@@ -103,3 +103,35 @@ __device__ __forceinline__ void stage_put32(unsigned char* row, int plane, int q
         *reinterpret_cast<u32x2*>(row + plane + q * 8) = p2;
     }
 }
+
+// max of v over the block, returned to every thread (blocks of 64 .. 1024 threads; every thread must call it)
+__device__ __forceinline__ float block_max_all(float v) {
+    __shared__ float viai_bmx[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) viai_bmx[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = viai_bmx[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, viai_bmx[w]);
+    return m;
+}
+
+// the tensor-wide bound |gamma| rad + |beta| over C channels (forward P16 producers; rad = sqrt(M - 1) of the statistics' population), identical in
+// every block; block 0 publishes it in *amax.  Returns the scale.
+__device__ __forceinline__ float p16_fwd_scale(const float* __restrict__ gamma, const float* __restrict__ beta, int C, float rad, float* __restrict__ amax) {
+    float b = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) b = fmaxf(b, fabsf(gamma ? gamma[c] : 1.f) * rad + fabsf(beta ? beta[c] : 0.f));
+    const float bound = block_max_all(b) * 1.001f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *amax = bound;
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f16_scale_from_amax_value(bound))));
+}
+// one channel quad (channels 4 q4 .. 4 q4 + 3 of the pixel at `pix`, a float pointer to the pixel's first channel) into the P16 planes: two 8-byte stores
+__device__ __forceinline__ void p16_store_quad(float* pix, int q4, const f32x4& v, float S, float L) {
+    unsigned h0, l0, h1, l1;
+    split2_pair(v[0], v[1], S, L, h0, l0);
+    split2_pair(v[2], v[3], S, L, h1, l1);
+    unsigned char* d = reinterpret_cast<unsigned char*>(pix) + (q4 >> 3) * 128 + (q4 & 7) * 8;
+    const u32x2 hi = {h0, h1}, lo = {l0, l1};
+    *reinterpret_cast<u32x2*>(d) = hi;
+    *reinterpret_cast<u32x2*>(d + 64) = lo;
+}

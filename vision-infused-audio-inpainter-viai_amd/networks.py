@@ -129,8 +129,10 @@ def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=N
     if upsample is not None:
         up = (int(upsample[0]), int(upsample[1]))
         if residual is None and pool is None and xmask is None and ops.upsample_fusable(x, conv.weight, conv.bias, bn, transposed, act, up):
+            p16 = (next_conv is not None and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training
+                   and takes_p16((x.shape[0], up[0], up[1], conv.out_channels), next_conv))
             return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
-                                   padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2, training=bn.training, upsample=up)
+                                   padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2, training=bn.training, upsample=up, out_p16=p16)
         return ops.bilinear_ac(fused_layer(x, conv, bn, act, x2=x2, training=training, xmask=xmask, residual=residual, pool=pool), up)
     if isinstance(bn, nn.InstanceNorm2d):
         if xmask is not None:
@@ -197,12 +199,13 @@ class TransConvBlock(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    def forward_nhwc(self, x, x2=None, upsample=None):
-        """`upsample` = (H, W): the F.interpolate the decoder applies to the block's output (New_Inpainting_Networks.py:78,83)"""
+    def forward_nhwc(self, x, x2=None, upsample=None, next_conv=None):
+        """`upsample` = (H, W): the F.interpolate the decoder applies to the block's output (New_Inpainting_Networks.py:78,83);
+        `next_conv`: the layer that alone consumes the (resized) output, if the caller knows it (fused_layer)"""
         for i in range(self.nums):
             conv = self._modules["conv%s_%d" % (self.name, i)]
             bn = self._modules["conv%s_%d_bn" % (self.name, i)]
-            nxt = self._modules["conv%s_%d" % (self.name, i + 1)] if i + 1 < self.nums else None
+            nxt = self._modules["conv%s_%d" % (self.name, i + 1)] if i + 1 < self.nums else next_conv
             x = fused_layer(x, conv, bn, ACT_RELU, x2=x2 if i == 0 else None, upsample=upsample if i == self.nums - 1 else None, next_conv=nxt)
         return x
 
@@ -281,8 +284,10 @@ class MelDecoder(nn.Module):
         self.skip_at = 3            # i == 3: concat with net[-4]
 
     def _head(self, net, upsample=None):
-        out = fused_layer(net[-1], self.deconv1_1, self.deconv1_1_bn, ACT_RELU)
-        return fused_layer(out, self.deconv1_2, self.deconv1_2_bn, ACT_RELU, upsample=upsample)
+        out = fused_layer(net[-1], self.deconv1_1, self.deconv1_1_bn, ACT_RELU, next_conv=self.deconv1_2)
+        nb = self._modules["convblock2"]
+        return fused_layer(out, self.deconv1_2, self.deconv1_2_bn, ACT_RELU, upsample=upsample,
+                           next_conv=None if self.skip_at == 1 else nb._modules["conv%s_0" % nb.name])
 
     def forward_nhwc(self, net, out_hw, head=None):
         # every F.interpolate of the reference's loop (New_Inpainting_Networks.py:76-83) follows the last layer of the block in front of it:
@@ -291,7 +296,13 @@ class MelDecoder(nn.Module):
         out = self._head(net, upsample=sizes[0]) if head is None else ops.bilinear_ac(head, sizes[0])
         for i in range(1, len(net)):
             skip = net[-(i + 1)] if i == self.skip_at else None     # virtual concat: two source pointers
-            out = self._modules["convblock%d" % (i + 1)].forward_nhwc(out, skip, upsample=sizes[i])
+            # the block's resized output feeds the first layer of the next block (pre-split where that layer stages pieces and has no second source)
+            if i + 1 < len(net):
+                nb = self._modules["convblock%d" % (i + 2)]
+                nxt = None if i + 1 == self.skip_at else nb._modules["conv%s_0" % nb.name]
+            else:
+                nxt = self.conv6_1
+            out = self._modules["convblock%d" % (i + 1)].forward_nhwc(out, skip, upsample=sizes[i], next_conv=nxt)
         return fused_pair(out, self.conv6_1, self.conv6_1_bn, ACT_RELU, self.conv6_2, ACT_SIGMOID)
 
     def forward(self, net, x_size):
@@ -387,7 +398,7 @@ class MelDiscriminator(nn.Module):
         self.conv4 = nn.Conv2d(ndf * nf_mult, 1, kernel_size=3, stride=1, padding=1, bias=use_bias)
 
     def forward_nhwc(self, x):
-        net = fused_layer(x, self.conv1, self.bn1, ACT_LRELU)
+        net = fused_layer(x, self.conv1, self.bn1, ACT_LRELU, next_conv=self._modules["conv2_1"] if self.n_layers > 1 else self.conv3)
         for n in range(1, self.n_layers):
             nxt = self._modules["conv2_%d" % (n + 1)] if n + 1 < self.n_layers else self.conv3
             net = fused_layer(net, self._modules["conv2_%d" % n], self._modules["norm_%d" % n], ACT_LRELU, next_conv=nxt)

@@ -54,7 +54,7 @@ def is_p16(t):
 def p16_mask(d):
     m = d.get("p16")
     if m is None:
-        m = d["p16"] = int(_lib.load().viai_conv2d_p16_ok(d["ref"])) if P16 else 0
+        m = d["p16"] = int(_lib.load().viai_conv2d_p16_ok(d["ref"]))
     return m
 
 
@@ -605,8 +605,13 @@ class _ConvBnAct(torch.autograd.Function):
             _bn_finalize(lib, d, stat, M, Cout, gamma, beta, rmean, rvar, nbt, cfg, coef, st)
             z = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
             za = _amax_slot(dev)
-            _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, 0, coef[2].data_ptr(), coef[3].data_ptr(),
-                                                   z.data_ptr(), act, za.data_ptr(), st), "viai_conv2d_cin1_bn_fwd")
+            if cfg.get("p16_out") and P16 and act in (ACT_NONE, ACT_RELU, ACT_LRELU):
+                _lib.check(lib.viai_conv2d_cin1_bn_fwd_p16(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, coef[2].data_ptr(), coef[3].data_ptr(),
+                                                           gamma.data_ptr(), beta.data_ptr(), M, z.data_ptr(), act, za.data_ptr(), st), "viai_conv2d_cin1_bn_fwd_p16")
+                cfg["z_p16"] = True
+            else:
+                _lib.check(lib.viai_conv2d_cin1_bn_fwd(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, 0, coef[2].data_ptr(), coef[3].data_ptr(),
+                                                       z.data_ptr(), act, za.data_ptr(), st), "viai_conv2d_cin1_bn_fwd")
             ctx.save_for_backward(x, None, weight, None, coef)
         elif has_bn:
             y = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
@@ -644,8 +649,13 @@ class _ConvBnAct(torch.autograd.Function):
                 # (the backward gathers its gradient with the resize's backward and goes on from y)
                 UH, UW = cfg["up"]
                 z = torch.empty((N, UH, UW, Cout), device=dev, dtype=torch.float32)
-                _lib.check(lib.viai_bn_act_bilinear_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(), N, OH, OW, UH, UW,
-                                                             Cout, act, 0.2, za.data_ptr(), st), "viai_bn_act_bilinear_fwd")
+                if cfg.get("p16_out") and P16 and training and Cout % 32 == 0:
+                    _lib.check(lib.viai_bn_act_bilinear_fwd_p16(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), gamma.data_ptr(), beta.data_ptr(), M,
+                                                                z.data_ptr(), N, OH, OW, UH, UW, Cout, act, 0.2, za.data_ptr(), st), "viai_bn_act_bilinear_fwd_p16")
+                    cfg["z_p16"] = True
+                else:
+                    _lib.check(lib.viai_bn_act_bilinear_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(), N, OH, OW, UH, UW,
+                                                                 Cout, act, 0.2, za.data_ptr(), st), "viai_bn_act_bilinear_fwd")
                 ctx.save_for_backward(x, x2, weight, y, coef)
             elif cfg.get("p16_out") and P16 and training and Cout % 32 == 0 and act in (ACT_NONE, ACT_RELU, ACT_LRELU):
                 # the consumer stages pre-split pieces (networks.py asked conv_takes_p16): z is written as the two fp16 planes, scale from the bound
@@ -1094,13 +1104,22 @@ class _ConvBnActCout1(torch.autograd.Function):
         amax = _amax_slot(dev) if (F16_BACKWARD and ((f16d and (need_x or need_x2)) or (f16w and need_w1))) else None
         want_dy = need_x or need_x2 or need_w1 or (need_b1 and ctx.has_bias)
         dy = torch.empty_like(y) if want_dy else None
-        _lib.check(lib.viai_pair_cout1_bn_bwd(d2["ref"], du.data_ptr(), wp2.data_ptr(), y.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
-                                              coef[2].data_ptr(), coef[3].data_ptr(), cfg["act"], part.data_ptr(), sums.data_ptr(), _ptr(pg), _ptr(pb),
-                                              _ptr(dy), (1 if cfg["training"] else 0) | (2 if acc_bn else 0), _ptr(amax), st), "viai_pair_cout1_bn_bwd")
+        pm = p16_mask(d)
+        nx = need_x or need_x2
+        dy_p16 = (P16 and want_dy and amax is not None and Cmid % 32 == 0 and cfg["act"] != ACT_SIGMOID and (nx or need_w1)
+                  and (not nx or (f16d and pm & P16_OK_DGRAD_DY)) and (not need_w1 or (f16w and pm & P16_OK_WGRAD_DY))
+                  and not (need_b1 and ctx.has_bias and not cfg["training"]))
+        if dy_p16:
+            part = _scratch("bnpart", 3 * Cmid * nblk, dev)
+            sums = _scratch("bnsums", 3 * Cmid, dev)
+        fn = lib.viai_pair_cout1_bn_bwd_p16 if dy_p16 else lib.viai_pair_cout1_bn_bwd
+        _lib.check(fn(d2["ref"], du.data_ptr(), wp2.data_ptr(), y.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                      coef[2].data_ptr(), coef[3].data_ptr(), cfg["act"], part.data_ptr(), sums.data_ptr(), _ptr(pg), _ptr(pb),
+                      _ptr(dy), (1 if cfg["training"] else 0) | (2 if acc_bn else 0), _ptr(amax), st), "viai_pair_cout1_bn_bwd")
         dx = dx2 = dw1 = db1 = None
         if want_dy:
             dx, dx2, dw1, db1 = _conv_grads(lib, d, cfg, ctx.dims, True, ctx.has_bias, (need_x, need_x2, need_w1, need_b1), ctx.xa,
-                                            x, x2, w1, dy, amax, st, x_p16=ctx.x_p16)
+                                            x, x2, w1, dy, amax, st, dy_p16=dy_p16, x_p16=ctx.x_p16)
         return dx, dx2, dw1, db1, dgamma, dbeta, None, None, None, dw2, db2, None
 
 
