@@ -427,7 +427,11 @@ static int block_ksplit(const ConvGeom& g, int Cout, int Cin, int cfg) {
     const long per = (long)(Cout / bm_of(cfg)) * (Cin / bn_of(cfg));
     static long blk4 = -1;
     if (blk4 < 0) { const char* e = getenv("VIAI_WGRAD_PATCH_BLOCKS_64"); blk4 = e ? atol(e) : 192; }
-    constexpr long blk1 = 192, blk2 = 192, blk3 = 128;       // stride-1 / stride-2 / narrow instance (measured optimum of the three-stream step, see below)
+    static long blk1 = -1, blk2 = -1, blk3 = -1;             // stride-1 / stride-2 / narrow instance (measured optimum of the three-stream step, see below)
+    if (blk1 < 0) {
+        const char* e1 = getenv("VIAI_WGRAD_PATCH_BLOCKS"); const char* e2 = getenv("VIAI_WGRAD_PATCH_BLOCKS_S2"); const char* e3 = getenv("VIAI_WGRAD_PATCH_BLOCKS_NARROW");
+        blk2 = e2 ? atol(e2) : 192; blk3 = e3 ? atol(e3) : 128; blk1 = e1 ? atol(e1) : 192;
+    }
     long ks = (cfg == 2 ? blk2 : cfg == 3 ? blk3 : cfg == 4 ? blk4 : blk1) / per;
     // the sub-CU grids above suit the audio step, whose weight gradients are short and share the chip with the main chain; a layer with
     // hundreds of tiles per block (the ResNet branch on 1024 frames) is worth every CU

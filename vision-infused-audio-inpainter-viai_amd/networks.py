@@ -511,7 +511,7 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward_nhwc(self, x):
-        out = fused_layer(x, self.conv1, self.bn1, ACT_RELU)
+        out = fused_layer(x, self.conv1, self.bn1, ACT_RELU, next_conv=self.conv2)
         res = x if self.downsample is None else fused_layer(x, self.downsample[0], self.downsample[1], ACT_NONE)
         return fused_layer(out, self.conv2, self.bn2, ACT_RELU, residual=res)        # relu(bn2(conv2(out)) + res), networks/ResNet.py:46-53
 

@@ -745,7 +745,7 @@ class _ConvBnAct(torch.autograd.Function):
             # dy pre-split (P16) when every kernel that reads it stages pieces: this layer's data gradient (if needed) and weight gradient
             # (if needed); a bias gradient (column sums of dy) needs the fp32 tensor
             pm = p16_mask(d)
-            dy_p16 = (P16 and amax is not None and Cout % 32 == 0 and act != ACT_SIGMOID and ctx.tail in (None, "up")
+            dy_p16 = (P16 and amax is not None and Cout % 32 == 0 and act != ACT_SIGMOID and ctx.tail in (None, "up", "res")
                       and (need_x or need_w) and (not need_x or (f16d and pm & P16_OK_DGRAD_DY)) and (not need_w or (f16w and pm & P16_OK_WGRAD_DY))
                       and not (need_b and ctx.has_bias and not cfg["training"]))
             if dy_p16:
