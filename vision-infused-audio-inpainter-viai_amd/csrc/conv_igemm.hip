@@ -151,6 +151,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int arow = (wm * TM * 32 + (lane & 31)) * LS + 4 * (lane >> 5);
     const int brow_l = (wn * TN * 32 + (lane & 31)) * LS + 4 * (lane >> 5);
 
+    // Blocked summation: a chunk (BK = 32 products per output) accumulates from zero and joins the running total once.  One fmaf chain over the whole
+    // K (2304 .. 4608 terms in the wide layers) rounds K times in sequence and was LESS accurate than the f16x2 kernels it is the reference point for
+    // (whose MFMAs add 16 exact products per rounding): sums with heavy cancellation behind it -- the BatchNorm bias gradients of the
+    // discriminator -- came out 3e-3 off fp64 where CPU fp32 (blocked GEMM) is at 6e-6 (tools/grad_table.py under VIAI_MATH=fp32).
+    f32x16 tot[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) tot[i][j] = acc[i][j];
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
         const bool more = (kc + 1 < nchunks);
@@ -176,9 +185,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                tot[i][j] += acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            }
         if (more) lstore(cur ^ 1);
         __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j];
 
     // ---------------------------------------------------------------- epilogue
     const int half = lane >> 5, col = lane & 31;
