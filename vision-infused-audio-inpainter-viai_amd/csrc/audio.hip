@@ -13,6 +13,7 @@
 // HBM traffic is the waveform in and the mel out: bandwidth-bound by design.
 #include "viai_common.h"
 #include "viai_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -179,6 +180,214 @@ __global__ __launch_bounds__(256) void stft_mel_banded_kernel(const float* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Wave-per-FFT kernel (round 4; fft = 1024).  The frame-batched kernel above moves every FFT through LDS five times (radix-4 passes, 41 KB of LDS
+// traffic per frame) and walks the mel bands with one dependent global load per bin: 1024 clips in 1.25 ms = 0.43 TB/s of its 0.54 GB.  Here
+//  * a WAVE owns one 1024-point complex FFT = two real frames (z = a + i b), 16 points per lane, as 1024 = 16 x 16 x 4:
+//      radix-16 in registers over n1 (x[n2 + 64 n1], lane = n2: the loads are coalesced and need no staging) -> twiddle W1024^(k1 n2) ->
+//      ONE transpose through LDS ([k1][n2], rows padded to 136 dwords: conflict-free both ways) ->
+//      radix-16 in registers over b (lane = (k1, a), element a + 4 b) -> twiddle W64^(a kb) ->
+//      radix-4 over a ACROSS the four lanes of a quad with DPP quad_perm moves (no LDS);
+//    output X[k1 + 16 (kb + 16 ka)] in lane (k1, q), register kb, ka = bit-reversed q;
+//  * the two real spectra need X[k] and X[N - k]: the wave parks X in LDS once and the lanes holding k < 512 fetch their partners;
+//    magnitudes go to a [bin][8 frames] table shared by the block's four waves (8 frames per block, as before: 32-byte output runs);
+//  * the mel weights (banded: ~1000 non-zeros for Slaney triangles) are copied to LDS once per PERSISTENT block, a thread owns a band for the
+//    eight frames and reads each bin's eight magnitudes with two 16-byte LDS loads;
+//  * twiddles and the window live in registers for the block's lifetime (sincospif once per thread, not per frame group).
+// LDS per frame: one transpose (8 KB out + 8 KB in per two frames) + the partner exchange + magnitudes + mel reads ~ 22 KB (was 41).
+constexpr int SW_EROW = 68;                    // float2 per row of the transpose buffer (64 + 4 pad = 136 dwords)
+constexpr int SW_WREG = 16 * SW_EROW;          // float2 per wave region (8704 bytes; the partner table, 1024 + 16 float2, fits in it)
+constexpr int SW_MROW = 8;                     // floats per bin of the magnitude table (8 frames)
+constexpr int SW_WCAP = 2048;                  // mel weights held in LDS (floats); a denser basis is read from global memory
+
+typedef float c32 __attribute__((ext_vector_type(2)));            // (re, im) as a register PAIR: the arithmetic below compiles to v_pk_* without shuffling moves
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return a + b; }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return a - b; }
+__device__ __forceinline__ c32 cmulc(c32 a, c32 w) { return a.xx * w + a.yy * c32{-w.y, w.x}; }
+// forward 4-point DFT (W4 = -i), in place
+__device__ __forceinline__ void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
+    const c32 s0 = a0 + a2, d0 = a0 - a2, s1 = a1 + a3, d1 = a1 - a3;
+    const c32 r = {d1.y, -d1.x};                // -i d1
+    a0 = s0 + s1; a2 = s0 - s1;
+    a1 = d0 + r;
+    a3 = d0 - r;
+}
+// forward 16-point DFT of v[0..15], in place: X[m + 4 q] = sum_j W4^(j q) W16^(j m) sum_p v[j + 4 p] W4^(p m)
+__device__ __forceinline__ void dft16(c32 (&v)[16]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dft4(v[j], v[j + 4], v[j + 8], v[j + 12]);           // v[j + 4 m] = T[j][m]
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+    // W16^(j m), j, m = 1 .. 3
+    v[1 + 4] = cmulc(v[1 + 4], c32{C1, -S1}); v[1 + 8] = cmulc(v[1 + 8], c32{H, -H}); v[1 + 12] = cmulc(v[1 + 12], c32{S1, -C1});
+    v[2 + 4] = cmulc(v[2 + 4], c32{H, -H});   v[2 + 8] = c32{v[2 + 8].y, -v[2 + 8].x}; v[2 + 12] = cmulc(v[2 + 12], c32{-H, -H});
+    v[3 + 4] = cmulc(v[3 + 4], c32{S1, -C1}); v[3 + 8] = cmulc(v[3 + 8], c32{-H, -H}); v[3 + 12] = cmulc(v[3 + 12], c32{-C1, S1});
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dft4(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]);   // over j: v[4 m + q] = X[m + 4 q]
+    // reorder to natural order k = m + 4 q
+    c32 t[16];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[m + 4 * q] = v[4 * m + q];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = t[k];
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false)); }
+
+// Block = 8 waves = 16 frames per iteration; two iterations fill a [band][32 frames] output tile in LDS that is then written as 128-byte
+// runs: with frame the fastest output index, a thread storing its band's 8 frames (32 bytes at a stride of `frames` floats, unaligned for odd
+// frame counts) made every store instruction touch 64 different lines -- THAT, not the FFTs, held both earlier kernels at 0.4 TB/s.
+constexpr int SW_NW = 8, SW_FPI = 2 * SW_NW, SW_MP = SW_FPI + 4, SW_TF = 32, SW_OT = SW_TF + 1, SW_OMEL = 256;     // SW_MP: floats per bin of the magnitude table (padded: 2-way instead of 8-way store conflicts)
+__global__ __launch_bounds__(64 * SW_NW) __attribute__((amdgpu_waves_per_eu(2))) void stft_mel_wave_kernel(const float* __restrict__ wav, const float* __restrict__ window,
+                                                            const float* __restrict__ basis_t, const int* __restrict__ band_lo,
+                                                            const int* __restrict__ band_cnt, const float* __restrict__ mask,
+                                                            float* __restrict__ mel, int n_clips, int n_samples, int hop, int n_mels,
+                                                            int frames, float min_db, float ref_db) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    constexpr int NT = 64 * SW_NW;
+    c32* ebuf = reinterpret_cast<c32*>(smem_w);                                  // [8 waves][SW_WREG]
+    float* mag = reinterpret_cast<float*>(ebuf + SW_NW * SW_WREG);                 // [513][16]
+    float* wts = mag + 516 * SW_MP;                                                // [SW_WCAP] band weights, band after band
+    int* boff = reinterpret_cast<int*>(wts + SW_WCAP);                             // [n_mels + 1] (n_mels <= 1024), boff[n_mels] = total
+    c32* t64 = reinterpret_cast<c32*>(boff + 1032);                                // [64] W64^n
+    float* otile = reinterpret_cast<float*>(t64 + 64);                             // [min(n_mels, 256)][33]: 32 frames of every band (n_mels <= 256)
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform: the buffer descriptors below must be scalar, or every load becomes a waterfall loop)
+    const bool tiled = n_mels <= SW_OMEL;
+    // ---- once per block: band weights into LDS (if they fit)
+    if (tid == 0) {
+        int o = 0;
+        for (int m = 0; m < n_mels; ++m) { boff[m] = o; o += band_cnt[m]; }
+        boff[n_mels] = o;
+    }
+    __syncthreads();
+    const bool wl = boff[n_mels] <= SW_WCAP;
+    if (wl)
+        for (int m = tid; m < n_mels; m += NT) {
+            const int lo = band_lo[m], cnt = band_cnt[m], o = boff[m];
+            for (int i = 0; i < cnt; ++i) wts[o + i] = basis_t[(size_t)(lo + i) * n_mels + m];
+        }
+    // ---- once per thread: window samples and twiddles of its lane
+    const int n2 = lane, k1r = lane >> 2, qa = lane & 3;
+    float win[16];
+    c32 tw1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        win[i] = window[n2 + 64 * i];
+        float sn, cs;
+        sincospif(-(float)(i * n2) * (1.0f / 512.0f), &sn, &cs); tw1[i] = c32{cs, sn};       // W1024^(k1 n2), k1 = i
+    }
+    if (tid < 64) { float sn, cs; sincospif(-(float)tid * (1.0f / 32.0f), &sn, &cs); t64[tid] = c32{cs, sn}; }      // W64^(a kb) is looked up (a kb < 48)
+    const int ka = ((qa & 1) << 1) | (qa >> 1);                                            // output index of the quad's radix-4 held by this lane
+    const float sg1 = (qa & 2) ? -1.f : 1.f, sg2 = (qa & 1) ? -1.f : 1.f;
+    const float rc = qa == 3 ? 0.f : 1.f, rd = qa == 3 ? 1.f : 0.f;                        // lane 3 multiplies by -i between the two steps
+    const float min_level = exp10f(min_db / 20.f), inv_mdb = -1.f / min_db;
+    c32* E = ebuf + w * SW_WREG;
+    const int gpc = (frames + SW_TF - 1) / SW_TF, total = n_clips * gpc;                   // super-groups of 32 frames
+    const int per = (total + gridDim.x - 1) / gridDim.x;
+    const int g_end = min(total, (int)(blockIdx.x + 1) * per);
+    __syncthreads();
+    for (int gi = blockIdx.x * per; gi < g_end; ++gi) {
+        const int clip = gi / gpc, F0 = (gi - clip * gpc) * SW_TF;
+        const float* y = wav + (size_t)clip * n_samples;
+        for (int sub = 0; sub < SW_TF / SW_FPI; ++sub) {
+            const int f0 = F0 + sub * SW_FPI;
+            if (f0 >= frames) break;                                                       // (uniform)
+            const int fa = f0 + 2 * w;
+            const int ia = fa * hop - (1024 - hop), ib = ia + hop;
+            const bool va = fa < frames, vb = fa + 1 < frames;
+            c32 v[16];
+            // buffer loads: a sample index outside [0, n_samples) -- the lws zero padding on either side, a frame past the end -- is out of the
+            // descriptor's range and reads as zero.  (Guarded plain loads compile to one exec-masked branch + wait PER load: 32 dependent memory
+            // round trips per iteration, which -- not the FFT -- was what both earlier kernels spent their 1.3 ms on.)
+            // (a negative byte offset is a huge unsigned one: the left padding needs no test either; a frame past the end gets an empty descriptor)
+            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, va ? n_samples * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, vb ? n_samples * 4 : 0, 0x00020000);
+            const int oa = (ia + n2) * 4, ob = (ib + n2) * 4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, oa + 256 * i, 0, 0));
+                const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, ob + 256 * i, 0, 0));
+                v[i] = c32{a, b} * win[i];
+            }
+            dft16(v);                                                                      // over n1 -> k1
+#pragma unroll
+            for (int i = 1; i < 16; ++i) v[i] = cmulc(v[i], tw1[i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) E[i * SW_EROW + n2] = v[i];
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 16; ++b) v[b] = E[k1r * SW_EROW + qa + 4 * b];
+            __syncthreads();                                                               // the region is re-used for the partner table below
+            dft16(v);                                                                      // over b -> kb
+#pragma unroll
+            for (int i = 1; i < 16; ++i) v[i] = cmulc(v[i], t64[i * qa]);
+            // radix-4 over a across the quad
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                c32 o = c32{dpp_f<0x4E>(v[i].x), dpp_f<0x4E>(v[i].y)};                     // lane ^ 2
+                c32 f = sg1 * v[i] + o;
+                f = rc * f + rd * c32{f.y, -f.x};
+                o = c32{dpp_f<0xB1>(f.x), dpp_f<0xB1>(f.y)};                               // lane ^ 1
+                v[i] = sg2 * f + o;
+            }
+            // v[kb] = X[k], k = k1r + 16 (kb + 16 ka).  Park X: entry k at float2 index k + 4 (k >> 8) (32 bytes of padding per 256 entries)
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) {
+                const int k = k1r + 16 * kb + 256 * ka;
+                E[k + 4 * (k >> 8)] = v[kb];
+            }
+            __syncthreads();
+            if (ka < 2) {
+#pragma unroll
+                for (int kb = 0; kb < 16; ++kb) {
+                    const int k = k1r + 16 * kb + 256 * ka, kp = (1024 - k) & 1023;
+                    const c32 p = E[kp + 4 * (kp >> 8)], x = v[kb];
+                    const float ar = x.x + p.x, ai = x.y - p.y, br = x.x - p.x, bi = x.y + p.y;
+                    *reinterpret_cast<float2*>(mag + k * SW_MP + 2 * w) = make_float2(0.5f * __builtin_amdgcn_sqrtf(ar * ar + ai * ai), 0.5f * __builtin_amdgcn_sqrtf(br * br + bi * bi));
+                }
+            } else if (ka == 2 && k1r == 0) {
+                *reinterpret_cast<float2*>(mag + 512 * SW_MP + 2 * w) = make_float2(fabsf(v[0].x), fabsf(v[0].y));  // k = 512: its own partner
+            }
+            __syncthreads();
+            // ---- mel bands: a thread owns band m for eight of the sixteen frames
+            for (int mh = tid; mh < 2 * n_mels; mh += NT) {
+                const int m = mh >> 1, hf = mh & 1;
+                const int lo = band_lo[m], cnt = band_cnt[m], o = boff[m];
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+                const float* mg = mag + lo * SW_MP + hf * 8;
+                for (int i = 0; i < cnt; ++i) {
+                    const float wt = wl ? wts[o + i] : basis_t[(size_t)(lo + i) * n_mels + m];
+                    const f32x4 m0 = *reinterpret_cast<const f32x4*>(mg + i * SW_MP), m1 = *reinterpret_cast<const f32x4*>(mg + i * SW_MP + 4);
+                    a0 += wt * m0; a1 += wt * m1;
+                }
+                const int fb = f0 + hf * 8;
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    const float acc = f < 4 ? a0[f] : a1[f - 4];
+                    const float S = 6.02059991327962f * __builtin_amdgcn_logf(fmaxf(min_level, acc)) - ref_db;      // 20 log10(x) = 6.0206 log2(x); v_log_f32: 1 ulp
+                    float nrm = (S - min_db) * inv_mdb;
+                    nrm = fminf(fmaxf(nrm, 0.f), 1.f);
+                    const float mk = (mask && fb + f < frames) ? mask[(size_t)clip * frames + fb + f] : 1.f;
+                    if (tiled) otile[m * SW_OT + (fb - F0) + f] = nrm * mk;
+                    else if (fb + f < frames) mel[((size_t)clip * n_mels + m) * frames + fb + f] = nrm * mk;
+                }
+            }
+            __syncthreads();                                                               // the magnitude table is rewritten by the next iteration
+        }
+        if (tiled) {
+            // the tile's rows out as runs of up to 32 consecutive frames: lane = frame, two bands per wave instruction
+            const int nf = min(SW_TF, frames - F0);
+            for (int idx = tid; idx < n_mels * SW_TF; idx += NT) {
+                const int m = idx >> 5, f = idx & 31;
+                if (f < nf) mel[((size_t)clip * n_mels + m) * frames + F0 + f] = otile[m * SW_OT + f];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 // as viai_stft_mel for fft = 1024 with the support of every mel band given: band m is nonzero on bins [band_lo[m], band_lo[m] + band_cnt[m])
@@ -186,6 +395,18 @@ extern "C" int viai_stft_mel_banded(const float* wav, const float* window, const
                                     const float* mask, float* mel, int B, int n_samples, int fft, int hop, int n_mels, int frames,
                                     float min_level_db, float ref_level_db, void* stream) {
     if (B <= 0 || frames <= 0 || hop <= 0 || hop > fft || n_mels <= 0 || fft != SB_N || band_lo == nullptr || band_cnt == nullptr) return (int)hipErrorInvalidValue;
+    static int wave_kernel = -1;
+    if (wave_kernel < 0) { const char* e = getenv("VIAI_STFT_WAVE"); wave_kernel = e ? atoi(e) : 1; }
+    if (wave_kernel && n_mels <= 1024) {
+        constexpr int ldsw = SW_NW * SW_WREG * 8 + 516 * SW_MP * 4 + SW_WCAP * 4 + 1032 * 4 + 64 * 8 + SW_OMEL * SW_OT * 4;
+        static bool attr_w = false;
+        if (!attr_w) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw); attr_w = true; }
+        const long groups = (long)B * ((frames + SW_TF - 1) / SW_TF);
+        const int grid = (int)(groups < 256 ? groups : 256);                     // persistent: one 8-wave block per CU
+        VIAI_LAUNCH(stft_mel_wave_kernel, dim3(grid), dim3(64 * SW_NW), ldsw, (hipStream_t)stream, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels,
+                    frames, min_level_db, ref_level_db);
+        return viai_launch_status();
+    }
     constexpr int lds = (8 * SB_N + 768) * (int)sizeof(float2);
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_banded_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
