@@ -143,7 +143,9 @@ def spawn_ranks(args):
 
 
 FAMILY_CALLS = ("viai_conv2d_fwd", "viai_conv2d_fwd_amax", "viai_conv2d_dgrad", "viai_conv2d_dgrad_f16", "viai_conv2d_wgrad", "viai_conv2d_wgrad_f16",
-                "viai_conv2d_cin1_bn_fwd", "viai_conv2d_cin1_bn_wgrad")
+                "viai_conv2d_cin1_bn_fwd", "viai_conv2d_cin1_bn_wgrad",
+                # the same launches on pre-split (P16) operands (ABI 13)
+                "viai_conv2d_fwd_p16", "viai_conv2d_dgrad_f16_p16", "viai_conv2d_wgrad_f16_p16", "viai_conv2d_cin1_bn_fwd_p16")
 
 
 class KernelTimer:

@@ -52,9 +52,11 @@ def is_p16(t):
 
 
 def p16_mask(d):
-    m = d.get("p16")
+    # (the library reads two of its kernel-family switches per call -- tests flip them at run time -- so the cached mask is keyed on them)
+    key = ("p16", os.environ.get("VIAI_WGRAD_PATCH_S2"), os.environ.get("VIAI_WGRAD_PATCH_NARROW"))
+    m = d.get(key)
     if m is None:
-        m = d["p16"] = int(_lib.load().viai_conv2d_p16_ok(d["ref"]))
+        m = d[key] = int(_lib.load().viai_conv2d_p16_ok(d["ref"]))
     return m
 
 
