@@ -660,7 +660,7 @@ def main():
                             "counters include Infinity-Cache hits, i.e. they are L2-miss traffic, an upper bound on HBM bytes") % os.path.basename(pmc)
                         break
         del m2
-    if rank == 0 and not av and not args.no_roofline:
+    if rank == 0 and world == 1 and not av and not args.no_roofline:            # (N = 1 only: at N > 1 the other ranks wait in the final barrier)
         out["stages"] = front_end_stages(dev, args.batch, args.bins, args.frames)
     if rank == 0 and world == 1 and not av and not args.no_roofline:
         out["config"]["launch_modes"] = launch_modes(hp, dev, s, mask)

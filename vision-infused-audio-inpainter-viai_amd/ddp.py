@@ -28,8 +28,11 @@ def init_from_env(backend=None):
             # VIAI_DIST_BACKEND=gloo: CPU-staged collectives (tests, or several ranks sharing one GPU, which RCCL refuses)
             backend = os.environ.get("VIAI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            # eager communicator on the device this rank owns (device_id): RCCL's set-up happens here, not inside the first collective of the step
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
 

@@ -609,13 +609,19 @@ class AudioModel:
         cap = torch.cuda.Stream(device=self.device)
         while cap.cuda_stream in taken:
             cap = torch.cuda.Stream(device=self.device)
+        # With a process group up, ProcessGroupNCCL's watchdog THREAD polls its work events (hipEventQuery) whenever it likes; under the default
+        # capture mode ("global") that call is illegal from any thread while this one captures, the watchdog dies with
+        # hipErrorStreamCaptureUnsupported and takes the process with it -- the "RCCL abort now and then" of rounds 2 and 3 (1 of 20 runs of the
+        # one-rank test; it was never RCCL's set-up or teardown).  "thread_local" confines the check to the capturing thread.
+        dist_up = torch.distributed.is_available() and torch.distributed.is_initialized()
+        gkw = {"capture_error_mode": "thread_local"} if dist_up else {}
         for f in segs:
             if self.use_plan:
                 # the capture is a recorder: the hipGraph is kept (it owns the kernel-argument arrays) but never instantiated
                 g = torch.cuda.CUDAGraph(keep_graph=True)
                 check(lib().viai_plan_log_begin(), "viai_plan_log_begin")
                 try:
-                    with torch.cuda.graph(g, pool=pool, stream=cap):
+                    with torch.cuda.graph(g, pool=pool, stream=cap, **gkw):
                         origin = torch.cuda.current_stream().cuda_stream
                         f()
                 finally:
@@ -625,7 +631,7 @@ class AudioModel:
                 plans.append(plan)
             else:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=cap):
+                with torch.cuda.graph(g, pool=pool, stream=cap, **gkw):
                     f()
             pool = g.pool()
             graphs.append(g)
