@@ -428,6 +428,14 @@ def main_wavenet(args):
         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel": "%s chain (csrc/wavenet.hip): %d dependent launches per time step" % (kernel_chain, n_launch),
                      "algorithmic_bytes_per_step": wbytes,
+                     # the second floor: a time step is a CHAIN of n_launch dependent stages; each hand-off costs a kernel boundary (1.5 - 1.9 us
+                     # between real kernels, MI355X_MICROARCH.md price list "boundary") or, inside one persistent kernel, an XCD-hierarchical grid
+                     # barrier (4 - 6 us, "barrier-xcd") -- the cheaper of the two, per dependency
+                     "dependency_chain_floor": {"launches_per_step": n_launch, "us_per_handoff": 1.7, "floor_us_per_step": round(n_launch * 1.7, 1),
+                                                "floor_samples_per_s": round(B / (n_launch * 1.7e-6), 0),
+                                                "frac_of_chain_floor": round(n_launch * 1.7e-3 / ms, 4),
+                                                "note": "a stage cannot start before its predecessor's output is visible chip-wide: %d x 1.7 us of boundaries alone; the "
+                                                        "measured %.1f us per step = %.1f us per stage (the stage kernels' own memory round trips)" % (n_launch, ms * 1e3, ms * 1e3 / n_launch)},
                      "note": "weight-streaming bound (SURVEY.md section 8d: incremental lower bound per time step = weight bytes / bandwidth): every time step reads "
                              "all %.1f MB of fp32 weights once, whatever level of the hierarchy serves them (they fit the 256 MB Infinity Cache, not the 32 MB of L2); "
                              "the floor at the HBM peak is %.1f us per step, the chain of dependent launches measures %.1f us" % (wbytes * 1e-6, wbytes / HBM_PEAK_GBPS * 1e-3, ms * 1e3)},
