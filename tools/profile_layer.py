@@ -23,6 +23,7 @@ ap.add_argument("--bn", action="store_true", help="BatchNorm + LeakyReLU behind 
 ap.add_argument("--stride", type=int, nargs="+", default=[1])
 ap.add_argument("--kernel", type=int, nargs=2, default=[3, 3])
 ap.add_argument("--pad", type=int, nargs=2, default=None)
+ap.add_argument("--p16", action="store_true", help="hand the layer a pre-split (P16) input, as the BatchNorm pass in front of it does in the networks")
 a = ap.parse_args()
 N, H, W, Ci, Co = a.shape
 x = (torch.rand(N, H, W, Ci, device="cuda") * 2 - 1).requires_grad_(True)
@@ -32,6 +33,16 @@ pad = tuple(a.pad) if a.pad else (kh // 2, kw // 2)
 wshape = (Ci, Co, kh, kw) if a.transposed else (Co, Ci, kh, kw)
 w = ((torch.rand(*wshape, device="cuda") - 0.5) * 0.1).requires_grad_(True)
 bn = torch.nn.BatchNorm2d(Co).cuda() if a.bn else None
+if a.p16:
+    from viai_amd import _lib
+    one, zero = torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda")
+    xp = torch.empty_like(x)
+    am = torch.zeros(1, device="cuda")
+    _lib.check(_lib.load().viai_bn_act_fwd_p16(x.data_ptr(), one.data_ptr(), zero.data_ptr(), one.data_ptr(), zero.data_ptr(), 16, xp.data_ptr(), N * H * W, Ci, 0, 0.2,
+                                               am.data_ptr(), torch.cuda.current_stream().cuda_stream), "p16")
+    xp._viai_p16, xp._viai_amax = True, am
+    x = xp.requires_grad_(True)
+    x._viai_p16, x._viai_amax = True, am
 for _ in range(a.iters):
     ops.begin_step(x.device)
     y = ops.conv_bn_act(x, w, None, bn, kernel=(kh, kw), stride=(sh, sw), padding=pad, transposed=a.transposed,

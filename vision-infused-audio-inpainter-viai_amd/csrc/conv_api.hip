@@ -355,7 +355,11 @@ extern "C" int viai_conv2d_stat_geom(const viai_conv2d* c, int* nblk, int* rows_
     int oh, ow;
     viai_conv2d_out_hw(c, &oh, &ow);
     long M = (long)c->N * oh * ow;
-    const int bm = (kind_of(c) == K_COUT1 || stem_f16(c) || halo_fwd(c) || halo_wide_fwd(c)) ? 128 : sk_fwd(c) ? 32 : viai_igemm_tile_m(M, c->Cout);
+    int bm = (kind_of(c) == K_COUT1 || stem_f16(c) || halo_fwd(c) || halo_wide_fwd(c)) ? 128 : sk_fwd(c) ? 32 : viai_igemm_tile_m(M, c->Cout);
+    if (kind_of(c) == K_IGEMM && !halo_fwd(c) && halo_wide_fwd(c) && c->sh == 2) {        // stride-2 wide halo forward: 64-pixel tiles where it runs them
+        ConvGeom g{}; viai_geom_fwd(c, &g);
+        bm = 16 * viai_halo_s2_rows(g);
+    }
     *rows_per_blk = bm;
     *nblk = (int)((M + bm - 1) / bm);
     int th, tw;

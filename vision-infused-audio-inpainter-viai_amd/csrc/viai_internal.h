@@ -55,6 +55,7 @@ int viai_conv_stem_pack(const float* w, float* wp, int Cin, hipStream_t st);
 bool viai_conv_halo_wide_ok(const ConvArgs& a);
 int viai_halo_tiles_y(const ConvGeom& g);      // 8 x 16 output tiles of the wide halo kernel (the last row / column of tiles may be partial)
 int viai_halo_tiles_x(const ConvGeom& g);
+int viai_halo_s2_rows(const ConvGeom& g);      // tile rows (8 or 4) of the wide halo kernel's stride-2 forward instance: BatchNorm partial blocks = 16 x rows pixels
 int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st);
 bool viai_dgrad_s2_ok(const viai_conv2d* c);
 int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st);
