@@ -613,17 +613,23 @@ def main():
         alone = None
         if m2._wgrad_stream is not None and not av:
             side, m2._wgrad_stream = m2._wgrad_stream, None
+            dreal, m2._dreal_stream = m2._dreal_stream, None
             m2.optimize_parameters(0)
             torch.cuda.synchronize()
             kt1 = KernelTimer(lib)
             kt1.install()
             for i in range(min(nprof, 5)):
                 m2.optimize_parameters(i)
-            f1, t1, n1 = kt1.summary()[dom]
+            fam1 = kt1.summary()
+            f1, t1, n1 = fam1[dom]
             kt1.uninstall()
-            m2._wgrad_stream = side
+            m2._wgrad_stream, m2._dreal_stream = side, dreal
             alone = {"achieved": round(f1 / t1 * 1e-12, 2), "frac": round(f1 / t1 * 1e-12 / peak, 4), "avg_launch_us": round(t1 / n1 * 1e6, 2),
-                     "note": "single-stream pass: the dominant kernel without the concurrent weight-gradient stream"}
+                     "note": "single-stream pass (weight gradients and D(real) back on the main stream): every launch with the chip to itself -- what the "
+                             "kernels reach, without the time-sharing the as-run figures include (the side streams' kernels run beside the main "
+                             "chain by design, on sub-CU grids)",
+                     "frac_by_kernel": {k: round(v[0] / v[1] * 1e-12 / peak_of(k), 3) for k, v in sorted(fam1.items()) if v[1] > 0 and k != "direct"},
+                     "conv_ms_per_step": round(sum(v[1] for v in fam1.values()) / min(nprof, 5) * 1e3, 3)}
         out["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": None,

@@ -274,3 +274,48 @@ def test_pair_backward_producer_matches_the_fp32_pass(Cc, tr):
     assert torch.equal(dg, dgp) and torch.equal(db, dbp) and torch.equal(sums, sumsp)
     assert float(am) <= float(amp) <= float(am) * 16, (float(am), float(amp))
     _close_to_split(decode(dyp, amp), dy, amp, extra=float(dy.abs().max()) * 2.0 ** -20)
+
+
+def test_discriminator_and_decoder_block_run_presplit_and_agree_with_the_fp32_path():
+    """networks.MelDiscriminator / TransConvBlock at the benchmark's map sizes: with ops.P16 the tensors between the layers are pre-split (the
+    consumer's input carries the tag), and outputs / gradients agree with the fp32-tensor path to rounding (a different scale = a different
+    rounding realisation of the same fp32-grade arithmetic)."""
+    from viai_amd import ops
+    from viai_amd.networks import MelDiscriminator, TransConvBlock, to_nhwc
+    torch.manual_seed(0)
+    D = MelDiscriminator().cuda()
+    blk = TransConvBlock(32, 32, "5", nums=3).cuda()
+    x = torch.rand(4, 1, 128, 128, device="cuda")
+    h = torch.rand(4, 64, 128, 32, device="cuda")              # NHWC (N, H, W, C) = (4, 64, 128, 32)
+    seen = []
+    orig = ops._ConvBnAct.forward
+
+    def spy(ctx, x_, *a):
+        seen.append(ops.is_p16(x_))
+        return orig(ctx, x_, *a)
+    res = {}
+    for mode in (True, False):
+        ops.P16 = mode
+        seen.clear()
+        ops._ConvBnAct.forward = staticmethod(spy)
+        try:
+            D.zero_grad(); blk.zero_grad()
+            ops.begin_step(x.device)
+            out = D(x)
+            out.mean().backward()
+            hh = h.clone().requires_grad_(True)
+            o2 = blk.forward_nhwc(hh)
+            (o2 * o2).mean().backward()
+            torch.cuda.synchronize()
+        finally:
+            ops._ConvBnAct.forward = staticmethod(orig)
+        res[mode] = (out.detach().clone(), [p.grad.clone() for p in D.parameters()], o2.detach().clone(), hh.grad.clone(), [p.grad.clone() for p in blk.parameters()], list(seen))
+    ops.P16 = True
+    assert sum(res[True][5]) >= 3 and sum(res[False][5]) == 0, (res[True][5], res[False][5])     # D.conv2_1 / conv2_2 and the block's inner layers took pre-split inputs
+
+    def rel(a, b):
+        return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+    assert rel(res[True][0], res[False][0]) < 1e-5 and rel(res[True][2], res[False][2]) < 1e-5
+    assert rel(res[True][3], res[False][3]) < 1e-4
+    for ga, gb in zip(res[True][1] + res[True][4], res[False][1] + res[False][4]):
+        assert rel(ga, gb) < 2e-3, rel(ga, gb)
