@@ -59,3 +59,14 @@ for q, ev in sorted(qs.items(), key=lambda kv: -sum(e[1] - e[0] for e in kv[1]))
     print("  largest gap classes:")
     for k, v in gaps.most_common(8):
         print("    %-50s %7.3f ms/step" % (k, v / 1e6 / nst))
+
+    # the largest individual gaps of the busiest queue, first analysed step: who waited for whom
+    if q == max(qs, key=lambda k: sum(e[1] - e[0] for e in qs[k])):
+        one = [e for e in ev if e[0] < rows[ends[first + 1]][1]]
+        big = sorted(((s1 - e0, n0, n1, s1) for (s0, e0, _, n0), (s1, e1, _, n1) in zip(one, one[1:]) if s1 > e0), reverse=True)[:14]
+        print("  largest single gaps (first step): us, after -> before, what ran on the other queues meanwhile")
+        for gap, n0, n1, s1 in big:
+            other = [r for r in step if r[2] != q and r[0] < s1 and r[1] > s1 - gap]
+            names = ", ".join(sorted({re.sub(r"\(.*", "", re.sub(r"^void |\(anonymous namespace\)::", "", r[3]))[:28] for r in other}))[:110]
+            short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void |\(anonymous namespace\)::", "", n))[:40]
+            print("    %6.1f  %-40s -> %-40s | %s" % (gap / 1e3, short(n0), short(n1), names))
