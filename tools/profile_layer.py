@@ -23,15 +23,16 @@ ap.add_argument("--bn", action="store_true", help="BatchNorm + LeakyReLU behind 
 ap.add_argument("--stride", type=int, nargs="+", default=[1])
 ap.add_argument("--kernel", type=int, nargs=2, default=[3, 3])
 ap.add_argument("--pad", type=int, nargs=2, default=None)
+ap.add_argument("--zeros", action="store_true", help="all-zero input, weights and gradient: same instruction stream, no toggling -- the DVFS headroom of the layer's kernels")
 ap.add_argument("--p16", action="store_true", help="hand the layer a pre-split (P16) input, as the BatchNorm pass in front of it does in the networks")
 a = ap.parse_args()
 N, H, W, Ci, Co = a.shape
-x = (torch.rand(N, H, W, Ci, device="cuda") * 2 - 1).requires_grad_(True)
+x = ((torch.rand(N, H, W, Ci, device="cuda") * 2 - 1) * (0.0 if a.zeros else 1.0)).requires_grad_(True)
 kh, kw = a.kernel
 sh, sw = (a.stride * 2)[:2]
 pad = tuple(a.pad) if a.pad else (kh // 2, kw // 2)
 wshape = (Ci, Co, kh, kw) if a.transposed else (Co, Ci, kh, kw)
-w = ((torch.rand(*wshape, device="cuda") - 0.5) * 0.1).requires_grad_(True)
+w = ((torch.rand(*wshape, device="cuda") - 0.5) * (0.0 if a.zeros else 0.1)).requires_grad_(True)
 bn = torch.nn.BatchNorm2d(Co).cuda() if a.bn else None
 if a.p16:
     from viai_amd import _lib
@@ -47,6 +48,6 @@ for _ in range(a.iters):
     ops.begin_step(x.device)
     y = ops.conv_bn_act(x, w, None, bn, kernel=(kh, kw), stride=(sh, sw), padding=pad, transposed=a.transposed,
                         act=ops.ACT_LRELU if a.bn else ops.ACT_NONE)
-    y.backward(torch.rand_like(y) - 0.5)
+    y.backward((torch.rand_like(y) - 0.5) * (0.0 if a.zeros else 1.0))
 torch.cuda.synchronize()
 print("ok", tuple(y.shape))
