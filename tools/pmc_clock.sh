@@ -1,12 +1,13 @@
 #!/bin/bash
 # Effective shader clock of one layer's kernels: GRBM_GUI_ACTIVE / wall time per dispatch (MI355X_MICROARCH.md, "DVFS give-back"),
 # plus the kernel-trace-only durations of the same command for comparison.    tools/pmc_clock.sh <out.txt> [profile_layer.py arguments]
+# PMC_SCRIPT=tools/probes/stft_time.py tools/pmc_clock.sh <out.txt> 1024 256    -- another script instead of profile_layer.py
 out=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 d=/tmp/pmc_clock_$$
 rm -rf "$d"; mkdir -p "$d"
-(cd /tmp && TMPDIR=/tmp rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$d/pmc" -o out -- python "$root/tools/profile_layer.py" "$@" > "$d/log1.txt" 2>&1) || tail -5 "$d/log1.txt"
-(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d "$d/plain" -o out -- python "$root/tools/profile_layer.py" "$@" > "$d/log2.txt" 2>&1) || tail -5 "$d/log2.txt"
+(cd /tmp && TMPDIR=/tmp rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$d/pmc" -o out -- python "$root/${PMC_SCRIPT:-tools/profile_layer.py}" "$@" > "$d/log1.txt" 2>&1) || tail -5 "$d/log1.txt"
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d "$d/plain" -o out -- python "$root/${PMC_SCRIPT:-tools/profile_layer.py}" "$@" > "$d/log2.txt" 2>&1) || tail -5 "$d/log2.txt"
 python - "$d" > "$out" <<'PY'
 import collections, csv, glob, os, sys
 d = sys.argv[1]

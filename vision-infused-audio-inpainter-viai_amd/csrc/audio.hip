@@ -199,7 +199,6 @@ __global__ __launch_bounds__(256) void stft_mel_banded_kernel(const float* __res
 constexpr int SW_EROW = 68;                    // float2 per row of the transpose buffer (64 + 4 pad = 136 dwords)
 constexpr int SW_WREG = 16 * SW_EROW;          // float2 per wave region (8704 bytes; the partner table, 1024 + 16 float2, fits in it)
 constexpr int SW_MROW = 8;                     // floats per bin of the magnitude table (8 frames)
-constexpr int SW_WCAP = 2048;                  // mel weights held in LDS (floats); a denser basis is read from global memory
 
 typedef float c32 __attribute__((ext_vector_type(2)));            // (re, im) as a register PAIR: the arithmetic below compiles to v_pk_* without shuffling moves
 __device__ __forceinline__ c32 cadd(c32 a, c32 b) { return a + b; }
@@ -233,25 +232,49 @@ __device__ __forceinline__ void dft16(c32 (&v)[16]) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = t[k];
 }
+// orders a wave's LDS stores before its own later LDS loads of other lanes' data (the LDS queue of a wave is in order: only the compiler must not move them)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int wave_max_i(int v) {           // wave-uniform maximum, in an SGPR
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false)); }
 
 // Block = 8 waves = 16 frames per iteration; two iterations fill a [band][32 frames] output tile in LDS that is then written as 128-byte
 // runs: with frame the fastest output index, a thread storing its band's 8 frames (32 bytes at a stride of `frames` floats, unaligned for odd
 // frame counts) made every store instruction touch 64 different lines -- THAT, not the FFTs, held both earlier kernels at 0.4 TB/s.
-constexpr int SW_NW = 8, SW_FPI = 2 * SW_NW, SW_MP = SW_FPI + 4, SW_TF = 32, SW_OT = SW_TF + 1, SW_OMEL = 256;     // SW_MP: floats per bin of the magnitude table (padded: 2-way instead of 8-way store conflicts)
+constexpr int SW_OMEL = 256;
+// NW waves per block (2 NW frames per iteration), TF frames per output tile, MP floats per bin of the magnitude table (a multiple of 4; padding turns 8-way store
+// conflicts into 2-way), WCAP mel weights held in LDS (a denser basis is read from global memory), MMAX the largest n_mels.
+//   <8, 32, 20, 2048, 1024>: one 8-wave block per CU (154 KB of LDS);  <4, 16, 8, 1024, 256>: TWO independent 4-wave blocks per CU (73 KB each) -- a block's waves
+//   meet at two barriers per iteration, so the two waves of a SIMD walk the phases of an iteration in lockstep; two blocks drift apart.  It did NOT help (551 vs
+//   523 us on 1024 clips): the bound is the per-wave VALU issue rate (`tools/probes/valu_rate.hip`: one wave issues a v_fma_f32 every ~7 cycles, a v_pk_fma_f32
+//   every ~10; the SIMD takes one per 2 -- it needs 4+ waves to fill, and 240 registers leave room for two: VALU 48 % busy, `profiles/r04_d_pmc_stft.json`).
+template <int NW, int TF, int MP, int WCAP, int MMAX>
+struct SwCfg {
+    static constexpr int FPI = 2 * NW, OT = TF + 1, NT = 64 * NW, FH = FPI / 8;
+    static constexpr int lds = NW * SW_WREG * 8 + 516 * MP * 4 + WCAP * 4 + (MMAX + 8) * 4 + 64 * 8 + SW_OMEL * OT * 4;
+};
+template <int SW_NW, int SW_TF, int SW_MP, int SW_WCAP, int SW_MMAX>
 __global__ __launch_bounds__(64 * SW_NW) __attribute__((amdgpu_waves_per_eu(2))) void stft_mel_wave_kernel(const float* __restrict__ wav, const float* __restrict__ window,
                                                             const float* __restrict__ basis_t, const int* __restrict__ band_lo,
                                                             const int* __restrict__ band_cnt, const float* __restrict__ mask,
                                                             float* __restrict__ mel, int n_clips, int n_samples, int hop, int n_mels,
                                                             int frames, float min_db, float ref_db) {
+    constexpr int SW_FPI = 2 * SW_NW, SW_OT = SW_TF + 1, SW_FH = SW_FPI / 8;      // SW_FH: eight-frame halves of an iteration (a mel item = (band, half))
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
     constexpr int NT = 64 * SW_NW;
     c32* ebuf = reinterpret_cast<c32*>(smem_w);                                  // [8 waves][SW_WREG]
     float* mag = reinterpret_cast<float*>(ebuf + SW_NW * SW_WREG);                 // [513][16]
     float* wts = mag + 516 * SW_MP;                                                // [SW_WCAP] band weights, band after band
     int* boff = reinterpret_cast<int*>(wts + SW_WCAP);                             // [n_mels + 1] (n_mels <= 1024), boff[n_mels] = total
-    c32* t64 = reinterpret_cast<c32*>(boff + 1032);                                // [64] W64^n
+    c32* t64 = reinterpret_cast<c32*>(boff + SW_MMAX + 8);                                // [64] W64^n
     float* otile = reinterpret_cast<float*>(t64 + 64);                             // [min(n_mels, 256)][33]: 32 frames of every band (n_mels <= 256)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform: the buffer descriptors below must be scalar, or every load becomes a waterfall loop)
     const bool tiled = n_mels <= SW_OMEL;
@@ -284,42 +307,54 @@ __global__ __launch_bounds__(64 * SW_NW) __attribute__((amdgpu_waves_per_eu(2)))
     const float rc = qa == 3 ? 0.f : 1.f, rd = qa == 3 ? 1.f : 0.f;                        // lane 3 multiplies by -i between the two steps
     const float min_level = exp10f(min_db / 20.f), inv_mdb = -1.f / min_db;
     c32* E = ebuf + w * SW_WREG;
+    // the first (for n_mels <= 256: the only) mel item of this thread: band tid >> 1, frames 8 (tid & 1) .. + 8 of the iteration
+    const bool own_0 = tid < SW_FH * n_mels;
+    const int m_0 = own_0 ? tid / SW_FH : 0, hf_0 = tid % SW_FH;
+    const int lo_0 = own_0 ? band_lo[m_0] : 0, cnt_0 = own_0 ? band_cnt[m_0] : 0, o_0 = boff[m_0];
+    const int cmax_0 = wave_max_i(cnt_0);
     const int gpc = (frames + SW_TF - 1) / SW_TF, total = n_clips * gpc;                   // super-groups of 32 frames
     const int per = (total + gridDim.x - 1) / gridDim.x;
     const int g_end = min(total, (int)(blockIdx.x + 1) * per);
     __syncthreads();
+    // the samples of an iteration are requested one iteration ahead (after the previous one's last use of v[]): a block's eight waves meet at two barriers per
+    // iteration, so nothing else covers the HBM round trip.  Buffer loads: a sample index outside [0, n_samples) -- the lws zero padding on either side, a frame past
+    // the end -- is out of the descriptor's range and reads as zero (guarded plain loads compile to one exec-masked branch + wait PER load: 32 dependent round trips
+    // per iteration, which -- not the FFT -- was what both earlier kernels spent their 1.3 ms on); a negative byte offset is a huge unsigned one, so the left
+    // padding needs no test either; a frame past the end (or an iteration past the block's range) gets an empty descriptor.
+    float ra[16], rb[16];
+    auto request = [&](int gi, int sub) {
+        const int clip = gi / gpc, f0 = (gi - clip * gpc) * SW_TF + sub * SW_FPI;
+        const float* y = wav + (size_t)clip * n_samples;
+        const int fa = f0 + 2 * w;
+        const int ia = fa * hop - (1024 - hop), ib = ia + hop;
+        const bool live = gi < g_end, va = live && fa < frames, vb = live && fa + 1 < frames;
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, va ? n_samples * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, vb ? n_samples * 4 : 0, 0x00020000);
+        const int oa = (ia + n2) * 4, ob = (ib + n2) * 4;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ra[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, oa + 256 * i, 0, 0));
+            rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, ob + 256 * i, 0, 0));
+        }
+    };
+    if ((int)(blockIdx.x * per) < g_end) request(blockIdx.x * per, 0);
     for (int gi = blockIdx.x * per; gi < g_end; ++gi) {
         const int clip = gi / gpc, F0 = (gi - clip * gpc) * SW_TF;
-        const float* y = wav + (size_t)clip * n_samples;
         for (int sub = 0; sub < SW_TF / SW_FPI; ++sub) {
             const int f0 = F0 + sub * SW_FPI;
             if (f0 >= frames) break;                                                       // (uniform)
-            const int fa = f0 + 2 * w;
-            const int ia = fa * hop - (1024 - hop), ib = ia + hop;
-            const bool va = fa < frames, vb = fa + 1 < frames;
             c32 v[16];
-            // buffer loads: a sample index outside [0, n_samples) -- the lws zero padding on either side, a frame past the end -- is out of the
-            // descriptor's range and reads as zero.  (Guarded plain loads compile to one exec-masked branch + wait PER load: 32 dependent memory
-            // round trips per iteration, which -- not the FFT -- was what both earlier kernels spent their 1.3 ms on.)
-            // (a negative byte offset is a huge unsigned one: the left padding needs no test either; a frame past the end gets an empty descriptor)
-            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, va ? n_samples * 4 : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, vb ? n_samples * 4 : 0, 0x00020000);
-            const int oa = (ia + n2) * 4, ob = (ib + n2) * 4;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, oa + 256 * i, 0, 0));
-                const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, ob + 256 * i, 0, 0));
-                v[i] = c32{a, b} * win[i];
-            }
+            for (int i = 0; i < 16; ++i) v[i] = c32{ra[i], rb[i]} * win[i];
             dft16(v);                                                                      // over n1 -> k1
 #pragma unroll
             for (int i = 1; i < 16; ++i) v[i] = cmulc(v[i], tw1[i]);
 #pragma unroll
             for (int i = 0; i < 16; ++i) E[i * SW_EROW + n2] = v[i];
-            __syncthreads();
+            wave_lds_sync();                                                               // E is this wave's own region: no block barrier
 #pragma unroll
             for (int b = 0; b < 16; ++b) v[b] = E[k1r * SW_EROW + qa + 4 * b];
-            __syncthreads();                                                               // the region is re-used for the partner table below
+            wave_lds_sync();                                                               // the region is re-used for the partner table below
             dft16(v);                                                                      // over b -> kb
 #pragma unroll
             for (int i = 1; i < 16; ++i) v[i] = cmulc(v[i], t64[i * qa]);
@@ -338,7 +373,7 @@ __global__ __launch_bounds__(64 * SW_NW) __attribute__((amdgpu_waves_per_eu(2)))
                 const int k = k1r + 16 * kb + 256 * ka;
                 E[k + 4 * (k >> 8)] = v[kb];
             }
-            __syncthreads();
+            wave_lds_sync();
             if (ka < 2) {
 #pragma unroll
                 for (int kb = 0; kb < 16; ++kb) {
@@ -350,28 +385,62 @@ __global__ __launch_bounds__(64 * SW_NW) __attribute__((amdgpu_waves_per_eu(2)))
             } else if (ka == 2 && k1r == 0) {
                 *reinterpret_cast<float2*>(mag + 512 * SW_MP + 2 * w) = make_float2(fabsf(v[0].x), fabsf(v[0].y));  // k = 512: its own partner
             }
+            {   // the next iteration's samples (v[] is dead from here on)
+                const bool more = sub + 1 < SW_TF / SW_FPI && f0 + SW_FPI < frames;
+                request(more ? gi : gi + 1, more ? sub + 1 : 0);
+            }
             __syncthreads();
-            // ---- mel bands: a thread owns band m for eight of the sixteen frames
-            for (int mh = tid; mh < 2 * n_mels; mh += NT) {
-                const int m = mh >> 1, hf = mh & 1;
-                const int lo = band_lo[m], cnt = band_cnt[m], o = boff[m];
-                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-                const float* mg = mag + lo * SW_MP + hf * 8;
-                for (int i = 0; i < cnt; ++i) {
-                    const float wt = wl ? wts[o + i] : basis_t[(size_t)(lo + i) * n_mels + m];
-                    const f32x4 m0 = *reinterpret_cast<const f32x4*>(mg + i * SW_MP), m1 = *reinterpret_cast<const f32x4*>(mg + i * SW_MP + 4);
-                    a0 += wt * m0; a1 += wt * m1;
+            // ---- mel bands: a thread owns band m for eight of the sixteen frames.  The band's extent is a per-thread constant for the first 512 items (fetched
+            // once per block, above); the walk over its bins has a WAVE-uniform trip count (the widest band of the wave: the bands are sorted by width, lanes past
+            // their own count multiply by zero) so that it is a scalar loop the compiler can unroll with its LDS reads in flight -- the per-lane `cnt` loop with
+            // a select between an LDS and a global weight pointer was one exec-masked round trip (flat load + wait) per bin, 11 of them for the last wave.
+            for (int mh = tid, pass = 0; mh - tid < SW_FH * n_mels; mh += NT, ++pass) {        // (uniform bound: every lane walks the same passes)
+                const bool own = mh < SW_FH * n_mels;
+                int m = m_0, hf = hf_0, lo = lo_0, cnt = cnt_0, o = o_0, cmax = cmax_0;
+                if (pass > 0) {
+                    m = own ? mh / SW_FH : 0; hf = mh % SW_FH;
+                    lo = own ? band_lo[m] : 0; cnt = own ? band_cnt[m] : 0; o = boff[m];
+                    cmax = wave_max_i(cnt);
                 }
                 const int fb = f0 + hf * 8;
+                float mk[8];
 #pragma unroll
-                for (int f = 0; f < 8; ++f) {
-                    const float acc = f < 4 ? a0[f] : a1[f - 4];
-                    const float S = 6.02059991327962f * __builtin_amdgcn_logf(fmaxf(min_level, acc)) - ref_db;      // 20 log10(x) = 6.0206 log2(x); v_log_f32: 1 ulp
-                    float nrm = (S - min_db) * inv_mdb;
-                    nrm = fminf(fmaxf(nrm, 0.f), 1.f);
-                    const float mk = (mask && fb + f < frames) ? mask[(size_t)clip * frames + fb + f] : 1.f;
-                    if (tiled) otile[m * SW_OT + (fb - F0) + f] = nrm * mk;
-                    else if (fb + f < frames) mel[((size_t)clip * n_mels + m) * frames + fb + f] = nrm * mk;
+                for (int f = 0; f < 8; ++f) mk[f] = 1.f;
+                if (mask != nullptr) {                                                            // (uniform) requested before the walk; frames past the end read as zero and are not stored
+                    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)(mask + (size_t)clip * frames), 0, frames * 4, 0x00020000);
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) mk[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, (fb + f) * 4, 0, 0));
+                }
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+                const float* mg = mag + lo * SW_MP + hf * 8;
+                if (wl) {
+#pragma unroll 4
+                    for (int i = 0; i < cmax; ++i) {
+                        const bool in = i < cnt;
+                        const int ii = in ? i : 0;
+                        const float wt = in ? wts[o + ii] : 0.f;
+                        const f32x4 m0 = *reinterpret_cast<const f32x4*>(mg + ii * SW_MP), m1 = *reinterpret_cast<const f32x4*>(mg + ii * SW_MP + 4);
+                        a0 += wt * m0; a1 += wt * m1;
+                    }
+                } else {
+                    for (int i = 0; i < cmax; ++i) {
+                        const bool in = i < cnt;
+                        const int ii = in ? i : 0;
+                        const float wt = in ? basis_t[(size_t)(lo + ii) * n_mels + m] : 0.f;
+                        const f32x4 m0 = *reinterpret_cast<const f32x4*>(mg + ii * SW_MP), m1 = *reinterpret_cast<const f32x4*>(mg + ii * SW_MP + 4);
+                        a0 += wt * m0; a1 += wt * m1;
+                    }
+                }
+                if (own) {
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) {
+                        const float acc = f < 4 ? a0[f] : a1[f - 4];
+                        const float S = 6.02059991327962f * __builtin_amdgcn_logf(fmaxf(min_level, acc)) - ref_db;      // 20 log10(x) = 6.0206 log2(x); v_log_f32: 1 ulp
+                        float nrm = (S - min_db) * inv_mdb;
+                        nrm = fminf(fmaxf(nrm, 0.f), 1.f);
+                        if (tiled) otile[m * SW_OT + (fb - F0) + f] = nrm * mk[f];
+                        else if (fb + f < frames) mel[((size_t)clip * n_mels + m) * frames + fb + f] = nrm * mk[f];
+                    }
                 }
             }
             __syncthreads();                                                               // the magnitude table is rewritten by the next iteration
@@ -380,12 +449,25 @@ __global__ __launch_bounds__(64 * SW_NW) __attribute__((amdgpu_waves_per_eu(2)))
             // the tile's rows out as runs of up to 32 consecutive frames: lane = frame, two bands per wave instruction
             const int nf = min(SW_TF, frames - F0);
             for (int idx = tid; idx < n_mels * SW_TF; idx += NT) {
-                const int m = idx >> 5, f = idx & 31;
+                const int m = idx / SW_TF, f = idx % SW_TF;
                 if (f < nf) mel[((size_t)clip * n_mels + m) * frames + F0 + f] = otile[m * SW_OT + f];
             }
             __syncthreads();
         }
     }
+}
+
+template <int NW, int TF, int MP, int WCAP, int MMAX>
+int launch_stft_wave(int per_cu, const float* wav, const float* window, const float* basis_t, const int* band_lo, const int* band_cnt, const float* mask, float* mel,
+                     int B, int n_samples, int hop, int n_mels, int frames, float min_db, float ref_db, hipStream_t st) {
+    using Cfg = SwCfg<NW, TF, MP, WCAP, MMAX>;
+    auto kern = stft_mel_wave_kernel<NW, TF, MP, WCAP, MMAX>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::lds); attr = true; }
+    const long groups = (long)B * ((frames + TF - 1) / TF);
+    const int grid = (int)(groups < 256 * per_cu ? groups : 256 * per_cu);      // persistent blocks
+    VIAI_LAUNCH(kern, dim3(grid), dim3(Cfg::NT), Cfg::lds, st, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_db, ref_db);
+    return viai_launch_status();
 }
 
 }  // namespace
@@ -396,17 +478,11 @@ extern "C" int viai_stft_mel_banded(const float* wav, const float* window, const
                                     float min_level_db, float ref_level_db, void* stream) {
     if (B <= 0 || frames <= 0 || hop <= 0 || hop > fft || n_mels <= 0 || fft != SB_N || band_lo == nullptr || band_cnt == nullptr) return (int)hipErrorInvalidValue;
     static int wave_kernel = -1;
-    if (wave_kernel < 0) { const char* e = getenv("VIAI_STFT_WAVE"); wave_kernel = e ? atoi(e) : 1; }
-    if (wave_kernel && n_mels <= 1024) {
-        constexpr int ldsw = SW_NW * SW_WREG * 8 + 516 * SW_MP * 4 + SW_WCAP * 4 + 1032 * 4 + 64 * 8 + SW_OMEL * SW_OT * 4;
-        static bool attr_w = false;
-        if (!attr_w) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw); attr_w = true; }
-        const long groups = (long)B * ((frames + SW_TF - 1) / SW_TF);
-        const int grid = (int)(groups < 256 ? groups : 256);                     // persistent: one 8-wave block per CU
-        VIAI_LAUNCH(stft_mel_wave_kernel, dim3(grid), dim3(64 * SW_NW), ldsw, (hipStream_t)stream, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels,
-                    frames, min_level_db, ref_level_db);
-        return viai_launch_status();
-    }
+    if (wave_kernel < 0) { const char* e = getenv("VIAI_STFT_WAVE"); wave_kernel = e ? atoi(e) : 1; }       // 0: frame-batched kernel, 1: one 8-wave block per CU (default), 2: two 4-wave blocks per CU (measured: 551 vs 523 us)
+    if (wave_kernel == 2 && n_mels <= 256)
+        return launch_stft_wave<4, 16, 8, 1024, 256>(2, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
+    if (wave_kernel && n_mels <= 1024)
+        return launch_stft_wave<8, 32, 20, 2048, 1024>(1, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
     constexpr int lds = (8 * SB_N + 768) * (int)sizeof(float2);
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_banded_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
