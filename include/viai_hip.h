@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 13
+#define VIAI_ABI_VERSION 14
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -457,6 +457,11 @@ int viai_conv2d_p16_ok(const viai_conv2d* c);
 /* z (P16) = act(scale * y + shift); gamma / beta (NULL = 1 / 0) and m_stat give the bound; *z_amax receives it.  act: none / ReLU / LeakyReLU */
 int viai_bn_act_fwd_p16(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
                         float* z, long M, int C, int act, float slope, float* z_amax, void* stream);
+/* viai_bn_add_act_fwd_amax (the residual join of networks/ResNet.py:49-53) writing z twice: fp32 (z, exact maximum to *z_amax: the next join's residual, the
+ * backward's mask) and P16 (z_p16, bound |gamma| sqrt(m_stat - 1) + |beta| + *res_amax to *p_amax: what the next block's conv1 stages).  C / 4 a power of two <= 256 */
+int viai_bn_add_act_fwd_twin(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
+                             const float* res, const float* res_amax, float* z, float* z_p16, long M, int C, int act, float slope,
+                             float* z_amax, float* p_amax, void* stream);
 /* viai_bn_act_bilinear_fwd_amax with the resized tensor written as P16 */
 int viai_bn_act_bilinear_fwd_p16(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
                                  float* out, int N, int IH, int IW, int OH, int OW, int C, int act, float slope, float* z_amax, void* stream);

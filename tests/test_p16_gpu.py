@@ -319,3 +319,61 @@ def test_discriminator_and_decoder_block_run_presplit_and_agree_with_the_fp32_pa
     assert rel(res[True][3], res[False][3]) < 1e-4
     for ga, gb in zip(res[True][1] + res[True][4], res[False][1] + res[False][4]):
         assert rel(ga, gb) < 2e-3, rel(ga, gb)
+
+
+@pytest.mark.parametrize("Cc", [64, 128, 512])
+@pytest.mark.parametrize("act", [0, 1], ids=["none", "relu"])
+def test_residual_join_twin_is_the_fp32_join_and_its_split(Cc, act):
+    """viai_bn_add_act_fwd_twin (ABI 14): z is bit for bit viai_bn_add_act_fwd_amax's, the planes decode to it, the bound adds max |res|
+    (the join of networks/ResNet.py:49-53)."""
+    from viai_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(7 * Cc + act)
+    M = 6001
+    y = torch.randn(M, Cc, device="cuda", generator=gen) * 2
+    res = torch.randn(M, Cc, device="cuda", generator=gen).abs() * 1.5
+    gamma, beta, mean, invstd, scale, shift = _bn_coeffs(Cc, gen)
+    ra = res.abs().max().reshape(1).contiguous()
+    z0, a0 = torch.empty_like(y), torch.zeros(1, device="cuda")
+    _lib.check(lib.viai_bn_add_act_fwd_amax(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr(), z0.data_ptr(), M, Cc, act, 0.2, a0.data_ptr(), _st()), "join")
+    z, zp, a1, pa = torch.empty_like(y), torch.empty_like(y), torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    _lib.check(lib.viai_bn_add_act_fwd_twin(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, res.data_ptr(), ra.data_ptr(),
+                                            z.data_ptr(), zp.data_ptr(), M, Cc, act, 0.2, a1.data_ptr(), pa.data_ptr(), _st()), "twin")
+    assert torch.equal(z, z0) and float(a1) == float(a0) == float(z0.abs().max())
+    bound = float(pa)
+    want = float((gamma.abs() * (M - 1) ** 0.5 + beta.abs()).max()) + float(ra)
+    assert want <= bound <= want * 1.01 and float(z.abs().max()) <= bound
+    d = decode(zp, pa)
+    S = 2.0 ** (14 - (torch.tensor(bound).log2().floor().item() + 1))
+    err = (d - z).abs()
+    tol = z.abs() * 2.0 ** -21 + 2.0 ** -24 / S
+    assert bool((err <= tol).all()), float((err - tol).max())
+
+
+def test_basic_block_chain_with_twins_matches_the_chain_without():
+    """two BasicBlocks (networks/ResNet.py:26-55) at a ResNet layer1 shape: with the join's twin the second block's conv1 reads planes; forward
+    and every gradient agree with the run whose conv1 splits the fp32 tensor itself (same arithmetic, a bound instead of the exact maximum as
+    the split's scale), and the twin is really taken."""
+    from viai_amd import networks, ops
+    torch.manual_seed(3)
+    b0, b1 = networks.BasicBlock(64, 64).cuda(), networks.BasicBlock(64, 64).cuda()
+    x = torch.randn(8, 56, 56, 64, device="cuda").relu()
+    g = torch.randn(8, 56, 56, 64, device="cuda")
+
+    def run(twins):
+        for m in (b0, b1):
+            m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        ops.begin_step(xi.device)
+        h = b0.forward_nhwc(xi, next_conv=b1.conv1 if twins else None)
+        took = getattr(h, "_viai_twin", None) is not None
+        out = b1.forward_nhwc(h)
+        out.backward(g)
+        torch.cuda.synchronize()
+        return took, out.detach().clone(), xi.grad.clone(), [p.grad.clone() for m in (b0, b1) for p in m.parameters()]
+
+    t0, o0, dx0, g0 = run(False)
+    t1, o1, dx1, g1 = run(True)
+    assert not t0 and t1 == ops.P16
+    for a, b in [(o0, o1), (dx0, dx1)] + list(zip(g0, g1)):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-7

@@ -22,7 +22,7 @@ class ViaiLibraryError(RuntimeError):
 
 # ABI version THIS file's SIGNATURES / struct mirrors were written against: bumped together with them.  load() compares it with the
 # library, and with the committed header where that is present (a source checkout), so a stale _lib.py cannot call a rebuilt .so.
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 def _header_abi_version():
@@ -176,6 +176,7 @@ SIGNATURES = {
     "viai_conv2d_cin1_bn_dgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "viai_conv2d_p16_ok": (_I, [_CP]),
     "viai_bn_act_fwd_p16": (_I, [_P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _F, _P, _P]),
+    "viai_bn_add_act_fwd_twin": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P, _P]),
     "viai_bn_act_bilinear_fwd_p16": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "viai_conv2d_cin1_bn_fwd_p16": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P, _P]),
     "viai_pair_cout1_bn_bwd_p16": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),

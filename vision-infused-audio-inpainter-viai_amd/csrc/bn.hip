@@ -514,6 +514,46 @@ __global__ __launch_bounds__(256) void bn_act_fwd_p16_kernel(const f32x4* __rest
     for (; i < n8; i += stride) item(i, y[2 * i], y[2 * i + 1]);
 }
 
+// The residual join of a ResNet block with a P16 TWIN: z = act(scale y + shift + res) as fp32 (the next join's residual, the mask of this join's backward, the
+// 1 x 1 downsample conv) AND as the two fp16 planes zp (the next block's conv1 forward and weight gradient stage 16-byte pieces instead of splitting 822 MB of
+// fp32 per pass).  Scale of the planes: |z| <= |gamma| rad + |beta| + max |res| (res_amax: the exact maximum its producer published), in *p_amax; z's own exact
+// maximum still goes to *z_amax (fp32 consumers keep their scale bit for bit).  C / 4 a power of two <= 256, C % 32 == 0.
+template <int ACT>
+__global__ __launch_bounds__(1024) void bn_add_act_twin_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float rad,
+                                                               const f32x4* __restrict__ res, const float* __restrict__ res_amax,
+                                                               f32x4* __restrict__ z, float* __restrict__ zp, long n4, int C, float slope,
+                                                               float* __restrict__ z_amax, float* __restrict__ p_amax) {
+    float b = 0.f;
+    for (int c = threadIdx.x; c < C; c += 1024) b = fmaxf(b, fabsf(gamma[c]) * rad + fabsf(beta[c]));
+    const float bound = (block_max_all(b) + res_amax[0]) * 1.001f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p_amax = bound;
+    const float S = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f16_scale_from_amax_value(bound)))), L = f16_clamp_for_scale(S);
+    const unsigned c4n = (unsigned)(C / 4);
+    const int lg = 31 - __builtin_clz(c4n);
+    const long stride = (long)gridDim.x * 1024;
+    long i = blockIdx.x * 1024L + threadIdx.x;
+    const unsigned cq = threadIdx.x & (c4n - 1);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cq * 4), sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
+    float mx = 0.f;
+    auto one = [&](long k, const f32x4& v, const f32x4& r) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = viai_act((v[e] * sc[e] + sh[e]) + r[e], ACT, slope); mx = fmaxf(mx, fabsf(o[e])); }
+        z[k] = o;
+        p16_store_quad(zp + (k >> lg) * C, (int)cq, o, S, L);
+    };
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        f32x4 v[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u] = y[i + u * stride]; r[u] = res[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(i + u * stride, v[u], r[u]);
+    }
+    for (; i < n4; i += stride) one(i, y[i], res[i]);
+    block_absmax_to(z_amax, mx);
+}
+
 // dy (P16) = scale dpre + k1 (y - mean) + k0
 template <bool FIXED>
 __global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ y, const float* __restrict__ mean,
@@ -638,6 +678,24 @@ extern "C" int viai_bn_add_act_fwd_amax(const float* y, const float* scale, cons
     }
     if (fixed) return launch_bn_act_fwd_t<VIAI_ACT_NONE, true, true>(y, scale, shift, res, z, n4, C, slope, z_amax, st);
     return launch_bn_act_fwd_t<VIAI_ACT_NONE, false, true>(y, scale, shift, res, z, n4, C, slope, z_amax, st);
+}
+
+// viai_bn_add_act_fwd_amax with a second, pre-split (P16) copy of z for consumers that stage fp16 pieces (viai_conv2d_p16_ok): see bn_add_act_twin_kernel.
+// m_stat: the population of the BatchNorm statistics; res_amax: max |res| (device, required); p_amax receives the planes' magnitude bound.
+extern "C" int viai_bn_add_act_fwd_twin(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
+                                        const float* res, const float* res_amax, float* z, float* z_p16, long M, int C, int act, float slope,
+                                        float* z_amax, float* p_amax, void* stream) {
+    const int c4 = C / 4;
+    if (C % 32 != 0 || c4 > 256 || (c4 & (c4 - 1)) != 0 || res == nullptr || res_amax == nullptr || gamma == nullptr || beta == nullptr || z_amax == nullptr ||
+        p_amax == nullptr || z_p16 == nullptr || (act != VIAI_ACT_RELU && act != VIAI_ACT_NONE))
+        return (int)hipErrorInvalidValue;
+    const long n4 = M * C / 4;
+    hipStream_t st = (hipStream_t)stream;
+    const float rad = sqrtf((float)(m_stat > 1 ? m_stat - 1 : 1));
+    auto a0 = reinterpret_cast<const f32x4*>(y); auto a1 = reinterpret_cast<f32x4*>(z); auto a2 = reinterpret_cast<const f32x4*>(res);
+    if (act == VIAI_ACT_RELU) VIAI_LAUNCH(bn_add_act_twin_kernel<VIAI_ACT_RELU>, dim3(stream_grid(n4, 1024)), dim3(1024), 0, st, a0, scale, shift, gamma, beta, rad, a2, res_amax, a1, z_p16, n4, C, slope, z_amax, p_amax);
+    else VIAI_LAUNCH(bn_add_act_twin_kernel<VIAI_ACT_NONE>, dim3(stream_grid(n4, 1024)), dim3(1024), 0, st, a0, scale, shift, gamma, beta, rad, a2, res_amax, a1, z_p16, n4, C, slope, z_amax, p_amax);
+    return viai_launch_status();
 }
 
 extern "C" int viai_bn_act_fwd(const float* y, const float* scale, const float* shift, float* z,

@@ -142,9 +142,11 @@ def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=N
             out = ops.add_relu(out, residual) if act == ACT_RELU else out + residual
         return ops.maxpool(out, *pool) if pool is not None else out
     if FUSE_BN_TAIL and isinstance(bn, nn.modules.batchnorm._BatchNorm) and act in (ACT_RELU, ACT_NONE) and (residual is not None or pool is not None):
+        # a residual join whose output feeds `next_conv` AND other readers (the next join, a downsample conv) writes a pre-split twin beside the fp32 tensor
+        twin = (next_conv is not None and residual is not None and bn.training and takes_p16(out_shape(x.shape, conv), next_conv))
         return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
                                padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2, training=bn.training, xmask=xmask,
-                               residual=residual, pool=pool)
+                               residual=residual, pool=pool, out_p16=twin)
     p16 = (next_conv is not None and residual is None and pool is None and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training
            and takes_p16(out_shape(x.shape, conv), next_conv))
     out = ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
@@ -510,10 +512,11 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, next_conv=None):
+        """`next_conv`: the next block's conv1 (fused_layer: the join then writes the planes its kernels stage beside the fp32 tensor)"""
         out = fused_layer(x, self.conv1, self.bn1, ACT_RELU, next_conv=self.conv2)
         res = x if self.downsample is None else fused_layer(x, self.downsample[0], self.downsample[1], ACT_NONE)
-        return fused_layer(out, self.conv2, self.bn2, ACT_RELU, residual=res)        # relu(bn2(conv2(out)) + res), networks/ResNet.py:46-53
+        return fused_layer(out, self.conv2, self.bn2, ACT_RELU, residual=res, next_conv=next_conv)   # relu(bn2(conv2(out)) + res), networks/ResNet.py:46-53
 
     def forward(self, x):
         return to_nchw_view(self.forward_nhwc(to_nhwc(x)))
@@ -557,9 +560,9 @@ class ResNet(nn.Module):
         """x: (N, C, 224, 224) NCHW frames -> (N, length_feature)."""
         h = ops.frames_to_nhwc4(x)
         h = fused_layer(h, self.conv1, self.bn1, ACT_RELU, pool=(3, 2, 1))           # conv1 -> bn1 -> relu -> maxpool, Image_Embedding.py:20-23
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            for blk in layer:
-                h = blk.forward_nhwc(h)
+        blocks = [blk for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for blk in layer]
+        for i, blk in enumerate(blocks):
+            h = blk.forward_nhwc(h, next_conv=blocks[i + 1].conv1 if i + 1 < len(blocks) else None)
         if h.shape[1] != 7 or h.shape[2] != 7:
             raise RuntimeError("the reference ResNet (AvgPool2d(7) + fc) needs 224x224 frames")
         h = ops.avgpool_hw(h)

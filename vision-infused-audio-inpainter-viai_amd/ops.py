@@ -571,6 +571,9 @@ class _ConvBnAct(torch.autograd.Function):
         f16f = d.get("fwd_f16")
         if f16f is None:
             f16f = d["fwd_f16"] = bool(lib.viai_conv2d_fwd_f16_ok(d["ref"]))
+        twin = cfg.pop("x_twin", None)          # a pre-split copy of x beside the fp32 tensor (the residual join of a ResNet block writes both)
+        if twin is not None and not xp and x2 is None and P16 and (p16_mask(d) & P16_OK_FWD_X):
+            x, xp = twin, True                  # the kernels read the planes; the gradient still goes to the fp32 tensor this op was applied to
         if xp and (x2 is not None or (p16_mask(d) & P16_OK_FWD_X) == 0):
             x = p16_decode(x)                   # (a layer without a P16 loader: the networks of this package ask conv_takes_p16 first)
             xp = False
@@ -643,8 +646,20 @@ class _ConvBnAct(torch.autograd.Function):
                 # BatchNorm + residual add + activation in one pass (ResNet BasicBlock); z is kept: the activation's mask needs the sum
                 res = _c(res)
                 z = torch.empty_like(y)
-                _lib.check(lib.viai_bn_add_act_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), res.data_ptr(), z.data_ptr(),
-                                                        M, Cout, act, 0.2, za.data_ptr(), st), "viai_bn_add_act_fwd")
+                ra = amax_of(res)
+                c4 = Cout // 4
+                if (cfg.get("p16_out") and P16 and training and ra is not None and Cout % 32 == 0 and c4 <= 256 and (c4 & (c4 - 1)) == 0):
+                    # the next block's conv1 stages pre-split pieces: the join writes z twice (fp32 for the next join and the mask, P16 for the convs)
+                    zp = torch.empty_like(y)
+                    pa = _amax_slot(dev)
+                    _lib.check(lib.viai_bn_add_act_fwd_twin(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), gamma.data_ptr(), beta.data_ptr(), M,
+                                                            res.data_ptr(), ra.data_ptr(), z.data_ptr(), zp.data_ptr(), M, Cout, act, 0.2,
+                                                            za.data_ptr(), pa.data_ptr(), st), "viai_bn_add_act_fwd_twin")
+                    zp._viai_p16, zp._viai_amax = True, pa
+                    cfg["z_twin"] = zp
+                else:
+                    _lib.check(lib.viai_bn_add_act_fwd_amax(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), res.data_ptr(), z.data_ptr(),
+                                                            M, Cout, act, 0.2, za.data_ptr(), st), "viai_bn_add_act_fwd")
                 ctx.save_for_backward(x, x2, weight, y, coef, z)
             elif cfg.get("up") is not None:
                 # BatchNorm + activation + the F.interpolate behind the layer in one pass over y: the post-activation map is not stored
@@ -894,7 +909,8 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
            "d": tuple(dilation), "p2": tuple(padding2), "xa_in": (amax_of(x), amax_of(x2)), "xmask": xmask,
            "pool": tuple(int(v) for v in pool) if pool is not None else None,
            "up": (int(upsample[0]), int(upsample[1])) if upsample is not None else None,
-           "p16_out": bool(out_p16) and bn is not None and isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) and bn.weight is not None}
+           "p16_out": bool(out_p16) and bn is not None and isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) and bn.weight is not None,
+           "x_twin": getattr(x, "_viai_twin", None) if x2 is None else None}
     if bn is not None:
         cfg["momentum"] = 0.1 if bn.momentum is None else float(bn.momentum)
         cfg["eps"] = float(bn.eps)
@@ -937,6 +953,9 @@ def _tag_amax(z, cfg):
         z._viai_amax = za
     if cfg.pop("z_p16", False):
         z._viai_p16 = True
+    zt = cfg.pop("z_twin", None)
+    if zt is not None:
+        z._viai_twin = zt
     return z
 
 
