@@ -462,6 +462,11 @@ int viai_bn_act_fwd_p16(const float* y, const float* scale, const float* shift, 
 int viai_bn_add_act_fwd_twin(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
                              const float* res, const float* res_amax, float* z, float* z_p16, long M, int C, int act, float slope,
                              float* z_amax, float* p_amax, void* stream);
+/* viai_bn_act_maxpool_fwd (3 x 3 / stride 2 / pad 1 only) writing the pooled tensor twice: fp32 (out, exact maximum to *out_amax) and P16 (out_p16, bound to
+ * *p_amax) -- the stem of networks/Image_Embedding.py:20-23 in front of the first BasicBlock.  C % 32 == 0 */
+int viai_bn_act_maxpool_fwd_twin(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
+                                 float* out, float* out_p16, unsigned char* idx, int N, int IH, int IW, int C, int k, int s, int p, int act, float slope,
+                                 float* out_amax, float* p_amax, void* stream);
 /* viai_bn_act_bilinear_fwd_amax with the resized tensor written as P16 */
 int viai_bn_act_bilinear_fwd_p16(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
                                  float* out, int N, int IH, int IW, int OH, int OW, int C, int act, float slope, float* z_amax, void* stream);

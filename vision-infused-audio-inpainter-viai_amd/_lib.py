@@ -176,6 +176,7 @@ SIGNATURES = {
     "viai_conv2d_cin1_bn_dgrad": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "viai_conv2d_p16_ok": (_I, [_CP]),
     "viai_bn_act_fwd_p16": (_I, [_P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _F, _P, _P]),
+    "viai_bn_act_maxpool_fwd_twin": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
     "viai_bn_add_act_fwd_twin": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P, _P]),
     "viai_bn_act_bilinear_fwd_p16": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "viai_conv2d_cin1_bn_fwd_p16": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P, _P]),

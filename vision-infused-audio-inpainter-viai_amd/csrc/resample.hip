@@ -331,6 +331,53 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     if constexpr (BN) { if (amax != nullptr) block_absmax_to(amax, mx); }
 }
 
+// The stem's pool (3 x 3, stride 2, pad 1: networks/Image_Embedding.py:23) with compile-time extents: the nine window loads of an output quad are issued
+// together (clamped addresses + a validity bit each; the generic kernel above walks the window with two run-time loops and a branch per tap: one dependent
+// load at a time), 32-bit index arithmetic (fewer than 2^31 output quads).  Same candidates in the same order: the result and the argmax bytes are the generic
+// kernel's bit for bit.  TWIN: the pooled tensor is also written pre-split (P16) for the first BasicBlock's conv1; |pooled| <= |gamma| rad + |beta|.
+template <bool TWIN>
+__global__ __launch_bounds__(256) void bn_act_maxpool3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                                                  int N, int IH, int IW, int OH, int OW, int C, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int act, float slope, float* __restrict__ amax,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float rad,
+                                                                  float* __restrict__ yp, float* __restrict__ p_amax) {
+    float S = 1.f, L = 0.f;
+    if constexpr (TWIN) { S = p16_fwd_scale(gamma, beta, C, rad, p_amax); L = f16_clamp_for_scale(S); }
+    const unsigned c4n = (unsigned)(C / 4);
+    const unsigned total = (unsigned)N * OH * OW * c4n;
+    float mx = 0.f;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned c4 = i % c4n, pix = i / c4n;
+        const unsigned ox = pix % (unsigned)OW, r = pix / (unsigned)OW;
+        const unsigned oy = r % (unsigned)OH, n = r / (unsigned)OH;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4), sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        f32x4 v[9]; bool ok[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int iy = 2 * (int)oy - 1 + a, ix = 2 * (int)ox - 1 + b;
+                ok[a * 3 + b] = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+                const int iyc = min(max(iy, 0), IH - 1), ixc = min(max(ix, 0), IW - 1);
+                v[a * 3 + b] = *reinterpret_cast<const f32x4*>(x + (((size_t)n * IH + iyc) * IW + ixc) * C + c4 * 4);
+            }
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = viai_act(v[t][e] * sc[e] + sh[e], act, slope);
+                if (ok[t] && u > best[e]) { best[e] = u; bi[e] = t; }
+            }
+        *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = best;
+        *reinterpret_cast<unsigned*>(idx + (size_t)i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        if constexpr (TWIN) p16_store_quad(yp + (size_t)pix * C, (int)c4, best, S, L);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(best[0]), fabsf(best[1]))), fmaxf(fabsf(best[2]), fabsf(best[3])));
+    }
+    if (amax != nullptr) block_absmax_to(amax, mx);
+}
+
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx,
                                                           int N, int IH, int IW, int OH, int OW, int C, int k, int st, int pd) {
     const int c4n = C / 4;
@@ -547,8 +594,30 @@ extern "C" int viai_bn_act_maxpool_fwd(const float* y, const float* scale, const
     if (C % 4 != 0 || k * k > 255 || (act != VIAI_ACT_RELU && act != VIAI_ACT_NONE)) return (int)hipErrorInvalidValue;
     int OH = (IH + 2 * p - k) / s + 1, OW = (IW + 2 * p - k) / s + 1;
     long total = (long)N * OH * OW * (C / 4);
+    if (k == 3 && s == 2 && p == 1 && total < (1L << 31) - (1L << 24)) {
+        VIAI_LAUNCH(bn_act_maxpool3_fwd_kernel<false>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, out, idx, N, IH, IW, OH, OW, C, scale, shift, act, slope,
+                    out_amax, (const float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr);
+        return viai_launch_status();
+    }
     VIAI_LAUNCH(maxpool_fwd_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, out, idx, N, IH, IW, OH, OW, C, k, s, p,
                 scale, shift, act, slope, out_amax);
+    return viai_launch_status();
+}
+
+// viai_bn_act_maxpool_fwd for the 3 x 3 / stride 2 / pad 1 pool with a second, pre-split (P16) copy of the pooled tensor (C % 32 == 0) whose scale comes from
+// the bound |gamma| sqrt(m_stat - 1) + |beta| (written to *p_amax): the first BasicBlock's conv1 stages its pieces, the fp32 copy stays the first join's residual.
+extern "C" int viai_bn_act_maxpool_fwd_twin(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,
+                                            float* out, float* out_p16, unsigned char* idx, int N, int IH, int IW, int C, int k, int s, int p, int act, float slope,
+                                            float* out_amax, float* p_amax, void* stream) {
+    if (C % 32 != 0 || k != 3 || s != 2 || p != 1 || (act != VIAI_ACT_RELU && act != VIAI_ACT_NONE) || gamma == nullptr || beta == nullptr || out_p16 == nullptr ||
+        p_amax == nullptr)
+        return (int)hipErrorInvalidValue;
+    int OH = (IH + 2 * p - k) / s + 1, OW = (IW + 2 * p - k) / s + 1;
+    long total = (long)N * OH * OW * (C / 4);
+    if (total >= (1L << 31) - (1L << 24)) return (int)hipErrorInvalidValue;
+    const float rad = sqrtf((float)(m_stat > 1 ? m_stat - 1 : 1));
+    VIAI_LAUNCH(bn_act_maxpool3_fwd_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, out, idx, N, IH, IW, OH, OW, C, scale, shift, act, slope,
+                out_amax, gamma, beta, rad, out_p16, p_amax);
     return viai_launch_status();
 }
 

@@ -143,7 +143,10 @@ def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=N
         return ops.maxpool(out, *pool) if pool is not None else out
     if FUSE_BN_TAIL and isinstance(bn, nn.modules.batchnorm._BatchNorm) and act in (ACT_RELU, ACT_NONE) and (residual is not None or pool is not None):
         # a residual join whose output feeds `next_conv` AND other readers (the next join, a downsample conv) writes a pre-split twin beside the fp32 tensor
-        twin = (next_conv is not None and residual is not None and bn.training and takes_p16(out_shape(x.shape, conv), next_conv))
+        oshape = out_shape(x.shape, conv)
+        if pool is not None:
+            oshape = (oshape[0], (oshape[1] + 2 * pool[2] - pool[0]) // pool[1] + 1, (oshape[2] + 2 * pool[2] - pool[0]) // pool[1] + 1, oshape[3])
+        twin = next_conv is not None and bn.training and takes_p16(oshape, next_conv)
         return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
                                padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2, training=bn.training, xmask=xmask,
                                residual=residual, pool=pool, out_p16=twin)
@@ -559,8 +562,8 @@ class ResNet(nn.Module):
     def forward(self, x):
         """x: (N, C, 224, 224) NCHW frames -> (N, length_feature)."""
         h = ops.frames_to_nhwc4(x)
-        h = fused_layer(h, self.conv1, self.bn1, ACT_RELU, pool=(3, 2, 1))           # conv1 -> bn1 -> relu -> maxpool, Image_Embedding.py:20-23
         blocks = [blk for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for blk in layer]
+        h = fused_layer(h, self.conv1, self.bn1, ACT_RELU, pool=(3, 2, 1), next_conv=blocks[0].conv1)   # conv1 -> bn1 -> relu -> maxpool, Image_Embedding.py:20-23
         for i, blk in enumerate(blocks):
             h = blk.forward_nhwc(h, next_conv=blocks[i + 1].conv1 if i + 1 < len(blocks) else None)
         if h.shape[1] != 7 or h.shape[2] != 7:

@@ -639,8 +639,17 @@ class _ConvBnAct(torch.autograd.Function):
                 PH, PW = (OH + 2 * p_ - k_) // s_ + 1, (OW + 2 * p_ - k_) // s_ + 1
                 z = torch.empty((N, PH, PW, Cout), device=dev, dtype=torch.float32)
                 pidx = torch.empty((N, PH, PW, Cout), device=dev, dtype=torch.uint8)
-                _lib.check(lib.viai_bn_act_maxpool_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(), pidx.data_ptr(),
-                                                       N, OH, OW, Cout, k_, s_, p_, act, 0.2, za.data_ptr(), st), "viai_bn_act_maxpool_fwd")
+                if cfg.get("p16_out") and P16 and training and Cout % 32 == 0 and (k_, s_, p_) == (3, 2, 1) and z.numel() // 4 < (1 << 31) - (1 << 24):
+                    zp = torch.empty_like(z)
+                    pa = _amax_slot(dev)
+                    _lib.check(lib.viai_bn_act_maxpool_fwd_twin(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), gamma.data_ptr(), beta.data_ptr(), M,
+                                                                z.data_ptr(), zp.data_ptr(), pidx.data_ptr(), N, OH, OW, Cout, k_, s_, p_, act, 0.2,
+                                                                za.data_ptr(), pa.data_ptr(), st), "viai_bn_act_maxpool_fwd_twin")
+                    zp._viai_p16, zp._viai_amax = True, pa
+                    cfg["z_twin"] = zp
+                else:
+                    _lib.check(lib.viai_bn_act_maxpool_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), z.data_ptr(), pidx.data_ptr(),
+                                                           N, OH, OW, Cout, k_, s_, p_, act, 0.2, za.data_ptr(), st), "viai_bn_act_maxpool_fwd")
                 ctx.save_for_backward(x, x2, weight, y, coef, pidx)
             elif res is not None:
                 # BatchNorm + residual add + activation in one pass (ResNet BasicBlock); z is kept: the activation's mask needs the sum
