@@ -350,11 +350,12 @@ def test_residual_join_twin_is_the_fp32_join_and_its_split(Cc, act):
     assert bool((err <= tol).all()), float((err - tol).max())
 
 
-def test_basic_block_chain_with_twins_matches_the_chain_without():
+def test_basic_block_chain_with_twins_matches_the_chain_without(monkeypatch):
     """two BasicBlocks (networks/ResNet.py:26-55) at a ResNet layer1 shape: with the join's twin the second block's conv1 reads planes; forward
     and every gradient agree with the run whose conv1 splits the fp32 tensor itself (same arithmetic, a bound instead of the exact maximum as
     the split's scale), and the twin is really taken."""
     from viai_amd import networks, ops
+    monkeypatch.setattr(networks, "P16_TWIN", True)          # (opt-in: VIAI_P16_TWIN)
     torch.manual_seed(3)
     b0, b1 = networks.BasicBlock(64, 64).cuda(), networks.BasicBlock(64, 64).cuda()
     x = torch.randn(8, 56, 56, 64, device="cuda").relu()
@@ -364,6 +365,7 @@ def test_basic_block_chain_with_twins_matches_the_chain_without():
         for m in (b0, b1):
             m.zero_grad(set_to_none=True)
         xi = x.clone().requires_grad_(True)
+        xi._viai_amax = x.abs().max().reshape(1)          # (as the stem's pool publishes it: the twin's bound adds max |residual|)
         ops.begin_step(xi.device)
         h = b0.forward_nhwc(xi, next_conv=b1.conv1 if twins else None)
         took = getattr(h, "_viai_twin", None) is not None

@@ -98,6 +98,13 @@ FLOW_STREAM = os.environ.get("VIAI_FLOW_STREAM", "1") != "0"           # ImageEm
 FUSE_BN_TAIL = os.environ.get("VIAI_FUSE_BN_TAIL", "1") != "0"      # BatchNorm apply + (residual add + ReLU | ReLU + max-pool) in one pass (A/B switch)
 
 
+# Residual joins / the stem's pool can write a pre-split (P16) twin of their output for the next BasicBlock's conv1 (ops.conv_bn_act `out_p16` on a layer with
+# `residual` / `pool`).  Measured on the vision-infused step: the kernel-time sum falls 224 -> 212 ms (the conv1 forward / weight-gradient kernels stop
+# splitting), the step does not move (118.7 without, 119.0 with: both queues stay full, the chip is at its power / bandwidth limit and the twin adds a write
+# of the tensor) -- so it is OFF by default; `VIAI_P16_TWIN=1` and tests/test_p16_gpu.py keep it alive.
+P16_TWIN = os.environ.get("VIAI_P16_TWIN", "0") != "0"
+
+
 def takes_p16(x_shape, conv):
     """will `conv` (the layer behind a BatchNorm pass) stage a pre-split (P16) input of this NHWC shape?  (ops.conv_takes_p16)"""
     tr = isinstance(conv, nn.ConvTranspose2d)
@@ -146,7 +153,7 @@ def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=N
         oshape = out_shape(x.shape, conv)
         if pool is not None:
             oshape = (oshape[0], (oshape[1] + 2 * pool[2] - pool[0]) // pool[1] + 1, (oshape[2] + 2 * pool[2] - pool[0]) // pool[1] + 1, oshape[3])
-        twin = next_conv is not None and bn.training and takes_p16(oshape, next_conv)
+        twin = P16_TWIN and next_conv is not None and bn.training and takes_p16(oshape, next_conv)
         return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
                                padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2, training=bn.training, xmask=xmask,
                                residual=residual, pool=pool, out_p16=twin)
