@@ -309,6 +309,35 @@ def launch_modes(hp, dev, s, mask, steps=30):
     return out
 
 
+def dvfs_probe(dev):
+    """The dominant kernel's launch on random and on all-zero operands (same instruction stream, same cycles): the ratio is the clock the power budget
+    takes away under this kernel (MI355X_MICROARCH.md 'DVFS give-back'; DESIGN.md 9.5b, profiles/r04_d_clock_dconv3*.txt)."""
+    from viai_amd import ops
+    N, H, W, Ci, Co = 16, 64, 32, 256, 512                        # D.conv3 of the metric config (Discriminator_Networks.py:44)
+    res = {}
+    for name, k in (("random", 1.0), ("zero", 0.0)):
+        x = (torch.rand(N, H, W, Ci, device=dev) * 2 - 1) * k
+        w = (torch.rand(Co, Ci, 3, 3, device=dev) - 0.5) * 0.1 * k
+        x._viai_amax = torch.ones(1, device=dev)                  # the operand magnitude a producer would publish (|x| <= 1): no abs-max pass in the timed loop
+        with torch.no_grad():
+            for _ in range(5):
+                ops.begin_step(dev)
+                ops.conv_bn_act(x, w, None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1), act=ops.ACT_NONE)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                ops.conv_bn_act(x, w, None, None, kernel=(3, 3), stride=(1, 1), padding=(1, 1), act=ops.ACT_NONE)
+            e1.record()
+            torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / 20 * 1e3
+    return {"layer": "D.conv3 forward, 16x64x32x256 -> 512 (the dominant kernel's largest launch), 20 back-to-back launches each",
+            "random_operand_us": round(res["random"], 1), "zero_operand_us": round(res["zero"], 1), "ratio": round(res["zero"] / res["random"], 3),
+            "note": "identical instruction stream and cycle count on all-zero operands: the difference is the shader clock under the kernel's power draw "
+                    "(profiles/r04_d_clock_dconv3.txt: 1.5 GHz with random operands against 2.15 GHz with zeros, 76 % of the MFMA issue slots taken in "
+                    "both) -- roofline.frac prices the launch against the 2.4 GHz peak"}
+
+
 def front_end_stages(dev, batch, bins, frames):
     """north_star: achieved HBM GB/s of the STFT / mask stages.  Algorithmic bytes: STFT -> mel reads the
     waveform (4 B x 65 536 samples per clip) and writes the mel (4 B x F x T); the mask multiply reads and writes the mel once."""
@@ -657,6 +686,8 @@ def main():
             out["config"]["algorithmic_gflop_note"] = "2 x MACs of every conv launch of the step (forward, data gradient, weight gradient), summed by the instrumented pass"
         if alone is not None:
             out["roofline"]["standalone"] = alone
+        if world == 1 and not av and BF3:
+            out["roofline"]["power_limit"] = dvfs_probe(dev)
         # memory-side traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
         # number comes from the committed counter summary of the same kernel on its largest layer (D.conv3)
         import glob

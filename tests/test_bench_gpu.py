@@ -55,6 +55,9 @@ def test_kernel_families_come_from_the_library():
     # the timed conv flops of the step are the SURVEY's 1 208 GFLOP (section 8d) to within the first-layer data gradients it leaves out
     assert abs(out["roofline"]["conv_gflop_per_step_timed"] - 1208.0) < 0.01 * 1208.0
     assert out["config"]["workload"].startswith("configs[1]") and out["n_gpus"] == 1 and "stages" in out
+    # the live DVFS probe: the dominant kernel's launch on zero operands is never slower than on random ones (same cycles, higher clock)
+    pl = out["roofline"]["power_limit"]
+    assert 0.4 < pl["ratio"] <= 1.05 and pl["random_operand_us"] > 50
 
 
 @pytest.mark.parametrize("config", ["av", "av_msd"])
