@@ -457,6 +457,191 @@ __global__ __launch_bounds__(64 * SW_NW) __attribute__((amdgpu_waves_per_eu(2)))
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// One real frame per wave as a 512-point complex FFT (late round 4).  The kernel above holds 16 complex points per lane (240 registers: two waves per SIMD) and
+// sits at the per-WAVE issue limit of the vector pipe (`tools/probes/valu_rate.hip`: one wave issues a VALU instruction every ~5 - 7 cycles, the SIMD accepts one
+// per 2).  Here z[n] = x[2n] + i x[2n+1], n < 512 (the even / odd samples of ONE windowed frame), 8 points per lane, <= 128 registers: sixteen waves per CU.
+//   512 = 8 x 8 x 8:  radix-8 in registers over n1 (n = n2 + 64 n1, lane = n2: one coalesced 8-byte load per point) -> twiddle W512^(k1 n2) ->
+//   transpose through LDS ([k1][n2], rows of 72) -> lane (k1, a): radix-8 over b (n2 = a + 8 b) -> twiddle W64^(a kb) -> transpose ([k1][kb][a], rows of 10) ->
+//   lane k1 + 8 kb: radix-8 over a -> Z[k], k = lane + 64 ka in register ka (natural order);
+//   real spectrum X[k] = (Z[k] + conj Z[512 - k]) / 2 - i W1024^k (Z[k] - conj Z[512 - k]) / 2: the partner sits in lane 64 - lane, register 7 - ka (lane 0:
+//   its own register 8 - ka) and is fetched with ds_bpermute (no LDS storage); |X| into the block's [bin][16 frames] table; band walk and output tile as above
+//   with a thread per (band, four frames).
+constexpr int R5_NW = 16, R5_TF = 32, R5_MP = 20, R5_WCAP = 1024, R5_MMAX = 256, R5_OT = R5_TF + 1;
+constexpr int R5_ROW1 = 72, R5_ROW2 = 10, R5_WREG = 640;           // c32 per wave region: max(8 x 72, 64 x 10)
+constexpr int R5_LDS = R5_NW * R5_WREG * 8 + 516 * R5_MP * 4 + R5_WCAP * 4 + (R5_MMAX + 8) * 4 + SW_OMEL * R5_OT * 4 + 64 * 8;
+// forward 8-point DFT of v[0..7] in place, natural order in and out: X[2m] = DFT4(v[n] + v[n + 4])[m], X[2m + 1] = DFT4((v[n] - v[n + 4]) W8^n)[m]
+__device__ __forceinline__ void dft8(c32 (&v)[8]) {
+    constexpr float H = 0.70710678118654752f;
+    c32 e0 = v[0] + v[4], o0 = v[0] - v[4], e1 = v[1] + v[5], o1 = v[1] - v[5], e2 = v[2] + v[6], o2 = v[2] - v[6], e3 = v[3] + v[7], o3 = v[3] - v[7];
+    o1 = c32{(o1.x + o1.y) * H, (o1.y - o1.x) * H};            // * (1 - i) / sqrt 2
+    o2 = c32{o2.y, -o2.x};                                      // * -i
+    o3 = c32{(o3.y - o3.x) * H, -(o3.x + o3.y) * H};           // * -(1 + i) / sqrt 2
+    dft4(e0, e1, e2, e3);
+    dft4(o0, o1, o2, o3);
+    v[0] = e0; v[2] = e1; v[4] = e2; v[6] = e3;
+    v[1] = o0; v[3] = o1; v[5] = o2; v[7] = o3;
+}
+__device__ __forceinline__ float lane_from(float x, int src_lane) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, x))); }
+
+__global__ __launch_bounds__(64 * R5_NW) void stft_mel_r512_kernel(const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ basis_t,
+                                                                    const int* __restrict__ band_lo, const int* __restrict__ band_cnt, const float* __restrict__ mask,
+                                                                    float* __restrict__ mel, int n_clips, int n_samples, int hop, int n_mels, int frames,
+                                                                    float min_db, float ref_db) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+    constexpr int NT = 64 * R5_NW;
+    c32* ebuf = reinterpret_cast<c32*>(smem_r);                                   // [16 waves][R5_WREG]
+    float* mag = reinterpret_cast<float*>(ebuf + R5_NW * R5_WREG);                 // [513][16 frames (+4)]
+    float* wts = mag + 516 * R5_MP;                                                // band weights, band after band
+    int* boff = reinterpret_cast<int*>(wts + R5_WCAP);                             // [n_mels + 1]
+    float* otile = reinterpret_cast<float*>(boff + R5_MMAX + 8);                   // [n_mels][33]
+    c32* t64 = reinterpret_cast<c32*>(otile + SW_OMEL * R5_OT);                    // [a][kb] W64^(a kb)
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) {
+        int o = 0;
+        for (int m = 0; m < n_mels; ++m) { boff[m] = o; o += band_cnt[m]; }
+        boff[n_mels] = o;
+    }
+    if (tid < 64) { float sn, cs; sincospif(-(float)((tid >> 3) * (tid & 7)) * (1.0f / 32.0f), &sn, &cs); t64[tid] = c32{cs, sn}; }
+    __syncthreads();
+    const bool wl = boff[n_mels] <= R5_WCAP;
+    if (wl)
+        for (int m = tid; m < n_mels; m += NT) {
+            const int lo = band_lo[m], cnt = band_cnt[m], o = boff[m];
+            for (int i = 0; i < cnt; ++i) wts[o + i] = basis_t[(size_t)(lo + i) * n_mels + m];
+        }
+    // ---- once per thread: window pairs, the three twiddle sets of its lane
+    const int n2 = lane, k1r = lane >> 3, a = lane & 7;
+    c32 win[8], tw1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        win[i] = c32{window[2 * (n2 + 64 * i)], window[2 * (n2 + 64 * i) + 1]};
+        float sn, cs;
+        sincospif(-(float)(i * n2) * (1.0f / 256.0f), &sn, &cs); tw1[i] = c32{cs, sn};       // W512^(k1 n2), k1 = i
+    }
+    float sn0, cs0;
+    sincospif(-(float)lane * (1.0f / 512.0f), &sn0, &cs0);
+    const c32 wk0 = {cs0, sn0};                                                            // W1024^lane; W1024^(lane + 64 ka) = wk0 W16^ka
+    const float min_level = exp10f(min_db / 20.f), inv_mdb = -1.f / min_db;
+    c32* E = ebuf + w * R5_WREG;
+    const int gpc = (frames + R5_TF - 1) / R5_TF, total = n_clips * gpc;
+    const int per = (total + gridDim.x - 1) / gridDim.x;
+    const int g_end = min(total, (int)(blockIdx.x + 1) * per);
+    // a thread's mel item: band tid >> 2, frames 4 (tid & 3) .. + 4 of the sixteen
+    const bool own = tid < 4 * n_mels;
+    const int m_ = own ? tid >> 2 : 0, qf = tid & 3;
+    const int lo_ = own ? band_lo[m_] : 0, cnt_ = own ? band_cnt[m_] : 0, o_ = boff[m_];
+    const int cmax = wave_max_i(cnt_);
+    const int partner = (64 - lane) & 63;
+    __syncthreads();
+    for (int gi = blockIdx.x * per; gi < g_end; ++gi) {
+        const int clip = gi / gpc, F0 = (gi - clip * gpc) * R5_TF;
+        const float* y = wav + (size_t)clip * n_samples;
+        for (int sub = 0; sub < R5_TF / R5_NW; ++sub) {
+            const int f0 = F0 + sub * R5_NW;
+            if (f0 >= frames) break;                                                       // (uniform)
+            const int fa = f0 + w;
+            const int ia = fa * hop - (1024 - hop);
+            // (range-checked buffer loads: the zero padding on either side and frames past the end read as zero; hop and n_samples are even, so a pair never straddles)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, fa < frames ? n_samples * 4 : 0, 0x00020000);
+            const int ob = (ia + 2 * n2) * 4;
+            c32 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = __builtin_bit_cast(c32, __builtin_amdgcn_raw_buffer_load_b64(rs, ob + 512 * i, 0, 0)) * win[i];      // (indexing the builtin's result element-wise compiled to a ONE-dword load)
+            }
+            dft8(v);                                                                       // over n1 -> k1
+#pragma unroll
+            for (int i = 1; i < 8; ++i) v[i] = cmulc(v[i], tw1[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) E[i * R5_ROW1 + n2] = v[i];
+            wave_lds_sync();
+#pragma unroll
+            for (int b = 0; b < 8; ++b) v[b] = E[k1r * R5_ROW1 + a + 8 * b];
+            wave_lds_sync();
+            dft8(v);                                                                       // over b -> kb
+#pragma unroll
+            for (int i = 1; i < 8; ++i) v[i] = cmulc(v[i], t64[a * 8 + i]);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) E[(k1r * 8 + kb) * R5_ROW2 + a] = v[kb];
+            wave_lds_sync();
+            {   // lane = k1 + 8 kb reads its eight a's: 64 contiguous bytes
+                const f32x4* src = reinterpret_cast<const f32x4*>(E + ((lane & 7) * 8 + (lane >> 3)) * R5_ROW2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const f32x4 t = src[j]; v[2 * j] = c32{t[0], t[1]}; v[2 * j + 1] = c32{t[2], t[3]}; }
+            }
+            wave_lds_sync();                                                               // (the region is rewritten by the next iteration's first transpose)
+            dft8(v);                                                                       // over a -> ka: v[ka] = Z[lane + 64 ka]
+            // ---- the real spectrum of the frame: partner Z[512 - k]
+            c32 p[8];
+#pragma unroll
+            for (int ka = 0; ka < 8; ++ka) {
+                const c32 q = {lane_from(v[7 - ka].x, partner), lane_from(v[7 - ka].y, partner)};
+                const c32 self = ka == 0 ? v[0] : v[8 - ka];                                // lane 0: 512 - 64 ka = 64 (8 - ka), Z[512] = Z[0]
+                p[ka] = lane == 0 ? self : q;
+            }
+            constexpr float W16C[8] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+            constexpr float W16S[8] = {0.f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+#pragma unroll
+            for (int ka = 0; ka < 8; ++ka) {
+                const int k = lane + 64 * ka;
+                const c32 z = v[ka], q = p[ka];
+                const float er = z.x + q.x, ei = z.y - q.y, dr = z.x - q.x, di = z.y + q.y;        // E = Z + conj P, D = Z - conj P
+                const c32 wk = cmulc(wk0, c32{W16C[ka], W16S[ka]});
+                const float tr = dr * wk.x - di * wk.y, ti = dr * wk.y + di * wk.x;                // T = W D
+                const float xr = er + ti, xi = ei - tr;                                             // 2 X = E - i T
+                mag[k * R5_MP + w] = 0.5f * __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+            }
+            if (lane == 0) mag[512 * R5_MP + w] = fabsf(v[0].x - v[0].y);                           // X[512] = Re Z[0] - Im Z[0]
+            __syncthreads();
+            // ---- mel bands: a thread owns (band, four frames); wave-uniform trip count (see the kernel above)
+            {
+                const int fb = f0 + qf * 4;
+                float mk[4] = {1.f, 1.f, 1.f, 1.f};
+                if (mask != nullptr) {
+                    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)(mask + (size_t)clip * frames), 0, frames * 4, 0x00020000);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) mk[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, (fb + f) * 4, 0, 0));
+                }
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* mg = mag + lo_ * R5_MP + qf * 4;
+                if (wl) {
+#pragma unroll 4
+                    for (int i = 0; i < cmax; ++i) {
+                        const bool in = i < cnt_;
+                        const int ii = in ? i : 0;
+                        const float wt = in ? wts[o_ + ii] : 0.f;
+                        acc += wt * *reinterpret_cast<const f32x4*>(mg + ii * R5_MP);
+                    }
+                } else {
+                    for (int i = 0; i < cmax; ++i) {
+                        const bool in = i < cnt_;
+                        const int ii = in ? i : 0;
+                        const float wt = in ? basis_t[(size_t)(lo_ + ii) * n_mels + m_] : 0.f;
+                        acc += wt * *reinterpret_cast<const f32x4*>(mg + ii * R5_MP);
+                    }
+                }
+                if (own) {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const float S = 6.02059991327962f * __builtin_amdgcn_logf(fmaxf(min_level, acc[f])) - ref_db;
+                        float nrm = (S - min_db) * inv_mdb;
+                        nrm = fminf(fmaxf(nrm, 0.f), 1.f);
+                        otile[m_ * R5_OT + (fb - F0) + f] = nrm * mk[f];
+                    }
+                }
+            }
+            __syncthreads();                                                               // the magnitude table is rewritten by the next iteration
+        }
+        const int nf = min(R5_TF, frames - F0);
+        for (int idx = tid; idx < n_mels * R5_TF; idx += NT) {
+            const int m = idx / R5_TF, f = idx % R5_TF;
+            if (f < nf) mel[((size_t)clip * n_mels + m) * frames + F0 + f] = otile[m * R5_OT + f];
+        }
+        __syncthreads();
+    }
+}
+
 template <int NW, int TF, int MP, int WCAP, int MMAX>
 int launch_stft_wave(int per_cu, const float* wav, const float* window, const float* basis_t, const int* band_lo, const int* band_cnt, const float* mask, float* mel,
                      int B, int n_samples, int hop, int n_mels, int frames, float min_db, float ref_db, hipStream_t st) {
@@ -478,7 +663,16 @@ extern "C" int viai_stft_mel_banded(const float* wav, const float* window, const
                                     float min_level_db, float ref_level_db, void* stream) {
     if (B <= 0 || frames <= 0 || hop <= 0 || hop > fft || n_mels <= 0 || fft != SB_N || band_lo == nullptr || band_cnt == nullptr) return (int)hipErrorInvalidValue;
     static int wave_kernel = -1;
-    if (wave_kernel < 0) { const char* e = getenv("VIAI_STFT_WAVE"); wave_kernel = e ? atoi(e) : 1; }       // 0: frame-batched kernel, 1: one 8-wave block per CU (default), 2: two 4-wave blocks per CU (measured: 551 vs 523 us)
+    if (wave_kernel < 0) { const char* e = getenv("VIAI_STFT_WAVE"); wave_kernel = e ? atoi(e) : 3; }       // 0: frame-batched kernel, 1: one 8-wave block per CU (523 us on 1024 clips), 2: two 4-wave blocks per CU (551), 3 (default): a frame per wave as a 512-point FFT (455 - 480)
+    if (wave_kernel == 3 && n_mels <= R5_MMAX && hop % 2 == 0 && n_samples % 2 == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_r512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R5_LDS); attr = true; }
+        const long groups = (long)B * ((frames + R5_TF - 1) / R5_TF);
+        const int grid = (int)(groups < 256 ? groups : 256);
+        VIAI_LAUNCH(stft_mel_r512_kernel, dim3(grid), dim3(64 * R5_NW), R5_LDS, (hipStream_t)stream, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels,
+                    frames, min_level_db, ref_level_db);
+        return viai_launch_status();
+    }
     if (wave_kernel == 2 && n_mels <= 256)
         return launch_stft_wave<4, 16, 8, 1024, 256>(2, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
     if (wave_kernel && n_mels <= 1024)
