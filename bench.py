@@ -663,8 +663,8 @@ def main():
             "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": None,
             "peak_note": ("algorithmic fp32 flops against the dense 16-bit MFMA peak (2500) / %d partial products per MAC; "
-                          "the same flops are %.2fx the fp32-MFMA peak (157.3); with random operands the pipes sustain 1810 "
-                          "(profiles/r01_e_mfma_probe.txt), i.e. %.2f of the sustained ceiling" % (nprod, ach / MFMA_F32_PEAK_TFLOPS, ach / (1810.0 / nprod)))
+                          "the same flops are %.2fx the fp32-MFMA peak (157.3); with random operands the fp16 pipes sustain 1677 at the clock the power budget "
+                          "leaves (profiles/r04_d_mfma_shapes.txt; bf16: 1810, profiles/r01_e_mfma_probe.txt), i.e. %.2f of the sustained ceiling" % (nprod, ach / MFMA_F32_PEAK_TFLOPS, ach / (1677.0 / nprod)))
                          if peak != MFMA_F32_PEAK_TFLOPS else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
             "dominant_rule": "the MFMA kernel family with the largest share of the summed conv-launch time of the step (conv_time_share_by_kernel); "
                              "frac_by_kernel prices every family against its own ceiling; families are the ones the library reports per call "
