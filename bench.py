@@ -331,7 +331,7 @@ def dvfs_probe(dev):
             e1.record()
             torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 20 * 1e3
-    return {"layer": "D.conv3 forward, 16x64x32x256 -> 512 (the dominant kernel's largest launch), 20 back-to-back launches each",
+    return {"layer": "D.conv3 forward, 16x64x32x256 -> 512 (the dominant kernel's largest launch; here on an fp32 tensor, i.e. with the operand split inside the kernel), 20 back-to-back launches each",
             "random_operand_us": round(res["random"], 1), "zero_operand_us": round(res["zero"], 1), "ratio": round(res["zero"] / res["random"], 3),
             "note": "identical instruction stream and cycle count on all-zero operands: the difference is the shader clock under the kernel's power draw "
                     "(profiles/r04_d_clock_dconv3.txt: 1.5 GHz with random operands against 2.15 GHz with zeros, 76 % of the MFMA issue slots taken in "
