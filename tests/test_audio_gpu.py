@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 from oracle import audio_oracle as A
 
 
-@pytest.mark.parametrize("n_mels,n_samples", [(80, 16384), (256, 65536), (80, 5000)])
+@pytest.mark.parametrize("n_mels,n_samples", [(80, 16384), (256, 65536), (80, 5000), (80, 5001)])      # (odd sample counts take the 16-points-per-lane kernel: no 8-byte pairs)
 def test_stft_mel_matches_oracle(n_mels, n_samples):
     from viai_amd import synth
     from viai_amd.audio import AudioConfig, MelFrontEnd
