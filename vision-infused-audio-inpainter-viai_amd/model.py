@@ -753,6 +753,8 @@ class AudioModel:
         self.sync_pending_update()
         both = torch.cat((self.losses, self._weight_range_check())).tolist()
         v, wmax = both[:self.losses.numel()], both[self.losses.numel():]
+        # (data-parallel runs: the weights are replicas -- same initial values, all-reduced gradients, same Adam -- so every rank sees the same maxima and
+        # raises in the same call; no rank is left waiting in a collective)
         if max(wmax) > ops.F16_WEIGHT_LIMIT and os.environ.get("VIAI_F16X2", "1") != "0" and os.environ.get("VIAI_MATH", "") != "fp32":
             raise FloatingPointError("max |weight| = %.4g (E+G) / %.4g (D) is beyond %.1f, where the f16x2 weight images of the conv kernels "
                                      "clamp: the model has diverged (VIAI_F16X2=0 selects the bf16x3 kernels, which have the fp32 exponent range)"
