@@ -856,6 +856,10 @@ int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
     // then feeds four M tiles, so the fragment stream through L1 halves (2 KB per 12 MFMAs) while the patch reads from LDS double (8 KB) --
     // LDS has twice L1's bandwidth, and the registers drop 231 -> 215.  D.conv3 203.5 -> 198 us, step 7.455 -> 7.423 ms (same box A/B).
     constexpr int tm4 = 1;
+    static int n128 = -1;                          // A/B switch: 128-channel blocks (four waves, 512 blocks, two per CU) for the wide layers too
+    if (n128 < 0) { const char* e = getenv("VIAI_HALO_WIDE_N128"); n128 = e ? atoi(e) : 0; }
+    if (n128 == 1) return launch_halo_wide<1, 4, 4, 1>(a, y0, x0, sl, st);
+    if (n128 == 2 && a.Cout % 256 == 0) return launch_halo_wide<2, 4, 2, 2>(a, y0, x0, sl, st);
     if (tm4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<1, 8, 4, 1>(a, y0, x0, sl, st);
     if (wn4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<2, 4, 2, 2>(a, y0, x0, sl, st);
     return launch_halo_wide<1, 4, 4, 1>(a, y0, x0, sl, st);           // (128-channel blocks, same reasoning: 899 -> 855 us on 1024 x 28 x 28 x 128, 122.5 -> 117 us on 16 x 64 x 128 x 128)
