@@ -467,9 +467,11 @@ __global__ __launch_bounds__(64 * SW_NW) __attribute__((amdgpu_waves_per_eu(2)))
 //   real spectrum X[k] = (Z[k] + conj Z[512 - k]) / 2 - i W1024^k (Z[k] - conj Z[512 - k]) / 2: the partner sits in lane 64 - lane, register 7 - ka (lane 0:
 //   its own register 8 - ka) and is fetched with ds_bpermute (no LDS storage); |X| into the block's [bin][16 frames] table; band walk and output tile as above
 //   with a thread per (band, four frames).
-constexpr int R5_NW = 16, R5_TF = 32, R5_MP = 20, R5_WCAP = 1024, R5_MMAX = 256, R5_OT = R5_TF + 1;
+constexpr int R5_WCAP = 1024, R5_MMAX = 256;
 constexpr int R5_ROW1 = 72, R5_ROW2 = 10, R5_WREG = 640;           // c32 per wave region: max(8 x 72, 64 x 10)
-constexpr int R5_LDS = R5_NW * R5_WREG * 8 + 516 * R5_MP * 4 + R5_WCAP * 4 + (R5_MMAX + 8) * 4 + SW_OMEL * R5_OT * 4 + 64 * 8;
+// <16, 32, 20>: one 1024-thread block per CU (159 KB of LDS);  <8, 16, 8>: TWO 512-thread blocks per CU (78 KB each; the band offsets share the output tile's
+// space: they are only read before the first iteration) -- one block's loads / barriers / write-out overlap the other's arithmetic
+template <int NW, int TF, int MP> constexpr int r5_lds() { return NW * R5_WREG * 8 + 516 * MP * 4 + R5_WCAP * 4 + (NW == 16 ? (R5_MMAX + 8) * 4 : 0) + SW_OMEL * (TF + 1) * 4 + 64 * 8; }
 // forward 8-point DFT of v[0..7] in place, natural order in and out: X[2m] = DFT4(v[n] + v[n + 4])[m], X[2m + 1] = DFT4((v[n] - v[n + 4]) W8^n)[m]
 __device__ __forceinline__ void dft8(c32 (&v)[8]) {
     constexpr float H = 0.70710678118654752f;
@@ -484,17 +486,18 @@ __device__ __forceinline__ void dft8(c32 (&v)[8]) {
 }
 __device__ __forceinline__ float lane_from(float x, int src_lane) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, x))); }
 
-__global__ __launch_bounds__(64 * R5_NW) void stft_mel_r512_kernel(const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ basis_t,
+template <int R5_NW, int R5_TF, int R5_MP>
+__global__ __launch_bounds__(64 * R5_NW) __attribute__((amdgpu_waves_per_eu(4))) void stft_mel_r512_kernel(const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ basis_t,
                                                                     const int* __restrict__ band_lo, const int* __restrict__ band_cnt, const float* __restrict__ mask,
                                                                     float* __restrict__ mel, int n_clips, int n_samples, int hop, int n_mels, int frames,
                                                                     float min_db, float ref_db) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
-    constexpr int NT = 64 * R5_NW;
+    constexpr int NT = 64 * R5_NW, R5_OT = R5_TF + 1, QN = R5_NW / 4;                // QN: four-frame quarters of an iteration (a mel item = (band, quarter))
     c32* ebuf = reinterpret_cast<c32*>(smem_r);                                   // [16 waves][R5_WREG]
     float* mag = reinterpret_cast<float*>(ebuf + R5_NW * R5_WREG);                 // [513][16 frames (+4)]
     float* wts = mag + 516 * R5_MP;                                                // band weights, band after band
-    int* boff = reinterpret_cast<int*>(wts + R5_WCAP);                             // [n_mels + 1]
-    float* otile = reinterpret_cast<float*>(boff + R5_MMAX + 8);                   // [n_mels][33]
+    int* boff = reinterpret_cast<int*>(wts + R5_WCAP);                             // [n_mels + 1]; the two-block shape overlays it on the output tile
+    float* otile = R5_NW == 16 ? reinterpret_cast<float*>(boff + R5_MMAX + 8) : reinterpret_cast<float*>(boff);       // [n_mels][TF + 1]
     c32* t64 = reinterpret_cast<c32*>(otile + SW_OMEL * R5_OT);                    // [a][kb] W64^(a kb)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) {
@@ -527,9 +530,9 @@ __global__ __launch_bounds__(64 * R5_NW) void stft_mel_r512_kernel(const float* 
     const int gpc = (frames + R5_TF - 1) / R5_TF, total = n_clips * gpc;
     const int per = (total + gridDim.x - 1) / gridDim.x;
     const int g_end = min(total, (int)(blockIdx.x + 1) * per);
-    // a thread's mel item: band tid >> 2, frames 4 (tid & 3) .. + 4 of the sixteen
-    const bool own = tid < 4 * n_mels;
-    const int m_ = own ? tid >> 2 : 0, qf = tid & 3;
+    // a thread's mel item: band tid / QN, frames 4 (tid % QN) .. + 4 of the iteration's
+    const bool own = tid < QN * n_mels;
+    const int m_ = own ? tid / QN : 0, qf = tid % QN;
     const int lo_ = own ? band_lo[m_] : 0, cnt_ = own ? band_cnt[m_] : 0, o_ = boff[m_];
     const int cmax = wave_max_i(cnt_);
     const int partner = (64 - lane) & 63;
@@ -642,6 +645,19 @@ __global__ __launch_bounds__(64 * R5_NW) void stft_mel_r512_kernel(const float* 
     }
 }
 
+template <int NW, int TF, int MP>
+int launch_stft_r512(int per_cu, const float* wav, const float* window, const float* basis_t, const int* band_lo, const int* band_cnt, const float* mask, float* mel,
+                     int B, int n_samples, int hop, int n_mels, int frames, float min_db, float ref_db, hipStream_t st) {
+    constexpr int lds = r5_lds<NW, TF, MP>();
+    auto kern = stft_mel_r512_kernel<NW, TF, MP>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    const long groups = (long)B * ((frames + TF - 1) / TF);
+    const int grid = (int)(groups < 256 * per_cu ? groups : 256 * per_cu);
+    VIAI_LAUNCH(kern, dim3(grid), dim3(64 * NW), lds, st, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_db, ref_db);
+    return viai_launch_status();
+}
+
 template <int NW, int TF, int MP, int WCAP, int MMAX>
 int launch_stft_wave(int per_cu, const float* wav, const float* window, const float* basis_t, const int* band_lo, const int* band_cnt, const float* mask, float* mel,
                      int B, int n_samples, int hop, int n_mels, int frames, float min_db, float ref_db, hipStream_t st) {
@@ -663,15 +679,10 @@ extern "C" int viai_stft_mel_banded(const float* wav, const float* window, const
                                     float min_level_db, float ref_level_db, void* stream) {
     if (B <= 0 || frames <= 0 || hop <= 0 || hop > fft || n_mels <= 0 || fft != SB_N || band_lo == nullptr || band_cnt == nullptr) return (int)hipErrorInvalidValue;
     static int wave_kernel = -1;
-    if (wave_kernel < 0) { const char* e = getenv("VIAI_STFT_WAVE"); wave_kernel = e ? atoi(e) : 3; }       // 0: frame-batched kernel, 1: one 8-wave block per CU (523 us on 1024 clips), 2: two 4-wave blocks per CU (551), 3 (default): a frame per wave as a 512-point FFT (455 - 480)
-    if (wave_kernel == 3 && n_mels <= R5_MMAX && hop % 2 == 0 && n_samples % 2 == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_r512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R5_LDS); attr = true; }
-        const long groups = (long)B * ((frames + R5_TF - 1) / R5_TF);
-        const int grid = (int)(groups < 256 ? groups : 256);
-        VIAI_LAUNCH(stft_mel_r512_kernel, dim3(grid), dim3(64 * R5_NW), R5_LDS, (hipStream_t)stream, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels,
-                    frames, min_level_db, ref_level_db);
-        return viai_launch_status();
+    if (wave_kernel < 0) { const char* e = getenv("VIAI_STFT_WAVE"); wave_kernel = e ? atoi(e) : 3; }       // 0: frame-batched kernel, 1: one 8-wave block per CU (523 us on 1024 clips), 2: two 4-wave blocks per CU (551), 3 (default): a frame per wave as a 512-point FFT (455 - 480), 4: the same as two 8-wave blocks per CU (479 - 491: exposed latency is not what bounds it)
+    if ((wave_kernel == 3 || wave_kernel == 4) && n_mels <= R5_MMAX && hop % 2 == 0 && n_samples % 2 == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0) {
+        if (wave_kernel == 4) return launch_stft_r512<8, 16, 8>(2, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
+        return launch_stft_r512<16, 32, 20>(1, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
     }
     if (wave_kernel == 2 && n_mels <= 256)
         return launch_stft_wave<4, 16, 8, 1024, 256>(2, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
