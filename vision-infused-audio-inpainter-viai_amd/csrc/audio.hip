@@ -468,7 +468,8 @@ __global__ __launch_bounds__(64 * SW_NW) __attribute__((amdgpu_waves_per_eu(2)))
 //   its own register 8 - ka) and is fetched with ds_bpermute (no LDS storage); |X| into the block's [bin][16 frames] table; band walk and output tile as above
 //   with a thread per (band, four frames).
 constexpr int R5_WCAP = 1024, R5_MMAX = 256;
-constexpr int R5_ROW1 = 72, R5_ROW2 = 10, R5_WREG = 640;           // c32 per wave region: max(8 x 72, 64 x 10)
+constexpr int R5_ROW1 = 72, R5_WREG = 640;                         // c32 per wave region: max(8 x 72, 64 x 10).  R5_ROW2 (template): rows of the second transpose; 10 = 16-byte reads, 4-way store
+// conflicts; 9 = conflict-free stores, 8-byte reads: measured SLOWER (491 - 510 vs 463 - 492 us, same box)            // c32 per wave region: max(8 x 72, 64 x 9).  Rows of 9: the (k1, kb) rows of one store instruction fall 16 banks apart (two passes, the minimum for 512 bytes; rows of 10 were 4-way)
 // <16, 32, 20>: one 1024-thread block per CU (159 KB of LDS);  <8, 16, 8>: TWO 512-thread blocks per CU (78 KB each; the band offsets share the output tile's
 // space: they are only read before the first iteration) -- one block's loads / barriers / write-out overlap the other's arithmetic
 template <int NW, int TF, int MP> constexpr int r5_lds() { return NW * R5_WREG * 8 + 516 * MP * 4 + R5_WCAP * 4 + (NW == 16 ? (R5_MMAX + 8) * 4 : 0) + SW_OMEL * (TF + 1) * 4 + 64 * 8; }
@@ -486,7 +487,7 @@ __device__ __forceinline__ void dft8(c32 (&v)[8]) {
 }
 __device__ __forceinline__ float lane_from(float x, int src_lane) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, x))); }
 
-template <int R5_NW, int R5_TF, int R5_MP>
+template <int R5_NW, int R5_TF, int R5_MP, int R5_ROW2>
 __global__ __launch_bounds__(64 * R5_NW) __attribute__((amdgpu_waves_per_eu(4))) void stft_mel_r512_kernel(const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ basis_t,
                                                                     const int* __restrict__ band_lo, const int* __restrict__ band_cnt, const float* __restrict__ mask,
                                                                     float* __restrict__ mel, int n_clips, int n_samples, int hop, int n_mels, int frames,
@@ -569,9 +570,14 @@ __global__ __launch_bounds__(64 * R5_NW) __attribute__((amdgpu_waves_per_eu(4)))
             for (int kb = 0; kb < 8; ++kb) E[(k1r * 8 + kb) * R5_ROW2 + a] = v[kb];
             wave_lds_sync();
             {   // lane = k1 + 8 kb reads its eight a's: 64 contiguous bytes
-                const f32x4* src = reinterpret_cast<const f32x4*>(E + ((lane & 7) * 8 + (lane >> 3)) * R5_ROW2);
+                const c32* src = E + ((lane & 7) * 8 + (lane >> 3)) * R5_ROW2;
+                if constexpr (R5_ROW2 % 2 == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const f32x4 t = src[j]; v[2 * j] = c32{t[0], t[1]}; v[2 * j + 1] = c32{t[2], t[3]}; }
+                    for (int j = 0; j < 4; ++j) { const f32x4 t = reinterpret_cast<const f32x4*>(src)[j]; v[2 * j] = c32{t[0], t[1]}; v[2 * j + 1] = c32{t[2], t[3]}; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = src[j];
+                }
             }
             wave_lds_sync();                                                               // (the region is rewritten by the next iteration's first transpose)
             dft8(v);                                                                       // over a -> ka: v[ka] = Z[lane + 64 ka]
@@ -645,11 +651,11 @@ __global__ __launch_bounds__(64 * R5_NW) __attribute__((amdgpu_waves_per_eu(4)))
     }
 }
 
-template <int NW, int TF, int MP>
+template <int NW, int TF, int MP, int ROW2>
 int launch_stft_r512(int per_cu, const float* wav, const float* window, const float* basis_t, const int* band_lo, const int* band_cnt, const float* mask, float* mel,
                      int B, int n_samples, int hop, int n_mels, int frames, float min_db, float ref_db, hipStream_t st) {
     constexpr int lds = r5_lds<NW, TF, MP>();
-    auto kern = stft_mel_r512_kernel<NW, TF, MP>;
+    auto kern = stft_mel_r512_kernel<NW, TF, MP, ROW2>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
     const long groups = (long)B * ((frames + TF - 1) / TF);
@@ -681,8 +687,8 @@ extern "C" int viai_stft_mel_banded(const float* wav, const float* window, const
     static int wave_kernel = -1;
     if (wave_kernel < 0) { const char* e = getenv("VIAI_STFT_WAVE"); wave_kernel = e ? atoi(e) : 3; }       // 0: frame-batched kernel, 1: one 8-wave block per CU (523 us on 1024 clips), 2: two 4-wave blocks per CU (551), 3 (default): a frame per wave as a 512-point FFT (455 - 480), 4: the same as two 8-wave blocks per CU (479 - 491: exposed latency is not what bounds it)
     if ((wave_kernel == 3 || wave_kernel == 4) && n_mels <= R5_MMAX && hop % 2 == 0 && n_samples % 2 == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0) {
-        if (wave_kernel == 4) return launch_stft_r512<8, 16, 8>(2, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
-        return launch_stft_r512<16, 32, 20>(1, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
+        if (wave_kernel == 4) return launch_stft_r512<8, 16, 8, 10>(2, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
+        return launch_stft_r512<16, 32, 20, 10>(1, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
     }
     if (wave_kernel == 2 && n_mels <= 256)
         return launch_stft_wave<4, 16, 8, 1024, 256>(2, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
