@@ -804,6 +804,12 @@ class _ConvBnAct(torch.autograd.Function):
         return dx, dx2, dw, db, dgamma, dbeta, None, None, None, dres, None
 
 
+# The first layer's weight gradient is the LAST launch of a backward: on the side stream it lengthens the tail the main chain waits for at the join in front
+# of Adam (84 / 60 us of waiting in the D / G step, profiles/r04_d_queues_plan.txt); on the main stream the two queues end together.  6.672 -> 6.622 ms
+# (six same-box pairs, ranges disjoint); VIAI_CIN1_WGRAD_MAIN=0 puts it back on the side stream.
+CIN1_WGRAD_MAIN = os.environ.get("VIAI_CIN1_WGRAD_MAIN", "1") != "0"
+
+
 def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
     """backward of the fused Cin = 1 conv + BatchNorm(train) + activation layer: y is recomputed from x; dy is written to memory only
     when a data gradient needs it (the frozen-D pass of the G step), the weight gradient forms it on the fly."""
@@ -846,7 +852,7 @@ def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
             _lib.check(lib.viai_conv2d_cin1_bn_wgrad(d["ref"], x.data_ptr(), _ptr(xmask), wp.data_ptr(), 0, dz.data_ptr(), coef[0].data_ptr(),
                                                      coef[2].data_ptr(), coef[3].data_ptr(), sums.data_ptr(), ws.data_ptr(), dw.data_ptr(),
                                                      1 if acc_w else 0, act, handle), "viai_conv2d_cin1_bn_wgrad")
-        if WGRAD_STREAM is not None and acc_w:
+        if WGRAD_STREAM is not None and acc_w and not CIN1_WGRAD_MAIN:
             ev = torch.cuda.Event()
             ev.record()
             WGRAD_STREAM.wait_event(ev)
