@@ -1,0 +1,70 @@
+// Standalone timing / stage-stamp harness for conv_s2_dma_kernel (csrc/conv_halo_dma.hip).  Results are not checked here (tests/test_p16_gpu.py).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DVIAI_PROF] -o s2_dma_bench tools/probes/s2_dma_bench.hip ;  ./s2_dma_bench N IH IW Cin Cout [iters]
+#include "../../vision-infused-audio-inpainter-viai_amd/csrc/conv_halo_dma.hip"
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+int viai_plan_log_on = 0;
+void viai_plan_note(const void*, void*, dim3, dim3, const unsigned char*, const unsigned*, int) {}
+thread_local ViaiKernelTag viai_kernel_tag = {nullptr, 0};
+static void fill_f16(std::vector<unsigned short>& v, unsigned seed) {
+    for (auto& x : v) { seed = seed * 1664525u + 1013904223u; x = (unsigned short)(((seed >> 9) & 0x83ffu) | 0x3000u | ((seed >> 3) & 0x0c00u)); }
+}
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 16, IH = argc > 2 ? atoi(argv[2]) : 256, IW = argc > 3 ? atoi(argv[3]) : 128, Ci = argc > 4 ? atoi(argv[4]) : 64, Co = argc > 5 ? atoi(argv[5]) : 128;
+    const int iters = argc > 6 ? atoi(argv[6]) : 20;
+    const int OH = IH / 2, OW = IW / 2;
+    const size_t ipx = (size_t)N * IH * IW, opx = (size_t)N * OH * OW;
+    std::vector<unsigned short> hx(ipx * Ci * 2), hw((size_t)Co * 9 * Ci * 2);
+    fill_f16(hx, 1); fill_f16(hw, 2);
+    unsigned short *dx, *dw; float *dy, *dstat, *damax;
+    hipMalloc(&dx, hx.size() * 2); hipMalloc(&dw, hw.size() * 2); hipMalloc(&dy, opx * Co * 4); hipMalloc(&dstat, 2 * Co * (opx / 64) * 4); hipMalloc(&damax, 4);
+    hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    const float am = 1.0f; hipMemcpy(damax, &am, 4, hipMemcpyHostToDevice);
+    ConvArgs a{};
+    a.in = (const float*)dx; a.wp = (const float*)dw; a.out = dy; a.stat = dstat; a.C1 = Ci; a.Cout = Co; a.OC1 = Co; a.M = (int)opx; a.amax = damax; a.in_p16 = 1;
+    a.g.N = N; a.g.IH = IH; a.g.IW = IW; a.g.OH = a.g.SH = OH; a.g.OW = a.g.SW = OW; a.g.ly = a.g.lx = 1; a.g.my = a.g.mx = 2; a.g.ntaps = a.g.wtaps = 9;
+    for (int t = 0; t < 9; ++t) { a.g.dy[t] = t / 3 - 1; a.g.dx[t] = t % 3 - 1; a.g.ws[t] = t; }
+    setenv("VIAI_HALO_DMA", "1", 1);
+#ifdef VIAI_PROF
+    const size_t pn = 256 * 2 * 32 * 4;
+    unsigned long long* dprof; hipMalloc(&dprof, pn * 8); hipMemset(dprof, 0, pn * 8);
+    viai_dma_prof_buf = dprof;
+#endif
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) if (int e = viai_conv_s2_dma_launch(a, 0)) { printf("launch error %d\n", e); return 1; }
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) viai_conv_s2_dma_launch(a, 0);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / iters, gf = 2.0 * opx * Co * 9 * Ci * 1e-9, mb = (ipx * Ci * 4 + opx * Co * 4) * 1e-6;
+    printf("s2 dma %d x %d x %d x %d -> %d : %.1f us per launch (%d back to back)  %.0f TFLOP/s  %.2f TB/s   last error %d\n", N, IH, IW, Ci, Co, us, iters, gf / us * 1e-3 * 1e3, mb / us * 1e-6 * 1e6 * 1e-6, (int)hipGetLastError());
+#ifdef VIAI_PROF
+    std::vector<unsigned long long> hp(pn); hipMemcpy(hp.data(), dprof, pn * 8, hipMemcpyDeviceToHost);
+    const char* cn[3] = {"barrier wait", "stage MFMAs", "epilogue"}; const char* ln[3] = {"barrier wait", "issue", "vmcnt wait"};
+    for (int role = 0; role < 2; ++role)
+        for (int q = 0; q < 32; ++q) {
+            double acc[3] = {0, 0, 0}; int cnt = 0;
+            for (int b = 0; b < 256; ++b) { const unsigned long long* s = &hp[(((size_t)b * 2 + role) * 32 + q) * 4]; if (!s[3]) continue; for (int i = 0; i < 3; ++i) acc[i] += (double)(s[i + 1] - s[i]); ++cnt; }
+            if (!cnt) break;
+            printf("%s stage %2d (%3d blocks), ticks of s_memtime (2.39 GHz):", role ? "loader  " : "consumer", q, cnt);
+            for (int i = 0; i < 3; ++i) printf("  %s %.0f", role ? ln[i] : cn[i], acc[i] / cnt);
+            printf("\n");
+        }
+    { double span = 0; int cnt = 0; for (int b = 0; b < 256; ++b) { const unsigned long long* s = &hp[((size_t)b * 2) * 32 * 4]; unsigned long long last = 0; for (int q = 0; q < 32; ++q) if (s[q * 4 + 3]) last = s[q * 4 + 3]; if (last) { span += (double)(last - s[0]); ++cnt; } }
+      printf("consumer wave 0: first barrier -> last stamp %.0f ticks = %.1f us\n", span / cnt, span / cnt / 2390.0); }
+    { std::vector<double> st, en; unsigned long long t0 = ~0ull;
+      for (int b = 0; b < 256; ++b) { const unsigned long long* s = &hp[(((size_t)b * 2 + 1) * 32 + 31) * 4]; if (s[0] && s[0] < t0) t0 = s[0]; }
+      for (int b = 0; b < 256; ++b) { const unsigned long long* s = &hp[(((size_t)b * 2 + 1) * 32 + 31) * 4]; if (s[1]) { st.push_back((s[0] - t0) / 100.0); en.push_back((s[1] - t0) / 100.0); } }
+      std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+      printf("s_memrealtime: block start (us after the first): min %.1f median %.1f p90 %.1f max %.1f;  block end: min %.1f median %.1f p90 %.1f max %.1f  (%zu blocks)\n",
+             st[0], st[st.size() / 2], st[st.size() * 9 / 10], st.back(), en[0], en[en.size() / 2], en[en.size() * 9 / 10], en.back(), st.size()); }
+    if (0) { std::vector<double> st, en; unsigned long long t0 = ~0ull; for (int b = 0; b < 256; ++b) { const unsigned long long* s = &hp[((size_t)b * 2) * 32 * 4]; if (s[0] && s[0] < t0) t0 = s[0]; }
+      for (int b = 0; b < 256; ++b) { const unsigned long long* s = &hp[((size_t)b * 2) * 32 * 4]; unsigned long long last = 0; for (int q = 0; q < 32; ++q) if (s[q * 4 + 3]) last = s[q * 4 + 3]; if (last) { st.push_back((s[0] - t0) / 2390.0); en.push_back((last - t0) / 2390.0); } }
+      std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+      printf("block start (us after the first block): min %.1f median %.1f p90 %.1f max %.1f;  block end: min %.1f median %.1f p90 %.1f max %.1f  (%zu blocks)\n",
+             st[0], st[st.size() / 2], st[st.size() * 9 / 10], st.back(), en[0], en[en.size() / 2], en[en.size() * 9 / 10], en.back(), st.size()); }
+#endif
+    return 0;
+}

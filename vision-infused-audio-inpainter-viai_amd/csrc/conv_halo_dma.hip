@@ -1,0 +1,695 @@
+// Patch-staged convolution kernels whose activation operand arrives by LDS-DMA (`buffer_load_dwordx4 ... lds`), gfx950, round 5.
+//
+// A P16 tensor (viai_bf3.h) already holds, per pixel and 32-channel group, the two fp16 planes the f16x2 kernels multiply: 128 bytes =
+// eight 16-byte pieces (pieces 0..3 = leading terms of channels 8 k .. 8 k + 7, pieces 4..7 = their remainders), and a piece is exactly
+// what one lane of `v_mfma_f32_32x32x16_f16` takes as its A operand.  So nothing has to pass through registers on the way to LDS: a
+// wave-instruction copies eight pixels (8 x 128 bytes = 1 KiB, lane = pixel * 8 + slot) straight into the stage, asynchronously, and
+// the only per-element work left in the kernel is the MFMA itself.  What that buys over the register-staged kernels
+// (conv_halo_bf3.hip): (i) no staging registers, so the ring can be THREE tiles deep -- the register-staged kernels had one tile of
+// loads in flight per block and were bound by memory latency, not bandwidth (G.convblock5: 67 MB in 25 us = 2.7 TB/s); (ii) no
+// ds_write pass and no per-quad VALU.
+//
+// LDS image of a stage: [patch pixel][128 bytes], the pixel's eight pieces permuted: piece q sits in slot q ^ ((column >> 1) & 7).
+// A `ds_read_b128` is serviced in groups of 16 lanes that together must touch all 64 banks once (MI355X_MICROARCH.md, LDS): the 16
+// lanes of a group read 16 consecutive patch columns (the MFMA row -> pixel map below), same piece q; a pixel record is half a bank
+// row, so eight lanes share each half and the XOR with (column >> 1) & 7 spreads them over its eight slots.  LDS-DMA writes lane-linear,
+// so the permutation is applied on the SOURCE side: lane (pixel, slot) fetches piece slot ^ f(column) of that pixel (same 128-byte
+// line, so the global access stays fully coalesced).  Pixels outside the image are lanes with an out-of-range offset: the DMA
+// writes zeros for them (tools/probes/glds_oob.hip, gpurun_out/r04_b/glds_oob.txt), which is the convolution's zero padding.
+//
+// The DMA is issued from inline asm (M0 = LDS destination, saved and restored around the batch): hipcc's waitcnt pass does not see
+// it, which is the point -- a compiler-visible LDS-DMA makes every later barrier drain `vmcnt(0)` (cdna_hip_programming.md,
+// "Pipelining across barriers").  Completion is counted by hand: after the MFMAs of tile k the wave waits `vmcnt(<DMA instructions of
+// the batch it issued at the top of this iteration>)`, i.e. until everything older than that batch -- tile k + 1's data -- has landed,
+// BEFORE it issues its epilogue stores (which share the counter); the barrier at the top of iteration k + 1 then covers the other waves'
+// parts.  Compiler-counted waits (the filter fetch of the prologue, nothing in the loop) can only over-wait beside invisible younger
+// operations, never under-wait.
+//
+// Reference call sites: the 32 -> 32 channel ConvTranspose2d layers of the decoder (networks/New_Inpainting_Networks.py:61-63,85-88:
+// convblock4_1/2, convblock5_0..3, conv6_1) and their autograd data gradients.
+#include "viai_common.h"
+#include "viai_internal.h"
+#include "viai_bf3.h"
+#include <cstdlib>
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DT_H = 8, DT_W = 16;                      // output tile: 128 pixels = 4 waves x 32 MFMA rows
+constexpr int DP_H = DT_H + 2, DP_W = DT_W + 2;         // staged patch: 10 x 18 pixels
+constexpr int DP_NPIX = DP_H * DP_W;                    // 180
+constexpr int DP_INSTR = 24;                            // DMA wave-instructions per stage (8 pixels each): 192 pixel slots, 6 per wave
+constexpr int DP_STAGE = DP_INSTR * 1024;               // 24 KB
+constexpr int DP_NSTG = 3;
+constexpr int DP_OOB = 0x7fffffff;
+
+// wave-uniform raw buffer descriptor in SGPRs (same words as __builtin_amdgcn_make_buffer_rsrc(p, 0, bytes, 0x00020000))
+__device__ __forceinline__ i32x4 rsrc_sgpr(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull));
+    r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffull));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+// q = n / d for n * d < 2^32 with magic = ceil(2^32 / d) (host side: tile_magic): one s_mul_hi_u32 instead of a ~25-instruction division
+__device__ __forceinline__ int div_magic(int n, unsigned magic) { return magic == 0u ? n : (int)__umulhi((unsigned)n, magic); }      // (magic 0: d = 1)
+struct TileDec {
+    int tiles_x, tiles_y; unsigned mx, my;                    // tiles per map row / column and their magics
+#ifdef VIAI_PROF
+    unsigned long long* prof;                                  // tools/probes/halo_dma_bench.hip: [block][16 tiles][8 stamps] shader-clock stamps of wave 0
+#endif
+};
+#ifdef VIAI_PROF
+#define PROF_STAMP(k, i) do { if (tid == 0 && (k) < 16) td.prof[((size_t)blockIdx.x * 16 + (k)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PROF_STAMP(k, i) do { } while (0)
+#endif
+
+// six LDS-DMA wave-instructions: lane l of instruction j copies the 16 bytes at (buffer + soff + v_j[l]) to LDS byte lds0 + j * 4096 + 16 l
+// (instruction i = wave + 4 j of a stage, 1 KiB each).  `s_nop 4`: the descriptor / offsets may come straight from v_readfirstlane;
+// `s_nop 0` after every M0 write (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void dma_batch6(const i32x4& rs, unsigned lds0, int soff, int v0, int v1, int v2, int v3, int v4, int v5) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %4, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %5, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %6, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %7, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %8, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %9, %1, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(rs), "s"(lds0), "s"(soff), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5)
+        : "memory", "scc");
+}
+
+struct DmaSlots { int s[9]; };                         // weight slot of window position (row * 3 + col)
+
+// 32 -> (<= 32) channel 3 x 3 stride-1 layer on a P16 input; the whole filter in registers (as conv_halo_f16_c32_kernel), the input
+// patch of tile k + 2 in flight while tile k is multiplied.  Same MFMA order and epilogue as the register-staged kernel: bit-identical.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_c32_dma_kernel(const ConvArgs a, int hy0, int hx0, int ntiles, DmaSlots slots, TileDec td) {
+    constexpr int KS = 2;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_d[];      // [3 stages][24 KB] + [4 waves][2][32] floats
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float ascale = f16_scale_from_amax(a.amax);
+    auto decode = [&](int tile, int& tx, int& ty, int& n) {      // tile -> (image, tile row, tile column)
+        const int r = div_magic(tile, td.mx);
+        tx = tile - r * td.tiles_x;
+        n = div_magic(r, td.my);
+        ty = r - n * td.tiles_y;
+    };
+
+    const long in_bytes = (long)g.N * g.IH * g.IW * 128;
+    const i32x4 rs_in = rsrc_sgpr(a.in, (unsigned)in_bytes);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_d;
+
+    // DMA lane map: instruction i = wave + 4 j covers patch pixels 8 i .. 8 i + 7; lane -> (pixel 8 i + (lane >> 3), slot lane & 7)
+    int vint[6], prc[6];                                // interior-tile offset (relative to the patch origin) / (row << 8) | col, -1 beyond the patch
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int p = 8 * (wave + 4 * j) + (lane >> 3);
+        const int pr_ = p / DP_W, pc_ = p - pr_ * DP_W;
+        const int q = (lane & 7) ^ ((pc_ >> 1) & 7);
+        prc[j] = p < DP_NPIX ? (pr_ << 8) | pc_ : -1;
+        vint[j] = p < DP_NPIX ? (pr_ * g.IW + pc_) * 128 + q * 16 : DP_OOB;
+    }
+    auto issue = [&](int tile, int stage) {             // tile, stage wave-uniform
+        int tx, ty, n;
+        decode(tile, tx, ty, n);
+        const int py = ty * DT_H + hy0, px = tx * DT_W + hx0;
+        const unsigned lds0 = lds_base + stage * DP_STAGE + wave * 1024;
+        const bool interior = py >= 0 && px >= 0 && py + DP_H <= g.IH && px + DP_W <= g.IW;
+        if (interior) {
+            const int soff = __builtin_amdgcn_readfirstlane(((n * g.IH + py) * g.IW + px) * 128);
+            dma_batch6(rs_in, lds0, soff, vint[0], vint[1], vint[2], vint[3], vint[4], vint[5]);
+        } else {
+            int v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int iy = py + (prc[j] >> 8), ix = px + (prc[j] & 255);
+                const int dm = ((g.IH - 1 - iy) | iy | (g.IW - 1 - ix) | ix | prc[j]) >> 31;          // all ones: outside the image / beyond the patch
+                const int q = (lane & 7) ^ (((prc[j] & 255) >> 1) & 7);
+                v[j] = ((((n * g.IH + iy) * g.IW + ix) * 128 + q * 16) & ~dm) | (dm & DP_OOB);
+            }
+            dma_batch6(rs_in, lds0, 0, v[0], v[1], v[2], v[3], v[4], v[5]);
+        }
+    };
+
+    const int G = gridDim.x;
+    const int t0 = blockIdx.x;
+    // the first tile on its way before anything else (the second follows the filter: see below)
+    if (t0 < ntiles) issue(xcd_remap(t0, ntiles), 0);
+
+    // the whole filter, once per block: wf[position][k-step][plane]
+    const int frag_plane = g.wtaps * KS * 1024;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 2 * frag_plane, 0x00020000);
+    u32x4 wf[9][KS][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                wf[t][ks][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, (slots.s[t] * KS + ks) * 1024 + p * frag_plane, 0);
+
+    // MFMA row i = lane & 31 -> tile pixel (2 * wave + (i >> 4), i & 15); lane >> 5 = k half.  Fragment address of window column tx, k-step ks
+    const int pr = 2 * wave + ((lane & 31) >> 4), pc = lane & 15, kh = lane >> 5;
+    int aoff[3][KS];
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            aoff[tx][ks] = (pr * DP_W + pc + tx) * 128 + (((2 * ks + kh) ^ (((pc + tx) >> 1) & 7)) * 16);
+    const int half = lane >> 5, col = lane & 31;
+    const float bv = a.bias != nullptr ? a.bias[col] : 0.f;
+    const float inv = 1.0f / (ascale * F16_WSCALE);
+    float* red = reinterpret_cast<float*>(smem_d + DP_NSTG * DP_STAGE);          // [4 waves][2][32]
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((long)g.N * g.OH * g.OW * 128), 0x00020000);
+    const int orow = g.OW * 128;                                                  // bytes per output row (32 channels)
+    const int ovoff = 2 * wave * orow + (4 * half) * 128 + col * 4;
+
+    // The filter fetch is the one compiler-counted load group of this kernel, and its last `vmcnt(0)` would sit in front of the first tile's
+    // last MFMAs -- draining every DMA issued before it.  So the values are pinned here (the compiler waits for them HERE, together with
+    // tile 0, which is older), and only then does tile 1 go out: compute starts after one tile's worth of the start-up burst instead of two.
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        asm volatile("" : "+v"(wf[t][0][0]), "+v"(wf[t][0][1]), "+v"(wf[t][1][0]), "+v"(wf[t][1][1]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t0 + G < ntiles) issue(xcd_remap(t0 + G, ntiles), 1);
+    int stage = 0;
+    [[maybe_unused]] int kk = 0;
+    PROF_STAMP(0, 7);
+    for (int it = t0; it < ntiles; it += G) {
+        const int tile = xcd_remap(it, ntiles);
+        PROF_STAMP(kk, 0);
+        __syncthreads();                               // every wave's part of this tile has landed; stage + 2 (tile k - 1) is free
+        PROF_STAMP(kk, 1);
+        const bool more2 = it + 2 * G < ntiles;
+        if (more2) issue(xcd_remap(it + 2 * G, ntiles), stage >= 1 ? stage - 1 : 2);
+        const unsigned char* Sb = smem_d + stage * DP_STAGE;
+        PROF_STAMP(kk, 2);
+
+        f32x16 c0, c1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { c0[e] = 0.f; c1[e] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const unsigned char* As = Sb + aoff[t % 3][ks] + (t / 3) * (DP_W * 128);
+                const f16x8 a1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(As));
+                const f16x8 a2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(Sb + (aoff[t % 3][ks] ^ 64) + (t / 3) * (DP_W * 128)));
+                const f16x8 b1 = __builtin_bit_cast(f16x8, wf[t][ks][0]), b2 = __builtin_bit_cast(f16x8, wf[t][ks][1]);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, c0, 0, 0, 0);      // small terms on one chain
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, c0, 0, 0, 0);
+            }
+        f32x16 acc = (c0 + c1) * inv;
+
+        PROF_STAMP(kk, 3);
+        // tile k + 1 (issued one iteration ago) must have landed before the next barrier: everything older than this iteration's batch
+        if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        PROF_STAMP(kk, 4);
+        // epilogue: the lane's sixteen values go to pixels (2 wave + (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 half) of the tile, channel col:
+        // one buffer store each, the per-lane part of the address in voff, the rest wave-uniform (scalar base + immediate)
+        int tx, ty, n;
+        decode(tile, tx, ty, n);
+        const int obase = __builtin_amdgcn_readfirstlane((((n * g.OH + ty * DT_H) * g.OW + tx * DT_W) * 32) * 4);
+        auto store16 = [&](auto ACT) {                  // (the activation decision once per tile, not once per element)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[e] + bv;
+                if constexpr (decltype(ACT)::value) v = viai_act(v, a.act, a.slope);
+                acc[e] = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, ovoff + ((e & 3) + 8 * ((e >> 2) & 1)) * 128,
+                                                      (e >> 3) ? obase + orow : obase, 0);
+            }
+        };
+        if (a.stat == nullptr && a.act != VIAI_ACT_NONE) store16(std::true_type{});
+        else store16(std::false_type{});
+        PROF_STAMP(kk, 5);
+        if (a.stat != nullptr) {          // block-local (mean, M2) over the 128 pixels of this tile (as conv_halo_f16_c32_kernel)
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) t += acc[e];
+            t += __shfl_xor(t, 32, 64);
+            const float mw = t * (1.f / 32.f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float d = acc[e] - mw; m2 += d * d; }
+            m2 += __shfl_xor(m2, 32, 64);
+            if (half == 0) { red[(wave * 2 + 0) * 32 + col] = mw; red[(wave * 2 + 1) * 32 + col] = m2; }
+            __syncthreads();
+            if (wave == 0 && half == 0) {
+                const float m0 = red[0 * 32 + col], m1 = red[2 * 32 + col], m2_ = red[4 * 32 + col], m3 = red[6 * 32 + col];
+                const float mean = 0.25f * ((m0 + m1) + (m2_ + m3));
+                float M2 = (red[1 * 32 + col] + red[3 * 32 + col]) + (red[5 * 32 + col] + red[7 * 32 + col]);
+                M2 += 32.f * (((m0 - mean) * (m0 - mean) + (m1 - mean) * (m1 - mean)) + ((m2_ - mean) * (m2_ - mean) + (m3 - mean) * (m3 - mean)));
+                a.stat[(size_t)col * a.nblk_m + tile] = mean;
+                a.stat[(size_t)(a.Cout + col) * a.nblk_m + tile] = M2;
+            }
+            // (red[] is rewritten only after the next iteration's top barrier)
+        }
+        PROF_STAMP(kk, 6);
+        ++kk;
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+}
+
+}  // namespace
+
+#ifdef VIAI_PROF
+static unsigned long long* viai_dma_prof_buf = nullptr;
+#endif
+static unsigned tile_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
+
+// P16 input, 32 -> 32 channels into one destination, byte offsets and tile counts within the 32-bit arithmetic of the kernel
+bool viai_conv_halo_c32_dma_ok(const ConvArgs& a) {
+    if (!viai_halo_dma_on() || !a.in_p16 || a.amax == nullptr || a.C1 != 32 || a.C2 != 0 || a.Cout != 32 || a.OC1 != 32) return false;
+    const ConvGeom& g = a.g;
+    if ((long)g.N * g.IH * g.IW * 128 >= (1l << 31) || (long)g.N * g.OH * g.OW * 128 >= (1l << 31)) return false;
+    const long tiles = (long)g.N * (g.OH / DT_H) * (g.OW / DT_W);
+    return g.OH % DT_H == 0 && g.OW % DT_W == 0 && tiles * 64 < (1l << 31);
+}
+
+// P16 launches of the register-filter halo kernel's layers (viai_conv_halo16_ok): called by viai_conv_halo_bf3_launch
+int viai_conv_halo_c32_dma_launch(ConvArgs& a, int y0, int x0, const int* slots9, hipStream_t st) {
+    if (!viai_conv_halo_c32_dma_ok(a)) return (int)hipErrorInvalidValue;
+    constexpr int lds = DP_NSTG * DP_STAGE + 4 * 2 * 32 * (int)sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_c32_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    DmaSlots sl;
+    for (int t = 0; t < 9; ++t) sl.s[t] = slots9[t];
+    a.nblk_m = a.M / 128;
+    a.nblk_n = 1;
+    int grid = 256 * 2;
+    if (grid > a.nblk_m) grid = a.nblk_m;
+    TileDec td;
+    td.tiles_x = a.g.OW / DT_W; td.tiles_y = a.g.OH / DT_H;
+    td.mx = tile_magic(td.tiles_x); td.my = tile_magic(td.tiles_y);
+#ifdef VIAI_PROF
+    td.prof = viai_dma_prof_buf;
+#endif
+    VIAI_LAUNCH(conv_halo_c32_dma_kernel, dim3(grid), dim3(256), lds, st, a, y0, x0, a.nblk_m, sl, td);
+    return viai_launch_status();
+}
+
+// bring-up switch (A/B against the register-staged kernels): VIAI_HALO_DMA=0
+bool viai_halo_dma_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_HALO_DMA"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+
+// =====================================================================================================================================
+// 3 x 3 STRIDE-2 forward conv on a P16 input, producer / consumer waves (round 5).
+//
+// Why not the plain LDS-DMA form of the kernel above: here the filter does not fit in registers, so every consumer wave streams weight
+// fragments from L2 all through the K loop -- and `vmcnt` retires in ORDER: a weight fragment requested after an activation DMA cannot be
+// consumed before that DMA has landed (HBM latency).  The register-staged kernel (conv_halo_wide_f16_kernel<.., 2>) has the same coupling
+// between its activation rows and its fragment stream.  The counters are per WAVE, so the two streams go to different waves:
+//
+//   * 4 LOADER waves (one per SIMD) issue nothing but LDS-DMA: the input patch of one 16-channel k-step -- 17 x 33 pixels x 64 bytes (the
+//     k-step's two leading and two remainder pieces of each pixel) -- into a three-deep ring, two stages ahead of the consumers;
+//   * 8 CONSUMER waves (2 x 4: 64 pixels x 32 channels each, two per SIMD) read A fragments from the ring (`ds_read_b128`), stream their
+//     own weight fragments (compiler-counted loads: nothing else is in their queue) and run 54 MFMAs per stage;
+//   * one `s_barrier` per stage joins them: behind it stage q has landed (the loaders waited for it) and the consumers are done with
+//     stage q - 1, whose slot the loaders refill with stage q + 2.
+// The ring runs across work items (8 x 16 output pixels x 128 channels each; a persistent block walks its items), so the loaders stream
+// the next item's patch under this item's epilogue.
+//
+// Stage image: the patch as four parity sub-patches P[py][px][r][c] = patch(2 r + py, 2 c + px) (window position (ty, tx) of output
+// pixel (r, c) is P[ty & 1][tx & 1] at (r + (ty >> 1), c + (tx >> 1)): consecutive output pixels read consecutive records), rows padded to
+// 20 / 16 records (multiples of the 256-byte bank row), record = 64 bytes = four 16-byte pieces {lead k-half 0, lead k-half 1, rem 0,
+// rem 1} stored at position piece ^ ((c >> 2) & 3): the 16 lanes of a `ds_read_b128` group read 16 consecutive columns, four per bank-row
+// quarter, and the XOR gives those four distinct positions -- conflict-free, checked with SQ_LDS_BANK_CONFLICT.
+// Reference call sites: networks/Discriminator_Networks.py:20-27 (conv2_1, conv2_2), networks/Inpainting_Networks.py:55-63 (conv3, conv4).
+namespace {
+
+constexpr int S2_TH = 8, S2_TW = 16;                                   // output tile
+constexpr int S2_P0 = 0, S2_P1 = 9 * 20, S2_P2 = S2_P1 + 9 * 16, S2_P3 = S2_P2 + 8 * 20, S2_NREC = S2_P3 + 8 * 16;   // record index of each sub-patch; 612 records
+constexpr int S2_INSTR = 40;                                           // DMA wave-instructions per stage (16 records each), 10 per loader wave
+constexpr int S2_STAGE = S2_INSTR * 1024;                              // 40 KB
+constexpr int S2_NSTG = 3;
+constexpr int S2_NLOAD = 4, S2_NCONS = 4;                              // waves: one loader and one consumer per SIMD
+constexpr int S2_TM = 4;                                               // 32-pixel MFMA tiles per consumer wave: all 128 pixels of the tile
+constexpr int S2_THREADS = 64 * (S2_NLOAD + S2_NCONS);
+
+struct S2Args {
+    int tiles_x, tiles_y; unsigned mx, my;                            // 8 x 16 tiles per map and their division magics
+    int nnb; unsigned mnb;                                             // 128-channel blocks per tile (item = tile * nnb + nb)
+    int nitems;
+    int slot[9];                                                       // weight slot of window position (row * 3 + col)
+#ifdef VIAI_PROF
+    unsigned long long* prof;                                          // [block][2 roles][32 stages][4 stamps]
+#endif
+};
+#ifdef VIAI_PROF
+#define S2_STAMP(role, q, i) do { if (lane == 0 && (wave == 0 || wave == S2_NCONS) && (q) < 32) sa.prof[(((size_t)blockIdx.x * 2 + (role)) * 32 + (q)) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S2_STAMP(role, q, i) do { } while (0)
+#endif
+
+// ten LDS-DMA wave-instructions of one loader wave: instruction j -> LDS lds0 + j * 4096 (instruction index = loader + 4 j)
+__device__ __forceinline__ void dma_batch10(const i32x4& rs, unsigned lds0, int soff, const int (&v)[10]) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %4, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %5, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %6, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %7, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %8, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %9, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %10, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %11, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %12, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %13, %1, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(rs), "s"(lds0), "s"(soff), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9])
+        : "memory", "scc");
+}
+
+__global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_s2_dma_kernel(const ConvArgs a, const S2Args sa) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_s2[];     // [3 stages][40 KB]
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cin = a.C1, k16 = Cin / 16;                                        // k-steps per item
+    const int G = gridDim.x;
+    const int nmine = (sa.nitems - (int)blockIdx.x + G - 1) / G;                  // work items of this block: blockIdx.x + k G
+    const int nstage = nmine * k16;
+    auto item_of = [&](int k, int& tx, int& ty, int& n, int& nb) {
+        const int item = xcd_remap(blockIdx.x + k * G, sa.nitems);
+        const int tile = div_magic(item, sa.mnb);
+        nb = item - tile * sa.nnb;
+        const int r = div_magic(tile, sa.mx);
+        tx = tile - r * sa.tiles_x;
+        n = div_magic(r, sa.my);
+        ty = r - n * sa.tiles_y;
+    };
+
+#ifdef VIAI_PROF
+    if (tid == 0) sa.prof[(((size_t)blockIdx.x * 2 + 1) * 32 + 31) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (wave >= S2_NCONS) {
+        // ------------------------------------------------------------------------------------------------ loader waves
+        const int lw = wave - S2_NCONS;
+#ifndef VIAI_S2_LOADER_PRIO
+#define VIAI_S2_LOADER_PRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(VIAI_S2_LOADER_PRIO);   // the loaders issue ~50 instructions per stage and must not queue behind the consumers' MFMA / fragment streams
+        const i32x4 rs_in = rsrc_sgpr(a.in, (unsigned)((long)g.N * g.IH * g.IW * Cin * 4));
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_s2 + lw * 1024;
+        // lane -> (record 16 i + (lane >> 2), position lane & 3) of instruction i = lw + 4 j
+        int vint[10], edge[10];                      // interior offset relative to the patch origin; bit 0: patch row 0, bit 1: patch column 0, -1: no pixel
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int L = 16 * (lw + 4 * j) + (lane >> 2);
+            int par, rec;
+            if (L < S2_P1) { par = 0; rec = L; } else if (L < S2_P2) { par = 1; rec = L - S2_P1; } else if (L < S2_P3) { par = 2; rec = L - S2_P2; } else { par = 3; rec = L - S2_P3; }
+            const int py = par >> 1, px = par & 1, pitch = px ? 16 : 20;
+            const int r = rec / pitch, c = rec - r * pitch;
+            const int qp = (lane & 3) ^ ((c >> 2) & 3);                          // piece held at this position: plane qp >> 1, k-half qp & 1
+            const bool pix = L < S2_NREC && c < (px ? 16 : 17);
+            const int prow = 2 * r + py, pcol = 2 * c + px;
+            vint[j] = pix ? (prow * g.IW + pcol) * Cin * 4 + (qp >> 1) * 64 + (qp & 1) * 16 : DP_OOB;
+            edge[j] = pix ? (prow == 0 ? 1 : 0) | (pcol == 0 ? 2 : 0) : -1;
+        }
+        auto issue = [&](int q) {                    // stage q = (item q / k16, k-step q % k16) -> ring slot q % 3
+            const int k = q / k16, kk = q - k * k16;
+            int tx, ty, n, nb;
+            item_of(k, tx, ty, n, nb);
+            const int py0 = 2 * ty * S2_TH - 1, px0 = 2 * tx * S2_TW - 1;       // patch origin (pad 1)
+            const unsigned lds0 = lds_base + (q % S2_NSTG) * S2_STAGE;
+            const int koff = (kk >> 1) * 128 + (kk & 1) * 32;                    // chunk, k-step within the chunk's 128-byte record
+            if (ty > 0 && tx > 0) {
+                const int soff = __builtin_amdgcn_readfirstlane(((n * g.IH + py0) * g.IW + px0) * Cin * 4 + koff);
+                dma_batch10(rs_in, lds0, soff, vint);
+            } else {                                  // the pad row / column: those lanes go out of range (zeros)
+                const int base = ((n * g.IH + py0) * g.IW + px0) * Cin * 4;
+                const int m = (ty == 0 ? 1 : 0) | (tx == 0 ? 2 : 0);
+                int v[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) v[j] = (edge[j] < 0 || (edge[j] & m)) ? DP_OOB : vint[j] + base;
+                dma_batch10(rs_in, lds0, koff, v);
+            }
+        };
+        if (nstage > 0) issue(0);
+        if (nstage > 1) issue(1);
+        if (nstage > 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int q = 0; q < nstage; ++q) {
+            S2_STAMP(1, q, 0);
+            __syncthreads();                         // stage q landed (every loader waited); the consumers are done with stage q - 1
+            S2_STAMP(1, q, 1);
+            if (q + 2 < nstage) { issue(q + 2); S2_STAMP(1, q, 2); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }       // stage q + 1 landed, q + 2 in flight
+            else { S2_STAMP(1, q, 2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            S2_STAMP(1, q, 3);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- consumer waves
+    // Four waves, one per SIMD: wave wn owns ALL 128 pixels of the tile (four MFMA row tiles) x channels 32 wn .. + 31 of the block.  With eight
+    // 64-pixel waves every weight fragment was fetched twice per block: 144 KB per stage through a 64 B/clk vector-memory path = 2 300 of the
+    // stage's 3 456 MFMA cycles, and the loaders' DMA queued behind it (tools/probes/s2_dma_bench.hip: loader issue 3 700 - 4 700 cycles per stage).
+    const int wn = wave;
+    const float ascale = f16_scale_from_amax(a.amax);
+    const int NT = a.Cout / 32;
+    const int frag_plane = NT * g.wtaps * k16 * 1024;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 2 * frag_plane, 0x00020000);
+    int sl[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sl[t] = __builtin_amdgcn_readfirstlane(sa.slot[t]);
+    // A fragment of MFMA row i = lane & 31 of row tile m (tile pixel (2 m + (i >> 4), i & 15)), k-half lane >> 5, window column tx: byte offset in the stage
+    const int pc = lane & 15, kh = lane >> 5, rr = (lane & 31) >> 4;
+    int abase[3];                                                                 // tx = 0 (px 0, +0), 1 (px 1, +0), 2 (px 0, +1); leading plane (remainder: ^ 32)
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+        const int c = pc + (tx >> 1), pitch = (tx & 1) ? 16 : 20;
+        abase[tx] = (rr * pitch + c) * 64 + ((kh ^ ((c >> 2) & 3)) * 16);
+    }
+    const int half = lane >> 5, col = lane & 31;
+    const float inv = 1.0f / (ascale * F16_WSCALE);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((long)g.N * g.OH * g.OW * a.Cout * 4), 0x00020000);
+    const int opix = a.Cout * 4, orow = g.OW * opix;                              // bytes per output pixel / row
+    const int ovoff = (4 * half) * opix + (wn * 32 + col) * 4;
+
+    f32x16 acc[S2_TM];
+#pragma unroll
+    for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    // weight fragments of (window position t, k-step kk) of this wave's 32 channels: both planes.  NINE sets, one per window position (so the set of a
+    // tap is the same in every stage and every register index is static), requested S2_BD taps ahead -- across the stage boundary: the compiler-counted
+    // `vmcnt` of a tap then leaves 2 (S2_BD - 1) younger loads in flight.  With three sets / two taps ahead hipcc sank every request to within four MFMAs
+    // of its use and the stage ran at 5 200 - 7 900 ticks against 3 900 of MFMA issue (tools/probes/s2_dma_bench.hip, -DVIAI_PROF).
+#ifndef VIAI_S2_BD
+#define VIAI_S2_BD 5
+#endif
+    constexpr int S2_BD = VIAI_S2_BD;
+    u32x4 B[9][2];
+    int ntb = 0;                                                                  // channel tile of the current item
+    auto gloadB = [&](u32x4 (&b)[2], int t, int kk_, int ok_, int nt_) {
+        const int kk = __builtin_amdgcn_readfirstlane(kk_);
+        const int dead = ok_ ? 0 : DP_OOB;
+        const int voff = (nt_ * g.wtaps * k16 * 1024 + lane * 16) | dead;
+        const int soff = dead ? 0 : (sl[t] * k16 + kk) * 1024;
+        b[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, soff, 0);
+        b[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, soff + frag_plane, 0);
+    };
+    int tx_, ty_, n_, nb_;
+    if (nmine > 0) {
+        item_of(0, tx_, ty_, n_, nb_); ntb = nb_ * 4 + wn;
+#pragma unroll
+        for (int t = 0; t < S2_BD; ++t) gloadB(B[t], t, 0, 1, ntb);
+    }
+
+    int k = 0, kk = 0;                                                            // item, k-step of stage q
+    for (int q = 0; q < nstage; ++q) {
+        S2_STAMP(0, q, 0);
+        __syncthreads();                              // (fence + s_barrier: the fragment reads below must not move above it; the weight prefetch stays in flight)
+        S2_STAMP(0, q, 1);
+        const unsigned char* Sb = smem_s2 + (q % S2_NSTG) * S2_STAGE;
+        const bool last = kk + 1 == k16;                                          // last k-step of the item: the next stage's fragments belong to item k + 1
+        int ntb_next = ntb;
+        if (last && k + 1 < nmine) { int a0, a1, a2, nb2; item_of(k + 1, a0, a1, a2, nb2); ntb_next = nb2 * 4 + wn; }
+        const int kk_next = last ? 0 : kk + 1, ok_next = q + 1 < nstage;
+        u32x4 af[2][S2_TM][2];                                                    // [buffer][M tile][plane]
+        auto loadA = [&](int t, u32x4 (&f)[S2_TM][2]) {
+            constexpr int PB[4] = {S2_P0 * 64, S2_P1 * 64, S2_P2 * 64, S2_P3 * 64};
+            const int ty = t / 3, tx = t % 3;
+            const int pitch = (tx & 1) ? 16 : 20;
+            const int off = PB[(ty & 1) * 2 + (tx & 1)] + (ty >> 1) * pitch * 64;
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m) {
+                f[m][0] = *reinterpret_cast<const u32x4*>(Sb + abase[tx] + off + m * 2 * pitch * 64);
+                f[m][1] = *reinterpret_cast<const u32x4*>(Sb + (abase[tx] ^ 32) + off + m * 2 * pitch * 64);
+            }
+        };
+        loadA(0, af[0]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ta = t + S2_BD;
+            if (ta < 9) gloadB(B[ta], ta, kk, 1, ntb);
+            else gloadB(B[ta - 9], ta - 9, kk_next, ok_next, ntb_next);
+            if (t + 1 < 9) loadA(t + 1, af[(t + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);        // keep the requests above and the six MFMAs below as written: a solid MFMA group per tap
+            const u32x4 (&f)[S2_TM][2] = af[t & 1];
+            const u32x4 (&b)[2] = B[t];
+            // smallest partial products first: rem x lead, lead x rem, lead x lead (the order of conv_halo_wide_f16_kernel)
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[m][1]), __builtin_bit_cast(f16x8, b[0]), acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[m][0]), __builtin_bit_cast(f16x8, b[1]), acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[m][0]), __builtin_bit_cast(f16x8, b[0]), acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        S2_STAMP(0, q, 2);
+        if (last) {
+            // ------------------------------------------------------------------------------------------ epilogue of item k
+            item_of(k, tx_, ty_, n_, nb_);
+            const int obase = __builtin_amdgcn_readfirstlane(((n_ * g.OH + ty_ * S2_TH) * g.OW + tx_ * S2_TW) * opix + nb_ * 128 * 4);
+            const int co = nb_ * 128 + wn * 32 + col;
+            const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
+            auto store = [&](auto ACT) {
+#pragma unroll
+                for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[m][e] * inv + bv;
+                        if constexpr (decltype(ACT)::value) v = viai_act(v, a.act, a.slope);
+                        acc[m][e] = v;
+                        // pixel (2 m + (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 half)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, ovoff,
+                                                              obase + (2 * m + (e >> 3)) * orow + ((e & 3) + 8 * ((e >> 2) & 1)) * opix, 0);
+                    }
+            };
+            if (a.stat == nullptr && a.act != VIAI_ACT_NONE) store(std::true_type{});
+            else store(std::false_type{});
+            if (a.stat != nullptr) {
+                // (mean, M2) per 4 x 16 pixel block (rows 0 - 3 = row tiles 0, 1; rows 4 - 7 = row tiles 2, 3) and channel: the partial-block geometry of
+                // the register-staged kernel's 64-pixel tiles (viai_halo_s2_rows = 4), same two-pass arithmetic
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int m = 2 * hb; m < 2 * hb + 2; ++m)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) t += acc[m][e];
+                    t += __shfl_xor(t, 32, 64);
+                    const float mw = t / 64.f;
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int m = 2 * hb; m < 2 * hb + 2; ++m)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { const float d = acc[m][e] - mw; m2 += d * d; }
+                    m2 += __shfl_xor(m2, 32, 64);
+                    if (half == 0) {
+                        const int blk = (n_ * (2 * sa.tiles_y) + 2 * ty_ + hb) * sa.tiles_x + tx_;
+                        a.stat[(size_t)co * a.nblk_m + blk] = mw;
+                        a.stat[(size_t)(a.Cout + co) * a.nblk_m + blk] = m2;
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+            ntb = ntb_next;
+            ++k; kk = 0;
+        } else ++kk;
+        S2_STAMP(0, q, 3);
+    }
+#ifdef VIAI_PROF
+    if (tid == 0) sa.prof[(((size_t)blockIdx.x * 2 + 1) * 32 + 31) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+}  // namespace
+
+// stride-2 3 x 3 pad-1 forward layers the producer / consumer kernel takes: P16 input with Cin a multiple of 32 (one source), Cout a multiple
+// of 128 into one destination, the input exactly twice the output, whole 8 x 16 tiles, 32-bit byte offsets
+bool viai_conv_s2_dma_ok(const ConvArgs& a) {
+    const ConvGeom& g = a.g;
+    if (!viai_halo_dma_on() || !a.in_p16 || a.amax == nullptr || a.C2 != 0 || a.C1 % 32 != 0 || a.Cout % 128 != 0 || a.OC1 != a.Cout) return false;
+    if (g.my != 2 || g.mx != 2 || g.ntaps != 9 || g.IH != 2 * g.OH || g.IW != 2 * g.OW || g.OH % S2_TH != 0 || g.OW % S2_TW != 0) return false;
+    for (int t = 0; t < 9; ++t) if (g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return false;
+    if ((long)g.N * g.IH * g.IW * a.C1 * 4 >= (1l << 31) || (long)g.N * g.OH * g.OW * a.Cout * 4 >= (1l << 31)) return false;
+    const long items = (long)g.N * (g.OH / S2_TH) * (g.OW / S2_TW) * (a.Cout / 128);
+    return items * 64 < (1l << 31);
+}
+
+int viai_conv_s2_dma_launch(ConvArgs& a, hipStream_t st) {
+    if (!viai_conv_s2_dma_ok(a)) return (int)hipErrorInvalidValue;
+    const ConvGeom& g = a.g;
+    constexpr int lds = S2_NSTG * S2_STAGE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    S2Args sa;
+    sa.tiles_x = g.OW / S2_TW; sa.tiles_y = g.OH / S2_TH; sa.mx = tile_magic(sa.tiles_x); sa.my = tile_magic(sa.tiles_y);
+    sa.nnb = a.Cout / 128; sa.mnb = tile_magic(sa.nnb);
+    sa.nitems = g.N * sa.tiles_y * sa.tiles_x * sa.nnb;
+    for (int t = 0; t < 9; ++t) sa.slot[(g.dy[t] + 1) * 3 + (g.dx[t] + 1)] = g.ws[t];
+#ifdef VIAI_PROF
+    sa.prof = viai_dma_prof_buf;
+#endif
+    a.nblk_m = a.M / 64;                                      // BatchNorm partial blocks: 64 pixels (4 x 16) each
+    a.nblk_n = sa.nnb;
+    int grid = 256;
+    if (grid > sa.nitems) grid = sa.nitems;
+    VIAI_LAUNCH(conv_s2_dma_kernel, dim3(grid), dim3(S2_THREADS), lds, st, a, sa);
+    return viai_launch_status();
+}

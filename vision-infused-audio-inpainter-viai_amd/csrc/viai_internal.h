@@ -46,6 +46,12 @@ bool viai_bf3_sk_ok(long M, int n_out, int C1, int C2);
 bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout);
 bool viai_conv_halo16_ok(const ConvGeom& g, int C1, int C2, int Cout);
 int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st);
+// conv_halo_dma.hip: P16 input patches by LDS-DMA (round 5)
+int viai_conv_halo_c32_dma_launch(ConvArgs& a, int y0, int x0, const int* slots9, hipStream_t st);
+bool viai_halo_dma_on();
+bool viai_conv_halo_c32_dma_ok(const ConvArgs& a);
+bool viai_conv_s2_dma_ok(const ConvArgs& a);          // stride-2 forward, loader / consumer waves
+int viai_conv_s2_dma_launch(ConvArgs& a, hipStream_t st);
 // conv_stem.hip: the 7 x 7 stride-2 image conv of the ResNet branch on the f16x2 matrix-core path (forward + weight gradient)
 bool viai_conv_stem_ok(const ConvGeom& g, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
 int viai_conv_stem_fwd_launch(ConvArgs& a, hipStream_t st);
