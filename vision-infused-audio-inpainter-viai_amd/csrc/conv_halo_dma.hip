@@ -356,6 +356,8 @@ constexpr int S2_P0 = 0, S2_P1 = 9 * 20, S2_P2 = S2_P1 + 9 * 16, S2_P3 = S2_P2 +
 constexpr int S2_INSTR = 40;                                           // DMA wave-instructions per stage (16 records each), 10 per loader wave
 constexpr int S2_STAGE = S2_INSTR * 1024;                              // 40 KB
 constexpr int S2_NSTG = 3;
+constexpr int S2_OUT = S2_NSTG * S2_STAGE, S2_OUT_BYTES = 64 * 128 * 4;       // behind the ring: half an output tile (64 pixels x 128 channels fp32) + 2 KB of BatchNorm partials
+constexpr int S2_LDS = S2_OUT + S2_OUT_BYTES + 2 * 2 * 128 * 4;
 constexpr int S2_NLOAD = 4, S2_NCONS = 4;                              // waves: one loader and one consumer per SIMD
 constexpr int S2_TM = 4;                                               // 32-pixel MFMA tiles per consumer wave: all 128 pixels of the tile
 constexpr int S2_THREADS = 64 * (S2_NLOAD + S2_NCONS);
@@ -418,7 +420,7 @@ __device__ __forceinline__ void dma_batch10(const i32x4& rs, unsigned lds0, int 
 }
 
 __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_s2_dma_kernel(const ConvArgs a, const S2Args sa) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_s2[];     // [3 stages][40 KB]
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_s2[];     // [3 stages][40 KB] [half output tile 32 KB] [partials 1 KB]
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -482,6 +484,19 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 dma_batch10(rs_in, lds0, koff, v);
             }
         };
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((long)g.N * g.OH * g.OW * a.Cout * 4), 0x00020000);
+        int kl = 0;                                  // k-step of stage q
+        u32x4 obuf[16];                              // the last finished item's tile part of this wave: 2 halves x 8 pieces (16 pixels x 128 channels each half)
+        int obase[2] = {0, 0}, pend = 16;            // their addresses; next piece to store (16: none pending)
+        const int ovoff = (lane >> 5) * a.Cout * 4 + (lane & 31) * 16;
+        const int npend = k16 >= 4 ? 4 : 16 / k16 * 2;       // pieces per stage: all sixteen within the next item's stages
+        auto flush = [&](int cnt) {
+            const int hi = pend + cnt;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j >= pend && j < hi) __builtin_amdgcn_raw_buffer_store_b128(obuf[j], rs_out, ovoff, obase[j >> 3] + 2 * (j & 7) * a.Cout * 4, 0);
+            pend = hi < 16 ? hi : 16;
+        };
         if (nstage > 0) issue(0);
         if (nstage > 1) issue(1);
         if (nstage > 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -492,7 +507,37 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (q + 2 < nstage) { issue(q + 2); S2_STAMP(1, q, 2); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }       // stage q + 1 landed, q + 2 in flight
             else { S2_STAMP(1, q, 2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             S2_STAMP(1, q, 3);
+            // output pieces of the previous item, a few per stage: 64 KB per item and CU in one burst sat in front of the consumers' weight-fragment loads
+            // (the stage behind an epilogue took 6 800 cycles instead of 4 400) and kept the loaders from the barrier
+            flush(npend);
+            if (++kl == k16) {                       // last k-step of an item: its tile arrives through LDS in two halves (see the consumers' epilogue)
+                kl = 0;
+                flush(16);                           // (nothing left unless k16 < 4)
+                int tx, ty, n, nb;
+                item_of(q / k16, tx, ty, n, nb);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    __syncthreads();                 // E1 / E3
+                    // pixel 16 lw + 2 j + (lane >> 5) of the half = tile row 4 hb + lw, column 2 j + (lane >> 5); channels 4 (lane & 31) .. + 3 of block nb
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) obuf[8 * hb + j] = *reinterpret_cast<const u32x4*>(smem_s2 + S2_OUT + (16 * lw + 2 * j + (lane >> 5)) * 512 + (lane & 31) * 16);
+                    obase[hb] = __builtin_amdgcn_readfirstlane((((n * g.OH + ty * S2_TH + 4 * hb + lw) * g.OW + tx * S2_TW) * a.Cout + nb * 128) * 4);
+                    if (hb == 0) __syncthreads();    // E2: half 0 is in registers (the barrier's fence waited for the reads), the consumers may write half 1
+                }
+                if (lw < 2 && a.stat != nullptr) {   // loader hb stores block hb's partials: 256 floats [mean | M2][128 channels], lane -> four consecutive
+                    // (four scalar reads: hipcc turned `u32x4 sv = {}; if (..) sv = *(u32x4*)p; ... sv[i]` into four stores of element 0 -- the
+                    // vector-element defect of DESIGN 9.3)
+                    const float* sp = reinterpret_cast<const float*>(smem_s2 + S2_OUT + S2_OUT_BYTES) + lw * 256 + lane * 4;
+                    const float sv0 = sp[0], sv1 = sp[1], sv2 = sp[2], sv3 = sp[3];
+                    const int blk = (n * (2 * sa.tiles_y) + 2 * ty + lw) * sa.tiles_x + tx;
+                    const int which = lane >> 5, ch = nb * 128 + (lane & 31) * 4;
+                    float* sd = a.stat + (size_t)(which * a.Cout + ch) * a.nblk_m + blk;
+                    sd[0] = sv0; sd[a.nblk_m] = sv1; sd[2 * (size_t)a.nblk_m] = sv2; sd[3 * (size_t)a.nblk_m] = sv3;
+                }
+                pend = 0;
+            }
         }
+        flush(16);
         return;
     }
 
@@ -518,9 +563,6 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     const int half = lane >> 5, col = lane & 31;
     const float inv = 1.0f / (ascale * F16_WSCALE);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((long)g.N * g.OH * g.OW * a.Cout * 4), 0x00020000);
-    const int opix = a.Cout * 4, orow = g.OW * opix;                              // bytes per output pixel / row
-    const int ovoff = (4 * half) * opix + (wn * 32 + col) * 4;
 
     f32x16 acc[S2_TM];
 #pragma unroll
@@ -582,7 +624,6 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (ta < 9) gloadB(B[ta], ta, kk, 1, ntb);
             else gloadB(B[ta - 9], ta - 9, kk_next, ok_next, ntb_next);
             if (t + 1 < 9) loadA(t + 1, af[(t + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);        // keep the requests above and the six MFMAs below as written: a solid MFMA group per tap
             const u32x4 (&f)[S2_TM][2] = af[t & 1];
             const u32x4 (&b)[2] = B[t];
             // smallest partial products first: rem x lead, lead x rem, lead x lead (the order of conv_halo_wide_f16_kernel)
@@ -592,16 +633,29 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             for (int m = 0; m < S2_TM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[m][0]), __builtin_bit_cast(f16x8, b[1]), acc[m], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < S2_TM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[m][0]), __builtin_bit_cast(f16x8, b[0]), acc[m], 0, 0, 0);
+            // One consumer wave per SIMD: nothing else fills the matrix pipe while this wave issues its ten requests, so they go BETWEEN the MFMAs
+            // (one request behind each of the first ten; none of them is needed before the next tap) instead of in a block in front of them.
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         S2_STAMP(0, q, 2);
         if (last) {
             // ------------------------------------------------------------------------------------------ epilogue of item k
+            // The consumers do NOT store to global memory: a store in this wave's queue would sit between its weight-fragment loads, hipcc would have to
+            // drain `vmcnt(0)` behind it (mixed loads and stores may retire out of order), and the 64 dword stores + that drain measured 6 500 of an item's
+            // 24 000 cycles.  The tile goes to the LOADER waves through LDS in two halves of 64 pixels x 128 channels (32 KB, rows 0 - 3 then 4 - 7)
+            // together with its BatchNorm partials; they store it as 16-byte pieces from their own queue while this wave runs the next item.
             item_of(k, tx_, ty_, n_, nb_);
-            const int obase = __builtin_amdgcn_readfirstlane(((n_ * g.OH + ty_ * S2_TH) * g.OW + tx_ * S2_TW) * opix + nb_ * 128 * 4);
             const int co = nb_ * 128 + wn * 32 + col;
             const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
-            auto store = [&](auto ACT) {
+            const bool actf = a.stat == nullptr && a.act != VIAI_ACT_NONE;
+            float* ob = reinterpret_cast<float*>(smem_s2 + S2_OUT) + (4 * half) * 128 + wn * 32 + col;
+            float* sb = reinterpret_cast<float*>(smem_s2 + S2_OUT + S2_OUT_BYTES) + wn * 32 + col;
+            auto finish = [&](auto ACT) {
 #pragma unroll
                 for (int m = 0; m < S2_TM; ++m)
 #pragma unroll
@@ -609,38 +663,45 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         float v = acc[m][e] * inv + bv;
                         if constexpr (decltype(ACT)::value) v = viai_act(v, a.act, a.slope);
                         acc[m][e] = v;
-                        // pixel (2 m + (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 half)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, ovoff,
-                                                              obase + (2 * m + (e >> 3)) * orow + ((e & 3) + 8 * ((e >> 2) & 1)) * opix, 0);
                     }
             };
-            if (a.stat == nullptr && a.act != VIAI_ACT_NONE) store(std::true_type{});
-            else store(std::false_type{});
+            if (actf) finish(std::true_type{}); else finish(std::false_type{});
+            auto put = [&](int hb) {                  // pixel (2 (m & 1) + (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 half) of the half
+#pragma unroll
+                for (int m = 2 * hb; m < 2 * hb + 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ob[((2 * (m & 1) + (e >> 3)) * 16 + (e & 3) + 8 * ((e >> 2) & 1)) * 128] = acc[m][e];
+            };
+            put(0);
+            __syncthreads();                          // E1: half 0 is in LDS; the loaders read it while this wave reduces its statistics
+            float mw[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
             if (a.stat != nullptr) {
-                // (mean, M2) per 4 x 16 pixel block (rows 0 - 3 = row tiles 0, 1; rows 4 - 7 = row tiles 2, 3) and channel: the partial-block geometry of
-                // the register-staged kernel's 64-pixel tiles (viai_halo_s2_rows = 4), same two-pass arithmetic
+                // (mean, M2) of each 4 x 16 pixel block and channel: the partial-block geometry of the register-staged kernel's 64-pixel tiles
+                // (viai_halo_s2_rows = 4), two-pass; one wave per SIMD has no neighbour to hide a 32-long dependent add chain behind, so four partial sums
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
-                    float t = 0.f;
+                    float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int m = 2 * hb; m < 2 * hb + 2; ++m)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) t += acc[m][e];
-                    t += __shfl_xor(t, 32, 64);
-                    const float mw = t / 64.f;
-                    float m2 = 0.f;
+                        for (int e = 0; e < 16; ++e) t[e & 3] += acc[m][e];
+                    float ts = (t[0] + t[1]) + (t[2] + t[3]);
+                    ts += __shfl_xor(ts, 32, 64);
+                    mw[hb] = ts / 64.f;
+                    float u[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int m = 2 * hb; m < 2 * hb + 2; ++m)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) { const float d = acc[m][e] - mw; m2 += d * d; }
-                    m2 += __shfl_xor(m2, 32, 64);
-                    if (half == 0) {
-                        const int blk = (n_ * (2 * sa.tiles_y) + 2 * ty_ + hb) * sa.tiles_x + tx_;
-                        a.stat[(size_t)co * a.nblk_m + blk] = mw;
-                        a.stat[(size_t)(a.Cout + co) * a.nblk_m + blk] = m2;
-                    }
+                        for (int e = 0; e < 16; ++e) { const float d = acc[m][e] - mw[hb]; u[e & 3] += d * d; }
+                    float us = (u[0] + u[1]) + (u[2] + u[3]);
+                    us += __shfl_xor(us, 32, 64);
+                    m2[hb] = us;
                 }
             }
+            __syncthreads();                          // E2: the loaders hold half 0 in registers
+            put(1);
+            if (a.stat != nullptr && half == 0) { sb[0] = mw[0]; sb[128] = m2[0]; sb[256] = mw[1]; sb[384] = m2[1]; }
+            __syncthreads();                          // E3: half 1 and both blocks' partials are in LDS
 #pragma unroll
             for (int m = 0; m < S2_TM; ++m)
 #pragma unroll
@@ -672,7 +733,7 @@ bool viai_conv_s2_dma_ok(const ConvArgs& a) {
 int viai_conv_s2_dma_launch(ConvArgs& a, hipStream_t st) {
     if (!viai_conv_s2_dma_ok(a)) return (int)hipErrorInvalidValue;
     const ConvGeom& g = a.g;
-    constexpr int lds = S2_NSTG * S2_STAGE;
+    constexpr int lds = S2_LDS;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
