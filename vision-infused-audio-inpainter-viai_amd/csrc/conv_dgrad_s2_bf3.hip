@@ -220,7 +220,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 // (shift, class, tap) units of a chunk are a static list -- one barrier per chunk, no branches in the K loop.
 template <bool P16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_dgrad_s2_patch_kernel(const ConvArgs a) {
-    constexpr int NP = 2, TM = 2, PITCH = 80, PH = 9, PW = 17, HP = PH * PW, PLANE = HP * PITCH, STAGE = NP * PLANE;
+    // RPB: bytes between patch rows.  17 x 80 = 1360 ran the fragment reads two-way conflicted in every other lane group (SQ_LDS_BANK_CONFLICT /
+    // SQ_LDS_IDX_ACTIVE = 0.50, profiles/r04_c_pmc_dconv2_1_p16.json): a `ds_read_b128` group mixes columns of one tile row with columns of the next, so the
+    // pitch must be a multiple of the 256-byte bank row (conv_halo_bf3.hip has the derivation)
+    constexpr int NP = 2, TM = 2, PITCH = 80, PH = 9, PW = 17, HP = PH * PW, RPB = 1536, PLANE = PH * RPB, STAGE = NP * PLANE;
     constexpr int NL = (HP * 8 + 255) / 256;         // float4 per thread per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [2 stages][2 planes][153][80]
     const ConvGeom& g = a.g;                         // N, IH/IW = dy extent = base lattice, OH/OW = dx extent
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         const int dead = (((g.IH - 1 - iy) | (g.IW - 1 - ix) | (HP - 1 - h)) >> 31) & OOB;
         poff[j] = ((((n * g.IH + iy) * g.IW + ix) * K + q * 4) * 4) | dead;
     }
+    const int hc0 = h0 % PW, ls0 = (h0 / PW) * RPB + hc0 * PITCH;           // LDS position of this thread's first patch pixel
     u32x4 raw[NL];
     auto gloadA = [&](int chunk_) {
         const int chunk = __builtin_amdgcn_readfirstlane(chunk_);
@@ -264,7 +268,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             const int h = h0 + 32 * j;
-            if (h < HP) stage_put32<P16>(smem_b + buf * STAGE + h * PITCH, PLANE, q, raw[j], ascale, alim);
+            // pixel h = h0 + 32 j = (row, column) of the 17-wide patch: 32 = one row + 15 columns, so with w = floor(15 j / 17) column wraps for column 0
+            // the pixel has wrapped once more iff hc0 >= 17 (w + 1) - 15 j: a compare per item instead of a division by 17
+            const int wj = (15 * j) / 17, thr = 17 * (wj + 1) - 15 * j;
+            const int lo = ls0 + (j + wj) * RPB + (15 * j - 17 * wj) * PITCH + (hc0 >= thr ? RPB - PW * PITCH : 0);
+            if (h < HP) stage_put32<P16>(smem_b + buf * STAGE + lo, PLANE, q, raw[j], ascale, alim);
         }
     };
     // the nine units of a chunk: (shift sy, sx) -> window offset; class (a, b) -> accumulator a * 2 + b; tap r * 3 + s
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             for (int e = 0; e < 16; ++e) acc[c][i][e] = 0.f;
 
     // MFMA row r = lane & 31 of M-tile i -> base pixel (2 (wm * TM + i) + (r >> 4), r & 15) of the tile
-    const int aoff = ((wm * TM * 2 + ((lane & 31) >> 4)) * PW + (lane & 15)) * PITCH + 16 * (lane >> 5);
+    const int aoff = (wm * TM * 2 + ((lane & 31) >> 4)) * RPB + (lane & 15) * PITCH + 16 * (lane >> 5);
     // weight fragments two units ahead (three register sets; nine units = 3 x 3, so the set of a unit is the same in every chunk), A
     // fragments one group ahead, and every group of six MFMAs fenced by scheduling barriers so that nothing is issued between two MFMAs
     // on the same accumulator (conv_halo_bf3.hip has the measurements: D.conv3 212 -> 205 us, step 7.90 -> 7.75 ms from the same change)
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(As + p * PLANE + i * 2 * PW * PITCH);
+            for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(As + p * PLANE + i * 2 * RPB);
     };
     auto mfmas = [&](f32x16 (&ac)[TM], const u32x4 (&af)[TM][NP], const u32x4 (&b)[NP]) {
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
@@ -317,18 +325,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     auto chunk = [&](int cc, auto P) {
         const unsigned char* S = smem_b + (cc & 1) * STAGE + aoff;
         u32x4 afq[2][TM][NP];
-        loadA(S + ((U_SH[0] >> 1) * PW + (U_SH[0] & 1)) * PITCH, afq[0]);
+        loadA(S + (U_SH[0] >> 1) * RPB + (U_SH[0] & 1) * PITCH, afq[0]);
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
             const int cur = u % 3, ua = u + 2, nxt = ua % 3;
             if (ua < 9) gloadB(B0[nxt], B1[nxt], ua, cc);
             else gloadB(B0[nxt], B1[nxt], ua - 9, cc + 1);
-            const unsigned char* As = S + ((U_SH[u] >> 1) * PW + (U_SH[u] & 1)) * PITCH;
+            const unsigned char* As = S + (U_SH[u] >> 1) * RPB + (U_SH[u] & 1) * PITCH;
             loadA(As + 32, afq[1]);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(acc[U_CL[u]], afq[0], B0[cur]);
             __builtin_amdgcn_sched_barrier(0);
-            if (u + 1 < 9) loadA(S + ((U_SH[u + 1] >> 1) * PW + (U_SH[u + 1] & 1)) * PITCH, afq[0]);
+            if (u + 1 < 9) loadA(S + (U_SH[u + 1] >> 1) * RPB + (U_SH[u + 1] & 1) * PITCH, afq[0]);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(acc[U_CL[u]], afq[1], B1[cur]);
             __builtin_amdgcn_sched_barrier(0);
@@ -395,7 +403,7 @@ int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st) {
     }
     constexpr int patch = 1;
     if (a.amax != nullptr && patch && a.g.IH % 8 == 0 && a.g.IW % 16 == 0 && a.g.OH == 2 * a.g.IH && a.g.OW == 2 * a.g.IW && a.C1 % 32 == 0) {
-        constexpr int lds_p = 2 * 2 * 9 * 17 * 80;
+        constexpr int lds_p = 2 * 2 * 9 * 1536;
         static bool attr_p = false;
         if (!attr_p) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_patch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p);
