@@ -18,6 +18,7 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -107,6 +108,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)    # kept for old command lines: eager is the default
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the bounded legs on the other configs / the exact-fp32 mode that the default N = 1 run appends under `extra`")
     ap.add_argument("--layers", action="store_true", help="print the per-layer conv timing table to stderr")
     ap.add_argument("--config", choices=["audio", "av", "av_msd", "wavenet"], default="audio",
                     help="audio = BASELINE configs[1] (the metric); av = configs[2] (+ResNet-18 visual branch, N = T/4 frames); "
@@ -230,6 +232,151 @@ def peak_of(family):
     if family.endswith("_bf16x3"):
         return MFMA_BF16_PEAK_TFLOPS / 6.0
     return MFMA_F32_PEAK_TFLOPS
+
+
+# ---- whole-step floor (round 5) ---------------------------------------------------------------------------------------------------
+# Per launch: floor_us = max(algorithmic flops / the SUSTAINED ceiling of its arithmetic, algorithmic bytes / the measured copy bandwidth).
+SUSTAINED_TFLOPS = {"f16x2": 1677.0 / 3.0,        # v_mfma_f32_32x32x16_f16 on random operands at the clock the power budget leaves (profiles/r04_d_mfma_shapes.txt), 3 products per MAC
+                    "bf16x3": 1810.0 / 6.0,       # bf16 MFMA, random operands (profiles/r01_e_mfma_probe.txt), 6 products per MAC
+                    "f32": 155.0}                 # v_mfma_f32_32x32x2_f32 micro-benchmark ceiling = the fp32 vector rate (MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6300.0                            # float4 copy, MI355X_MICROARCH.md
+
+
+def _arith_of(family):
+    return "f16x2" if family.endswith("_f16x2") else "bf16x3" if family.endswith("_bf16x3") else "f32"
+
+
+def _conv_bytes(d):
+    oh = (d.IH - 1 - 2 * d.ph + d.kh) if d.transposed else (d.IH + 2 * d.ph - d.kh) // d.sh + 1
+    ow = (d.IW - 1 - 2 * d.pw + d.kw) if d.transposed else (d.IW + 2 * d.pw - d.kw) // d.sw + 1
+    cin = d.C1 + d.C2
+    return 4.0 * (d.N * d.IH * d.IW * cin + d.N * oh * ow * d.Cout + d.Cout * cin * d.kh * d.kw), d.N * oh * ow
+
+
+# algorithmic bytes of the non-conv entry points of the step, from their scalar arguments (tools/step_calls.py prints the argument lists
+# this table was written against); M = pixels, C = channels, fp32 elements.  Entry points not listed count 0 bytes (their time stays in
+# single_stream_ms, their floor is 0: the floor errs low).
+NONCONV_BYTES = {
+    "viai_bn_act_fwd_p16": lambda a: 8.0 * a[7] * a[8],                                   # read y, write z
+    "viai_bn_act_fwd_amax": lambda a: 8.0 * a[4] * a[5],
+    "viai_bn_act_fwd": lambda a: 8.0 * a[4] * a[5],
+    "viai_bn_act_bilinear_fwd_p16": lambda a: 4.0 * a[7] * a[12] * (a[8] * a[9] + a[10] * a[11]),      # read y at (IH, IW), write z at (OH, OW)
+    "viai_bn_act_bilinear_fwd_amax": lambda a: 4.0 * a[4] * a[9] * (a[5] * a[6] + a[7] * a[8]),
+    "viai_bn_act_bwd_p16": lambda a: 20.0 * a[11] * a[12],                                # reduce: dz, y; apply: dz, y -> dy
+    "viai_bn_act_bwd_amax": lambda a: 20.0 * a[11] * a[12],
+    "viai_bilinear_ac_bwd": lambda a: 4.0 * a[2] * a[7] * (a[3] * a[4] + a[5] * a[6]),
+    "viai_adam_step": lambda a: 28.0 * a[4],                                              # p, g, m, v read; p, m, v written
+    "viai_bce_fwd": lambda a: 8.0 * a[2], "viai_bce_bwd": lambda a: 12.0 * a[2],
+    "viai_l1_fwd": lambda a: 8.0 * a[2], "viai_l1_bwd": lambda a: 12.0 * a[2],
+    "viai_act_bwd_from_output": lambda a: 12.0 * a[3],
+    "viai_colsum": lambda a: 4.0 * a[1] * a[2],
+}
+# entry points that take a viai_conv2d descriptor first and stream one multi-channel tensor: bytes per (pixel x channel) of that tensor
+DESC_STREAM_BYTES = {
+    "viai_conv2d_cin1_bn_fwd": lambda a: 4.0 if a[6] else 0.0,                            # statistics pass writes nothing; the apply pass writes z
+    "viai_conv2d_cin1_bn_fwd_p16": lambda a: 4.0,
+    "viai_conv2d_cin1_bn_bwd": lambda a: 4.0, "viai_conv2d_cin1_bn_wgrad": lambda a: 4.0, "viai_conv2d_cin1_bn_dgrad": lambda a: 4.0,      # read dz once each
+    "viai_pair_cout1_fwd_dots": lambda a: 4.0, "viai_pair_cout1_fwd": lambda a: 8.0, "viai_pair_cout1_wgrad": lambda a: 4.0,
+    "viai_pair_cout1_bn_bwd_p16": lambda a: 20.0, "viai_pair_cout1_bn_bwd": lambda a: 20.0,
+}
+
+
+class StepFloor:
+    """Every launch of ONE single-stream step (weight gradients and D(real) back on the main stream): HIP events around every library call,
+    the call's algorithmic (flops, bytes), floor = max(flops / sustained ceiling, bytes / copy bandwidth)."""
+
+    def __init__(self, lib):
+        from viai_amd import _lib as L
+        # entry points that launch: their last parameter is the stream (void*); geometry / size queries are left alone
+        self.lib = lib
+        self.names = [n for n, (_r, at) in L.SIGNATURES.items() if hasattr(lib, n) and at and at[-1] is ctypes.c_void_p and not n.endswith(("_ok", "_blocks"))]
+        self.rec, self.orig = [], {}
+        self._buf = ctypes.create_string_buffer(64)
+
+    def install(self):
+        lib = self.lib
+        for name in self.names:
+            fn = getattr(lib, name)
+            self.orig[name] = fn
+            setattr(lib, name, self._wrap(name, fn))
+
+    def _wrap(self, name, fn):
+        lib = self.lib
+        is_conv = name in FAMILY_CALLS
+
+        def timed(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*args)
+            e1.record()
+            flops, nbytes, fam, key = 0.0, 0.0, "", ()
+            d = getattr(args[0], "_obj", None) if args else None
+            if is_conv and d is not None:
+                lib.viai_conv2d_last_kernel(self._buf, 64)
+                fam = self._buf.value.decode() or "unknown"
+                flops = KernelTimer._geom(d)[1]
+                if name == "viai_conv2d_cin1_bn_fwd" and not args[7]:
+                    flops = 0.0
+                nbytes = _conv_bytes(d)[0]
+                key = (d.N, d.IH, d.IW, d.C1 + d.C2, d.Cout, d.kh, d.kw, d.sh, d.sw)
+                if name in DESC_STREAM_BYTES:                      # the fused Cin = 1 layer: its input is one channel, the traffic is the multi-channel side
+                    nbytes = DESC_STREAM_BYTES[name](args) * _conv_bytes(d)[1] * d.Cout
+            elif d is not None and name in DESC_STREAM_BYTES:
+                px = _conv_bytes(d)[1] if (d.C1 + d.C2) == 1 else d.N * d.IH * d.IW
+                ch = d.Cout if (d.C1 + d.C2) == 1 else d.C1 + d.C2
+                nbytes = DESC_STREAM_BYTES[name](args) * px * ch
+                key = (d.N, d.IH, d.IW, d.C1 + d.C2, d.Cout)
+            elif name in NONCONV_BYTES:
+                nbytes = float(NONCONV_BYTES[name](args))
+                key = tuple(x for x in args if isinstance(x, int) and 0 < x < (1 << 31))[:6]
+            self.rec.append((name, fam, key, flops, nbytes, e0, e1))
+            return r
+        return timed
+
+    def uninstall(self):
+        for k, fn in self.orig.items():
+            setattr(self.lib, k, fn)
+
+    def summary(self, nsteps, ms_per_step):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fam, key, flops, nbytes, e0, e1 in self.rec:
+            t = e0.elapsed_time(e1) * 1e3                            # us
+            if t <= 0.0:
+                continue                                             # host-only entry points (geometry queries) launch nothing
+            arith = _arith_of(fam) if fam and fam != "direct" else "f32"
+            f_us = flops / (SUSTAINED_TFLOPS[arith] * 1e12) * 1e6
+            b_us = nbytes / (HBM_COPY_GBPS * 1e9) * 1e6
+            a = agg.setdefault((name, fam, key), [0, 0.0, 0.0, 0.0, 0.0, "mfma" if f_us >= b_us else "hbm"])
+            a[0] += 1; a[1] += t; a[2] += max(f_us, b_us); a[3] += flops; a[4] += nbytes
+        tot_t = sum(a[1] for a in agg.values()) / nsteps
+        tot_f = sum(a[2] for a in agg.values()) / nsteps
+        by_bound = {"mfma": 0.0, "hbm": 0.0}
+        for a in agg.values():
+            by_bound[a[5]] += a[2] / nsteps
+        fam_hbm = {}
+        for (name, fam, key), a in agg.items():
+            if fam:
+                h = fam_hbm.setdefault(fam, [0.0, 0.0, 0.0])
+                h[0] += a[1]; h[1] += a[3] / (SUSTAINED_TFLOPS[_arith_of(fam) if fam != "direct" else "f32"] * 1e12) * 1e6; h[2] += a[4] / (HBM_COPY_GBPS * 1e9) * 1e6
+        gaps = sorted(agg.items(), key=lambda kv: -(kv[1][1] - kv[1][2]))[:10]
+        return {
+            "step_floor_ms": round(tot_f * 1e-3, 3),
+            "frac_of_floor": round(tot_f * 1e-3 / ms_per_step, 4),
+            "single_stream_ms": round(tot_t * 1e-3, 3),
+            "floor_ms_by_bound": {k: round(v * 1e-3, 3) for k, v in by_bound.items()},
+            "launches_per_step": round(sum(a[0] for a in agg.values()) / nsteps),
+            "family_bound": {f: {"bound": "hbm" if h[2] > h[1] else "mfma", "frac_of_own_floor": round(max(h[1], h[2]) / h[0], 3),
+                                 "hbm_frac_of_copy_rate": round(h[2] / h[0], 3)} for f, h in sorted(fam_hbm.items()) if h[0] > 0},
+            "largest_gaps": [{"call": k[0][5:], "family": k[1], "shape": list(k[2]), "launches_per_step": round(a[0] / nsteps, 2),
+                              "measured_us": round(a[1] / a[0], 1), "floor_us": round(a[2] / a[0], 1), "bound": a[5],
+                              "gap_us_per_step": round((a[1] - a[2]) / nsteps, 1)} for k, a in gaps],
+            "model": ("per launch of one single-stream step (HIP events around every libviai_hip.so call, %d steps): floor = max(2 x MACs / sustained "
+                      "ceiling of the launch's arithmetic [f16x2 %.0f, bf16x3 %.0f, fp32 %.0f TFLOP/s: random-operand MFMA rates under the power limit], algorithmic "
+                      "bytes / %.1f TB/s [float4 copy]); conv bytes = input + output + weights once, BatchNorm forward 8 B / element, backward 20 B / element "
+                      "(two passes), resize in + out, Adam 28 B / parameter; frac_of_floor = step_floor_ms / ms_per_step of the timed (three-stream) step"
+                      % (nsteps, SUSTAINED_TFLOPS["f16x2"], SUSTAINED_TFLOPS["bf16x3"], SUSTAINED_TFLOPS["f32"], HBM_COPY_GBPS * 1e-3)),
+        }
 
 
 def cpu_baseline(args):
@@ -491,6 +638,28 @@ def main_wavenet(args):
     print(json.dumps(out), flush=True)
 
 
+def extra_legs():
+    """The other BASELINE configs and the exact-fp32 companion as bounded child runs of this script AFTER the timed region (default N = 1 run only):
+    configs[2] (vision-infused, 3 steps), configs[4] (WaveNet synthesis, 2048 time steps), configs[1] under VIAI_MATH=fp32 (5 steps).  Each child
+    prints its own contract line (with its own roofline); the lines are quoted whole under `extra`, with the wall time each leg took."""
+    legs = {"av": (["--config", "av", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {}),
+            "wavenet": (["--config", "wavenet", "--steps", "2048", "--warmup", "64", "--no-cpu-baseline"], {}),
+            "audio_exact_fp32": (["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extra"], {"VIAI_MATH": "fp32"})}
+    res = {}
+    for tag, (argv, envx) in legs.items():
+        env = dict(os.environ)
+        env.update(envx)
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + argv, env=env, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+            res[tag] = json.loads(line[-1]) if line else {"error": (p.stderr or p.stdout)[-400:]}
+        except Exception as e:                                     # a leg that fails must not take the headline line with it
+            res[tag] = {"error": repr(e)[:400]}
+        res[tag]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+    return res
+
+
 def shutdown(world):
     """leave the process group the clean way: every collective of this process has completed (device sync + barrier) before the
     communicator is destroyed, and nothing of torch.distributed is left for interpreter exit to tear down in an arbitrary order."""
@@ -639,7 +808,7 @@ def main():
         nprod = 3 if dom.endswith("_f16x2") else 6
         # the same kernel with nothing running beside it (weight gradients back on the main stream): what the kernel
         # itself reaches, without the time-sharing the as-run figure above includes
-        alone = None
+        alone = step_floor = None
         if m2._wgrad_stream is not None and not av:
             side, m2._wgrad_stream = m2._wgrad_stream, None
             dreal, m2._dreal_stream = m2._dreal_stream, None
@@ -652,6 +821,12 @@ def main():
             fam1 = kt1.summary()
             f1, t1, n1 = fam1[dom]
             kt1.uninstall()
+            sf = StepFloor(lib)
+            sf.install()
+            for i in range(3):
+                m2.optimize_parameters(i)
+            step_floor = sf.summary(3, ms_per_step)
+            sf.uninstall()
             m2._wgrad_stream, m2._dreal_stream = side, dreal
             alone = {"achieved": round(f1 / t1 * 1e-12, 2), "frac": round(f1 / t1 * 1e-12 / peak, 4), "avg_launch_us": round(t1 / n1 * 1e6, 2),
                      "note": "single-stream pass (weight gradients and D(real) back on the main stream): every launch with the chip to itself -- what the "
@@ -686,6 +861,10 @@ def main():
             out["config"]["algorithmic_gflop_note"] = "2 x MACs of every conv launch of the step (forward, data gradient, weight gradient), summed by the instrumented pass"
         if alone is not None:
             out["roofline"]["standalone"] = alone
+        if step_floor is not None:
+            out["roofline"]["step_floor"] = step_floor
+            out["roofline"]["step_floor_ms"] = step_floor["step_floor_ms"]
+            out["roofline"]["frac_of_floor"] = step_floor["frac_of_floor"]
         if world == 1 and not av and BF3:
             out["roofline"]["power_limit"] = dvfs_probe(dev)
         # memory-side traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
@@ -713,6 +892,11 @@ def main():
                                               "waits inside a launch, so it tracks the device time in every launch mode; the host's own cost per step is "
                                               "launch_modes.*.host_ms_per_step_idle_queue (one step enqueued into an idle queue): eager vs the C launch "
                                               "plan (bench.py --plan; bitwise the eager step)")
+    if rank == 0 and world == 1 and not av and not args.no_roofline and not args.no_extra and (args.batch, args.bins, args.frames) == (16, 256, 256):
+        del model
+        model = None
+        torch.cuda.empty_cache()
+        out["extra"] = extra_legs()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_av(args, hp.num_D) if av else cpu_baseline(args)
     if rank == 0:

