@@ -582,7 +582,7 @@ def main_wavenet(args):
     ms = timing["ms"] / timing["steps"]
     n_param = sum(p.numel() for p in net.parameters())
     fused = os.environ.get("VIAI_WN_FUSED", "1") != "0"
-    head_rows = os.environ.get("VIAI_WN_HEAD_ROWS", "1") != "0"
+    head_rows = True
     n_launch = len(net.conv_layers) + (3 if head_rows else 1) if fused else 2 * len(net.conv_layers) + 2
     kernel_chain = ("wn_stage_kernel x %d / %s" % (len(net.conv_layers), "wn_head_rows_kernel x 2 / wn_head_sample_kernel (head rows spread over the blocks, every row read once for all streams)"
                                                    if head_rows else "wn_head_fused_kernel")

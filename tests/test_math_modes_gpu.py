@@ -54,6 +54,17 @@ def test_step_goldens_hold_in_the_other_arithmetic_modes(mode):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-4000:]
 
 
+def test_step_goldens_hold_on_the_register_staged_kernels():
+    """VIAI_HALO_DMA=0 (round 5): the layers that run on the LDS-DMA kernels of csrc/conv_halo_dma.hip by default (G's 32-channel layers, the stride-2
+    forward convs of D and E) fall back to the register-staged kernels of conv_halo_bf3.hip -- the pre-split bitwise / tolerance tests and the step goldens
+    must hold on both."""
+    env = {"VIAI_HALO_DMA": "0"}
+    r = _child(env, ["-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                     "tests/test_networks_gpu.py::test_step_no_update_matches_oracle_and_golden",
+                     "tests/test_p16_gpu.py::test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_input_kernels"])
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-4000:]
+
+
 @pytest.mark.parametrize("act", [0, 1, 2], ids=["none", "relu", "lrelu"])
 def test_nan_propagates_through_the_piecewise_linear_activations(act):
     """torch: relu(nan) = leaky_relu(nan) = nan.  Through the BatchNorm apply pass (eval coefficients 1 / 0) and through a conv epilogue

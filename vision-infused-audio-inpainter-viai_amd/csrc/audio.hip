@@ -684,15 +684,12 @@ extern "C" int viai_stft_mel_banded(const float* wav, const float* window, const
                                     const float* mask, float* mel, int B, int n_samples, int fft, int hop, int n_mels, int frames,
                                     float min_level_db, float ref_level_db, void* stream) {
     if (B <= 0 || frames <= 0 || hop <= 0 || hop > fft || n_mels <= 0 || fft != SB_N || band_lo == nullptr || band_cnt == nullptr) return (int)hipErrorInvalidValue;
-    static int wave_kernel = -1;
-    if (wave_kernel < 0) { const char* e = getenv("VIAI_STFT_WAVE"); wave_kernel = e ? atoi(e) : 3; }       // 0: frame-batched kernel, 1: one 8-wave block per CU (523 us on 1024 clips), 2: two 4-wave blocks per CU (551), 3 (default): a frame per wave as a 512-point FFT (455 - 480), 4: the same as two 8-wave blocks per CU (479 - 491: exposed latency is not what bounds it)
-    if ((wave_kernel == 3 || wave_kernel == 4) && n_mels <= R5_MMAX && hop % 2 == 0 && n_samples % 2 == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0) {
-        if (wave_kernel == 4) return launch_stft_r512<8, 16, 8, 10>(2, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
+    // kernel choice by shape (the A/B variants of round 4 -- two 4-wave blocks per CU: 551 us on 1024 clips, the r512 kernel as two 8-wave blocks: 479 - 491 -- were
+    // measured, lost and are gone): a frame per wave as a 512-point FFT (455 - 480 us) where the shape allows, else one 8-wave block per CU (523), else the
+    // frame-batched kernel
+    if (n_mels <= R5_MMAX && hop % 2 == 0 && n_samples % 2 == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0)
         return launch_stft_r512<16, 32, 20, 10>(1, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
-    }
-    if (wave_kernel == 2 && n_mels <= 256)
-        return launch_stft_wave<4, 16, 8, 1024, 256>(2, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
-    if (wave_kernel && n_mels <= 1024)
+    if (n_mels <= 1024)
         return launch_stft_wave<8, 32, 20, 2048, 1024>(1, wav, window, basis_t, band_lo, band_cnt, mask, mel, B, n_samples, hop, n_mels, frames, min_level_db, ref_level_db, (hipStream_t)stream);
     constexpr int lds = (8 * SB_N + 768) * (int)sizeof(float2);
     static bool attr_done = false;

@@ -776,9 +776,7 @@ int viai_halo_tiles_y(const ConvGeom& g) { return (g.OH + HT_H - 1) / HT_H; }
 // tile rows of the stride-2 forward instance: 4 (64-pixel tiles, two blocks per CU) when the map is a whole number of them and large enough
 // to fill the chip that way, else 8
 int viai_halo_s2_rows(const ConvGeom& g) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VIAI_HALO_S2_ROWS4"); on = e ? atoi(e) : 1; }
-    if (!on || g.my != 2 || g.OH % 4 != 0) return 8;
+    if (g.my != 2 || g.OH % 4 != 0) return 8;
     // (round 5) the loader / consumer kernel (conv_halo_dma.hip) writes one partial block per 4 x 16 pixels whatever the map size; the block geometry is a
     // property of the LAYER (viai_conv2d_stat_geom does not know which kernel will run), so the register-staged kernel follows on every map that kernel takes
     if (viai_halo_dma_on() && g.OH % 8 == 0 && g.OW % 16 == 0 && g.IH == 2 * g.OH && g.IW == 2 * g.OW) return 4;
@@ -787,10 +785,8 @@ int viai_halo_s2_rows(const ConvGeom& g) {
 int viai_halo_tiles_x(const ConvGeom& g) { return (g.OW + HT_W - 1) / HT_W; }
 
 bool viai_conv_halo_wide_ok(const ConvArgs& a) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VIAI_HALO_WIDE"); on = e ? atoi(e) : 1; }
     const ConvGeom& g = a.g;
-    if (!on || a.C1 % 32 != 0 || a.C2 % 32 != 0 || a.C1 < 32 || (a.OC1 != a.Cout && a.OC1 % 32 != 0)) return false;
+    if (a.C1 % 32 != 0 || a.C2 % 32 != 0 || a.C1 < 32 || (a.OC1 != a.Cout && a.OC1 % 32 != 0)) return false;
     if (!(a.Cout == 32 || a.Cout == 64 || a.Cout % 128 == 0)) return false;
     const bool whole = g.OH % HT_H == 0 && g.OW % HT_W == 0;
     if (whole && a.Cout <= 64 && a.C1 + a.C2 <= 64 && a.C2 == 0) return false;     // the small-channel halo kernels take these (whole tiles only)
@@ -862,10 +858,6 @@ int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
     // then feeds four M tiles, so the fragment stream through L1 halves (2 KB per 12 MFMAs) while the patch reads from LDS double (8 KB) --
     // LDS has twice L1's bandwidth, and the registers drop 231 -> 215.  D.conv3 203.5 -> 198 us, step 7.455 -> 7.423 ms (same box A/B).
     constexpr int tm4 = 1;
-    static int n128 = -1;                          // A/B switch: 128-channel blocks (four waves, 512 blocks, two per CU) for the wide layers too
-    if (n128 < 0) { const char* e = getenv("VIAI_HALO_WIDE_N128"); n128 = e ? atoi(e) : 0; }
-    if (n128 == 1) return launch_halo_wide<1, 4, 4, 1>(a, y0, x0, sl, st);
-    if (n128 == 2 && a.Cout % 256 == 0) return launch_halo_wide<2, 4, 2, 2>(a, y0, x0, sl, st);
     if (tm4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<1, 8, 4, 1>(a, y0, x0, sl, st);
     if (wn4 && a.Cout % 256 == 0 && (long)a.nblk_m * (a.Cout / 256) >= 256) return launch_halo_wide<2, 4, 2, 2>(a, y0, x0, sl, st);
     return launch_halo_wide<1, 4, 4, 1>(a, y0, x0, sl, st);           // (128-channel blocks, same reasoning: 899 -> 855 us on 1024 x 28 x 28 x 128, 122.5 -> 117 us on 16 x 64 x 128 x 128)

@@ -404,9 +404,7 @@ constexpr int STEM_WGRAD_BLOCKS = 512;
 
 // 7 x 7, stride 2, padding 3, 2 - 4 input channels stored four per pixel, 64 output channels, output extent a whole number of 8 x 16 tiles
 bool viai_conv_stem_ok(const ConvGeom& g, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VIAI_STEM_F16"); on = e ? atoi(e) : 1; }
-    if (!on || Cin < 2 || Cin > 4 || Cout != ST_COUT || kh != ST_K || kw != ST_K || sh != 2 || sw != 2 || ph != 3 || pw != 3) return false;
+    if (Cin < 2 || Cin > 4 || Cout != ST_COUT || kh != ST_K || kw != ST_K || sh != 2 || sw != 2 || ph != 3 || pw != 3) return false;
     if (g.OH % ST_TH != 0 || g.OW % ST_TW != 0 || g.IH != 2 * g.OH || g.IW != 2 * g.OW) return false;
     return (long)g.IH * g.IW * 16 < (1l << 31) && (long)g.N * (g.OH / ST_TH) * (g.OW / ST_TW) < (1l << 30);
 }

@@ -1048,8 +1048,7 @@ int wn_step_fused_impl(const viai_wn_synth* s, int t_arg, hipStream_t st) {
         const int nb = H + (l == 0 ? 1 : (C + S + 3) / 4);
         VIAI_LAUNCH(wn_stage_kernel<NB>, dim3(nb), dim3(256), 0, st, a);
     }
-    static const bool split_head = !(getenv("VIAI_WN_HEAD_ROWS") != nullptr && atoi(getenv("VIAI_WN_HEAD_ROWS")) == 0);
-    if (split_head && S <= H && s->out_ch <= 256) {
+    if (S <= H && s->out_ch <= 256) {
         float* zlast = zb[(n - 1) & 1];
         float* hid = zb[n & 1];                    // (B, S) fits the (B, H) buffer; the next time step's stage 0 overwrites it
         VIAI_LAUNCH(wn_head_rows_kernel<NB>, dim3((S + 3) / 4), dim3(256), 0, st, L[n - 1].w_skip, L[n - 1].b_skip, (const float*)zlast, H, s->skips, S, 0, n == 1 ? 1 : 0);

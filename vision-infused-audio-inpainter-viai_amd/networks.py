@@ -94,15 +94,15 @@ def _instance_norm_layer(x, conv, inorm, act, x2, transposed):
 
 
 _FLOW_STREAMS = {}
-FLOW_STREAM = os.environ.get("VIAI_FLOW_STREAM", "1") != "0"           # ImageEmbedding: the flow ResNet on its own stream (A/B switch)
-FUSE_BN_TAIL = os.environ.get("VIAI_FUSE_BN_TAIL", "1") != "0"      # BatchNorm apply + (residual add + ReLU | ReLU + max-pool) in one pass (A/B switch)
+FLOW_STREAM = True           # ImageEmbedding: the flow ResNet on its own stream (module switch)
+FUSE_BN_TAIL = True      # BatchNorm apply + (residual add + ReLU | ReLU + max-pool) in one pass (module switch: tests/test_resnet_gpu.py flips it)
 
 
 # Residual joins / the stem's pool can write a pre-split (P16) twin of their output for the next BasicBlock's conv1 (ops.conv_bn_act `out_p16` on a layer with
 # `residual` / `pool`).  Measured on the vision-infused step: the kernel-time sum falls 224 -> 212 ms (the conv1 forward / weight-gradient kernels stop
 # splitting), the step does not move (118.7 without, 119.0 with: both queues stay full, the chip is at its power / bandwidth limit and the twin adds a write
-# of the tensor) -- so it is OFF by default; `VIAI_P16_TWIN=1` and tests/test_p16_gpu.py keep it alive.
-P16_TWIN = os.environ.get("VIAI_P16_TWIN", "0") != "0"
+# of the tensor) -- so it is OFF; tests/test_p16_gpu.py flips the module switch and keeps the path alive.
+P16_TWIN = False
 
 
 def takes_p16(x_shape, conv):

@@ -36,7 +36,7 @@ DIRECT_GRAD = False
 WGRAD_STREAM = None
 _deferred = []
 F16_BACKWARD = os.environ.get("VIAI_F16_BACKWARD", "1") != "0"     # f16x2 data gradients (dynamic per-tensor scale)
-F16_DYNAMIC = os.environ.get("VIAI_F16_DYNAMIC", "1") != "0"       # 0: static x16 activation scale in the forward / weight-gradient kernels (A/B only)
+F16_DYNAMIC = True                                                 # False: static x16 activation scale in the forward / weight-gradient kernels (module switch, A/B only)
 
 # Pre-split tensors (P16, include/viai_hip.h ABI 13).  A tensor tagged `_viai_p16` holds, in the bytes of an fp32 NHWC tensor of the same
 # shape, the two fp16 planes the f16x2 kernels would make of its values (scale from its `_viai_amax` slot, filled by the producer with an
@@ -53,7 +53,7 @@ def is_p16(t):
 
 def p16_mask(d):
     # (the library reads two of its kernel-family switches per call -- tests flip them at run time -- so the cached mask is keyed on them)
-    key = ("p16", os.environ.get("VIAI_WGRAD_PATCH_S2"), os.environ.get("VIAI_WGRAD_PATCH_NARROW"))
+    key = ("p16", os.environ.get("VIAI_WGRAD_PATCH_S2"))
     m = d.get(key)
     if m is None:
         m = d[key] = int(_lib.load().viai_conv2d_p16_ok(d["ref"]))
@@ -806,8 +806,8 @@ class _ConvBnAct(torch.autograd.Function):
 
 # The first layer's weight gradient is the LAST launch of a backward: on the side stream it lengthens the tail the main chain waits for at the join in front
 # of Adam (84 / 60 us of waiting in the D / G step, profiles/r04_d_queues_plan.txt); on the main stream the two queues end together.  6.672 -> 6.622 ms
-# (six same-box pairs, ranges disjoint); VIAI_CIN1_WGRAD_MAIN=0 puts it back on the side stream.
-CIN1_WGRAD_MAIN = os.environ.get("VIAI_CIN1_WGRAD_MAIN", "1") != "0"
+# (six same-box pairs, ranges disjoint); module switch.
+CIN1_WGRAD_MAIN = True
 
 
 def _backward_cin1(ctx, lib, dz, x, weight, coef, st):
@@ -944,7 +944,7 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
     return _tag_amax(_ConvBnAct.apply(x, x2, weight, bias, None, None, None, None, None, None, cfg), cfg)
 
 
-FUSE_BN_UP = os.environ.get("VIAI_FUSE_BN_UP", "1") != "0"      # BatchNorm apply + the resize behind a decoder block in one pass (A/B switch)
+FUSE_BN_UP = True      # BatchNorm apply + the resize behind a decoder block in one pass (module switch: tests/test_kernels_gpu.py flips it)
 
 
 def upsample_fusable(x, weight, bias, bn, transposed, act, size=None):
@@ -974,9 +974,9 @@ def _tag_amax(z, cfg):
     return z
 
 
-PAIR_FUSED = os.environ.get("VIAI_PAIR_FUSED", "1") != "0"     # (conv + BN + act) -> (Cout = 1 conv) pairs as one op (A/B switch)
+PAIR_FUSED = True     # (conv + BN + act) -> (Cout = 1 conv) pairs as one op (module switch: tests/test_kernels_gpu.py flips it)
 PAIR_FWD_DOTS = True        # wide pairs: tap products per pixel + gather instead of bn_act + the row-run forward (7.00 -> 6.94 ms; module switch for A/B)
-PAIR_FWD_FUSED = os.environ.get("VIAI_PAIR_FWD_FUSED", "1") != "0"     # ... and their forward without the tensor in between (A/B switch)
+PAIR_FWD_FUSED = True     # ... and their forward without the tensor in between (module switch)
 
 
 class _ConvBnActCout1(torch.autograd.Function):
