@@ -148,7 +148,9 @@ def test_weight_gradient_on_presplit_operands_is_bitwise_the_fp32_input_kernel(c
 
 CONV_CASES = {"wide_s1_128to256": (1, 128, 256, False, 64), "wide_s1_256to128_T": (1, 256, 128, True, 64), "wide_s1_128to32_T": (1, 128, 32, True, 96),
               "halo64_64to64_T": (1, 64, 64, True, 64), "c32_32to32_T": (1, 32, 32, True, 64), "halo32_32to64": (1, 32, 64, False, 64),
-              "wide_s2_64to128": (2, 64, 128, False, 64), "wide_s2_128to256": (2, 128, 256, False, 32)}
+              "wide_s2_64to128": (2, 64, 128, False, 64), "wide_s2_128to256": (2, 128, 256, False, 32),
+              # 256 work items of 128 pixels x 256 channels: the stride-1 instance of the loader / consumer kernel (D.conv3's kernel in both directions)
+              "wide_s1_256to512_dma": (1, 256, 512, False, 64), "wide_s1_256to256_T_dma": (1, 256, 256, True, 128)}
 
 
 @pytest.mark.parametrize("case", list(CONV_CASES), ids=list(CONV_CASES))
@@ -179,11 +181,12 @@ def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_inp
     _lib.check(lib.viai_conv2d_fwd_p16(d["ref"], xp.data_ptr(), wp.data_ptr(), 0, y1.data_ptr(), st1.data_ptr(), 0, xa.data_ptr(), _st()), "fwd_p16")
     lib.viai_conv2d_last_kernel(fam, 64)
     assert fam.value == f0 and f0.endswith(b"_f16x2"), (f0, fam.value)
-    if S == 2:
+    dma = S == 2 or case.endswith("_dma")
+    if dma:
         # the pre-split input runs on the loader / consumer kernel (csrc/conv_halo_dma.hip), which walks K as (16-channel k-step, tap) where the
         # register-staged kernel walks (32-channel chunk, tap, k-step): the same products, summed in another order -- fp32 rounding apart
         assert ((y0 - y1).norm() / y0.norm()).item() < 1e-6
-        Mb = y0.numel() // Co // 64                                     # 64-pixel partial blocks: (mean, M2) per block and channel
+        Mb = d["nblk"]                                                   # 64- / 128-pixel partial blocks: (mean, M2) per block and channel
         m0, m1 = st0.view(2, Co, Mb), st1.view(2, Co, Mb)
         assert (m0[0] - m1[0]).abs().max().item() < 1e-5 * y0.abs().max().item()
         assert ((m0[1] - m1[1]).abs() / m0[1].abs().clamp_min(1e-12)).max().item() < 1e-4
@@ -202,7 +205,10 @@ def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_inp
     lib.viai_conv2d_last_kernel(fam, 64)
     assert fam.value == f0, (f0, fam.value)
     torch.cuda.synchronize()
-    assert torch.equal(g0, g1)
+    if dma and S == 1:
+        assert ((g0 - g1).norm() / g0.norm()).item() < 1e-6          # (the data gradient of a stride-1 layer is the same kernel on the flipped filter)
+    else:
+        assert torch.equal(g0, g1)
     xr = x.double().permute(0, 3, 1, 2).cpu().requires_grad_(True)
     o = torch.nn.functional.conv_transpose2d(xr, w.double().cpu(), None, 1, 1) if tr else torch.nn.functional.conv2d(xr, w.double().cpu(), None, S, 1)
     (o * dy.double().permute(0, 3, 1, 2).cpu()).sum().backward()
@@ -326,13 +332,14 @@ def test_discriminator_and_decoder_block_run_presplit_and_agree_with_the_fp32_pa
         return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
     assert rel(res[True][0], res[False][0]) < 1e-5 and rel(res[True][2], res[False][2]) < 1e-5
     assert rel(res[True][3], res[False][3]) < 1e-4
+    nD = len(res[True][1])
     for i, (ga, gb) in enumerate(zip(res[True][1] + res[True][4], res[False][1] + res[False][4])):
-        # D.conv1.weight and its BatchNorm's gamma / beta (indices 0 - 2: behind three BatchNorm layers whose gradients sum to ~0 per channel) are the tensors of
-        # this comparison whose value is mostly cancellation: two fp32-grade evaluations that differ only in summation order -- the reference's own modules on
+        # The discriminator's gradients (indices < nD; most of all D.conv1.weight and its BatchNorm's gamma / beta, behind three BatchNorm layers whose gradients
+        # sum to ~0 per channel) are the tensors of this comparison whose value is mostly cancellation: two fp32-grade evaluations that differ only in summation order -- the reference's own modules on
         # the CPU against the oracle, tools/grad_table.py -- land 1e-3 .. 3e-3 apart on them.  Since round 5 the pre-split path runs D.conv2_1 / conv2_2 on
-        # the loader / consumer kernel (another K order than the fp32-input kernel): 4.2e-3 / 3.9e-3 here; the fp64-truth test at benchmark size
+        # the loader / consumer kernels (another K order than the fp32-input kernels, D.conv3 included): up to 4.2e-3 here; the fp64-truth test at benchmark size
         # (tests/test_networks_gpu.py) is what bounds the accuracy of either path.
-        assert rel(ga, gb) < (8e-3 if i < 3 else 2e-3), (i, rel(ga, gb))
+        assert rel(ga, gb) < (8e-3 if i < nD else 2e-3), (i, rel(ga, gb))
 
 
 @pytest.mark.parametrize("Cc", [64, 128, 512])

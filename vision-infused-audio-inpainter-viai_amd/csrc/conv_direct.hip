@@ -241,49 +241,65 @@ __global__ __launch_bounds__(NT) void cin1_fwd_kernel(const DirectArgs a) {
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void cin1_stats_cov_kernel(const DirectArgs a) {
     constexpr int T = KH * KW, NC = T * (T + 1) / 2;
-    __shared__ double sm[4][T], sc[4][NC], mt[T], cm[NC];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int SL = 256 / NC;                       // pixel slices per (t, u) pair: thread = (pair, slice)
+    constexpr int MS = 256 / T;                        // ... per tap for the means
+    __shared__ float xs[T][257];                       // the block's tap vectors, tap-major; rows of 257 words: lanes that read the same pixel of different taps hit different banks
+    __shared__ double part[256], mt[T], cm[NC];
+    const int tid = threadIdx.x;
     const int p0 = blockIdx.x * CIN1_PB, p = p0 + tid;
     const int cnt = min(CIN1_PB, a.M - p0);
-    float xt[T];
+    {
+        float xt[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) xt[t] = 0.f;
-    if (p < a.M) {
-        const int ox = p % a.OW; const int r_ = p / a.OW; const int oy = r_ % a.OH, n = r_ / a.OH;
-        const float* xb = a.x + (size_t)n * a.IH * a.IW;
+        for (int t = 0; t < T; ++t) xt[t] = 0.f;
+        if (p < a.M) {
+            const int ox = p % a.OW; const int r_ = p / a.OW; const int oy = r_ % a.OH, n = r_ / a.OH;
+            const float* xb = a.x + (size_t)n * a.IH * a.IW;
 #pragma unroll
-        for (int r = 0; r < KH; ++r) {
-            const int iy = oy * a.sh + tap_dy(a, r);
+            for (int r = 0; r < KH; ++r) {
+                const int iy = oy * a.sh + tap_dy(a, r);
 #pragma unroll
-            for (int q = 0; q < KW; ++q) {
-                const int ix = ox * a.sw + tap_dx(a, q);
-                if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) xt[r * KW + q] = cin1_x(a, xb, n, iy, ix);
+                for (int q = 0; q < KW; ++q) {
+                    const int ix = ox * a.sw + tap_dx(a, q);
+                    if ((unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW) xt[r * KW + q] = cin1_x(a, xb, n, iy, ix);
+                }
             }
         }
-    }
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const double sv = wave_sum_d_dpp((double)xt[t]);
-        if (lane == 0) sm[wave][t] = sv;
+        for (int t = 0; t < T; ++t) xs[t][tid] = xt[t];
     }
     __syncthreads();
-    if (tid < T) mt[tid] = ((sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid])) / (double)cnt;
-    __syncthreads();
-    double dv[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) dv[t] = p < a.M ? (double)xt[t] - mt[t] : 0.0;
-    {
-        int k = 0;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int u = t; u < T; ++u, ++k) {
-                const double sv = wave_sum_d_dpp(dv[t] * dv[u]);
-                if (lane == 0) sc[wave][k] = sv;
-            }
+    // tap means: thread (t, slice) sums its pixels, thread t adds the slices in a fixed order
+    if (tid < T * MS) {
+        const int t = tid / MS, sl = tid % MS;
+        double sv = 0.0;
+        for (int i = sl; i < cnt; i += MS) sv += (double)xs[t][i];
+        part[tid] = sv;
     }
     __syncthreads();
-    if (tid < NC) cm[tid] = (sc[0][tid] + sc[1][tid]) + (sc[2][tid] + sc[3][tid]);
+    if (tid < T) {
+        double sv = 0.0;
+        for (int sl = 0; sl < MS; ++sl) sv += part[tid * MS + sl];
+        mt[tid] = sv / (double)cnt;
+    }
+    __syncthreads();
+    // centred second moments: thread (pair k = (t, u), slice)
+    if (tid < NC * SL) {
+        const int k = tid / SL, sl = tid % SL;
+        int t = 0, rem = k;
+        while (rem >= T - t) { rem -= T - t; ++t; }
+        const int u = t + rem;
+        const double m0 = mt[t], m1 = mt[u];
+        double sv = 0.0;
+        for (int i = sl; i < cnt; i += SL) sv += ((double)xs[t][i] - m0) * ((double)xs[u][i] - m1);
+        part[tid] = sv;
+    }
+    __syncthreads();
+    if (tid < NC) {
+        double sv = 0.0;
+        for (int sl = 0; sl < SL; ++sl) sv += part[tid * SL + sl];
+        cm[tid] = sv;
+    }
     __syncthreads();
     for (int c = tid; c < a.Cout; c += 256) {
         double w[T], mean = a.bias ? (double)a.bias[c] : 0.0, m2 = 0.0;
@@ -1474,8 +1490,12 @@ static int cin1_bn_fwd_impl(const viai_conv2d* c, const float* x, const float* x
     a.nblk = (a.M + CIN1_PB - 1) / CIN1_PB;
     cin1_rows_ok(a, CIN1_PB, c->kh, c->kw);
 #define CALL(KH, KW)                                                                                                               \
-    if (z == nullptr) {                                                                                                            \
+    if (z == nullptr && KH * KW <= 4) {           /* tap-covariance statistics: 25.7 -> 9.5 us on D.conv1 (1 x 4); the 3 x 3 window (45 moments, 18 scattered loads per pixel: 18.6 against 14.4 us on E.conv1) keeps the conv-then-reduce pass */ \
         VIAI_LAUNCH((cin1_stats_cov_kernel<KH, KW>), dim3(a.nblk), dim3(256), 0, st, a);                                          \
+    } else if (z == nullptr) {                                                                                                     \
+        if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                       \
+        else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                 \
+        else VIAI_LAUNCH((cin1_fwd_kernel<32, KH, KW, 1>), dim3(a.nblk), dim3(256), 0, st, a);                                    \
     } else if (z_amax != nullptr && a.nblk >= 512 && !p16) {                                                                                                       \
         if (c->Cout == 32) VIAI_LAUNCH((cin1_fwd_kernel<8, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);      \
         else if (c->Cout == 64) VIAI_LAUNCH((cin1_fwd_kernel<16, KH, KW, 2, 1024>), dim3((a.nblk + 3) / 4), dim3(1024), 0, st, a);\

@@ -849,6 +849,7 @@ int viai_conv_halo_wide_launch(ConvArgs& a, hipStream_t st) {
     // share a CU and one block's patch load / epilogue runs under the other's MFMAs -- the 128-pixel block is alone on its CU (98 KB, one LDS
     // stage) and its K loop is only 2 .. 4 chunks long, so nothing covered its prologue and epilogue
     if (g.my == 2 && viai_conv_s2_dma_ok(a)) { viai_tag_kernel("halo_wide_s2_f16x2"); return viai_conv_s2_dma_launch(a, st); }
+    if (g.my == 1 && viai_conv_s1_dma_ok(a)) { viai_tag_kernel("halo_wide256_f16x2"); return viai_conv_s1_dma_launch(a, st); }
     if (g.my == 2 && viai_halo_s2_rows(g) == 4) return (a.Cout % 256 == 0) ? launch_halo_wide<1, 4, 2, 2, 2>(a, y0, x0, sl, st) : launch_halo_wide<1, 4, 2, 1, 2>(a, y0, x0, sl, st);
     if (g.my == 2) return (a.Cout % 256 == 0) ? launch_halo_wide<2, 4, 2, 2, 2>(a, y0, x0, sl, st) : launch_halo_wide<2, 4, 2, 1, 2>(a, y0, x0, sl, st);
     if (a.Cout == 32) return launch_halo_wide<4, 1, 1, 1>(a, y0, x0, sl, st);

@@ -352,15 +352,25 @@ bool viai_halo_dma_on() {
 namespace {
 
 constexpr int S2_TH = 8, S2_TW = 16;                                   // output tile
-constexpr int S2_P0 = 0, S2_P1 = 9 * 20, S2_P2 = S2_P1 + 9 * 16, S2_P3 = S2_P2 + 8 * 20, S2_NREC = S2_P3 + 8 * 16;   // record index of each sub-patch; 612 records
-constexpr int S2_INSTR = 40;                                           // DMA wave-instructions per stage (16 records each), 10 per loader wave
-constexpr int S2_STAGE = S2_INSTR * 1024;                              // 40 KB
+constexpr int S2_P0 = 0, S2_P1 = 9 * 20, S2_P2 = S2_P1 + 9 * 16, S2_P3 = S2_P2 + 8 * 20;    // stride 2: record index of each parity sub-patch
 constexpr int S2_NSTG = 3;
-constexpr int S2_OUT = S2_NSTG * S2_STAGE, S2_OUT_BYTES = 64 * 128 * 4;       // behind the ring: half an output tile (64 pixels x 128 channels fp32) + 2 KB of BatchNorm partials
-constexpr int S2_LDS = S2_OUT + S2_OUT_BYTES + 2 * 2 * 128 * 4;
 constexpr int S2_NLOAD = 4, S2_NCONS = 4;                              // waves: one loader and one consumer per SIMD
 constexpr int S2_TM = 4;                                               // 32-pixel MFMA tiles per consumer wave: all 128 pixels of the tile
 constexpr int S2_THREADS = 64 * (S2_NLOAD + S2_NCONS);
+// S = 2: 17 x 33 patch as four parity sub-patches (612 records, 40 DMA instructions per stage).  S = 1 (round 5, the stride-1 wide layers: D.conv3 forward
+// and data gradient): 10 x 18 patch, rows of 20 records (200 records, 16 instructions).  TN = 32-channel tiles per consumer wave: the block covers
+// 128 TN output channels.
+template <int S, int TN>
+struct WideDma {
+    static constexpr int NREC = S == 2 ? S2_P3 + 8 * 16 : 10 * 20;
+    static constexpr int NPL = S == 2 ? 10 : 4;                        // DMA instructions per loader wave and stage (16 records each)
+    static constexpr int STAGE = 4 * NPL * 1024;
+    static constexpr int CW = 128 * TN;                                // channels of the block
+    static constexpr int OUT = S2_NSTG * STAGE, OUT_BYTES = 64 * CW * 4;   // behind the ring: half an output tile (64 pixels x CW channels fp32) ...
+    static constexpr int STAT = OUT + OUT_BYTES;                       // ... and the BatchNorm partials of the tile: [block][mean | M2][CW]
+    static constexpr int LDS = STAT + 2 * 2 * CW * 4;
+    static constexpr int NOB = 16 * TN;                                // 1 KB output pieces per loader wave and item
+};
 
 struct S2Args {
     int tiles_x, tiles_y; unsigned mx, my;                            // 8 x 16 tiles per map and their division magics
@@ -419,8 +429,36 @@ __device__ __forceinline__ void dma_batch10(const i32x4& rs, unsigned lds0, int 
         : "memory", "scc");
 }
 
-__global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_s2_dma_kernel(const ConvArgs a, const S2Args sa) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_s2[];     // [3 stages][40 KB] [half output tile 32 KB] [partials 1 KB]
+__device__ __forceinline__ void dma_batch4(const i32x4& rs, unsigned lds0, int soff, const int (&v)[4]) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %4, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %5, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %6, %1, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %7, %1, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(rs), "s"(lds0), "s"(soff), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])
+        : "memory", "scc");
+}
+__device__ __forceinline__ void dma_batch(const i32x4& rs, unsigned lds0, int soff, const int (&v)[10]) { dma_batch10(rs, lds0, soff, v); }
+__device__ __forceinline__ void dma_batch(const i32x4& rs, unsigned lds0, int soff, const int (&v)[4]) { dma_batch4(rs, lds0, soff, v); }
+
+template <int S, int TN>
+__global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wide_dma_kernel(const ConvArgs a, const S2Args sa) {
+    using W = WideDma<S, TN>;
+    constexpr int NPL = W::NPL, CW = W::CW, NOB = W::NOB;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_s2[];     // [3 stages][W::STAGE] [half output tile] [partials]
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -445,99 +483,118 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // ------------------------------------------------------------------------------------------------ loader waves
         const int lw = wave - S2_NCONS;
 #ifndef VIAI_S2_LOADER_PRIO
-#define VIAI_S2_LOADER_PRIO 3
+#define VIAI_S2_LOADER_PRIO 0
 #endif
-        __builtin_amdgcn_s_setprio(VIAI_S2_LOADER_PRIO);   // the loaders issue ~50 instructions per stage and must not queue behind the consumers' MFMA / fragment streams
+        __builtin_amdgcn_s_setprio(VIAI_S2_LOADER_PRIO);   // (raised priority was measured: the loaders then steal issue slots from the one consumer wave of their SIMD, 64.4 -> 69.9 us)
         const i32x4 rs_in = rsrc_sgpr(a.in, (unsigned)((long)g.N * g.IH * g.IW * Cin * 4));
         const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_s2 + lw * 1024;
         // lane -> (record 16 i + (lane >> 2), position lane & 3) of instruction i = lw + 4 j
-        int vint[10], edge[10];                      // interior offset relative to the patch origin; bit 0: patch row 0, bit 1: patch column 0, -1: no pixel
+        int vint[NPL], edge[NPL];                    // interior offset relative to the patch origin; bits 0 .. 3: patch row 0, column 0, last row, last column; -1: no pixel
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
+        for (int j = 0; j < NPL; ++j) {
             const int L = 16 * (lw + 4 * j) + (lane >> 2);
-            int par, rec;
-            if (L < S2_P1) { par = 0; rec = L; } else if (L < S2_P2) { par = 1; rec = L - S2_P1; } else if (L < S2_P3) { par = 2; rec = L - S2_P2; } else { par = 3; rec = L - S2_P3; }
-            const int py = par >> 1, px = par & 1, pitch = px ? 16 : 20;
-            const int r = rec / pitch, c = rec - r * pitch;
+            int prow, pcol, c; bool pix;
+            if constexpr (S == 2) {
+                int par, rec;
+                if (L < S2_P1) { par = 0; rec = L; } else if (L < S2_P2) { par = 1; rec = L - S2_P1; } else if (L < S2_P3) { par = 2; rec = L - S2_P2; } else { par = 3; rec = L - S2_P3; }
+                const int py = par >> 1, px = par & 1, pitch = px ? 16 : 20;
+                const int r = rec / pitch;
+                c = rec - r * pitch;
+                pix = L < W::NREC && c < (px ? 16 : 17);
+                prow = 2 * r + py; pcol = 2 * c + px;
+            } else {
+                prow = L / 20; c = L - prow * 20; pcol = c;
+                pix = L < W::NREC && c < 18;
+            }
             const int qp = (lane & 3) ^ ((c >> 2) & 3);                          // piece held at this position: plane qp >> 1, k-half qp & 1
-            const bool pix = L < S2_NREC && c < (px ? 16 : 17);
-            const int prow = 2 * r + py, pcol = 2 * c + px;
             vint[j] = pix ? (prow * g.IW + pcol) * Cin * 4 + (qp >> 1) * 64 + (qp & 1) * 16 : DP_OOB;
-            edge[j] = pix ? (prow == 0 ? 1 : 0) | (pcol == 0 ? 2 : 0) : -1;
+            edge[j] = pix ? (prow == 0 ? 1 : 0) | (pcol == 0 ? 2 : 0) | ((S == 1 && prow == 9) ? 4 : 0) | ((S == 1 && pcol == 17) ? 8 : 0) : -1;
         }
         auto issue = [&](int q) {                    // stage q = (item q / k16, k-step q % k16) -> ring slot q % 3
             const int k = q / k16, kk = q - k * k16;
             int tx, ty, n, nb;
             item_of(k, tx, ty, n, nb);
-            const int py0 = 2 * ty * S2_TH - 1, px0 = 2 * tx * S2_TW - 1;       // patch origin (pad 1)
-            const unsigned lds0 = lds_base + (q % S2_NSTG) * S2_STAGE;
+            const int py0 = S * ty * S2_TH - 1, px0 = S * tx * S2_TW - 1;       // patch origin (pad 1)
+            const unsigned lds0 = lds_base + (q % S2_NSTG) * W::STAGE;
             const int koff = (kk >> 1) * 128 + (kk & 1) * 32;                    // chunk, k-step within the chunk's 128-byte record
-            if (ty > 0 && tx > 0) {
+            // tile at the map's edge: the pad rows / columns of the patch (stride 2 with the input exactly twice the output: top and left only)
+            const int m = (ty == 0 ? 1 : 0) | (tx == 0 ? 2 : 0) | ((S == 1 && ty == sa.tiles_y - 1) ? 4 : 0) | ((S == 1 && tx == sa.tiles_x - 1) ? 8 : 0);
+            if (m == 0) {
                 const int soff = __builtin_amdgcn_readfirstlane(((n * g.IH + py0) * g.IW + px0) * Cin * 4 + koff);
-                dma_batch10(rs_in, lds0, soff, vint);
-            } else {                                  // the pad row / column: those lanes go out of range (zeros)
+                dma_batch(rs_in, lds0, soff, vint);
+            } else {                                  // those lanes go out of range (zeros)
                 const int base = ((n * g.IH + py0) * g.IW + px0) * Cin * 4;
-                const int m = (ty == 0 ? 1 : 0) | (tx == 0 ? 2 : 0);
-                int v[10];
+                int v[NPL];
 #pragma unroll
-                for (int j = 0; j < 10; ++j) v[j] = (edge[j] < 0 || (edge[j] & m)) ? DP_OOB : vint[j] + base;
-                dma_batch10(rs_in, lds0, koff, v);
+                for (int j = 0; j < NPL; ++j) v[j] = (edge[j] < 0 || (edge[j] & m)) ? DP_OOB : vint[j] + base;
+                dma_batch(rs_in, lds0, koff, v);
             }
         };
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((long)g.N * g.OH * g.OW * a.Cout * 4), 0x00020000);
         int kl = 0;                                  // k-step of stage q
-        u32x4 obuf[16];                              // the last finished item's tile part of this wave: 2 halves x 8 pieces (16 pixels x 128 channels each half)
-        int obase[2] = {0, 0}, pend = 16;            // their addresses; next piece to store (16: none pending)
-        const int ovoff = (lane >> 5) * a.Cout * 4 + (lane & 31) * 16;
-        const int npend = k16 >= 4 ? 4 : 16 / k16 * 2;       // pieces per stage: all sixteen within the next item's stages
+        u32x4 obuf[NOB];                             // the last finished item's tile part of this wave: 2 halves x NOB / 2 pieces (a row of 16 pixels x CW channels each half)
+        int obase[2] = {0, 0}, pend = NOB;           // their addresses; next piece to store (NOB: none pending)
+        // piece P = 64 j + lane of a row (16 pixels x CW / 4 pieces): pixel P / (CW / 4), 16-byte piece P % (CW / 4)
+        const int ovoff = TN == 1 ? (lane >> 5) * a.Cout * 4 + (lane & 31) * 16 : lane * 16;
+        const int npend = (NOB + k16 - 1) / k16 < 4 ? 4 : (NOB + k16 - 1) / k16;       // pieces per stage: all of them within the next item's stages
         auto flush = [&](int cnt) {
             const int hi = pend + cnt;
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j >= pend && j < hi) __builtin_amdgcn_raw_buffer_store_b128(obuf[j], rs_out, ovoff, obase[j >> 3] + 2 * (j & 7) * a.Cout * 4, 0);
-            pend = hi < 16 ? hi : 16;
+            for (int j = 0; j < NOB; ++j)
+                if (j >= pend && j < hi) __builtin_amdgcn_raw_buffer_store_b128(obuf[j], rs_out, ovoff, obase[j / (NOB / 2)] + (TN == 1 ? 2 : 1) * (j % (NOB / 2)) * a.Cout * 4, 0);
+            pend = hi < NOB ? hi : NOB;
         };
         if (nstage > 0) issue(0);
         if (nstage > 1) issue(1);
-        if (nstage > 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        auto wait_older = [&](bool younger) {         // everything older than the batch just issued has landed (no batch issued: everything)
+            if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (NPL == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        };
+        wait_older(nstage > 1);
         for (int q = 0; q < nstage; ++q) {
             S2_STAMP(1, q, 0);
             __syncthreads();                         // stage q landed (every loader waited); the consumers are done with stage q - 1
             S2_STAMP(1, q, 1);
-            if (q + 2 < nstage) { issue(q + 2); S2_STAMP(1, q, 2); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }       // stage q + 1 landed, q + 2 in flight
-            else { S2_STAMP(1, q, 2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (q + 2 < nstage) issue(q + 2);
+            S2_STAMP(1, q, 2);
+            wait_older(q + 2 < nstage);              // stage q + 1 landed, q + 2 in flight
             S2_STAMP(1, q, 3);
             // output pieces of the previous item, a few per stage: 64 KB per item and CU in one burst sat in front of the consumers' weight-fragment loads
             // (the stage behind an epilogue took 6 800 cycles instead of 4 400) and kept the loaders from the barrier
             flush(npend);
             if (++kl == k16) {                       // last k-step of an item: its tile arrives through LDS in two halves (see the consumers' epilogue)
                 kl = 0;
-                flush(16);                           // (nothing left unless k16 < 4)
+                flush(NOB);                          // (nothing left unless the item was short)
                 int tx, ty, n, nb;
                 item_of(q / k16, tx, ty, n, nb);
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
                     __syncthreads();                 // E1 / E3
-                    // pixel 16 lw + 2 j + (lane >> 5) of the half = tile row 4 hb + lw, column 2 j + (lane >> 5); channels 4 (lane & 31) .. + 3 of block nb
+                    // row lw of the half (tile row 4 hb + lw): 16 pixels x CW channels, contiguous in the hand-off buffer
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) obuf[8 * hb + j] = *reinterpret_cast<const u32x4*>(smem_s2 + S2_OUT + (16 * lw + 2 * j + (lane >> 5)) * 512 + (lane & 31) * 16);
-                    obase[hb] = __builtin_amdgcn_readfirstlane((((n * g.OH + ty * S2_TH + 4 * hb + lw) * g.OW + tx * S2_TW) * a.Cout + nb * 128) * 4);
+                    for (int j = 0; j < NOB / 2; ++j) obuf[(NOB / 2) * hb + j] = *reinterpret_cast<const u32x4*>(smem_s2 + W::OUT + lw * 16 * CW * 4 + j * 1024 + lane * 16);
+                    obase[hb] = __builtin_amdgcn_readfirstlane((((n * g.OH + ty * S2_TH + 4 * hb + lw) * g.OW + tx * S2_TW) * a.Cout + nb * CW) * 4);
                     if (hb == 0) __syncthreads();    // E2: half 0 is in registers (the barrier's fence waited for the reads), the consumers may write half 1
                 }
-                if (lw < 2 && a.stat != nullptr) {   // loader hb stores block hb's partials: 256 floats [mean | M2][128 channels], lane -> four consecutive
-                    // (four scalar reads: hipcc turned `u32x4 sv = {}; if (..) sv = *(u32x4*)p; ... sv[i]` into four stores of element 0 -- the
+                if (lw < (S == 2 ? 2 : 1) && a.stat != nullptr) {   // loader b stores partial block b of the tile: 2 CW floats [mean | M2][CW], lane -> four consecutive, TN rounds
+                    // (scalar reads: hipcc turned `u32x4 sv = {}; if (..) sv = *(u32x4*)p; ... sv[i]` into four stores of element 0 -- the
                     // vector-element defect of DESIGN 9.3)
-                    const float* sp = reinterpret_cast<const float*>(smem_s2 + S2_OUT + S2_OUT_BYTES) + lw * 256 + lane * 4;
-                    const float sv0 = sp[0], sv1 = sp[1], sv2 = sp[2], sv3 = sp[3];
-                    const int blk = (n * (2 * sa.tiles_y) + 2 * ty + lw) * sa.tiles_x + tx;
-                    const int which = lane >> 5, ch = nb * 128 + (lane & 31) * 4;
-                    float* sd = a.stat + (size_t)(which * a.Cout + ch) * a.nblk_m + blk;
-                    sd[0] = sv0; sd[a.nblk_m] = sv1; sd[2 * (size_t)a.nblk_m] = sv2; sd[3 * (size_t)a.nblk_m] = sv3;
+                    const int blk = S == 2 ? (n * (2 * sa.tiles_y) + 2 * ty + lw) * sa.tiles_x + tx : (n * sa.tiles_y + ty) * sa.tiles_x + tx;
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) {
+                        const int idx = (i * 64 + lane) * 4;
+                        const float* sp = reinterpret_cast<const float*>(smem_s2 + W::STAT) + lw * 2 * CW + idx;
+                        const float sv0 = sp[0], sv1 = sp[1], sv2 = sp[2], sv3 = sp[3];
+                        const int which = idx / CW, ch = nb * CW + idx % CW;
+                        float* sd = a.stat + (size_t)(which * a.Cout + ch) * a.nblk_m + blk;
+                        sd[0] = sv0; sd[a.nblk_m] = sv1; sd[2 * (size_t)a.nblk_m] = sv2; sd[3 * (size_t)a.nblk_m] = sv3;
+                    }
                 }
                 pend = 0;
             }
         }
-        flush(16);
+        flush(NOB);
         return;
     }
 
@@ -555,42 +612,47 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int t = 0; t < 9; ++t) sl[t] = __builtin_amdgcn_readfirstlane(sa.slot[t]);
     // A fragment of MFMA row i = lane & 31 of row tile m (tile pixel (2 m + (i >> 4), i & 15)), k-half lane >> 5, window column tx: byte offset in the stage
     const int pc = lane & 15, kh = lane >> 5, rr = (lane & 31) >> 4;
-    int abase[3];                                                                 // tx = 0 (px 0, +0), 1 (px 1, +0), 2 (px 0, +1); leading plane (remainder: ^ 32)
+    int abase[3];                                                                 // leading plane (remainder: ^ 32).  S = 2: tx = 0 (px 0, +0), 1 (px 1, +0), 2 (px 0, +1)
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx) {
-        const int c = pc + (tx >> 1), pitch = (tx & 1) ? 16 : 20;
+        const int c = S == 2 ? pc + (tx >> 1) : pc + tx, pitch = (S == 2 && (tx & 1)) ? 16 : 20;
         abase[tx] = (rr * pitch + c) * 64 + ((kh ^ ((c >> 2) & 3)) * 16);
     }
     const int half = lane >> 5, col = lane & 31;
     const float inv = 1.0f / (ascale * F16_WSCALE);
 
-    f32x16 acc[S2_TM];
+    f32x16 acc[S2_TM][TN];
 #pragma unroll
     for (int m = 0; m < S2_TM; ++m)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
 
-    // weight fragments of (window position t, k-step kk) of this wave's 32 channels: both planes.  NINE sets, one per window position (so the set of a
+    // weight fragments of (window position t, k-step kk) of this wave's 32 TN channels: both planes.  NINE sets, one per window position (so the set of a
     // tap is the same in every stage and every register index is static), requested S2_BD taps ahead -- across the stage boundary: the compiler-counted
-    // `vmcnt` of a tap then leaves 2 (S2_BD - 1) younger loads in flight.  With three sets / two taps ahead hipcc sank every request to within four MFMAs
+    // `vmcnt` of a tap then leaves 2 TN (S2_BD - 1) younger loads in flight.  With three sets / two taps ahead hipcc sank every request to within four MFMAs
     // of its use and the stage ran at 5 200 - 7 900 ticks against 3 900 of MFMA issue (tools/probes/s2_dma_bench.hip, -DVIAI_PROF).
 #ifndef VIAI_S2_BD
 #define VIAI_S2_BD 5
 #endif
-    constexpr int S2_BD = VIAI_S2_BD;
-    u32x4 B[9][2];
-    int ntb = 0;                                                                  // channel tile of the current item
-    auto gloadB = [&](u32x4 (&b)[2], int t, int kk_, int ok_, int nt_) {
+    constexpr int S2_BD = TN == 1 ? VIAI_S2_BD : 2;
+    u32x4 B[9][TN][2];
+    int ntb = 0;                                                                  // first channel tile of this wave in the current item
+    auto gloadB = [&](u32x4 (&b)[TN][2], int t, int kk_, int ok_, int nt_) {
         const int kk = __builtin_amdgcn_readfirstlane(kk_);
         const int dead = ok_ ? 0 : DP_OOB;
-        const int voff = (nt_ * g.wtaps * k16 * 1024 + lane * 16) | dead;
         const int soff = dead ? 0 : (sl[t] * k16 + kk) * 1024;
-        b[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, soff, 0);
-        b[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, soff + frag_plane, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int voff = ((nt_ + j) * g.wtaps * k16 * 1024 + lane * 16) | dead;
+            b[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, soff, 0);
+            b[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, soff + frag_plane, 0);
+        }
     };
     int tx_, ty_, n_, nb_;
     if (nmine > 0) {
-        item_of(0, tx_, ty_, n_, nb_); ntb = nb_ * 4 + wn;
+        item_of(0, tx_, ty_, n_, nb_); ntb = (nb_ * 4 + wn) * TN;
 #pragma unroll
         for (int t = 0; t < S2_BD; ++t) gloadB(B[t], t, 0, 1, ntb);
     }
@@ -600,46 +662,62 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         S2_STAMP(0, q, 0);
         __syncthreads();                              // (fence + s_barrier: the fragment reads below must not move above it; the weight prefetch stays in flight)
         S2_STAMP(0, q, 1);
-        const unsigned char* Sb = smem_s2 + (q % S2_NSTG) * S2_STAGE;
+        const unsigned char* Sb = smem_s2 + (q % S2_NSTG) * W::STAGE;
         const bool last = kk + 1 == k16;                                          // last k-step of the item: the next stage's fragments belong to item k + 1
         int ntb_next = ntb;
-        if (last && k + 1 < nmine) { int a0, a1, a2, nb2; item_of(k + 1, a0, a1, a2, nb2); ntb_next = nb2 * 4 + wn; }
+        if (last && k + 1 < nmine) { int a0, a1, a2, nb2; item_of(k + 1, a0, a1, a2, nb2); ntb_next = (nb2 * 4 + wn) * TN; }
         const int kk_next = last ? 0 : kk + 1, ok_next = q + 1 < nstage;
-        u32x4 af[2][S2_TM][2];                                                    // [buffer][M tile][plane]
-        auto loadA = [&](int t, u32x4 (&f)[S2_TM][2]) {
+        // A fragments: ONE set of leading and ONE of remainder pieces per row tile (32 registers; double-buffering both planes would not fit beside the
+        // 16 TN accumulator tiles).  The products of a tap run rem x lead-B first, then lead x rem-B and lead x lead-B, so the remainder registers are free
+        // after the first 4 TN MFMAs of tap t and are refilled for tap t + 1 under the other 8 TN; the leading registers are refilled behind the tap's last MFMA
+        // and are not needed before the 4 TN rem MFMAs of tap t + 1 have run.
+        u32x4 alead[S2_TM], arem[S2_TM];
+        auto aaddr = [&](int t, int m) -> int {
             constexpr int PB[4] = {S2_P0 * 64, S2_P1 * 64, S2_P2 * 64, S2_P3 * 64};
             const int ty = t / 3, tx = t % 3;
-            const int pitch = (tx & 1) ? 16 : 20;
-            const int off = PB[(ty & 1) * 2 + (tx & 1)] + (ty >> 1) * pitch * 64;
-#pragma unroll
-            for (int m = 0; m < S2_TM; ++m) {
-                f[m][0] = *reinterpret_cast<const u32x4*>(Sb + abase[tx] + off + m * 2 * pitch * 64);
-                f[m][1] = *reinterpret_cast<const u32x4*>(Sb + (abase[tx] ^ 32) + off + m * 2 * pitch * 64);
-            }
+            const int pitch = (S == 2 && (tx & 1)) ? 16 : 20;
+            return (S == 2 ? PB[(ty & 1) * 2 + (tx & 1)] + (ty >> 1) * pitch * 64 : ty * pitch * 64) + m * 2 * pitch * 64;
         };
-        loadA(0, af[0]);
+        auto loadLead = [&](int t) {
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m) alead[m] = *reinterpret_cast<const u32x4*>(Sb + abase[t % 3] + aaddr(t, m));
+        };
+        auto loadRem = [&](int t) {
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m) arem[m] = *reinterpret_cast<const u32x4*>(Sb + (abase[t % 3] ^ 32) + aaddr(t, m));
+        };
+        loadRem(0);
+        loadLead(0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ta = t + S2_BD;
             if (ta < 9) gloadB(B[ta], ta, kk, 1, ntb);
             else gloadB(B[ta - 9], ta - 9, kk_next, ok_next, ntb_next);
-            if (t + 1 < 9) loadA(t + 1, af[(t + 1) & 1]);
-            const u32x4 (&f)[S2_TM][2] = af[t & 1];
-            const u32x4 (&b)[2] = B[t];
+            const u32x4 (&b)[TN][2] = B[t];
             // smallest partial products first: rem x lead, lead x rem, lead x lead (the order of conv_halo_wide_f16_kernel)
 #pragma unroll
-            for (int m = 0; m < S2_TM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[m][1]), __builtin_bit_cast(f16x8, b[0]), acc[m], 0, 0, 0);
+            for (int m = 0; m < S2_TM; ++m)
 #pragma unroll
-            for (int m = 0; m < S2_TM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[m][0]), __builtin_bit_cast(f16x8, b[1]), acc[m], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, arem[m]), __builtin_bit_cast(f16x8, b[j][0]), acc[m][j], 0, 0, 0);
+            // one consumer wave per SIMD: the weight-fragment requests go BETWEEN these MFMAs, not in a block in front of them
 #pragma unroll
-            for (int m = 0; m < S2_TM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[m][0]), __builtin_bit_cast(f16x8, b[0]), acc[m], 0, 0, 0);
-            // One consumer wave per SIMD: nothing else fills the matrix pipe while this wave issues its ten requests, so they go BETWEEN the MFMAs
-            // (one request behind each of the first ten; none of them is needed before the next tap) instead of in a block in front of them.
+            for (int i = 0; i < 2 * TN; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TN - 2 * TN, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < 9) loadRem(t + 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, alead[m]), __builtin_bit_cast(f16x8, b[j][1 - pr]), acc[m][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8 * TN - 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < 9) loadLead(t + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         S2_STAMP(0, q, 2);
@@ -650,62 +728,77 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             // 24 000 cycles.  The tile goes to the LOADER waves through LDS in two halves of 64 pixels x 128 channels (32 KB, rows 0 - 3 then 4 - 7)
             // together with its BatchNorm partials; they store it as 16-byte pieces from their own queue while this wave runs the next item.
             item_of(k, tx_, ty_, n_, nb_);
-            const int co = nb_ * 128 + wn * 32 + col;
-            const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
             const bool actf = a.stat == nullptr && a.act != VIAI_ACT_NONE;
-            float* ob = reinterpret_cast<float*>(smem_s2 + S2_OUT) + (4 * half) * 128 + wn * 32 + col;
-            float* sb = reinterpret_cast<float*>(smem_s2 + S2_OUT + S2_OUT_BYTES) + wn * 32 + col;
+            float* ob = reinterpret_cast<float*>(smem_s2 + W::OUT) + (4 * half) * CW + wn * 32 * TN + col;
+            float* sb = reinterpret_cast<float*>(smem_s2 + W::STAT) + wn * 32 * TN + col;
             auto finish = [&](auto ACT) {
 #pragma unroll
-                for (int m = 0; m < S2_TM; ++m)
+                for (int j = 0; j < TN; ++j) {
+                    const float bv = a.bias != nullptr ? a.bias[nb_ * CW + (wn * TN + j) * 32 + col] : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float v = acc[m][e] * inv + bv;
-                        if constexpr (decltype(ACT)::value) v = viai_act(v, a.act, a.slope);
-                        acc[m][e] = v;
-                    }
+                    for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            float v = acc[m][j][e] * inv + bv;
+                            if constexpr (decltype(ACT)::value) v = viai_act(v, a.act, a.slope);
+                            acc[m][j][e] = v;
+                        }
+                }
             };
             if (actf) finish(std::true_type{}); else finish(std::false_type{});
             auto put = [&](int hb) {                  // pixel (2 (m & 1) + (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 half) of the half
 #pragma unroll
                 for (int m = 2 * hb; m < 2 * hb + 2; ++m)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) ob[((2 * (m & 1) + (e >> 3)) * 16 + (e & 3) + 8 * ((e >> 2) & 1)) * 128] = acc[m][e];
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) ob[((2 * (m & 1) + (e >> 3)) * 16 + (e & 3) + 8 * ((e >> 2) & 1)) * CW + j * 32] = acc[m][j][e];
             };
             put(0);
             __syncthreads();                          // E1: half 0 is in LDS; the loaders read it while this wave reduces its statistics
-            float mw[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
+            constexpr int NBLK = S == 2 ? 2 : 1, MPB = S2_TM / NBLK;      // partial blocks per tile and row tiles per block
+            float mw[NBLK][TN], m2[NBLK][TN];
             if (a.stat != nullptr) {
-                // (mean, M2) of each 4 x 16 pixel block and channel: the partial-block geometry of the register-staged kernel's 64-pixel tiles
-                // (viai_halo_s2_rows = 4), two-pass; one wave per SIMD has no neighbour to hide a 32-long dependent add chain behind, so four partial sums
+                // (mean, M2) per partial block and channel.  Stride 2: two 4 x 16 pixel blocks per tile (the partial-block geometry of the register-staged kernel's
+                // 64-pixel tiles, viai_halo_s2_rows = 4); stride 1: the 8 x 16 tile.  Two-pass; one wave per SIMD has no neighbour to hide a long dependent add
+                // chain behind, so four partial sums
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
-                    float t[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int hb = 0; hb < NBLK; ++hb)
 #pragma unroll
-                    for (int m = 2 * hb; m < 2 * hb + 2; ++m)
+                    for (int j = 0; j < TN; ++j) {
+                        float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) t[e & 3] += acc[m][e];
-                    float ts = (t[0] + t[1]) + (t[2] + t[3]);
-                    ts += __shfl_xor(ts, 32, 64);
-                    mw[hb] = ts / 64.f;
-                    float u[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int m = MPB * hb; m < MPB * hb + MPB; ++m)
 #pragma unroll
-                    for (int m = 2 * hb; m < 2 * hb + 2; ++m)
+                            for (int e = 0; e < 16; ++e) t[e & 3] += acc[m][j][e];
+                        float ts = (t[0] + t[1]) + (t[2] + t[3]);
+                        ts += __shfl_xor(ts, 32, 64);
+                        mw[hb][j] = ts / (float)(32 * MPB);
+                        float u[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) { const float d = acc[m][e] - mw[hb]; u[e & 3] += d * d; }
-                    float us = (u[0] + u[1]) + (u[2] + u[3]);
-                    us += __shfl_xor(us, 32, 64);
-                    m2[hb] = us;
-                }
+                        for (int m = MPB * hb; m < MPB * hb + MPB; ++m)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) { const float d = acc[m][j][e] - mw[hb][j]; u[e & 3] += d * d; }
+                        float us = (u[0] + u[1]) + (u[2] + u[3]);
+                        us += __shfl_xor(us, 32, 64);
+                        m2[hb][j] = us;
+                    }
             }
             __syncthreads();                          // E2: the loaders hold half 0 in registers
             put(1);
-            if (a.stat != nullptr && half == 0) { sb[0] = mw[0]; sb[128] = m2[0]; sb[256] = mw[1]; sb[384] = m2[1]; }
-            __syncthreads();                          // E3: half 1 and both blocks' partials are in LDS
+            if (a.stat != nullptr && half == 0) {
+#pragma unroll
+                for (int hb = 0; hb < NBLK; ++hb)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) { sb[hb * 2 * CW + j * 32] = mw[hb][j]; sb[hb * 2 * CW + CW + j * 32] = m2[hb][j]; }
+            }
+            __syncthreads();                          // E3: half 1 and the tile's partials are in LDS
 #pragma unroll
             for (int m = 0; m < S2_TM; ++m)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
             ntb = ntb_next;
             ++k; kk = 0;
         } else ++kk;
@@ -720,37 +813,62 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
 // stride-2 3 x 3 pad-1 forward layers the producer / consumer kernel takes: P16 input with Cin a multiple of 32 (one source), Cout a multiple
 // of 128 into one destination, the input exactly twice the output, whole 8 x 16 tiles, 32-bit byte offsets
-bool viai_conv_s2_dma_ok(const ConvArgs& a) {
+static bool wide_dma_common(const ConvArgs& a) {
     const ConvGeom& g = a.g;
     if (!viai_halo_dma_on() || !a.in_p16 || a.amax == nullptr || a.C2 != 0 || a.C1 % 32 != 0 || a.Cout % 128 != 0 || a.OC1 != a.Cout) return false;
-    if (g.my != 2 || g.mx != 2 || g.ntaps != 9 || g.IH != 2 * g.OH || g.IW != 2 * g.OW || g.OH % S2_TH != 0 || g.OW % S2_TW != 0) return false;
-    for (int t = 0; t < 9; ++t) if (g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return false;
+    if (g.ntaps != 9 || g.OH % S2_TH != 0 || g.OW % S2_TW != 0 || g.ly != 1 || g.lx != 1 || g.SH != g.OH || g.SW != g.OW) return false;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        if (g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return false;
+        seen |= 1u << ((g.dy[t] + 1) * 3 + (g.dx[t] + 1));
+    }
+    if (seen != 0x1ffu) return false;
     if ((long)g.N * g.IH * g.IW * a.C1 * 4 >= (1l << 31) || (long)g.N * g.OH * g.OW * a.Cout * 4 >= (1l << 31)) return false;
     const long items = (long)g.N * (g.OH / S2_TH) * (g.OW / S2_TW) * (a.Cout / 128);
     return items * 64 < (1l << 31);
 }
-
-int viai_conv_s2_dma_launch(ConvArgs& a, hipStream_t st) {
-    if (!viai_conv_s2_dma_ok(a)) return (int)hipErrorInvalidValue;
+bool viai_conv_s2_dma_ok(const ConvArgs& a) {
     const ConvGeom& g = a.g;
-    constexpr int lds = S2_LDS;
+    return wide_dma_common(a) && g.my == 2 && g.mx == 2 && g.IH == 2 * g.OH && g.IW == 2 * g.OW;
+}
+// stride-1 3 x 3 pad-1 layers (forward, and the data gradient as the forward of the flipped filter) with 256 k output channels and at least one
+// 128-pixel x 256-channel work item per CU: D.conv3 in both directions (networks/Discriminator_Networks.py:29-31)
+bool viai_conv_s1_dma_ok(const ConvArgs& a) {
+    const ConvGeom& g = a.g;
+    if (!wide_dma_common(a) || g.my != 1 || g.mx != 1 || g.IH != g.OH || g.IW != g.OW || a.Cout % 256 != 0) return false;
+    return (long)g.N * (g.OH / S2_TH) * (g.OW / S2_TW) * (a.Cout / 256) >= 256;
+}
+
+template <int S, int TN>
+static int launch_wide_dma(ConvArgs& a, hipStream_t st) {
+    using W = WideDma<S, TN>;
+    const ConvGeom& g = a.g;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wide_dma_kernel<S, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, W::LDS);
         attr_done = true;
     }
     S2Args sa;
     sa.tiles_x = g.OW / S2_TW; sa.tiles_y = g.OH / S2_TH; sa.mx = tile_magic(sa.tiles_x); sa.my = tile_magic(sa.tiles_y);
-    sa.nnb = a.Cout / 128; sa.mnb = tile_magic(sa.nnb);
+    sa.nnb = a.Cout / W::CW; sa.mnb = tile_magic(sa.nnb);
     sa.nitems = g.N * sa.tiles_y * sa.tiles_x * sa.nnb;
     for (int t = 0; t < 9; ++t) sa.slot[(g.dy[t] + 1) * 3 + (g.dx[t] + 1)] = g.ws[t];
 #ifdef VIAI_PROF
     sa.prof = viai_dma_prof_buf;
 #endif
-    a.nblk_m = a.M / 64;                                      // BatchNorm partial blocks: 64 pixels (4 x 16) each
+    a.nblk_m = a.M / (S == 2 ? 64 : 128);                     // BatchNorm partial blocks: 4 x 16 pixels (stride 2) / the 8 x 16 tile (stride 1)
     a.nblk_n = sa.nnb;
     int grid = 256;
     if (grid > sa.nitems) grid = sa.nitems;
-    VIAI_LAUNCH(conv_s2_dma_kernel, dim3(grid), dim3(S2_THREADS), lds, st, a, sa);
+    VIAI_LAUNCH((conv_wide_dma_kernel<S, TN>), dim3(grid), dim3(S2_THREADS), W::LDS, st, a, sa);
     return viai_launch_status();
+}
+
+int viai_conv_s2_dma_launch(ConvArgs& a, hipStream_t st) {
+    if (!viai_conv_s2_dma_ok(a)) return (int)hipErrorInvalidValue;
+    return launch_wide_dma<2, 1>(a, st);
+}
+int viai_conv_s1_dma_launch(ConvArgs& a, hipStream_t st) {
+    if (!viai_conv_s1_dma_ok(a)) return (int)hipErrorInvalidValue;
+    return launch_wide_dma<1, 2>(a, st);
 }

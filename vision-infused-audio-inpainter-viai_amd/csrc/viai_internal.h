@@ -52,6 +52,8 @@ bool viai_halo_dma_on();
 bool viai_conv_halo_c32_dma_ok(const ConvArgs& a);
 bool viai_conv_s2_dma_ok(const ConvArgs& a);          // stride-2 forward, loader / consumer waves
 int viai_conv_s2_dma_launch(ConvArgs& a, hipStream_t st);
+bool viai_conv_s1_dma_ok(const ConvArgs& a);          // stride-1 256 k-channel layers on the same kernel (D.conv3)
+int viai_conv_s1_dma_launch(ConvArgs& a, hipStream_t st);
 // conv_stem.hip: the 7 x 7 stride-2 image conv of the ResNet branch on the f16x2 matrix-core path (forward + weight gradient)
 bool viai_conv_stem_ok(const ConvGeom& g, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
 int viai_conv_stem_fwd_launch(ConvArgs& a, hipStream_t st);
