@@ -12,18 +12,18 @@ static void fill_f16(std::vector<unsigned short>& v, unsigned seed) {
 }
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 16, IH = argc > 2 ? atoi(argv[2]) : 256, IW = argc > 3 ? atoi(argv[3]) : 128, Ci = argc > 4 ? atoi(argv[4]) : 64, Co = argc > 5 ? atoi(argv[5]) : 128;
-    const int iters = argc > 6 ? atoi(argv[6]) : 20;
-    const int OH = IH / 2, OW = IW / 2;
+    const int iters = argc > 6 ? atoi(argv[6]) : 20, S = argc > 7 ? atoi(argv[7]) : 2;
+    const int OH = IH / S, OW = IW / S;
     const size_t ipx = (size_t)N * IH * IW, opx = (size_t)N * OH * OW;
     std::vector<unsigned short> hx(ipx * Ci * 2), hw((size_t)Co * 9 * Ci * 2);
     fill_f16(hx, 1); fill_f16(hw, 2);
     unsigned short *dx, *dw; float *dy, *dstat, *damax;
-    hipMalloc(&dx, hx.size() * 2); hipMalloc(&dw, hw.size() * 2); hipMalloc(&dy, opx * Co * 4); hipMalloc(&dstat, 2 * Co * (opx / 64) * 4); hipMalloc(&damax, 4);
+    hipMalloc(&dx, hx.size() * 2); hipMalloc(&dw, hw.size() * 2); hipMalloc(&dy, opx * Co * 4); hipMalloc(&dstat, 2 * (size_t)Co * (opx / 64) * 4); hipMalloc(&damax, 4);
     hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     const float am = 1.0f; hipMemcpy(damax, &am, 4, hipMemcpyHostToDevice);
     ConvArgs a{};
     a.in = (const float*)dx; a.wp = (const float*)dw; a.out = dy; a.stat = dstat; a.C1 = Ci; a.Cout = Co; a.OC1 = Co; a.M = (int)opx; a.amax = damax; a.in_p16 = 1;
-    a.g.N = N; a.g.IH = IH; a.g.IW = IW; a.g.OH = a.g.SH = OH; a.g.OW = a.g.SW = OW; a.g.ly = a.g.lx = 1; a.g.my = a.g.mx = 2; a.g.ntaps = a.g.wtaps = 9;
+    a.g.N = N; a.g.IH = IH; a.g.IW = IW; a.g.OH = a.g.SH = OH; a.g.OW = a.g.SW = OW; a.g.ly = a.g.lx = 1; a.g.my = a.g.mx = S; a.g.ntaps = a.g.wtaps = 9;
     for (int t = 0; t < 9; ++t) { a.g.dy[t] = t / 3 - 1; a.g.dx[t] = t % 3 - 1; a.g.ws[t] = t; }
     setenv("VIAI_HALO_DMA", "1", 1);
 #ifdef VIAI_PROF
@@ -32,14 +32,15 @@ int main(int argc, char** argv) {
     viai_dma_prof_buf = dprof;
 #endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) if (int e = viai_conv_s2_dma_launch(a, 0)) { printf("launch error %d\n", e); return 1; }
+    auto launch = [&]() { return S == 2 ? viai_conv_s2_dma_launch(a, 0) : viai_conv_s1_dma_launch(a, 0); };
+    for (int i = 0; i < 3; ++i) if (int e = launch()) { printf("launch error %d\n", e); return 1; }
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) viai_conv_s2_dma_launch(a, 0);
+    for (int i = 0; i < iters; ++i) launch();
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, gf = 2.0 * opx * Co * 9 * Ci * 1e-9, mb = (ipx * Ci * 4 + opx * Co * 4) * 1e-6;
-    printf("s2 dma %d x %d x %d x %d -> %d : %.1f us per launch (%d back to back)  %.0f TFLOP/s  %.2f TB/s   last error %d\n", N, IH, IW, Ci, Co, us, iters, gf / us * 1e-3 * 1e3, mb / us * 1e-6 * 1e6 * 1e-6, (int)hipGetLastError());
+    printf("wide dma stride %d  %d x %d x %d x %d -> %d : %.1f us per launch (%d back to back)  %.0f TFLOP/s  %.2f TB/s   last error %d\n", S, N, IH, IW, Ci, Co, us, iters, gf / us * 1e3, mb / us * 1e-6, (int)hipGetLastError());
 #ifdef VIAI_PROF
     std::vector<unsigned long long> hp(pn); hipMemcpy(hp.data(), dprof, pn * 8, hipMemcpyDeviceToHost);
     const char* cn[3] = {"barrier wait", "stage MFMAs", "epilogue"}; const char* ln[3] = {"barrier wait", "issue", "vmcnt wait"};

@@ -368,7 +368,8 @@ struct WideDma {
     static constexpr int CW = 128 * TN;                                // channels of the block
     static constexpr int OUT = S2_NSTG * STAGE, OUT_BYTES = 64 * CW * 4;   // behind the ring: half an output tile (64 pixels x CW channels fp32) ...
     static constexpr int STAT = OUT + OUT_BYTES;                       // ... and the BatchNorm partials of the tile: [block][mean | M2][CW]
-    static constexpr int LDS = STAT + 2 * 2 * CW * 4;
+    static constexpr int BIAS = STAT + 2 * 2 * CW * 4;                 // ... and the bias of the block's channels (the loaders apply it: see the epilogue)
+    static constexpr int LDS = BIAS + CW * 4;
     static constexpr int NOB = 16 * TN;                                // 1 KB output pieces per loader wave and item
 };
 
@@ -537,11 +538,21 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // piece P = 64 j + lane of a row (16 pixels x CW / 4 pieces): pixel P / (CW / 4), 16-byte piece P % (CW / 4)
         const int ovoff = TN == 1 ? (lane >> 5) * a.Cout * 4 + (lane & 31) * 16 : lane * 16;
         const int npend = (NOB + k16 - 1) / k16 < 4 ? 4 : (NOB + k16 - 1) / k16;       // pieces per stage: all of them within the next item's stages
+        const float oinv = 1.0f / (f16_scale_from_amax(a.amax) * F16_WSCALE);          // undoes the operand scales (a power of two)
+        const bool oact = a.stat == nullptr && a.act != VIAI_ACT_NONE;
+        f32x4 obias = {0.f, 0.f, 0.f, 0.f};                                            // bias of this lane's four channels in the pending item's block
         auto flush = [&](int cnt) {
             const int hi = pend + cnt;
 #pragma unroll
             for (int j = 0; j < NOB; ++j)
-                if (j >= pend && j < hi) __builtin_amdgcn_raw_buffer_store_b128(obuf[j], rs_out, ovoff, obase[j / (NOB / 2)] + (TN == 1 ? 2 : 1) * (j % (NOB / 2)) * a.Cout * 4, 0);
+                if (j >= pend && j < hi) {
+                    f32x4 o = __builtin_bit_cast(f32x4, obuf[j]) * oinv + obias;          // raw accumulators -> conv output
+                    if (oact) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = viai_act(o[e], a.act, a.slope);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, ovoff, obase[j / (NOB / 2)] + (TN == 1 ? 2 : 1) * (j % (NOB / 2)) * a.Cout * 4, 0);
+                }
             pend = hi < NOB ? hi : NOB;
         };
         if (nstage > 0) issue(0);
@@ -575,6 +586,9 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                     for (int j = 0; j < NOB / 2; ++j) obuf[(NOB / 2) * hb + j] = *reinterpret_cast<const u32x4*>(smem_s2 + W::OUT + lw * 16 * CW * 4 + j * 1024 + lane * 16);
                     obase[hb] = __builtin_amdgcn_readfirstlane((((n * g.OH + ty * S2_TH + 4 * hb + lw) * g.OW + tx * S2_TW) * a.Cout + nb * CW) * 4);
+                    // (through LDS, written by the consumers: a global load in this wave's queue would make hipcc drain `vmcnt(0)` -- the DMA in flight -- in front of
+                    // every output piece that uses it)
+                    if (hb == 1 && a.bias != nullptr) obias = *reinterpret_cast<const f32x4*>(smem_s2 + W::BIAS + (lane & (CW / 4 - 1)) * 16);
                     if (hb == 0) __syncthreads();    // E2: half 0 is in registers (the barrier's fence waited for the reads), the consumers may write half 1
                 }
                 if (lw < (S == 2 ? 2 : 1) && a.stat != nullptr) {   // loader b stores partial block b of the tile: 2 CW floats [mean | M2][CW], lane -> four consecutive, TN rounds
@@ -728,24 +742,10 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             // 24 000 cycles.  The tile goes to the LOADER waves through LDS in two halves of 64 pixels x 128 channels (32 KB, rows 0 - 3 then 4 - 7)
             // together with its BatchNorm partials; they store it as 16-byte pieces from their own queue while this wave runs the next item.
             item_of(k, tx_, ty_, n_, nb_);
-            const bool actf = a.stat == nullptr && a.act != VIAI_ACT_NONE;
+            // (the accumulators go out RAW: the loaders apply the operand-scale factor, the bias and a fused activation to the 16-byte pieces they store;
+            // the statistics are taken on the raw values and scaled at the end -- the factor is a power of two, so this is exact)
             float* ob = reinterpret_cast<float*>(smem_s2 + W::OUT) + (4 * half) * CW + wn * 32 * TN + col;
             float* sb = reinterpret_cast<float*>(smem_s2 + W::STAT) + wn * 32 * TN + col;
-            auto finish = [&](auto ACT) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float bv = a.bias != nullptr ? a.bias[nb_ * CW + (wn * TN + j) * 32 + col] : 0.f;
-#pragma unroll
-                    for (int m = 0; m < S2_TM; ++m)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            float v = acc[m][j][e] * inv + bv;
-                            if constexpr (decltype(ACT)::value) v = viai_act(v, a.act, a.slope);
-                            acc[m][j][e] = v;
-                        }
-                }
-            };
-            if (actf) finish(std::true_type{}); else finish(std::false_type{});
             auto put = [&](int hb) {                  // pixel (2 (m & 1) + (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 half) of the half
 #pragma unroll
                 for (int m = 2 * hb; m < 2 * hb + 2; ++m)
@@ -773,19 +773,24 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                             for (int e = 0; e < 16; ++e) t[e & 3] += acc[m][j][e];
                         float ts = (t[0] + t[1]) + (t[2] + t[3]);
                         ts += __shfl_xor(ts, 32, 64);
-                        mw[hb][j] = ts / (float)(32 * MPB);
+                        const float mraw = ts / (float)(32 * MPB);
                         float u[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int m = MPB * hb; m < MPB * hb + MPB; ++m)
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) { const float d = acc[m][j][e] - mw[hb][j]; u[e & 3] += d * d; }
+                            for (int e = 0; e < 16; ++e) { const float d = acc[m][j][e] - mraw; u[e & 3] += d * d; }
                         float us = (u[0] + u[1]) + (u[2] + u[3]);
                         us += __shfl_xor(us, 32, 64);
-                        m2[hb][j] = us;
+                        mw[hb][j] = mraw * inv + (a.bias != nullptr ? a.bias[nb_ * CW + (wn * TN + j) * 32 + col] : 0.f);
+                        m2[hb][j] = us * (inv * inv);
                     }
             }
             __syncthreads();                          // E2: the loaders hold half 0 in registers
             put(1);
+            if (a.bias != nullptr && half == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) reinterpret_cast<float*>(smem_s2 + W::BIAS)[(wn * TN + j) * 32 + col] = a.bias[nb_ * CW + (wn * TN + j) * 32 + col];
+            }
             if (a.stat != nullptr && half == 0) {
 #pragma unroll
                 for (int hb = 0; hb < NBLK; ++hb)
