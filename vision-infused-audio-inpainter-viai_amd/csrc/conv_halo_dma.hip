@@ -555,18 +555,20 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 }
             pend = hi < NOB ? hi : NOB;
         };
+        // start-up: ONLY stage 0 goes out before the first barrier (with two stages queued by every CU of the chip at once the consumers' first barrier came
+        // ~9 000 cycles into the kernel: the second batch's issue waits behind the first's back-pressure); stage 1 follows behind barrier 0 together with stage 2
         if (nstage > 0) issue(0);
-        if (nstage > 1) issue(1);
         auto wait_older = [&](bool younger) {         // everything older than the batch just issued has landed (no batch issued: everything)
             if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if constexpr (NPL == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         };
-        wait_older(nstage > 1);
+        wait_older(false);
         for (int q = 0; q < nstage; ++q) {
             S2_STAMP(1, q, 0);
             __syncthreads();                         // stage q landed (every loader waited); the consumers are done with stage q - 1
             S2_STAMP(1, q, 1);
+            if (q == 0 && nstage > 1) issue(1);
             if (q + 2 < nstage) issue(q + 2);
             S2_STAMP(1, q, 2);
             wait_older(q + 2 < nstage);              // stage q + 1 landed, q + 2 in flight
