@@ -48,12 +48,15 @@ FAMILY_KERNELS = {
     "wgrad_bf3_bf16x3": "wgrad_bf3_kernel<3,TM,TN> (bf16x3 weight gradient)",
     "wgrad_mfma_f32": "wgrad_mfma_kernel<*> (exact fp32 MFMA weight gradient: <= 32-channel layers the patch kernel does not tile, the 7x7 image conv)",
     "wgrad32_all_taps_f32": "wgrad32_halo_kernel (exact fp32 MFMA, <= 32 x <= 32 channels, stride 1: all taps per block)",
-    "halo_wide256_f16x2": "conv_halo_wide_f16_kernel<1,8,4,1> (stride-1 3x3 conv, 8x16-pixel x 256-channel tile, eight waves of 128 pixels x 32 channels, f16x2 split MFMA: the 10x18 input patch of a 32-channel chunk is "
-                          "staged once in LDS and read by all nine taps; weight fragments straight from global; forward and data-gradient launches of D.conv3)",
+    "halo_wide256_f16x2": "conv_wide_dma_kernel<1,2> (csrc/conv_halo_dma.hip, round 5: stride-1 3x3 conv on a pre-split (P16) input, 8x16-pixel x 256-channel work items walked by persistent blocks of "
+                          "four LOADER waves (the 10x18 patch of a 16-channel k-step by LDS-DMA, three stages deep; they also store the output tile, handed over through LDS) and four CONSUMER waves "
+                          "(128 pixels x 64 channels each, weight fragments from global, f16x2 split MFMA); forward and data-gradient launches of D.conv3.  fp32 inputs / small maps: "
+                          "conv_halo_wide_f16_kernel<1,8,4,1> (register-staged, eight waves of 128 pixels x 32 channels)",
     "halo_wide128_f16x2": "conv_halo_wide_f16_kernel<1,4,4,1> (as above, 128-channel tile, four waves of 128 pixels x 32 channels)",
     "halo_wide64_f16x2": "conv_halo_wide_f16_kernel<2,2,2,1> (64-channel tile)", "halo_wide32_f16x2": "conv_halo_wide_f16_kernel<4,1,1,1> (32-channel tile)",
-    "halo_wide_s2_f16x2": "conv_halo_wide_f16_kernel<2,4,2,{2,1},2> (stride-2 forward, four parity sub-patches)",
-    "halo_c32_f16x2": "conv_halo_f16_c32_kernel (32 -> <= 32 channels, stride-1 3x3, the whole filter in registers; f16x2)",
+    "halo_wide_s2_f16x2": "conv_wide_dma_kernel<2,1> (stride-2 forward on a P16 input: loader / consumer waves, the 17x33 patch as four parity sub-patches by LDS-DMA; "
+                          "fp32 inputs: conv_halo_wide_f16_kernel<..,2>, register-staged)",
+    "halo_c32_f16x2": "conv_halo_c32_dma_kernel (32 -> 32 channels, stride-1 3x3, P16 input by LDS-DMA three tiles deep, the whole filter in registers; f16x2; fp32 inputs: conv_halo_f16_c32_kernel)",
     "halo_f16x2": "conv_halo_bf3_kernel<CIN,TN,2> (32/64-channel stride-1 layers, filter streamed; f16x2)",
     "halo_bf16x3": "conv_halo_bf3_kernel<CIN,TN,3> (32/64-channel stride-1 layers, bf16x3)",
     "dgrad_s2_patch_f16x2": "conv_dgrad_s2_patch_kernel (3x3 stride-2 data gradient, four parity classes fused, dy patch staged once per 32-channel chunk; f16x2)",
@@ -72,7 +75,7 @@ FAMILY_KERNELS = {
 }
 # kernel-name fragment of a family in the rocprofv3 counter summaries under profiles/ (traffic of the dominant kernel)
 PMC_KERNEL_OF = {"wgrad_patch_f16x2": "wgrad_patch_f16_kernel<1, 128", "wgrad_patch_s2_f16x2": "wgrad_patch_f16_kernel<2", "wgrad_patch_narrow_f16x2": "wgrad_patch_f16_kernel<1, 32",
-                 "wgrad_bf3_f16x2": "wgrad_bf3_kernel", "halo_wide256_f16x2": "conv_halo_wide_f16_kernel", "halo_wide128_f16x2": "conv_halo_wide_f16_kernel",
+                 "wgrad_bf3_f16x2": "wgrad_bf3_kernel", "halo_wide256_f16x2": "conv_wide_dma_kernel<1, 2>", "halo_wide128_f16x2": "conv_halo_wide_f16_kernel",
                  "igemm128x256_f16x2": "frag_kernel<2, 2, 2, 2, 4", "igemm128x128_f16x2": "frag_kernel<2", "igemm128x128_bf16x3": "frag_kernel<3"}
 
 
@@ -879,10 +882,17 @@ def main():
                     if want in k and "hbm_bytes" in v:
                         out["roofline"]["traffic"] = round(v["hbm_bytes"])
                         out["roofline"]["traffic_note"] = (
-                            "bytes per launch of this kernel on D.conv3 (algorithmic: x 33.6 MB + dy 67.1 MB + dw 4.7 MB for the weight gradient; 57 MB in + 50 MB out for "
+                            "bytes per launch of this kernel on D.conv3 (algorithmic: x 33.6 MB + dy 67.1 MB + dw 4.7 MB for the weight gradient; 105.4 MB = in + out + weights for "
                             "forward / data gradient): 2*FETCH_SIZE + WRITE_SIZE from profiles/%s (tools/profile_layer.py under rocprofv3 --pmc); these L2 memory-side "
                             "counters include Infinity-Cache hits, i.e. they are L2-miss traffic, an upper bound on HBM bytes") % os.path.basename(pmc)
                         break
+        steps_pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step.json")))
+        if BF3 and steps_pmc and not av:
+            ps = json.load(open(steps_pmc[-1]))
+            out["roofline"]["mfma_busy"] = {"conv_kernels_time_weighted": ps["mfma_busy_conv_kernels_time_weighted"], "whole_step": ps["mfma_busy_whole_step"],
+                                            "dominant_kernel": next((v["mfma_busy"] for k, v in ps["kernels"].items() if PMC_KERNEL_OF.get(dom, "?").replace(" ", "") in k.replace(" ", "")), None),
+                                            "source": "profiles/%s (tools/pmc_step.sh: one rocprofv3 --pmc pass of the single-stream step, SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), "
+                                                      "cycle-weighted; in-process counters are not available to bench.py, so this is the committed pass of the same code)" % os.path.basename(steps_pmc[-1])}
         del m2
     if rank == 0 and world == 1 and not av and not args.no_roofline:            # (N = 1 only: at N > 1 the other ranks wait in the final barrier)
         out["stages"] = front_end_stages(dev, args.batch, args.bins, args.frames)

@@ -55,9 +55,24 @@ def test_kernel_families_come_from_the_library():
     # the timed conv flops of the step are the SURVEY's 1 208 GFLOP (section 8d) to within the first-layer data gradients it leaves out
     assert abs(out["roofline"]["conv_gflop_per_step_timed"] - 1208.0) < 0.01 * 1208.0
     assert out["config"]["workload"].startswith("configs[1]") and out["n_gpus"] == 1 and "stages" in out
-    # the live DVFS probe: the dominant kernel's launch on zero operands is never slower than on random ones (same cycles, higher clock)
+    # the live DVFS probe (round-4 advice: existence and finiteness only -- the ratio is a property of the SKU and the box, not of the code)
     pl = out["roofline"]["power_limit"]
-    assert 0.4 < pl["ratio"] <= 1.05 and pl["random_operand_us"] > 50
+    assert pl["ratio"] > 0 and pl["random_operand_us"] > 0 and pl["ratio"] == pl["ratio"]
+    # round 5: the whole-step floor (per-launch max(flops / sustained ceiling, bytes / copy bandwidth) over a single-stream step), the counter-derived
+    # MFMA-busy figures, and the bounded legs on the other configs / the exact-fp32 mode
+    rf = out["roofline"]
+    sf = rf["step_floor"]
+    assert 0 < rf["step_floor_ms"] == sf["step_floor_ms"] < out["ms_per_step"] and 0 < rf["frac_of_floor"] < 1
+    assert abs(sf["floor_ms_by_bound"]["mfma"] + sf["floor_ms_by_bound"]["hbm"] - sf["step_floor_ms"]) < 0.01 and sf["single_stream_ms"] > sf["step_floor_ms"]
+    assert len(sf["largest_gaps"]) == 10 and all(g["measured_us"] > 0 for g in sf["largest_gaps"]) and sf["launches_per_step"] > 100
+    assert sf["family_bound"]["halo_c32_f16x2"]["bound"] == "hbm" and sf["family_bound"]["halo_wide256_f16x2"]["bound"] == "mfma"
+    mb = rf["mfma_busy"]
+    assert 0 < mb["whole_step"] < mb["conv_kernels_time_weighted"] < 1 and mb["source"].startswith("profiles/")
+    ex = out["extra"]
+    assert set(ex) == {"av", "wavenet", "audio_exact_fp32"}
+    for k, unit in (("av", "clips/s"), ("wavenet", "samples/s"), ("audio_exact_fp32", "clips/s")):
+        assert "error" not in ex[k] and ex[k]["unit"] == unit and ex[k]["value"] > 0 and "roofline" in ex[k], (k, ex[k].get("error"))
+    assert ex["audio_exact_fp32"]["ms_per_step"] > out["ms_per_step"] and ex["av"]["config"]["workload"].startswith("configs[2]")
 
 
 @pytest.mark.parametrize("config", ["av", "av_msd"])
