@@ -126,7 +126,9 @@ def out_shape(x_shape, conv):
 
 def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=None, pool=None, upsample=None, next_conv=None):
     """`next_conv`: the conv layer that consumes this layer's output (and nothing else does): where its kernels stage pre-split pieces, the
-    BatchNorm apply pass writes them (ops.conv_bn_act(out_p16=True)).
+    BatchNorm apply pass writes them (ops.conv_bn_act(out_p16=True)).  THE RESULT MAY THEN BE A P16 TENSOR (`ops.is_p16`): the bytes of an fp32
+    tensor holding fp16 planes.  Hand it only to ops.conv_bn_act / conv_bn_act_cout1 (they check the tag); any torch op on it -- detach, clone, view, +, cat,
+    a hook that reads values -- drops the tag and reinterprets the planes as fp32.  ops.p16_decode gives the values.
     conv (nn.Conv2d | nn.ConvTranspose2d holder) -> bn (nn.BatchNorm2d | nn.InstanceNorm2d holder | None) -> act, on NHWC.
     `xmask`: the layer convolves x * xmask (ops.conv_bn_act).  `upsample` = (H, W): F.interpolate(.., align_corners=True) behind the
     layer -- inside the BatchNorm apply pass where ops.upsample_fusable allows, as a pass of its own otherwise."""
@@ -213,7 +215,8 @@ class TransConvBlock(nn.Module):
 
     def forward_nhwc(self, x, x2=None, upsample=None, next_conv=None):
         """`upsample` = (H, W): the F.interpolate the decoder applies to the block's output (New_Inpainting_Networks.py:78,83);
-        `next_conv`: the layer that alone consumes the (resized) output, if the caller knows it (fused_layer)"""
+        `next_conv`: the layer that alone consumes the (resized) output, if the caller knows it (fused_layer) -- the result may then be a P16 tensor
+        (see fused_layer: consume it with ops.conv_bn_act only)"""
         for i in range(self.nums):
             conv = self._modules["conv%s_%d" % (self.name, i)]
             bn = self._modules["conv%s_%d_bn" % (self.name, i)]

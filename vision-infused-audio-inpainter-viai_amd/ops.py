@@ -42,7 +42,8 @@ F16_DYNAMIC = True                                                 # False: stat
 # shape, the two fp16 planes the f16x2 kernels would make of its values (scale from its `_viai_amax` slot, filled by the producer with an
 # a-priori bound).  Producers: the BatchNorm apply passes (forward: where the caller asks with out_p16 -- networks.py knows the consumer;
 # backward: where this layer's own data- / weight-gradient kernels take it).  Consumers: conv_bn_act / conv_bn_act_cout1 (anything else
-# refuses a P16 tensor; p16_decode() gives the fp32 values).  VIAI_P16=0 switches the format off (A/B; results are bit-identical).
+# refuses a P16 tensor; p16_decode() gives the fp32 values).  VIAI_P16=0 switches the format off (A/B: a kernel returns the same bits on P16 operands as on the fp32 tensors AT EQUAL SCALE -- tests/test_p16_gpu.py;
+# the P16 producers derive the scale from an a-priori bound where the fp32 path measures the maximum, so whole-network results agree to rounding, not bit for bit).
 P16 = os.environ.get("VIAI_P16", "1") != "0"
 P16_OK_FWD_X, P16_OK_DGRAD_DY, P16_OK_WGRAD_DY, P16_OK_WGRAD_X = 1, 2, 4, 8
 
@@ -572,7 +573,8 @@ class _ConvBnAct(torch.autograd.Function):
         if f16f is None:
             f16f = d["fwd_f16"] = bool(lib.viai_conv2d_fwd_f16_ok(d["ref"]))
         twin = cfg.pop("x_twin", None)          # a pre-split copy of x beside the fp32 tensor (the residual join of a ResNet block writes both)
-        if twin is not None and not xp and x2 is None and P16 and (p16_mask(d) & P16_OK_FWD_X):
+        # (both consumers of x must stage pieces: otherwise the weight gradient would decode the twin -- coarser scale -- although the exact fp32 x is at hand)
+        if twin is not None and not xp and x2 is None and P16 and (p16_mask(d) & P16_OK_FWD_X) and (p16_mask(d) & P16_OK_WGRAD_X) and F16_BACKWARD:
             x, xp = twin, True                  # the kernels read the planes; the gradient still goes to the fp32 tensor this op was applied to
         if xp and (x2 is not None or (p16_mask(d) & P16_OK_FWD_X) == 0):
             x = p16_decode(x)                   # (a layer without a P16 loader: the networks of this package ask conv_takes_p16 first)
