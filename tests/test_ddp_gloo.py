@@ -40,6 +40,10 @@ def _worker(rank, world, port, out_dir):
     torch.save({"flat": arena.flat.clone(), "grad": arena.grad.clone(), "x": x}, os.path.join(out_dir, "r%d.pt" % rank))
     t = ddp.barrier_max_ms(float(rank + 1))
     assert t == float(world)
+    # the divergence flag of model.get_loss_items is collective: rank 1's bad maximum (a NaN mapped to +inf) reaches rank 0, so both raise in the same call
+    flag = torch.tensor([1.0 + rank, float("inf") if rank == 1 else 3.0])
+    ddp.all_reduce_max_(flag)
+    assert flag.tolist() == [float(world), float("inf")]
     dist.barrier()
     dist.destroy_process_group()
 

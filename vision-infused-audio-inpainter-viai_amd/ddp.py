@@ -75,6 +75,19 @@ def all_reduce_sum_(t: torch.Tensor, group=None):
     return t
 
 
+def all_reduce_max_(t: torch.Tensor, group=None):
+    """in-place max-all-reduce of a small tensor (the divergence flag of model.get_loss_items); gloo: staged through the host."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
 def barrier_max_ms(elapsed_ms: float, device=None) -> float:
     """max over ranks of a per-rank time (bench contract)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -751,10 +751,15 @@ class AudioModel:
     def get_loss_items(self):
         """host sync point (train_whole_sync.py:85)."""
         self.sync_pending_update()
-        both = torch.cat((self.losses, self._weight_range_check())).tolist()
+        wr = self._weight_range_check()
+        if self._exchanging():
+            # data-parallel runs: the weights are replicas, so every rank should see the same maxima -- but a rank whose replica has gone bad on its own (a
+            # corrupted exchange, a NaN that only its clips produce) must not raise alone and leave the others waiting in the next collective: the flag is
+            # the MAX over the ranks (NaN propagates through max), one tiny all-reduce at a point where the host synchronises anyway
+            from . import ddp
+            wr = ddp.all_reduce_max_(torch.nan_to_num(wr, nan=float("inf")), self.pg)
+        both = torch.cat((self.losses, wr)).tolist()
         v, wmax = both[:self.losses.numel()], both[self.losses.numel():]
-        # (data-parallel runs: the weights are replicas -- same initial values, all-reduced gradients, same Adam -- so every rank sees the same maxima and
-        # raises in the same call; no rank is left waiting in a collective)
         if max(wmax) > ops.F16_WEIGHT_LIMIT and os.environ.get("VIAI_F16X2", "1") != "0" and os.environ.get("VIAI_MATH", "") != "fp32":
             raise FloatingPointError("max |weight| = %.4g (E+G) / %.4g (D) is beyond %.1f, where the f16x2 weight images of the conv kernels "
                                      "clamp: the model has diverged (VIAI_F16X2=0 selects the bf16x3 kernels, which have the fp32 exponent range)"
