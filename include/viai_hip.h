@@ -453,6 +453,8 @@ int viai_conv2d_cin1_bn_dgrad(const viai_conv2d* c, const float* x, const float*
 #define VIAI_P16_OK_DGRAD_DY 2     /*                          the data-gradient kernel takes a P16 dy */
 #define VIAI_P16_OK_WGRAD_DY 4     /*                          the weight-gradient kernel takes a P16 dy */
 #define VIAI_P16_OK_WGRAD_X 8      /*                          ... and a P16 x */
+#define VIAI_P16_OK_FWD_LIN 16     /*                          the P16 forward writes its BatchNorm partials per 128 CONSECUTIVE pixels
+                                                                (viai_bn_finalize with rows = 128, nblk = M / 128), whatever viai_conv2d_stat_geom says of the fp32-input launch */
 int viai_conv2d_p16_ok(const viai_conv2d* c);
 /* z (P16) = act(scale * y + shift); gamma / beta (NULL = 1 / 0) and m_stat give the bound; *z_amax receives it.  act: none / ReLU / LeakyReLU */
 int viai_bn_act_fwd_p16(const float* y, const float* scale, const float* shift, const float* gamma, const float* beta, long m_stat,

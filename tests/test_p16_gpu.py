@@ -150,7 +150,12 @@ CONV_CASES = {"wide_s1_128to256": (1, 128, 256, False, 64), "wide_s1_256to128_T"
               "halo64_64to64_T": (1, 64, 64, True, 64), "c32_32to32_T": (1, 32, 32, True, 64), "halo32_32to64": (1, 32, 64, False, 64),
               "wide_s2_64to128": (2, 64, 128, False, 64), "wide_s2_128to256": (2, 128, 256, False, 32),
               # 256 work items of 128 pixels x 256 channels: the stride-1 instance of the loader / consumer kernel (D.conv3's kernel in both directions)
-              "wide_s1_256to512_dma": (1, 256, 512, False, 64), "wide_s1_256to256_T_dma": (1, 256, 256, True, 128)}
+              "wide_s1_256to512_dma": (1, 256, 512, False, 64), "wide_s1_256to256_T_dma": (1, 256, 256, True, 128),
+              # the loader / consumer kernel over LINEAR pixel tiles (maps that are not whole 8 x 16 tiles: ResNet-18's four stages, networks/ResNet.py:26-55,
+              # and a map with H != W); (stride, Cin, Cout, transposed, (H, W), N) with N sized for >= 256 work items
+              "lin_64to64_56": (1, 64, 64, False, (56, 56), 64), "lin_128to128_28_T": (1, 128, 128, True, (28, 28), 128),
+              "lin_256to256_14": (1, 256, 256, False, (14, 14), 256), "lin_512to512_7": (1, 512, 512, False, (7, 7), 512),
+              "lin_64to128_12x20_T": (1, 64, 128, True, (12, 20), 576)}
 
 
 @pytest.mark.parametrize("case", list(CONV_CASES), ids=list(CONV_CASES))
@@ -158,12 +163,17 @@ def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_inp
     """every patch-staged f16x2 kernel family: wide halo (stride 1 and 2), streamed-filter halo, register-filter halo, stride-2 data gradient"""
     from viai_amd import _lib, ops
     lib = _lib.load()
-    S, Ci, Co, tr, OHW = CONV_CASES[case]
-    N = 4
-    H = W = OHW * S
+    lin = case.startswith("lin_")
+    if lin:
+        S, Ci, Co, tr, (OH_, OW_), N = CONV_CASES[case]
+    else:
+        S, Ci, Co, tr, OHW = CONV_CASES[case]
+        N, OH_, OW_ = 4, OHW, OHW
+    H, W = OH_ * S, OW_ * S
+    NR = min(N, 4)                                        # images checked against torch in fp64 on the CPU
     gen = torch.Generator(device="cuda").manual_seed(5)
     x = torch.randn(N, H, W, Ci, device="cuda", generator=gen)
-    dy = torch.randn(N, OHW, OHW, Co, device="cuda", generator=gen) * 1e-2
+    dy = torch.randn(N, OH_, OW_, Co, device="cuda", generator=gen) * 1e-2
     w = torch.randn((Ci, Co, 3, 3) if tr else (Co, Ci, 3, 3), device="cuda", generator=gen) * 0.05
     d = ops.conv_desc(N, H, W, Ci, 0, Co, 3, 3, S, S, 1, 1, 1 if tr else 0)
     ok = lib.viai_conv2d_p16_ok(d["ref"])
@@ -174,15 +184,25 @@ def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_inp
     # forward
     wp = torch.empty(d["packed"], device="cuda")
     _lib.check(lib.viai_conv2d_pack_fwd(d["ref"], w.data_ptr(), wp.data_ptr(), _st()), "pack_fwd")
-    y0, y1 = torch.empty(N, OHW, OHW, Co, device="cuda"), torch.empty(N, OHW, OHW, Co, device="cuda")
-    st0 = torch.empty(2 * Co * d["nblk"], device="cuda"); st1 = torch.empty_like(st0)
+    y0, y1 = torch.empty(N, OH_, OW_, Co, device="cuda"), torch.empty(N, OH_, OW_, Co, device="cuda")
+    Mpix = N * OH_ * OW_
+    st0 = torch.empty(2 * Co * max(d["nblk"], Mpix // 128), device="cuda"); st1 = torch.empty_like(st0)
     _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), 0, wp.data_ptr(), 0, y0.data_ptr(), st0.data_ptr(), 0, xa.data_ptr(), _st()), "fwd_amax")
     lib.viai_conv2d_last_kernel(fam, 64); f0 = fam.value
     _lib.check(lib.viai_conv2d_fwd_p16(d["ref"], xp.data_ptr(), wp.data_ptr(), 0, y1.data_ptr(), st1.data_ptr(), 0, xa.data_ptr(), _st()), "fwd_p16")
     lib.viai_conv2d_last_kernel(fam, 64)
-    assert fam.value == f0 and f0.endswith(b"_f16x2"), (f0, fam.value)
+    assert (fam.value == b"lin_dma_f16x2" if lin else fam.value == f0) and f0.endswith(b"_f16x2"), (f0, fam.value)
     dma = S == 2 or case.endswith("_dma")
-    if dma:
+    if lin:
+        assert ok & 16                                                    # VIAI_P16_OK_FWD_LIN: partial blocks of 128 consecutive pixels
+        assert ((y0 - y1).norm() / y0.norm()).item() < 1e-6
+        blocks = y1.view(Mpix // 128, 128, Co)
+        mean = blocks.mean(1)
+        m2 = ((blocks - mean[:, None, :]) ** 2).sum(1)
+        sp = st1[:2 * Co * (Mpix // 128)].view(2, Co, Mpix // 128)
+        assert (sp[0].t() - mean).abs().max().item() < 1e-5 * y1.abs().max().item()
+        assert ((sp[1].t() - m2).abs() / m2.clamp_min(1e-12)).max().item() < 1e-4
+    elif dma:
         # the pre-split input runs on the loader / consumer kernel (csrc/conv_halo_dma.hip), which walks K as (16-channel k-step, tap) where the
         # register-staged kernel walks (32-channel chunk, tap, k-step): the same products, summed in another order -- fp32 rounding apart
         assert ((y0 - y1).norm() / y0.norm()).item() < 1e-6
@@ -192,9 +212,13 @@ def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_inp
         assert ((m0[1] - m1[1]).abs() / m0[1].abs().clamp_min(1e-12)).max().item() < 1e-4
     else:
         assert torch.equal(y0, y1) and torch.equal(st0, st1)
-    ref = torch.nn.functional.conv_transpose2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, 1, 1) if tr else \
-        torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, S, 1)
-    assert ((y1.double().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm()).item() < 2e-6
+    ref = torch.nn.functional.conv_transpose2d(x[:NR].double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, 1, 1) if tr else \
+        torch.nn.functional.conv2d(x[:NR].double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, S, 1)
+    assert ((y1[:NR].double().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm()).item() < 2e-6
+    if lin:                                                               # ... and the LAST images (the tensor's tail: records behind the last pixel)
+        ref = torch.nn.functional.conv_transpose2d(x[-2:].double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, 1, 1) if tr else \
+            torch.nn.functional.conv2d(x[-2:].double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, S, 1)
+        assert ((y1[-2:].double().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm()).item() < 2e-6
     # data gradient
     wpd = torch.empty(d["packed"], device="cuda")
     _lib.check(lib.viai_conv2d_pack_dgrad_f16(d["ref"], w.data_ptr(), wpd.data_ptr(), _st()), "pack_dgrad_f16")
@@ -203,17 +227,17 @@ def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_inp
     lib.viai_conv2d_last_kernel(fam, 64); f0 = fam.value
     _lib.check(lib.viai_conv2d_dgrad_f16_p16(d["ref"], dyp.data_ptr(), wpd.data_ptr(), g1.data_ptr(), 0, da.data_ptr(), _st()), "dgrad_f16_p16")
     lib.viai_conv2d_last_kernel(fam, 64)
-    assert fam.value == f0, (f0, fam.value)
+    assert fam.value == (b"lin_dma_f16x2" if lin else f0), (f0, fam.value)
     torch.cuda.synchronize()
-    if dma:
+    if dma or lin:
         # (stride 1: the same kernel on the flipped filter; stride 2: the class-split loader / consumer data-gradient kernel -- another K order in both)
         assert ((g0 - g1).norm() / g0.norm()).item() < 1e-6
     else:
         assert torch.equal(g0, g1)
-    xr = x.double().permute(0, 3, 1, 2).cpu().requires_grad_(True)
+    xr = x[:NR].double().permute(0, 3, 1, 2).cpu().requires_grad_(True)
     o = torch.nn.functional.conv_transpose2d(xr, w.double().cpu(), None, 1, 1) if tr else torch.nn.functional.conv2d(xr, w.double().cpu(), None, S, 1)
-    (o * dy.double().permute(0, 3, 1, 2).cpu()).sum().backward()
-    assert ((g1.double().cpu().permute(0, 3, 1, 2) - xr.grad).norm() / xr.grad.norm()).item() < 2e-6
+    (o * dy[:NR].double().permute(0, 3, 1, 2).cpu()).sum().backward()
+    assert ((g1[:NR].double().cpu().permute(0, 3, 1, 2) - xr.grad).norm() / xr.grad.norm()).item() < 2e-6
 
 
 def _close_to_split(d, ref, am, extra=0.0):

@@ -110,6 +110,22 @@ static bool halo_wide_dgrad(const viai_conv2d* c) {
     a.C1 = c->Cout; a.C2 = 0; a.Cout = cin_of(c); a.OC1 = c->C1; a.M = a.g.N * a.g.SH * a.g.SW;
     return viai_conv_halo_wide_ok(a);
 }
+// loader / consumer kernel over linear pixel tiles (conv_halo_dma.hip, round 5): stride-1 3 x 3 layers on maps that are not whole 8 x 16 tiles, when
+// the operand arrives pre-split (geometry only here: the launch decides by a.in_p16)
+static bool lin_fwd(const viai_conv2d* c) {
+    if (!f16x2_enabled() || !use_bf3_fwd(c)) return false;
+    ConvArgs a{};
+    viai_geom_fwd(c, &a.g);
+    a.C1 = c->C1; a.C2 = c->C2; a.Cout = c->Cout; a.OC1 = c->Cout; a.M = a.g.N * a.g.OH * a.g.OW;
+    return viai_conv_lin_dma_geom_ok(a);
+}
+static bool lin_dgrad(const viai_conv2d* c) {
+    if (!f16x2_enabled() || !use_bf3_dgrad(c) || c->sh != 1 || c->sw != 1) return false;
+    ConvArgs a{};
+    if (viai_geom_dgrad_class(c, 0, 0, &a.g) == 0) return false;
+    a.C1 = c->Cout; a.C2 = 0; a.Cout = cin_of(c); a.OC1 = c->C1; a.M = a.g.N * a.g.SH * a.g.SW;
+    return viai_conv_lin_dma_geom_ok(a);
+}
 // f16x2 for the LDS-weight / split-K kernels too (planar fp16 planes); VIAI_F16_PLANAR=0 keeps them on bf16x3
 static bool planar16_enabled() {
     constexpr int on = 1;
@@ -119,14 +135,14 @@ static bool planar16_enabled() {
 static int frag_fwd(const viai_conv2d* c) {
     if (halo_fwd(c)) return f16x2_enabled() ? 3 : 1;            // f16x2: filter in registers (32 -> <= 32 channels) or streamed
     if (viai_bf3_frag_layout(bf3_rows_fwd(c), c->Cout)) return f16x2_enabled() ? 3 : 1;
-    if (halo_wide_fwd(c)) return 3;
+    if (halo_wide_fwd(c) || lin_fwd(c)) return 3;
     return planar16_enabled() ? 4 : 0;
 }
 // data gradient on the f16x2 wide-tile kernel (needs the abs-max of dy): the layers whose classes run on the fragment-major kernel
 static bool dgrad_f16(const viai_conv2d* c) {
     if (!f16x2_enabled() || !use_bf3_dgrad(c)) return false;
     if (halo_dgrad(c)) return true;
-    if (halo_wide_dgrad(c)) return true;
+    if (halo_wide_dgrad(c) || lin_dgrad(c)) return true;
     if (!frag_dgrad(c)) return planar16_enabled();              // LDS-weight / split-K kernels: planar fp16 planes
     return s2_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c));
 }
@@ -137,7 +153,7 @@ static bool sk_fwd(const viai_conv2d* c) {
 static bool s2_dgrad(const viai_conv2d* c) { return use_bf3_dgrad(c) && viai_dgrad_s2_ok(c); }     // fused parity classes (conv_dgrad_s2_bf3.hip)
 static bool frag_dgrad(const viai_conv2d* c) { return halo_dgrad(c) || s2_dgrad(c) || viai_bf3_frag_layout(bf3_rows_dgrad(c), cin_of(c)); }
 // layout of the f16x2 data-gradient image: fragment-major also for the wide halo kernel's layers
-static bool frag_dgrad16(const viai_conv2d* c) { return frag_dgrad(c) || halo_wide_dgrad(c); }
+static bool frag_dgrad16(const viai_conv2d* c) { return frag_dgrad(c) || halo_wide_dgrad(c) || lin_dgrad(c); }
 
 static bool use_bf3_fwd(const viai_conv2d* c) {
     if (kind_of(c) != K_IGEMM) return false;
@@ -399,7 +415,7 @@ extern "C" int viai_conv2d_fwd_amax(const viai_conv2d* c, const float* x, const 
     return fwd_impl(c, x, x2, wp, bias, y, stat_part, act, x_amax, stream, 0);
 }
 static bool p16_fwd_ok(const viai_conv2d* c) {
-    return valid(c) && kind_of(c) == K_IGEMM && f16x2_enabled() && c->C2 == 0 && (halo_fwd(c) || halo_wide_fwd(c));
+    return valid(c) && kind_of(c) == K_IGEMM && f16x2_enabled() && c->C2 == 0 && (halo_fwd(c) || halo_wide_fwd(c) || lin_fwd(c));
 }
 // (ABI 13) the forward with x pre-split (P16 planes, scale from *x_amax): layers with VIAI_P16_OK_FWD_X in viai_conv2d_p16_ok
 extern "C" int viai_conv2d_fwd_p16(const viai_conv2d* c, const float* x, const float* wp, const float* bias, float* y, float* stat_part,
@@ -473,7 +489,7 @@ static bool s2_patch_dgrad(const viai_conv2d* c) {
 static bool p16_dgrad_ok(const viai_conv2d* c) {
     if (!valid(c) || kind_of(c) != K_IGEMM || !dgrad_f16(c)) return false;
     if (s2_dgrad(c)) return s2_patch_dgrad(c);
-    return c->sh == 1 && c->sw == 1 && (halo_dgrad(c) || halo_wide_dgrad(c));
+    return c->sh == 1 && c->sw == 1 && (halo_dgrad(c) || halo_wide_dgrad(c) || lin_dgrad(c));
 }
 // (ABI 13) viai_conv2d_dgrad_f16 with dy pre-split (P16 planes, scale from *dy_amax): layers with VIAI_P16_OK_DGRAD_DY
 extern "C" int viai_conv2d_dgrad_f16_p16(const viai_conv2d* c, const float* dy, const float* wp, float* dx, float* dx2,
@@ -608,6 +624,7 @@ extern "C" int viai_conv2d_p16_ok(const viai_conv2d* c) {
     int m = 0;
     if (wgrad_patch(c)) { m |= VIAI_P16_OK_WGRAD_DY; if (c->C2 == 0) m |= VIAI_P16_OK_WGRAD_X; }
     if (p16_fwd_ok(c)) m |= VIAI_P16_OK_FWD_X;
+    if (p16_fwd_ok(c) && lin_fwd(c)) m |= VIAI_P16_OK_FWD_LIN;
     if (p16_dgrad_ok(c)) m |= VIAI_P16_OK_DGRAD_DY;
     return m;
 }

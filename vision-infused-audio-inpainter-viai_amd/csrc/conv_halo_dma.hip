@@ -816,6 +816,364 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The loader / consumer kernel over LINEAR pixel tiles (round 5): stride-1 3 x 3 pad-1 layers on maps that are not whole 8 x 16 tiles -- ResNet-18's
+// 56 / 28 / 14 / 7-pixel maps (networks/ResNet.py:26-55: conv3x3 -> bn -> relu -> conv3x3 -> bn, both directions; Image_Embedding.py:187-200).
+//
+// A work item is PIX = 128 PW CONSECUTIVE pixels of the flattened [N][H][W] map x CW = 256 / PW channels; the four consumer waves split it PW ways along
+// the pixels and 4 / PW ways along the channels (128 pixels x 64 channels each, as in conv_wide_dma_kernel<1, 2>).  Window position (dy, dx) of pixel m is
+// pixel m + dy W + dx of the same flattened map, so a stage holds the k-step's records of pixels m0 - W - 1 .. m0 + PIX + W (one contiguous range of the
+// P16 tensor: the loaders' offsets are linear in the record index, no division anywhere) and a fragment read is 32 consecutive 64-byte records
+// shifted by the tap.  What the 2-D patch did with out-of-range lanes -- the zero padding -- the CONSUMERS do here: a lane whose window position falls
+// outside its image (nine validity bits per pixel, worked out once per item) reads the all-zero record at LDS byte 0 instead.
+// Records keep the piece swizzle of the 2-D kernels, position = piece ^ ((record >> 2) & 3): a shift by a whole number of records moves a read to other
+// records, the 16 lanes of a `ds_read_b128` group still take 16 consecutive ones, four per bank-row quarter.
+template <int PW>
+struct LinDma {
+    static constexpr int NWN = 4 / PW;                                 // consumer waves along the channels
+    static constexpr int CW = 64 * NWN;                                // channels of an item
+    static constexpr int PIX = 128 * PW;                               // pixels of an item
+    static constexpr int NPL = PW == 4 ? 10 : PW == 2 ? 6 : 4;         // DMA instructions per loader wave and stage (16 records each)
+    static constexpr int NREC = 64 * NPL;                              // record slots of a stage >= PIX + 2 W + 2: W <= 63
+    static constexpr int STAGE = NREC * 64;
+    static constexpr int RING = 1024;                                  // behind the zero record
+    static constexpr int NH = PW == 4 ? 4 : 2;                         // hand-off parts of the item's 128 KB output
+    static constexpr int OUT = RING + S2_NSTG * STAGE, OUT_BYTES = PIX * CW * 4 / NH;
+    static constexpr int STAT = OUT + OUT_BYTES;                       // [PW 128-pixel blocks][mean | M2][CW]
+    static constexpr int BIAS = STAT + PW * 2 * CW * 4;
+    static constexpr int LDS = BIAS + CW * 4;
+    static constexpr int NOB = 32;                                     // 1 KB output pieces per loader wave and item
+    static constexpr int NOP = NOB / NH;                               // ... per part
+};
+
+struct LinArgs {
+    int H, W, HW, M;                                                   // map, pixels per image, pixels in all
+    float rhw; unsigned mw;                                            // 1 / HW (float quotient, corrected), division magic of W
+    int nnb; unsigned mnb;                                             // channel blocks per pixel tile (item = tile * nnb + nb)
+    int nitems;
+    int slot[9];                                                       // weight slot of window position (row * 3 + col)
+};
+
+__device__ __forceinline__ void dma_batch(const i32x4& rs, unsigned lds0, int soff, const int (&v)[6]) { dma_batch6(rs, lds0, soff, v[0], v[1], v[2], v[3], v[4], v[5]); }
+
+template <int PW>
+__global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_lin_dma_kernel(const ConvArgs a, const LinArgs sa) {
+    using L = LinDma<PW>;
+    constexpr int NPL = L::NPL, CW = L::CW, NOB = L::NOB, NH = L::NH, NOP = L::NOP, NWN = L::NWN, PIX = L::PIX, TN = 2;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_ln[];     // [zero record] [3 stages] [output part] [partials] [bias]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cin = a.C1, k16 = Cin / 16;
+    const int G = gridDim.x;
+    const int nmine = (sa.nitems - (int)blockIdx.x + G - 1) / G;
+    const int nstage = nmine * k16;
+    const int nrec = PIX + 2 * sa.W + 2;
+    auto item_of = [&](int k, int& m0, int& nb) {
+        const int item = xcd_remap(blockIdx.x + k * G, sa.nitems);
+        const int tile = div_magic(item, sa.mnb);
+        nb = item - tile * sa.nnb;
+        m0 = tile * PIX;
+    };
+    if (tid < 16) reinterpret_cast<unsigned*>(smem_ln)[tid] = 0u;               // the zero record (visible behind the first stage barrier)
+
+    if (wave >= S2_NCONS) {
+        // ------------------------------------------------------------------------------------------------ loader waves
+        const int lw = wave - S2_NCONS;
+        const i32x4 rs_in = rsrc_sgpr(a.in, (unsigned)((long)sa.M * Cin * 4));
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_ln + L::RING + lw * 1024;
+        // lane -> (record 16 i + (lane >> 2), position lane & 3) of instruction i = lw + 4 j
+        int vint[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int rec = 16 * (lw + 4 * j) + (lane >> 2);
+            const int qp = (lane & 3) ^ ((rec >> 2) & 3);                         // piece held at this position: plane qp >> 1, k-half qp & 1
+            vint[j] = rec < nrec ? rec * Cin * 4 + (qp >> 1) * 64 + (qp & 1) * 16 : DP_OOB;
+        }
+        auto issue = [&](int q) {                    // stage q = (item q / k16, k-step q % k16) -> ring slot q % 3
+            const int k = q / k16, kk = q - k * k16;
+            int m0, nb;
+            item_of(k, m0, nb);
+            const int ms = m0 - sa.W - 1;                                         // pixel of record 0
+            const unsigned lds0 = lds_base + (q % S2_NSTG) * L::STAGE;
+            const int koff = (kk >> 1) * 128 + (kk & 1) * 32;                     // chunk, k-step within the chunk's 128-byte record
+            if (ms >= 0 && ms + nrec <= sa.M) {
+                const int soff = __builtin_amdgcn_readfirstlane(ms * Cin * 4 + koff);
+                dma_batch(rs_in, lds0, soff, vint);
+            } else {                                  // first / last pixels of the tensor: records in front of pixel 0 / behind pixel M - 1 go out of range (zeros)
+                int v[NPL];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const int mm = ms + 16 * (lw + 4 * j) + (lane >> 2);
+                    v[j] = (vint[j] == DP_OOB || mm < 0 || mm >= sa.M) ? DP_OOB : vint[j] + ms * Cin * 4;
+                }
+                dma_batch(rs_in, lds0, koff, v);
+            }
+        };
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((long)sa.M * a.Cout * 4), 0x00020000);
+        int kl = 0;
+        u32x4 obuf[NOB];                             // this wave's share of the last finished item: NH parts x NOP pieces (PW pixels x CW channels each)
+        int obase[NH], pend = NOB;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) obase[h] = 0;
+        const int ovoff = (lane / (CW / 4)) * a.Cout * 4 + (lane % (CW / 4)) * 16;
+        const int npend = (NOB + k16 - 1) / k16 < 4 ? 4 : (NOB + k16 - 1) / k16;
+        const float oinv = 1.0f / (f16_scale_from_amax(a.amax) * F16_WSCALE);
+        const bool oact = a.stat == nullptr && a.act != VIAI_ACT_NONE;
+        f32x4 obias = {0.f, 0.f, 0.f, 0.f};
+        auto flush = [&](int cnt) {
+            const int hi = pend + cnt;
+#pragma unroll
+            for (int j = 0; j < NOB; ++j)
+                if (j >= pend && j < hi) {
+                    f32x4 o = __builtin_bit_cast(f32x4, obuf[j]) * oinv + obias;
+                    if (oact) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = viai_act(o[e], a.act, a.slope);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, ovoff, obase[j / NOP] + (j % NOP) * PW * a.Cout * 4, 0);
+                }
+            pend = hi < NOB ? hi : NOB;
+        };
+        if (nstage > 0) issue(0);
+        auto wait_older = [&](bool younger) {
+            if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (NPL == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if constexpr (NPL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        };
+        wait_older(false);
+        // the part's pixels this wave stores: part-local pixels lw Q .. + Q - 1 (Q = PIX / NH / 4); part-local pixel (wp (4 / NH) + ml) 32 + i is item pixel
+        // wp 128 + (h (4 / NH) + ml) 32 + i
+        constexpr int Q = PIX / NH / 4, PPW = 128 / NH;
+        const int lpix = (lw * Q / PPW) * 128 + (lw * Q) % PPW;
+        for (int q = 0; q < nstage; ++q) {
+            __syncthreads();                         // stage q landed (every loader waited); the consumers are done with stage q - 1
+            if (q == 0 && nstage > 1) issue(1);
+            if (q + 2 < nstage) issue(q + 2);
+            wait_older(q + 2 < nstage);
+            flush(npend);
+            if (++kl == k16) {                       // last k-step of an item: its output arrives through LDS in NH parts
+                kl = 0;
+                flush(NOB);
+                int m0, nb;
+                item_of(q / k16, m0, nb);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    __syncthreads();                 // part h is in LDS
+#pragma unroll
+                    for (int j = 0; j < NOP; ++j) obuf[NOP * h + j] = *reinterpret_cast<const u32x4*>(smem_ln + L::OUT + (lw * NOP + j) * 1024 + lane * 16);
+                    obase[h] = __builtin_amdgcn_readfirstlane(((m0 + lpix + h * PPW) * a.Cout + nb * CW) * 4);
+                    if (h == NH - 1 && a.bias != nullptr) obias = *reinterpret_cast<const f32x4*>(smem_ln + L::BIAS + (lane & (CW / 4 - 1)) * 16);
+                    if (h < NH - 1) __syncthreads(); // part h is in registers, the consumers may write part h + 1
+                }
+                if (lw < PW && a.stat != nullptr) {  // loader b stores the partials of 128-pixel block b of the item: [mean | M2][CW]
+                    const int blk = m0 / 128 + lw;
+#pragma unroll
+                    for (int i = 0; i < (2 * CW + 255) / 256; ++i) {
+                        const int idx = (i * 64 + lane) * 4;
+                        if (idx < 2 * CW) {
+                            const float* sp = reinterpret_cast<const float*>(smem_ln + L::STAT) + lw * 2 * CW + idx;
+                            const float sv0 = sp[0], sv1 = sp[1], sv2 = sp[2], sv3 = sp[3];
+                            const int which = idx / CW, ch = nb * CW + idx % CW;
+                            float* sd = a.stat + (size_t)(which * a.Cout + ch) * a.nblk_m + blk;
+                            sd[0] = sv0; sd[a.nblk_m] = sv1; sd[2 * (size_t)a.nblk_m] = sv2; sd[3 * (size_t)a.nblk_m] = sv3;
+                        }
+                    }
+                }
+                pend = 0;
+            }
+        }
+        flush(NOB);
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- consumer waves
+    const int wp = wave / NWN, wn = wave % NWN;
+    const float ascale = f16_scale_from_amax(a.amax);
+    const int NT = a.Cout / 32;
+    const int wtaps = a.g.wtaps;
+    const int frag_plane = NT * wtaps * k16 * 1024;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 2 * frag_plane, 0x00020000);
+    int sl[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sl[t] = __builtin_amdgcn_readfirstlane(sa.slot[t]);
+    // A fragment of MFMA row i = lane & 31 of row tile m (item pixel wp 128 + 32 m + i), k-half lane >> 5, window position t: leading piece (remainder: ^ 32)
+    const int half = lane >> 5, col = lane & 31;
+    int at[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int rec = wp * 128 + col + (t / 3) * sa.W + (t % 3);
+        at[t] = L::RING + rec * 64 + ((half ^ ((rec >> 2) & 3)) * 16);
+    }
+    const float inv = 1.0f / (ascale * F16_WSCALE);
+
+    f32x16 acc[S2_TM][TN];
+#pragma unroll
+    for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+
+    constexpr int BD = 2;
+    u32x4 B[9][TN][2];
+    int ntb = 0;
+    auto gloadB = [&](u32x4 (&b)[TN][2], int t, int kk_, int ok_, int nt_) {
+        const int kk = __builtin_amdgcn_readfirstlane(kk_);
+        const int dead = ok_ ? 0 : DP_OOB;
+        const int soff = dead ? 0 : (sl[t] * k16 + kk) * 1024;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int voff = ((nt_ + j) * wtaps * k16 * 1024 + lane * 16) | dead;
+            b[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, soff, 0);
+            b[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, soff + frag_plane, 0);
+        }
+    };
+    // validity of the nine window positions of this lane's pixel in row tile m (bit t): positions outside the pixel's image read the zero record
+    int vm[S2_TM];
+    auto masks_of = [&](int m0) {
+#pragma unroll
+        for (int m = 0; m < S2_TM; ++m) {
+            const int p = m0 + wp * 128 + m * 32 + col;
+            int n = (int)((float)p * sa.rhw);                                      // p < 2^24: the float quotient is within one of the integer one
+            int r = p - n * sa.HW;
+            if (r < 0) r += sa.HW; else if (r >= sa.HW) r -= sa.HW;
+            const int y = div_magic(r, sa.mw), x = r - y * sa.W;
+            int v = 0x1ff;
+            if (y == 0) v &= ~0x007;
+            if (y == sa.H - 1) v &= ~0x1c0;
+            if (x == 0) v &= ~0x049;
+            if (x == sa.W - 1) v &= ~0x124;
+            vm[m] = v;
+        }
+    };
+    int m0_, nb_;
+    if (nmine > 0) {
+        item_of(0, m0_, nb_); ntb = (nb_ * NWN + wn) * TN;
+        masks_of(m0_);
+#pragma unroll
+        for (int t = 0; t < BD; ++t) gloadB(B[t], t, 0, 1, ntb);
+    }
+
+    int k = 0, kk = 0;
+    for (int q = 0; q < nstage; ++q) {
+        __syncthreads();
+        const int sbase = (q % S2_NSTG) * L::STAGE;
+        const bool last = kk + 1 == k16;
+        int ntb_next = ntb, m0_next = m0_;
+        if (last && k + 1 < nmine) { int nb2; item_of(k + 1, m0_next, nb2); ntb_next = (nb2 * NWN + wn) * TN; }
+        const int kk_next = last ? 0 : kk + 1, ok_next = q + 1 < nstage;
+        u32x4 alead[S2_TM], arem[S2_TM];
+        auto aaddr = [&](int t, int m) -> int { return ((vm[m] >> t) & 1) ? at[t] + sbase + m * 2048 : 0; };
+        auto loadLead = [&](int t) {
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m) alead[m] = *reinterpret_cast<const u32x4*>(smem_ln + aaddr(t, m));
+        };
+        auto loadRem = [&](int t) {
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m) arem[m] = *reinterpret_cast<const u32x4*>(smem_ln + (aaddr(t, m) ^ 32));
+        };
+        loadRem(0);
+        loadLead(0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ta = t + BD;
+            if (ta < 9) gloadB(B[ta], ta, kk, 1, ntb);
+            else gloadB(B[ta - 9], ta - 9, kk_next, ok_next, ntb_next);
+            const u32x4 (&b)[TN][2] = B[t];
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, arem[m]), __builtin_bit_cast(f16x8, b[j][0]), acc[m][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2 * TN; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TN - 2 * TN, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < 9) loadRem(t + 1);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, alead[m]), __builtin_bit_cast(f16x8, b[j][1 - pr]), acc[m][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8 * TN - 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < 9) loadLead(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (last) {
+            // ------------------------------------------------------------------------------------------ epilogue of item k (see conv_wide_dma_kernel)
+            item_of(k, m0_, nb_);
+            constexpr int MPP = S2_TM / NH;                                        // row tiles per part
+            // part h holds row tiles h MPP .. + MPP - 1 of every consumer: part-local pixel ((wp MPP + ml) 32 + i), CW channels each
+            float* ob = reinterpret_cast<float*>(smem_ln + L::OUT) + (wp * MPP * 32 + 4 * half) * CW + wn * 64 + col;
+            float* sb = reinterpret_cast<float*>(smem_ln + L::STAT) + wp * 2 * CW + wn * 64 + col;
+            auto put = [&](int h) {                   // MFMA row (e & 3) + 8 (e >> 2) + 4 half of row tile m
+#pragma unroll
+                for (int m = h * MPP; m < h * MPP + MPP; ++m)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) ob[((m - h * MPP) * 32 + (e & 3) + 8 * (e >> 2)) * CW + j * 32] = acc[m][j][e];
+            };
+            float mw[TN], m2[TN];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                put(h);
+                if (h == NH - 1) {
+                    if (a.bias != nullptr && half == 0 && wp == 0) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) reinterpret_cast<float*>(smem_ln + L::BIAS)[(wn * TN + j) * 32 + col] = a.bias[nb_ * CW + (wn * TN + j) * 32 + col];
+                    }
+                    if (a.stat != nullptr && half == 0) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) { sb[j * 32] = mw[j]; sb[CW + j * 32] = m2[j]; }
+                    }
+                }
+                __syncthreads();                      // part h is in LDS
+                if (h == 0 && a.stat != nullptr) {
+                    // (mean, M2) of this wave's 128 pixels per channel, on the raw accumulators (the scale is a power of two: exact); two-pass, four partial sums
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float t4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) t4[e & 3] += acc[m][j][e];
+                        float ts = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+                        ts += __shfl_xor(ts, 32, 64);
+                        const float mraw = ts / 128.f;
+                        float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) { const float d = acc[m][j][e] - mraw; u[e & 3] += d * d; }
+                        float us = (u[0] + u[1]) + (u[2] + u[3]);
+                        us += __shfl_xor(us, 32, 64);
+                        mw[j] = mraw * inv + (a.bias != nullptr ? a.bias[nb_ * CW + (wn * TN + j) * 32 + col] : 0.f);
+                        m2[j] = us * (inv * inv);
+                    }
+                }
+                if (h < NH - 1) __syncthreads();      // the loaders hold part h in registers
+            }
+#pragma unroll
+            for (int m = 0; m < S2_TM; ++m)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+            ntb = ntb_next;
+            ++k; kk = 0;
+            if (k < nmine) { m0_ = m0_next; masks_of(m0_); }
+        } else ++kk;
+    }
+}
+
 }  // namespace
 
 // stride-2 3 x 3 pad-1 forward layers the producer / consumer kernel takes: P16 input with Cin a multiple of 32 (one source), Cout a multiple
@@ -878,4 +1236,54 @@ int viai_conv_s2_dma_launch(ConvArgs& a, hipStream_t st) {
 int viai_conv_s1_dma_launch(ConvArgs& a, hipStream_t st) {
     if (!viai_conv_s1_dma_ok(a)) return (int)hipErrorInvalidValue;
     return launch_wide_dma<1, 2>(a, st);
+}
+
+// stride-1 3 x 3 pad-1 layers the linear-tile kernel takes (geometry only: the launch also needs the pre-split input and its scale): one source with
+// Cin a multiple of 32, Cout a multiple of 64 into one destination, maps up to 63 pixels wide, whole items, at least one item per CU, 32-bit offsets.
+// Maps of whole 8 x 16 tiles with 256 k channels stay on conv_wide_dma_kernel<1, 2> (D.conv3: no validity selects in its fragment reads).
+static int lin_dma_pw(int Cout) { return Cout % 256 == 0 ? 1 : Cout % 128 == 0 ? 2 : 4; }
+bool viai_conv_lin_dma_geom_ok(const ConvArgs& a) {
+    const ConvGeom& g = a.g;
+    if (!viai_halo_dma_on() || a.C2 != 0 || a.C1 % 32 != 0 || a.Cout % 64 != 0 || a.OC1 != a.Cout) return false;
+    if (g.ntaps != 9 || g.ly != 1 || g.lx != 1 || g.my != 1 || g.mx != 1 || g.SH != g.OH || g.SW != g.OW || g.IH != g.OH || g.IW != g.OW || g.OW > 63) return false;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        if (g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return false;
+        seen |= 1u << ((g.dy[t] + 1) * 3 + (g.dx[t] + 1));
+    }
+    if (seen != 0x1ffu) return false;
+    const long M = (long)g.N * g.OH * g.OW;
+    const int pw = lin_dma_pw(a.Cout);
+    if (M % (128 * pw) != 0 || M * a.C1 * 4 >= (1l << 31) || M * a.Cout * 4 >= (1l << 31)) return false;
+    if (g.OH % S2_TH == 0 && g.OW % S2_TW == 0 && a.Cout % 256 == 0) return false;
+    return (M / (128 * pw)) * (a.Cout / (256 / pw)) >= 256;
+}
+bool viai_conv_lin_dma_ok(const ConvArgs& a) { return a.in_p16 && a.amax != nullptr && viai_conv_lin_dma_geom_ok(a); }
+
+template <int PW>
+static int launch_lin_dma(ConvArgs& a, hipStream_t st) {
+    using L = LinDma<PW>;
+    const ConvGeom& g = a.g;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lin_dma_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS);
+        attr_done = true;
+    }
+    LinArgs sa;
+    sa.H = g.OH; sa.W = g.OW; sa.HW = g.OH * g.OW; sa.M = g.N * sa.HW;
+    sa.rhw = 1.0f / (float)sa.HW; sa.mw = tile_magic(sa.W);
+    sa.nnb = a.Cout / L::CW; sa.mnb = tile_magic(sa.nnb);
+    sa.nitems = sa.M / L::PIX * sa.nnb;
+    for (int t = 0; t < 9; ++t) sa.slot[(g.dy[t] + 1) * 3 + (g.dx[t] + 1)] = g.ws[t];
+    a.nblk_m = sa.M / 128;                                    // BatchNorm partial blocks: 128 consecutive pixels (viai_bn_finalize with rows = 128)
+    a.nblk_n = sa.nnb;
+    int grid = 256;
+    if (grid > sa.nitems) grid = sa.nitems;
+    VIAI_LAUNCH((conv_lin_dma_kernel<PW>), dim3(grid), dim3(S2_THREADS), L::LDS, st, a, sa);
+    return viai_launch_status();
+}
+int viai_conv_lin_dma_launch(ConvArgs& a, hipStream_t st) {
+    if (!viai_conv_lin_dma_ok(a)) return (int)hipErrorInvalidValue;
+    const int pw = lin_dma_pw(a.Cout);
+    return pw == 1 ? launch_lin_dma<1>(a, st) : pw == 2 ? launch_lin_dma<2>(a, st) : launch_lin_dma<4>(a, st);
 }

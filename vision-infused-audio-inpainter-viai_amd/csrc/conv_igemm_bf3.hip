@@ -954,10 +954,11 @@ int viai_conv_igemm_bf3_launch(ConvArgs& a, hipStream_t st) {
     const int Cin = a.C1 + a.C2;
     if (Cin % 16 != 0 || (a.C2 > 0 && a.C1 % 32 != 0)) return (int)hipErrorInvalidValue;
     if (a.OC1 % 32 != 0 && a.OC1 != a.Cout) return (int)hipErrorInvalidValue;
-    if (a.in_p16 && !(a.wfrag == 3 && !a.sk && viai_conv_halo_wide_ok(a))) return (int)hipErrorInvalidValue;     // only the patch-staged kernels stage P16 pieces
+    if (a.in_p16 && !(a.wfrag == 3 && !a.sk && (viai_conv_halo_wide_ok(a) || viai_conv_lin_dma_ok(a)))) return (int)hipErrorInvalidValue;     // only the patch-staged kernels stage P16 pieces
     if (a.sk) return launch_bf3_sk(a, st);
     const int bm = viai_igemm_tile_m(a.M, a.Cout);           // same tile rule as the fp32 kernels (BN partial geometry)
     if (a.wfrag == 3) {                                                        // f16x2 weights
+        if (viai_conv_lin_dma_ok(a)) { viai_tag_kernel("lin_dma_f16x2"); return viai_conv_lin_dma_launch(a, st); }   // pre-split input, maps that are not whole 8 x 16 tiles
         if (viai_conv_halo_wide_ok(a)) return viai_conv_halo_wide_launch(a, st);   // stride-1 3 x 3: patch staged once per chunk, not once per tap
         // 128 x 256 tile (eight waves) where the layer is wide and tall enough: every staged activation row then feeds 256
         // output channels, halving the load / split / LDS-store work per MFMA

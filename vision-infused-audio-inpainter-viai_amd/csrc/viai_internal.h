@@ -54,6 +54,9 @@ bool viai_conv_s2_dma_ok(const ConvArgs& a);          // stride-2 forward, loade
 int viai_conv_s2_dma_launch(ConvArgs& a, hipStream_t st);
 bool viai_conv_s1_dma_ok(const ConvArgs& a);          // stride-1 256 k-channel layers on the same kernel (D.conv3)
 int viai_conv_s1_dma_launch(ConvArgs& a, hipStream_t st);
+bool viai_conv_lin_dma_geom_ok(const ConvArgs& a);   // stride-1 3 x 3 layers on linear pixel tiles (maps that are not whole 8 x 16 tiles: the ResNet branch)
+bool viai_conv_lin_dma_ok(const ConvArgs& a);
+int viai_conv_lin_dma_launch(ConvArgs& a, hipStream_t st);
 // conv_stem.hip: the 7 x 7 stride-2 image conv of the ResNet branch on the f16x2 matrix-core path (forward + weight gradient)
 bool viai_conv_stem_ok(const ConvGeom& g, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
 int viai_conv_stem_fwd_launch(ConvArgs& a, hipStream_t st);

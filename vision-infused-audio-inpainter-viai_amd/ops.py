@@ -45,7 +45,7 @@ F16_DYNAMIC = True                                                 # False: stat
 # refuses a P16 tensor; p16_decode() gives the fp32 values).  VIAI_P16=0 switches the format off (A/B: a kernel returns the same bits on P16 operands as on the fp32 tensors AT EQUAL SCALE -- tests/test_p16_gpu.py;
 # the P16 producers derive the scale from an a-priori bound where the fp32 path measures the maximum, so whole-network results agree to rounding, not bit for bit).
 P16 = os.environ.get("VIAI_P16", "1") != "0"
-P16_OK_FWD_X, P16_OK_DGRAD_DY, P16_OK_WGRAD_DY, P16_OK_WGRAD_X = 1, 2, 4, 8
+P16_OK_FWD_X, P16_OK_DGRAD_DY, P16_OK_WGRAD_DY, P16_OK_WGRAD_X, P16_OK_FWD_LIN = 1, 2, 4, 8, 16
 
 
 def is_p16(t):
@@ -412,10 +412,13 @@ def weights_changed(params=None, owner=None):
     repack(params, owner)
 
 
-def _bn_finalize(lib, d, stat, M, Cc, gamma, beta, rmean, rvar, nbt, cfg, coef, st):
+def _bn_finalize(lib, d, stat, M, Cc, gamma, beta, rmean, rvar, nbt, cfg, coef, st, lin=False):
     """partials of the conv forward -> (mean, invstd, scale, shift) + running statistics; tile-shaped partial blocks where the forward
-    kernel's tiles are clipped at the map's edge (viai_conv2d_stat_tiles)"""
-    th, tw = d["tiles"]
+    kernel's tiles are clipped at the map's edge (viai_conv2d_stat_tiles); `lin`: the pre-split forward ran on the linear-tile kernel, whose
+    partial blocks are 128 consecutive pixels (VIAI_P16_OK_FWD_LIN)"""
+    th, tw = (0, 0) if lin else d["tiles"]
+    if lin:
+        d = {"nblk": M // 128, "rows": 128}
     tail = (Cc, gamma.data_ptr(), beta.data_ptr(), _ptr(rmean), _ptr(rvar), _ptr(nbt), cfg["momentum"], cfg["eps"],
             coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st)
     if th > 0:
@@ -626,7 +629,7 @@ class _ConvBnAct(torch.autograd.Function):
             if training:
                 stat = _scratch("stat", 2 * Cout * d["nblk"], dev)
                 conv_fwd(y, stat.data_ptr(), ACT_NONE)
-                _bn_finalize(lib, d, stat, M, Cout, gamma, beta, rmean, rvar, nbt, cfg, coef, st)
+                _bn_finalize(lib, d, stat, M, Cout, gamma, beta, rmean, rvar, nbt, cfg, coef, st, lin=xp and bool(p16_mask(d) & P16_OK_FWD_LIN))
             else:
                 conv_fwd(y, 0, ACT_NONE)
                 _lib.check(lib.viai_bn_eval_coeffs(Cout, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(),
@@ -1031,7 +1034,7 @@ class _ConvBnActCout1(torch.autograd.Function):
         if cfg["training"]:
             stat = _scratch("stat", 2 * Cmid * d["nblk"], dev)
             conv_fwd(stat.data_ptr())
-            _bn_finalize(lib, d, stat, M, Cmid, gamma, beta, rmean, rvar, nbt, cfg, coef, st)
+            _bn_finalize(lib, d, stat, M, Cmid, gamma, beta, rmean, rvar, nbt, cfg, coef, st, lin=xp and bool(p16_mask(d) & P16_OK_FWD_LIN))
         else:
             conv_fwd(0)
             _lib.check(lib.viai_bn_eval_coeffs(Cmid, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), cfg["eps"],
