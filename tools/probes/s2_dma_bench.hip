@@ -1,5 +1,5 @@
 // Standalone timing / stage-stamp harness for conv_s2_dma_kernel (csrc/conv_halo_dma.hip).  Results are not checked here (tests/test_p16_gpu.py).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DVIAI_PROF] -o s2_dma_bench tools/probes/s2_dma_bench.hip ;  ./s2_dma_bench N IH IW Cin Cout [iters]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DVIAI_PROF] -o s2_dma_bench tools/probes/s2_dma_bench.hip ;  ./s2_dma_bench N IH IW Cin Cout [iters] [stride] [linear-tile kernel: 1]
 #include "../../vision-infused-audio-inpainter-viai_amd/csrc/conv_halo_dma.hip"
 #include <cstdio>
 #include <vector>
@@ -32,7 +32,8 @@ int main(int argc, char** argv) {
     viai_dma_prof_buf = dprof;
 #endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto launch = [&]() { return S == 2 ? viai_conv_s2_dma_launch(a, 0) : viai_conv_s1_dma_launch(a, 0); };
+    const bool lin = argc > 8 && atoi(argv[8]) != 0;              // the linear-tile kernel (stride 1)
+    auto launch = [&]() { return lin ? viai_conv_lin_dma_launch(a, 0) : S == 2 ? viai_conv_s2_dma_launch(a, 0) : viai_conv_s1_dma_launch(a, 0); };
     for (int i = 0; i < 3; ++i) if (int e = launch()) { printf("launch error %d\n", e); return 1; }
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);

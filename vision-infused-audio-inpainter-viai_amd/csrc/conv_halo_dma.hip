@@ -826,7 +826,7 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // pixel m + dy W + dx of the same flattened map, so a stage holds the k-step's records of pixels m0 - W - 1 .. m0 + PIX + W (one contiguous range of the
 // P16 tensor: the loaders' offsets are linear in the record index, no division anywhere) and a fragment read is 32 consecutive 64-byte records
 // shifted by the tap.  What the 2-D patch did with out-of-range lanes -- the zero padding -- the CONSUMERS do here: a lane whose window position falls
-// outside its image (nine validity bits per pixel, worked out once per item) reads the all-zero record at LDS byte 0 instead.
+// outside its image (nine validity bits per pixel, worked out once per item) reads the all-zero bank row at LDS byte 0 instead.
 // Records keep the piece swizzle of the 2-D kernels, position = piece ^ ((record >> 2) & 3): a shift by a whole number of records moves a read to other
 // records, the 16 lanes of a `ds_read_b128` group still take 16 consecutive ones, four per bank-row quarter.
 template <int PW>
@@ -853,6 +853,9 @@ struct LinArgs {
     int nnb; unsigned mnb;                                             // channel blocks per pixel tile (item = tile * nnb + nb)
     int nitems;
     int slot[9];                                                       // weight slot of window position (row * 3 + col)
+#ifdef VIAI_PROF
+    unsigned long long* prof;                                          // [block][2 roles][32 stages][4 stamps] (tools/probes/s2_dma_bench.hip)
+#endif
 };
 
 __device__ __forceinline__ void dma_batch(const i32x4& rs, unsigned lds0, int soff, const int (&v)[6]) { dma_batch6(rs, lds0, soff, v[0], v[1], v[2], v[3], v[4], v[5]); }
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         nb = item - tile * sa.nnb;
         m0 = tile * PIX;
     };
-    if (tid < 16) reinterpret_cast<unsigned*>(smem_ln)[tid] = 0u;               // the zero record (visible behind the first stage barrier)
+    if (tid < 64) reinterpret_cast<unsigned*>(smem_ln)[tid] = 0u;               // the zero row: 256 bytes (visible behind the first stage barrier)
 
     if (wave >= S2_NCONS) {
         // ------------------------------------------------------------------------------------------------ loader waves
@@ -948,10 +951,14 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         constexpr int Q = PIX / NH / 4, PPW = 128 / NH;
         const int lpix = (lw * Q / PPW) * 128 + (lw * Q) % PPW;
         for (int q = 0; q < nstage; ++q) {
+            S2_STAMP(1, q, 0);
             __syncthreads();                         // stage q landed (every loader waited); the consumers are done with stage q - 1
+            S2_STAMP(1, q, 1);
             if (q == 0 && nstage > 1) issue(1);
             if (q + 2 < nstage) issue(q + 2);
+            S2_STAMP(1, q, 2);
             wait_older(q + 2 < nstage);
+            S2_STAMP(1, q, 3);
             flush(npend);
             if (++kl == k16) {                       // last k-step of an item: its output arrives through LDS in NH parts
                 kl = 0;
@@ -1058,14 +1065,18 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
     int k = 0, kk = 0;
     for (int q = 0; q < nstage; ++q) {
+        S2_STAMP(0, q, 0);
         __syncthreads();
+        S2_STAMP(0, q, 1);
         const int sbase = (q % S2_NSTG) * L::STAGE;
         const bool last = kk + 1 == k16;
         int ntb_next = ntb, m0_next = m0_;
         if (last && k + 1 < nmine) { int nb2; item_of(k + 1, m0_next, nb2); ntb_next = (nb2 * NWN + wn) * TN; }
         const int kk_next = last ? 0 : kk + 1, ok_next = q + 1 < nstage;
         u32x4 alead[S2_TM], arem[S2_TM];
-        auto aaddr = [&](int t, int m) -> int { return ((vm[m] >> t) & 1) ? at[t] + sbase + m * 2048 : 0; };
+        // (a masked lane keeps the low 8 address bits -- its place in the 256-byte bank row -- and reads the zero ROW at LDS byte 0: with one zero record for all of
+        // them the masked lanes of a 16-lane group landed on banks a valid lane of the group was reading: SQ_LDS_BANK_CONFLICT 0.22 on the 28-pixel maps)
+        auto aaddr = [&](int t, int m) -> int { const int ad = at[t] + sbase + m * 2048; return ((vm[m] >> t) & 1) ? ad : (ad & 255); };
         auto loadLead = [&](int t) {
 #pragma unroll
             for (int m = 0; m < S2_TM; ++m) alead[m] = *reinterpret_cast<const u32x4*>(smem_ln + aaddr(t, m));
@@ -1106,6 +1117,7 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (t + 1 < 9) loadLead(t + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        S2_STAMP(0, q, 2);
         if (last) {
             // ------------------------------------------------------------------------------------------ epilogue of item k (see conv_wide_dma_kernel)
             item_of(k, m0_, nb_);
@@ -1171,6 +1183,7 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             ++k; kk = 0;
             if (k < nmine) { m0_ = m0_next; masks_of(m0_); }
         } else ++kk;
+        S2_STAMP(0, q, 3);
     }
 }
 
@@ -1275,6 +1288,9 @@ static int launch_lin_dma(ConvArgs& a, hipStream_t st) {
     sa.nnb = a.Cout / L::CW; sa.mnb = tile_magic(sa.nnb);
     sa.nitems = sa.M / L::PIX * sa.nnb;
     for (int t = 0; t < 9; ++t) sa.slot[(g.dy[t] + 1) * 3 + (g.dx[t] + 1)] = g.ws[t];
+#ifdef VIAI_PROF
+    sa.prof = viai_dma_prof_buf;
+#endif
     a.nblk_m = sa.M / 128;                                    // BatchNorm partial blocks: 128 consecutive pixels (viai_bn_finalize with rows = 128)
     a.nblk_n = sa.nnb;
     int grid = 256;

@@ -99,10 +99,9 @@ FUSE_BN_TAIL = True      # BatchNorm apply + (residual add + ReLU | ReLU + max-p
 
 
 # Residual joins / the stem's pool can write a pre-split (P16) twin of their output for the next BasicBlock's conv1 (ops.conv_bn_act `out_p16` on a layer with
-# `residual` / `pool`).  Measured on the vision-infused step: the kernel-time sum falls 224 -> 212 ms (the conv1 forward / weight-gradient kernels stop
-# splitting), the step does not move (118.7 without, 119.0 with: both queues stay full, the chip is at its power / bandwidth limit and the twin adds a write
-# of the tensor) -- so it is OFF; tests/test_p16_gpu.py flips the module switch and keeps the path alive.
-P16_TWIN = False
+# `residual` / `pool`).  Round 4, on the register-staged kernels: kernel-time sum 224 -> 212 ms, the step did not move (118.7 / 119.0 ms) -- OFF then.  Round 5: a
+# pre-split conv1 runs on the linear-tile loader / consumer kernel (csrc/conv_halo_dma.hip), 110.1 -> 108.1 ms on the vision-infused step -- ON.
+P16_TWIN = True
 
 
 def takes_p16(x_shape, conv):
