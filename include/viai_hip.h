@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 14
+#define VIAI_ABI_VERSION 15
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -182,6 +182,10 @@ int viai_bn_act_bwd_amax(const float* dz, const float* y, const float* mean, con
  * dx = dz * act'(.) expressed through the activation OUTPUT z                    */
 int viai_act_bwd_from_output(const float* dz, const float* z, float* dx, long n, int act,
                              float slope, void* stream);
+/* (ABI 15) the same on a gradient that arrives as two addends: dx = (dz + dz2) * act'(.); n a multiple of 4.  The residual join of
+ * networks/ResNet.py:46-53: d(out) = conv1's data gradient + the next join's residual gradient, summed where the ReLU mask is applied */
+int viai_add_act_bwd_from_output(const float* dz, const float* dz2, const float* z, float* dx, long n, int act,
+                                 float slope, void* stream);
 
 /* ------------------------------------------------------------------ resampling
  * F.interpolate(mode='bilinear', align_corners=True)  New_Inpainting_Networks.py:78,83 */

@@ -177,6 +177,8 @@ def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_inp
     w = torch.randn((Ci, Co, 3, 3) if tr else (Co, Ci, 3, 3), device="cuda", generator=gen) * 0.05
     d = ops.conv_desc(N, H, W, Ci, 0, Co, 3, 3, S, S, 1, 1, 1 if tr else 0)
     ok = lib.viai_conv2d_p16_ok(d["ref"])
+    if lin and not ok & 16:
+        pytest.skip("the linear-tile kernel is switched off (VIAI_HALO_DMA=0)")
     assert ok & 1 and ok & 2, (case, ok)                  # (the shapes are chosen so that both directions run on a patch-staged kernel)
     xp, xa = to_p16(x)
     dyp, da = to_p16(dy)

@@ -22,7 +22,7 @@ class ViaiLibraryError(RuntimeError):
 
 # ABI version THIS file's SIGNATURES / struct mirrors were written against: bumped together with them.  load() compares it with the
 # library, and with the committed header where that is present (a source checkout), so a stale _lib.py cannot call a rebuilt .so.
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 def _header_abi_version():
@@ -105,6 +105,7 @@ SIGNATURES = {
     "viai_conv2d_pack_dgrad_f16": (_I, [_CP, _P, _P, _P]),
     "viai_conv2d_dgrad_f16": (_I, [_CP, _P, _P, _P, _P, _P, _P]),
     "viai_act_bwd_from_output": (_I, [_P, _P, _P, _L, _I, _F, _P]),
+    "viai_add_act_bwd_from_output": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "viai_bilinear_ac_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "viai_bilinear_ac_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "viai_bn_act_bilinear_fwd_amax": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),

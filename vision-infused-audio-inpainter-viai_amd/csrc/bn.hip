@@ -796,6 +796,31 @@ extern "C" int viai_bn_act_bwd(const float* dz, const float* y, const float* mea
     return viai_bn_act_bwd_amax(dz, y, mean, invstd, scale, shift, part, sums, dgamma, dbeta, dy, M, C, act, slope, training, nullptr, stream);
 }
 
+// dx = (dz + dz2) * act'(.): the gradient of a residual join's output arrives as its two addends (the next block's conv1 data gradient and the
+// next join's residual gradient, networks/ResNet.py:46-53) and is summed where the activation's mask is applied, instead of in a pass of its own
+__global__ void add_act_bwd_out_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ dz2, const f32x4* __restrict__ z, f32x4* __restrict__ dx,
+                                       long n4, int act, float slope) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 zz = z[i], g = dz[i] + dz2[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = 1.f;
+            if (act == VIAI_ACT_SIGMOID) d = zz[e] * (1.f - zz[e]);
+            else if (act == VIAI_ACT_RELU) d = zz[e] > 0.f ? 1.f : 0.f;
+            else if (act == VIAI_ACT_LRELU) d = zz[e] > 0.f ? 1.f : slope;
+            o[e] = g[e] * d;
+        }
+        dx[i] = o;
+    }
+}
+extern "C" int viai_add_act_bwd_from_output(const float* dz, const float* dz2, const float* z, float* dx, long n, int act, float slope, void* stream) {
+    if (n % 4 != 0) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(add_act_bwd_out_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dz, (const f32x4*)dz2, (const f32x4*)z, (f32x4*)dx,
+                n / 4, act, slope);
+    return viai_launch_status();
+}
+
 extern "C" int viai_act_bwd_from_output(const float* dz, const float* z, float* dx, long n, int act, float slope, void* stream) {
     VIAI_LAUNCH(act_bwd_out_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dz, z, dx, n, act, slope);
     return viai_launch_status();

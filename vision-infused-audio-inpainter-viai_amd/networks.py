@@ -526,8 +526,9 @@ class BasicBlock(nn.Module):
 
     def forward_nhwc(self, x, next_conv=None):
         """`next_conv`: the next block's conv1 (fused_layer: the join then writes the planes its kernels stage beside the fp32 tensor)"""
+        x, xr = ops.fork2(x)                          # two readers: their gradients reach the producer as two addends (no pass for the sum)
         out = fused_layer(x, self.conv1, self.bn1, ACT_RELU, next_conv=self.conv2)
-        res = x if self.downsample is None else fused_layer(x, self.downsample[0], self.downsample[1], ACT_NONE)
+        res = xr if self.downsample is None else fused_layer(xr, self.downsample[0], self.downsample[1], ACT_NONE)
         return fused_layer(out, self.conv2, self.bn2, ACT_RELU, residual=res, next_conv=next_conv)   # relu(bn2(conv2(out)) + res), networks/ResNet.py:46-53
 
     def forward(self, x):

@@ -728,8 +728,12 @@ class _ConvBnAct(torch.autograd.Function):
         M = N * OH * OW
         st = _stream()
         dev = dz.device
+        addend = _take_addend(dz)
         dz = _c(dz)
         act = cfg["act"]
+        if addend is not None and not (ctx.tail == "res" and act != ACT_NONE and not ctx.fused1 and dz.numel() % 4 == 0):
+            dz = dz + addend                              # no pass of this backward to fold the sum into
+            addend = None
         need_x, need_x2, need_w, need_b, need_g, need_be = ctx.needs_input_grad[:6]
         gt = cfg.get("gt") or (None, None, None, None)       # in-place gradient targets (arena views)
         dgamma = dbeta = None
@@ -747,8 +751,12 @@ class _ConvBnAct(torch.autograd.Function):
             # d/d(sum) through the activation (mask from the saved output); the same tensor is the residual branch's gradient
             if act != ACT_NONE:
                 dres = torch.empty_like(dz)
-                _lib.check(lib.viai_act_bwd_from_output(dz.data_ptr(), ctx.saved_tensors[5].data_ptr(), dres.data_ptr(), dz.numel(), act, 0.2, st),
-                           "viai_act_bwd_from_output")
+                if addend is not None:
+                    _lib.check(lib.viai_add_act_bwd_from_output(dz.data_ptr(), addend.data_ptr(), ctx.saved_tensors[5].data_ptr(), dres.data_ptr(), dz.numel(), act, 0.2,
+                                                                st), "viai_add_act_bwd_from_output")
+                else:
+                    _lib.check(lib.viai_act_bwd_from_output(dz.data_ptr(), ctx.saved_tensors[5].data_ptr(), dres.data_ptr(), dz.numel(), act, 0.2, st),
+                               "viai_act_bwd_from_output")
                 dz = dres
             else:
                 dres = dz
@@ -940,9 +948,11 @@ def conv_bn_act(x, weight, bias=None, bn=None, *, kernel, stride=(1, 1), padding
         if DIRECT_GRAD:
             cfg["gt"] = tuple(p.grad if (p is not None and p.is_leaf and p.requires_grad and p.grad is not None) else None
                               for p in (weight, bias, bn.weight, bn.bias))
-        return _tag_amax(_ConvBnAct.apply(x, x2, weight, bias, bn.weight, bn.bias,
-                                          bn.running_mean if track else None, bn.running_var if track else None,
-                                          bn.num_batches_tracked if (track and cfg["training"]) else None, residual, cfg), cfg)
+        z = _tag_amax(_ConvBnAct.apply(x, x2, weight, bias, bn.weight, bn.bias,
+                                       bn.running_mean if track else None, bn.running_var if track else None,
+                                       bn.num_batches_tracked if (track and cfg["training"]) else None, residual, cfg), cfg)
+        z._viai_lazy_sum_ok = True                        # its backward takes a gradient with an addend attached (fork2)
+        return z
     if DIRECT_GRAD:
         cfg["gt"] = tuple(p.grad if (p is not None and p.is_leaf and p.requires_grad and p.grad is not None) else None
                           for p in (weight, bias, None, None))
@@ -1402,6 +1412,54 @@ class _AvgPoolHW(torch.autograd.Function):
 
 def avgpool_hw(x):
     return inherit_amax(_AvgPoolHW.apply(x), x)
+
+
+LAZY_SUM = True      # gradients of a tensor with two readers reach its producer as two addends (fork2; module switch: tests/test_resnet_gpu.py flips it)
+
+
+class _Fork2(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two readers (a BasicBlock's input: conv1 and the residual join / the downsample conv, networks/ResNet.py:40-53).
+    The backward does NOT add the two gradients: it hands the first on with the second attached (`_viai_addend`), and the producer's backward --
+    _ConvBnAct, the only producer fork2() is applied to -- adds them in the pass that reads the gradient anyway (the join: where the ReLU mask
+    is applied, viai_add_act_bwd_from_output).  The autograd engine would have spent a pass of its own on the sum."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g1 if g2 is None else g2
+        if g1.shape != g2.shape or g1.dtype != torch.float32 or g2.dtype != torch.float32 or getattr(g1, "_viai_addend", None) is not None:
+            return g1 + g2
+        g1 = _c(g1)
+        if getattr(g2, "_viai_addend", None) is not None:
+            g2 = g2 + g2._viai_addend
+        g1._viai_addend = _c(g2)
+        return g1
+
+
+def fork2(x):
+    """two handles of x for its two readers, when x comes straight out of conv_bn_act (whose backward takes the gradient as two addends) and the
+    sum is worth fusing; (x, x) otherwise"""
+    if not (LAZY_SUM and getattr(x, "_viai_lazy_sum_ok", False) and x.requires_grad and x.is_cuda):
+        return x, x
+    a, b = _Fork2.apply(x)
+    for t in (a, b):                                      # the tags conv_bn_act left for the next layer
+        for k in ("_viai_amax", "_viai_twin", "_viai_p16"):
+            v = getattr(x, k, None)
+            if v is not None:
+                setattr(t, k, v)
+    return a, b
+
+
+def _take_addend(dz):
+    """the second addend of a gradient that arrived lazily summed (fork2), or None"""
+    a = getattr(dz, "_viai_addend", None)
+    if a is not None:
+        dz._viai_addend = None
+    return a
 
 
 class _AddRelu(torch.autograd.Function):
