@@ -38,6 +38,12 @@ constexpr int WP_TW = 16, WP_TH = 8;                // output pixel tile
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct WgPatchSlots { int s[9]; };
+#ifdef VIAI_PROF
+__device__ unsigned long long* wg_prof_buf;      // tools/probes/wgrad_patch_bench.hip: [block][32 stages][4 stamps] shader-clock stamps of wave 0
+#define WG_STAMP(s, i) do { if (tid == 0 && (s) < 32) wg_prof_buf[((size_t)blockIdx.x * 32 + (s)) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WG_STAMP(s, i) do { } while (0)
+#endif
 
 // two images per tile (stride 1, maps of at most 8 x 7 pixels, same extent in and out)
 __host__ __device__ inline bool wgrad_patch_pairs(const ConvGeom& g) {
@@ -69,7 +75,10 @@ struct WgCfg {
                                                                      // groups swapped by bit 1 of the pixel (rows p, p+1 are the two halves of a 256-B bank row, p+2, p+3
                                                                      // take the other group: four distinct 64-B segments per four rows); 32 ch = 64 B
     static constexpr int DPIX = HR * WP_TW;
-    static constexpr int DPLANE = DPIX * DROW, XPLANE = XSLOTS * XPITCH;
+    // plane strides: + 64 bytes where the raw size is a multiple of 128 -- a P16 staging store (`ds_write_b128`: groups of 8 lanes, bank = (a / 4) mod 32,
+    // MI355X_MICROARCH.md section LDS) writes the four leading and the four remainder pieces of a pixel's 32-channel group from the 8 lanes of one group, and
+    // with the planes a multiple of 128 bytes apart the two halves hit the same banks (SQ_LDS_BANK_CONFLICT 0.135 on ResNet layer2's weight gradient)
+    static constexpr int DPLANE = DPIX * DROW + ((DPIX * DROW) % 128 == 0 ? 64 : 0), XPLANE = XSLOTS * XPITCH + ((XSLOTS * XPITCH) % 128 == 0 ? 64 : 0);
     static constexpr int STAGE = 2 * DPLANE + 2 * XPLANE;
     static constexpr int LDS = 2 * STAGE;
     static constexpr int DQ = BM / 4;                                // channel quads per dy pixel
@@ -307,6 +316,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
     __syncthreads();
     for (int s = 0; s + 1 < nst; ++s) {
         const unsigned char* Sb = smem_p + (s & 1) * STAGE;
+        WG_STAMP(s, 0);
         gstage(s + 2);
 #pragma unroll
         for (int r = 0; r < C::KSW; ++r)
@@ -320,7 +330,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
                         if (U & 1) gload_item(U >> 1);
                     }
             });
+        WG_STAMP(s, 1);
         __syncthreads();
+        WG_STAMP(s, 2);
     }
     if (nst > 0) {                                  // last stage: nothing left to stage
         const unsigned char* Sb = smem_p + ((nst - 1) & 1) * STAGE;
@@ -429,6 +441,8 @@ static int block_ksplit(const ConvGeom& g, int Cout, int Cin, int cfg) {
     long ks = (cfg == 2 ? blk2 : cfg == 3 ? blk3 : cfg == 4 ? blk4 : blk1) / per;
     // the sub-CU grids above suit the audio step, whose weight gradients are short and share the chip with the main chain; a layer with
     // hundreds of tiles per block (the ResNet branch on 1024 frames) is worth every CU
+    // (ResNet layer2 - 4 sit at 85 tiles per block and keep the 192-block grid: alone they would be a quarter faster on every CU -- tools/probes/wgrad_patch_bench.hip,
+    // 947 us, in-loop MFMA use 0.79 -- but inside the vision-infused step, beside the main chain, 256 blocks measured 107.1 ms against 106.5)
     if (ks >= 1 && tiles / ks > 128) ks = 256 / per;
     if (ks > tiles / 4) ks = tiles / 4;
     if (ks < 1) ks = 1;
