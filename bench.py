@@ -52,6 +52,8 @@ FAMILY_KERNELS = {
                           "four LOADER waves (the 10x18 patch of a 16-channel k-step by LDS-DMA, three stages deep; they also store the output tile, handed over through LDS) and four CONSUMER waves "
                           "(128 pixels x 64 channels each, weight fragments from global, f16x2 split MFMA); forward and data-gradient launches of D.conv3.  fp32 inputs / small maps: "
                           "conv_halo_wide_f16_kernel<1,8,4,1> (register-staged, eight waves of 128 pixels x 32 channels)",
+    "lin_dma_f16x2": "conv_lin_dma_kernel<PW> (csrc/conv_halo_dma.hip, round 5: the loader / consumer kernel over LINEAR pixel tiles -- stride-1 3x3 conv on a pre-split (P16) input on maps that "
+                     "are not whole 8x16 tiles (ResNet-18's 56 / 28 / 14 / 7-pixel stages): 128 PW consecutive pixels x 256 / PW channels per work item, zero padding as a per-lane select in the fragment reads)",
     "halo_wide128_f16x2": "conv_halo_wide_f16_kernel<1,4,4,1> (as above, 128-channel tile, four waves of 128 pixels x 32 channels)",
     "halo_wide64_f16x2": "conv_halo_wide_f16_kernel<2,2,2,1> (64-channel tile)", "halo_wide32_f16x2": "conv_halo_wide_f16_kernel<4,1,1,1> (32-channel tile)",
     "halo_wide_s2_f16x2": "conv_wide_dma_kernel<2,1> (stride-2 forward on a P16 input: loader / consumer waves, the 17x33 patch as four parity sub-patches by LDS-DMA; "
@@ -75,7 +77,7 @@ FAMILY_KERNELS = {
 }
 # kernel-name fragment of a family in the rocprofv3 counter summaries under profiles/ (traffic of the dominant kernel)
 PMC_KERNEL_OF = {"wgrad_patch_f16x2": "wgrad_patch_f16_kernel<1, 128", "wgrad_patch_s2_f16x2": "wgrad_patch_f16_kernel<2", "wgrad_patch_narrow_f16x2": "wgrad_patch_f16_kernel<1, 32",
-                 "wgrad_bf3_f16x2": "wgrad_bf3_kernel", "halo_wide256_f16x2": "conv_wide_dma_kernel<1, 2>", "halo_wide128_f16x2": "conv_halo_wide_f16_kernel",
+                 "wgrad_bf3_f16x2": "wgrad_bf3_kernel", "halo_wide256_f16x2": "conv_wide_dma_kernel<1, 2>", "halo_wide128_f16x2": "conv_halo_wide_f16_kernel", "lin_dma_f16x2": "conv_lin_dma_kernel",
                  "igemm128x256_f16x2": "frag_kernel<2, 2, 2, 2, 4", "igemm128x128_f16x2": "frag_kernel<2", "igemm128x128_bf16x3": "frag_kernel<3"}
 
 
