@@ -8,7 +8,7 @@ tools/pmc_layer.sh $o/pmc_dconv2_1.json --shape 16 256 128 64 128 --stride 2 --b
 tools/pmc_layer.sh $o/pmc_gconv6_1.json --shape 16 256 256 32 32 --transposed --bn --p16 > /dev/null 2>&1
 # the vision-infused step: kernel stats of the three-stream step, counters of ResNet layer1 / layer2 alone (forward, data gradient, weight gradient)
 d=/tmp/avp_$$; rm -rf $d; mkdir -p $d
-(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python '$GRAFT_REPO_ROOT'/bench.py --config av --steps 3 --warmup 1 --no-roofline --no-cpu-baseline --no-extra > $d/log.txt 2>&1)
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python "$GRAFT_REPO_ROOT/bench.py" --config av --steps 3 --warmup 1 --no-roofline --no-cpu-baseline --no-extra > $d/log.txt 2>&1)
 f=$(find $d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $o/av_kernel_stats.csv
 tools/pmc_layer.sh $o/pmc_resnet_layer1.json --shape 1024 56 56 64 64 --bn --p16 --iters 3 > /dev/null 2>&1
 tools/pmc_layer.sh $o/pmc_resnet_layer2.json --shape 1024 28 28 128 128 --bn --p16 --iters 3 > /dev/null 2>&1
