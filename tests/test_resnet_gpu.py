@@ -205,7 +205,8 @@ def test_stem_conv_on_the_f16x2_kernels_against_fp64(cin, N, hw):
 def test_batchnorm_tail_fusions_equal_the_separate_passes(what, monkeypatch):
     """BatchNorm apply + (residual add + ReLU) of a BasicBlock (networks/ResNet.py:46-53) and BatchNorm apply + ReLU + MaxPool2d(3, 2, 1) of
     the stem (Image_Embedding.py:20-23) as one pass each, and the pool's backward gathered inside the BatchNorm backward: every output,
-    statistic and gradient bit-identical to the separate kernels (same arithmetic, fewer passes over memory)."""
+    statistic and gradient bit-identical to the separate kernels (same arithmetic, fewer passes over memory) -- except the pool case's gradients
+    since round 5 (see below)."""
     from viai_amd import networks as N_, ops
     import torch.nn as nn
     if what == "pool":
@@ -239,8 +240,13 @@ def test_batchnorm_tail_fusions_equal_the_separate_passes(what, monkeypatch):
         torch.cuda.synchronize()
         outs.append([z.detach().clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()]
                     + ([x.grad.clone(), r.grad.clone()] if r is not None else []))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for i, (a, b) in enumerate(zip(*outs)):
+        if what == "pool" and i in (1, 2, 3):
+            # round 5: the pool-fused BatchNorm backward takes its two sums from the POOLED side (bn_pool_bwd_reduce_kernel: the same terms in another
+            # order), so the gradients of the fused path agree with the separate passes to rounding; outputs and statistics stay bit-identical
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), (i, float((a - b).abs().max()), float(a.abs().max()))
+        else:
+            assert torch.equal(a, b)
     assert float(outs[0][0].abs().max()) > 0
 
 

@@ -317,6 +317,79 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 }
 
+// The pool-fused reduce from the POOLED side (round 5).  The two sums are linear in the un-pooled gradient, and that gradient is a scatter of the pooled
+// one: sum over pixels of dz(pixel) f(pixel) = sum over pooled elements of dpool f(its argmax pixel).  So the pass walks the pooled tensor (a quarter of
+// the pixels for the stem's 3 x 3 / stride-2 pool) and fetches y at the argmax position of each element -- one 4-byte read per element -- instead of
+// walking the un-pooled map and testing up to four windows per pixel (16 GB of L1 / L2 traffic and the compares on the ResNet stem's 3.3 GB map:
+// 2.27 ms where the memory time is 0.8).  Same terms as bn_bwd_reduce_kernel<true>, summed in another order (an un-pooled pixel that is the argmax of
+// two windows contributes twice instead of once with the summed gradient): results agree to rounding, not bit for bit.  k = 3 only (the stem).
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(
+    const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ part, long MP, int C, long rows_per_blk, int act, float slope, const PoolGather p) {
+    __shared__ f32x4 r1[256], r2[256];
+    const int tid = threadIdx.x;
+    const int CG = C / 4;
+    const long row0 = blockIdx.x * rows_per_blk;                 // pooled pixels of this block
+    long row1 = row0 + rows_per_blk; if (row1 > MP) row1 = MP;
+    for (int g0 = 0; g0 < CG; g0 += 256) {
+        const int cgw = min(256, CG - g0);
+        const int pg = 256 / cgw;
+        const int cg = tid % cgw, pl = tid / cgw;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (pl < pg) {
+            const int c = (g0 + cg) * 4;
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+            // pooled pixel r = (n, oy, ox), advanced by pg pixels per step (pg <= 256 < OW * OH is not assumed: general carry)
+            long r = row0 + pl;
+            int ox = (int)(r % p.OW); long t = r / p.OW; int oy = (int)(t % p.OH); int n = (int)(t / p.OH);
+            const int sx = pg % p.OW, sy = (pg / p.OW) % p.OH, sn = pg / (p.OW * p.OH);
+            for (; r < row1; r += 2L * pg) {
+                unsigned pk[2]; f32x4 g[2]; float v[2][4]; bool ok[2];
+                int bo[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {                    // two pooled elements x (1 + 1 + 4) loads in flight per lane
+                    ok[u] = r + (long)u * pg < row1;
+                    const size_t o = ok[u] ? (size_t)(r + (long)u * pg) * C + c : (size_t)row0 * C + c;
+                    pk[u] = *reinterpret_cast<const unsigned*>(p.idx + o);
+                    g[u] = *reinterpret_cast<const f32x4*>(p.dpool + o);
+                    // window origin (may lie in the padding: the argmax never does); a lane past the block's range reads element row0's window position of pixel 0
+                    bo[u] = ok[u] ? ((n * p.IH + oy * p.st - p.pd) * p.IW + ox * p.st - p.pd) * C + c : c;
+                    ox += sx; if (ox >= p.OW) { ox -= p.OW; ++oy; }
+                    oy += sy; if (oy >= p.OH) { oy -= p.OH; ++n; }
+                    n += sn;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int b = (int)((pk[u] >> (8 * e)) & 0xffu);
+                        const int wy = (b * 11) >> 5, wx = b - 3 * wy;   // b / 3, b % 3 (b < 9)
+                        v[u][e] = y[(long)bo[u] + (long)(wy * p.IW + wx) * C + e];
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dp = ok[u] ? g[u][e] * act_grad(v[u][e] * sc[e] + sh[e], act, slope) : 0.f;
+                        s1[e] += dp;
+                        s2[e] += dp * (v[u][e] - mu[e]) * is[e];
+                    }
+            }
+        }
+        r1[tid] = s1; r2[tid] = s2;
+        __syncthreads();
+        if (tid < cgw) {
+            f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < pg; ++k) { t1 += r1[k * cgw + tid]; t2 += r2[k * cgw + tid]; }
+            const int c = (g0 + tid) * 4;
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + c) = t1;
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + c) = t2;
+        }
+        __syncthreads();
+    }
+}
+
 // sums over the row-block partials (fp64, fixed order), 4 channels x 64 partial lanes per block.  Emits
 //   sums[0][c] = k0, sums[1][c] = k1  with  dy = scale*dpre + k1*(y-mean) + k0   (training-mode BN backward:
 //   dy = scale*(dpre - s1/M - xhat*s2/M), xhat = (y-mean)*invstd), plus dgamma = s2, dbeta = s1.
@@ -770,8 +843,16 @@ extern "C" int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char
     PoolGather pg{dpool, idx, IH, IW, (IH + 2 * p - k) / s + 1, (IW + 2 * p - k) / s + 1, k, s, p};
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
-    VIAI_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, (const float*)nullptr, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, pg);
-    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 2);
+    const long MP = (long)N * pg.OH * pg.OW;
+    int nb = nblk;
+    if (k == 3 && M * C < (1l << 31)) {                  // the sums from the pooled side (int offsets into y): same partial layout, blocks over pooled pixels
+        nb = viai_bn_bwd_blocks(MP, C);
+        if (nb > nblk) nb = nblk;                        // (`part` is sized for viai_bn_bwd_blocks(M, C))
+        const long rpp = (MP + nb - 1) / nb;
+        VIAI_LAUNCH(bn_pool_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, y, mean, invstd, scale, shift, part, MP, C, rpp, act, slope, pg);
+    } else
+        VIAI_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, (const float*)nullptr, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, pg);
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nb, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 2);
     const long n4 = M * C / 4;
     const bool fixed = 256 % (C / 4) == 0;
     if (act == VIAI_ACT_RELU) {
