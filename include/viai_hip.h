@@ -489,6 +489,12 @@ int viai_bn_act_bwd_p16(const float* dz, const float* y, const float* mean, cons
                         const float* scale, const float* shift, float* part, float* sums,
                         float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
                         int training, float* amax, void* stream);
+/* (ABI 15) the same with the fp32 tensor written beside the planes (dy32: M x C floats, the values of viai_bn_act_bwd_amax): for a layer
+ * whose data-gradient kernel takes fp32 while its weight-gradient kernel takes planes */
+int viai_bn_act_bwd_p16_twin(const float* dz, const float* y, const float* mean, const float* invstd,
+                             const float* scale, const float* shift, float* part, float* sums,
+                             float* dgamma, float* dbeta, float* dy, float* dy32, long M, int C, int act, float slope,
+                             int training, float* amax, void* stream);
 /* x (fp32) = the values a P16 tensor holds, (lead + rem) / S(*amax) */
 int viai_p16_decode(const float* p16, float* x, long M, int C, const float* amax, void* stream);
 /* viai_conv2d_fwd_amax / viai_conv2d_dgrad_f16 with the gathered tensor pre-split (one source; scale from *x_amax / *dy_amax) */

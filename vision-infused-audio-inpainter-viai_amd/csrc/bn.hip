@@ -631,7 +631,9 @@ __global__ __launch_bounds__(1024) void bn_add_act_twin_kernel(const f32x4* __re
 template <bool FIXED>
 __global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ y, const float* __restrict__ mean,
                                                                const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ sums,
-                                                               u32x4* __restrict__ dy, long n8, int C, int act, float slope, float* __restrict__ amax) {
+                                                               u32x4* __restrict__ dy, long n8, int C, int act, float slope, float* __restrict__ amax,
+                                                               f32x4* __restrict__ dy32 = nullptr) {
+    // dy32 (viai_bn_act_bwd_p16_twin): the fp32 values as well, for a data-gradient kernel without a P16 loader beside a weight-gradient kernel with one
     float b = 0.f;
     for (int c = threadIdx.x; c < C; c += 256) b = fmaxf(b, sums[2 * C + c]);
     const float bound = block_max_all(b);
@@ -668,6 +670,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const f32x4* __re
         p16_split8(r[0], r[1], S, L, hi, lo);
         u32x4* dst = dy + pix * (C / 4) + (o >> 2) * 8 + (o & 3);
         dst[0] = hi; dst[4] = lo;
+        if (dy32 != nullptr) { dy32[2 * i] = r[0]; dy32[2 * i + 1] = r[1]; }
     };
     long i = blockIdx.x * 256L + threadIdx.x;
     for (; i + stride < n8; i += 2 * stride) {                            // eight independent 16-byte loads in flight per thread
@@ -926,10 +929,10 @@ extern "C" int viai_bn_act_fwd_p16(const float* y, const float* scale, const flo
 }
 
 // viai_bn_act_bwd_amax with dy pre-split; part: 3 * C * viai_bn_bwd_blocks(M, C) floats, sums: 3 * C floats
-extern "C" int viai_bn_act_bwd_p16(const float* dz, const float* y, const float* mean, const float* invstd,
+static int bn_act_bwd_p16_impl(const float* dz, const float* y, const float* mean, const float* invstd,
                                    const float* scale, const float* shift, float* part, float* sums,
                                    float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
-                                   int training, float* amax, void* stream) {
+                                   int training, float* amax, float* dy32, void* stream) {
     if (C % 32 != 0 || amax == nullptr || dy == nullptr || act == VIAI_ACT_SIGMOID) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = viai_bn_bwd_blocks(M, C);
@@ -940,11 +943,26 @@ extern "C" int viai_bn_act_bwd_p16(const float* dz, const float* y, const float*
     const int c8n = C / 8;
     if ((c8n & (c8n - 1)) == 0 && c8n <= 256)
         VIAI_LAUNCH(bn_bwd_apply_p16_kernel<true>, dim3(stream_grid(n8, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz), reinterpret_cast<const f32x4*>(y), mean, scale, shift, sums,
-                    reinterpret_cast<u32x4*>(dy), n8, C, act, slope, amax);
+                    reinterpret_cast<u32x4*>(dy), n8, C, act, slope, amax, reinterpret_cast<f32x4*>(dy32));
     else
         VIAI_LAUNCH(bn_bwd_apply_p16_kernel<false>, dim3(stream_grid(n8, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dz), reinterpret_cast<const f32x4*>(y), mean, scale, shift, sums,
-                    reinterpret_cast<u32x4*>(dy), n8, C, act, slope, amax);
+                    reinterpret_cast<u32x4*>(dy), n8, C, act, slope, amax, reinterpret_cast<f32x4*>(dy32));
     return viai_launch_status();
+}
+extern "C" int viai_bn_act_bwd_p16(const float* dz, const float* y, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, float* part, float* sums,
+                                   float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
+                                   int training, float* amax, void* stream) {
+    return bn_act_bwd_p16_impl(dz, y, mean, invstd, scale, shift, part, sums, dgamma, dbeta, dy, M, C, act, slope, training, amax, nullptr, stream);
+}
+// (ABI 15) ... and the fp32 tensor beside the planes (dy32: M x C floats, the values viai_bn_act_bwd_amax writes): a layer whose data-gradient kernel
+// has no P16 loader while its weight-gradient kernel has one (the stride-2 3 x 3 convs of ResNet-18 on 28 / 14 / 7-pixel maps, networks/ResNet.py:100-112)
+extern "C" int viai_bn_act_bwd_p16_twin(const float* dz, const float* y, const float* mean, const float* invstd,
+                                        const float* scale, const float* shift, float* part, float* sums,
+                                        float* dgamma, float* dbeta, float* dy, float* dy32, long M, int C, int act, float slope,
+                                        int training, float* amax, void* stream) {
+    if (dy32 == nullptr) return (int)hipErrorInvalidValue;
+    return bn_act_bwd_p16_impl(dz, y, mean, invstd, scale, shift, part, sums, dgamma, dbeta, dy, M, C, act, slope, training, amax, dy32, stream);
 }
 
 // fp32 view of a pre-split tensor: x[i] = (leading + remainder) / scale(*amax).  For tests and for consumers without a P16 loader.

@@ -114,6 +114,14 @@ def takes_p16(x_shape, conv):
     return ops.conv_takes_p16(tuple(x_shape), conv.weight, _pair(conv.kernel_size), _pair(conv.stride), _pair(conv.padding), tr)
 
 
+def wgrad_takes_p16(x_shape, conv):
+    """... or at least in its weight-gradient kernel (ops.conv_wgrad_takes_p16: the stride-2 3 x 3 convs of the ResNet branch)?"""
+    tr = isinstance(conv, nn.ConvTranspose2d)
+    if not isinstance(conv, (nn.Conv2d, nn.ConvTranspose2d)) or getattr(conv, "groups", 1) != 1 or _pair(conv.dilation) != (1, 1) or tr:
+        return False
+    return ops.conv_wgrad_takes_p16(tuple(x_shape), conv.weight, _pair(conv.kernel_size), _pair(conv.stride), _pair(conv.padding), tr)
+
+
 def out_shape(x_shape, conv):
     """NHWC shape of conv(x)"""
     N, H, W, _ = x_shape
@@ -154,7 +162,7 @@ def fused_layer(x, conv, bn, act, x2=None, training=True, xmask=None, residual=N
         oshape = out_shape(x.shape, conv)
         if pool is not None:
             oshape = (oshape[0], (oshape[1] + 2 * pool[2] - pool[0]) // pool[1] + 1, (oshape[2] + 2 * pool[2] - pool[0]) // pool[1] + 1, oshape[3])
-        twin = P16_TWIN and next_conv is not None and bn.training and takes_p16(oshape, next_conv)
+        twin = P16_TWIN and next_conv is not None and bn.training and (takes_p16(oshape, next_conv) or wgrad_takes_p16(oshape, next_conv))
         return ops.conv_bn_act(x, conv.weight, conv.bias, bn, kernel=_pair(conv.kernel_size), stride=_pair(conv.stride),
                                padding=_pair(conv.padding), transposed=transposed, act=act, x2=x2, training=bn.training, xmask=xmask,
                                residual=residual, pool=pool, out_p16=twin)

@@ -87,6 +87,20 @@ def conv_takes_p16(x_shape, weight, kernel, stride, padding, transposed):
     return (p16_mask(d) & (P16_OK_FWD_X | P16_OK_WGRAD_X)) == (P16_OK_FWD_X | P16_OK_WGRAD_X)
 
 
+def conv_wgrad_takes_p16(x_shape, weight, kernel, stride, padding, transposed):
+    """... or at least in its weight-gradient kernel?  (a residual join then still writes the twin: the forward of such a layer reads the fp32 tensor)"""
+    if not (P16 and F16_BACKWARD):
+        return False
+    N, IH, IW, C1 = x_shape
+    Cout = weight.shape[1] if transposed else weight.shape[0]
+    if C1 % 32 != 0:
+        return False
+    d = conv_desc(N, IH, IW, C1, 0, Cout, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], 1 if transposed else 0)
+    if d.get("wgrad_f16") is None:
+        d["wgrad_f16"] = bool(_lib.load().viai_conv2d_wgrad_f16_ok(d["ref"]))
+    return bool(p16_mask(d) & P16_OK_WGRAD_X) and d["wgrad_f16"]
+
+
 # Gradient-ready hooks (set by model.AudioModel for the data-parallel exchange): {weight.data_ptr(): callable}.  The callable runs
 # right after the backward of the layer owning that weight has queued its LAST gradient launch (weight gradient on WGRAD_STREAM,
 # BatchNorm gamma / beta gradients on the current stream), i.e. every parameter gradient of that layer and of all layers behind it
@@ -461,7 +475,7 @@ def _wgrad_call(lib, d, x, x2, dy, ws, dw, db, acc, amax, xa, flags, handle):
                    "viai_conv2d_wgrad")
 
 
-def _conv_grads(lib, d, cfg, dims, has_bn, has_bias, needs, xa, x, x2, weight, dy, amax, st, dy_p16=False, x_p16=False):
+def _conv_grads(lib, d, cfg, dims, has_bn, has_bias, needs, xa, x, x2, weight, dy, amax, st, dy_p16=False, x_p16=False, dy_w=None):
     """weight / bias / data gradients of one conv layer from dy (the gradient of its output): the tail every fused layer's backward
     shares.  needs = (need_x, need_x2, need_w, need_b); returns (dx, dx2, dw, db) with None where the gradient went into the arena."""
     N, IH, IW, C1, C2, Cout, OH, OW = dims
@@ -473,7 +487,9 @@ def _conv_grads(lib, d, cfg, dims, has_bn, has_bias, needs, xa, x, x2, weight, d
     if need_w and x_p16 and not (p16_mask(d) & P16_OK_WGRAD_X and (amax is not None and d.get("wgrad_f16"))):
         x = _p16_decode(x, xa)                 # (a layer whose weight gradient cannot stage pieces: not reached by the networks of this package)
         x_p16 = False
-    flags = (1 if dy_p16 else 0) | (2 if x_p16 else 0)
+    # dy_w: dy once more as planes, for the weight gradient only (the data gradient below reads the fp32 `dy`)
+    dyw = dy_w if dy_w is not None else dy
+    flags = (1 if (dy_p16 or dy_w is not None) else 0) | (2 if x_p16 else 0)
     if need_w or (need_b and has_bias):
         ws = None
         shadowed = has_bn and cfg["training"]     # bias in front of train-mode BN: gradient is exactly 0
@@ -496,11 +512,11 @@ def _conv_grads(lib, d, cfg, dims, has_bn, has_bias, needs, xa, x, x2, weight, d
             # (no `with torch.cuda.stream(...)` here: the launch takes the stream handle explicitly, and entering / leaving the
             # context costs ~25 us of host time per layer)
             ws = _scratch("wgrad", d["ws_floats"], dev, WGRAD_STREAM)
-            _wgrad_call(lib, d, x, x2, dy, ws, dw, db.data_ptr() if want_db else 0, 1, amax, xa, flags, WGRAD_STREAM.cuda_stream)
-            _deferred.append((x, x2, dy, weight, amax, xa))
+            _wgrad_call(lib, d, x, x2, dyw, ws, dw, db.data_ptr() if want_db else 0, 1, amax, xa, flags, WGRAD_STREAM.cuda_stream)
+            _deferred.append((x, x2, dyw, weight, amax, xa))
         elif acc_w == acc_b or not want_db:
             ws = _scratch("wgrad", d["ws_floats"], dev)
-            _wgrad_call(lib, d, x, x2, dy, ws, dw, db.data_ptr() if want_db else 0, 1 if acc_w else 0, amax, xa, flags, st)
+            _wgrad_call(lib, d, x, x2, dyw, ws, dw, db.data_ptr() if want_db else 0, 1 if acc_w else 0, amax, xa, flags, st)
         else:   # mixed modes (only outside AudioModel): two calls keep the accumulate flag consistent
             if flags:
                 raise RuntimeError("pre-split operands with a mixed accumulate / overwrite bias gradient")
@@ -577,8 +593,13 @@ class _ConvBnAct(torch.autograd.Function):
             f16f = d["fwd_f16"] = bool(lib.viai_conv2d_fwd_f16_ok(d["ref"]))
         twin = cfg.pop("x_twin", None)          # a pre-split copy of x beside the fp32 tensor (the residual join of a ResNet block writes both)
         # (both consumers of x must stage pieces: otherwise the weight gradient would decode the twin -- coarser scale -- although the exact fp32 x is at hand)
+        ctx.x_twin_w = None
         if twin is not None and not xp and x2 is None and P16 and (p16_mask(d) & P16_OK_FWD_X) and (p16_mask(d) & P16_OK_WGRAD_X) and F16_BACKWARD:
             x, xp = twin, True                  # the kernels read the planes; the gradient still goes to the fp32 tensor this op was applied to
+        elif twin is not None and not xp and x2 is None and P16 and (p16_mask(d) & P16_OK_WGRAD_X) and F16_BACKWARD and ctx.needs_input_grad[2]:
+            # only the weight-gradient kernel stages pieces (the stride-2 3 x 3 convs of ResNet-18 on 28 / 14 / 7-pixel maps: their forward runs on the
+            # gather kernel): the forward reads the fp32 tensor, the weight gradient the planes -- it splits nothing (1143 -> ~650 us per launch)
+            ctx.x_twin_w = twin
         if xp and (x2 is not None or (p16_mask(d) & P16_OK_FWD_X) == 0):
             x = p16_decode(x)                   # (a layer without a P16 loader: the networks of this package ask conv_takes_p16 first)
             xp = False
@@ -739,6 +760,7 @@ class _ConvBnAct(torch.autograd.Function):
         dgamma = dbeta = None
         amax = None
         dy_p16 = False
+        dy_w = None                                    # dy as planes for the weight gradient only (see dy_tw below)
         if ctx.fused1:
             return _ConvBnAct._backward_cin1(ctx, lib, dz, x, weight, coef, st)
         dres = None
@@ -787,7 +809,18 @@ class _ConvBnAct(torch.autograd.Function):
             dy_p16 = (P16 and amax is not None and Cout % 32 == 0 and act != ACT_SIGMOID and ctx.tail in (None, "up", "res")
                       and (need_x or need_w) and (not need_x or (f16d and pm & P16_OK_DGRAD_DY)) and (not need_w or (f16w and pm & P16_OK_WGRAD_DY))
                       and not (need_b and ctx.has_bias and not cfg["training"]))
-            if dy_p16:
+            # ... and where only the weight gradient does (its data-gradient kernel reads fp32): both forms in one apply pass
+            dy_tw = (not dy_p16 and P16 and amax is not None and Cout % 32 == 0 and act != ACT_SIGMOID and ctx.tail in (None, "up", "res")
+                     and need_x and need_w and f16w and bool(pm & P16_OK_WGRAD_DY) and not (need_b and ctx.has_bias and not cfg["training"]))
+            if dy_tw:
+                part = _scratch("bnpart", 3 * Cout * nblk, dev)
+                sums = _scratch("bnsums", 3 * Cout, dev)
+                dy_w = torch.empty_like(dz)
+                _lib.check(lib.viai_bn_act_bwd_p16_twin(dz.data_ptr(), y_or_z.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                                        coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
+                                                        _ptr(pg), _ptr(pb), dy_w.data_ptr(), dy.data_ptr(), M, Cout, act, 0.2,
+                                                        (1 if cfg["training"] else 0) | (2 if acc_bn else 0), amax.data_ptr(), st), "viai_bn_act_bwd_p16_twin")
+            elif dy_p16:
                 part = _scratch("bnpart", 3 * Cout * nblk, dev)
                 sums = _scratch("bnsums", 3 * Cout, dev)
                 _lib.check(lib.viai_bn_act_bwd_p16(dz.data_ptr(), y_or_z.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
@@ -812,8 +845,11 @@ class _ConvBnAct(torch.autograd.Function):
             dy = torch.empty_like(dz)
             _lib.check(lib.viai_act_bwd_from_output(dz.data_ptr(), y_or_z.data_ptr(), dy.data_ptr(), dz.numel(), act,
                                                     0.2, st), "viai_act_bwd_from_output")
-        dx, dx2, dw, db = _conv_grads(lib, d, cfg, ctx.dims, ctx.has_bn, ctx.has_bias, (need_x, need_x2, need_w, need_b), ctx.xa,
-                                      x, x2, weight, dy, amax, st, dy_p16=dy_p16, x_p16=ctx.x_p16)
+        xw, xwa, xwp = x, ctx.xa, ctx.x_p16
+        if ctx.x_twin_w is not None and need_w:
+            xw, xwa, xwp = ctx.x_twin_w, amax_of(ctx.x_twin_w), True          # planes for the weight gradient (the forward read the fp32 tensor)
+        dx, dx2, dw, db = _conv_grads(lib, d, cfg, ctx.dims, ctx.has_bn, ctx.has_bias, (need_x, need_x2, need_w, need_b), xwa,
+                                      xw, x2, weight, dy, amax, st, dy_p16=dy_p16, x_p16=xwp, dy_w=dy_w)
         return dx, dx2, dw, db, dgamma, dbeta, None, None, None, dres, None
 
 
