@@ -495,6 +495,12 @@ int viai_bn_act_bwd_p16_twin(const float* dz, const float* y, const float* mean,
                              const float* scale, const float* shift, float* part, float* sums,
                              float* dgamma, float* dbeta, float* dy, float* dy32, long M, int C, int act, float slope,
                              int training, float* amax, void* stream);
+/* (ABI 15) the BatchNorm backward behind a residual join with a ReLU (networks/ResNet.py:46-53): the gradient of the join's output arrives as
+ * dz (+ dz2, may be NULL); dres = (dz + dz2) * [zj > 0] is written (M x C floats: the residual branch's gradient) and stands in for dz in
+ * viai_bn_act_bwd_p16 with act = none -- the same values as viai_add_act_bwd_from_output + viai_bn_act_bwd_p16, one pass over memory fewer */
+int viai_bn_join_bwd_p16(const float* dz, const float* dz2, const float* zj, float* dres, const float* y, const float* mean, const float* invstd,
+                         const float* scale, const float* shift, float* part, float* sums, float* dgamma, float* dbeta, float* dy,
+                         long M, int C, int training, float* amax, void* stream);
 /* x (fp32) = the values a P16 tensor holds, (lead + rem) / S(*amax) */
 int viai_p16_decode(const float* p16, float* x, long M, int C, const float* amax, void* stream);
 /* viai_conv2d_fwd_amax / viai_conv2d_dgrad_f16 with the gathered tensor pre-split (one source; scale from *x_amax / *dy_amax) */

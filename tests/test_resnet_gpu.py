@@ -252,43 +252,58 @@ def test_batchnorm_tail_fusions_equal_the_separate_passes(what, monkeypatch):
 
 def test_two_reader_gradients_reach_the_join_as_addends_and_sum_to_the_same_bits(monkeypatch):
     """three BasicBlocks behind a conv + BatchNorm layer (networks/ResNet.py:26-55; the second block with a stride-2 downsample): with ops.LAZY_SUM the
-    gradient of every block input reaches its producer as two addends (ops.fork2) and is summed inside the producer's backward -- the fused
-    add + ReLU-mask pass at a join, a plain add elsewhere.  The sum is the same single fp32 addition: every gradient is bit for bit the one of the
-    run in which the autograd engine adds, and the fused pass is really taken."""
+    gradient of every block input reaches its producer as two addends (ops.fork2) and is summed inside the producer's backward -- at a join in the pass
+    that applies the ReLU mask (ops.JOIN_FUSED: inside the BatchNorm backward's reduce pass, viai_bn_join_bwd_p16; otherwise viai_add_act_bwd_from_output),
+    a plain add elsewhere.  The sum is the same single fp32 addition and the reduce pass sums in the same order: every gradient is bit for bit the one of
+    the run in which the autograd engine adds and the join's mask is a pass of its own, and the fused passes are really taken."""
     from viai_amd import _lib, networks, ops
     torch.manual_seed(11)
     stem = torch.nn.Conv2d(32, 64, 3, 1, 1, bias=False).cuda()
     stem_bn = torch.nn.BatchNorm2d(64).cuda()
     ds = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, 2, bias=False), torch.nn.BatchNorm2d(128)).cuda()
     blocks = [networks.BasicBlock(64, 64).cuda(), networks.BasicBlock(64, 128, stride=2, downsample=ds).cuda(), networks.BasicBlock(128, 128).cuda()]
-    x = torch.randn(4, 28, 28, 32, device="cuda")
-    g = torch.randn(4, 14, 14, 128, device="cuda")
+    x = torch.randn(32, 28, 28, 32, device="cuda")          # (enough 8 x 16 tiles for every layer's patch weight gradient: dy is then written as planes)
+    g = torch.randn(32, 14, 14, 128, device="cuda")
     lib = _lib.load()
-    calls = []
-    real = lib.viai_add_act_bwd_from_output
+    calls = {"add_act": 0, "join": 0, "join2": 0}
+    real_a, real_j = lib.viai_add_act_bwd_from_output, lib.viai_bn_join_bwd_p16
 
-    def spy(*a):
-        calls.append(1)
-        return real(*a)
+    def spy_a(*a):
+        calls["add_act"] += 1
+        return real_a(*a)
 
-    def run(lazy):
+    def spy_j(*a):
+        calls["join"] += 1
+        calls["join2"] += 1 if a[1] else 0
+        return real_j(*a)
+
+    monkeypatch.setattr(lib, "viai_add_act_bwd_from_output", spy_a, raising=False)
+    monkeypatch.setattr(lib, "viai_bn_join_bwd_p16", spy_j, raising=False)
+
+    def run(lazy, fused):
         monkeypatch.setattr(ops, "LAZY_SUM", lazy)
+        monkeypatch.setattr(ops, "JOIN_FUSED", fused)
+        for k in calls:
+            calls[k] = 0
         for m in [stem, stem_bn] + blocks:
             m.zero_grad(set_to_none=True)
         xi = x.clone().requires_grad_(True)
         ops.begin_step(xi.device)
-        h = networks.fused_layer(xi, stem, stem_bn, networks.ACT_RELU, next_conv=blocks[0].conv1)
+        h = networks.fused_layer(xi, stem, stem_bn, networks.ACT_RELU)          # (two readers behind it: a plain fp32 output, no `next_conv`)
         for i, b in enumerate(blocks):
             h = b.forward_nhwc(h, next_conv=blocks[i + 1].conv1 if i + 1 < len(blocks) else None)
         h.backward(g)
         torch.cuda.synchronize()
-        return h.detach().clone(), xi.grad.clone(), [p.grad.clone() for m in [stem, stem_bn] + blocks for p in m.parameters()]
+        return dict(calls), [h.detach().clone(), xi.grad.clone()] + [p.grad.clone() for m in [stem, stem_bn] + blocks for p in m.parameters()]
 
-    o0, dx0, g0 = run(False)
-    monkeypatch.setattr(lib, "viai_add_act_bwd_from_output", spy, raising=False)
-    n0 = len(calls)
-    o1, dx1, g1 = run(True)
-    assert len(calls) - n0 == 2                            # the joins of blocks 0 and 1 (block 2's output has one reader; the stem layer has no join: plain add)
-    assert torch.equal(o0, o1) and torch.equal(dx0, dx1)
-    for a, b in zip(g0, g1):
-        assert torch.equal(a, b)
+    c0, r0 = run(False, False)
+    assert c0 == {"add_act": 0, "join": 0, "join2": 0}
+    c1, r1 = run(True, False)
+    assert c1["add_act"] == 2 and c1["join"] == 0          # the joins of blocks 0 and 1 (block 2's output has one reader; the stem layer has no join: plain add)
+    c2, r2 = run(True, True)
+    assert c2["add_act"] == 0 and c2["join"] == 3 * ops.P16 and c2["join2"] == 2 * ops.P16
+    c3, r3 = run(False, True)
+    assert c3["join"] == 3 * ops.P16 and c3["join2"] == 0
+    for r in (r1, r2, r3):
+        for a, b in zip(r0, r):
+            assert torch.equal(a, b)

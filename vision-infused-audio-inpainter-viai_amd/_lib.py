@@ -183,6 +183,7 @@ SIGNATURES = {
     "viai_conv2d_cin1_bn_fwd_p16": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P, _P]),
     "viai_pair_cout1_bn_bwd_p16": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "viai_bn_act_bwd_p16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P, _P]),
+    "viai_bn_join_bwd_p16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "viai_bn_act_bwd_p16_twin": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P, _P]),
     "viai_p16_decode": (_I, [_P, _P, _L, _I, _P, _P]),
     "viai_conv2d_fwd_p16": (_I, [_CP, _P, _P, _P, _P, _P, _I, _P, _P]),

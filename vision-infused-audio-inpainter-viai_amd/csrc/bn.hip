@@ -253,11 +253,16 @@ struct PoolPos {
 
 // partial sums over a row range: part[blk][0][c] = sum dpre, part[blk][1][c] = sum dpre * xhat
 // MAXDP: a third partial per channel, max |dpre| over the block's rows (part[blk][2][c]): what the pre-split (P16) apply pass bounds |dy| with
-template <bool POOL = false, bool MAXDP = false>
+// JOIN (round 5): the BatchNorm in front of a residual join (networks/ResNet.py:46-53).  The gradient of the join's output arrives as one or two addends
+// (dz, dz2 or null: ops.fork2) and goes through the join's ReLU (mask from its saved output zj) before it reaches this BatchNorm, whose own activation is
+// none: the masked sum is formed on load, written out once (dres: it is also the residual branch's gradient, and the apply pass reads it) and reduced in
+// the same pass -- the elementwise pass that made it and the re-read of it are gone.
+template <bool POOL = false, bool MAXDP = false, bool JOIN = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dz, const float* __restrict__ y, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
-    float* __restrict__ part, long M, int C, long rows_per_blk, int act, float slope, const PoolGather pg_ = PoolGather{}) {
+    float* __restrict__ part, long M, int C, long rows_per_blk, int act, float slope, const PoolGather pg_ = PoolGather{},
+    const float* __restrict__ dz2 = nullptr, const float* __restrict__ zj = nullptr, float* __restrict__ dres = nullptr) {
     __shared__ f32x4 r1[256], r2[256];
     __shared__ f32x4 r3[MAXDP ? 256 : 1];
     constexpr int PS = MAXDP ? 3 : 2;
@@ -287,6 +292,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                     if constexpr (POOL) { g[u] = ok ? pool_dz(pg_, pp.n, pp.iy, pp.ix, c, C) : f32x4{0.f, 0.f, 0.f, 0.f}; pp.step(pg_, sn, sy, sx); }
                     else g[u] = ok ? *reinterpret_cast<const f32x4*>(dz + rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
                     v[u] = ok ? *reinterpret_cast<const f32x4*>(y + rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (JOIN) {
+                        if (ok) {
+                            const f32x4 zz = *reinterpret_cast<const f32x4*>(zj + rr * C + c);
+                            if (dz2 != nullptr) g[u] += *reinterpret_cast<const f32x4*>(dz2 + rr * C + c);      // the same single fp32 addition autograd would have made
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) g[u][e] = g[u][e] * (zz[e] > 0.f ? 1.f : 0.f);           // act_bwd_out_kernel's product, ReLU
+                            *reinterpret_cast<f32x4*>(dres + rr * C + c) = g[u];
+                        }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -823,7 +837,7 @@ extern "C" int viai_bn_act_bwd_amax(const float* dz, const float* y, const float
     hipStream_t st = (hipStream_t)stream;
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
-    VIAI_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, PoolGather{});
+    VIAI_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, PoolGather{}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 2);
     if (dy != nullptr) {
         long n4 = M * C / 4;
@@ -854,7 +868,7 @@ extern "C" int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char
         const long rpp = (MP + nb - 1) / nb;
         VIAI_LAUNCH(bn_pool_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, y, mean, invstd, scale, shift, part, MP, C, rpp, act, slope, pg);
     } else
-        VIAI_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, (const float*)nullptr, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, pg);
+        VIAI_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, (const float*)nullptr, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, pg, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nb, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 2);
     const long n4 = M * C / 4;
     const bool fixed = 256 % (C / 4) == 0;
@@ -929,6 +943,29 @@ extern "C" int viai_bn_act_fwd_p16(const float* y, const float* scale, const flo
 }
 
 // viai_bn_act_bwd_amax with dy pre-split; part: 3 * C * viai_bn_bwd_blocks(M, C) floats, sums: 3 * C floats
+// (ABI 15) BatchNorm backward behind a residual join with a ReLU: dres = (dz + dz2) * [zj > 0] (dz2 may be NULL) is written and takes dz's place in
+// viai_bn_act_bwd_p16 with no activation of the BatchNorm's own -- bit for bit viai_add_act_bwd_from_output followed by viai_bn_act_bwd_p16
+extern "C" int viai_bn_join_bwd_p16(const float* dz, const float* dz2, const float* zj, float* dres, const float* y, const float* mean, const float* invstd,
+                                    const float* scale, const float* shift, float* part, float* sums, float* dgamma, float* dbeta, float* dy,
+                                    long M, int C, int training, float* amax, void* stream) {
+    if (C % 32 != 0 || amax == nullptr || dy == nullptr || dres == nullptr || zj == nullptr) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = viai_bn_bwd_blocks(M, C);
+    const long rpb = (M + nblk - 1) / nblk;
+    VIAI_LAUNCH((bn_bwd_reduce_kernel<false, true, true>), dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, VIAI_ACT_NONE, 0.f, PoolGather{},
+                dz2, zj, dres);
+    VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 3);
+    const long n8 = M * C / 8;
+    const int c8n = C / 8;
+    if ((c8n & (c8n - 1)) == 0 && c8n <= 256)
+        VIAI_LAUNCH(bn_bwd_apply_p16_kernel<true>, dim3(stream_grid(n8, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dres), reinterpret_cast<const f32x4*>(y), mean, scale, shift, sums,
+                    reinterpret_cast<u32x4*>(dy), n8, C, VIAI_ACT_NONE, 0.f, amax, (f32x4*)nullptr);
+    else
+        VIAI_LAUNCH(bn_bwd_apply_p16_kernel<false>, dim3(stream_grid(n8, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dres), reinterpret_cast<const f32x4*>(y), mean, scale, shift, sums,
+                    reinterpret_cast<u32x4*>(dy), n8, C, VIAI_ACT_NONE, 0.f, amax, (f32x4*)nullptr);
+    return viai_launch_status();
+}
+
 static int bn_act_bwd_p16_impl(const float* dz, const float* y, const float* mean, const float* invstd,
                                    const float* scale, const float* shift, float* part, float* sums,
                                    float* dgamma, float* dbeta, float* dy, long M, int C, int act, float slope,
@@ -937,7 +974,7 @@ static int bn_act_bwd_p16_impl(const float* dz, const float* y, const float* mea
     hipStream_t st = (hipStream_t)stream;
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
-    VIAI_LAUNCH((bn_bwd_reduce_kernel<false, true>), dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, PoolGather{});
+    VIAI_LAUNCH((bn_bwd_reduce_kernel<false, true>), dim3(nblk), dim3(256), 0, st, dz, y, mean, invstd, scale, shift, part, M, C, rpb, act, slope, PoolGather{}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nblk, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 3);
     const long n8 = M * C / 8;
     const int c8n = C / 8;

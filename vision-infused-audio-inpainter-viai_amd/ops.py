@@ -769,7 +769,23 @@ class _ConvBnAct(torch.autograd.Function):
             dlo = torch.empty((N, OH, OW, Cout), device=dev, dtype=torch.float32)
             _lib.check(lib.viai_bilinear_ac_bwd(dz.data_ptr(), dlo.data_ptr(), N, OH, OW, UH, UW, Cout, st), "viai_bilinear_ac_bwd")
             dz = dlo
-        if ctx.tail == "res":
+        join = None                                    # (dz, addend, saved join output): the masked sum is made inside the BatchNorm backward's reduce pass
+        if ctx.tail == "res" and act == ACT_RELU and JOIN_FUSED and ctx.has_bn and P16 and F16_BACKWARD and Cout % 32 == 0 and (need_x or need_w):
+            pm_ = p16_mask(d)
+            f16d_ = d.get("dgrad_f16")
+            if f16d_ is None:
+                f16d_ = d["dgrad_f16"] = bool(lib.viai_conv2d_dgrad_f16_ok(d["ref"]))
+            f16w_ = d.get("wgrad_f16")
+            if f16w_ is None:
+                f16w_ = d["wgrad_f16"] = bool(lib.viai_conv2d_wgrad_f16_ok(d["ref"]))
+            # (exactly the layers whose dy the plain path below would write as planes: same condition)
+            if ((f16d_ and need_x) or (f16w_ and need_w)) and (not need_x or (f16d_ and pm_ & P16_OK_DGRAD_DY)) and (not need_w or (f16w_ and pm_ & P16_OK_WGRAD_DY)) \
+                    and not (need_b and ctx.has_bias and not cfg["training"]):
+                join = (dz, addend, ctx.saved_tensors[5])
+                dres = torch.empty_like(dz)
+                dz = dres
+                act = ACT_NONE
+        if ctx.tail == "res" and join is None:
             # d/d(sum) through the activation (mask from the saved output); the same tensor is the residual branch's gradient
             if act != ACT_NONE:
                 dres = torch.empty_like(dz)
@@ -820,6 +836,15 @@ class _ConvBnAct(torch.autograd.Function):
                                                         coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
                                                         _ptr(pg), _ptr(pb), dy_w.data_ptr(), dy.data_ptr(), M, Cout, act, 0.2,
                                                         (1 if cfg["training"] else 0) | (2 if acc_bn else 0), amax.data_ptr(), st), "viai_bn_act_bwd_p16_twin")
+            elif join is not None:
+                if not dy_p16:
+                    raise RuntimeError("conv_bn_act backward: the fused join pass was chosen for a layer whose dy is not written as planes")
+                part = _scratch("bnpart", 3 * Cout * nblk, dev)
+                sums = _scratch("bnsums", 3 * Cout, dev)
+                _lib.check(lib.viai_bn_join_bwd_p16(join[0].data_ptr(), _ptr(join[1]), join[2].data_ptr(), dres.data_ptr(), y_or_z.data_ptr(),
+                                                    coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
+                                                    _ptr(pg), _ptr(pb), dy.data_ptr(), M, Cout, (1 if cfg["training"] else 0) | (2 if acc_bn else 0), amax.data_ptr(), st),
+                           "viai_bn_join_bwd_p16")
             elif dy_p16:
                 part = _scratch("bnpart", 3 * Cout * nblk, dev)
                 sums = _scratch("bnsums", 3 * Cout, dev)
@@ -1450,6 +1475,7 @@ def avgpool_hw(x):
     return inherit_amax(_AvgPoolHW.apply(x), x)
 
 
+JOIN_FUSED = True    # a residual join's masked gradient sum is made inside the BatchNorm backward's reduce pass (viai_bn_join_bwd_p16; module switch: tests flip it)
 LAZY_SUM = True      # gradients of a tensor with two readers reach its producer as two addends (fork2; module switch: tests/test_resnet_gpu.py flips it)
 
 
