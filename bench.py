@@ -888,6 +888,19 @@ def main():
                             "forward / data gradient): 2*FETCH_SIZE + WRITE_SIZE from profiles/%s (tools/profile_layer.py under rocprofv3 --pmc); these L2 memory-side "
                             "counters include Infinity-Cache hits, i.e. they are L2-miss traffic, an upper bound on HBM bytes") % os.path.basename(pmc)
                         break
+        # the vision-infused step: the dominant family's kernel on the ResNet stage it spends most time in (layer1 for the 64-channel instances, layer2 otherwise)
+        pmcs_av = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_resnet_layer2.json")))
+        if BF3 and av and pmcs_av:
+            want = PMC_KERNEL_OF.get(dom)
+            if want:
+                for k, v in json.load(open(pmcs_av[-1])).items():
+                    if want in k and "hbm_bytes" in v:
+                        out["roofline"]["traffic"] = round(v["hbm_bytes"])
+                        out["roofline"]["traffic_note"] = (
+                            "bytes per launch of this kernel on ResNet layer2's 3x3 conv (1024 frames x 28 x 28 x 128 -> 128; algorithmic: in 411 MB + out 411 MB + weights 0.6 MB "
+                            "for forward / data gradient, x 411 MB + dy 411 MB + dw 0.6 MB x slabs for the weight gradient): 2*FETCH_SIZE + WRITE_SIZE from profiles/%s "
+                            "(tools/profile_layer.py under rocprofv3 --pmc); L2-miss traffic, an upper bound on HBM bytes") % os.path.basename(pmcs_av[-1])
+                        break
         steps_pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step.json")))
         if BF3 and steps_pmc and not av:
             ps = json.load(open(steps_pmc[-1]))
