@@ -229,6 +229,11 @@ int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char* idx, int 
                               const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
                               float* part, float* sums, float* dgamma, float* dbeta, float* dy, int C, int act, float slope,
                               int training, float* amax, void* stream);
+/* (ABI 15) the pooled gradient as two addends, summed where it is loaded (dpool2 may be NULL) */
+int viai_bn_act_pool_bwd_amax2(const float* dpool, const float* dpool2, const unsigned char* idx, int N, int IH, int IW, int k, int s, int p,
+                               const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
+                               float* part, float* sums, float* dgamma, float* dbeta, float* dy, int C, int act, float slope,
+                               int training, float* amax, void* stream);
 int viai_relu_bwd(const float* g, const float* out, float* d, long n, void* stream);
 
 /* ----------------------------------------------------------------------- losses

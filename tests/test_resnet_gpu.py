@@ -307,3 +307,44 @@ def test_two_reader_gradients_reach_the_join_as_addends_and_sum_to_the_same_bits
     for r in (r1, r2, r3):
         for a, b in zip(r0, r):
             assert torch.equal(a, b)
+
+
+def test_the_stem_pool_backward_takes_its_gradient_as_two_addends(monkeypatch):
+    """conv7x7 s2 -> bn -> relu -> maxpool -> BasicBlock (networks/Image_Embedding.py:20-23, ResNet.py:26-55): the pooled map has two readers, so with
+    ops.LAZY_SUM its gradient reaches the stem's backward as two addends and viai_bn_act_pool_bwd_amax2 sums them where it loads the pooled gradient --
+    bit for bit the run in which autograd adds them first."""
+    from viai_amd import _lib, networks, ops
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda()
+    bn = torch.nn.BatchNorm2d(64).cuda()
+    blk = networks.BasicBlock(64, 64).cuda()
+    frames = torch.randn(8, 3, 64, 96, device="cuda")
+    g = torch.randn(8, 16, 24, 64, device="cuda")
+    lib = _lib.load()
+    seen = []
+    real = lib.viai_bn_act_pool_bwd_amax2
+
+    def spy(*a):
+        seen.append(bool(a[1]))
+        return real(*a)
+
+    monkeypatch.setattr(lib, "viai_bn_act_pool_bwd_amax2", spy, raising=False)
+
+    monkeypatch.setattr(ops, "POOL_ADDENDS", True)             # (off by default: gathering two tensors in the apply pass costs more than the add)
+
+    def run(lazy):
+        monkeypatch.setattr(ops, "LAZY_SUM", lazy)
+        for m in (conv, bn, blk):
+            m.zero_grad(set_to_none=True)
+        ops.begin_step(frames.device)
+        h = networks.fused_layer(ops.frames_to_nhwc4(frames), conv, bn, networks.ACT_RELU, pool=(3, 2, 1), next_conv=blk.conv1)
+        out = blk.forward_nhwc(h)
+        out.backward(g)
+        torch.cuda.synchronize()
+        return [out.detach().clone()] + [p.grad.clone() for m in (conv, bn, blk) for p in m.parameters()]
+
+    r0 = run(False)
+    r1 = run(True)
+    assert seen == [False, True]
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)

@@ -122,6 +122,7 @@ SIGNATURES = {
     "viai_bn_add_act_fwd_amax": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P]),
     "viai_bn_act_maxpool_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "viai_bn_act_pool_bwd_amax": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P]),
+    "viai_bn_act_pool_bwd_amax2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P]),
     "viai_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
     "viai_reduce_blocks": (_I, [_L]),
     "viai_bce_fwd": (_I, [_P, _F, _L, _P, _P, _P]),

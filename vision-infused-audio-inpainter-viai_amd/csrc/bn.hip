@@ -194,6 +194,7 @@ __device__ __forceinline__ float act_grad(float pre, int act, float slope) {
 // backward loads it -- the 3.3 GB tensor per 1024 frames is neither written nor read back twice.
 struct PoolGather {
     const float* dpool; const unsigned char* idx;
+    const float* dpool2;          // second addend of the pooled gradient, or null (ops.fork2: the gradient of the stem's output reaches it as two addends)
     int IH, IW, OH, OW, k, st, pd;
 };
 // pixel (n, iy, ix) of the un-pooled map, channels c .. c + 3.  The kernels below walk the pixels with a constant stride and keep the
@@ -219,6 +220,7 @@ __device__ __forceinline__ f32x4 pool_dz(const PoolGather& p, int n, int iy, int
                 const size_t o = (((size_t)n * p.OH + oyc) * p.OW + oxc) * C + c;
                 pk[a * 2 + b] = *reinterpret_cast<const unsigned*>(p.idx + o);
                 g[a * 2 + b] = *reinterpret_cast<const f32x4*>(p.dpool + o);
+                if (p.dpool2 != nullptr) g[a * 2 + b] += *reinterpret_cast<const f32x4*>(p.dpool2 + o);
             }
 #pragma unroll
         for (int w = 0; w < 4; ++w)                 // (same order as the loop below: oy outer, ox inner)
@@ -231,7 +233,8 @@ __device__ __forceinline__ f32x4 pool_dz(const PoolGather& p, int n, int iy, int
             const unsigned want = (unsigned)((iy - (oy * p.st - p.pd)) * p.k + (ix - (ox * p.st - p.pd)));
             const size_t o = (((size_t)n * p.OH + oy) * p.OW + ox) * C + c;
             const unsigned pk = *reinterpret_cast<const unsigned*>(p.idx + o);
-            const f32x4 g = *reinterpret_cast<const f32x4*>(p.dpool + o);
+            f32x4 g = *reinterpret_cast<const f32x4*>(p.dpool + o);
+            if (p.dpool2 != nullptr) g += *reinterpret_cast<const f32x4*>(p.dpool2 + o);
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (((pk >> (8 * e)) & 0xffu) == want) acc[e] += g[e];
         }
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(
                     const size_t o = ok[u] ? (size_t)(r + (long)u * pg) * C + c : (size_t)row0 * C + c;
                     pk[u] = *reinterpret_cast<const unsigned*>(p.idx + o);
                     g[u] = *reinterpret_cast<const f32x4*>(p.dpool + o);
+                    if (p.dpool2 != nullptr) g[u] += *reinterpret_cast<const f32x4*>(p.dpool2 + o);
                     // window origin (may lie in the padding: the argmax never does); a lane past the block's range reads element row0's window position of pixel 0
                     bo[u] = ok[u] ? ((n * p.IH + oy * p.st - p.pd) * p.IW + ox * p.st - p.pd) * C + c : c;
                     ox += sx; if (ox >= p.OW) { ox -= p.OW; ++oy; }
@@ -850,14 +854,14 @@ extern "C" int viai_bn_act_bwd_amax(const float* dz, const float* y, const float
 
 // The same backward where nn.MaxPool2d(k, s, p) follows the activation (ReLU or none): dpool (N, OH, OW, C) and the argmax bytes of
 // viai_bn_act_maxpool_fwd stand in for dz, which is gathered on load in both passes.  y, dy: (N, IH, IW, C).
-extern "C" int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char* idx, int N, int IH, int IW, int k, int s, int p,
+static int bn_act_pool_bwd_impl(const float* dpool, const float* dpool2, const unsigned char* idx, int N, int IH, int IW, int k, int s, int p,
                                          const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
                                          float* part, float* sums, float* dgamma, float* dbeta, float* dy, int C, int act, float slope,
                                          int training, float* amax, void* stream) {
     if (C % 4 != 0 || dy == nullptr || k * k > 255 || (act != VIAI_ACT_RELU && act != VIAI_ACT_NONE)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     const long M = (long)N * IH * IW;
-    PoolGather pg{dpool, idx, IH, IW, (IH + 2 * p - k) / s + 1, (IW + 2 * p - k) / s + 1, k, s, p};
+    PoolGather pg{dpool, idx, dpool2, IH, IW, (IH + 2 * p - k) / s + 1, (IW + 2 * p - k) / s + 1, k, s, p};
     const int nblk = viai_bn_bwd_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
     const long MP = (long)N * pg.OH * pg.OW;
@@ -878,6 +882,20 @@ extern "C" int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char
     }
     if (fixed) return launch_bn_bwd_apply_t<VIAI_ACT_NONE, true, true>(nullptr, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
     return launch_bn_bwd_apply_t<VIAI_ACT_NONE, false, true>(nullptr, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
+}
+
+extern "C" int viai_bn_act_pool_bwd_amax(const float* dpool, const unsigned char* idx, int N, int IH, int IW, int k, int s, int p,
+                                         const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                         float* part, float* sums, float* dgamma, float* dbeta, float* dy, int C, int act, float slope,
+                                         int training, float* amax, void* stream) {
+    return bn_act_pool_bwd_impl(dpool, nullptr, idx, N, IH, IW, k, s, p, y, mean, invstd, scale, shift, part, sums, dgamma, dbeta, dy, C, act, slope, training, amax, stream);
+}
+// (ABI 15) the pooled gradient as two addends (dpool + dpool2, summed where it is loaded: the one fp32 addition autograd would have made in a pass of its own)
+extern "C" int viai_bn_act_pool_bwd_amax2(const float* dpool, const float* dpool2, const unsigned char* idx, int N, int IH, int IW, int k, int s, int p,
+                                          const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                          float* part, float* sums, float* dgamma, float* dbeta, float* dy, int C, int act, float slope,
+                                          int training, float* amax, void* stream) {
+    return bn_act_pool_bwd_impl(dpool, dpool2, idx, N, IH, IW, k, s, p, y, mean, invstd, scale, shift, part, sums, dgamma, dbeta, dy, C, act, slope, training, amax, stream);
 }
 
 // the final pass alone (conv_direct.hip: the fused Cin = 1 layer produces the partials itself)

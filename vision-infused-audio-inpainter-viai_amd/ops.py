@@ -752,7 +752,9 @@ class _ConvBnAct(torch.autograd.Function):
         addend = _take_addend(dz)
         dz = _c(dz)
         act = cfg["act"]
-        if addend is not None and not (ctx.tail == "res" and act != ACT_NONE and not ctx.fused1 and dz.numel() % 4 == 0):
+        # (the pool tail could take two addends too -- viai_bn_act_pool_bwd_amax2 -- but its apply pass GATHERS the pooled gradient, up to four windows per
+        # pixel, and gathering two tensors costs more than the add it saves: 103.5 against 102.2 ms on the vision-infused step; POOL_ADDENDS keeps the path testable)
+        if addend is not None and not ((ctx.tail == "res" and act != ACT_NONE and not ctx.fused1 and dz.numel() % 4 == 0) or (POOL_ADDENDS and ctx.tail == "pool" and ctx.has_bn)):
             dz = dz + addend                              # no pass of this backward to fold the sum into
             addend = None
         need_x, need_x2, need_w, need_b, need_g, need_be = ctx.needs_input_grad[:6]
@@ -855,10 +857,11 @@ class _ConvBnAct(torch.autograd.Function):
             elif ctx.tail == "pool":
                 k_, s_, p_ = cfg["pool"]
                 dy = torch.empty_like(y_or_z)
-                _lib.check(lib.viai_bn_act_pool_bwd_amax(dz.data_ptr(), ctx.saved_tensors[5].data_ptr(), N, OH, OW, k_, s_, p_, y_or_z.data_ptr(),
+                # (the pooled gradient may have arrived as two addends -- ops.fork2: the stem's output feeds layer1's conv1 and its first join -- summed on load)
+                _lib.check(lib.viai_bn_act_pool_bwd_amax2(dz.data_ptr(), _ptr(addend), ctx.saved_tensors[5].data_ptr(), N, OH, OW, k_, s_, p_, y_or_z.data_ptr(),
                                                          coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
                                                          part.data_ptr(), sums.data_ptr(), _ptr(pg), _ptr(pb), dy.data_ptr(), Cout, act, 0.2,
-                                                         (1 if cfg["training"] else 0) | (2 if acc_bn else 0), _ptr(amax), st), "viai_bn_act_pool_bwd")
+                                                          (1 if cfg["training"] else 0) | (2 if acc_bn else 0), _ptr(amax), st), "viai_bn_act_pool_bwd")
             else:
                 _lib.check(lib.viai_bn_act_bwd_amax(dz.data_ptr(), y_or_z.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
                                                     coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), sums.data_ptr(),
@@ -1475,6 +1478,7 @@ def avgpool_hw(x):
     return inherit_amax(_AvgPoolHW.apply(x), x)
 
 
+POOL_ADDENDS = False  # the stem's pool backward sums two gradient addends on load (module switch: slower, see _ConvBnAct.backward; tests/test_resnet_gpu.py flips it)
 JOIN_FUSED = True    # a residual join's masked gradient sum is made inside the BatchNorm backward's reduce pass (viai_bn_join_bwd_p16; module switch: tests flip it)
 LAZY_SUM = True      # gradients of a tensor with two readers reach its producer as two addends (fork2; module switch: tests/test_resnet_gpu.py flips it)
 
