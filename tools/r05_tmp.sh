@@ -1,2 +1,4 @@
-timeout 900 python -m pytest tests/test_resnet_gpu.py -x -q 2>&1 | tail -4
-for i in 1 2; do python bench.py --config av --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-extra 2>/dev/null | grep '^{"metric"' | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("av ms", d["ms_per_step"], d["roofline"].get("traffic") if "roofline" in d else None)'; done
+d=/tmp/avp; rm -rf $d; mkdir -p $d gpurun_out/r05_av
+(cd /tmp && TMPDIR=/tmp VIAI_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python $GRAFT_REPO_ROOT/tools/r05_tmp2.py > $d/log.txt 2>&1)
+f=$(find $d -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/r05_av/av_serial4_kernel_stats.csv
+grep '^{"metric"' $d/log.txt | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("serial ms", d["ms_per_step"])'

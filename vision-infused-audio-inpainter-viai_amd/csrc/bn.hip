@@ -541,6 +541,68 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     if (amax != nullptr) block_absmax_to(amax, mx);
 }
 
+// The pool-fused apply pass for the stem's 3 x 3 / stride-2 / pad-1 pool on an even map, by 2 x 2 PIXEL BLOCKS (round 5).  The four pixels (2a + dy, 2b + dx)
+// lie in the windows (a, b), (a, b + 1), (a + 1, b), (a + 1, b + 1) only -- 1, 2, 2 and 4 of them -- so a thread that owns the block (and a channel quad)
+// loads those four pooled elements ONCE and hands each to the pixels it may belong to; the per-pixel kernel fetched four candidates for every pixel
+// (16 pooled loads per block instead of 4).  Same sums in the same order (windows by rows, then columns), same expression: bit-identical.
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_pool2x2_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ sums, float* __restrict__ dy,
+                                                                   long nblk4, int C, float slope, float* __restrict__ amax, const PoolGather p) {
+    const int c4n = C / 4, BW = p.IW / 2, BH = p.IH / 2;
+    float mx = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < nblk4; i += (long)gridDim.x * 256) {
+        const int cq = (int)(i % c4n); long t = i / c4n;
+        const int b = (int)(t % BW); t /= BW;
+        const int a = (int)(t % BH); const int n = (int)(t / BH);
+        const int c = cq * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(sums + c), k1 = *reinterpret_cast<const f32x4*>(sums + C + c), mu = *reinterpret_cast<const f32x4*>(mean + c);
+        // the four windows (wa, wb) = (a + r, b + s): argmax bytes and gradients (a window past the pooled map: no contribution)
+        unsigned pk[4]; f32x4 g[4]; bool ok[4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int wa = a + r, wb = b + q;
+                ok[r * 2 + q] = wa < p.OH && wb < p.OW;
+                const size_t o = (((size_t)n * p.OH + (ok[r * 2 + q] ? wa : a)) * p.OW + (ok[r * 2 + q] ? wb : b)) * C + c;
+                pk[r * 2 + q] = *reinterpret_cast<const unsigned*>(p.idx + o);
+                g[r * 2 + q] = *reinterpret_cast<const f32x4*>(p.dpool + o);
+            }
+        f32x4 v[4];
+#pragma unroll
+        for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+            for (int dx_ = 0; dx_ < 2; ++dx_) v[dy_ * 2 + dx_] = *reinterpret_cast<const f32x4*>(y + (((size_t)n * p.IH + 2 * a + dy_) * p.IW + 2 * b + dx_) * C + c);
+#pragma unroll
+        for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+            for (int dx_ = 0; dx_ < 2; ++dx_) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                // windows (a + r, b + q) that hold pixel (2a + dy_, 2b + dx_): r <= dy_, q <= dx_; its position in that window: row dy_ + 1 - 2 r, column dx_ + 1 - 2 q
+#pragma unroll
+                for (int r = 0; r <= dy_; ++r)
+#pragma unroll
+                    for (int q = 0; q <= dx_; ++q) {
+                        const unsigned want = (unsigned)((dy_ + 1 - 2 * r) * 3 + (dx_ + 1 - 2 * q));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (ok[r * 2 + q] && ((pk[r * 2 + q] >> (8 * e)) & 0xffu) == want) acc[e] += g[r * 2 + q][e];
+                    }
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float vv = v[dy_ * 2 + dx_][e];
+                    const float dp = acc[e] * act_grad(vv * sc[e] + sh[e], ACT, slope);
+                    o[e] = sc[e] * dp + (k1[e] * (vv - mu[e]) + k0[e]);
+                    mx = fmaxf(mx, fabsf(o[e]));
+                }
+                *reinterpret_cast<f32x4*>(dy + (((size_t)n * p.IH + 2 * a + dy_) * p.IW + 2 * b + dx_) * C + c) = o;
+            }
+    }
+    if (amax != nullptr) block_absmax_to(amax, mx);
+}
+
 template <int ACT, bool FIXED, bool POOL>
 int launch_bn_bwd_apply_t(const float* dz, const float* y, const float* mean, const float* scale, const float* shift, const float* sums,
                           float* dy, long n4, int C, float slope, float* amax, hipStream_t st, const PoolGather& pg) {
@@ -876,6 +938,12 @@ static int bn_act_pool_bwd_impl(const float* dpool, const float* dpool2, const u
     VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nb, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 2);
     const long n4 = M * C / 4;
     const bool fixed = 256 % (C / 4) == 0;
+    if (k == 3 && s == 2 && p == 1 && IH % 2 == 0 && IW % 2 == 0 && dpool2 == nullptr) {       // the stem's pool: by 2 x 2 pixel blocks
+        const long nb4 = n4 / 4;
+        if (act == VIAI_ACT_RELU) VIAI_LAUNCH(bn_pool2x2_bwd_apply_kernel<VIAI_ACT_RELU>, dim3(stream_grid(nb4, 256)), dim3(256), 0, st, y, mean, scale, shift, sums, dy, nb4, C, slope, amax, pg);
+        else VIAI_LAUNCH(bn_pool2x2_bwd_apply_kernel<VIAI_ACT_NONE>, dim3(stream_grid(nb4, 256)), dim3(256), 0, st, y, mean, scale, shift, sums, dy, nb4, C, slope, amax, pg);
+        return viai_launch_status();
+    }
     if (act == VIAI_ACT_RELU) {
         if (fixed) return launch_bn_bwd_apply_t<VIAI_ACT_RELU, true, true>(nullptr, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
         return launch_bn_bwd_apply_t<VIAI_ACT_RELU, false, true>(nullptr, y, mean, scale, shift, sums, dy, n4, C, slope, amax, st, pg);
