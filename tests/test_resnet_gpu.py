@@ -330,7 +330,6 @@ def test_the_stem_pool_backward_takes_its_gradient_as_two_addends(monkeypatch):
 
     monkeypatch.setattr(lib, "viai_bn_act_pool_bwd_amax2", spy, raising=False)
 
-    monkeypatch.setattr(ops, "POOL_ADDENDS", True)             # (off by default: gathering two tensors in the apply pass costs more than the add)
 
     def run(lazy):
         monkeypatch.setattr(ops, "LAZY_SUM", lazy)

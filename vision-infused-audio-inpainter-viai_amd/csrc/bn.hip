@@ -569,6 +569,7 @@ __global__ __launch_bounds__(256) void bn_pool2x2_bwd_apply_kernel(const float* 
                 const size_t o = (((size_t)n * p.OH + (ok[r * 2 + q] ? wa : a)) * p.OW + (ok[r * 2 + q] ? wb : b)) * C + c;
                 pk[r * 2 + q] = *reinterpret_cast<const unsigned*>(p.idx + o);
                 g[r * 2 + q] = *reinterpret_cast<const f32x4*>(p.dpool + o);
+                if (p.dpool2 != nullptr) g[r * 2 + q] += *reinterpret_cast<const f32x4*>(p.dpool2 + o);
             }
         f32x4 v[4];
 #pragma unroll
@@ -938,7 +939,7 @@ static int bn_act_pool_bwd_impl(const float* dpool, const float* dpool2, const u
     VIAI_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nb, C, M, mean, invstd, scale, training & 1, sums, dgamma, dbeta, (training >> 1) & 1, 2);
     const long n4 = M * C / 4;
     const bool fixed = 256 % (C / 4) == 0;
-    if (k == 3 && s == 2 && p == 1 && IH % 2 == 0 && IW % 2 == 0 && dpool2 == nullptr) {       // the stem's pool: by 2 x 2 pixel blocks
+    if (k == 3 && s == 2 && p == 1 && IH % 2 == 0 && IW % 2 == 0) {       // the stem's pool: by 2 x 2 pixel blocks
         const long nb4 = n4 / 4;
         if (act == VIAI_ACT_RELU) VIAI_LAUNCH(bn_pool2x2_bwd_apply_kernel<VIAI_ACT_RELU>, dim3(stream_grid(nb4, 256)), dim3(256), 0, st, y, mean, scale, shift, sums, dy, nb4, C, slope, amax, pg);
         else VIAI_LAUNCH(bn_pool2x2_bwd_apply_kernel<VIAI_ACT_NONE>, dim3(stream_grid(nb4, 256)), dim3(256), 0, st, y, mean, scale, shift, sums, dy, nb4, C, slope, amax, pg);

@@ -752,8 +752,9 @@ class _ConvBnAct(torch.autograd.Function):
         addend = _take_addend(dz)
         dz = _c(dz)
         act = cfg["act"]
-        # (the pool tail could take two addends too -- viai_bn_act_pool_bwd_amax2 -- but its apply pass GATHERS the pooled gradient, up to four windows per
-        # pixel, and gathering two tensors costs more than the add it saves: 103.5 against 102.2 ms on the vision-infused step; POOL_ADDENDS keeps the path testable)
+        # (the pool tail takes two addends as well -- viai_bn_act_pool_bwd_amax2.  With the per-pixel apply pass, which gathered up to four windows per pixel,
+        # two tensors to gather cost more than the add they save (103.5 against 102.2 ms on the vision-infused step); with the 2 x 2-block pass it is a
+        # small gain: 102.17 -> 101.99, two same-box pairs)
         if addend is not None and not ((ctx.tail == "res" and act != ACT_NONE and not ctx.fused1 and dz.numel() % 4 == 0) or (POOL_ADDENDS and ctx.tail == "pool" and ctx.has_bn)):
             dz = dz + addend                              # no pass of this backward to fold the sum into
             addend = None
@@ -1478,7 +1479,7 @@ def avgpool_hw(x):
     return inherit_amax(_AvgPoolHW.apply(x), x)
 
 
-POOL_ADDENDS = False  # the stem's pool backward sums two gradient addends on load (module switch: slower, see _ConvBnAct.backward; tests/test_resnet_gpu.py flips it)
+POOL_ADDENDS = True   # the stem's pool backward sums two gradient addends on load (module switch; see _ConvBnAct.backward)
 JOIN_FUSED = True    # a residual join's masked gradient sum is made inside the BatchNorm backward's reduce pass (viai_bn_join_bwd_p16; module switch: tests flip it)
 LAZY_SUM = True      # gradients of a tensor with two readers reach its producer as two addends (fork2; module switch: tests/test_resnet_gpu.py flips it)
 
