@@ -205,6 +205,8 @@ int viai_avgpool_h_bwd(const float* dy, float* dx, int N, int IH, int W, int C, 
  * For 1 < C1 <= 4 (conv1 on RGB / flow frames) the conv entry points expect x stored with channel stride 4
  * (zero padded): viai_nchw_to_nhwc4 produces that layout from the loader's NCHW frames.                */
 int viai_nchw_to_nhwc4(const float* x, float* y, long N, int C, long HW, void* stream);
+/* (ABI 15) the same, and max |x| into *amax (one zero-initialised float): the operand scale of the stem conv's f16x2 kernels */
+int viai_nchw_to_nhwc4_amax(const float* x, float* y, long N, int C, long HW, float* amax, void* stream);
 /* nn.MaxPool2d(k, s, p); idx: one byte per output element (window argmax) kept for the backward */
 int viai_maxpool_fwd(const float* x, float* y, unsigned char* idx, int N, int IH, int IW, int C, int k, int s, int p, void* stream);
 int viai_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int IH, int IW, int C, int k, int s, int p, void* stream);

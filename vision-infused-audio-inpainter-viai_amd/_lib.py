@@ -112,6 +112,7 @@ SIGNATURES = {
     "viai_avgpool_h_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "viai_avgpool_h_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "viai_nchw_to_nhwc4": (_I, [_P, _P, _L, _I, _L, _P]),
+    "viai_nchw_to_nhwc4_amax": (_I, [_P, _P, _L, _I, _L, _P, _P]),
     "viai_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "viai_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "viai_avgpool_hw_fwd": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -446,14 +446,18 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const f32x4* __restrict__
 
 // frames (N, C, H, W) NCHW -> (N, H, W, 4) NHWC with zero-padded channels (C <= 4): the layout conv1 of the
 // ResNets consumes (Image_Embedding.py:188-189 view(-1, 3|2, 224, 224))
-__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long N, int C, long HW) {
+// amax (optional, one zero-initialised float): receives max |x| -- the operand scale of the stem conv's f16x2 kernels (a pass of its own over the 0.8 GB of
+// 1024 frames otherwise: viai_absmax)
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long N, int C, long HW, float* __restrict__ amax) {
     const long total = N * HW;
+    float mx = 0.f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
         long n = i / HW, p = i % HW;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < C; ++c) v[c] = x[(n * C + c) * HW + p];
+        for (int c = 0; c < C; ++c) { v[c] = x[(n * C + c) * HW + p]; mx = fmaxf(mx, fabsf(v[c])); }
         y[i] = v;
     }
+    if (amax != nullptr) block_absmax_to(amax, mx);
 }
 
 // F.avg_pool2d(x, k, s, p, count_include_pad=False) on NHWC: the pix2pixHD input pyramid of a multi-scale
@@ -655,7 +659,13 @@ extern "C" int viai_relu_bwd(const float* g, const float* out, float* d, long n,
 
 extern "C" int viai_nchw_to_nhwc4(const float* x, float* y, long N, int C, long HW, void* stream) {
     if (C < 1 || C > 4) return (int)hipErrorInvalidValue;
-    VIAI_LAUNCH(nchw_to_nhwc4_kernel, dim3(ew_blocks(N * HW)), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<f32x4*>(y), N, C, HW);
+    VIAI_LAUNCH(nchw_to_nhwc4_kernel, dim3(ew_blocks(N * HW)), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<f32x4*>(y), N, C, HW, (float*)nullptr);
+    return viai_launch_status();
+}
+// (ABI 15) ... and max |x| into *amax (zero-initialised)
+extern "C" int viai_nchw_to_nhwc4_amax(const float* x, float* y, long N, int C, long HW, float* amax, void* stream) {
+    if (C < 1 || C > 4 || amax == nullptr) return (int)hipErrorInvalidValue;
+    VIAI_LAUNCH(nchw_to_nhwc4_kernel, dim3(ew_blocks(N * HW)), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<f32x4*>(y), N, C, HW, amax);
     return viai_launch_status();
 }
 

@@ -1567,7 +1567,9 @@ def frames_to_nhwc4(x):
     x = _c(x.detach())
     N, Cc, H, W = x.shape
     y = torch.empty((N, H, W, 4), device=x.device, dtype=torch.float32)
-    _lib.check(lib.viai_nchw_to_nhwc4(x.data_ptr(), y.data_ptr(), N, Cc, H * W, _stream()), "viai_nchw_to_nhwc4")
+    za = _amax_slot(x.device)                   # max |x| on the way through: the stem conv's operand scale (otherwise a pass of its own over the frames)
+    _lib.check(lib.viai_nchw_to_nhwc4_amax(x.data_ptr(), y.data_ptr(), N, Cc, H * W, za.data_ptr(), _stream()), "viai_nchw_to_nhwc4_amax")
+    y._viai_amax = za
     return y
 
 
