@@ -108,6 +108,60 @@ def test_backward_producer_matches_the_fp32_pass_and_bounds_dy():
         assert bool((err <= tol).all()), (Cc, float((err - tol).max()))
 
 
+def test_backward_twin_and_join_producers_are_the_separate_passes_bit_for_bit():
+    """ABI 15: viai_bn_act_bwd_p16_twin writes viai_bn_act_bwd_p16's planes AND an fp32 tensor that decodes-equal the planes' source (the kernel's own
+    fp32 values); viai_bn_join_bwd_p16 = viai_add_act_bwd_from_output (one or two addends, ReLU mask of the join's output) + viai_bn_act_bwd_p16 with no
+    activation, with the masked sum written once: planes, sums, gradients and the masked sum identical."""
+    from viai_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    for Cc, M in ((64, 6016), (128, 3008), (96, 2000)):
+        y = torch.randn(M, Cc, device="cuda", generator=gen)
+        dz = torch.randn(M, Cc, device="cuda", generator=gen) * 1e-3
+        dz2 = torch.randn(M, Cc, device="cuda", generator=gen) * 1e-3
+        zj = torch.randn(M, Cc, device="cuda", generator=gen).relu()
+        gamma, beta, mean, invstd, scale, shift = _bn_coeffs(Cc, gen)
+        nblk = lib.viai_bn_bwd_blocks(M, Cc)
+
+        def bufs():
+            return (torch.empty(3 * Cc * nblk, device="cuda"), torch.empty(3 * Cc, device="cuda"), torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda"),
+                    torch.empty_like(y), torch.zeros(1, device="cuda"))
+
+        # twin against the planes-only pass (act = ReLU of the BatchNorm itself)
+        part, sums, dg, db, dyp, am = bufs()
+        _lib.check(lib.viai_bn_act_bwd_p16(dz.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), part.data_ptr(), sums.data_ptr(),
+                                           dg.data_ptr(), db.data_ptr(), dyp.data_ptr(), M, Cc, 1, 0.2, 1, am.data_ptr(), _st()), "p16")
+        part2, sums2, dg2, db2, dyp2, am2 = bufs()
+        dy32 = torch.empty_like(y)
+        _lib.check(lib.viai_bn_act_bwd_p16_twin(dz.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), part2.data_ptr(),
+                                                sums2.data_ptr(), dg2.data_ptr(), db2.data_ptr(), dyp2.data_ptr(), dy32.data_ptr(), M, Cc, 1, 0.2, 1, am2.data_ptr(), _st()), "twin")
+        assert torch.equal(dyp.view(torch.int32), dyp2.view(torch.int32)) and torch.equal(sums, sums2) and torch.equal(dg, dg2) and torch.equal(db, db2) and float(am) == float(am2)
+        ref = torch.empty_like(y)
+        am3 = torch.zeros(1, device="cuda")
+        _lib.check(lib.viai_bn_act_bwd_amax(dz.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), part.data_ptr(), sums.data_ptr(),
+                                            dg.data_ptr(), db.data_ptr(), ref.data_ptr(), M, Cc, 1, 0.2, 1, am3.data_ptr(), _st()), "fp32")
+        # (the two apply kernels may contract scale * dpre + (k1 (y - mean) + k0) differently: an ulp of the largest term, as in the test above)
+        tol = (scale.abs() * dz.abs() + sums[Cc:2 * Cc].abs() * (y - mean).abs() + sums[:Cc].abs()) * 2.0 ** -22
+        assert bool(((dy32 - ref).abs() <= tol).all())
+        # join against the two separate passes, with one and with two addends
+        for second in (None, dz2):
+            dres0 = torch.empty_like(y)
+            if second is None:
+                _lib.check(lib.viai_act_bwd_from_output(dz.data_ptr(), zj.data_ptr(), dres0.data_ptr(), dz.numel(), 1, 0.2, _st()), "act")
+            else:
+                _lib.check(lib.viai_add_act_bwd_from_output(dz.data_ptr(), second.data_ptr(), zj.data_ptr(), dres0.data_ptr(), dz.numel(), 1, 0.2, _st()), "add_act")
+            part, sums, dg, db, dyp, am = bufs()
+            _lib.check(lib.viai_bn_act_bwd_p16(dres0.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), part.data_ptr(),
+                                               sums.data_ptr(), dg.data_ptr(), db.data_ptr(), dyp.data_ptr(), M, Cc, 0, 0.2, 1, am.data_ptr(), _st()), "p16")
+            part2, sums2, dg2, db2, dyp2, am2 = bufs()
+            dres1 = torch.empty_like(y)
+            _lib.check(lib.viai_bn_join_bwd_p16(dz.data_ptr(), 0 if second is None else second.data_ptr(), zj.data_ptr(), dres1.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), part2.data_ptr(), sums2.data_ptr(), dg2.data_ptr(), db2.data_ptr(),
+                                                dyp2.data_ptr(), M, Cc, 1, am2.data_ptr(), _st()), "join")
+            assert torch.equal(dres0, dres1) and torch.equal(dyp.view(torch.int32), dyp2.view(torch.int32)) and torch.equal(sums, sums2)
+            assert torch.equal(dg, dg2) and torch.equal(db, db2) and float(am) == float(am2)
+
+
 WG_CASES = {"s1_128to128": (1, 128, 128, False), "s1_64to128_T": (1, 64, 128, True), "s2_64to128": (2, 64, 128, False), "s2_32to256": (2, 32, 256, False),
             "narrow_32to32_T": (1, 32, 32, True), "narrow_64to32": (1, 64, 32, False), "p64_64to64": (1, 64, 64, False)}
 
