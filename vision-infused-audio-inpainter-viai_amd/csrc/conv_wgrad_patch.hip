@@ -326,8 +326,12 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * WK) __attribute__((amd
                 for (int u = 0; u < C::UPK; ++u)
                     if ((u * 9) / C::UPK == t) {
                         const int U = r * C::UPK + u;
+#if !(defined(VIAI_WG_ABL) && (VIAI_WG_ABL & 1))
                         lstore_unit((s & 1) ^ 1, U);
+#endif
+#if !(defined(VIAI_WG_ABL) && (VIAI_WG_ABL & 2))
                         if (U & 1) gload_item(U >> 1);
+#endif
                     }
             });
         WG_STAMP(s, 1);
