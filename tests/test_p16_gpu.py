@@ -271,6 +271,17 @@ def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_inp
     ref = torch.nn.functional.conv_transpose2d(x[:NR].double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, 1, 1) if tr else \
         torch.nn.functional.conv2d(x[:NR].double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, S, 1)
     assert ((y1[:NR].double().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm()).item() < 2e-6
+    if lin:
+        # a layer without BatchNorm: bias and LeakyReLU applied by the loader waves where they store the tile (no statistics)
+        bias = torch.randn(Co, device="cuda", generator=gen) * 0.1
+        yb0, yb1 = torch.empty_like(y0), torch.empty_like(y0)
+        _lib.check(lib.viai_conv2d_fwd_amax(d["ref"], x.data_ptr(), 0, wp.data_ptr(), bias.data_ptr(), yb0.data_ptr(), 0, 2, xa.data_ptr(), _st()), "fwd_amax bias")
+        _lib.check(lib.viai_conv2d_fwd_p16(d["ref"], xp.data_ptr(), wp.data_ptr(), bias.data_ptr(), yb1.data_ptr(), 0, 2, xa.data_ptr(), _st()), "fwd_p16 bias")
+        lib.viai_conv2d_last_kernel(fam, 64)
+        assert fam.value == b"lin_dma_f16x2"
+        assert ((yb0 - yb1).norm() / yb0.norm()).item() < 1e-6
+        want = torch.nn.functional.leaky_relu(y1 + bias, 0.2)
+        assert ((yb1 - want).abs().max() / want.abs().max()).item() < 1e-6
     if lin:                                                               # ... and the LAST images (the tensor's tail: records behind the last pixel)
         ref = torch.nn.functional.conv_transpose2d(x[-2:].double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, 1, 1) if tr else \
             torch.nn.functional.conv2d(x[-2:].double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, S, 1)
