@@ -307,6 +307,36 @@ def test_forward_and_data_gradient_on_presplit_operands_are_bitwise_the_fp32_inp
     assert ((g1[:NR].double().cpu().permute(0, 3, 1, 2) - xr.grad).norm() / xr.grad.norm()).item() < 2e-6
 
 
+def test_stride2_data_gradient_on_a_ragged_map_takes_presplit_dy():
+    """the ResNet branch's stride-2 3 x 3 convs (networks/ResNet.py:100-112) produce 28 / 14 / 7-pixel maps, which the patch-staged data-gradient kernel does not
+    tile: conv_dgrad_s2_bf3_kernel<2, true> stages dy's pieces as they are -- the same kernel, the same products in the same order: bit-identical to the
+    fp32-dy launch at equal scale, and right against fp64."""
+    from viai_amd import _lib, ops
+    lib = _lib.load()
+    N, Ci, Co, H = 64, 64, 128, 56
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(N, H, H, Ci, device="cuda", generator=gen)
+    dy = torch.randn(N, H // 2, H // 2, Co, device="cuda", generator=gen) * 1e-2
+    w = torch.randn(Co, Ci, 3, 3, device="cuda", generator=gen) * 0.05
+    d = ops.conv_desc(N, H, H, Ci, 0, Co, 3, 3, 2, 2, 1, 1, 0)
+    assert lib.viai_conv2d_p16_ok(d["ref"]) & 2
+    dyp, da = to_p16(dy)
+    fam = C.create_string_buffer(64)
+    wpd = torch.empty(d["packed"], device="cuda")
+    _lib.check(lib.viai_conv2d_pack_dgrad_f16(d["ref"], w.data_ptr(), wpd.data_ptr(), _st()), "pack_dgrad_f16")
+    g0, g1 = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(lib.viai_conv2d_dgrad_f16(d["ref"], dy.data_ptr(), wpd.data_ptr(), g0.data_ptr(), 0, da.data_ptr(), _st()), "dgrad_f16")
+    lib.viai_conv2d_last_kernel(fam, 64); f0 = fam.value
+    _lib.check(lib.viai_conv2d_dgrad_f16_p16(d["ref"], dyp.data_ptr(), wpd.data_ptr(), g1.data_ptr(), 0, da.data_ptr(), _st()), "dgrad_f16_p16")
+    lib.viai_conv2d_last_kernel(fam, 64)
+    assert f0 == fam.value == b"dgrad_s2_f16x2"
+    assert torch.equal(g0, g1)
+    xr = x[:2].double().permute(0, 3, 1, 2).cpu().requires_grad_(True)
+    o = torch.nn.functional.conv2d(xr, w.double().cpu(), None, 2, 1)
+    (o * dy[:2].double().permute(0, 3, 1, 2).cpu()).sum().backward()
+    assert ((g1[:2].double().cpu().permute(0, 3, 1, 2) - xr.grad).norm() / xr.grad.norm()).item() < 2e-6
+
+
 def _close_to_split(d, ref, am, extra=0.0):
     S = 2.0 ** (14 - (am.log2().floor().item() + 1))
     err = (d - ref).abs()

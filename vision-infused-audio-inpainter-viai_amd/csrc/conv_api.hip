@@ -488,7 +488,7 @@ static bool s2_patch_dgrad(const viai_conv2d* c) {
 }
 static bool p16_dgrad_ok(const viai_conv2d* c) {
     if (!valid(c) || kind_of(c) != K_IGEMM || !dgrad_f16(c)) return false;
-    if (s2_dgrad(c)) return s2_patch_dgrad(c);
+    if (s2_dgrad(c)) return s2_patch_dgrad(c) || c->Cout % 32 == 0;          // (round 5: the gather kernel of the fused classes stages pieces too)
     return c->sh == 1 && c->sw == 1 && (halo_dgrad(c) || halo_wide_dgrad(c) || lin_dgrad(c));
 }
 // (ABI 13) viai_conv2d_dgrad_f16 with dy pre-split (P16 planes, scale from *dy_amax): layers with VIAI_P16_OK_DGRAD_DY

@@ -22,7 +22,9 @@
 namespace {
 
 // NP = 3: bf16x3 (six partial products); NP = 2: f16x2 (three, dy scaled by a power of two derived from a.amax)
-template <int NP>
+// P16 (round 5, NP = 2 only): dy arrives pre-split -- a thread's 16-byte item of a pixel's 32-channel chunk is then a PIECE (piece q & 3 of plane q >> 2) at the
+// same global address, stored as it is (the ResNet branch's stride-2 layers on 28 / 14 / 7-pixel maps, which the patch kernel below does not tile)
+template <int NP, bool P16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_dgrad_s2_bf3_kernel(const ConvArgs a) {
     constexpr int BK = BF3_BK, BM = 128, TM = 2, NA = BM / 32;
     constexpr int APLANE = BM * BF3_PITCH, STAGE = NP * APLANE;
@@ -94,6 +96,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         unsigned char* As = smem_b + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
+            if constexpr (P16) {
+                *reinterpret_cast<u32x4*>(As + (q >> 2) * APLANE + (r0 + 32 * j) * BF3_PITCH + (q & 3) * 16) = raw[j];
+                continue;
+            }
             const f32x4 v = __builtin_bit_cast(f32x4, raw[j]);
             unsigned char* d = As + (r0 + 32 * j) * BF3_PITCH + q * 8;
             if constexpr (NP == 3) {
@@ -399,6 +405,7 @@ int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st) {
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_bf3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_bf3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_bf3_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     constexpr int patch = 1;
@@ -415,9 +422,10 @@ int viai_conv_dgrad_s2_bf3_launch(ConvArgs& a, hipStream_t st) {
         else VIAI_LAUNCH(conv_dgrad_s2_patch_kernel<false>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds_p, st, a);
         return viai_launch_status();
     }
-    if (a.in_p16) return (int)hipErrorInvalidValue;
+    if (a.in_p16 && (a.amax == nullptr || a.C1 % 32 != 0)) return (int)hipErrorInvalidValue;
     viai_tag_kernel(a.amax != nullptr ? "dgrad_s2_f16x2" : "dgrad_s2_bf16x3");
-    if (a.amax != nullptr) VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<2>, dim3(a.nblk_m * a.nblk_n), dim3(256), 2 * 2 * 128 * BF3_PITCH, st, a);   // f16x2
+    if (a.in_p16) VIAI_LAUNCH((conv_dgrad_s2_bf3_kernel<2, true>), dim3(a.nblk_m * a.nblk_n), dim3(256), 2 * 2 * 128 * BF3_PITCH, st, a);
+    else if (a.amax != nullptr) VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<2>, dim3(a.nblk_m * a.nblk_n), dim3(256), 2 * 2 * 128 * BF3_PITCH, st, a);   // f16x2
     else VIAI_LAUNCH(conv_dgrad_s2_bf3_kernel<3>, dim3(a.nblk_m * a.nblk_n), dim3(256), lds, st, a);
     return viai_launch_status();
 }
