@@ -11,15 +11,40 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*argv, timeout=900):
+def _strings(o):
+    if isinstance(o, str):
+        yield o
+    elif isinstance(o, dict):
+        for k, v in o.items():
+            yield k
+            yield from _strings(v)
+    elif isinstance(o, list):
+        for v in o:
+            yield from _strings(v)
+
+
+def run_bench(*argv, timeout=900, detail=False):
+    """bench.py as the driver runs it.  The contract line must be the LAST line of stdout, strict JSON, < 8 KB, every string <= 120 characters
+    (round 5's 38 KB line was not parsed by the driver); everything else bench.py measures goes to the --detail file."""
+    import tempfile
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
-    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as td:
+        dpath = os.path.join(td, "detail.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--detail", dpath] + list(argv), capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+        assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+        assert len(lines) == 1, r.stdout[-2000:]
+        assert r.stdout.rstrip("\n").splitlines()[-1] == lines[0], "the contract line is not the last line of stdout"
+        assert len(lines[0]) < 8192, len(lines[0])
+        out = json.loads(lines[0], parse_constant=lambda c: (_ for _ in ()).throw(ValueError("non-strict JSON constant " + c)))
+        assert max(len(s) for s in _strings(out)) <= 120
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert k in out, k
+        if detail:
+            return out, json.load(open(dpath))
+        return out
 
 
 def test_gpus_2_spawns_its_own_ranks_and_exits_cleanly():
@@ -47,7 +72,17 @@ def test_kernel_families_come_from_the_library():
     kernel instance the step runs, every family priced against the ceiling its suffix names; bench.py holds no dispatch mirror."""
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "viai_conv2d_last_kernel" in src and "mirror of viai_" not in src
-    out = run_bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    line, out = run_bench("--steps", "3", "--warmup", "1", detail=True)
+    # the contract line itself: roofline + cpu_baseline of the headline, and a few numbers of each bounded leg
+    assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["bound"] == "mfma" and line["roofline"]["family"] == out["roofline"]["family"]
+    assert line["roofline"]["avg_launch_us"] > 0 and line["roofline"]["peak"] > line["roofline"]["achieved"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] == "port"
+    assert line["ms_per_step"] == out["ms_per_step"] and line["config"]["workload"].startswith("configs[1]")
+    for k, unit in (("av", "clips/s"), ("wavenet", "samples/s"), ("audio_exact_fp32", "clips/s")):
+        leg = line["extra"][k]
+        assert "error" not in leg and leg["unit"] == unit and leg["value"] > 0 and 0 < leg["roofline"]["frac"] < 1, (k, leg)
+    assert line["extra"]["av"]["cpu_baseline"]["value"] > 0 and line["extra"]["wavenet"]["cpu_baseline"]["value"] > 0
+    assert line["roofline"].get("traffic") is None or line["roofline"]["traffic_source"].startswith("committed:")
     fams = out["roofline"]["conv_time_share_by_kernel"]
     assert "direct" in fams and "halo_wide256_f16x2" in fams and "wgrad_patch_f16x2" in fams and "unknown" not in fams
     assert abs(sum(fams.values()) - 1.0) < 0.02
@@ -67,7 +102,8 @@ def test_kernel_families_come_from_the_library():
     assert len(sf["largest_gaps"]) == 10 and all(g["measured_us"] > 0 for g in sf["largest_gaps"]) and sf["launches_per_step"] > 100
     assert sf["family_bound"]["halo_c32_f16x2"]["bound"] == "hbm" and sf["family_bound"]["halo_wide256_f16x2"]["bound"] == "mfma"
     mb = rf["mfma_busy"]
-    assert 0 < mb["whole_step"] < mb["conv_kernels_time_weighted"] < 1 and mb["source"].startswith("profiles/")
+    assert 0 < mb["whole_step"] < mb["conv_kernels_time_weighted"] < 1 and mb["source"].startswith("committed: profiles/")
+    assert sf["step_floor_at_peak_ms"] < sf["step_floor_ms"] and 0 < sf["frac_of_floor_at_peak"] < sf["frac_of_floor"]
     ex = out["extra"]
     assert set(ex) == {"av", "wavenet", "audio_exact_fp32"}
     for k, unit in (("av", "clips/s"), ("wavenet", "samples/s"), ("audio_exact_fp32", "clips/s")):

@@ -47,7 +47,14 @@ def to64(sd):
     return type(sd)((k, (v.double() if v.is_floating_point() else v.clone())) for k, v in sd.items())
 
 
-def check_against_oracle(model, ocap, dcap, oE, oG, oD):
+# The only tensors allowed above the per-tensor bound, and only at the tiny shape (2 clips x 80 x 32): two BatchNorm-bias gradients of D, sums over 2 560 / 640
+# pixels that nearly cancel.  D.bn1.bias is the worst-conditioned tensor of the step in ANY fp32 arithmetic -- tests/test_oracle_golden.py::
+# test_d_bn1_bias_is_the_ill_conditioned_gradient shows CPU fp32 itself 10x further from fp64 on it than on the median D tensor -- and the f16x2 products
+# (22 significand bits) and P16 storage (absolute error 2^-25 of a BOUND on the tensor) pay that conditioning with a larger constant.
+TINY_ILL_CONDITIONED = {("grads_D", "bn1.bias"), ("grads_D", "norm_2.bias")}
+
+
+def check_against_oracle(model, ocap, dcap, oE, oG, oD, tiny=False):
     """Parity criterion for gradients: against an fp64 run of the oracle ("truth"), the HIP path must be
     as accurate as the reference's fp32 CPU arithmetic is (factor 4 + a floor of 1.5e-3 per network / 3e-3 per tensor -- round 1
     had 5e-3 / 1e-2 there, an order of magnitude above what the kernels deliver; a 1 % systematic gradient error now fails).  Backprop through
@@ -63,7 +70,6 @@ def check_against_oracle(model, ocap, dcap, oE, oG, oD):
     for idx, key, tol in ((0, "loss_d", 1e-4), (1, "loss_g", 1e-4), (3, "loss_l1", 1e-5)):
         assert abs(model.losses[idx].item() - dcap[key].item()) < tol * abs(dcap[key].item()), key
     report = {}
-    outliers = []
     for mod, grp in ((model.netD, "grads_D"), (model.Mel_Encoder, "grads_E"), (model.Mel_Decoder, "grads_G")):
         n_hip = n_o32 = den = 0.0
         for k, g in named_grads(mod).items():
@@ -75,14 +81,10 @@ def check_against_oracle(model, ocap, dcap, oE, oG, oD):
                 assert float(g.abs().max()) < 1e-4
                 continue
             e_hip, e_o32 = relerr(g, truth), relerr(ocap[grp][k], truth)
-            # per tensor: 4 e_o32 + 3e-3 (measured worst e_hip - 4 e_o32: 7.2e-4, cfg 1, D.norm_2.bias).  TWO tensors per network may sit in the flip tail
-            # described above (up to 8e-3): round 5 made the first layer's BatchNorm statistics MORE accurate (tap-covariance kernel: 6e-8 against fp64 where
-            # the conv-then-reduce pass had 2.5e-7, tools/probes/cin1_stats_check.py) and that 2e-7 change of (mean, invstd) moved D.bn1.bias at the tiny shape
-            # from below 3.6e-3 to 5.7e-3 (and D.norm_2.bias to 3.4e-3) -- BatchNorm-bias gradients in front of another BatchNorm, i.e. near-cancelling sums over
-            # 2 560 pixels.  The network-level bound below is unchanged.
-            if not e_hip < 4 * e_o32 + 3e-3:
-                outliers.append((grp, k, e_hip, e_o32))
-                assert e_hip < 4 * e_o32 + 8e-3 and len([o for o in outliers if o[0] == grp]) <= 2, outliers
+            # per tensor: 4 e_o32 + 3e-3 (measured worst e_hip - 4 e_o32: 7.2e-4, cfg 1, D.norm_2.bias) for EVERY tensor of every shape; the two named
+            # near-cancelling sums above may reach 8e-3 at the tiny shape (measured 5.7e-3 / 3.4e-3).  The network-level bound below is unchanged.
+            floor = 8e-3 if (tiny and (grp, k) in TINY_ILL_CONDITIONED) else 3e-3
+            assert e_hip < 4 * e_o32 + floor, (grp, k, e_hip, e_o32)
             n_hip += (g.detach().cpu().double() - truth).pow(2).sum().item()
             n_o32 += (ocap[grp][k].double() - truth).pow(2).sum().item()
             den += truth.pow(2).sum().item()
@@ -145,7 +147,7 @@ def test_step_no_update_matches_oracle_and_golden(shape, golden_dir):
     oE, oG, oD = O.encoder_state(), O.decoder_state(), O.disc_state()
     ocap = O.step_no_update(oE, oG, oD, s2, mask)
     dcap = O.step_no_update(to64(O.encoder_state()), to64(O.decoder_state()), to64(O.disc_state()), s2.double(), mask.double())
-    print(check_against_oracle(model, ocap, dcap, oE, oG, oD))
+    print(check_against_oracle(model, ocap, dcap, oE, oG, oD, tiny=(name == "tiny")))
 
 
 def test_step_no_update_matches_reference_golden_at_benchmark_size(golden_dir):

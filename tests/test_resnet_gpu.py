@@ -309,6 +309,56 @@ def test_two_reader_gradients_reach_the_join_as_addends_and_sum_to_the_same_bits
             assert torch.equal(a, b)
 
 
+def test_lazy_addend_survives_a_third_reader_and_a_gradient_hook(monkeypatch):
+    """round-5 advice: the second addend of a lazily summed gradient used to ride on the gradient TENSOR, so anything that made autograd build a new
+    tensor on the way to the producer (a third reader of the producer's output, a hook that returns a new gradient) dropped it silently.  It now waits in
+    a slot shared by the fork and the producer's node: the gradients equal the ones of the run in which the autograd engine sums, in every such case;
+    forking the same tensor twice, or a tensor that is not a conv_bn_act output, falls back to autograd's sum."""
+    from viai_amd import networks, ops
+    torch.manual_seed(3)
+    stem = torch.nn.Conv2d(32, 64, 3, 1, 1, bias=False).cuda()
+    stem_bn = torch.nn.BatchNorm2d(64).cuda()
+    blk = networks.BasicBlock(64, 64).cuda()
+    x = torch.randn(8, 16, 32, 32, device="cuda")
+    g = torch.randn(8, 16, 32, 64, device="cuda")
+
+    def run(lazy, third_reader, hook, fork_twice=False):
+        monkeypatch.setattr(ops, "LAZY_SUM", lazy)
+        for m in (stem, stem_bn, blk):
+            m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        ops.begin_step(xi.device)
+        h = networks.fused_layer(xi, stem, stem_bn, networks.ACT_RELU)
+        extra = (h * 0.5).sum() if third_reader else 0.0                       # a reader of the producer's output OUTSIDE the fork
+        if hook:
+            h.register_hook(lambda gr: gr * 1.0)                               # returns a NEW tensor: attributes of the incoming gradient would be lost
+        if fork_twice:
+            a, b = ops.fork2(h)
+            c, d_ = ops.fork2(h)                                               # second fork of the same tensor: plain (h, h)
+            assert c is h and d_ is h and a is not h
+            out = blk.forward_nhwc(a) + b * 0.25 + c * 0.125
+        else:
+            out = blk.forward_nhwc(h)
+        (out * g).sum().backward() if not third_reader else ((out * g).sum() + extra).backward()
+        torch.cuda.synchronize()
+        return [xi.grad.clone()] + [p.grad.clone() for m in (stem, stem_bn, blk) for p in m.parameters()]
+
+    for third, hook in ((True, False), (False, True), (True, True)):
+        ref, lazy = run(False, third, hook), run(True, third, hook)
+        for a, b in zip(ref, lazy):
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-12, (third, hook, float((a - b).abs().max()), float(a.abs().max()))
+    ref = run(False, False, False, fork_twice=True)
+    lazy = run(True, False, False, fork_twice=True)
+    for a, b in zip(ref, lazy):
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-12
+    # a tensor that does not come out of conv_bn_act is never forked lazily
+    monkeypatch.setattr(ops, "LAZY_SUM", True)
+    t = torch.randn(4, 4, device="cuda", requires_grad=True) * 2.0
+    t._viai_lazy_sum_ok = True
+    a, b = ops.fork2(t)
+    assert a is t and b is t
+
+
 def test_the_stem_pool_backward_takes_its_gradient_as_two_addends(monkeypatch):
     """conv7x7 s2 -> bn -> relu -> maxpool -> BasicBlock (networks/Image_Embedding.py:20-23, ResNet.py:26-55): the pooled map has two readers, so with
     ops.LAZY_SUM its gradient reaches the stem's backward as two addends and viai_bn_act_pool_bwd_amax2 sums them where it loads the pooled gradient --

@@ -666,6 +666,7 @@ class AudioModel:
         prev_s, ops.WGRAD_STREAM = ops.WGRAD_STREAM, self._wgrad_stream
         try:
             self._optimize_parameters()
+            self._stepped_since_range_check = True
         finally:
             ops.DIRECT_GRAD, ops.WGRAD_STREAM = prev, prev_s
 
@@ -749,15 +750,18 @@ class AudioModel:
         return self._wmax
 
     def get_loss_items(self):
-        """host sync point (train_whole_sync.py:85)."""
+        """host sync point (train_whole_sync.py:85).  COLLECTIVE in a data-parallel run, but only when a train step ran since the last call: train steps
+        are collective themselves, so every rank gets here the same number of times; calls in the no-grad test phase (train_whole_sync.py:79-80 reads the
+        losses there too, and ranks may hold unequal numbers of validation batches) and repeated reads on one rank do not communicate."""
         self.sync_pending_update()
         wr = self._weight_range_check()
-        if self._exchanging():
+        stepped, self._stepped_since_range_check = getattr(self, "_stepped_since_range_check", False), False
+        if self._exchanging() and stepped:
             # data-parallel runs: the weights are replicas, so every rank should see the same maxima -- but a rank whose replica has gone bad on its own (a
             # corrupted exchange, a NaN that only its clips produce) must not raise alone and leave the others waiting in the next collective: the flag is
             # the MAX over the ranks (NaN propagates through max), one tiny all-reduce at a point where the host synchronises anyway
             from . import ddp
-            wr = ddp.all_reduce_max_(torch.nan_to_num(wr, nan=float("inf")), self.pg)
+            wr = ddp.all_reduce_max_(torch.nan_to_num(wr, nan=float("inf"), posinf=float("inf")), self.pg)
         both = torch.cat((self.losses, wr)).tolist()
         v, wmax = both[:self.losses.numel()], both[self.losses.numel():]
         if max(wmax) > ops.F16_WEIGHT_LIMIT and os.environ.get("VIAI_F16X2", "1") != "0" and os.environ.get("VIAI_MATH", "") != "fp32":

@@ -749,7 +749,7 @@ class _ConvBnAct(torch.autograd.Function):
         M = N * OH * OW
         st = _stream()
         dev = dz.device
-        addend = _take_addend(dz)
+        addend = _take_addend(ctx)
         dz = _c(dz)
         act = cfg["act"]
         # (the pool tail takes two addends as well -- viai_bn_act_pool_bwd_amax2.  With the per-pixel apply pass, which gathered up to four windows per pixel,
@@ -1484,35 +1484,51 @@ JOIN_FUSED = True    # a residual join's masked gradient sum is made inside the 
 LAZY_SUM = True      # gradients of a tensor with two readers reach its producer as two addends (fork2; module switch: tests/test_resnet_gpu.py flips it)
 
 
+class _AddendSlot:
+    """where a lazily summed gradient's second addend waits for the producer's backward.  The slot is shared by the _Fork2 node (which fills it)
+    and the producer's autograd node (which empties it): it does not ride on the gradient TENSOR, so it survives whatever autograd does to that
+    tensor on the way (accumulation with a third reader's gradient, hooks, a contiguous copy)."""
+    __slots__ = ("addend",)
+
+    def __init__(self):
+        self.addend = None
+
+
 class _Fork2(torch.autograd.Function):
     """x -> (x, x) for a tensor with two readers (a BasicBlock's input: conv1 and the residual join / the downsample conv, networks/ResNet.py:40-53).
-    The backward does NOT add the two gradients: it hands the first on with the second attached (`_viai_addend`), and the producer's backward --
-    _ConvBnAct, the only producer fork2() is applied to -- adds them in the pass that reads the gradient anyway (the join: where the ReLU mask
-    is applied, viai_add_act_bwd_from_output).  The autograd engine would have spent a pass of its own on the sum."""
+    The backward does NOT add the two gradients: it hands the first on and leaves the second in the slot it shares with the producer's node, and the
+    producer's backward -- _ConvBnAct, the only producer fork2() is applied to -- adds them in the pass that reads the gradient anyway (the join: where
+    the ReLU mask is applied, viai_add_act_bwd_from_output).  The autograd engine would have spent a pass of its own on the sum."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, slot):
+        ctx.slot = slot
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
     def backward(ctx, g1, g2):
         if g1 is None or g2 is None:
-            return g1 if g2 is None else g2
-        if g1.shape != g2.shape or g1.dtype != torch.float32 or g2.dtype != torch.float32 or getattr(g1, "_viai_addend", None) is not None:
-            return g1 + g2
-        g1 = _c(g1)
-        if getattr(g2, "_viai_addend", None) is not None:
-            g2 = g2 + g2._viai_addend
-        g1._viai_addend = _c(g2)
-        return g1
+            return (g1 if g2 is None else g2), None
+        if g1.shape != g2.shape or g1.dtype != torch.float32 or g2.dtype != torch.float32:
+            return g1 + g2, None
+        if ctx.slot.addend is not None:                      # a second backward through the same graph before the producer consumed the first addend
+            g2 = g2 + ctx.slot.addend
+        ctx.slot.addend = _c(g2)
+        return _c(g1), None
 
 
 def fork2(x):
     """two handles of x for its two readers, when x comes straight out of conv_bn_act (whose backward takes the gradient as two addends) and the
-    sum is worth fusing; (x, x) otherwise"""
+    sum is worth fusing; (x, x) otherwise.  The producer's node and the fork share an _AddendSlot; a tensor whose node is not a _ConvBnAct node, or that
+    was forked before, is left to autograd's own sum."""
     if not (LAZY_SUM and getattr(x, "_viai_lazy_sum_ok", False) and x.requires_grad and x.is_cuda):
         return x, x
-    a, b = _Fork2.apply(x)
+    node = x.grad_fn
+    if not isinstance(node, _ConvBnAct._backward_cls) or getattr(node, "_viai_addend_slot", None) is not None:
+        return x, x
+    slot = _AddendSlot()
+    node._viai_addend_slot = slot
+    a, b = _Fork2.apply(x, slot)
     for t in (a, b):                                      # the tags conv_bn_act left for the next layer
         for k in ("_viai_amax", "_viai_twin", "_viai_p16"):
             v = getattr(x, k, None)
@@ -1521,11 +1537,12 @@ def fork2(x):
     return a, b
 
 
-def _take_addend(dz):
-    """the second addend of a gradient that arrived lazily summed (fork2), or None"""
-    a = getattr(dz, "_viai_addend", None)
-    if a is not None:
-        dz._viai_addend = None
+def _take_addend(ctx):
+    """the second addend of a gradient that arrives lazily summed (fork2) at the node `ctx`, or None"""
+    slot = getattr(ctx, "_viai_addend_slot", None)
+    if slot is None:
+        return None
+    a, slot.addend = slot.addend, None
     return a
 
 
