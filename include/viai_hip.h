@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 15
+#define VIAI_ABI_VERSION 16
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -328,6 +328,25 @@ int viai_wavenet_synth_step(const viai_wn_synth* s, void* stream);
  * with a load of `*step` in front of its address arithmetic (a full memory round trip at these grid sizes).  `step` is not touched.
  * wavenet.py:237-364 incremental_forward's loop body, n_steps at a time.                                                         */
 int viai_wavenet_synth_run(const viai_wn_synth* s, int t0, int n_steps, void* stream);
+
+/* Incremental synthesis as ONE persistent launch (ABI v16, csrc/wavenet_pipe.hip): a weight-stationary pipeline for the reference-size
+ * network (24 layers, 512 residual / 512 gate / 256 skip channels, 80 conditioning channels, 30 outputs, no global conditioning).  Every
+ * stage owns compute units (10 per layer, 4 + 4 + 1 for the head) and keeps its weights in registers / LDS; the streams travel round the
+ * stages as tokens of 8-byte {tag, value} granules, so up to B stages work at once where the chain form (viai_wavenet_synth_run) has one.
+ * Same time steps, same folded weights (layers[].w_stage / b_stage), fp32, fixed summation order; replaces the per-step loop of
+ * wavenet.py:322-357 for this configuration.
+ *   viai_wn_pipe_ok            1 if `s` is that configuration and the device has >= 256 compute units (all blocks must be resident)
+ *   viai_wn_pipe_image_floats  sizes of the five weight images the HOST packs (viai_amd.wavenet._pipe_images): 0 wreg [24][10][8][168][64],
+ *                              1 wlds [24][10][136][256], 2 bias [24][10][136], 3 head_w [544][256], 4 head_b [544], 5 wcond [24][10][64][80]
+ *   viai_wn_pipe_token_granules  8-byte granules of the token rings for B streams (dil: the 24 dilations)
+ *   viai_wn_pipe_run           time steps [t0, t0 + n_steps) of every stream.  tok: the rings, ZERO before t0 == 0 and carried over between
+ *                              calls; err: 4 zeroed uint32, err[0] != 0 afterwards = failure (1: a wait timed out at stage / stream / t =
+ *                              err[1..3]; 2: a past tap was missing) -- the caller must check it after synchronising.                      */
+int viai_wn_pipe_ok(const viai_wn_synth* s);
+long viai_wn_pipe_image_floats(int which);
+long viai_wn_pipe_token_granules(int B, const int* dil);
+int viai_wn_pipe_run(const viai_wn_synth* s, const float* wreg, const float* wcond, const float* wlds, const float* bias, const float* head_w, const float* head_b,
+                     void* tok, unsigned* err, int t0, int n_steps, void* stream);
 
 /* ------------------------------------------------------------ mask / optimizer
  * s_in = s * mask, mask (N, T) broadcast over frequency (the missing

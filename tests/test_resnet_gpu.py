@@ -335,7 +335,7 @@ def test_lazy_addend_survives_a_third_reader_and_a_gradient_hook(monkeypatch):
         if fork_twice:
             a, b = ops.fork2(h)
             c, d_ = ops.fork2(h)                                               # second fork of the same tensor: plain (h, h)
-            assert c is h and d_ is h and a is not h
+            assert c is h and d_ is h and ((a is not h) == bool(lazy))
             out = blk.forward_nhwc(a) + b * 0.25 + c * 0.125
         else:
             out = blk.forward_nhwc(h)

@@ -22,7 +22,7 @@ class ViaiLibraryError(RuntimeError):
 
 # ABI version THIS file's SIGNATURES / struct mirrors were written against: bumped together with them.  load() compares it with the
 # library, and with the committed header where that is present (a source checkout), so a stale _lib.py cannot call a rebuilt .so.
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 def _header_abi_version():
@@ -151,6 +151,10 @@ SIGNATURES = {
     "viai_mol_sample": (_I, [_P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "viai_wavenet_synth_step": (_I, [C.POINTER(WnSynth), _P]),
     "viai_wavenet_synth_run": (_I, [C.POINTER(WnSynth), _I, _I, _P]),
+    "viai_wn_pipe_ok": (_I, [C.POINTER(WnSynth)]),
+    "viai_wn_pipe_image_floats": (C.c_long, [_I]),
+    "viai_wn_pipe_token_granules": (C.c_long, [_I, C.POINTER(C.c_int)]),
+    "viai_wn_pipe_run": (_I, [C.POINTER(WnSynth), _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "viai_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "viai_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _D, _D, _D, _F, _P]),
     "viai_colsum_blocks": (_I, [_L, _I]),
