@@ -336,13 +336,16 @@ int viai_wavenet_synth_run(const viai_wn_synth* s, int t0, int n_steps, void* st
  * Same time steps, same folded weights (layers[].w_stage / b_stage), fp32, fixed summation order; replaces the per-step loop of
  * wavenet.py:322-357 for this configuration.
  *   viai_wn_pipe_ok            1 if `s` is that configuration and the device has >= 256 compute units (all blocks must be resident)
- *   viai_wn_pipe_image_floats  sizes of the five weight images the HOST packs (viai_amd.wavenet._pipe_images): 0 wreg [24][10][8][168][64],
- *                              1 wlds [24][10][136][256], 2 bias [24][10][136], 3 head_w [544][256], 4 head_b [544], 5 wcond [24][10][64][80]
+ *   viai_wn_pipe_image_floats  sizes of the five weight images the HOST packs (viai_amd.wavenet._pipe_images): 0 wreg [24][10][8][156][64],
+ *                              1 wlds [24][10][130][260], 2 bias [24][10][136], 3 head_w [544][256], 4 head_b [544], 5 wcond [24][10][64][80]
  *   viai_wn_pipe_token_granules  8-byte granules of the token rings for B streams (dil: the 24 dilations)
  *   viai_wn_pipe_run           time steps [t0, t0 + n_steps) of every stream.  tok: the rings, ZERO before t0 == 0 and carried over between
  *                              calls; err: 4 zeroed uint32, err[0] != 0 afterwards = failure (1: a wait timed out at stage / stream / t =
  *                              err[1..3]; 2: a past tap was missing) -- the caller must check it after synchronising.                      */
 int viai_wn_pipe_ok(const viai_wn_synth* s);
+/* debug aid (tools/wn_pipe_stamps.py): later viai_wn_pipe_run calls record wall-clock stamps (100 MHz) of time step t on compute unit 0 of every stage
+ * into buf, 2 x [27 stages][8 streams][4] uint64 (wall clock, then shader cycles; wait begins / x part complete / z part complete / published); buf = NULL switches it off */
+int viai_wn_pipe_profile(void* buf, int t);
 long viai_wn_pipe_image_floats(int which);
 long viai_wn_pipe_token_granules(int B, const int* dil);
 int viai_wn_pipe_run(const viai_wn_synth* s, const float* wreg, const float* wcond, const float* wlds, const float* bias, const float* head_w, const float* head_b,

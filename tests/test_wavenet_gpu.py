@@ -286,11 +286,13 @@ def test_incremental_synthesis_at_reference_depth_matches_reference_golden(use_g
     assert relerr(gen_free[:, :, :64], gold["gen_free"][:, :, :64]) < 2e-4
 
 
-def test_incremental_equals_batch_forward_at_reference_size():
+def test_incremental_equals_batch_forward_at_reference_size(monkeypatch):
     """configs[4] as benchmarked: 24 layers / 4 stacks / 512 residual + gate / 256 skip channels (24.7 M parameters), B = 8 streams,
     T = 256 = one conditioning frame at hop 256 (the dilation-32 ring of 65 slots wraps three times): with every input
-    teacher-forced the step-by-step logits of both launch forms equal the teacher-forced forward() (SURVEY.md section 4 invariant i;
-    wavenet.py:268-280), and each other bit for bit."""
+    teacher-forced the step-by-step logits of all three launch forms equal the teacher-forced forward() (SURVEY.md section 4 invariant i;
+    wavenet.py:268-280).  The two chain forms (C loop / captured graph) agree bit for bit; the pipelined form (round 6: one persistent launch,
+    csrc/wavenet_pipe.hip -- the default at this size) sums the same products in another order and agrees with them to fp32 rounding."""
+    from viai_amd import _lib
     cfg = W.WNConfigFull
     net = build_cfg(cfg, "WN.").eval()
     assert sum(p.numel() for p in net.parameters()) == 24737396
@@ -301,10 +303,41 @@ def test_incremental_equals_batch_forward_at_reference_size():
     with torch.no_grad():
         yh = net(xin.cuda(), c.cuda())
     u = (O.cf_uniform("wnf8.u1", (B, T, 10), 1e-5, 1 - 1e-5), O.cf_uniform("wnf8.u2", (B, T), 1e-5, 1 - 1e-5))
+    lib = _lib.load()
+    ran = []
+    real = lib.viai_wn_pipe_run
+    monkeypatch.setattr(lib, "viai_wn_pipe_run", lambda *a: (ran.append(a[-3:-1]), real(*a))[1], raising=False)
+    out_p, log_p = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=xin.cuda(), log_scale_min=-7.0, use_graph=False,
+                                           return_logits=True, uniforms=u)
+    assert ran == [(0, T)]                                       # the pipelined kernel took the whole call
+    monkeypatch.setenv("VIAI_WN_PIPE", "0")
     out_r, log_r = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=xin.cuda(), log_scale_min=-7.0, use_graph=False,
                                            return_logits=True, uniforms=u)
     out_g, log_g = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=xin.cuda(), log_scale_min=-7.0, use_graph=True,
                                            return_logits=True, uniforms=u)
+    assert len(ran) == 1
     assert torch.equal(log_r, log_g) and torch.equal(out_r, out_g)
-    assert relerr(log_r.transpose(1, 2), yh) < 1e-4, relerr(log_r.transpose(1, 2), yh)
-    assert relerr(log_r[:, 130:].transpose(1, 2), yh[:, :, 130:]) < 1e-4            # the steps after every ring has wrapped
+    assert relerr(log_p, log_r) < 1e-5 and relerr(out_p, out_r) < 1e-4, (relerr(log_p, log_r), relerr(out_p, out_r))
+    for lg in (log_r, log_p):
+        assert relerr(lg.transpose(1, 2), yh) < 1e-4, relerr(lg.transpose(1, 2), yh)
+        assert relerr(lg[:, 130:].transpose(1, 2), yh[:, :, 130:]) < 1e-4            # the steps after every ring has wrapped
+
+
+def test_pipelined_synthesis_free_running_matches_the_chain_and_continues_across_launches(monkeypatch):
+    """free-running synthesis (every sample feeds the next time step: the hand-off from the sampler back to stage 0) at the reference size, B = 4
+    streams, in two launches (time steps [0, 100) then [100, 256): rings and tags carry over) against the chain of launches, which the reference goldens
+    pin (tests above).  Autoregression amplifies rounding, so the first 48 samples are held to 1e-4 and the whole signal to 2e-3."""
+    from viai_amd import _lib
+    cfg = W.WNConfigFull
+    net = build_cfg(cfg, "WN.").eval()
+    B, T = 4, 256
+    c = O.cf_uniform("wnp4.c", (B, cfg.cin_channels, 1), 0, 1)
+    u = (O.cf_uniform("wnp4.u1", (B, T, 10), 1e-5, 1 - 1e-5), O.cf_uniform("wnp4.u2", (B, T), 1e-5, 1 - 1e-5))
+    timing = {"warmup": 100}
+    out_p = net.incremental_forward(None, c=c.cuda(), T=T, log_scale_min=-7.0, uniforms=u, timing=timing)
+    assert timing.get("form") == "pipe" and timing["steps"] == T - 100
+    monkeypatch.setenv("VIAI_WN_PIPE", "0")
+    out_r = net.incremental_forward(None, c=c.cuda(), T=T, log_scale_min=-7.0, uniforms=u)
+    assert float(out_r.abs().max()) > 0.01
+    assert relerr(out_p[:, :, :48], out_r[:, :, :48]) < 1e-4, relerr(out_p[:, :, :48], out_r[:, :, :48])
+    assert relerr(out_p, out_r) < 2e-3, relerr(out_p, out_r)

@@ -152,6 +152,7 @@ SIGNATURES = {
     "viai_wavenet_synth_step": (_I, [C.POINTER(WnSynth), _P]),
     "viai_wavenet_synth_run": (_I, [C.POINTER(WnSynth), _I, _I, _P]),
     "viai_wn_pipe_ok": (_I, [C.POINTER(WnSynth)]),
+    "viai_wn_pipe_profile": (_I, [_P, _I]),
     "viai_wn_pipe_image_floats": (C.c_long, [_I]),
     "viai_wn_pipe_token_granules": (C.c_long, [_I, C.POINTER(C.c_int)]),
     "viai_wn_pipe_run": (_I, [C.POINTER(WnSynth), _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -8,9 +8,9 @@
 // different streams at the same moment.  Here every stage OWNS compute units and its weights never move again:
 //
 //   stage l (l < 24): 10 compute units hold layer l's fused rows (the extended gate rows [Wc^0 | Wc^1 | c | r Wc^2 | r Wc^2 Wo_prev] of the chain
-//                     form, and the out / skip rows of layer l - 1) -- 182 registers per lane of the past-tap / current-tap columns, 136 KB of
-//                     LDS for the z columns and the out / skip rows; CU j owns gate pairs h in [26 j, 26 j + 26), residual rows
-//                     [52 j, 52 j + 52), skip rows [26 j, 26 j + 26);
+//                     form, and the out / skip rows of layer l - 1) -- 176 registers per lane of the past-tap / current-tap columns, 135 KB of
+//                     LDS for the z columns and the out / skip rows, the conditioning columns streamed from L2 while the stage waits; CU j owns
+//                     gate pairs h in [26 j, 26 j + 26), residual rows [52 j, 52 j + 52), skip rows [26 j, 26 j + 26);
 //   stage 24 / 25:    4 compute units each: the last layer's skip rows (+ ReLU), the head's first 1x1 (+ ReLU);
 //   stage 26:         1 compute unit: the head's second 1x1 and the mixture-of-logistics sample, which is stage 0's next input.
 //
@@ -29,28 +29,28 @@
 namespace {
 
 typedef unsigned long long u64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr int PC = 512, PH = 256, PS = 256, PCIN = 80;
 constexpr int NL = 24, NCU = 10, NHS = 4, NH1 = 4;
 constexpr int HSL = 26, XSL = 52, SSL = 26;           // per-CU slices of the gate pairs / residual rows / skip rows
-constexpr int GW = 7, BW = 10;                        // row slots per wave: gate (56 slots, 52 used), out + skip (80 slots, 78 used)
 constexpr int NW = 8, NT = 512;
 constexpr int KPRE = 1024;                            // [x(t - 2d) 512 | x(t - d) 512]: 16 columns per lane
-constexpr int PRE_M = 4;                              // 4 x (4 columns per lane)
-constexpr int NREG = GW * 16 + GW * 8;                // 168 weight registers per lane
+constexpr int NREG = 13 * 8 + 13 * 4;                 // 156 weight registers per lane: 13 rows x (8 past-tap + 4 current-tap columns)
+constexpr int PBS = 96;                               // row length of the out / skip partial sums
+constexpr int GROWS = 52, BROWS = 78, LROW = 260;     // LDS rows (gate z columns / out + skip), padded row length: lane = row reads are conflict-free
 constexpr int CROWS = 64;                             // conditioning rows: 8 lanes per row (streamed from L2 while the stage waits)
 constexpr int TOK = 1024, TOK_X = 0, TOK_Z = 512, TOK_S = 768;
 constexpr int NSTAGE = NL + 3;
-constexpr int LDS_ROWS = NW * GW + NW * BW;           // 136 rows of 256 floats
 constexpr unsigned SPIN_LIMIT = 400000u;              // ~0.3 - 0.5 s of polling: a stage that starves this long has lost its producer
 
 struct WnPipe {
     const float* wreg;        // [NL][NCU][NW][NREG][64]
     const float* wcond;       // [NL][NCU][CROWS][80]: conditioning columns of the gate row slots (slots >= 56: zero)
-    const float* wlds;        // [NL][NCU][LDS_ROWS][256]
-    const float* bias;        // [NL][NCU][LDS_ROWS]
+    const float* wlds;        // [NL][NCU][GROWS + BROWS][LROW]
+    const float* bias;        // [NL][NCU][136]: 56 gate row slots, 80 out / skip row slots
     const float* head_w;      // [NHS*64 + NH1*64 + 32][256]
     const float* head_b;      // [NHS*64 + NH1*64 + 32]
     const float* w_first; const float* b_first;
@@ -65,7 +65,16 @@ struct WnPipe {
     int dil[NL];
     int B, T, n_test, t0, t1, out_ch;
     float log_scale_min;
+    u64* prof; int prof_t;    // debug aid (viai_wn_pipe_profile): wall-clock stamps of time step prof_t, [stage][stream][4]
 };
+
+// stamps of one time step on CU 0 of every stage: 0 = the wait for the token begins, 1 = token complete, 2 = results in LDS, 3 = publish stores issued
+__device__ __forceinline__ void stamp(const WnPipe& a, int st, int j, int s, int t, int k) {
+    if (a.prof != nullptr && t == a.prof_t && j == 0 && threadIdx.x == 0) {
+        a.prof[((size_t)st * 8 + s) * 4 + k] = wall_clock64();
+        a.prof[27 * 8 * 4 + ((size_t)st * 8 + s) * 4 + k] = (u64)clock64();          // shader cycles beside the 100 MHz wall clock: the clock the stage runs at
+    }
+}
 
 __device__ __forceinline__ u64 gload(const u64* p) { return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void gstore(u64* p, unsigned tag, float v) {
@@ -105,161 +114,279 @@ __device__ __forceinline__ bool poll_fail(const WnPipe& a, unsigned& spins, int 
     return false;
 }
 
+// the same for a wave that polls on its own (no block barrier per poll): on a timeout or a raised flag it marks the block's LDS abort word and leaves
+// its loop; every wave then meets at the phase's block barrier, sees the word and returns
+__device__ __forceinline__ bool wave_poll_fail(const WnPipe& a, unsigned& spins, int* abortf, int st, int s, int t) {
+    ++spins;
+    bool bad = false;
+    if (spins > SPIN_LIMIT) {
+        bad = true;
+        if ((threadIdx.x & 63) == 0 && atomicCAS(a.err, 0u, 1u) == 0u) { a.err[1] = (unsigned)st; a.err[2] = (unsigned)s; a.err[3] = (unsigned)t; }
+    } else if ((spins & 63u) == 0u && eload(a.err) != 0u) bad = true;                  // (one address: uniform over the wave)
+    if (bad) *abortf = 1;
+    return bad;
+}
+
 __device__ __forceinline__ float dot4(const f32x4 w, const f32x4 x, float acc) {
     acc = fmaf(w[0], x[0], acc); acc = fmaf(w[1], x[1], acc); acc = fmaf(w[2], x[2], acc); return fmaf(w[3], x[3], acc);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ a layer stage
-__device__ void layer_stage(const WnPipe& a, const int l, const int j, float* lds) {
+// Register image, no slot wasted: a wave owns 128 past-tap columns and 64 current-tap columns of ALL 52 gate rows; its lane (g, cg) = (lane / 16, lane % 16)
+// holds rows 13 g .. 13 g + 12 x 8 past-tap columns (104 registers) and x 4 current-tap columns (52 registers).  A lane's 13 partial sums are reduced over
+// the 16 lanes of its row group with four DPP adds each (no readlane, no LDS crossbar), the eight waves' sums meet in LDS, and the thread that publishes a
+// row adds them in a fixed order.  The z columns and the out / skip rows live in LDS rows padded to 260 floats, lane = row, the waves split the columns.
+// (History, tools/wn_pipe_stamps.py: 17 full-wave reductions per wave behind the token cost 2.0 us of a 4 us stage; a lane = row register layout needed
+// 176 registers of weights and the compiler spilt addresses into scratch on the publish path: 1.3 us.)
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const int j, float* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* wz = lds;                                  // [56][256] gate rows, z columns
-    float* wb = wz + NW * GW * 256;                   // [80][256] out / skip rows
-    float* xpre = wb + NW * BW * 256;                 // [1152]
+    const int g = lane >> 4, cg = lane & 15;
+    float* wz = lds;                                  // [52][260] gate rows, z columns
+    float* wb = wz + GROWS * LROW;                    // [78][260] out / skip rows
+    float* xpre = wb + BROWS * LROW;                  // [1024]
     float* xcur = xpre + KPRE;                        // [512]
     float* zin = xcur + PC;                           // [256]
-    float* skin = zin + PH;                           // [32]
-    float* gsum = skin + 32;                          // [56]
-    float* bres = gsum + 64;                          // [80]
-    float* bia = bres + 80;                           // [136]
-    float* cnd = bia + LDS_ROWS;                      // [80] c_t
-    float* cpart = cnd + PCIN;                        // [64] conditioning contribution of each gate row slot
+    float* skin = zin + PH;                           // [32] (unused)
+    float* cpart = skin + 32;                         // [64] conditioning part of each gate row
+    float* bia = cpart + 64;                          // [136]
+    float* cnd = bia + 136;                           // [80] c_t
+    float* pg = cnd + PCIN;                           // [8][52] the waves' partial sums of the gate rows (past taps + current tap + z columns)
+    float* pb = pg + NW * GROWS;                      // [8][96] out / skip partials: residual rows at 0 .. 51, skip rows at 64 .. 89
+    int* abortf = reinterpret_cast<int*>(pb + NW * PBS);   // a wave gave up waiting (timeout / error flag raised elsewhere)
+    if (tid == 0) *abortf = 0;
     // ---- weights: never move again
     float w[NREG];
     {
         const float* src = a.wreg + (((size_t)(l * NCU + j) * NW + wave) * NREG) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NREG; ++i) w[i] = src[(size_t)i * 64];
-        const f32x4* ls = reinterpret_cast<const f32x4*>(a.wlds + (size_t)(l * NCU + j) * LDS_ROWS * 256);
-        for (int i = tid; i < LDS_ROWS * 64; i += NT) reinterpret_cast<f32x4*>(lds)[i] = ls[i];
-        if (tid < LDS_ROWS) bia[tid] = a.bias[(size_t)(l * NCU + j) * LDS_ROWS + tid];
+        const f32x4* ls = reinterpret_cast<const f32x4*>(a.wlds + (size_t)(l * NCU + j) * (GROWS + BROWS) * LROW);
+        for (int i = tid; i < (GROWS + BROWS) * LROW / 4; i += NT) reinterpret_cast<f32x4*>(lds)[i] = ls[i];
+        if (tid < 136) bia[tid] = a.bias[(size_t)(l * NCU + j) * 136 + tid];
     }
     const float* wcrow = a.wcond + ((size_t)(l * NCU + j) * CROWS + (tid >> 3)) * PCIN + (tid & 7) * 10;
     __syncthreads();
     const int d = a.dil[l];
     const float r5 = 0.70710678118654752f;
+    // what the loops need of the argument block, once (hipcc re-read the arrays and re-derived `t % ring length` with a 30-instruction division per use)
+    const int rl = a.rl[l], B = a.B, T = a.T, n_test = a.n_test;
+    u64* const ring = a.tok + a.tok_off[l];
+    const u64* const prev = l > 0 ? a.tok + a.tok_off[l - 1] : a.tok + a.tok_off[NL + 2];
+    const int prl = l > 0 ? a.rl[l - 1] : 2;
     for (int t = a.t0; t < a.t1; ++t) {
-        for (int s = 0; s < a.B; ++s) {
+        const int m0 = t % rl, m1 = t - d >= 0 ? (t - d) % rl : 0, m2 = t - 2 * d >= 0 ? (t - 2 * d) % rl : 0;
+        const int mp = l > 0 ? t % prl : (t + 1) % 2;                          // stage 0 reads the sample of t - 1
+        for (int s = 0; s < B; ++s) {
             // ---- what does not depend on the arriving token: the two past taps (this stage's own ring) and the conditioning
             {
                 float v0 = 0.f, v1 = 0.f;
                 bool ok = true;
-                if (t - 2 * d >= 0) { const u64 g = gload(slot_of(a, l, s, t - 2 * d) + TOK_X + tid); ok &= (unsigned)(g >> 32) == (unsigned)(t - 2 * d + 1); v0 = __uint_as_float((unsigned)g); }
-                if (t - d >= 0) { const u64 g = gload(slot_of(a, l, s, t - d) + TOK_X + tid); ok &= (unsigned)(g >> 32) == (unsigned)(t - d + 1); v1 = __uint_as_float((unsigned)g); }
+                if (t - 2 * d >= 0) { const u64 gq = gload(ring + ((long)s * rl + m2) * TOK + TOK_X + tid); ok &= (unsigned)(gq >> 32) == (unsigned)(t - 2 * d + 1); v0 = __uint_as_float((unsigned)gq); }
+                if (t - d >= 0) { const u64 gq = gload(ring + ((long)s * rl + m1) * TOK + TOK_X + tid); ok &= (unsigned)(gq >> 32) == (unsigned)(t - d + 1); v1 = __uint_as_float((unsigned)gq); }
                 xpre[tid] = v0; xpre[PC + tid] = v1;
-                if (tid < PCIN) cnd[tid] = a.cond[((size_t)s * a.T + t) * PCIN + tid];
+                if (tid < PCIN) cnd[tid] = a.cond[((size_t)s * T + t) * PCIN + tid];
                 if (!ok && atomicCAS(a.err, 0u, 2u) == 0u) { a.err[1] = (unsigned)l; a.err[2] = (unsigned)s; a.err[3] = (unsigned)t; }   // a past tap that is not there: protocol defect
             }
             __syncthreads();
-            float acc[GW];
+            float mine_pre = 0.f;
+            {
+                float acc[13];
 #pragma unroll
-            for (int i = 0; i < GW; ++i) acc[i] = 0.f;
+                for (int i = 0; i < 13; ++i) acc[i] = 0.f;
 #pragma unroll
-            for (int m = 0; m < PRE_M; ++m) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xpre + 256 * m + 4 * lane);
+                for (int m = 0; m < 2; ++m) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xpre + 128 * wave + 64 * m + 4 * cg);
 #pragma unroll
-                for (int i = 0; i < GW; ++i) {
-                    const int r = i * 16 + 4 * m;
-                    acc[i] = fmaf(w[r], xv[0], acc[i]); acc[i] = fmaf(w[r + 1], xv[1], acc[i]); acc[i] = fmaf(w[r + 2], xv[2], acc[i]); acc[i] = fmaf(w[r + 3], xv[3], acc[i]);
+                    for (int i = 0; i < 13; ++i) {
+                        const int r = i * 8 + 4 * m;
+                        acc[i] = fmaf(w[r], xv[0], acc[i]); acc[i] = fmaf(w[r + 1], xv[1], acc[i]); acc[i] = fmaf(w[r + 2], xv[2], acc[i]); acc[i] = fmaf(w[r + 3], xv[3], acc[i]);
+                    }
                 }
-            }
-            {   // conditioning columns (modules.py:189-193 conv1x1c): row slot tid / 8, ten columns per lane, weights from L2 -- nothing waits for this
+                // lane (g, cg) keeps the past-tap sum of row 13 g + cg for later (one register; cg >= 13: unused)
+#pragma unroll
+                for (int i = 0; i < 13; ++i) { const float v = row16_sum(acc[i]); mine_pre = (i == 0 || cg == i) ? v : mine_pre; }
+                // conditioning columns (modules.py:189-193 conv1x1c): row tid / 8, ten columns per lane, weights from L2 -- nothing waits for this
                 float cs = 0.f;
 #pragma unroll
                 for (int k = 0; k < 10; ++k) cs = fmaf(wcrow[k], cnd[(tid & 7) * 10 + k], cs);
                 cs += __shfl_xor(cs, 1, 64); cs += __shfl_xor(cs, 2, 64); cs += __shfl_xor(cs, 4, 64);
                 if ((tid & 7) == 0) cpart[tid >> 3] = cs;
             }
-            // ---- the token: x_{l-1}(t) | z_{l-1}(t) | skip sum (own rows) from stage l - 1; stage 0: the previous sample
-            unsigned spins = 0;
+            // ---- the token arrives in two parts.  x_{l-1}(t) and the skip sum leave stage l - 1 about half a microsecond before z_{l-1}(t) (it publishes them
+            // first), so the current tap is done by the time z arrives; behind z: the out / skip rows first (x_l(t) goes out early for the same reason), then
+            // the z columns of the gate rows, tanh / sigmoid, z_l(t).  Every wave polls its own granules until all carry the tag -- no block barrier per poll.
+            stamp(a, l, j, s, t, 0);
+            const u64* p = prev + ((long)s * prl + mp) * TOK;
+            int qt = tid;
+            asm volatile("" : "+v"(qt));              // (per-thread indices re-derived per token: hoisted out of the loop they cost ~30 registers for its whole length)
             if (l == 0) {
+                // the previous sample of this stream.  Teacher-forced steps (t < n_test) take the given input instead but WAIT for the sample all the
+                // same: that wait is the pipeline's only back-pressure -- without it stage 0 runs ahead of the later stages and laps its own ring
                 float cur = 0.f;
-                if (t < a.n_test) cur = a.test_inputs[(size_t)s * a.n_test + t];
-                else if (t > 0) {
-                    const u64* p = slot_of(a, NL + 2, s, t - 1);
-                    for (;;) {
-                        const u64 g = gload(p);
-                        const bool ok = (unsigned)(g >> 32) == (unsigned)t;
-                        cur = __uint_as_float((unsigned)g);
-                        if (__syncthreads_and(ok)) break;
-                        if (poll_fail(a, spins, l, s, t)) return;
+                if (t > 0) {
+                    for (unsigned spins = 0;;) {
+                        const u64 gq = gload(p);
+                        cur = __uint_as_float((unsigned)gq);
+                        if ((unsigned)(gq >> 32) == (unsigned)t) break;                            // (one address for the whole wave: uniform)
+                        if (wave_poll_fail(a, spins, abortf, l, s, t)) break;
                     }
                 }
-                xcur[tid] = fmaf(cur, a.w_first[tid], a.b_first[tid]);          // wavenet.py:118 first_conv
-                __syncthreads();
+                if (t < n_test) cur = a.test_inputs[(size_t)s * n_test + t];
+                xcur[qt] = fmaf(cur, a.w_first[qt], a.b_first[qt]);            // wavenet.py:118 first_conv
             } else {
-                const u64* p = slot_of(a, l - 1, s, t);
-                const bool has2 = tid < PH + SSL;
-                const int i2 = tid < PH ? TOK_Z + tid : TOK_S + min(SSL * j + (tid - PH), PS - 1);
-                for (;;) {
-                    const u64 g0 = gload(p + TOK_X + tid);
-                    bool ok = (unsigned)(g0 >> 32) == (unsigned)(t + 1);
-                    xcur[tid] = __uint_as_float((unsigned)g0);
-                    if (has2) {
-                        const u64 g1 = gload(p + i2);
-                        ok &= (unsigned)(g1 >> 32) == (unsigned)(t + 1);
-                        if (tid < PH) zin[tid] = __uint_as_float((unsigned)g1); else skin[tid - PH] = __uint_as_float((unsigned)g1);
-                    }
-                    if (__syncthreads_and(ok)) break;
-                    if (poll_fail(a, spins, l, s, t)) return;
+                for (unsigned spins = 0;;) {
+                    const u64 g0 = gload(p + TOK_X + qt);
+                    if (__all((unsigned)(g0 >> 32) == (unsigned)(t + 1))) { xcur[qt] = __uint_as_float((unsigned)g0); break; }
+                    if (wave_poll_fail(a, spins, abortf, l, s, t)) break;
                 }
             }
-            // ---- current tap (registers), z columns and the out / skip rows (LDS)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xcur + 256 * m + 4 * lane);
-#pragma unroll
-                for (int i = 0; i < GW; ++i) {
-                    const int r = GW * 16 + i * 8 + 4 * m;
-                    acc[i] = fmaf(w[r], xv[0], acc[i]); acc[i] = fmaf(w[r + 1], xv[1], acc[i]); acc[i] = fmaf(w[r + 2], xv[2], acc[i]); acc[i] = fmaf(w[r + 3], xv[3], acc[i]);
-                }
-            }
-            float bacc[BW];
-            if (l > 0) {
-                const f32x4 zv = *reinterpret_cast<const f32x4*>(zin + 4 * lane);
-                // (two groups of five rows: with all ten in flight hipcc keeps 40 more registers live than the weights leave room for)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                    for (int i = 5 * h; i < 5 * h + 5; ++i) bacc[i] = dot4(*reinterpret_cast<const f32x4*>(wb + (wave * BW + i) * 256 + 4 * lane), zv, 0.f);
-#pragma unroll
-                    for (int i = 5 * h; i < 5 * h + 5; ++i) { const float v = wave_sum_dpp(bacc[i]); if (lane == 0) bres[wave * BW + i] = v; }
-                    asm volatile("" ::: "memory");
-                }
-#pragma unroll
-                for (int i = 0; i < GW; ++i) acc[i] = dot4(*reinterpret_cast<const f32x4*>(wz + (wave * GW + i) * 256 + 4 * lane), zv, acc[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < GW; ++i) { const float v = wave_sum_dpp(acc[i]); if (lane == 0) gsum[wave * GW + i] = v; }
             __syncthreads();
-            // ---- publish: z_l (26 pairs), x_l(t) (52 rows), the skip sum (26 rows)
-            u64* q = slot_of(a, l, s, t);
-            const unsigned tag = (unsigned)(t + 1);
-            if (tid < HSL) {
-                const int h = HSL * j + tid;
-                if (h < PH) {
-                    const float va = gsum[tid] + bia[tid] + cpart[tid], vg = gsum[HSL + tid] + bia[HSL + tid] + cpart[HSL + tid];
-                    gstore(q + TOK_Z + h, tag, tanhf(va) * (1.f / (1.f + expf(-vg))));            // modules.py:201
+            if (*abortf) return;
+            stamp(a, l, j, s, t, 1);
+            // ---- current tap: the wave's 64 columns (registers); lane (g, cg) ends up with the sum of row 13 g + cg over past + current taps
+            float mine;
+            {
+                float acc[13];
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xcur + 64 * wave + 4 * cg);
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+                    const int r = 104 + 4 * i;
+                    acc[i] = fmaf(w[r + 3], xv[3], fmaf(w[r + 2], xv[2], fmaf(w[r + 1], xv[1], w[r] * xv[0])));
                 }
-            } else if (tid >= 64 && tid < 64 + XSL) {
-                const int k = tid - 64, c = XSL * j + k;
-                if (c < PC) gstore(q + TOK_X + c, tag, l == 0 ? xcur[c] : (bres[k] + bia[NW * GW + k] + xcur[c]) * r5);          // modules.py:204-206
-            } else if (tid >= 128 && tid < 128 + SSL) {
-                const int k = tid - 128, si = SSL * j + k;
-                if (si < PS) {
-                    float v = 0.f;
-                    if (l == 1) v = bres[XSL + k] + bia[NW * GW + XSL + k];
-                    else if (l > 1) v = (skin[k] + bres[XSL + k] + bia[NW * GW + XSL + k]) * r5;          // wavenet.py:343-346
-                    gstore(q + TOK_S + si, tag, v);
+#pragma unroll
+                for (int i = 0; i < 13; ++i) acc[i] = row16_sum(acc[i]);
+                mine = acc[0];
+#pragma unroll
+                for (int i = 1; i < 13; ++i) mine = cg == i ? acc[i] : mine;
+                mine += mine_pre;
+            }
+            if (l > 0) {
+                // ---- z_{l-1}(t): waves 0 .. 3 fetch it
+                if (wave < 4) {
+                    for (unsigned spins = 0;;) {
+                        const u64 g0 = gload(p + TOK_Z + qt);
+                        if (__all((unsigned)(g0 >> 32) == (unsigned)(t + 1))) { zin[qt] = __uint_as_float((unsigned)g0); break; }
+                        if (wave_poll_fail(a, spins, abortf, l, s, t)) break;
+                    }
+                }
+                __syncthreads();
+                if (*abortf) return;
+            }
+            stamp(a, l, j, s, t, 2);
+            u64* q = ring + ((long)s * rl + m0) * TOK;
+            const unsigned tag = (unsigned)(t + 1);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            if (l > 0) {
+                // ---- residual rows (LDS, lane = row, this wave's 32 columns of z; z by broadcast reads, two products per v_pk_fma_f32)
+                f32x2 b1 = {0.f, 0.f};
+                const float* rb1 = wb + min(ln, XSL - 1) * LROW + 32 * wave;                // (lanes past the last row re-read it: a broadcast, and nobody reads their sums)
+#pragma unroll 2
+                for (int k4 = 0; k4 < 8; ++k4) {                                          // (a real loop: unrolled, its row reads are hoisted into registers the weights do not leave)
+                    const f32x4 zv = *reinterpret_cast<const f32x4*>(zin + 32 * wave + 4 * k4);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(rb1 + 4 * k4);
+                    b1 = __builtin_elementwise_fma(wv.xy, zv.xy, b1); b1 = __builtin_elementwise_fma(wv.zw, zv.zw, b1);
+                }
+                if (ln < XSL) pb[wave * PBS + ln] = b1.x + b1.y;
+                __syncthreads();
+            }
+            // ---- x_l(t) goes out now (wave 7: 52 rows, each adds the eight waves' partials in a fixed order)
+            if (qt >= NT - 64 && qt < NT - 64 + XSL) {
+                const int k = qt - (NT - 64), c = XSL * j + k;
+                if (c < PC) {
+                    float v = xcur[c];
+                    if (l > 0) {
+                        float sum = bia[56 + k];
+#pragma unroll
+                        for (int wv = 0; wv < NW; ++wv) sum += pb[wv * PBS + k];
+                        v = (sum + v) * r5;                                                       // modules.py:204-206
+                    }
+                    gstore(q + TOK_X + c, tag, v);
                 }
             }
-            // (no barrier: the next token's staging writes xpre only, and its first barrier orders everything after these reads)
+            // ---- z columns of the gate rows (lane = row), joined with the register part through LDS
+            {
+                f32x2 ga = {0.f, 0.f};
+                if (l > 0) {
+                    const float* rz = wz + min(ln, GROWS - 1) * LROW + 32 * wave;
+#pragma unroll 2
+                    for (int k4 = 0; k4 < 8; ++k4) {
+                        const f32x4 zv = *reinterpret_cast<const f32x4*>(zin + 32 * wave + 4 * k4);
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(rz + 4 * k4);
+                        ga = __builtin_elementwise_fma(wv.xy, zv.xy, ga); ga = __builtin_elementwise_fma(wv.zw, zv.zw, ga);
+                    }
+                }
+                if (ln < GROWS) pg[wave * GROWS + ln] = ga.x + ga.y;
+                __builtin_amdgcn_wave_barrier();
+                if (cg < 13) pg[wave * GROWS + 13 * g + cg] += mine;                          // (same wave wrote it just above: LDS operations of a wave complete in order)
+            }
+            __syncthreads();
+            // ---- z_l(t) = tanh(a) sigmoid(b) (modules.py:201): lane r < 26 forms tanh of row r, lane 26 + r the sigmoid of row 26 + r, one shuffle joins them
+            if (qt < 64) {
+                const int r = min(qt, GROWS - 1);
+                float v = bia[r] + cpart[r];
+#pragma unroll
+                for (int wv = 0; wv < NW; ++wv) v += pg[wv * GROWS + r];
+                const bool th = qt < HSL;
+                const float e = expf(th ? -2.f * v : -v);                                         // tanh(a) = (1 - e^-2a) / (1 + e^-2a)
+                const float f = (th ? 1.f - e : 1.f) / (1.f + e);
+                const float sg = __shfl(f, qt + HSL, 64);
+                const int h = HSL * j + qt;
+                if (th && h < PH) gstore(q + TOK_Z + h, tag, f * sg);
+            }
+            stamp(a, l, j, s, t, 3);
+            // ---- nothing waits for the skip sum before the head: its 26 rows come last (wavenet.py:343-346), the previous stage's sum was fetched with x
+            if (l > 0) {
+                f32x2 b2 = {0.f, 0.f};
+                const float* rb2 = wb + (XSL + min(ln, SSL - 1)) * LROW + 32 * wave;
+#pragma unroll 2
+                for (int k4 = 0; k4 < 8; ++k4) {
+                    const f32x4 zv = *reinterpret_cast<const f32x4*>(zin + 32 * wave + 4 * k4);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(rb2 + 4 * k4);
+                    b2 = __builtin_elementwise_fma(wv.xy, zv.xy, b2); b2 = __builtin_elementwise_fma(wv.zw, zv.zw, b2);
+                }
+                if (ln < SSL) pb[wave * PBS + 64 + ln] = b2.x + b2.y;
+                __syncthreads();
+            }
+            if (qt >= 64 && qt < 128) {                   // wave 1: the skip rows; the previous stage's sum arrives last of all, fetched here by the thread that needs it
+                const int k = min(qt - 64, SSL - 1), si = min(SSL * j + k, PS - 1);
+                float v = 0.f;
+                if (l > 0) {
+                    float sum = bia[56 + XSL + k];
+#pragma unroll
+                    for (int wv = 0; wv < NW; ++wv) sum += pb[wv * PBS + 64 + k];
+                    float prevsum = 0.f;
+                    if (l > 1) {
+                        for (unsigned spins = 0;;) {
+                            const u64 g1 = gload(p + TOK_S + si);
+                            prevsum = __uint_as_float((unsigned)g1);
+                            if (__all((unsigned)(g1 >> 32) == (unsigned)(t + 1))) break;
+                            if (wave_poll_fail(a, spins, abortf, l, s, t)) break;
+                        }
+                    }
+                    v = l == 1 ? sum : (prevsum + sum) * r5;
+                }
+                if (qt - 64 < SSL && SSL * j + (qt - 64) < PS) gstore(q + TOK_S + si, tag, v);
+            }
+            // (no barrier: the next token's staging writes xpre / cnd only, and its first barrier orders everything else behind these reads)
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ head stages
 // rows of a 256-wide 1x1 layer held in LDS; `mode` 0: v = relu((skin + W z + b) sqrt(.5)) (the last layer's skip rows), 1: v = relu(W x + b)
-__device__ void dense_stage(const WnPipe& a, const int st, const int j, const int mode, float* lds) {
+__device__ __forceinline__ void dense_stage(const WnPipe& a, const int st, const int j, const int mode, float* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* wr = lds;                  // [64][256]
     float* xin = wr + 64 * 256;       // [256]
@@ -278,39 +405,50 @@ __device__ void dense_stage(const WnPipe& a, const int st, const int j, const in
         for (int s = 0; s < a.B; ++s) {
             const u64* p = slot_of(a, st - 1, s, t);
             unsigned spins = 0;
-            const bool act = tid < 256 || (mode == 0 && tid < 256 + 64);
-            const int idx = tid < 256 ? in_off + tid : TOK_S + 64 * j + (tid - 256);
+            stamp(a, st, j, s, t, 0);
             for (;;) {
                 bool ok = true;
-                if (act) {
-                    const u64 g = gload(p + idx);
+                if (tid < 256) {
+                    const u64 g = gload(p + in_off + tid);
                     ok = (unsigned)(g >> 32) == (unsigned)(t + 1);
-                    if (tid < 256) xin[tid] = __uint_as_float((unsigned)g); else skin[tid - 256] = __uint_as_float((unsigned)g);
+                    xin[tid] = __uint_as_float((unsigned)g);
                 }
                 if (__syncthreads_and(ok)) break;
                 if (poll_fail(a, spins, st, s, t)) return;
             }
+            stamp(a, st, j, s, t, 1);
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + 4 * lane);
             float acc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = dot4(*reinterpret_cast<const f32x4*>(wr + (wave * 8 + i) * 256 + 4 * lane), xv, 0.f);
             u64* q = slot_of(a, st, s, t);
+            float mine = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float v = wave_sum_dpp(acc[i]);
-                if (lane == i) {
-                    const int k = wave * 8 + i;
-                    float y = v + bia[k];
-                    if (mode == 0) y = (skin[k] + y) * r5;                                        // wavenet.py:343-346, then :349 ReLU
-                    gstore(q + 64 * j + k, (unsigned)(t + 1), y > 0.f ? y : 0.f);
+            for (int i = 0; i < 8; ++i) { const float v = wave_sum_dpp(acc[i]); mine = lane == i ? v : mine; }
+            if (lane < 8) {
+                const int k = wave * 8 + lane;
+                float y = mine + bia[k];
+                if (mode == 0) {
+                    // the skip sum of stage 23 is the last thing it publishes: fetched here, behind the products, by the lane that adds it
+                    float prevsum = 0.f;
+                    for (unsigned sp2 = 0;;) {
+                        const u64 g1 = gload(p + TOK_S + 64 * j + k);
+                        prevsum = __uint_as_float((unsigned)g1);
+                        if ((unsigned)(g1 >> 32) == (unsigned)(t + 1)) break;
+                        if (++sp2 > SPIN_LIMIT) { if (atomicCAS(a.err, 0u, 1u) == 0u) { a.err[1] = (unsigned)st; a.err[2] = (unsigned)s; a.err[3] = (unsigned)t; } break; }
+                        if ((sp2 & 63u) == 0u && eload(a.err) != 0u) break;
+                    }
+                    y = (prevsum + y) * r5;                                                       // wavenet.py:343-346, then :349 ReLU
                 }
+                gstore(q + 64 * j + k, (unsigned)(t + 1), y > 0.f ? y : 0.f);
             }
+            stamp(a, st, j, s, t, 3);
             __syncthreads();                          // xin / skin are rewritten by the next poll
         }
 }
 
 // the head's second 1x1 (30 rows) and the sampler (mixture.py:117-153 with injected uniforms)
-__device__ void sample_stage(const WnPipe& a, float* lds) {
+__device__ __forceinline__ void sample_stage(const WnPipe& a, float* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* wr = lds;                  // [32][256]
     float* xin = wr + 32 * 256;       // [256]
@@ -328,12 +466,14 @@ __device__ void sample_stage(const WnPipe& a, float* lds) {
         for (int s = 0; s < a.B; ++s) {
             const u64* p = slot_of(a, NL + 1, s, t);
             unsigned spins = 0;
+            stamp(a, NL + 2, 0, s, t, 0);
             for (;;) {
                 bool ok = true;
                 if (tid < 256) { const u64 g = gload(p + tid); ok = (unsigned)(g >> 32) == (unsigned)(t + 1); xin[tid] = __uint_as_float((unsigned)g); }
                 if (__syncthreads_and(ok)) break;
                 if (poll_fail(a, spins, NL + 2, s, t)) return;
             }
+            stamp(a, NL + 2, 0, s, t, 1);
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + 4 * lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -353,6 +493,7 @@ __device__ void sample_stage(const WnPipe& a, float* lds) {
                 x = fminf(fmaxf(x, -1.f), 1.f);
                 a.out[(size_t)s * a.T + t] = x;
                 gstore(slot_of(a, NL + 2, s, t), (unsigned)(t + 1), x);
+                stamp(a, NL + 2, 0, s, t, 3);
             }
             __syncthreads();
         }
@@ -368,7 +509,7 @@ __global__ __launch_bounds__(NT) void wn_pipe_kernel(const WnPipe a) {
     else sample_stage(a, lds);
 }
 
-constexpr size_t PIPE_LDS_BYTES = (size_t)(LDS_ROWS * 256 + KPRE + PC + PH + 32 + 64 + 80 + LDS_ROWS + PCIN + 64) * sizeof(float);
+constexpr size_t PIPE_LDS_BYTES = (size_t)((GROWS + BROWS) * LROW + KPRE + PC + PH + 32 + 64 + 136 + PCIN + NW * GROWS + NW * PBS + 4) * sizeof(float);
 
 }  // namespace
 
@@ -389,8 +530,8 @@ extern "C" long viai_wn_pipe_image_floats(int which) {
     switch (which) {
     case 5: return (long)NL * NCU * CROWS * PCIN;                // wcond
     case 0: return (long)NL * NCU * NW * NREG * 64;              // wreg
-    case 1: return (long)NL * NCU * LDS_ROWS * 256;              // wlds
-    case 2: return (long)NL * NCU * LDS_ROWS;                    // bias
+    case 1: return (long)NL * NCU * (GROWS + BROWS) * LROW;      // wlds
+    case 2: return (long)NL * NCU * 136;                         // bias
     case 3: return (long)(NHS * 64 + NH1 * 64 + 32) * 256;       // head_w
     case 4: return (long)(NHS * 64 + NH1 * 64 + 32);             // head_b
     default: return 0;
@@ -403,6 +544,11 @@ extern "C" long viai_wn_pipe_token_granules(int B, const int* dil) {
     for (int l = 0; l < NL; ++l) n += (long)B * (2 * dil[l] + 2) * TOK;
     return n + 3L * B * 2 * TOK;
 }
+
+static u64* g_prof = nullptr;
+static int g_prof_t = -1;
+// debug aid: the next viai_wn_pipe_run calls stamp time step t (100 MHz wall clock) into buf, [27 stages][8 streams][4] uint64; buf = NULL switches it off
+extern "C" int viai_wn_pipe_profile(void* buf, int t) { g_prof = (u64*)buf; g_prof_t = t; return 0; }
 
 // time steps [t0, t0 + n) of every stream in ONE launch.  `tok` must be zero before the call with t0 == 0 and carried over between calls;
 // err: 4 zeroed uint32 (err[0] != 0 after the call: 1 = a wait timed out at (stage, stream, t) = err[1..3], 2 = a past tap was missing).
@@ -417,6 +563,7 @@ extern "C" int viai_wn_pipe_run(const viai_wn_synth* s, const float* wreg, const
     long off = 0;
     for (int l = 0; l < NL; ++l) { a.dil[l] = s->layers[l].dilation; a.rl[l] = 2 * a.dil[l] + 2; a.tok_off[l] = off; off += (long)s->B * a.rl[l] * TOK; }
     for (int k = NL; k < NSTAGE; ++k) { a.rl[k] = 2; a.tok_off[k] = off; off += (long)s->B * 2 * TOK; }
+    a.prof = g_prof; a.prof_t = g_prof_t;
     a.B = s->B; a.T = s->T; a.n_test = s->n_test; a.t0 = t0; a.t1 = t0 + n_steps; a.out_ch = s->out_ch; a.log_scale_min = s->log_scale_min;
     static bool attr_set = false;
     if (!attr_set) {

@@ -281,6 +281,52 @@ def conv1d_apply(x, m, act=ACT_NONE, causal_crop=False):
                            padding2=(-1, 0 if causal_crop else -1), act=act)
 
 
+def _pipe_images(w_stage, b_stage, w_c, w_out, b_out, w_skip, b_skip, w_l1, b_l1, w_l2, b_l2, dev):
+    """Weight images of the pipelined synthesis kernel (csrc/wavenet_pipe.hip; layouts in include/viai_hip.h, viai_wn_pipe_image_floats).
+    Inputs: per layer the fused gate rows `w_stage[l]` [G][3C (+H for l > 0)] / `b_stage[l]` [G] of the chain form, the conditioning rows `w_c[l]`
+    [G][cin], and the out / skip 1x1s; the head's two 1x1s.  Compute unit j of layer l owns gate pairs h in [26 j, 26 j + 26), residual rows
+    [52 j, 52 j + 52) and skip rows [26 j, 26 j + 26) -- row SLOTS beyond a range are zero rows.  Pure re-arrangement: no arithmetic on the weights."""
+    NL, NCU, NW, GW, BW, C, H, S = 24, 10, 8, 7, 10, 512, 256, 256
+    G = 2 * H
+    j = torch.arange(NCU).view(NCU, 1)
+    r = torch.arange(NW * GW).view(1, -1)
+    hh = 26 * j + torch.where(r < 26, r, r - 26)
+    grow = torch.where((r < 52) & (hh < H), hh + torch.where(r < 26, 0, H), torch.full_like(hh, G)).to(dev)          # [10][56] -> gate row, G = the zero row
+    q = torch.arange(NW * BW).view(1, -1)
+    xrow = 52 * j + q
+    srow = 26 * j + (q - 52)
+    # B slots: < 52 residual row, 52 .. 77 skip row (offset C in the stacked [Wo; Ws] matrix), C + S = the zero row
+    brow = torch.where((q < 52) & (xrow < C), xrow, torch.where((q >= 52) & (q < 78) & (srow < S), C + srow, torch.full_like(xrow, C + S))).to(dev)
+    wreg, wcond, wlds, bias = [], [], [], []
+    z1 = lambda n: torch.zeros(1, n, device=dev)
+    for l in range(NL):
+        ws = w_stage[l]
+        if ws.size(1) == 3 * C:
+            ws = torch.cat((ws, torch.zeros(G, H, device=dev)), 1)                      # layer 0: no z columns
+        W = torch.cat((ws, z1(3 * C + H)), 0)[grow]                                     # [10][56][1792]
+        # register image: wave = 128 past-tap / 64 current-tap columns of all 52 rows; lane (g, cg) = (lane / 16, lane % 16) holds rows 13 g + i (i < 13):
+        # register 8 i + 4 m + e = past-tap column 128 wave + 64 m + 4 cg + e, register 104 + 4 i + e = current-tap column 64 wave + 4 cg + e
+        pre = W[:, :52, :2 * C].reshape(NCU, 4, 13, NW, 2, 16, 4).permute(0, 3, 2, 4, 6, 1, 5).reshape(NCU, NW, 104, 64)
+        cur = W[:, :52, 2 * C:3 * C].reshape(NCU, 4, 13, NW, 16, 4).permute(0, 3, 2, 5, 1, 4).reshape(NCU, NW, 52, 64)
+        wreg.append(torch.cat((pre, cur), 2))                                           # 104 + 52 registers
+        wc = torch.cat((w_c[l], z1(w_c[l].size(1))), 0)[grow]                           # [10][56][80]
+        wcond.append(torch.cat((wc, torch.zeros(NCU, 8, wc.size(2), device=dev)), 1))   # 64 row slots
+        bg = torch.cat((b_stage[l], torch.zeros(1, device=dev)))[grow]                  # [10][56]
+        if l == 0:
+            wB, bB = torch.zeros(NCU, NW * BW, H, device=dev), torch.zeros(NCU, NW * BW, device=dev)
+        else:
+            wB = torch.cat((w_out[l - 1], w_skip[l - 1], z1(H)), 0)[brow]               # [10][80][256]
+            bB = torch.cat((b_out[l - 1], b_skip[l - 1], torch.zeros(1, device=dev)))[brow]
+        rows = torch.cat((W[:, :52, 3 * C:], wB[:, :78]), 1)                            # LDS rows: 52 gate rows (z columns), 78 out / skip rows
+        wlds.append(torch.nn.functional.pad(rows, (0, 4)))                              # rows padded to 260 floats (lane = row reads without bank conflicts)
+        bias.append(torch.cat((bg, bB), 1))
+    head_w = torch.cat((w_skip[NL - 1], w_l1, w_l2, torch.zeros(32 - w_l2.size(0), S, device=dev)), 0)
+    head_b = torch.cat((b_skip[NL - 1], b_l1, b_l2, torch.zeros(32 - b_l2.numel(), device=dev)))
+    c = lambda ts: torch.stack(ts).float().contiguous()
+    return c(wreg), c(wcond), c(wlds), c(bias), head_w.float().contiguous(), head_b.float().contiguous()
+
+
+
 class ResidualConv1dGLU(nn.Module):
     """modules.py:84-216."""
 
@@ -460,6 +506,13 @@ class WaveNet(nn.Module):
             keep.append(x)
             return x.data_ptr()
         layers = (_lib.WnLayer * len(self.conv_layers))()
+        held = {k: [] for k in ("w_stage", "b_stage", "w_c", "w_out", "b_out", "w_skip", "b_skip")}         # the tensors behind the pointers (pipelined form)
+
+        def th(key, x):
+            x = x.detach().float().contiguous()
+            keep.append(x)
+            held[key].append(x)
+            return x.data_ptr()
         # fused stages (csrc/wavenet.hip, ABI 7): gate_l from z_{l-1} and x_{l-1}(t) through the extended rows built below -- one
         # dependent launch per layer instead of two
         import os
@@ -473,10 +526,10 @@ class WaveNet(nn.Module):
             L = layers[i]
             L.w_conv = t(normed_weight(f.conv).permute(0, 2, 1).reshape(G, -1))       # linearised (conv.py:53-57)
             L.b_conv = t(f.conv.bias)
-            L.w_c = t(normed_weight(f.conv1x1c).reshape(G, -1)) if (f.conv1x1c is not None and cond is not None) else None
+            L.w_c = th("w_c", normed_weight(f.conv1x1c).reshape(G, -1)) if (f.conv1x1c is not None and cond is not None) else None
             L.b_c = t(f.conv1x1c.bias) if (f.conv1x1c is not None and cond is not None) else None
-            L.w_out, L.b_out = t(normed_weight(f.conv1x1_out).reshape(Cc, -1)), t(f.conv1x1_out.bias)
-            L.w_skip, L.b_skip = t(normed_weight(f.conv1x1_skip).reshape(S, -1)), t(f.conv1x1_skip.bias)
+            L.w_out, L.b_out = th("w_out", normed_weight(f.conv1x1_out).reshape(Cc, -1)), th("b_out", f.conv1x1_out.bias)
+            L.w_skip, L.b_skip = th("w_skip", normed_weight(f.conv1x1_skip).reshape(S, -1)), th("b_skip", f.conv1x1_skip.bias)
             L.ring, L.dilation, L.ring_len = ring.data_ptr(), d, 2 * d + 1
             if fuse:
                 # (set-up arithmetic, once per synthesis call, in fp64 on the host: no library GEMM on the device path)
@@ -489,7 +542,7 @@ class WaveNet(nn.Module):
                     wo, bo = normed_weight(prev.conv1x1_out).reshape(Cc, -1).double().cpu(), prev.conv1x1_out.bias.double().cpu()
                     wlin = torch.cat((wlin[:, :2 * Cc], r5 * wc2, r5 * (wc2 @ wo)), 1)
                     bias = bias + r5 * (wc2 @ bo)
-                L.w_stage, L.b_stage = t(wlin.float().to(dev)), t(bias.float().to(dev))
+                L.w_stage, L.b_stage = th("w_stage", wlin.float().to(dev)), th("b_stage", bias.float().to(dev))
                 prev = f
             # global conditioning adds conv1x1g(g) + bias to the gate pre-activation at every step (modules.py:195-199):
             # computed once per layer by the HIP 1x1 conv and handed to the step kernel as a per-stream constant
@@ -515,7 +568,39 @@ class WaveNet(nn.Module):
         st.yhat_dbg = logits.data_ptr() if logits is not None else None
         st.z2, st.fused = z2.data_ptr(), 1 if fuse else 0
         ref = Ct.byref(st)
-        if use_graph and T > 2:
+        # the pipelined form (csrc/wavenet_pipe.hip): one persistent launch, the stages work on different streams at the same time.  Reference-size
+        # network with local conditioning only; everything else (and use_graph) takes the chain of launches below.
+        pipe = (not use_graph) and fuse and os.environ.get("VIAI_WN_PIPE", "1") != "0" and bool(lib.viai_wn_pipe_ok(ref))
+        if pipe:
+            imgs = _pipe_images(held["w_stage"], held["b_stage"], held["w_c"], held["w_out"], held["b_out"], held["w_skip"], held["b_skip"],
+                                normed_weight(self.last_conv_layers[1]).reshape(S, -1).detach().float(), self.last_conv_layers[1].bias.detach().float(),
+                                normed_weight(self.last_conv_layers[3]).reshape(self.out_channels, -1).detach().float(), self.last_conv_layers[3].bias.detach().float(), dev)
+            for k, im in enumerate((imgs[0], imgs[2], imgs[3], imgs[4], imgs[5], imgs[1])):
+                assert im.numel() == lib.viai_wn_pipe_image_floats(k), (k, im.numel(), lib.viai_wn_pipe_image_floats(k))
+            dil = (Ct.c_int * len(self.conv_layers))(*[f.conv.dilation[0] for f in self.conv_layers])
+            tok = torch.zeros(lib.viai_wn_pipe_token_granules(B, dil), dtype=torch.int64, device=dev)
+            err = torch.zeros(4, dtype=torch.int32, device=dev)
+            w0 = min(int(timing.get("warmup", 0)), T) if timing is not None else 0
+
+            def run(t0, n):
+                _lib.check(lib.viai_wn_pipe_run(ref, imgs[0].data_ptr(), imgs[1].data_ptr(), imgs[2].data_ptr(), imgs[3].data_ptr(), imgs[4].data_ptr(), imgs[5].data_ptr(),
+                                                tok.data_ptr(), err.data_ptr(), t0, n, torch.cuda.current_stream().cuda_stream), "viai_wn_pipe_run")
+            if w0 > 0:
+                run(0, w0)
+            if timing is not None:
+                import time
+                torch.cuda.synchronize()
+                t_start = time.perf_counter()
+            for t0 in tqdm(range(w0, T, 1024)):
+                run(t0, min(1024, T - t0))
+            if timing is not None:
+                torch.cuda.synchronize()
+                timing["ms"], timing["steps"], timing["form"] = (time.perf_counter() - t_start) * 1e3, T - w0, "pipe"
+            e = err.tolist()
+            if e[0] != 0:
+                raise _lib.ViaiLibraryError("viai_wn_pipe_run failed on the device: %s at stage %d, stream %d, t = %d"
+                                            % ("a wait timed out" if e[0] == 1 else "a past tap was missing", e[1], e[2], e[3]))
+        elif use_graph and T > 2:
             # device-side time index: one step captured into a HIP graph and replayed (every kernel starts with a load of the index)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
