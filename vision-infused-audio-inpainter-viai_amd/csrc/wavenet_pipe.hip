@@ -149,9 +149,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// the lane id, computed where it is used (two VALU instructions, opaque to the compiler): kept live across the token loop, hipcc spills it -- and LDS
+// addresses derived from it -- to scratch and reloads them on the critical path, each reload a memory round trip
+__device__ __forceinline__ int lane_now() {
+    int x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
+
 __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const int j, float* lds) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, cg = lane & 15;
+    const int tid = threadIdx.x;                                                   // (prologue only)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);           // a scalar
     float* wz = lds;                                  // [52][260] gate rows, z columns
     float* wb = wz + GROWS * LROW;                    // [78][260] out / skip rows
     float* xpre = wb + BROWS * LROW;                  // [1024]
@@ -168,14 +176,13 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
     // ---- weights: never move again
     float w[NREG];
     {
-        const float* src = a.wreg + (((size_t)(l * NCU + j) * NW + wave) * NREG) * 64 + lane;
+        const float* src = a.wreg + (((size_t)(l * NCU + j) * NW + wave) * NREG) * 64 + (tid & 63);
 #pragma unroll
         for (int i = 0; i < NREG; ++i) w[i] = src[(size_t)i * 64];
         const f32x4* ls = reinterpret_cast<const f32x4*>(a.wlds + (size_t)(l * NCU + j) * (GROWS + BROWS) * LROW);
         for (int i = tid; i < (GROWS + BROWS) * LROW / 4; i += NT) reinterpret_cast<f32x4*>(lds)[i] = ls[i];
         if (tid < 136) bia[tid] = a.bias[(size_t)(l * NCU + j) * 136 + tid];
     }
-    const float* wcrow = a.wcond + ((size_t)(l * NCU + j) * CROWS + (tid >> 3)) * PCIN + (tid & 7) * 10;
     __syncthreads();
     const int d = a.dil[l];
     const float r5 = 0.70710678118654752f;
@@ -188,19 +195,26 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
         const int m0 = t % rl, m1 = t - d >= 0 ? (t - d) % rl : 0, m2 = t - 2 * d >= 0 ? (t - 2 * d) % rl : 0;
         const int mp = l > 0 ? t % prl : (t + 1) % 2;                          // stage 0 reads the sample of t - 1
         for (int s = 0; s < B; ++s) {
-            // ---- what does not depend on the arriving token: the two past taps (this stage's own ring) and the conditioning
+            // ---- what does not depend on the arriving token: the two past taps (this stage's own ring) and the conditioning.  A wave stages exactly the
+            // 128 past-tap columns it multiplies (waves 0 - 3: x(t - 2d), waves 4 - 7: x(t - d)): no block barrier
             {
+                const int dd = wave < 4 ? 2 * d : d, mm = wave < 4 ? m2 : m1;
+                const int lane = lane_now();
                 float v0 = 0.f, v1 = 0.f;
                 bool ok = true;
-                if (t - 2 * d >= 0) { const u64 gq = gload(ring + ((long)s * rl + m2) * TOK + TOK_X + tid); ok &= (unsigned)(gq >> 32) == (unsigned)(t - 2 * d + 1); v0 = __uint_as_float((unsigned)gq); }
-                if (t - d >= 0) { const u64 gq = gload(ring + ((long)s * rl + m1) * TOK + TOK_X + tid); ok &= (unsigned)(gq >> 32) == (unsigned)(t - d + 1); v1 = __uint_as_float((unsigned)gq); }
-                xpre[tid] = v0; xpre[PC + tid] = v1;
-                if (tid < PCIN) cnd[tid] = a.cond[((size_t)s * T + t) * PCIN + tid];
+                if (t - dd >= 0) {
+                    const u64* pr = ring + ((long)s * rl + mm) * TOK + TOK_X + 128 * (wave & 3) + lane;
+                    const u64 ga_ = gload(pr), gb_ = gload(pr + 64);
+                    ok = (unsigned)(ga_ >> 32) == (unsigned)(t - dd + 1) && (unsigned)(gb_ >> 32) == (unsigned)(t - dd + 1);
+                    v0 = __uint_as_float((unsigned)ga_); v1 = __uint_as_float((unsigned)gb_);
+                }
+                xpre[128 * wave + lane] = v0; xpre[128 * wave + 64 + lane] = v1;
                 if (!ok && atomicCAS(a.err, 0u, 2u) == 0u) { a.err[1] = (unsigned)l; a.err[2] = (unsigned)s; a.err[3] = (unsigned)t; }   // a past tap that is not there: protocol defect
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             float mine_pre = 0.f;
             {
+                const int lane = lane_now(), cg = lane & 15;
                 float acc[13];
 #pragma unroll
                 for (int i = 0; i < 13; ++i) acc[i] = 0.f;
@@ -218,18 +232,20 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
                 for (int i = 0; i < 13; ++i) { const float v = row16_sum(acc[i]); mine_pre = (i == 0 || cg == i) ? v : mine_pre; }
                 // conditioning columns (modules.py:189-193 conv1x1c): row tid / 8, ten columns per lane, weights from L2 -- nothing waits for this
                 float cs = 0.f;
-#pragma unroll
-                for (int k = 0; k < 10; ++k) cs = fmaf(wcrow[k], cnd[(tid & 7) * 10 + k], cs);
+                const int tq = 64 * wave + lane;
+                const float* wcrow = a.wcond + ((size_t)(l * NCU + j) * CROWS + (tq >> 3)) * PCIN + (tq & 7) * 10;
+                const float* cq = a.cond + ((size_t)s * T + t) * PCIN + (tq & 7) * 10;
+#pragma unroll 2
+                for (int k = 0; k < 10; ++k) cs = fmaf(wcrow[k], cq[k], cs);                    // (a real loop: twenty loads in flight cost registers the weights do not leave)
                 cs += __shfl_xor(cs, 1, 64); cs += __shfl_xor(cs, 2, 64); cs += __shfl_xor(cs, 4, 64);
-                if ((tid & 7) == 0) cpart[tid >> 3] = cs;
+                if ((tq & 7) == 0) cpart[tq >> 3] = cs;
             }
             // ---- the token arrives in two parts.  x_{l-1}(t) and the skip sum leave stage l - 1 about half a microsecond before z_{l-1}(t) (it publishes them
             // first), so the current tap is done by the time z arrives; behind z: the out / skip rows first (x_l(t) goes out early for the same reason), then
             // the z columns of the gate rows, tanh / sigmoid, z_l(t).  Every wave polls its own granules until all carry the tag -- no block barrier per poll.
             stamp(a, l, j, s, t, 0);
             const u64* p = prev + ((long)s * prl + mp) * TOK;
-            int qt = tid;
-            asm volatile("" : "+v"(qt));              // (per-thread indices re-derived per token: hoisted out of the loop they cost ~30 registers for its whole length)
+            int qt = 64 * wave + lane_now();          // (per-thread indices are re-derived where they are used: hoisted out of the loop they cost ~30 registers for its whole length)
             if (l == 0) {
                 // the previous sample of this stream.  Teacher-forced steps (t < n_test) take the given input instead but WAIT for the sample all the
                 // same: that wait is the pipeline's only back-pressure -- without it stage 0 runs ahead of the later stages and laps its own ring
@@ -251,12 +267,12 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
                     if (wave_poll_fail(a, spins, abortf, l, s, t)) break;
                 }
             }
-            __syncthreads();
-            if (*abortf) return;
+            __builtin_amdgcn_wave_barrier();          // (a wave multiplies the 64 columns it fetched itself: no block barrier; an abort is seen at the next one)
             stamp(a, l, j, s, t, 1);
             // ---- current tap: the wave's 64 columns (registers); lane (g, cg) ends up with the sum of row 13 g + cg over past + current taps
             float mine;
             {
+                const int cg = lane_now() & 15;
                 float acc[13];
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(xcur + 64 * wave + 4 * cg);
 #pragma unroll
@@ -272,72 +288,82 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
                 mine += mine_pre;
             }
             if (l > 0) {
-                // ---- z_{l-1}(t): waves 0 .. 3 fetch it
-                if (wave < 4) {
-                    for (unsigned spins = 0;;) {
-                        const u64 g0 = gload(p + TOK_Z + qt);
-                        if (__all((unsigned)(g0 >> 32) == (unsigned)(t + 1))) { zin[qt] = __uint_as_float((unsigned)g0); break; }
-                        if (wave_poll_fail(a, spins, abortf, l, s, t)) break;
-                    }
+                // ---- z_{l-1}(t): every wave fetches the 32 values it multiplies (lanes 32 - 63 repeat them)
+                for (unsigned spins = 0;;) {
+                    const int l31 = lane_now() & 31;
+                    const u64 g0 = gload(p + TOK_Z + 32 * wave + l31);
+                    if (__all((unsigned)(g0 >> 32) == (unsigned)(t + 1))) { zin[32 * wave + l31] = __uint_as_float((unsigned)g0); break; }
+                    if (wave_poll_fail(a, spins, abortf, l, s, t)) break;
                 }
-                __syncthreads();
-                if (*abortf) return;
+                __builtin_amdgcn_wave_barrier();
             }
             stamp(a, l, j, s, t, 2);
             u64* q = ring + ((long)s * rl + m0) * TOK;
             const unsigned tag = (unsigned)(t + 1);
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            if (l > 0) {
-                // ---- residual rows (LDS, lane = row, this wave's 32 columns of z; z by broadcast reads, two products per v_pk_fma_f32)
-                f32x2 b1 = {0.f, 0.f};
-                const float* rb1 = wb + min(ln, XSL - 1) * LROW + 32 * wave;                // (lanes past the last row re-read it: a broadcast, and nobody reads their sums)
-#pragma unroll 2
-                for (int k4 = 0; k4 < 8; ++k4) {                                          // (a real loop: unrolled, its row reads are hoisted into registers the weights do not leave)
-                    const f32x4 zv = *reinterpret_cast<const f32x4*>(zin + 32 * wave + 4 * k4);
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(rb1 + 4 * k4);
-                    b1 = __builtin_elementwise_fma(wv.xy, zv.xy, b1); b1 = __builtin_elementwise_fma(wv.zw, zv.zw, b1);
+            int ln = lane_now();
+            // ---- behind z (LDS rows, lane = row, a wave's 32 columns of z by broadcast reads, two products per v_pk_fma_f32; each loop software-pipelined by hand:
+            // the reads of step i + 1 are issued before the products of step i -- left to hipcc, a loop either waits out an LDS round trip per step or, unrolled,
+            // hoists all its reads into registers the weights do not leave):
+            //   1. the residual rows, all waves; block barrier; WAVE 7 publishes x_l(t) -- half a microsecond ahead of z_l(t), so that the next stage has its
+            //      current tap done when z_l(t) lands;
+            //   2. meanwhile waves 0 - 6 do the z columns of the gate rows (wave 7's 32 columns are shared out to waves 0 - 3, eight each); block barrier;
+            //   3. wave 0 finishes z_l(t).
+            auto rowdot = [&](const float* zp, const float* rp, int n8, f32x2 acc) {      // n8 steps of 8 columns, the next step's four reads in flight
+                f32x4 zc0 = *reinterpret_cast<const f32x4*>(zp), zc1 = *reinterpret_cast<const f32x4*>(zp + 4);
+                f32x4 wc0 = *reinterpret_cast<const f32x4*>(rp), wc1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll 1
+                for (int k8 = 1; k8 < n8; ++k8) {
+                    const f32x4 zn0 = *reinterpret_cast<const f32x4*>(zp + 8 * k8), zn1 = *reinterpret_cast<const f32x4*>(zp + 8 * k8 + 4);
+                    const f32x4 wn0 = *reinterpret_cast<const f32x4*>(rp + 8 * k8), wn1 = *reinterpret_cast<const f32x4*>(rp + 8 * k8 + 4);
+                    acc = __builtin_elementwise_fma(wc0.xy, zc0.xy, acc); acc = __builtin_elementwise_fma(wc0.zw, zc0.zw, acc);
+                    acc = __builtin_elementwise_fma(wc1.xy, zc1.xy, acc); acc = __builtin_elementwise_fma(wc1.zw, zc1.zw, acc);
+                    zc0 = zn0; zc1 = zn1; wc0 = wn0; wc1 = wn1;
                 }
+                acc = __builtin_elementwise_fma(wc0.xy, zc0.xy, acc); acc = __builtin_elementwise_fma(wc0.zw, zc0.zw, acc);
+                acc = __builtin_elementwise_fma(wc1.xy, zc1.xy, acc);
+                return __builtin_elementwise_fma(wc1.zw, zc1.zw, acc);
+            };
+            if (l > 0) {
+                const f32x2 b1 = rowdot(zin + 32 * wave, wb + min(ln, XSL - 1) * LROW + 32 * wave, 4, f32x2{0.f, 0.f});   // (lanes past the last row re-read it: a broadcast, nobody reads their sums)
                 if (ln < XSL) pb[wave * PBS + ln] = b1.x + b1.y;
                 __syncthreads();
             }
-            // ---- x_l(t) goes out now (wave 7: 52 rows, each adds the eight waves' partials in a fixed order)
-            if (qt >= NT - 64 && qt < NT - 64 + XSL) {
-                const int k = qt - (NT - 64), c = XSL * j + k;
-                if (c < PC) {
-                    float v = xcur[c];
-                    if (l > 0) {
-                        float sum = bia[56 + k];
+            if (wave == NW - 1) {
+                if (ln < XSL) {
+                    const int c = XSL * j + ln;
+                    if (c < PC) {
+                        float v = xcur[c];
+                        if (l > 0) {
+                            float sum = bia[56 + ln];
 #pragma unroll
-                        for (int wv = 0; wv < NW; ++wv) sum += pb[wv * PBS + k];
-                        v = (sum + v) * r5;                                                       // modules.py:204-206
+                            for (int wv = 0; wv < NW; ++wv) sum += pb[wv * PBS + ln];           // fixed order
+                            v = (sum + v) * r5;                                                   // modules.py:204-206
+                        }
+                        gstore(q + TOK_X + c, tag, v);
                     }
-                    gstore(q + TOK_X + c, tag, v);
                 }
-            }
-            // ---- z columns of the gate rows (lane = row), joined with the register part through LDS
-            {
+            } else {
                 f32x2 ga = {0.f, 0.f};
                 if (l > 0) {
-                    const float* rz = wz + min(ln, GROWS - 1) * LROW + 32 * wave;
-#pragma unroll 2
-                    for (int k4 = 0; k4 < 8; ++k4) {
-                        const f32x4 zv = *reinterpret_cast<const f32x4*>(zin + 32 * wave + 4 * k4);
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(rz + 4 * k4);
-                        ga = __builtin_elementwise_fma(wv.xy, zv.xy, ga); ga = __builtin_elementwise_fma(wv.zw, zv.zw, ga);
-                    }
+                    const float* rz = wz + min(ln, GROWS - 1) * LROW;
+                    ga = rowdot(zin + 32 * wave, rz + 32 * wave, 4, ga);
+                    if (wave < 4) ga = rowdot(zin + 32 * (NW - 1) + 8 * wave, rz + 32 * (NW - 1) + 8 * wave, 1, ga);          // its share of wave 7's columns
                 }
                 if (ln < GROWS) pg[wave * GROWS + ln] = ga.x + ga.y;
-                __builtin_amdgcn_wave_barrier();
-                if (cg < 13) pg[wave * GROWS + 13 * g + cg] += mine;                          // (same wave wrote it just above: LDS operations of a wave complete in order)
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((ln & 15) < 13) {                                                             // the register part (past + current taps) of row 13 g + cg
+                const int r = wave * GROWS + 13 * (ln >> 4) + (ln & 15);
+                pg[r] = wave == NW - 1 ? mine : pg[r] + mine;                                 // (the same wave wrote pg[r] just above: LDS operations of a wave complete in order)
             }
             __syncthreads();
+            if (*abortf) return;
             // ---- z_l(t) = tanh(a) sigmoid(b) (modules.py:201): lane r < 26 forms tanh of row r, lane 26 + r the sigmoid of row 26 + r, one shuffle joins them
+            qt = 64 * wave + lane_now();
             if (qt < 64) {
                 const int r = min(qt, GROWS - 1);
-                float v = bia[r] + cpart[r];
-#pragma unroll
-                for (int wv = 0; wv < NW; ++wv) v += pg[wv * GROWS + r];
+                const float v = ((bia[r] + cpart[r]) + ((pg[r] + pg[GROWS + r]) + (pg[2 * GROWS + r] + pg[3 * GROWS + r]))) +
+                                ((pg[4 * GROWS + r] + pg[5 * GROWS + r]) + (pg[6 * GROWS + r] + pg[7 * GROWS + r]));        // fixed order, depth 4
                 const bool th = qt < HSL;
                 const float e = expf(th ? -2.f * v : -v);                                         // tanh(a) = (1 - e^-2a) / (1 + e^-2a)
                 const float f = (th ? 1.f - e : 1.f) / (1.f + e);
@@ -347,6 +373,8 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
             }
             stamp(a, l, j, s, t, 3);
             // ---- nothing waits for the skip sum before the head: its 26 rows come last (wavenet.py:343-346), the previous stage's sum was fetched with x
+            ln = lane_now();
+            qt = 64 * wave + ln;
             if (l > 0) {
                 f32x2 b2 = {0.f, 0.f};
                 const float* rb2 = wb + (XSL + min(ln, SSL - 1)) * LROW + 32 * wave;
@@ -357,8 +385,8 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
                     b2 = __builtin_elementwise_fma(wv.xy, zv.xy, b2); b2 = __builtin_elementwise_fma(wv.zw, zv.zw, b2);
                 }
                 if (ln < SSL) pb[wave * PBS + 64 + ln] = b2.x + b2.y;
-                __syncthreads();
             }
+            __syncthreads();                          // (also keeps a fast wave's next token out of cpart / pg / pb / xcur while waves 0 and 7 still publish this one)
             if (qt >= 64 && qt < 128) {                   // wave 1: the skip rows; the previous stage's sum arrives last of all, fetched here by the thread that needs it
                 const int k = min(qt - 64, SSL - 1), si = min(SSL * j + k, PS - 1);
                 float v = 0.f;
@@ -379,7 +407,6 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
                 }
                 if (qt - 64 < SSL && SSL * j + (qt - 64) < PS) gstore(q + TOK_S + si, tag, v);
             }
-            // (no barrier: the next token's staging writes xpre / cnd only, and its first barrier orders everything else behind these reads)
         }
     }
 }
@@ -392,6 +419,8 @@ __device__ __forceinline__ void dense_stage(const WnPipe& a, const int st, const
     float* xin = wr + 64 * 256;       // [256]
     float* skin = xin + 256;          // [64]
     float* bia = skin + 64;           // [64]
+    int* abortf = reinterpret_cast<int*>(bia + 64);
+    if (tid == 0) *abortf = 0;
     const int row0 = (mode == 0 ? 0 : NHS * 64) + 64 * j;
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.head_w + (size_t)row0 * 256);
@@ -404,18 +433,16 @@ __device__ __forceinline__ void dense_stage(const WnPipe& a, const int st, const
     for (int t = a.t0; t < a.t1; ++t)
         for (int s = 0; s < a.B; ++s) {
             const u64* p = slot_of(a, st - 1, s, t);
-            unsigned spins = 0;
             stamp(a, st, j, s, t, 0);
-            for (;;) {
-                bool ok = true;
-                if (tid < 256) {
+            if (wave < 4) {                           // every wave polls its own 64 granules: no block barrier per poll
+                for (unsigned spins = 0;;) {
                     const u64 g = gload(p + in_off + tid);
-                    ok = (unsigned)(g >> 32) == (unsigned)(t + 1);
-                    xin[tid] = __uint_as_float((unsigned)g);
+                    if (__all((unsigned)(g >> 32) == (unsigned)(t + 1))) { xin[tid] = __uint_as_float((unsigned)g); break; }
+                    if (wave_poll_fail(a, spins, abortf, st, s, t)) break;
                 }
-                if (__syncthreads_and(ok)) break;
-                if (poll_fail(a, spins, st, s, t)) return;
             }
+            __syncthreads();
+            if (*abortf) return;
             stamp(a, st, j, s, t, 1);
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + 4 * lane);
             float acc[8];
@@ -454,6 +481,9 @@ __device__ __forceinline__ void sample_stage(const WnPipe& a, float* lds) {
     float* xin = wr + 32 * 256;       // [256]
     float* yo = xin + 256;            // [32]
     float* bia = yo + 32;             // [32]
+    float* us = bia + 32;             // [16] the sampler's noise terms
+    int* abortf = reinterpret_cast<int*>(us + 16);
+    if (tid == 0) *abortf = 0;
     const int row0 = NHS * 64 + NH1 * 64;
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.head_w + (size_t)row0 * 256);
@@ -465,14 +495,19 @@ __device__ __forceinline__ void sample_stage(const WnPipe& a, float* lds) {
     for (int t = a.t0; t < a.t1; ++t)
         for (int s = 0; s < a.B; ++s) {
             const u64* p = slot_of(a, NL + 1, s, t);
-            unsigned spins = 0;
             stamp(a, NL + 2, 0, s, t, 0);
-            for (;;) {
-                bool ok = true;
-                if (tid < 256) { const u64 g = gload(p + tid); ok = (unsigned)(g >> 32) == (unsigned)(t + 1); xin[tid] = __uint_as_float((unsigned)g); }
-                if (__syncthreads_and(ok)) break;
-                if (poll_fail(a, spins, NL + 2, s, t)) return;
+            // the sampler's noise does not depend on the logits: formed while the token is on its way (same expressions as mixture.py:125-150, so the same bits)
+            if (tid < K3) us[tid] = logf(-logf(a.u1[((size_t)s * a.T + t) * K3 + tid]));
+            if (tid == 32) { const float u = a.u2[(size_t)s * a.T + t]; us[K3] = logf(u) - logf(1.f - u); }
+            if (wave < 4) {
+                for (unsigned spins = 0;;) {
+                    const u64 g = gload(p + tid);
+                    if (__all((unsigned)(g >> 32) == (unsigned)(t + 1))) { xin[tid] = __uint_as_float((unsigned)g); break; }
+                    if (wave_poll_fail(a, spins, abortf, NL + 2, s, t)) break;
+                }
             }
+            __syncthreads();
+            if (*abortf) return;
             stamp(a, NL + 2, 0, s, t, 1);
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + 4 * lane);
 #pragma unroll
@@ -485,11 +520,11 @@ __device__ __forceinline__ void sample_stage(const WnPipe& a, float* lds) {
             if (tid == 0) {
                 float best = -INFINITY; int arg = 0;
                 for (int k = 0; k < K3; ++k) {
-                    const float v = yo[k] - logf(-logf(a.u1[((size_t)s * a.T + t) * K3 + k]));
+                    const float v = yo[k] - us[k];
                     if (v > best) { best = v; arg = k; }
                 }
-                const float m = yo[K3 + arg], ls = fmaxf(yo[2 * K3 + arg], a.log_scale_min), u = a.u2[(size_t)s * a.T + t];
-                float x = m + expf(ls) * (logf(u) - logf(1.f - u));
+                const float m = yo[K3 + arg], ls = fmaxf(yo[2 * K3 + arg], a.log_scale_min);
+                float x = m + expf(ls) * us[K3];
                 x = fminf(fmaxf(x, -1.f), 1.f);
                 a.out[(size_t)s * a.T + t] = x;
                 gstore(slot_of(a, NL + 2, s, t), (unsigned)(t + 1), x);
