@@ -671,13 +671,14 @@ def main_wavenet(args):
     ms = timing["ms"] / timing["steps"]
     n_param = sum(p.numel() for p in net.parameters())
     fused = os.environ.get("VIAI_WN_FUSED", "1") != "0"
+    pipe = timing.get("form") == "pipe"           # round 6: one persistent launch, the 27 stages own compute units and work on different streams (csrc/wavenet_pipe.hip)
     head_rows = True
-    n_launch = len(net.conv_layers) + (3 if head_rows else 1) if fused else 2 * len(net.conv_layers) + 2
-    kernel_chain = ("wn_stage_kernel x %d / %s" % (len(net.conv_layers), "wn_head_rows_kernel x 2 / wn_head_sample_kernel (head rows spread over the blocks, every row read once for all streams)"
-                                                   if head_rows else "wn_head_fused_kernel")
-                    if fused else "wn_gate_kernel / wn_out_kernel / wn_head_kernel")
-    launch_form = ("fused stages: gate_l computed from z_(l-1) and x_(l-1)(t) through host-folded rows [Wc0 | Wc1 | r Wc2 | r Wc2 Wo_prev], "
-                   "one dependent launch per layer") if fused else "two dependent launches per layer (VIAI_WN_FUSED=0)"
+    n_stage = len(net.conv_layers) + 3
+    n_launch = n_stage if fused else 2 * len(net.conv_layers) + 2
+    kernel_chain = ("wn_pipe_kernel: %d resident stages (10 CUs per layer, 4 + 4 + 1 for the head), weights in registers / LDS, 8-byte granule tokens" % n_stage if pipe else
+                    "wn_stage_kernel x %d / wn_head_rows_kernel x 2 / wn_head_sample_kernel" % len(net.conv_layers) if fused else "wn_gate_kernel / wn_out_kernel / wn_head_kernel")
+    launch_form = ("one persistent launch per 1024 time steps: a weight-stationary pipeline, up to %d stages busy at once" % B if pipe else
+                   "fused stages: one dependent launch per layer" if fused else "two dependent launches per layer (VIAI_WN_FUSED=0)")
     # weight bytes one time step must stream: every layer's linearised dilated conv (3 x 512 x 512), conditioning (512 x 80), out and
     # skip 1x1s, first conv, head -- the fp32 weights the step kernels read (the up-sampling net runs once, outside the loop)
     wbytes = 4 * sum(p.numel() for n, p in net.named_parameters() if n.endswith("weight_v") and not n.startswith("upsample_conv"))
@@ -688,9 +689,11 @@ def main_wavenet(args):
         "config": {"workload": "configs[4] (not the headline): wavenet_vocoder incremental synthesis, %d layers, %.1f M params, %d streams; step = 1 time step"
                                % (len(net.conv_layers), n_param * 1e-6, B),
                    "global_batch": B, "parallelism": "replicas only (independent streams)", "real_time_factor_16khz": round(1e3 / ms / 16000.0, 3),
-                   "launches_per_step": n_launch, "launch": "viai_wavenet_synth_run: C loop over the time steps", "launch_form": launch_form},
+                   "launches_per_step": (round(1.0 / 1024, 5) if pipe else n_launch), "dependent_stages_per_step": n_launch,
+                   "launch": "viai_wn_pipe_run: one persistent launch" if pipe else "viai_wavenet_synth_run: C loop over the time steps", "launch_form": launch_form},
         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "wn_stage_kernel x %d + head (csrc/wavenet.hip): %d dependent launches per time step" % (len(net.conv_layers), n_launch),
+                     "kernel": ("wn_pipe_kernel (csrc/wavenet_pipe.hip): %d pipelined stages, %d streams in flight" % (n_stage, B)) if pipe else
+                               "wn_stage_kernel x %d + head (csrc/wavenet.hip): %d dependent launches per time step" % (len(net.conv_layers), n_launch),
                      "kernel_chain": kernel_chain, "algorithmic_bytes_per_step": wbytes, "frac_of_chain_floor": round(n_launch * 1.7e-3 / ms, 4),
                      # the second floor: a time step is a CHAIN of n_launch dependent stages; each hand-off costs a kernel boundary (1.5 - 1.9 us
                      # between real kernels, MI355X_MICROARCH.md price list "boundary") or, inside one persistent kernel, an XCD-hierarchical grid
@@ -698,12 +701,21 @@ def main_wavenet(args):
                      "dependency_chain_floor": {"launches_per_step": n_launch, "us_per_handoff": 1.7, "floor_us_per_step": round(n_launch * 1.7, 1),
                                                 "floor_samples_per_s": round(B / (n_launch * 1.7e-6), 0),
                                                 "frac_of_chain_floor": round(n_launch * 1.7e-3 / ms, 4),
-                                                "note": "a stage cannot start before its predecessor's output is visible chip-wide: %d x 1.7 us of boundaries alone; the "
-                                                        "measured %.1f us per step = %.1f us per stage (the stage kernels' own memory round trips)" % (n_launch, ms * 1e3, ms * 1e3 / n_launch)},
+                                                "note": "a stage of ONE stream cannot start before its predecessor's output is visible to it: %d x 1.7 us of hand-offs per time step "
+                                                        "whatever runs them; the measured %.1f us per step = %.1f us per stage" % (n_launch, ms * 1e3, ms * 1e3 / n_launch)},
                      "note": "weight-streaming bound (SURVEY.md section 8d: incremental lower bound per time step = weight bytes / bandwidth): every time step reads "
                              "all %.1f MB of fp32 weights once, whatever level of the hierarchy serves them (they fit the 256 MB Infinity Cache, not the 32 MB of L2); "
                              "the floor at the HBM peak is %.1f us per step, the chain of dependent launches measures %.1f us" % (wbytes * 1e-6, wbytes / HBM_PEAK_GBPS * 1e-3, ms * 1e3)},
     }
+    if pipe:
+        # memory-side traffic of the persistent kernel: the committed counter pass (rocprofv3 cannot run inside this process)
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_wn_pipe.json")))
+        if pm:
+            for k, v in json.load(open(pm[-1])).items():
+                if "wn_pipe" in k and "hbm_bytes_per_time_step" in v:
+                    out["roofline"]["traffic"] = round(v["hbm_bytes_per_time_step"])
+                    out["roofline"]["traffic_source"] = "committed: profiles/%s (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE per time step)" % os.path.basename(pm[-1])
     if not args.no_cpu_baseline:
         from oracle import wavenet_oracle as W
         try:
