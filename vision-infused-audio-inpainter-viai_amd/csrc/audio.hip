@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64 * SW_NW) __attribute__((amdgpu_waves_per_eu(2)))
 //   its own register 8 - ka) and is fetched with ds_bpermute (no LDS storage); |X| into the block's [bin][16 frames] table; band walk and output tile as above
 //   with a thread per (band, four frames).
 constexpr int R5_WCAP = 1024, R5_MMAX = 256;
-constexpr int R5_ROW1 = 72, R5_WREG = 640;                         // c32 per wave region: max(8 x 72, 64 x 10).  R5_ROW2 (template): rows of the second transpose; 10 = 16-byte reads, 4-way store
+constexpr int R5_ROW1 = 72, R5_WREG = 640;                         // c32 per wave region: max(8 x 72, 64 x 10).  R5_ROW2 (template): rows of the second transpose (10 c32 = 80 bytes: 16-byte reads; row index kb 8 + k1, conflict-free both ways)
 // conflicts; 9 = conflict-free stores, 8-byte reads: measured SLOWER (491 - 510 vs 463 - 492 us, same box)            // c32 per wave region: max(8 x 72, 64 x 9).  Rows of 9: the (k1, kb) rows of one store instruction fall 16 banks apart (two passes, the minimum for 512 bytes; rows of 10 were 4-way)
 // <16, 32, 20>: one 1024-thread block per CU (159 KB of LDS);  <8, 16, 8>: TWO 512-thread blocks per CU (78 KB each; the band offsets share the output tile's
 // space: they are only read before the first iteration) -- one block's loads / barriers / write-out overlap the other's arithmetic
@@ -567,10 +567,12 @@ __global__ __launch_bounds__(64 * R5_NW) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
             for (int i = 1; i < 8; ++i) v[i] = cmulc(v[i], t64[a * 8 + i]);
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) E[(k1r * 8 + kb) * R5_ROW2 + a] = v[kb];
+            for (int kb = 0; kb < 8; ++kb) E[(kb * 8 + k1r) * R5_ROW2 + a] = v[kb];          // row kb 8 + k1: the reader's rows are then lane-consecutive (see below)
             wave_lds_sync();
-            {   // lane = k1 + 8 kb reads its eight a's: 64 contiguous bytes
-                const c32* src = E + ((lane & 7) * 8 + (lane >> 3)) * R5_ROW2;
+            {   // lane = k1 + 8 kb reads its eight a's: 64 contiguous bytes of row kb 8 + k1 = lane.  (Round 6: the rows were k1 8 + kb, i.e. row 8 (lane & 7) + (lane >> 3):
+                // with 80-byte rows the start banks of lanes 0, 2, 4, 6 (mod 8) coincided -- a 4-way conflict on every ds_read_b128, 44 % of the kernel's LDS cycles,
+                // profiles/r04_d_pmc_stft_r512.json.  Lane-consecutive rows start at banks 20 lane mod 64: sixteen distinct multiples of 4 per read group.)
+                const c32* src = E + lane * R5_ROW2;
                 if constexpr (R5_ROW2 % 2 == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { const f32x4 t = reinterpret_cast<const f32x4*>(src)[j]; v[2 * j] = c32{t[0], t[1]}; v[2 * j + 1] = c32{t[2], t[3]}; }

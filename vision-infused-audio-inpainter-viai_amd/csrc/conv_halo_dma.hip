@@ -32,6 +32,16 @@
 #include "viai_bf3.h"
 #include <cstdlib>
 
+// persistent grid of the loader / consumer kernels: 256 blocks = one per compute unit.  A block of these kernels takes a CU's whole register file, so
+// while one launch is resident NOTHING of another stream starts anywhere on the chip until a block exits -- in the vision-infused step, where two ResNet
+// chains share the chip, the other chain's 10 us BatchNorm-finalize launches then wait hundreds of microseconds (profiles/r05_f_av_kernel_stats.csv:
+// 238 us as run, 10 us alone).  VIAI_DMA_GRID (tuning switch) leaves some compute units to the other streams.
+static int viai_dma_grid() {
+    static int g = -1;
+    if (g < 0) { const char* e = getenv("VIAI_DMA_GRID"); g = e ? atoi(e) : 256; if (g < 16 || g > 256) g = 256; }
+    return g;
+}
+
 namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -1236,7 +1246,7 @@ static int launch_wide_dma(ConvArgs& a, hipStream_t st) {
 #endif
     a.nblk_m = a.M / (S == 2 ? 64 : 128);                     // BatchNorm partial blocks: 4 x 16 pixels (stride 2) / the 8 x 16 tile (stride 1)
     a.nblk_n = sa.nnb;
-    int grid = 256;
+    int grid = viai_dma_grid();
     if (grid > sa.nitems) grid = sa.nitems;
     VIAI_LAUNCH((conv_wide_dma_kernel<S, TN>), dim3(grid), dim3(S2_THREADS), W::LDS, st, a, sa);
     return viai_launch_status();
@@ -1293,7 +1303,7 @@ static int launch_lin_dma(ConvArgs& a, hipStream_t st) {
 #endif
     a.nblk_m = sa.M / 128;                                    // BatchNorm partial blocks: 128 consecutive pixels (viai_bn_finalize with rows = 128)
     a.nblk_n = sa.nnb;
-    int grid = 256;
+    int grid = viai_dma_grid();
     if (grid > sa.nitems) grid = sa.nitems;
     VIAI_LAUNCH((conv_lin_dma_kernel<PW>), dim3(grid), dim3(S2_THREADS), L::LDS, st, a, sa);
     return viai_launch_status();
