@@ -341,3 +341,24 @@ def test_pipelined_synthesis_free_running_matches_the_chain_and_continues_across
     assert float(out_r.abs().max()) > 0.01
     assert relerr(out_p[:, :, :48], out_r[:, :, :48]) < 1e-4, relerr(out_p[:, :, :48], out_r[:, :, :48])
     assert relerr(out_p, out_r) < 2e-3, relerr(out_p, out_r)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_pipelined_synthesis_with_few_streams_and_a_teacher_forced_prefix(B, monkeypatch):
+    """fewer streams than stages in flight (B = 1: the pipeline holds ONE token, every stage waits for the whole revolution; B = 2), and a teacher-forced prefix of
+    40 samples followed by free-running synthesis (the switch from `test_inputs` to the sampler's own output inside one launch): the pipelined form against the
+    chain of launches, same injected uniforms."""
+    cfg = W.WNConfigFull
+    net = build_cfg(cfg, "WN.").eval()
+    T = 256
+    c = O.cf_uniform("wnp%d.c" % B, (B, cfg.cin_channels, 1), 0, 1)
+    tin = O.cf_uniform("wnp%d.x" % B, (B, 1, 40), -1, 1)
+    u = (O.cf_uniform("wnp%d.u1" % B, (B, T, 10), 1e-5, 1 - 1e-5), O.cf_uniform("wnp%d.u2" % B, (B, T), 1e-5, 1 - 1e-5))
+    timing = {"warmup": 0}
+    out_p = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=tin.cuda(), log_scale_min=-7.0, uniforms=u, timing=timing)
+    assert timing.get("form") == "pipe"
+    monkeypatch.setenv("VIAI_WN_PIPE", "0")
+    out_r = net.incremental_forward(None, c=c.cuda(), T=T, test_inputs=tin.cuda(), log_scale_min=-7.0, uniforms=u)
+    assert tuple(out_p.shape) == (B, 1, T) and float(out_r.abs().max()) > 0.01
+    assert relerr(out_p[:, :, :64], out_r[:, :, :64]) < 1e-4, relerr(out_p[:, :, :64], out_r[:, :, :64])
+    assert relerr(out_p, out_r) < 2e-3, relerr(out_p, out_r)

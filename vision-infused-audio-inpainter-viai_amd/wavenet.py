@@ -598,7 +598,8 @@ class WaveNet(nn.Module):
                 timing["ms"], timing["steps"], timing["form"] = (time.perf_counter() - t_start) * 1e3, T - w0, "pipe"
             e = err.tolist()
             if e[0] != 0:
-                raise _lib.ViaiLibraryError("viai_wn_pipe_run failed on the device: %s at stage %d, stream %d, t = %d"
+                raise _lib.ViaiLibraryError("viai_wn_pipe_run failed on the device: %s at stage %d, stream %d, t = %d (the pipelined form needs all of its 249 blocks "
+                                            "resident at once, i.e. the whole chip to itself; VIAI_WN_PIPE=0 selects the chain of launches)"
                                             % ("a wait timed out" if e[0] == 1 else "a past tap was missing", e[1], e[2], e[3]))
         elif use_graph and T > 2:
             # device-side time index: one step captured into a HIP graph and replayed (every kernel starts with a load of the index)
