@@ -53,6 +53,9 @@ CONV_CASES = [
     ("halo64to32T", 2, 8, 32, 64, 32, (3, 3), (1, 1), (1, 1), True, True),
     ("halo48out", 1, 16, 16, 32, 48, (3, 3), (1, 1), (1, 1), False, False),
     ("halo1x3", 2, 8, 64, 32, 32, (1, 3), (1, 1), (0, 1), False, False),
+    # round 6: the stride-(2, 1) layer on the halo kernel -- forward with vertical gather stride 2, data gradient as two row-parity classes with scatter stride 2
+    ("halo_s21", 2, 32, 32, 32, 64, (3, 3), (2, 1), (1, 1), False, False),
+    ("halo_s21_bias", 1, 48, 16, 32, 64, (3, 3), (2, 1), (1, 1), False, True),
     # big enough that the 64x64-tile LDS-weight kernel (not the small-M split-K kernel) takes the layer
     # fused-class stride-2 dgrad (needs >= 256 tiles of 128 base pixels x 64 channels): two channel blocks / ragged M
     ("D.conv2_2", 4, 128, 128, 128, 64, (3, 3), (2, 2), (1, 1), False, False),

@@ -74,7 +74,15 @@ static bool halo_fwd(const viai_conv2d* c) {
     return viai_conv_halo_ok(g, c->C1, c->C2, c->Cout);
 }
 static bool halo_dgrad(const viai_conv2d* c) {
-    if (!use_bf3_dgrad(c) || c->sh != 1 || c->sw != 1) return false;
+    if (!use_bf3_dgrad(c) || c->sw != 1 || (c->sh != 1 && c->sh != 2)) return false;
+    if (c->sh == 2) {                                      // round 6: the stride-(2, 1) layer (MelEncoder.conv2): both row-parity classes on the halo kernel
+        if (!f16x2_enabled() || c->transposed) return false;
+        for (int a_ = 0; a_ < 2; ++a_) {
+            ConvGeom g{}; if (viai_geom_dgrad_class(c, a_, 0, &g) == 0) return false;
+            if (!viai_conv_halo_ok(g, c->Cout, 0, cin_of(c))) return false;
+        }
+        return true;
+    }
     ConvGeom g{}; if (viai_geom_dgrad_class(c, 0, 0, &g) == 0) return false;
     return viai_conv_halo_ok(g, c->Cout, 0, cin_of(c));
 }

@@ -23,12 +23,16 @@ constexpr int HALO_WIDE_ROW_BYTES = 1536;       // conv_halo_wide_f16_kernel, st
 
 // NP = 3: bf16x3; NP = 2: f16x2 (two fp16 planes, three partial products; operand scale static or from a.amax)
 // P16 (NP = 2 only): the gathered tensor arrives pre-split (viai_bf3.h): pieces are copied into their plane instead of quads being split
-template <int CIN, int TN, int NP = 3, bool P16 = false>
+// MY (round 6): vertical gather stride.  MY = 2 is the forward of a stride-(2, 1) conv (MelEncoder.conv2, Inpainting_Networks.py:58): the patch of an 8 x 16 output tile is
+// 17 x 18 input pixels and output row r reads patch rows 2 r + dy.  The data gradient of such a layer runs as its two row-parity classes (unit gather stride, scatter
+// stride ly = 2): the epilogue writes output pixel (oy ly + ay, ox lx + ax) of the full tensor, tiles are counted on the class's sub-lattice (SH x SW).
+template <int CIN, int TN, int NP = 3, bool P16 = false, int MY = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 && TN == 1) ? 3 : 2))) void conv_halo_bf3_kernel(const ConvArgs a, int hy0, int hx0, int ntiles) {
     static_assert(!P16 || NP == 2, "P16 is an f16x2 format");
     constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int PITCH = CIN * 2 + 16;             // bytes per LDS pixel row (80 / 144: conflict-free ds_read_b128)
     constexpr int Q = CIN / 4;                      // float4 per pixel
+    constexpr int HT_HH = (HT_H - 1) * MY + 3, HT_HP = HT_HH * HT_HW;      // staged patch (shadows the stride-1 constants of the file scope)
     constexpr int NL = (HT_HP * Q + 255) / 256;     // float4 per thread
     constexpr int KS = CIN / 16;                    // 16-deep k-steps per tap
     constexpr int BN = 32 * TN;
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
     const float alim = f16_clamp_for_scale(ascale);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = g.OW / HT_W, tiles_y = g.OH / HT_H;
+    const int tiles_x = g.SW / HT_W, tiles_y = g.SH / HT_H;          // (SH x SW = OH x OW except for a data-gradient parity class)
 
     constexpr int OOB = 0x7fffffff;
     const long in_pixels = (long)g.N * g.IH * g.IW;
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
     auto load_patch = [&](int tile) {               // tile is wave-uniform; loads land in reg[] while the MFMAs run
         const int tx = tile % tiles_x; int r = tile / tiles_x;
         const int ty = r % tiles_y, n = r / tiles_y;
-        const int py = ty * HT_H + hy0, px = tx * HT_W + hx0;
+        const int py = ty * HT_H * MY + hy0, px = tx * HT_W + hx0;
         const int pbase = ((n * g.IH + py) * g.IW + px) * CIN * 4;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
 
     // MFMA row i = lane & 31 -> tile pixel (2 * wave + (i >> 4), i & 15)
     const int pr = 2 * wave + ((lane & 31) >> 4), pc = lane & 15;
-    const unsigned char* abase = smem_h + ((pr - hy0) * HT_HW + (pc - hx0)) * PITCH + 16 * (lane >> 5);
+    const unsigned char* abase = smem_h + ((pr * MY - hy0) * HT_HW + (pc - hx0)) * PITCH + 16 * (lane >> 5);
     constexpr int PA[6] = {1, NP == 3 ? 2 : 0, 0, 1, 0, 0}, PB[6] = {NP == 3 ? 1 : 0, NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
     const int half = lane >> 5, col = lane & 31;
     float bv[TN];
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 32 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-            const int oy = oy0 + 2 * wave + (row >> 4), ox = ox0 + (row & 15);
+            const int oy = (oy0 + 2 * wave + (row >> 4)) * g.ly + g.ay, ox = (ox0 + (row & 15)) * g.lx + g.ax;
             const size_t opix = ((size_t)n * g.OH + oy) * g.OW + ox;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -673,14 +677,15 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     }
 }
 
-template <int CIN, int TN, int NP = 3>
+template <int CIN, int TN, int NP = 3, int MY = 1>
 int launch_halo(ConvArgs& a, int hy0, int hx0, hipStream_t st) {
     constexpr int PITCH = CIN * 2 + 16;
+    constexpr int HT_HP = ((HT_H - 1) * MY + 3) * HT_HW;
     size_t lds = (size_t)NP * HT_HP * PITCH;
     if (lds < (size_t)4 * 32 * TN * sizeof(float)) lds = (size_t)4 * 32 * TN * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bf3_kernel<CIN, TN, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bf3_kernel<CIN, TN, NP, false, MY>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
@@ -694,13 +699,13 @@ int launch_halo(ConvArgs& a, int hy0, int hx0, hipStream_t st) {
     if constexpr (NP == 2) {
         if (a.in_p16) {
             static bool attr_p = false;
-            if (!attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bf3_kernel<CIN, TN, NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_p = true; }
-            VIAI_LAUNCH((conv_halo_bf3_kernel<CIN, TN, NP, true>), dim3(grid), dim3(256), lds, st, a, hy0, hx0, a.nblk_m);
+            if (!attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bf3_kernel<CIN, TN, NP, true, MY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_p = true; }
+            VIAI_LAUNCH((conv_halo_bf3_kernel<CIN, TN, NP, true, MY>), dim3(grid), dim3(256), lds, st, a, hy0, hx0, a.nblk_m);
             return viai_launch_status();
         }
     }
     if (a.in_p16) return (int)hipErrorInvalidValue;
-    VIAI_LAUNCH((conv_halo_bf3_kernel<CIN, TN, NP>), dim3(grid), dim3(256), lds, st, a, hy0, hx0, a.nblk_m);
+    VIAI_LAUNCH((conv_halo_bf3_kernel<CIN, TN, NP, false, MY>), dim3(grid), dim3(256), lds, st, a, hy0, hx0, a.nblk_m);
     return viai_launch_status();
 }
 
@@ -708,10 +713,16 @@ int launch_halo(ConvArgs& a, int hy0, int hx0, hipStream_t st) {
 
 // Shapes the halo kernel takes: one source of 32 or 64 channels, <= 64 output channels, unit stride in both the
 // gather and the scatter, taps within a 3 x 3 window, output extent a multiple of the 8 x 16 tile.
+// Round 6: also the stride-(2, 1) layer of the encoder -- forward (gather stride my = 2, 32 -> 64 channels) and the two row-parity classes of its data gradient
+// (scatter stride ly = 2 on a sub-lattice of SH x SW pixels).
 bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout) {
     if (C2 != 0 || (C1 != 32 && C1 != 64) || Cout > 64 || Cout < 1) return false;
-    if (g.run || g.ly != 1 || g.lx != 1 || g.my != 1 || g.mx != 1 || g.SH != g.OH || g.SW != g.OW) return false;
-    if (g.OH % HT_H != 0 || g.OW % HT_W != 0 || g.ntaps < 1) return false;
+    if (g.run || g.lx != 1 || g.mx != 1 || g.ax != 0 || g.SW != g.OW) return false;
+    const bool plain = g.ly == 1 && g.my == 1 && g.ay == 0 && g.SH == g.OH;
+    const bool fwd_s21 = g.ly == 1 && g.my == 2 && g.ay == 0 && g.SH == g.OH && C1 == 32;
+    const bool dgrad_s21 = g.ly == 2 && g.my == 1 && (g.ay == 0 || g.ay == 1) && C1 == 64 && Cout == 32;
+    if (!plain && !fwd_s21 && !dgrad_s21) return false;
+    if (g.SH % HT_H != 0 || g.SW % HT_W != 0 || g.ntaps < 1) return false;
     int y0 = g.dy[0], y1 = g.dy[0], x0 = g.dx[0], x1 = g.dx[0];
     for (int t = 1; t < g.ntaps; ++t) {
         y0 = g.dy[t] < y0 ? g.dy[t] : y0; y1 = g.dy[t] > y1 ? g.dy[t] : y1;
@@ -723,7 +734,7 @@ bool viai_conv_halo_ok(const ConvGeom& g, int C1, int C2, int Cout) {
 // f16x2 register-resident-filter variant: 32 input channels, <= 32 output channels, all nine positions of a 3 x 3 window
 bool viai_conv_halo16_ok(const ConvGeom& g, int C1, int C2, int Cout) {
     constexpr int on = 1;
-    if (!on || !viai_conv_halo_ok(g, C1, C2, Cout) || C1 != 32 || Cout > 32 || g.ntaps != 9) return false;
+    if (!on || !viai_conv_halo_ok(g, C1, C2, Cout) || C1 != 32 || Cout > 32 || g.ntaps != 9 || g.my != 1 || g.ly != 1) return false;
     int y0 = g.dy[0], x0 = g.dx[0];
     for (int t = 1; t < 9; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
     unsigned seen = 0;
@@ -739,6 +750,7 @@ int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st) {
         int y0 = g.dy[0], x0 = g.dx[0];
         for (int t = 1; t < g.ntaps; ++t) { y0 = g.dy[t] < y0 ? g.dy[t] : y0; x0 = g.dx[t] < x0 ? g.dx[t] : x0; }
         const bool wide = a.Cout > 32;
+        if (g.my == 2) return wide ? launch_halo<32, 2, 2, 2>(a, y0, x0, st) : launch_halo<32, 1, 2, 2>(a, y0, x0, st);
         if (a.C1 == 32) return wide ? launch_halo<32, 2, 2>(a, y0, x0, st) : launch_halo<32, 1, 2>(a, y0, x0, st);
         return wide ? launch_halo<64, 2, 2>(a, y0, x0, st) : launch_halo<64, 1, 2>(a, y0, x0, st);
     }
@@ -764,6 +776,7 @@ int viai_conv_halo_bf3_launch(ConvArgs& a, hipStream_t st) {
         x0 = g.dx[t] < x0 ? g.dx[t] : x0; x1 = g.dx[t] > x1 ? g.dx[t] : x1;
     }
     const bool wide = a.Cout > 32;
+    if (g.my == 2) return wide ? launch_halo<32, 2, 3, 2>(a, y0, x0, st) : launch_halo<32, 1, 3, 2>(a, y0, x0, st);
     if (a.C1 == 32) return wide ? launch_halo<32, 2>(a, y0, x0, st) : launch_halo<32, 1>(a, y0, x0, st);
     return wide ? launch_halo<64, 2>(a, y0, x0, st) : launch_halo<64, 1>(a, y0, x0, st);
 }
