@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIAI_ABI_VERSION 16
+#define VIAI_ABI_VERSION 17
 
 enum { VIAI_ACT_NONE = 0, VIAI_ACT_RELU = 1, VIAI_ACT_LRELU = 2, VIAI_ACT_SIGMOID = 3 };
 
@@ -149,6 +149,13 @@ int viai_bn_finalize(const float* stat_part, int nblk, int rows_per_blk, long M,
                      float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* (ABI 9) the same merge where block b = tile (n, ty, tx) of tile_h x tile_w output pixels clipped at the edge of the OH x OW map
  * (viai_conv2d_stat_tiles): N * ceil(OH / tile_h) * ceil(OW / tile_w) blocks of min(tile_h, OH - ty tile_h) * min(tile_w, OW - tx tile_w) rows */
+/* (ABI 17) the finalize behind a pre-split forward on the linear-tile kernel (VIAI_P16_OK_FWD_LIN in viai_conv2d_p16_ok): its partials are per 128 consecutive pixels
+ * or, for layers with one channel block (Cout 64 / 128 / 256), merged per persistent block inside the conv kernel -- the library applies the same rule here as at
+ * the launch.  Replaces the nn.BatchNorm2d statistics of networks/ResNet.py:26-55 behind those convs; stat_part as sized by viai_conv2d_stat_geom. */
+int viai_bn_finalize_lin(const float* stat_part, long M, int C,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         int64_t* nbt, float momentum, float eps,
+                         float* mean, float* invstd, float* scale, float* shift, void* stream);
 int viai_bn_finalize_tiles(const float* stat_part, int N, int OH, int OW, int tile_h, int tile_w, int C,
                            const float* gamma, const float* beta, float* running_mean, float* running_var,
                            int64_t* num_batches_tracked, float momentum, float eps,

@@ -22,7 +22,7 @@ class ViaiLibraryError(RuntimeError):
 
 # ABI version THIS file's SIGNATURES / struct mirrors were written against: bumped together with them.  load() compares it with the
 # library, and with the committed header where that is present (a source checkout), so a stale _lib.py cannot call a rebuilt .so.
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 def _header_abi_version():
@@ -93,6 +93,7 @@ SIGNATURES = {
     "viai_pack_weight": (_I, [_P, _P, _I, _I, _I, _L, _L, _P]),
     "viai_bn_finalize": (_I, [_P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "viai_bn_finalize_tiles": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "viai_bn_finalize_lin": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "viai_conv2d_stat_tiles": (_I, [_CP, _IP, _IP]),
     "viai_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
     "viai_bn_act_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _F, _P]),

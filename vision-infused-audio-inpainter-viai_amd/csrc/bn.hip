@@ -54,6 +54,10 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(
     // th > 0: block b is the th x tw output tile (n, ty, tx) of an OH x OW map, clipped at the map's edge (viai_bn_finalize_tiles)
     const int tiles_x = th > 0 ? (OW + tw - 1) / tw : 1, tiles_y = th > 0 ? (OH + th - 1) / th : 1;
     auto count = [&](int b) -> double {
+        if (th < 0) {                                       // partials merged per persistent block of the linear-tile conv kernel (viai_bn_finalize_lin): part b =
+            const int blk = b / tw;                         // (block b / PW, pixel sub-block b % PW) holds 128 pixels of every item the block walked: items blk, blk + G, ...
+            return 128.0 * (double)((OH - blk + OW - 1) / OW);          // (tw = PW, OH = items, OW = G = blocks)
+        }
         if (th > 0) {
             const int tx = b % tiles_x, ty = (b / tiles_x) % tiles_y;
             return (double)(min(th, OH - ty * th) * min(tw, OW - tx * tw));
@@ -804,6 +808,21 @@ extern "C" int viai_bn_finalize_tiles(const float* stat_part, int N, int OH, int
                                  gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, tile_h, tile_w, OH, OW);
     else VIAI_LAUNCH(bn_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, nblk, tile_h * tile_w, (long)N * OH * OW, C,
                      gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, tile_h, tile_w, OH, OW);
+    return viai_launch_status();
+}
+
+// (ABI 17) the finalize behind conv_lin_dma_kernel (a pre-split forward whose viai_conv2d_p16_ok mask has VIAI_P16_OK_FWD_LIN): the kernel's partials are per 128
+// consecutive pixels, or -- layers with one channel block, round 6 -- merged per persistent block; the library knows which (same predicate as the launch).
+extern "C" int viai_bn_finalize_lin(const float* stat_part, long M, int C,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    int64_t* nbt, float momentum, float eps,
+                                    float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    if (C <= 0 || M <= 0 || M % 128 != 0) return (int)hipErrorInvalidValue;
+    int G = 0, PW = 0, items = 0;
+    const int parts = viai_lin_dma_stat_merge(M, C, &G, &PW, &items);
+    if (parts <= 0) return viai_bn_finalize(stat_part, (int)(M / 128), 128, M, C, gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, stream);
+    VIAI_LAUNCH(bn_finalize_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, parts, 128, M, C,
+                gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, -1, PW, items, G);
     return viai_launch_status();
 }
 

@@ -863,6 +863,7 @@ struct LinArgs {
     int nnb; unsigned mnb;                                             // channel blocks per pixel tile (item = tile * nnb + nb)
     int nitems;
     int slot[9];                                                       // weight slot of window position (row * 3 + col)
+    int stat_parts;                                                    // > 0 (round 6): BatchNorm partials merged over a block's items, [2][Cout][stat_parts] (viai_lin_dma_stat_merge)
 #ifdef VIAI_PROF
     unsigned long long* prof;                                          // [block][2 roles][32 stages][4 stamps] (tools/probes/s2_dma_bench.hip)
 #endif
@@ -984,7 +985,7 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     if (h == NH - 1 && a.bias != nullptr) obias = *reinterpret_cast<const f32x4*>(smem_ln + L::BIAS + (lane & (CW / 4 - 1)) * 16);
                     if (h < NH - 1) __syncthreads(); // part h is in registers, the consumers may write part h + 1
                 }
-                if (lw < PW && a.stat != nullptr) {  // loader b stores the partials of 128-pixel block b of the item: [mean | M2][CW]
+                if (lw < PW && a.stat != nullptr && sa.stat_parts == 0) {  // loader b stores the partials of 128-pixel block b of the item: [mean | M2][CW]
                     const int blk = m0 / 128 + lw;
 #pragma unroll
                     for (int i = 0; i < (2 * CW + 255) / 256; ++i) {
@@ -1065,6 +1066,12 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             vm[m] = v;
         }
     };
+    // BatchNorm partials merged over this block's items (stat_parts > 0: one channel block per layer, so a wave's channels never change): Chan's update of
+    // (count, mean, M2) per channel and wave -- the 25 088 partial blocks per channel of ResNet layer1 on 1024 frames become 1024, and bn_finalize's launch, which
+    // waited 238 us as run behind the other chain's resident blocks, shrinks to the small form
+    float rcnt = 0.f, rmean[TN], rm2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { rmean[j] = 0.f; rm2[j] = 0.f; }
     int m0_, nb_;
     if (nmine > 0) {
         item_of(0, m0_, nb_); ntb = (nb_ * NWN + wn) * TN;
@@ -1152,7 +1159,7 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                         for (int j = 0; j < TN; ++j) reinterpret_cast<float*>(smem_ln + L::BIAS)[(wn * TN + j) * 32 + col] = a.bias[nb_ * CW + (wn * TN + j) * 32 + col];
                     }
-                    if (a.stat != nullptr && half == 0) {
+                    if (a.stat != nullptr && half == 0 && sa.stat_parts == 0) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) { sb[j * 32] = mw[j]; sb[CW + j * 32] = m2[j]; }
                     }
@@ -1180,6 +1187,16 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         mw[j] = mraw * inv + (a.bias != nullptr ? a.bias[nb_ * CW + (wn * TN + j) * 32 + col] : 0.f);
                         m2[j] = us * (inv * inv);
                     }
+                    if (sa.stat_parts > 0) {
+                        const float nn = rcnt + 128.f, f = 128.f / nn;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float dl = mw[j] - rmean[j];
+                            rmean[j] += dl * f;
+                            rm2[j] += m2[j] + dl * dl * (rcnt * f);
+                        }
+                        rcnt = nn;
+                    }
                 }
                 if (h < NH - 1) __syncthreads();      // the loaders hold part h in registers
             }
@@ -1194,6 +1211,15 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (k < nmine) { m0_ = m0_next; masks_of(m0_); }
         } else ++kk;
         S2_STAMP(0, q, 3);
+    }
+    if (a.stat != nullptr && sa.stat_parts > 0 && half == 0 && nmine > 0) {
+        const int part = blockIdx.x * PW + wp;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ch = (wn * TN + j) * 32 + col;
+            a.stat[(size_t)ch * sa.stat_parts + part] = rmean[j];
+            a.stat[(size_t)(a.Cout + ch) * sa.stat_parts + part] = rm2[j];
+        }
     }
 }
 
@@ -1283,6 +1309,24 @@ bool viai_conv_lin_dma_geom_ok(const ConvArgs& a) {
 }
 bool viai_conv_lin_dma_ok(const ConvArgs& a) { return a.in_p16 && a.amax != nullptr && viai_conv_lin_dma_geom_ok(a); }
 
+// BatchNorm partials of the linear-tile kernel merged per persistent block and consumer wave: layers with ONE channel block (Cout = 64 / 128 / 256), where a
+// wave's channels are the same for every item.  parts = blocks x PW; part p = (block p / PW, pixel sub-block p % PW) covers 128 x (items of that block) pixels
+// (viai_bn_finalize_lin derives the counts from the same numbers).  Returns 0 where the partials stay per 128 pixels.
+int viai_lin_dma_stat_merge(long M, int Cout, int* grid, int* pw, int* nitems) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VIAI_LIN_STAT_MERGE"); on = e ? atoi(e) : 1; }      // (A/B switch: 0 keeps the partials per 128 pixels)
+    const int PW = lin_dma_pw(Cout);
+    if (!on || Cout != 256 / PW || M % (128 * PW) != 0) return 0;
+    const long items = M / (128 * PW);
+    if (items >= (1l << 30)) return 0;
+    int g = viai_dma_grid();
+    if (g > items) g = (int)items;
+    if (grid) *grid = g;
+    if (pw) *pw = PW;
+    if (nitems) *nitems = (int)items;
+    return g * PW;
+}
+
 template <int PW>
 static int launch_lin_dma(ConvArgs& a, hipStream_t st) {
     using L = LinDma<PW>;
@@ -1305,6 +1349,7 @@ static int launch_lin_dma(ConvArgs& a, hipStream_t st) {
     a.nblk_n = sa.nnb;
     int grid = viai_dma_grid();
     if (grid > sa.nitems) grid = sa.nitems;
+    sa.stat_parts = a.stat != nullptr ? viai_lin_dma_stat_merge(sa.M, a.Cout, nullptr, nullptr, nullptr) : 0;      // ... or merged per block (viai_bn_finalize_lin)
     VIAI_LAUNCH((conv_lin_dma_kernel<PW>), dim3(grid), dim3(S2_THREADS), L::LDS, st, a, sa);
     return viai_launch_status();
 }

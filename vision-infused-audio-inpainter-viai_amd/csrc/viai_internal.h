@@ -57,6 +57,7 @@ int viai_conv_s1_dma_launch(ConvArgs& a, hipStream_t st);
 bool viai_conv_lin_dma_geom_ok(const ConvArgs& a);   // stride-1 3 x 3 layers on linear pixel tiles (maps that are not whole 8 x 16 tiles: the ResNet branch)
 bool viai_conv_lin_dma_ok(const ConvArgs& a);
 int viai_conv_lin_dma_launch(ConvArgs& a, hipStream_t st);
+int viai_lin_dma_stat_merge(long M, int Cout, int* grid, int* pw, int* nitems);   // > 0: the kernel's BatchNorm partials are merged per block (that many per channel)
 // conv_stem.hip: the 7 x 7 stride-2 image conv of the ResNet branch on the f16x2 matrix-core path (forward + weight gradient)
 bool viai_conv_stem_ok(const ConvGeom& g, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
 int viai_conv_stem_fwd_launch(ConvArgs& a, hipStream_t st);

@@ -431,10 +431,12 @@ def _bn_finalize(lib, d, stat, M, Cc, gamma, beta, rmean, rvar, nbt, cfg, coef, 
     kernel's tiles are clipped at the map's edge (viai_conv2d_stat_tiles); `lin`: the pre-split forward ran on the linear-tile kernel, whose
     partial blocks are 128 consecutive pixels (VIAI_P16_OK_FWD_LIN)"""
     th, tw = (0, 0) if lin else d["tiles"]
-    if lin:
-        d = {"nblk": M // 128, "rows": 128}
     tail = (Cc, gamma.data_ptr(), beta.data_ptr(), _ptr(rmean), _ptr(rvar), _ptr(nbt), cfg["momentum"], cfg["eps"],
             coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st)
+    if lin:
+        # (the kernel's partials are per 128 pixels or merged per persistent block: the library applies the launch's rule, round 6)
+        _lib.check(lib.viai_bn_finalize_lin(stat.data_ptr(), M, *tail), "viai_bn_finalize_lin")
+        return
     if th > 0:
         _lib.check(lib.viai_bn_finalize_tiles(stat.data_ptr(), d["N"], d["OH"], d["OW"], th, tw, *tail), "viai_bn_finalize_tiles")
     else:
