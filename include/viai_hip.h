@@ -348,7 +348,7 @@ int viai_wavenet_synth_run(const viai_wn_synth* s, int t0, int n_steps, void* st
  *   viai_wn_pipe_token_granules  8-byte granules of the token rings for B streams (dil: the 24 dilations)
  *   viai_wn_pipe_run           time steps [t0, t0 + n_steps) of every stream.  tok: the rings, ZERO before t0 == 0 and carried over between
  *                              calls; err: 4 zeroed uint32, err[0] != 0 afterwards = failure (1: a wait timed out at stage / stream / t =
- *                              err[1..3]; 2: a past tap was missing) -- the caller must check it after synchronising.                      */
+ *                              err[1..3]) -- the caller must check it after synchronising.                                                 */
 int viai_wn_pipe_ok(const viai_wn_synth* s);
 /* debug aid (tools/wn_pipe_stamps.py): later viai_wn_pipe_run calls record wall-clock stamps (100 MHz) of time step t on compute unit 0 of every stage
  * into buf, 2 x [27 stages][8 streams][4] uint64 (wall clock, then shader cycles; wait begins / x part complete / z part complete / published); buf = NULL switches it off */

@@ -201,15 +201,21 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
                 const int dd = wave < 4 ? 2 * d : d, mm = wave < 4 ? m2 : m1;
                 const int lane = lane_now();
                 float v0 = 0.f, v1 = 0.f;
-                bool ok = true;
                 if (t - dd >= 0) {
+                    // The columns come from the stage's nine sibling blocks.  Nothing downstream orders a sibling's x_l(t - d) before this block's step t
+                    // when d = 1 and there is one stream (the sample of t - 2 proves x_l(t - 2) only; at t = 1 a sibling may still be loading its weights),
+                    // so this is a wait like any other: in the common case the first load carries the tag.  A sibling cannot lap the slot -- it is at
+                    // most one time step ahead of this block, whose columns the next stage needs before the next sample exists.
                     const u64* pr = ring + ((long)s * rl + mm) * TOK + TOK_X + 128 * (wave & 3) + lane;
-                    const u64 ga_ = gload(pr), gb_ = gload(pr + 64);
-                    ok = (unsigned)(ga_ >> 32) == (unsigned)(t - dd + 1) && (unsigned)(gb_ >> 32) == (unsigned)(t - dd + 1);
-                    v0 = __uint_as_float((unsigned)ga_); v1 = __uint_as_float((unsigned)gb_);
+                    const unsigned want = (unsigned)(t - dd + 1);
+                    for (unsigned spins = 0;;) {
+                        const u64 ga_ = gload(pr), gb_ = gload(pr + 64);
+                        v0 = __uint_as_float((unsigned)ga_); v1 = __uint_as_float((unsigned)gb_);
+                        if (__all((unsigned)(ga_ >> 32) == want && (unsigned)(gb_ >> 32) == want)) break;
+                        if (wave_poll_fail(a, spins, abortf, l, s, t)) break;
+                    }
                 }
                 xpre[128 * wave + lane] = v0; xpre[128 * wave + 64 + lane] = v1;
-                if (!ok && atomicCAS(a.err, 0u, 2u) == 0u) { a.err[1] = (unsigned)l; a.err[2] = (unsigned)s; a.err[3] = (unsigned)t; }   // a past tap that is not there: protocol defect
             }
             __builtin_amdgcn_wave_barrier();
             float mine_pre = 0.f;
@@ -586,7 +592,7 @@ static int g_prof_t = -1;
 extern "C" int viai_wn_pipe_profile(void* buf, int t) { g_prof = (u64*)buf; g_prof_t = t; return 0; }
 
 // time steps [t0, t0 + n) of every stream in ONE launch.  `tok` must be zero before the call with t0 == 0 and carried over between calls;
-// err: 4 zeroed uint32 (err[0] != 0 after the call: 1 = a wait timed out at (stage, stream, t) = err[1..3], 2 = a past tap was missing).
+// err: 4 zeroed uint32 (err[0] != 0 after the call: 1 = a wait timed out at (stage, stream, t) = err[1..3]; 2 is no longer raised: a past tap is waited for like a token).
 extern "C" int viai_wn_pipe_run(const viai_wn_synth* s, const float* wreg, const float* wcond, const float* wlds, const float* bias, const float* head_w, const float* head_b,
                                 void* tok, unsigned* err, int t0, int n_steps, void* stream) {
     if (!viai_wn_pipe_ok(s) || t0 < 0 || n_steps < 0 || t0 + n_steps > s->T) return (int)hipErrorInvalidValue;
