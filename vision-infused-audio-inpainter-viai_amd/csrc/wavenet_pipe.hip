@@ -332,8 +332,8 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
             if (l > 0) {
                 const f32x2 b1 = rowdot(zin + 32 * wave, wb + min(ln, XSL - 1) * LROW + 32 * wave, 4, f32x2{0.f, 0.f});   // (lanes past the last row re-read it: a broadcast, nobody reads their sums)
                 if (ln < XSL) pb[wave * PBS + ln] = b1.x + b1.y;
-                __syncthreads();
             }
+            __syncthreads();                          // (layer 0 too: wave 7 publishes columns of xcur that other waves wrote)
             if (wave == NW - 1) {
                 if (ln < XSL) {
                     const int c = XSL * j + ln;
