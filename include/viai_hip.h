@@ -351,7 +351,8 @@ int viai_wavenet_synth_run(const viai_wn_synth* s, int t0, int n_steps, void* st
  *                              err[1..3]) -- the caller must check it after synchronising.                                                 */
 int viai_wn_pipe_ok(const viai_wn_synth* s);
 /* debug aid (tools/wn_pipe_stamps.py): later viai_wn_pipe_run calls record wall-clock stamps (100 MHz) of time step t on compute unit 0 of every stage
- * into buf, 2 x [27 stages][8 streams][4] uint64 (wall clock, then shader cycles; wait begins / x part complete / z part complete / published); buf = NULL switches it off */
+ * into buf, 2 x [27 stages][8 streams][8] uint64 (wall clock, then shader cycles; 0 wait begins / 1 x part complete / 2 z part complete / 3 published / 4 .. 7 inside a layer
+ * stage: residual rows done, past barrier 1, gate rows done, past barrier 2); buf = NULL switches it off */
 int viai_wn_pipe_profile(void* buf, int t);
 long viai_wn_pipe_image_floats(int which);
 long viai_wn_pipe_token_granules(int B, const int* dil);

@@ -65,16 +65,23 @@ struct WnPipe {
     int dil[NL];
     int B, T, n_test, t0, t1, out_ch;
     float log_scale_min;
-    u64* prof; int prof_t;    // debug aid (viai_wn_pipe_profile): wall-clock stamps of time step prof_t, [stage][stream][4]
+    u64* prof; int prof_t;    // debug aid (viai_wn_pipe_profile): wall-clock stamps of time step prof_t, [stage][stream][8]
 };
 
-// stamps of one time step on CU 0 of every stage: 0 = the wait for the token begins, 1 = token complete, 2 = results in LDS, 3 = publish stores issued
+// stamps of one time step on CU 0 of every stage: 0 = the wait for the token begins, 1 = token complete, 2 = results in LDS, 3 = publish stores issued;
+// layer stages also 4 = residual rows done, 5 = past barrier 1, 6 = gate rows done, 7 = past barrier 2 (thread 0's view)
 __device__ __forceinline__ void stamp(const WnPipe& a, int st, int j, int s, int t, int k) {
     if (a.prof != nullptr && t == a.prof_t && j == 0 && threadIdx.x == 0) {
-        a.prof[((size_t)st * 8 + s) * 4 + k] = wall_clock64();
-        a.prof[27 * 8 * 4 + ((size_t)st * 8 + s) * 4 + k] = (u64)clock64();          // shader cycles beside the 100 MHz wall clock: the clock the stage runs at
+        a.prof[((size_t)st * 8 + s) * 8 + k] = wall_clock64();
+        a.prof[27 * 8 * 8 + ((size_t)st * 8 + s) * 8 + k] = (u64)clock64();          // shader cycles beside the 100 MHz wall clock: the clock the stage runs at
     }
 }
+
+#ifdef VIAI_WN_FINE_STAMPS
+#define FINE_STAMP(k) stamp(a, l, j, s, t, k)
+#else
+#define FINE_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ u64 gload(const u64* p) { return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void gstore(u64* p, unsigned tag, float v) {
@@ -293,6 +300,8 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
                 for (int i = 1; i < 13; ++i) mine = cg == i ? acc[i] : mine;
                 mine += mine_pre;
             }
+            // the register part of row r sits in lane 16 (r / 13) + r % 13; the lane that adds it to the z columns of row r is lane r: moved now, before z arrives
+
             if (l > 0) {
                 // ---- z_{l-1}(t): every wave fetches the 32 values it multiplies (lanes 32 - 63 repeat them)
                 for (unsigned spins = 0;;) {
@@ -312,7 +321,7 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
             // hoists all its reads into registers the weights do not leave):
             //   1. the residual rows, all waves; block barrier; WAVE 7 publishes x_l(t) -- half a microsecond ahead of z_l(t), so that the next stage has its
             //      current tap done when z_l(t) lands;
-            //   2. meanwhile waves 0 - 6 do the z columns of the gate rows (wave 7's 32 columns are shared out to waves 0 - 3, eight each); block barrier;
+            //   2. meanwhile waves 0 - 6 do the z columns of the gate rows (40 / 32 columns each); block barrier;
             //   3. wave 0 finishes z_l(t).
             auto rowdot = [&](const float* zp, const float* rp, int n8, f32x2 acc) {      // n8 steps of 8 columns, the next step's four reads in flight
                 f32x4 zc0 = *reinterpret_cast<const f32x4*>(zp), zc1 = *reinterpret_cast<const f32x4*>(zp + 4);
@@ -333,7 +342,9 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
                 const f32x2 b1 = rowdot(zin + 32 * wave, wb + min(ln, XSL - 1) * LROW + 32 * wave, 4, f32x2{0.f, 0.f});   // (lanes past the last row re-read it: a broadcast, nobody reads their sums)
                 if (ln < XSL) pb[wave * PBS + ln] = b1.x + b1.y;
             }
+            FINE_STAMP(4);
             __syncthreads();                          // (layer 0 too: wave 7 publishes columns of xcur that other waves wrote)
+            FINE_STAMP(5);
             if (wave == NW - 1) {
                 if (ln < XSL) {
                     const int c = XSL * j + ln;
@@ -349,21 +360,23 @@ __device__ __forceinline__ void layer_stage(const WnPipe& a, const int l, const 
                     }
                 }
             } else {
+                // seven waves share the 256 z columns: waves 0 - 3 take 40 (five steps), waves 4 - 6 take 32 -- one pipelined loop each
                 f32x2 ga = {0.f, 0.f};
                 if (l > 0) {
-                    const float* rz = wz + min(ln, GROWS - 1) * LROW;
-                    ga = rowdot(zin + 32 * wave, rz + 32 * wave, 4, ga);
-                    if (wave < 4) ga = rowdot(zin + 32 * (NW - 1) + 8 * wave, rz + 32 * (NW - 1) + 8 * wave, 1, ga);          // its share of wave 7's columns
+                    const int c0 = wave < 4 ? 40 * wave : 160 + 32 * (wave - 4);
+                    ga = rowdot(zin + c0, wz + min(ln, GROWS - 1) * LROW + c0, wave < 4 ? 5 : 4, ga);
                 }
                 if (ln < GROWS) pg[wave * GROWS + ln] = ga.x + ga.y;
             }
             __builtin_amdgcn_wave_barrier();
-            if ((ln & 15) < 13) {                                                             // the register part (past + current taps) of row 13 g + cg
+            if ((ln & 15) < 13) {
                 const int r = wave * GROWS + 13 * (ln >> 4) + (ln & 15);
-                pg[r] = wave == NW - 1 ? mine : pg[r] + mine;                                 // (the same wave wrote pg[r] just above: LDS operations of a wave complete in order)
+                pg[r] = wave == NW - 1 ? mine : pg[r] + mine;
             }
+            FINE_STAMP(6);
             __syncthreads();
             if (*abortf) return;
+            FINE_STAMP(7);
             // ---- z_l(t) = tanh(a) sigmoid(b) (modules.py:201): lane r < 26 forms tanh of row r, lane 26 + r the sigmoid of row 26 + r, one shuffle joins them
             qt = 64 * wave + lane_now();
             if (qt < 64) {
