@@ -16,7 +16,7 @@ B, hop, T = 8, 256, 1024
 net = WaveNet(dropout=0.0).to(dev).eval()
 c = torch.rand(B, 80, T // hop, device=dev)
 lib = _lib.load()
-buf = torch.zeros(2 * 27 * 8 * 8 + 27 * 8 * 4, dtype=torch.int64, device=dev)
+buf = torch.zeros(2 * 27 * 8 * 8, dtype=torch.int64, device=dev)
 lib.viai_wn_pipe_profile(buf.data_ptr(), t_prof)
 timing = {"warmup": 256}
 net.incremental_forward(None, c=c, T=T, log_scale_min=-7.0, timing=timing)
@@ -40,13 +40,8 @@ ghz = [((cy[k, 0, 3] - cy[k, 0, 1]) / ((st[k, 0, 3] - st[k, 0, 1]) * 1e3)).item(
 print("shader clock over (x complete -> published), stages 1 .. 23: %.2f - %.2f GHz" % (min(ghz), max(ghz)))
 occ = [(st[k, 1, 0] - st[k, 0, 3]).item() for k in range(1, 24)]
 print("published(stream 0) -> next token's wait begins (past taps + conditioning of stream 1), stages 1 .. 23: %.2f - %.2f us" % (min(occ), max(occ)))
-# inside z -> pub of the layer stages (a -DVIAI_WN_FINE_STAMPS build), in shader cycles of thread 0: z columns | barrier | tanh / sigmoid + stores
+# inside z -> pub of the layer stages (a -DVIAI_WN_FINE_STAMPS build), in shader cycles of thread 0: residual rows | barrier 1 | gate rows | barrier 2 | tanh / sigmoid + stores
 if float(cy[1, 0, 4]) > 0:
-    for a_, b_, name in [(2, 4, "z columns"), (4, 5, "barrier"), (5, 3, "finalize + stores")]:
+    for a_, b_, name in [(2, 4, "residual rows"), (4, 5, "barrier 1"), (5, 6, "gate rows"), (6, 7, "barrier 2"), (7, 3, "finalize + stores")]:
         v = [(cy[k, 0, b_] - cy[k, 0, a_]).item() for k in range(1, 24)]
         print("  %-20s %6.0f - %6.0f cycles (median %6.0f)" % (name, min(v), max(v), sorted(v)[len(v) // 2]))
-wv = buf[2 * 27 * 64:].view(27, 8, 4).cpu().double()
-if float(wv.abs().sum()) > 0:        # a -DVIAI_WN_FINE_STAMPS build with per-wave stamps: z complete / at barrier 1 / at barrier 2, cycles relative to wave 0's z complete
-    for k in (5, 11, 17):
-        base = wv[k, 0, 0]
-        print("  stage %2d per wave: z complete %s | at barrier 1 %s | at barrier 2 %s" % (k, [int(x - base) for x in wv[k, :, 0]], [int(x - base) for x in wv[k, :, 1]], [int(x - base) for x in wv[k, :, 2]]))
