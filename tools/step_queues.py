@@ -70,3 +70,16 @@ for q, ev in sorted(qs.items(), key=lambda kv: -sum(e[1] - e[0] for e in kv[1]))
             names = ", ".join(sorted({re.sub(r"\(.*", "", re.sub(r"^void |\(anonymous namespace\)::", "", r[3]))[:28] for r in other}))[:110]
             short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void |\(anonymous namespace\)::", "", n))[:40]
             print("    %6.1f  %-40s -> %-40s | %s" % (gap / 1e3, short(n0), short(n1), names))
+
+# the tail of the first analysed step: what separates the last kernels of the backward chain from the optimizer (us relative to the step's end)
+if "--tail" in sys.argv:
+    n_tail = int(sys.argv[sys.argv.index("--tail") + 1])
+    one = rows[ends[first] + 1:ends[first + 1] + 1]
+    tend = max(r[1] for r in one)
+    print("\nlast %d kernels of a step (start, end in us before the step's end; queue; name):" % n_tail)
+    for s, e, q, n in sorted(one, key=lambda r: r[0])[-n_tail:]:
+        print("  %8.1f %8.1f  q%-2d %s" % ((s - tend) / 1e3, (e - tend) / 1e3, q, re.sub(r"\(anonymous namespace\)::", "", n)[:110]))
+    print("first 12 kernels of the next step:")
+    nxt = rows[ends[first + 1] + 1:ends[first + 1] + 13]
+    for s, e, q, n in nxt:
+        print("  %8.1f %8.1f  q%-2d %s" % ((s - tend) / 1e3, (e - tend) / 1e3, q, re.sub(r"\(anonymous namespace\)::", "", n)[:110]))
