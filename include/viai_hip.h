@@ -342,7 +342,7 @@ int viai_wavenet_synth_run(const viai_wn_synth* s, int t0, int n_steps, void* st
  * stages as tokens of 8-byte {tag, value} granules, so up to B stages work at once where the chain form (viai_wavenet_synth_run) has one.
  * Same time steps, same folded weights (layers[].w_stage / b_stage), fp32, fixed summation order; replaces the per-step loop of
  * wavenet.py:322-357 for this configuration.
- *   viai_wn_pipe_ok            1 if `s` is that configuration and the device has >= 256 compute units (all blocks must be resident)
+ *   viai_wn_pipe_ok            1 if `s` is that configuration with 1 .. 32 streams and the device has >= 256 compute units (all blocks must be resident)
  *   viai_wn_pipe_image_floats  sizes of the five weight images the HOST packs (viai_amd.wavenet._pipe_images): 0 wreg [24][10][8][156][64],
  *                              1 wlds [24][10][130][260], 2 bias [24][10][136], 3 head_w [544][256], 4 head_b [544], 5 wcond [24][10][64][80]
  *   viai_wn_pipe_token_granules  8-byte granules of the token rings for B streams (dil: the 24 dilations)

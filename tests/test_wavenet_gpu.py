@@ -367,3 +367,21 @@ def test_pipelined_synthesis_with_few_streams_and_a_teacher_forced_prefix(B, mon
     assert tuple(out_p.shape) == (B, 1, T) and float(out_r.abs().max()) > 0.01
     assert relerr(out_p[:, :, :64], out_r[:, :, :64]) < 1e-4, relerr(out_p[:, :, :64], out_r[:, :, :64])
     assert relerr(out_p, out_r) < 2e-3, relerr(out_p, out_r)
+
+
+@pytest.mark.gpu
+def test_pipelined_synthesis_with_more_streams_than_the_chain_form_takes():
+    """12 streams in one launch (the chain of launches is built for 1, 2, 4 or 8): the streams are independent and a stream's arithmetic does not depend on how
+    many travel with it, so streams 0 - 7 and 4 - 11 must be BITWISE the two 8-stream runs on the same conditioning and uniforms."""
+    cfg = W.WNConfigFull
+    net = build_cfg(cfg, "WN.").eval()
+    B, T = 12, 256
+    c = O.cf_uniform("wn12.c", (B, cfg.cin_channels, 1), 0, 1)
+    u1, u2 = O.cf_uniform("wn12.u1", (B, T, 10), 1e-5, 1 - 1e-5), O.cf_uniform("wn12.u2", (B, T), 1e-5, 1 - 1e-5)
+    timing = {"warmup": 0}
+    out = net.incremental_forward(None, c=c.cuda(), T=T, log_scale_min=-7.0, uniforms=(u1, u2), timing=timing)
+    assert timing.get("form") == "pipe" and tuple(out.shape) == (B, 1, T) and float(out.abs().max()) > 0.01
+    for lo in (0, 4):
+        sl = slice(lo, lo + 8)
+        part = net.incremental_forward(None, c=c[sl].cuda(), T=T, log_scale_min=-7.0, uniforms=(u1[sl], u2[sl]))
+        assert torch.equal(out[sl], part), lo

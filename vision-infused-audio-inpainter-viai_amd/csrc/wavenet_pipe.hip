@@ -44,6 +44,7 @@ constexpr int GROWS = 52, BROWS = 78, LROW = 260;     // LDS rows (gate z column
 constexpr int CROWS = 64;                             // conditioning rows: 8 lanes per row (streamed from L2 while the stage waits)
 constexpr int TOK = 1024, TOK_X = 0, TOK_Z = 512, TOK_S = 768;
 constexpr int NSTAGE = NL + 3;
+constexpr int PIPE_MAXB = 32;                            // streams per launch (the benchmark's 8 leave a stage idle 60 % of the time: the revolution is latency)
 constexpr unsigned SPIN_LIMIT = 400000u;              // ~0.3 - 0.5 s of polling: a stage that starves this long has lost its producer
 
 struct WnPipe {
@@ -71,7 +72,7 @@ struct WnPipe {
 // stamps of one time step on CU 0 of every stage: 0 = the wait for the token begins, 1 = token complete, 2 = results in LDS, 3 = publish stores issued;
 // layer stages also 4 = residual rows done, 5 = past barrier 1, 6 = gate rows done, 7 = past barrier 2 (thread 0's view)
 __device__ __forceinline__ void stamp(const WnPipe& a, int st, int j, int s, int t, int k) {
-    if (a.prof != nullptr && t == a.prof_t && j == 0 && threadIdx.x == 0) {
+    if (a.prof != nullptr && t == a.prof_t && j == 0 && s < 8 && threadIdx.x == 0) {
         a.prof[((size_t)st * 8 + s) * 8 + k] = wall_clock64();
         a.prof[27 * 8 * 8 + ((size_t)st * 8 + s) * 8 + k] = (u64)clock64();          // shader cycles beside the 100 MHz wall clock: the clock the stage runs at
     }
@@ -570,7 +571,7 @@ constexpr size_t PIPE_LDS_BYTES = (size_t)((GROWS + BROWS) * LROW + KPRE + PC + 
 // ---- C ABI ------------------------------------------------------------------------------------------------------------------------
 extern "C" int viai_wn_pipe_ok(const viai_wn_synth* s) {
     if (!s || s->C != PC || s->G != 2 * PH || s->S != PS || s->cin != PCIN || s->n_layers != NL || s->out_ch != 30 || s->out_ch % 3 != 0) return 0;
-    if (s->B < 1 || s->B > 8 || s->cond == nullptr) return 0;
+    if (s->B < 1 || s->B > PIPE_MAXB || s->cond == nullptr) return 0;
     for (int l = 0; l < NL; ++l) {
         if (s->layers[l].g_add != nullptr || s->layers[l].w_stage == nullptr || s->layers[l].w_c == nullptr) return 0;
         if (s->layers[l].dilation < 1 || s->layers[l].dilation > 4096) return 0;

@@ -480,8 +480,8 @@ class WaveNet(nn.Module):
             B = c.size(0) if c is not None else 1
             tin = None
         T = int(T)
-        if B not in (1, 2, 4, 8):
-            raise NotImplementedError("incremental_forward: batch must be 1, 2, 4 or 8 streams")
+        if not 1 <= B <= 32:
+            raise NotImplementedError("incremental_forward: 1 to 32 streams")
         cond = None
         if c is not None:
             cu = self._upsample(c.to(dev).float())
@@ -571,6 +571,9 @@ class WaveNet(nn.Module):
         # the pipelined form (csrc/wavenet_pipe.hip): one persistent launch, the stages work on different streams at the same time.  Reference-size
         # network with local conditioning only; everything else (and use_graph) takes the chain of launches below.
         pipe = (not use_graph) and fuse and os.environ.get("VIAI_WN_PIPE", "1") != "0" and bool(lib.viai_wn_pipe_ok(ref))
+        if not pipe and B not in (1, 2, 4, 8):
+            raise NotImplementedError("incremental_forward: the chain of launches takes 1, 2, 4 or 8 streams; any other count up to 32 needs the pipelined form "
+                                      "(reference-size network, local conditioning only, no use_graph, VIAI_WN_PIPE != 0, a device with 256 compute units)")
         if pipe:
             imgs = _pipe_images(held["w_stage"], held["b_stage"], held["w_c"], held["w_out"], held["b_out"], held["w_skip"], held["b_skip"],
                                 normed_weight(self.last_conv_layers[1]).reshape(S, -1).detach().float(), self.last_conv_layers[1].bias.detach().float(),
